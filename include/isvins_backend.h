@@ -1,0 +1,249 @@
+/*
+ * isvins_backend.h -- C ABI of the MI355X sliding-window VIO backend.
+ *
+ * Drop-in boundary for ONE path of lyeemax/IS-VINS: the per-frame sliding-window solve
+ *   Estimator::solveOdometry()        src/estimator.cpp:461-472
+ *     -> Estimator::backendOptimization()   src/estimator.cpp:1541-1562
+ *          vector2double()  :474-516, problemSolve() :1004-1146, double2vector() :518-594,
+ *          MargForward() :1149-1352, MargBackward() :1354-1539
+ * The reference has no FFI layer: the seam is that C++ member call.  Every
+ * struct below mirrors the Estimator members that call reads and writes
+ * (include/estimator.h:90-154); every entry point names the reference function it replaces.
+ *
+ * Conventions (identical to the reference):
+ *   - all reals are IEEE float64, all indices int32
+ *   - matrices are ROW-MAJOR here (Eigen's default is column-major: the C++ shim in
+ *     include/isvins_estimator_shim.hpp converts)
+ *   - pose block  = [px py pz qx qy qz qw]              (src/estimator.cpp:476-485)
+ *   - speed-bias  = [vx vy vz bax bay baz bgx bgy bgz]  (src/estimator.cpp:487-497)
+ *   - IMU residual/tangent order O_P=0 O_R=3 O_V=6 O_BA=9 O_BG=12 (include/parameters.h:89-96)
+ *   - landmark parameter = inverse depth in its host (start) frame
+ * No allocation crosses this ABI: the caller owns every buffer it passes; the handle owns
+ * all device memory.  Functions return ISV_OK (0) or a negative isv_status_t; they never abort
+ * (the reference asserts instead, src/estimator.cpp:773,1218,1386).
+ */
+#ifndef ISVINS_BACKEND_H
+#define ISVINS_BACKEND_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ISV_ABI_VERSION 1
+
+typedef enum isv_status {
+    ISV_OK = 0,
+    ISV_ERR_INVALID_ARG = -1,   /* null pointer, bad size, index out of window          */
+    ISV_ERR_CAPACITY = -2,      /* more landmarks / observations / windows than created  */
+    ISV_ERR_NONFINITE = -3,     /* NaN/Inf in inputs or produced by the solve            */
+    ISV_ERR_DEVICE = -4,        /* HIP runtime error (no GPU, OOM, launch failure)       */
+    ISV_ERR_UNSUPPORTED = -5    /* e.g. estimate_extrinsic=1 (not built yet)             */
+} isv_status_t;
+
+/* ceres::TerminationType + the reason strings of TrustRegionMinimizer (Ceres 2.0.0) */
+typedef enum isv_termination {
+    ISV_TERM_RUNNING = 0,
+    ISV_TERM_GRADIENT_TOL = 1,     /* CONVERGENCE: max_norm(gradient) <= 1e-10            */
+    ISV_TERM_PARAMETER_TOL = 2,    /* CONVERGENCE: |step| <= 1e-8 (|x| + 1e-8)            */
+    ISV_TERM_FUNCTION_TOL = 3,     /* CONVERGENCE: |dcost| <= 1e-6 cost                   */
+    ISV_TERM_MAX_ITERATIONS = 4,   /* NO_CONVERGENCE: NUM_ITERATIONS reached              */
+    ISV_TERM_MIN_RADIUS = 5,       /* CONVERGENCE: trust region radius <= 1e-32           */
+    ISV_TERM_INVALID_STEPS = 6,    /* FAILURE: 5 consecutive invalid steps                */
+    ISV_TERM_LINEAR_SOLVER = 7     /* FAILURE: Cholesky failed up to mu = 1               */
+} isv_termination_t;
+
+/* ---- configuration: include/parameters.h:35-40 + config/euroc_config.yaml ------------- */
+typedef struct isv_config {
+    int32_t n_frames;            /* ALL_BUF_SIZE (18 in the reference; 11 / 20 synthetic)      */
+    int32_t n_vo;                /* Vo_SIZE (8 in the reference), 2 <= n_vo <= n_frames-1      */
+    int32_t max_landmarks;       /* NUM_OF_F capacity per window                              */
+    int32_t max_obs;             /* capacity: sum over landmarks of track length, per window  */
+    int32_t max_rollpitch;       /* capacity of vioRollPitchEdges (<= n_vo + 1)               */
+    int32_t max_batch;           /* windows the handle can hold at once                       */
+    int32_t num_iterations;      /* NUM_ITERATIONS (yaml:50) -> max_num_iterations            */
+    int32_t estimate_extrinsic;  /* ESTIMATE_EXTRINSIC; only 0 is built (block constant)      */
+    double  proj_sqrt_info[4];   /* ProjectionFactor::sqrt_info = PIXEL_SQRT_INFO * I2        */
+    double  gravity[3];          /* G (src/parameters.cpp), enters the IMU residual with '+'  */
+    double  alpha;               /* ALPHA eigenvalue cut of the sparsification (yaml:86)      */
+    double  init_depth;          /* INIT_DEPTH                                                */
+} isv_config_t;
+
+/* ---- IntegrationBase members read by IMUFactor (include/factor/integration_base.h:188-207) */
+typedef struct isv_imu {
+    double delta_p[3];
+    double delta_q[4];           /* x y z w */
+    double delta_v[3];
+    double linearized_ba[3];
+    double linearized_bg[3];
+    double sum_dt;
+    double jacobian[225];        /* 15x15 row-major */
+    double covariance[225];      /* 15x15 row-major */
+} isv_imu_t;
+
+/* ---- prior factors: include/estimator.h:134-154 --------------------------------------- */
+typedef struct isv_se3_prior {   /* SE3PriorFactor  include/factor/se3_prior_factor.h:135-140 */
+    double t[3];
+    double R[9];
+    double sqrt_info[36];
+    int32_t index;
+    int32_t _pad;
+} isv_se3_prior_t;
+
+typedef struct isv_linear9 {     /* Linear9Factor   include/factor/linear9_factor.h:69-73      */
+    double VB[9];
+    double sqrt_info[81];
+    int32_t index;
+    int32_t _pad;
+} isv_linear9_t;
+
+typedef struct isv_relpose {     /* RelativePoseFactor include/factor/relative_pose_factor.h:190-195 */
+    double delta_t[3];
+    double delta_R[9];
+    double sqrt_info[36];
+    int32_t imu_i, imu_j;
+} isv_relpose_t;
+
+typedef struct isv_rollpitch {   /* RollPitchFactor include/factor/rollpitch_factor.h:132-136  */
+    double R[9];
+    double sqrt_info[4];
+    int32_t index;
+    int32_t _pad;
+} isv_rollpitch_t;
+
+/* ---- one sliding window = the Estimator members backendOptimization() touches --------- */
+typedef struct isv_window {
+    /* Eigen-level state, in/out (include/estimator.h:90-94,84-85) */
+    double *Ps;                  /* [N][3]                                               */
+    double *Rs;                  /* [N][9]  rotation matrices, row-major                 */
+    double *Vs;                  /* [N][3]                                               */
+    double *Bas;                 /* [N][3]                                               */
+    double *Bgs;                 /* [N][3]                                               */
+    double *tic;                 /* [3]                                                  */
+    double *ric;                 /* [9]                                                  */
+    /* FeatureManager view in IDsfeatures order restricted to goodFeature() landmarks
+     * (feature_manager.cpp:27-31,188-204): landmark l has host frame lm_start_frame[l]
+     * and observations obs_point[lm_obs_ptr[l] .. lm_obs_ptr[l+1]) in consecutive frames */
+    int32_t n_landmarks;         /* L = getFeatureCount()                                */
+    int32_t n_obs;               /* lm_obs_ptr[L] = F + L                                */
+    const int32_t *lm_start_frame; /* [L]                                                */
+    const int32_t *lm_obs_ptr;   /* [L+1]                                                */
+    const double *obs_point;     /* [n_obs][3] normalised image points (x, y, 1)         */
+    double *lm_depth;            /* [L] estimated_depth, in/out (getDepthVector/setDepth) */
+    int32_t *lm_solve_flag;      /* [L] out: 1 ok, 2 depth<0 or >10 (feature_manager.cpp:156-161) */
+    /* pre_integrations[1..N-1]: imu[i] links frame i -> i+1 */
+    const isv_imu_t *imu;        /* [N-1]                                                */
+    /* prior factors, in/out (update() shifts them, double2vector rotates two of them)   */
+    isv_se3_prior_t *pose_prior; /* vioPosePriorEdge                                     */
+    isv_linear9_t   *vb_prior;   /* vioVBPrior                                           */
+    isv_relpose_t   *relpose;    /* [n_vo-1] = vioRelativePoseEdges[1..n_vo-1]           */
+    isv_rollpitch_t *rollpitch;  /* [n_rollpitch] vioRollPitchEdges                      */
+    int32_t n_rollpitch;
+    int32_t margin_old;          /* marginalization_flag == MARGIN_OLD                   */
+    double  header0;             /* Headers[0] (copied into CombinedFactors.ts)          */
+    /* para_* arrays, out (include/estimator.h:122-126); may be NULL                      */
+    double *para_Pose;           /* [N][7]                                               */
+    double *para_SpeedBias;      /* [N][9]                                               */
+    double *para_Ex_Pose;        /* [7]                                                  */
+    double *para_Feature;        /* [L]                                                  */
+} isv_window_t;
+
+#define ISV_MAX_TRACE 64
+typedef struct isv_summary {     /* ceres::Solver::Summary subset + per-iteration trace  */
+    int32_t status;              /* isv_status_t of this window                          */
+    int32_t termination;         /* isv_termination_t                                    */
+    int32_t iterations;          /* trust-region iterations performed (<= num_iterations) */
+    int32_t num_successful;
+    double  initial_cost;
+    double  final_cost;
+    double  trace_cost[ISV_MAX_TRACE];    /* cost after iteration k (k=0: initial)        */
+    double  trace_radius[ISV_MAX_TRACE];  /* trust-region radius after iteration k        */
+    double  trace_step_norm[ISV_MAX_TRACE];
+    int32_t trace_accepted[ISV_MAX_TRACE];
+} isv_summary_t;
+
+/* ---- outputs of MargForward / MargBackward ------------------------------------------- */
+typedef struct isv_combined_factors {  /* CombinedFactors include/factor/pose_graph_factors.h:6-17 */
+    isv_relpose_t relative_pose;       /* pgRaltivePoseFactor (src/estimator.cpp:1243-1255) */
+    int32_t has_rollpitch;             /* vioRollPitchEdges[0]->index == 0                */
+    int32_t _pad;
+    isv_rollpitch_t rollpitch;
+    double covRel[36];
+    double covAbs[4];
+    double distance;
+    double ts;
+    double Ri[9];
+    double ti[3];
+} isv_combined_factors_t;
+
+typedef struct isv_marg_result {
+    int32_t valid;                     /* 1 when margin_old was set and marg ran          */
+    int32_t n_marg_landmarks;          /* MargPointIdx.size()                             */
+    isv_combined_factors_t combined;   /* -> pose_graph_factors_buf                       */
+    isv_se3_prior_t forward_pose_prior;      /* forwardPosePriorEdgeToAdd                 */
+    isv_relpose_t   backward_relpose;        /* backwardRelativePoseEdgeToAdd             */
+    isv_linear9_t   backward_vb;             /* backwardVBEdgeToAdd                       */
+    isv_rollpitch_t backward_rollpitch;      /* pushed to vioRollPitchEdges, index n_vo-1 */
+    double forward_kld;                /* the reference's "zero test" (estimator.cpp:1337-1343) */
+    double backward_kld;               /* (estimator.cpp:1528-1533)                       */
+} isv_marg_result_t;
+
+/* ---- linearisation output (config "residual+Jacobian kernels only") ------------------ */
+/* Jacobian strip of one reprojection factor, in CSR (landmark-major) factor order:
+ *   [ r(2) | J_pose_i 2x6 row-major | J_pose_j 2x6 row-major | J_lambda 2x1 ] = 28 doubles,
+ * already Cauchy-corrected (ceres Corrector) and with the local-parameterisation
+ * Jacobian applied (first 6 of the 7 pose columns).                                      */
+#define ISV_PROJ_STRIP 28
+/* IMU factor strip: [ r(15) | 15x6 pose_i | 15x9 sb_i | 15x6 pose_j | 15x9 sb_j ] row-major
+ * blocks = 15 + 450 = 465 doubles                                                        */
+#define ISV_IMU_STRIP 465
+
+typedef struct isv_backend isv_backend_t;
+
+/* lifecycle ------------------------------------------------------------------------- */
+int  isv_abi_version(void);
+/* Estimator::Estimator()/setParameter(): src/estimator.cpp:16-38 */
+int  isv_backend_create(const isv_config_t *cfg, isv_backend_t **out);
+void isv_backend_destroy(isv_backend_t *h);
+const char *isv_backend_last_error(const isv_backend_t *h);
+
+/* Estimator::backendOptimization() NON_LINEAR branch (src/estimator.cpp:1549-1560):
+ * vector2double, problemSolve, double2vector, and when w->margin_old MargForward+MargBackward.
+ * marg may be NULL when margin_old == 0.                                                */
+int  isv_backend_optimize(isv_backend_t *h, isv_window_t *w, isv_summary_t *summary,
+                          isv_marg_result_t *marg);
+/* the same over n independent windows (multi-sequence throughput entry) */
+int  isv_backend_optimize_batch(isv_backend_t *h, int32_t n, isv_window_t *const *w,
+                                isv_summary_t *summary, isv_marg_result_t *marg);
+
+/* Stages, for tests and for the "kernels only" configuration --------------------------- */
+/* One evaluation of every residual block at the window's current state, as
+ * ceres::Problem::Evaluate would do for the problem problemSolve() builds
+ * (src/estimator.cpp:1022-1117): ProjectionFactor::Evaluate (projection_factor.cpp:24-122),
+ * IMUFactor::Evaluate (imu_factor.h:23-159), the four prior factors, CauchyLoss(1.0) corrector.
+ * proj_strips [F][28], imu_strips [N-1][465], cost (1/2 sum rho) may each be NULL.       */
+int  isv_backend_linearize(isv_backend_t *h, const isv_window_t *w,
+                           double *proj_strips, double *imu_strips, double *cost);
+
+/* Device-resident batch: upload once, run many times (what bench.py times) -------------- */
+int  isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const *w);
+/* restore the uploaded initial state, then run backendOptimization on every resident window;
+ * asynchronous on the handle's stream unless sync != 0                                   */
+int  isv_batch_optimize(isv_backend_t *h, int32_t sync);
+/* only the factor-linearisation kernels over the resident batch */
+int  isv_batch_linearize(isv_backend_t *h, int32_t sync);
+int  isv_batch_download(isv_backend_t *h, int32_t n, isv_window_t *const *w,
+                        isv_summary_t *summary, isv_marg_result_t *marg);
+int  isv_batch_sync(isv_backend_t *h);
+/* HIP-event timing of the last isv_batch_* launch sequence, milliseconds, per kernel family:
+ * out[0]=total, [1]=proj linearize, [2]=imu+prior linearize, [3]=build+solve, [4]=step/eval,
+ * [5]=marg.  Events are recorded on the handle's own stream.                              */
+int  isv_batch_last_timing(isv_backend_t *h, double out_ms[8]);
+/* launches of the dominant (projection linearise) kernel in the last run */
+int  isv_batch_last_counts(isv_backend_t *h, int64_t out[8]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ISVINS_BACKEND_H */
