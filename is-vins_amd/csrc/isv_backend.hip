@@ -1,0 +1,414 @@
+// isv_backend.hip -- host side of the C ABI (include/isvins_backend.h): owns the device-resident
+// batch, packs caller windows into it, and enqueues the kernel sequence on the handle's HIP stream.
+// No torch types, no allocation across the ABI.  There is NO CPU fallback: every entry point
+// fails with ISV_ERR_DEVICE when HIP is unavailable.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "isv_device_types.h"
+#include "isv_kernels.h"
+
+#define HIPCHK(h, call)                                                                          \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                        \
+            return ISV_ERR_DEVICE;                                                               \
+        }                                                                                        \
+    } while (0)
+
+struct isv_backend {
+    isv_config_t cfg;
+    std::string err;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[8] = {};
+    DevBatch d{};                 // device pointers
+    std::vector<void *> allocs;
+    // capacities
+    size_t capB = 0, capL = 0, capF = 0, capTiles = 0;
+    // host staging (pinned)
+    struct Host {
+        double *Ps, *Rs, *Vs, *Bas, *Bgs, *tic, *ric, *depth, *lm_pts_i, *f_pts_j, *imu_in, *imu_cov;
+        int32_t *lm_off, *f_off, *lm_host, *lm_k, *lm_f0, *tile_win, *tile_f0, *tile_n, *imu_skip, *n_rp, *solve_flag;
+        FactorRec *f_rec;
+        isv_se3_prior_t *se3; isv_linear9_t *lin9; isv_relpose_t *relpose; isv_rollpitch_t *rollpitch;
+        SolveState *st;
+        double *pose, *sb, *ex, *lam;
+    } h{};
+    std::vector<void *> hallocs;
+    // pristine copies for isv_batch_optimize restore
+    double *Ps0 = nullptr, *Rs0 = nullptr, *Vs0 = nullptr, *Bas0 = nullptr, *Bgs0 = nullptr, *depth0 = nullptr;
+    isv_se3_prior_t *se30 = nullptr; isv_linear9_t *lin90 = nullptr; isv_relpose_t *relpose0 = nullptr; isv_rollpitch_t *rollpitch0 = nullptr;
+    int resident = 0;
+    double last_ms[8] = {};
+    int64_t last_counts[8] = {};
+};
+
+template <typename T>
+static int dalloc(isv_backend *h, T **p, size_t n) {
+    void *q = nullptr;
+    HIPCHK(h, hipMalloc(&q, (n ? n : 1) * sizeof(T)));
+    h->allocs.push_back(q);
+    *p = (T *)q;
+    return ISV_OK;
+}
+template <typename T>
+static int halloc(isv_backend *h, T **p, size_t n) {
+    void *q = nullptr;
+    HIPCHK(h, hipHostMalloc(&q, (n ? n : 1) * sizeof(T), hipHostMallocDefault));
+    h->hallocs.push_back(q);
+    *p = (T *)q;
+    return ISV_OK;
+}
+#define TRY(x) do { int rc_ = (x); if (rc_ != ISV_OK) return rc_; } while (0)
+
+extern "C" int isv_abi_version(void) { return ISV_ABI_VERSION; }
+
+extern "C" const char *isv_backend_last_error(const isv_backend_t *h) { return h ? h->err.c_str() : "null handle"; }
+
+extern "C" void isv_backend_destroy(isv_backend_t *h) {
+    if (!h) return;
+    for (void *p : h->allocs) (void)hipFree(p);
+    for (void *p : h->hallocs) (void)hipHostFree(p);
+    for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+static int create_impl(isv_backend *h) {
+    const isv_config_t &c = h->cfg;
+    int ndev = 0;
+    HIPCHK(h, hipGetDeviceCount(&ndev));
+    if (ndev <= 0) { h->err = "no HIP device"; return ISV_ERR_DEVICE; }
+    HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    for (auto &e : h->ev) HIPCHK(h, hipEventCreate(&e));
+    const size_t B = c.max_batch, N = c.n_frames, L = B * (size_t)c.max_landmarks, F = B * (size_t)c.max_obs;
+    const size_t T = F / ISV_TILE + B + 1;
+    h->capB = B; h->capL = L; h->capF = F; h->capTiles = T;
+    DevBatch &d = h->d;
+    d.N = c.n_frames; d.Nvo = c.n_vo; d.np = 15 * c.n_frames; d.max_rp = c.max_rollpitch; d.max_iter = c.num_iterations;
+    d.n_prior_slots = 2 + (c.n_vo - 1) + c.max_rollpitch;
+    d.prior_strip_sz = PR_REL0 + PR_REL_SZ * (c.n_vo - 1) + PR_RP_SZ * c.max_rollpitch;
+    memcpy(d.proj_sqrt_info, c.proj_sqrt_info, sizeof(d.proj_sqrt_info));
+    memcpy(d.G, c.gravity, sizeof(d.G));
+    d.alpha_cut = c.alpha;
+    const size_t NI = B * (N - 1);
+    TRY(dalloc(h, &d.Ps, B * N * 3)); TRY(dalloc(h, &d.Rs, B * N * 9)); TRY(dalloc(h, &d.Vs, B * N * 3));
+    TRY(dalloc(h, &d.Bas, B * N * 3)); TRY(dalloc(h, &d.Bgs, B * N * 3)); TRY(dalloc(h, &d.tic, B * 3)); TRY(dalloc(h, &d.ric, B * 9));
+    TRY(dalloc(h, &d.depth, L)); TRY(dalloc(h, &d.solve_flag, L));
+    TRY(dalloc(h, &d.pose, B * N * 7)); TRY(dalloc(h, &d.sb, B * N * 9)); TRY(dalloc(h, &d.ex, B * 7)); TRY(dalloc(h, &d.lam, L));
+    TRY(dalloc(h, &d.cpose, B * N * 7)); TRY(dalloc(h, &d.csb, B * N * 9)); TRY(dalloc(h, &d.clam, L));
+    TRY(dalloc(h, &d.lm_off, B + 1)); TRY(dalloc(h, &d.f_off, B + 1));
+    TRY(dalloc(h, &d.lm_host, L)); TRY(dalloc(h, &d.lm_k, L)); TRY(dalloc(h, &d.lm_f0, L)); TRY(dalloc(h, &d.lm_pts_i, L * 3));
+    TRY(dalloc(h, &d.f_rec, F)); TRY(dalloc(h, &d.f_pts_j, F * 2));
+    TRY(dalloc(h, &d.tile_win, T)); TRY(dalloc(h, &d.tile_f0, T)); TRY(dalloc(h, &d.tile_n, T));
+    TRY(dalloc(h, &d.imu_in, NI * ISV_IMU_IN)); TRY(dalloc(h, &d.imu_cov, NI * 225)); TRY(dalloc(h, &d.imu_sqrt, NI * 225));
+    TRY(dalloc(h, &d.imu_skip, NI));
+    TRY(dalloc(h, &d.se3, B)); TRY(dalloc(h, &d.lin9, B)); TRY(dalloc(h, &d.relpose, B * (c.n_vo - 1))); TRY(dalloc(h, &d.rollpitch, B * (size_t)c.max_rollpitch));
+    TRY(dalloc(h, &d.n_rp, B));
+    TRY(dalloc(h, &d.strip, F * ISV_PROJ_STRIP)); TRY(dalloc(h, &d.fcost, F));
+    TRY(dalloc(h, &d.imu_strip, NI * ISV_IMU_STRIP)); TRY(dalloc(h, &d.imu_cost, NI));
+    TRY(dalloc(h, &d.prior_strip, B * (size_t)d.prior_strip_sz)); TRY(dalloc(h, &d.prior_cost, B * (size_t)d.n_prior_slots));
+    TRY(dalloc(h, &d.cost, B)); TRY(dalloc(h, &d.st, B));
+    TRY(dalloc(h, &h->Ps0, B * N * 3)); TRY(dalloc(h, &h->Rs0, B * N * 9)); TRY(dalloc(h, &h->Vs0, B * N * 3));
+    TRY(dalloc(h, &h->Bas0, B * N * 3)); TRY(dalloc(h, &h->Bgs0, B * N * 3)); TRY(dalloc(h, &h->depth0, L));
+    TRY(dalloc(h, &h->se30, B)); TRY(dalloc(h, &h->lin90, B)); TRY(dalloc(h, &h->relpose0, B * (c.n_vo - 1))); TRY(dalloc(h, &h->rollpitch0, B * (size_t)c.max_rollpitch));
+    auto &s = h->h;
+    TRY(halloc(h, &s.Ps, B * N * 3)); TRY(halloc(h, &s.Rs, B * N * 9)); TRY(halloc(h, &s.Vs, B * N * 3));
+    TRY(halloc(h, &s.Bas, B * N * 3)); TRY(halloc(h, &s.Bgs, B * N * 3)); TRY(halloc(h, &s.tic, B * 3)); TRY(halloc(h, &s.ric, B * 9));
+    TRY(halloc(h, &s.depth, L)); TRY(halloc(h, &s.solve_flag, L)); TRY(halloc(h, &s.lm_pts_i, L * 3)); TRY(halloc(h, &s.f_pts_j, F * 2));
+    TRY(halloc(h, &s.imu_in, NI * ISV_IMU_IN)); TRY(halloc(h, &s.imu_cov, NI * 225));
+    TRY(halloc(h, &s.lm_off, B + 1)); TRY(halloc(h, &s.f_off, B + 1)); TRY(halloc(h, &s.lm_host, L)); TRY(halloc(h, &s.lm_k, L)); TRY(halloc(h, &s.lm_f0, L));
+    TRY(halloc(h, &s.tile_win, T)); TRY(halloc(h, &s.tile_f0, T)); TRY(halloc(h, &s.tile_n, T)); TRY(halloc(h, &s.imu_skip, NI)); TRY(halloc(h, &s.n_rp, B));
+    TRY(halloc(h, &s.f_rec, F));
+    TRY(halloc(h, &s.se3, B)); TRY(halloc(h, &s.lin9, B)); TRY(halloc(h, &s.relpose, B * (c.n_vo - 1))); TRY(halloc(h, &s.rollpitch, B * (size_t)c.max_rollpitch));
+    TRY(halloc(h, &s.st, B));
+    TRY(halloc(h, &s.pose, B * N * 7)); TRY(halloc(h, &s.sb, B * N * 9)); TRY(halloc(h, &s.ex, B * 7)); TRY(halloc(h, &s.lam, L));
+    TRY(isv_solver_alloc(h->d, B, L, F, h->allocs, h->err));
+    return ISV_OK;
+}
+
+extern "C" int isv_backend_create(const isv_config_t *cfg, isv_backend_t **out) {
+    if (!cfg || !out) return ISV_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (cfg->n_frames < 3 || cfg->n_frames > ISV_MAX_FRAMES || cfg->n_vo < 2 || cfg->n_vo > cfg->n_frames - 1 ||
+        cfg->max_landmarks < 0 || cfg->max_obs < 0 || cfg->max_batch < 1 || cfg->max_rollpitch < 0 || cfg->num_iterations < 0 ||
+        cfg->num_iterations >= ISV_MAX_TRACE)
+        return ISV_ERR_INVALID_ARG;
+    if (cfg->estimate_extrinsic != 0) return ISV_ERR_UNSUPPORTED;
+    isv_backend *h = new isv_backend();
+    h->cfg = *cfg;
+    int rc = create_impl(h);
+    if (rc != ISV_OK) {
+        fprintf(stderr, "isv_backend_create: %s\n", h->err.c_str());
+        isv_backend_destroy(h);
+        return rc;
+    }
+    *out = h;
+    return ISV_OK;
+}
+
+static bool finite_all(const double *p, size_t n) {
+    for (size_t i = 0; i < n; i++) if (!(p[i] - p[i] == 0.0)) return false;
+    return true;
+}
+
+// pack n caller windows into the pinned staging area and copy them to the device
+extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const *ws) {
+    if (!h || !ws || n < 1) return ISV_ERR_INVALID_ARG;
+    if ((size_t)n > h->capB) { h->err = "batch larger than max_batch"; return ISV_ERR_CAPACITY; }
+    const isv_config_t &c = h->cfg;
+    const int N = c.n_frames;
+    auto &s = h->h;
+    size_t L = 0, F = 0, T = 0;
+    for (int b = 0; b < n; b++) {
+        const isv_window_t *w = ws[b];
+        if (!w || !w->Ps || !w->Rs || !w->Vs || !w->Bas || !w->Bgs || !w->tic || !w->ric || !w->imu || !w->pose_prior ||
+            !w->vb_prior || !w->relpose || (w->n_rollpitch > 0 && !w->rollpitch) || w->n_landmarks < 0 ||
+            (w->n_landmarks > 0 && (!w->lm_start_frame || !w->lm_obs_ptr || !w->obs_point || !w->lm_depth)))
+            return ISV_ERR_INVALID_ARG;
+        if (w->n_landmarks > c.max_landmarks || w->n_obs > c.max_obs || w->n_rollpitch > c.max_rollpitch) { h->err = "window exceeds capacity"; return ISV_ERR_CAPACITY; }
+        s.lm_off[b] = (int32_t)L; s.f_off[b] = (int32_t)F;
+        memcpy(s.Ps + (size_t)b * N * 3, w->Ps, sizeof(double) * N * 3); memcpy(s.Rs + (size_t)b * N * 9, w->Rs, sizeof(double) * N * 9);
+        memcpy(s.Vs + (size_t)b * N * 3, w->Vs, sizeof(double) * N * 3); memcpy(s.Bas + (size_t)b * N * 3, w->Bas, sizeof(double) * N * 3);
+        memcpy(s.Bgs + (size_t)b * N * 3, w->Bgs, sizeof(double) * N * 3);
+        memcpy(s.tic + (size_t)b * 3, w->tic, 24); memcpy(s.ric + (size_t)b * 9, w->ric, 72);
+        if (!finite_all(w->Ps, N * 3) || !finite_all(w->Rs, N * 9) || !finite_all(w->Vs, N * 3)) return ISV_ERR_NONFINITE;
+        for (int l = 0; l < w->n_landmarks; l++) {
+            const int hst = w->lm_start_frame[l], o0 = w->lm_obs_ptr[l], k = w->lm_obs_ptr[l + 1] - o0;
+            if (hst < 0 || k < 2 || hst + k > N || o0 < 0 || o0 + k > w->n_obs) { h->err = "bad landmark track"; return ISV_ERR_INVALID_ARG; }
+            s.lm_host[L] = hst; s.lm_k[L] = k; s.lm_f0[L] = (int32_t)F;
+            s.depth[L] = w->lm_depth[l];
+            memcpy(s.lm_pts_i + L * 3, w->obs_point + (size_t)o0 * 3, 24);
+            for (int o = 1; o < k; o++) {
+                s.f_rec[F].lm = (int32_t)L; s.f_rec[F].ij = hst | ((hst + o) << 8);
+                s.f_pts_j[F * 2] = w->obs_point[(size_t)(o0 + o) * 3]; s.f_pts_j[F * 2 + 1] = w->obs_point[(size_t)(o0 + o) * 3 + 1];
+                F++;
+            }
+            L++;
+        }
+        // tiles of <= 64 consecutive factors of this window
+        for (size_t f = s.f_off[b]; f < F; f += ISV_TILE) {
+            s.tile_win[T] = b; s.tile_f0[T] = (int32_t)f; s.tile_n[T] = (int32_t)((F - f) < ISV_TILE ? (F - f) : ISV_TILE); T++;
+        }
+        for (int i = 0; i < N - 1; i++) {
+            const isv_imu_t &im = w->imu[i];
+            double *r = s.imu_in + ((size_t)b * (N - 1) + i) * ISV_IMU_IN;
+            memset(r, 0, sizeof(double) * ISV_IMU_IN);
+            memcpy(r + IMU_DP, im.delta_p, 24); memcpy(r + IMU_DQ, im.delta_q, 32); memcpy(r + IMU_DV, im.delta_v, 24);
+            memcpy(r + IMU_LBA, im.linearized_ba, 24); memcpy(r + IMU_LBG, im.linearized_bg, 24); r[IMU_DT] = im.sum_dt;
+            for (int a = 0; a < 3; a++) for (int bb = 0; bb < 3; bb++) {
+                r[IMU_DP_DBA + a * 3 + bb] = im.jacobian[(0 + a) * 15 + 9 + bb];
+                r[IMU_DP_DBG + a * 3 + bb] = im.jacobian[(0 + a) * 15 + 12 + bb];
+                r[IMU_DQ_DBG + a * 3 + bb] = im.jacobian[(3 + a) * 15 + 12 + bb];
+                r[IMU_DV_DBA + a * 3 + bb] = im.jacobian[(6 + a) * 15 + 9 + bb];
+                r[IMU_DV_DBG + a * 3 + bb] = im.jacobian[(6 + a) * 15 + 12 + bb];
+            }
+            memcpy(s.imu_cov + ((size_t)b * (N - 1) + i) * 225, im.covariance, sizeof(double) * 225);
+            s.imu_skip[(size_t)b * (N - 1) + i] = im.sum_dt > 10.0;
+        }
+        s.se3[b] = *w->pose_prior; s.lin9[b] = *w->vb_prior;
+        for (int i = 0; i < c.n_vo - 1; i++) s.relpose[(size_t)b * (c.n_vo - 1) + i] = w->relpose[i];
+        for (int i = 0; i < c.max_rollpitch; i++) {
+            if (i < w->n_rollpitch) {
+                if (w->rollpitch[i].index < 0 || w->rollpitch[i].index >= N) return ISV_ERR_INVALID_ARG;
+                s.rollpitch[(size_t)b * c.max_rollpitch + i] = w->rollpitch[i];
+            } else memset(&s.rollpitch[(size_t)b * c.max_rollpitch + i], 0, sizeof(isv_rollpitch_t));
+        }
+        s.n_rp[b] = w->n_rollpitch;
+    }
+    s.lm_off[n] = (int32_t)L; s.f_off[n] = (int32_t)F;
+    DevBatch &d = h->d;
+    d.B = n; d.Ltot = (int32_t)L; d.Ftot = (int32_t)F; d.n_tiles = (int32_t)T;
+    hipStream_t st = h->stream;
+#define H2D(dst, src, cnt) HIPCHK(h, hipMemcpyAsync(dst, src, sizeof(*(src)) * (size_t)(cnt), hipMemcpyHostToDevice, st))
+    const size_t NI = (size_t)n * (N - 1);
+    H2D(d.Ps, s.Ps, (size_t)n * N * 3); H2D(d.Rs, s.Rs, (size_t)n * N * 9); H2D(d.Vs, s.Vs, (size_t)n * N * 3);
+    H2D(d.Bas, s.Bas, (size_t)n * N * 3); H2D(d.Bgs, s.Bgs, (size_t)n * N * 3); H2D(d.tic, s.tic, (size_t)n * 3); H2D(d.ric, s.ric, (size_t)n * 9);
+    H2D(d.depth, s.depth, L); H2D(d.lm_off, s.lm_off, n + 1); H2D(d.f_off, s.f_off, n + 1);
+    H2D(d.lm_host, s.lm_host, L); H2D(d.lm_k, s.lm_k, L); H2D(d.lm_f0, s.lm_f0, L); H2D(d.lm_pts_i, s.lm_pts_i, L * 3);
+    H2D(d.f_rec, s.f_rec, F); H2D(d.f_pts_j, s.f_pts_j, F * 2);
+    H2D(d.tile_win, s.tile_win, T); H2D(d.tile_f0, s.tile_f0, T); H2D(d.tile_n, s.tile_n, T);
+    H2D(d.imu_in, s.imu_in, NI * ISV_IMU_IN); H2D(d.imu_cov, s.imu_cov, NI * 225); H2D(d.imu_skip, s.imu_skip, NI);
+    H2D(d.se3, s.se3, n); H2D(d.lin9, s.lin9, n); H2D(d.relpose, s.relpose, (size_t)n * (c.n_vo - 1)); H2D(d.rollpitch, s.rollpitch, (size_t)n * c.max_rollpitch);
+    H2D(d.n_rp, s.n_rp, n);
+#undef H2D
+#define D2D(dst, src, cnt) HIPCHK(h, hipMemcpyAsync(dst, src, sizeof(*(src)) * (size_t)(cnt), hipMemcpyDeviceToDevice, st))
+    D2D(h->Ps0, d.Ps, (size_t)n * N * 3); D2D(h->Rs0, d.Rs, (size_t)n * N * 9); D2D(h->Vs0, d.Vs, (size_t)n * N * 3);
+    D2D(h->Bas0, d.Bas, (size_t)n * N * 3); D2D(h->Bgs0, d.Bgs, (size_t)n * N * 3); D2D(h->depth0, d.depth, L);
+    D2D(h->se30, d.se3, n); D2D(h->lin90, d.lin9, n); D2D(h->relpose0, d.relpose, (size_t)n * (c.n_vo - 1)); D2D(h->rollpitch0, d.rollpitch, (size_t)n * c.max_rollpitch);
+    // IMU sqrt_info once per upload (the covariances do not change during a solve)
+    if (NI) hipLaunchKernelGGL(k_imu_prep, dim3((unsigned)NI), dim3(64), 0, st, d);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipStreamSynchronize(st));
+    h->resident = n;
+    return ISV_OK;
+}
+
+static int restore_initial(isv_backend *h) {
+    DevBatch &d = h->d; const isv_config_t &c = h->cfg; hipStream_t st = h->stream;
+    const size_t n = d.B, N = d.N, L = d.Ltot;
+    D2D(d.Ps, h->Ps0, n * N * 3); D2D(d.Rs, h->Rs0, n * N * 9); D2D(d.Vs, h->Vs0, n * N * 3);
+    D2D(d.Bas, h->Bas0, n * N * 3); D2D(d.Bgs, h->Bgs0, n * N * 3); D2D(d.depth, h->depth0, L);
+    D2D(d.se3, h->se30, n); D2D(d.lin9, h->lin90, n); D2D(d.relpose, h->relpose0, n * (c.n_vo - 1)); D2D(d.rollpitch, h->rollpitch0, n * c.max_rollpitch);
+    return ISV_OK;
+}
+
+// the factor-linearisation kernels at the current point (pose/sb/lam); ev[1]..ev[3] bracket them
+static int enqueue_linearize(isv_backend *h, bool timed) {
+    DevBatch &d = h->d; hipStream_t st = h->stream;
+    const size_t NI = (size_t)d.B * (d.N - 1);
+    if (timed) HIPCHK(h, hipEventRecord(h->ev[1], st));
+    if (d.n_tiles > 0) {
+        const size_t lds = 4 * proj_lds_doubles_per_wave(d.N) * sizeof(double);
+        hipLaunchKernelGGL(k_proj_linearize<0>, dim3((d.n_tiles + 3) / 4), dim3(256), lds, st, d, d.pose, d.lam, d.fcost);
+        h->last_counts[0] += 1;
+    }
+    if (timed) HIPCHK(h, hipEventRecord(h->ev[2], st));
+    if (NI) hipLaunchKernelGGL(k_imu_linearize<true>, dim3((unsigned)NI), dim3(64), 0, st, d, d.pose, d.sb, d.imu_cost);
+    {
+        const int tot = d.B * d.n_prior_slots;
+        hipLaunchKernelGGL(k_prior_linearize<true>, dim3((tot + 63) / 64), dim3(64), 0, st, d, d.pose, d.sb, d.prior_cost);
+    }
+    hipLaunchKernelGGL(k_cost_reduce, dim3(d.B), dim3(256), 0, st, d, d.fcost, d.imu_cost, d.prior_cost, d.cost);
+    if (timed) HIPCHK(h, hipEventRecord(h->ev[3], st));
+    HIPCHK(h, hipGetLastError());
+    return ISV_OK;
+}
+
+extern "C" int isv_batch_sync(isv_backend_t *h) {
+    if (!h) return ISV_ERR_INVALID_ARG;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return ISV_OK;
+}
+
+extern "C" int isv_batch_linearize(isv_backend_t *h, int32_t sync) {
+    if (!h || !h->resident) return ISV_ERR_INVALID_ARG;
+    DevBatch &d = h->d; hipStream_t st = h->stream;
+    memset(h->last_counts, 0, sizeof(h->last_counts));
+    HIPCHK(h, hipEventRecord(h->ev[0], st));
+    TRY(restore_initial(h));
+    hipLaunchKernelGGL(k_vector2double, dim3(d.B), dim3(64), 0, st, d);
+    TRY(enqueue_linearize(h, true));
+    HIPCHK(h, hipEventRecord(h->ev[4], st));
+    if (sync) HIPCHK(h, hipStreamSynchronize(st));
+    return ISV_OK;
+}
+
+extern "C" int isv_batch_last_timing(isv_backend_t *h, double out_ms[8]) {
+    if (!h || !out_ms) return ISV_ERR_INVALID_ARG;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    float ms = 0;
+    for (int i = 0; i < 8; i++) out_ms[i] = 0;
+    if (hipEventElapsedTime(&ms, h->ev[0], h->ev[4]) == hipSuccess) out_ms[0] = ms;
+    if (hipEventElapsedTime(&ms, h->ev[1], h->ev[2]) == hipSuccess) out_ms[1] = ms;
+    if (hipEventElapsedTime(&ms, h->ev[2], h->ev[3]) == hipSuccess) out_ms[2] = ms;
+    for (int i = 3; i < 8; i++) out_ms[i] = h->last_ms[i];
+    return ISV_OK;
+}
+
+extern "C" int isv_batch_last_counts(isv_backend_t *h, int64_t out[8]) {
+    if (!h || !out) return ISV_ERR_INVALID_ARG;
+    memcpy(out, h->last_counts, sizeof(h->last_counts));
+    return ISV_OK;
+}
+
+extern "C" int isv_batch_optimize(isv_backend_t *h, int32_t sync) {
+    if (!h || !h->resident) return ISV_ERR_INVALID_ARG;
+    DevBatch &d = h->d; hipStream_t st = h->stream;
+    memset(h->last_counts, 0, sizeof(h->last_counts));
+    HIPCHK(h, hipEventRecord(h->ev[0], st));
+    TRY(restore_initial(h));
+    hipLaunchKernelGGL(k_vector2double, dim3(d.B), dim3(64), 0, st, d);
+    int rc = isv_solver_enqueue(h->d, st, h->last_counts, h->err);
+    if (rc != ISV_OK) return rc;
+    HIPCHK(h, hipEventRecord(h->ev[4], st));
+    if (sync) HIPCHK(h, hipStreamSynchronize(st));
+    return ISV_OK;
+}
+
+extern "C" int isv_batch_download(isv_backend_t *h, int32_t n, isv_window_t *const *ws, isv_summary_t *summary,
+                                  isv_marg_result_t *marg) {
+    if (!h || !ws || n != h->resident) return ISV_ERR_INVALID_ARG;
+    DevBatch &d = h->d; hipStream_t st = h->stream; auto &s = h->h; const isv_config_t &c = h->cfg;
+    const size_t N = d.N, L = d.Ltot;
+#define D2H(dst, src, cnt) HIPCHK(h, hipMemcpyAsync(dst, src, sizeof(*(src)) * (size_t)(cnt), hipMemcpyDeviceToHost, st))
+    D2H(s.Ps, d.Ps, n * N * 3); D2H(s.Rs, d.Rs, n * N * 9); D2H(s.Vs, d.Vs, n * N * 3); D2H(s.Bas, d.Bas, n * N * 3); D2H(s.Bgs, d.Bgs, n * N * 3);
+    D2H(s.tic, d.tic, (size_t)n * 3); D2H(s.ric, d.ric, (size_t)n * 9); D2H(s.depth, d.depth, L); D2H(s.solve_flag, d.solve_flag, L);
+    D2H(s.se3, d.se3, n); D2H(s.lin9, d.lin9, n); D2H(s.relpose, d.relpose, (size_t)n * (c.n_vo - 1)); D2H(s.rollpitch, d.rollpitch, (size_t)n * c.max_rollpitch);
+    D2H(s.pose, d.pose, n * N * 7); D2H(s.sb, d.sb, n * N * 9); D2H(s.ex, d.ex, (size_t)n * 7); D2H(s.lam, d.lam, L);
+    D2H(s.st, d.st, n);
+    HIPCHK(h, hipStreamSynchronize(st));
+    int rcs = isv_solver_download(h->d, st, n, summary, marg, h->err);
+    if (rcs != ISV_OK) return rcs;
+    for (int b = 0; b < n; b++) {
+        isv_window_t *w = ws[b];
+        memcpy(w->Ps, s.Ps + (size_t)b * N * 3, sizeof(double) * N * 3); memcpy(w->Rs, s.Rs + (size_t)b * N * 9, sizeof(double) * N * 9);
+        memcpy(w->Vs, s.Vs + (size_t)b * N * 3, sizeof(double) * N * 3); memcpy(w->Bas, s.Bas + (size_t)b * N * 3, sizeof(double) * N * 3);
+        memcpy(w->Bgs, s.Bgs + (size_t)b * N * 3, sizeof(double) * N * 3);
+        memcpy(w->tic, s.tic + (size_t)b * 3, 24); memcpy(w->ric, s.ric + (size_t)b * 9, 72);
+        const int l0 = s.lm_off[b];
+        for (int l = 0; l < w->n_landmarks; l++) {
+            w->lm_depth[l] = s.depth[l0 + l];
+            if (w->lm_solve_flag) w->lm_solve_flag[l] = s.solve_flag[l0 + l];
+            if (w->para_Feature) w->para_Feature[l] = s.lam[l0 + l];
+        }
+        *w->pose_prior = s.se3[b]; *w->vb_prior = s.lin9[b];
+        for (int i = 0; i < c.n_vo - 1; i++) w->relpose[i] = s.relpose[(size_t)b * (c.n_vo - 1) + i];
+        for (int i = 0; i < w->n_rollpitch; i++) w->rollpitch[i] = s.rollpitch[(size_t)b * c.max_rollpitch + i];
+        if (w->para_Pose) memcpy(w->para_Pose, s.pose + (size_t)b * N * 7, sizeof(double) * N * 7);
+        if (w->para_SpeedBias) memcpy(w->para_SpeedBias, s.sb + (size_t)b * N * 9, sizeof(double) * N * 9);
+        if (w->para_Ex_Pose) memcpy(w->para_Ex_Pose, s.ex + (size_t)b * 7, 56);
+    }
+    return ISV_OK;
+}
+
+extern "C" int isv_backend_optimize_batch(isv_backend_t *h, int32_t n, isv_window_t *const *w, isv_summary_t *summary,
+                                          isv_marg_result_t *marg) {
+    TRY(isv_batch_upload(h, n, w));
+    TRY(isv_batch_optimize(h, 1));
+    return isv_batch_download(h, n, w, summary, marg);
+}
+
+extern "C" int isv_backend_optimize(isv_backend_t *h, isv_window_t *w, isv_summary_t *summary, isv_marg_result_t *marg) {
+    isv_window_t *ws[1] = {w};
+    return isv_backend_optimize_batch(h, 1, ws, summary, marg);
+}
+
+extern "C" int isv_backend_linearize(isv_backend_t *h, const isv_window_t *w, double *proj_strips, double *imu_strips,
+                                     double *cost) {
+    if (!h || !w) return ISV_ERR_INVALID_ARG;
+    isv_window_t *ws[1] = {const_cast<isv_window_t *>(w)};
+    TRY(isv_batch_upload(h, 1, ws));
+    TRY(isv_batch_linearize(h, 1));
+    DevBatch &d = h->d; hipStream_t st = h->stream;
+    if (proj_strips && d.Ftot) D2H(proj_strips, d.strip, (size_t)d.Ftot * ISV_PROJ_STRIP);
+    if (imu_strips) D2H(imu_strips, d.imu_strip, (size_t)(d.N - 1) * ISV_IMU_STRIP);
+    if (cost) D2H(cost, d.cost, 1);
+    HIPCHK(h, hipStreamSynchronize(st));
+    return ISV_OK;
+}
+
+// test hook: prior strips / per-block costs of window 0 after isv_backend_linearize
+extern "C" int isv_debug_read(isv_backend_t *h, int32_t what, double *out, int64_t count) {
+    if (!h || !out) return ISV_ERR_INVALID_ARG;
+    DevBatch &d = h->d; hipStream_t st = h->stream;
+    const double *src = nullptr;
+    switch (what) {
+    case 0: src = d.prior_strip; break;
+    case 1: src = d.prior_cost; break;
+    case 2: src = d.imu_sqrt; break;
+    case 3: src = d.fcost; break;
+    case 4: src = d.imu_cost; break;
+    case 5: src = d.pose; break;
+    case 6: src = d.lam; break;
+    case 7: src = d.cost; break;
+    default: return isv_solver_debug_read(h->d, st, what, out, count, h->err);
+    }
+    D2H(out, src, count);
+    HIPCHK(h, hipStreamSynchronize(st));
+    return ISV_OK;
+}

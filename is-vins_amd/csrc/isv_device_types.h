@@ -1,0 +1,81 @@
+// isv_device_types.h -- device-resident layout of a batch of sliding windows (HBM) shared by the
+// kernels and the host side of the C ABI.
+//
+// All windows of a handle share N (ALL_BUF_SIZE) and Nvo (Vo_SIZE); landmark and factor counts are
+// ragged and addressed through per-window offsets (CSR over windows, then CSR over landmarks:
+// a landmark's factors are contiguous, in FeatureManager traversal order -- the reference's
+// "bit-identical indexing" contract, src/feature_tracker/feature_manager.cpp:27-31,188-204 and
+// src/estimator.cpp:1057-1092).
+#pragma once
+#include <stdint.h>
+#include "../../include/isvins_backend.h"
+
+#define ISV_TILE 64            // reprojection factors per wavefront tile
+#define ISV_MAX_FRAMES 32
+#define ISV_IMU_IN 64          // packed IMU record (doubles)
+// offsets inside the packed IMU record
+#define IMU_DP 0
+#define IMU_DQ 3               // x y z w
+#define IMU_DV 7
+#define IMU_LBA 10
+#define IMU_LBG 13
+#define IMU_DT 16
+#define IMU_DP_DBA 17
+#define IMU_DP_DBG 26
+#define IMU_DQ_DBG 35
+#define IMU_DV_DBA 44
+#define IMU_DV_DBG 53
+
+// per-window prior strip layout (doubles): [se3: r6 J36][lin9: r9 J81][relpose k: r6 Ji36 Jj36]...[rollpitch m: r2 J12]
+#define PR_SE3 0
+#define PR_LIN9 42
+#define PR_REL0 132
+#define PR_REL_SZ 78
+#define PR_RP_SZ 14
+
+struct FactorRec { int32_t lm; int32_t ij; };   // global landmark index; frame_i | frame_j << 8
+
+// solver scalars of one window (DoglegStrategy + TrustRegionMinimizer state, Ceres 2.0.0)
+struct SolveState {
+    double x_cost, cand_cost, model_cost_change, radius, mu, alpha, dogleg_step_norm;
+    double x_norm, gmax, step_norm, gn_norm, g_norm;
+    int32_t iteration, termination, reuse, invalid, need_linearize, step_valid, num_successful, ls_fail;
+};
+
+struct DevBatch {
+    int32_t B, N, Nvo, Ltot, Ftot, n_tiles, max_rp, np;   // np = 15 N
+    int32_t prior_strip_sz, n_prior_slots, max_iter, _pad;
+    double proj_sqrt_info[4];
+    double G[3];
+    double alpha_cut;
+    // Eigen-level state, in/out
+    double *Ps, *Rs, *Vs, *Bas, *Bgs, *tic, *ric, *depth;
+    int32_t *solve_flag;
+    // para_* (current point x), candidate point
+    double *pose, *sb, *ex, *lam;
+    double *cpose, *csb, *clam;
+    // structure
+    int32_t *lm_off, *f_off;            // [B+1]
+    int32_t *lm_host, *lm_k, *lm_f0;    // [Ltot]
+    double *lm_pts_i;                   // [Ltot][3]
+    FactorRec *f_rec;                   // [Ftot]
+    double *f_pts_j;                    // [Ftot][2]
+    int32_t *tile_win, *tile_f0, *tile_n;   // [n_tiles]
+    // IMU
+    double *imu_in;                     // [B (N-1)][ISV_IMU_IN]
+    double *imu_cov;                    // [B (N-1)][225]
+    double *imu_sqrt;                   // [B (N-1)][225]
+    int32_t *imu_skip;                  // [B (N-1)]  sum_dt > 10 (estimator.cpp:1043)
+    // priors (the C ABI structs, verbatim)
+    isv_se3_prior_t *se3; isv_linear9_t *lin9; isv_relpose_t *relpose; isv_rollpitch_t *rollpitch;
+    int32_t *n_rp;
+    // linearisation outputs
+    double *strip;                      // [Ftot][28]  Jacobian strips, CSR factor order
+    double *fcost;                      // [Ftot]      rho(s)/2 per factor
+    double *imu_strip;                  // [B (N-1)][465]
+    double *imu_cost;                   // [B (N-1)]
+    double *prior_strip;                // [B][prior_strip_sz]
+    double *prior_cost;                 // [B][n_prior_slots]
+    double *cost;                       // [B] total cost of the last linearisation
+    SolveState *st;                     // [B]
+};

@@ -1,0 +1,21 @@
+// isv_kernels.h -- kernel and solver-stage declarations shared by the host translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include <vector>
+#include "isv_device_types.h"
+
+__host__ __device__ inline size_t proj_lds_doubles_per_wave(int N) { return (size_t)N * 12 + 12 + 64 * 30; }
+
+__global__ void k_vector2double(DevBatch d);
+__global__ void k_imu_prep(DevBatch d);
+template <int MODE> __global__ void k_proj_linearize(DevBatch d, const double *pose_src, const double *lam_src, double *fcost_out);
+template <bool JAC> __global__ void k_imu_linearize(DevBatch d, const double *pose_src, const double *sb_src, double *cost_out);
+template <bool JAC> __global__ void k_prior_linearize(DevBatch d, const double *pose_src, const double *sb_src, double *cost_out);
+__global__ void k_cost_reduce(DevBatch d, const double *fcost, const double *imu_cost, const double *prior_cost, double *out);
+
+// solver stage (isv_solver.hip)
+int isv_solver_alloc(DevBatch &d, size_t B, size_t L, size_t F, std::vector<void *> &allocs, std::string &err);
+int isv_solver_enqueue(DevBatch &d, hipStream_t st, int64_t *counts, std::string &err);
+int isv_solver_download(DevBatch &d, hipStream_t st, int n, isv_summary_t *summary, isv_marg_result_t *marg, std::string &err);
+int isv_solver_debug_read(DevBatch &d, hipStream_t st, int what, double *out, int64_t count, std::string &err);

@@ -1,0 +1,536 @@
+// isv_linearize.hip -- factor linearisation kernels for gfx950 (MI355X).
+//
+//   k_vector2double    Estimator::vector2double              src/estimator.cpp:474-516
+//   k_imu_prep         sqrt_info = LLT(cov^-1).L^T            include/factor/imu_factor.h:44 (once per solve)
+//   k_proj_linearize   ProjectionFactor::Evaluate + CauchyLoss corrector
+//                                                             src/factor/projection_factor.cpp:24-122
+//   k_imu_linearize    IMUFactor::Evaluate                    include/factor/imu_factor.h:23-159
+//   k_prior_linearize  SE3Prior/Linear9/RelativePose/RollPitch::Evaluate + corrector
+//   k_cost_reduce      0.5 sum rho over the window's residual blocks, fixed order
+//
+// Design (MI355X): the reprojection kernel is the HBM-bound one (60 B in, 232 B out, ~350 fp64
+// FMA per factor = 1.5 flop/B, ridge ~10).  One LANE per factor, one 64-factor tile per
+// wavefront; the window's pose blocks are staged once per wave in LDS as rotation matrices; the
+// 28-double strip of every factor is transposed through LDS so that the wave stores its
+// 64 x 224 B = 14 KiB of strips as 14 fully coalesced 1-KiB (16 B/lane) store instructions.
+// IMU / prior factors are matrix shaped (15x15 . 15x30): one wavefront per IMU factor.
+#include <hip/hip_runtime.h>
+#include "isv_device_types.h"
+#include "isv_device_math.h"
+
+// ------------------------------------------------------------------------------------------
+__global__ void k_vector2double(DevBatch d) {
+    int w = blockIdx.x, i = threadIdx.x;
+    if (i < d.N) {
+        const double *R = d.Rs + ((size_t)w * d.N + i) * 9;
+        Quat q = q_from_R(R);
+        double *p = d.pose + ((size_t)w * d.N + i) * 7;
+        const double *P = d.Ps + ((size_t)w * d.N + i) * 3;
+        p[0] = P[0]; p[1] = P[1]; p[2] = P[2]; p[3] = q.x; p[4] = q.y; p[5] = q.z; p[6] = q.w;
+        double *s = d.sb + ((size_t)w * d.N + i) * 9;
+        for (int k = 0; k < 3; k++) {
+            s[k] = d.Vs[((size_t)w * d.N + i) * 3 + k];
+            s[3 + k] = d.Bas[((size_t)w * d.N + i) * 3 + k];
+            s[6 + k] = d.Bgs[((size_t)w * d.N + i) * 3 + k];
+        }
+    }
+    if (i == 0) {
+        Quat q = q_from_R(d.ric + (size_t)w * 9);
+        double *e = d.ex + (size_t)w * 7;
+        e[0] = d.tic[w * 3]; e[1] = d.tic[w * 3 + 1]; e[2] = d.tic[w * 3 + 2];
+        e[3] = q.x; e[4] = q.y; e[5] = q.z; e[6] = q.w;
+    }
+    // para_Feature = 1 / estimated_depth (getDepthVector, feature_manager.cpp:188-204)
+    for (int l = d.lm_off[w] + i; l < d.lm_off[w + 1]; l += blockDim.x) d.lam[l] = 1. / d.depth[l];
+}
+
+// ------------------------------------------------------------------------------------------
+// sqrt_info of every IMU factor.  The covariance is badly conditioned, so any change of
+// operation order moves the result by cond*eps; to stay comparable with the CPU restatement this
+// kernel keeps the textbook order (LU with partial pivoting, column-wise solves, Cholesky) and
+// forbids FMA contraction.  One wavefront per factor; the work is 15^3 and runs once per solve.
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(64) void k_imu_prep(DevBatch d) {
+    __shared__ double A[225], Inv[225], L[225];
+    __shared__ int perm[15];
+    int f = blockIdx.x, t = threadIdx.x;
+    const double *cov = d.imu_cov + (size_t)f * 225;
+    for (int e = t; e < 225; e += 64) A[e] = cov[e];
+    if (t < 15) perm[t] = t;
+    __syncthreads();
+    for (int k = 0; k < 15; k++) {
+        if (t == 0) {
+            int p = k; double best = fabs(A[k * 15 + k]);
+            for (int i = k + 1; i < 15; i++) if (fabs(A[i * 15 + k]) > best) { best = fabs(A[i * 15 + k]); p = i; }
+            if (p != k) {
+                for (int j = 0; j < 15; j++) { double tmp = A[k * 15 + j]; A[k * 15 + j] = A[p * 15 + j]; A[p * 15 + j] = tmp; }
+                int tp = perm[k]; perm[k] = perm[p]; perm[p] = tp;
+            }
+        }
+        __syncthreads();
+        if (t > k && t < 15) A[t * 15 + k] /= A[k * 15 + k];
+        __syncthreads();
+        for (int e = t; e < 225; e += 64) {
+            int i = e / 15, j = e % 15;
+            if (i > k && j > k) A[e] -= A[i * 15 + k] * A[k * 15 + j];
+        }
+        __syncthreads();
+    }
+    if (t < 15) {   // lane c solves column c of the inverse, same order as the restatement
+        int c = t; double x[15];
+        for (int i = 0; i < 15; i++) x[i] = (perm[i] == c) ? 1.0 : 0.0;
+        for (int i = 0; i < 15; i++) { double s = x[i]; for (int k = 0; k < i; k++) s -= A[i * 15 + k] * x[k]; x[i] = s; }
+        for (int i = 14; i >= 0; i--) { double s = x[i]; for (int k = i + 1; k < 15; k++) s -= A[i * 15 + k] * x[k]; x[i] = s / A[i * 15 + i]; }
+        for (int i = 0; i < 15; i++) Inv[i * 15 + c] = x[i];
+    }
+    __syncthreads();
+    for (int e = t; e < 225; e += 64) L[e] = Inv[e];
+    __syncthreads();
+    for (int j = 0; j < 15; j++) {      // Cholesky, lower, reads the lower triangle (Eigen LLT)
+        if (t == 0) {
+            double dd = L[j * 15 + j];
+            for (int k = 0; k < j; k++) dd -= L[j * 15 + k] * L[j * 15 + k];
+            L[j * 15 + j] = sqrt(dd);
+        }
+        __syncthreads();
+        if (t > j && t < 15) {
+            double s = L[t * 15 + j];
+            for (int k = 0; k < j; k++) s -= L[t * 15 + k] * L[j * 15 + k];
+            L[t * 15 + j] = s / L[j * 15 + j];
+        }
+        __syncthreads();
+    }
+    double *out = d.imu_sqrt + (size_t)f * 225;
+    for (int e = t; e < 225; e += 64) { int i = e / 15, j = e % 15; out[e] = (j >= i) ? L[j * 15 + i] : 0.0; }
+}
+#pragma clang fp contract(fast)
+
+// ------------------------------------------------------------------------------------------
+// Reprojection factor geometry for one lane.  R*/P* come from LDS (staged per wave).
+template <bool JAC>
+DEV void proj_factor(const double *Ri, const double *Pi, const double *Rj, const double *Pj,
+                     const double *ric, const double *tic, const double *sq, double lam,
+                     double pix, double piy, double piz, double pjx, double pjy,
+                     double &r0, double &r1, double *Ji, double *Jj, double *Jl) {
+    double inv = 1.0 / lam;
+    double pc[3] = {pix * inv, piy * inv, piz * inv};           // pts_camera_i = pts_i / inv_dep_i
+    double pb[3], pw[3], t[3], pbj[3], pcj[3];
+    m3v(ric, pc, pb); pb[0] += tic[0]; pb[1] += tic[1]; pb[2] += tic[2];     // pts_imu_i
+    m3v(Ri, pb, pw);
+    t[0] = pw[0] + Pi[0] - Pj[0]; t[1] = pw[1] + Pi[1] - Pj[1]; t[2] = pw[2] + Pi[2] - Pj[2];
+    m3tv(Rj, t, pbj);                                                        // pts_imu_j
+    t[0] = pbj[0] - tic[0]; t[1] = pbj[1] - tic[1]; t[2] = pbj[2] - tic[2];
+    m3tv(ric, t, pcj);                                                       // pts_camera_j
+    double idep = 1.0 / pcj[2];
+    double u0 = pcj[0] * idep - pjx, u1 = pcj[1] * idep - pjy;
+    r0 = sq[0] * u0 + sq[1] * u1;
+    r1 = sq[2] * u0 + sq[3] * u1;
+    if (!JAC) return;
+    // reduce = sqrt_info * [[1/z, 0, -x/z^2],[0, 1/z, -y/z^2]]
+    double a0 = idep, a2 = -pcj[0] * idep * idep, b2 = -pcj[1] * idep * idep;
+    double red[6] = {sq[0] * a0, sq[1] * a0, sq[0] * a2 + sq[1] * b2,
+                     sq[2] * a0, sq[3] * a0, sq[2] * a2 + sq[3] * b2};
+    double A[9], RA[6];
+    // A := ric^T * Rj^T
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) A[i * 3 + j] = ric[i] * Rj[j * 3] + ric[3 + i] * Rj[j * 3 + 1] + ric[6 + i] * Rj[j * 3 + 2];
+    // RA = reduce * A   (2x3)
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) RA[i * 3 + j] = red[i * 3] * A[j] + red[i * 3 + 1] * A[3 + j] + red[i * 3 + 2] * A[6 + j];
+    // J_pose_i = [RA, -RA Ri [pts_imu_i]x]
+    double RB[6];                          // RA * Ri
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) RB[i * 3 + j] = RA[i * 3] * Ri[j] + RA[i * 3 + 1] * Ri[3 + j] + RA[i * 3 + 2] * Ri[6 + j];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        Ji[i * 6 + 0] = RA[i * 3 + 0]; Ji[i * 6 + 1] = RA[i * 3 + 1]; Ji[i * 6 + 2] = RA[i * 3 + 2];
+        // -(row) * skew(pb): row*S = [r1*pb2 - r2*pb1, r2*pb0 - r0*pb2, r0*pb1 - r1*pb0]
+        double x = RB[i * 3], y = RB[i * 3 + 1], z = RB[i * 3 + 2];
+        Ji[i * 6 + 3] = -(y * pb[2] - z * pb[1]);
+        Ji[i * 6 + 4] = -(z * pb[0] - x * pb[2]);
+        Ji[i * 6 + 5] = -(x * pb[1] - y * pb[0]);
+    }
+    // J_pose_j = [-RA, reduce ric^T [pts_imu_j]x]
+    double RC[6];                          // reduce * ric^T
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) RC[i * 3 + j] = red[i * 3] * ric[j * 3] + red[i * 3 + 1] * ric[j * 3 + 1] + red[i * 3 + 2] * ric[j * 3 + 2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        Jj[i * 6 + 0] = -RA[i * 3 + 0]; Jj[i * 6 + 1] = -RA[i * 3 + 1]; Jj[i * 6 + 2] = -RA[i * 3 + 2];
+        double x = RC[i * 3], y = RC[i * 3 + 1], z = RC[i * 3 + 2];
+        Jj[i * 6 + 3] = y * pbj[2] - z * pbj[1];
+        Jj[i * 6 + 4] = z * pbj[0] - x * pbj[2];
+        Jj[i * 6 + 5] = x * pbj[1] - y * pbj[0];
+    }
+    // J_lambda = reduce ric^T Rj^T Ri ric pts_i * -1/lambda^2 = RB * (ric * pts_i) * -inv^2
+    double v[3] = {ric[0] * pix + ric[1] * piy + ric[2] * piz, ric[3] * pix + ric[4] * piy + ric[5] * piz,
+                   ric[6] * pix + ric[7] * piy + ric[8] * piz};
+    double s = -inv * inv;
+    Jl[0] = (RB[0] * v[0] + RB[1] * v[1] + RB[2] * v[2]) * s;
+    Jl[1] = (RB[3] * v[0] + RB[4] * v[1] + RB[5] * v[2]) * s;
+}
+
+#define TILE_LD 30     // padded strip row in LDS (doubles): 16-B aligned pairs for ds_read_b128
+
+// LDS per wave: N*12 (R,P per frame) + 12 (ric,tic) + 64*TILE_LD doubles
+#include "isv_kernels.h"
+
+// MODE 0: linearise at x (strips + per-factor cost).  MODE 1: cost only at the candidate point
+// (cpose/clam), per-factor candidate cost into fcost_out.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_proj_linearize(DevBatch d, const double *pose_src, const double *lam_src,
+                                                         double *fcost_out) {
+    extern __shared__ __align__(16) double lds[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int tile = blockIdx.x * 4 + wv;
+    const bool live = tile < d.n_tiles;                // dead waves still reach the barriers
+    const int N = d.N;
+    double *sPose = lds + (size_t)wv * proj_lds_doubles_per_wave(N);
+    double *sEx = sPose + N * 12;
+    double *sOut = sEx + 12;
+    const int win = live ? d.tile_win[tile] : 0, f0 = live ? d.tile_f0[tile] : 0, n = live ? d.tile_n[tile] : 0;
+    // stage this window's pose blocks as rotation matrices (one lane per frame)
+    if (!live) {
+    } else if (lane < N) {
+        const double *p = pose_src + ((size_t)win * N + lane) * 7;
+        double R[9]; q_to_R(q_from_pose(p), R);
+#pragma unroll
+        for (int k = 0; k < 9; k++) sPose[lane * 12 + k] = R[k];
+        sPose[lane * 12 + 9] = p[0]; sPose[lane * 12 + 10] = p[1]; sPose[lane * 12 + 11] = p[2];
+    } else if (lane == 63) {
+        const double *e = d.ex + (size_t)win * 7;
+        double R[9]; q_to_R(q_from_pose(e), R);
+#pragma unroll
+        for (int k = 0; k < 9; k++) sEx[k] = R[k];
+        sEx[9] = e[0]; sEx[10] = e[1]; sEx[11] = e[2];
+    }
+    __syncthreads();
+
+    double r0 = 0, r1 = 0, Ji[12], Jj[12], Jl[2], cost = 0;
+    const bool active = lane < n;
+    if (active) {
+        const int f = f0 + lane;
+        FactorRec rec = d.f_rec[f];
+        const int fi = rec.ij & 255, fj = (rec.ij >> 8) & 255;
+        const double lam = lam_src[rec.lm];
+        const double *pi3 = d.lm_pts_i + (size_t)rec.lm * 3;
+        const double2 pj = *reinterpret_cast<const double2 *>(d.f_pts_j + (size_t)f * 2);
+        double ric[9], tic[3], Ri[9], Rj[9], Pi[3], Pj[3];
+#pragma unroll
+        for (int k = 0; k < 9; k++) { ric[k] = sEx[k]; Ri[k] = sPose[fi * 12 + k]; Rj[k] = sPose[fj * 12 + k]; }
+#pragma unroll
+        for (int k = 0; k < 3; k++) { tic[k] = sEx[9 + k]; Pi[k] = sPose[fi * 12 + 9 + k]; Pj[k] = sPose[fj * 12 + 9 + k]; }
+        proj_factor<MODE == 0>(Ri, Pi, Rj, Pj, ric, tic, d.proj_sqrt_info, lam, pi3[0], pi3[1], pi3[2], pj.x, pj.y,
+                               r0, r1, Ji, Jj, Jl);
+        // CauchyLoss(1.0): rho = log(1+s), rho' = 1/(1+s), rho'' < 0 -> Corrector scales r and J by sqrt(rho')
+        const double s = r0 * r0 + r1 * r1;
+        const double sum = 1.0 + s;
+        cost = 0.5 * log(sum);
+        if (MODE == 0) {
+            const double sc = sqrt(fmax(1.0 / sum, 2.2250738585072014e-308));
+            r0 *= sc; r1 *= sc;
+#pragma unroll
+            for (int k = 0; k < 12; k++) { Ji[k] *= sc; Jj[k] *= sc; }
+            Jl[0] *= sc; Jl[1] *= sc;
+        }
+        fcost_out[f] = cost;
+    }
+    if (MODE != 0) return;                            // uniform over the block
+    // transpose through LDS: lane l owns row l of sOut[64][TILE_LD]
+    {
+        double *row = sOut + lane * TILE_LD;
+        row[0] = r0; row[1] = r1;
+#pragma unroll
+        for (int k = 0; k < 12; k++) { row[2 + k] = Ji[k]; row[14 + k] = Jj[k]; }
+        row[26] = Jl[0]; row[27] = Jl[1];
+    }
+    __syncthreads();
+    // 14 coalesced 16-B/lane stores: element pair e = it*128 + 2*lane of the tile's n*28 doubles
+    double *gout = d.strip + (size_t)f0 * ISV_PROJ_STRIP;
+    const int total = n * ISV_PROJ_STRIP;
+#pragma unroll
+    for (int it = 0; it < 14; it++) {
+        const int e = it * 128 + 2 * lane;
+        if (e < total) {
+            const int ff = e / ISV_PROJ_STRIP, c = e - ff * ISV_PROJ_STRIP;
+            const double2 v = *reinterpret_cast<const double2 *>(sOut + ff * TILE_LD + c);
+            *reinterpret_cast<double2 *>(gout + e) = v;
+        }
+    }
+}
+template __global__ void k_proj_linearize<0>(DevBatch, const double *, const double *, double *);
+template __global__ void k_proj_linearize<1>(DevBatch, const double *, const double *, double *);
+
+// ------------------------------------------------------------------------------------------
+// IMU factor: one wavefront per factor.  raw residual (15) and raw Jacobian (15 x 30) are built by
+// a few lanes in LDS, then every lane forms rows of sqrt_info * [r | J] (15-term dot products).
+// JAC=false: residual only (candidate point), cost into cost_out.
+template <bool JAC>
+__global__ __launch_bounds__(64) void k_imu_linearize(DevBatch d, const double *pose_src, const double *sb_src,
+                                                       double *cost_out) {
+    __shared__ double sS[225], sRaw[15 * 31], sRes[16];
+    const int f = blockIdx.x, t = threadIdx.x;
+    const int N = d.N, w = f / (N - 1), i = f % (N - 1);
+    if (d.imu_skip[f]) { if (t == 0) cost_out[f] = 0.0; return; }
+    const double *rec = d.imu_in + (size_t)f * ISV_IMU_IN;
+    const double *pi = pose_src + ((size_t)w * N + i) * 7, *pj = pi + 7;
+    const double *si = sb_src + ((size_t)w * N + i) * 9, *sj = si + 9;
+    for (int e = t; e < 225; e += 64) sS[e] = d.imu_sqrt[(size_t)f * 225 + e];
+    for (int e = t; e < 15 * 31; e += 64) sRaw[e] = 0.0;
+    __syncthreads();
+    if (t == 0) {
+        // IntegrationBase::evaluate  integration_base.h:160-186 (raw residual -> column 30 of sRaw)
+        Quat Qi = q_from_pose(pi), Qj = q_from_pose(pj);
+        Quat Qii = q_inv(Qi);
+        const double dt = rec[IMU_DT];
+        double dba[3], dbg[3], tt[3], t2[3];
+        for (int k = 0; k < 3; k++) { dba[k] = si[3 + k] - rec[IMU_LBA + k]; dbg[k] = si[6 + k] - rec[IMU_LBG + k]; }
+        Quat dq = Quat{rec[IMU_DQ + 3], rec[IMU_DQ], rec[IMU_DQ + 1], rec[IMU_DQ + 2]};
+        m3v(rec + IMU_DQ_DBG, dbg, tt);
+        Quat cdq = q_mul(dq, q_delta(tt));
+        double cdv[3], cdp[3];
+        m3v(rec + IMU_DV_DBA, dba, tt); m3v(rec + IMU_DV_DBG, dbg, t2);
+        for (int k = 0; k < 3; k++) cdv[k] = rec[IMU_DV + k] + tt[k] + t2[k];
+        m3v(rec + IMU_DP_DBA, dba, tt); m3v(rec + IMU_DP_DBG, dbg, t2);
+        for (int k = 0; k < 3; k++) cdp[k] = rec[IMU_DP + k] + tt[k] + t2[k];
+        double u[3], o1[3], o2[3];
+        for (int k = 0; k < 3; k++) u[k] = 0.5 * d.G[k] * dt * dt + pj[k] - pi[k] - si[k] * dt;
+        q_rot(Qii, u, o1);
+        for (int k = 0; k < 3; k++) sRaw[k * 31 + 30] = o1[k] - cdp[k];
+        Quat e = q_mul(q_inv(cdq), q_mul(Qii, Qj));
+        sRaw[3 * 31 + 30] = 2 * e.x; sRaw[4 * 31 + 30] = 2 * e.y; sRaw[5 * 31 + 30] = 2 * e.z;
+        for (int k = 0; k < 3; k++) u[k] = d.G[k] * dt + sj[k] - si[k];
+        q_rot(Qii, u, o2);
+        for (int k = 0; k < 3; k++) sRaw[(6 + k) * 31 + 30] = o2[k] - cdv[k];
+        for (int k = 0; k < 3; k++) { sRaw[(9 + k) * 31 + 30] = sj[3 + k] - si[3 + k]; sRaw[(12 + k) * 31 + 30] = sj[6 + k] - si[6 + k]; }
+        if (JAC) {
+            // raw Jacobian, tangent columns: pose_i 0..5, sb_i 6..14, pose_j 15..20, sb_j 21..29
+            double RiT[9]; q_to_R(Qii, RiT);
+            double S1[9], S2[9], B1[9], B2[9], L[9], Rr[9], T[9];
+            skew3(o1, S1); skew3(o2, S2);
+            // -(Qleft(Qj^-1 Qi) Qright(cdq)).bottomRight3x3 : bottom-right of a 4x4 product
+            {
+                Quat a = q_mul(q_inv(Qj), Qi);
+                // (L4 R4)[1+r][1+c] = a_vec[r] * (-b_vec[c]) + sum_k L33[r][k] R33[k][c]
+                qleft33(a, L); qright33(cdq, Rr); m3_mul(L, Rr, B1);
+                double av[3] = {a.x, a.y, a.z}, bv[3] = {cdq.x, cdq.y, cdq.z};
+                for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) B1[r * 3 + c] += av[r] * (-bv[c]);
+            }
+            qleft33(q_mul(q_mul(q_inv(Qj), Qi), dq), L);
+            m3_mul(L, rec + IMU_DQ_DBG, T);                                 // -> -T at [R, bg]
+            qleft33(q_mul(q_mul(q_inv(cdq), Qii), Qj), B2);                 // pose_j [R,R]
+            for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) {
+                const int ab = a * 3 + b;
+                sRaw[(0 + a) * 31 + 0 + b] = -RiT[ab];
+                sRaw[(0 + a) * 31 + 3 + b] = S1[ab];
+                sRaw[(3 + a) * 31 + 3 + b] = -B1[ab];
+                sRaw[(6 + a) * 31 + 3 + b] = S2[ab];
+                sRaw[(0 + a) * 31 + 6 + b] = -RiT[ab] * dt;
+                sRaw[(0 + a) * 31 + 9 + b] = -rec[IMU_DP_DBA + ab];
+                sRaw[(0 + a) * 31 + 12 + b] = -rec[IMU_DP_DBG + ab];
+                sRaw[(3 + a) * 31 + 12 + b] = -T[ab];
+                sRaw[(6 + a) * 31 + 6 + b] = -RiT[ab];
+                sRaw[(6 + a) * 31 + 9 + b] = -rec[IMU_DV_DBA + ab];
+                sRaw[(6 + a) * 31 + 12 + b] = -rec[IMU_DV_DBG + ab];
+                sRaw[(9 + a) * 31 + 9 + b] = (a == b) ? -1.0 : 0.0;
+                sRaw[(12 + a) * 31 + 12 + b] = (a == b) ? -1.0 : 0.0;
+                sRaw[(0 + a) * 31 + 15 + b] = RiT[ab];
+                sRaw[(3 + a) * 31 + 18 + b] = B2[ab];
+                sRaw[(6 + a) * 31 + 21 + b] = RiT[ab];
+                sRaw[(9 + a) * 31 + 24 + b] = (a == b) ? 1.0 : 0.0;
+                sRaw[(12 + a) * 31 + 27 + b] = (a == b) ? 1.0 : 0.0;
+            }
+        }
+    }
+    __syncthreads();
+    // weighted residual: lane e < 15
+    if (t < 15) {
+        double s = 0;
+        for (int k = 0; k < 15; k++) s += sS[t * 15 + k] * sRaw[k * 31 + 30];
+        sRes[t] = s;
+        if (JAC) d.imu_strip[(size_t)f * ISV_IMU_STRIP + t] = s;
+    }
+    if (JAC) {
+        // strip layout: [r15 | 15x6 | 15x9 | 15x6 | 15x9] row-major blocks
+        double *out = d.imu_strip + (size_t)f * ISV_IMU_STRIP + 15;
+        for (int e = t; e < 450; e += 64) {
+            int blk, row, col, c;
+            if (e < 90) { blk = 0; row = e / 6; col = e % 6; c = col; }
+            else if (e < 225) { blk = 1; int q = e - 90; row = q / 9; col = q % 9; c = 6 + col; }
+            else if (e < 315) { blk = 2; int q = e - 225; row = q / 6; col = q % 6; c = 15 + col; }
+            else { blk = 3; int q = e - 315; row = q / 9; col = q % 9; c = 21 + col; }
+            (void)blk;
+            double s = 0;
+            for (int k = 0; k < 15; k++) s += sS[row * 15 + k] * sRaw[k * 31 + c];
+            out[e] = s;
+        }
+    }
+    __syncthreads();
+    if (t == 0) {
+        double s = 0;
+        for (int k = 0; k < 15; k++) s += sRes[k] * sRes[k];
+        cost_out[f] = 0.5 * s;                          // no loss function on IMU factors (:1050)
+    }
+}
+template __global__ void k_imu_linearize<true>(DevBatch, const double *, const double *, double *);
+template __global__ void k_imu_linearize<false>(DevBatch, const double *, const double *, double *);
+
+// ------------------------------------------------------------------------------------------
+// small row-major helpers for the prior factors (run by single lanes; sizes <= 9)
+DEV void mat_mul_small(const double *A, const double *B, double *C, int m, int k, int n) {
+    for (int i = 0; i < m; i++) for (int j = 0; j < n; j++) {
+        double s = 0;
+        for (int p = 0; p < k; p++) s += A[i * k + p] * B[p * n + j];
+        C[i * n + j] = s;
+    }
+}
+// apply CauchyLoss corrector to r (dim) and n Jacobian entries, return 0.5 rho(s)
+DEV double cauchy_correct(double *r, int dim, double *J, int nj, bool jac) {
+    double s = 0;
+    for (int k = 0; k < dim; k++) s += r[k] * r[k];
+    const double sum = 1.0 + s;
+    const double sc = sqrt(fmax(1.0 / sum, 2.2250738585072014e-308));
+    for (int k = 0; k < dim; k++) r[k] *= sc;
+    if (jac) for (int k = 0; k < nj; k++) J[k] *= sc;
+    return 0.5 * log(sum);
+}
+
+// One lane per prior factor: slot 0 = SE3 prior, 1 = Linear9, 2..Nvo = relative pose, then roll-pitch.
+template <bool JAC>
+__global__ void k_prior_linearize(DevBatch d, const double *pose_src, const double *sb_src, double *cost_out) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int slots = d.n_prior_slots;
+    if (gid >= d.B * slots) return;
+    const int w = gid / slots, s = gid % slots, N = d.N;
+    double *strip = d.prior_strip + (size_t)w * d.prior_strip_sz;
+    const double *poseW = pose_src + (size_t)w * N * 7;
+    double cost = 0.0;
+    if (s == 0) {
+        // SE3PriorFactor::Evaluate  se3_prior_factor.h:21-53
+        const isv_se3_prior_t &f = d.se3[w];
+        const double *p = poseW;
+        Quat ri = q_normalized(q_from_pose(p)), rp = q_from_R(f.R);
+        Quat rr = so3_mul(q_conj(rp), ri);
+        double raw[6], lg[3], r[6];
+        so3_log(rr, lg);
+        for (int k = 0; k < 3; k++) { raw[k] = p[k] - f.t[k]; raw[3 + k] = lg[k]; }
+        mat_mul_small(f.sqrt_info, raw, r, 6, 6, 1);
+        double J[36];
+        if (JAC) {
+            double Jr[9], rawJ[36];
+            so3_rjac_inv(lg, Jr);
+            for (int k = 0; k < 36; k++) rawJ[k] = 0;
+            rawJ[0] = rawJ[7] = rawJ[14] = 1.0;
+            for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) rawJ[(3 + a) * 6 + 3 + b] = Jr[a * 3 + b];
+            mat_mul_small(f.sqrt_info, rawJ, J, 6, 6, 6);
+        }
+        cost = cauchy_correct(r, 6, J, 36, JAC);
+        if (JAC) { for (int k = 0; k < 6; k++) strip[PR_SE3 + k] = r[k]; for (int k = 0; k < 36; k++) strip[PR_SE3 + 6 + k] = J[k]; }
+    } else if (s == 1) {
+        // Linear9Factor::Evaluate  linear9_factor.h:20-44
+        const isv_linear9_t &f = d.lin9[w];
+        const double *sb = sb_src + ((size_t)w * N + (d.Nvo - 1)) * 9;
+        double raw[9], r[9], J[81];
+        for (int k = 0; k < 9; k++) raw[k] = sb[k] - f.VB[k];
+        mat_mul_small(f.sqrt_info, raw, r, 9, 9, 1);
+        if (JAC) for (int k = 0; k < 81; k++) J[k] = f.sqrt_info[k];
+        cost = cauchy_correct(r, 9, J, 81, JAC);
+        if (JAC) { for (int k = 0; k < 9; k++) strip[PR_LIN9 + k] = r[k]; for (int k = 0; k < 81; k++) strip[PR_LIN9 + 9 + k] = J[k]; }
+    } else if (s < 1 + d.Nvo) {
+        // RelativePoseFactor::Evaluate  relative_pose_factor.h:27-70
+        const int i = s - 2;
+        const isv_relpose_t &f = d.relpose[(size_t)w * (d.Nvo - 1) + i];
+        const double *pi = poseW + i * 7, *pj = pi + 7;
+        Quat Qi = q_from_pose(pi), Qj = q_from_pose(pj);
+        double Ri[9], Rj[9], dd[3], qd[3], M1[9], M2[9], lg[3], raw[6], r[6];
+        q_to_R(Qi, Ri); q_to_R(Qj, Rj);
+        for (int k = 0; k < 3; k++) dd[k] = pj[k] - pi[k];
+        q_rot(q_inv(Qi), dd, qd);
+        m3_mul_nt(f.delta_R, Rj, M1); m3_mul(M1, Ri, M2);
+        so3_log(q_from_R(M2), lg);
+        for (int k = 0; k < 3; k++) { raw[k] = f.delta_t[k] - qd[k]; raw[3 + k] = lg[k]; }
+        mat_mul_small(f.sqrt_info, raw, r, 6, 6, 1);
+        double J[72];
+        if (JAC) {
+            double Jr[9], rawJ[36], S[9], T1[9], T2[9];
+            so3_rjac_inv(lg, Jr); skew3(qd, S);
+            for (int k = 0; k < 36; k++) rawJ[k] = 0;
+            for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) {
+                rawJ[a * 6 + b] = Ri[b * 3 + a];                 // Ri^T
+                rawJ[a * 6 + 3 + b] = -S[a * 3 + b];
+                rawJ[(3 + a) * 6 + 3 + b] = Jr[a * 3 + b];
+            }
+            mat_mul_small(f.sqrt_info, rawJ, J, 6, 6, 6);
+            for (int k = 0; k < 36; k++) rawJ[k] = 0;
+            double nJ[9]; for (int k = 0; k < 9; k++) nJ[k] = -Jr[k];
+            m3_mul_nt(nJ, Ri, T1);                               // -J Ri^T  (A B^T with B = Ri)
+            // m3_mul_nt computes A * B^T: here B^T must be Ri^T -> B = Ri  OK
+            m3_mul(T1, Rj, T2);
+            for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) {
+                rawJ[a * 6 + b] = -Ri[b * 3 + a];
+                rawJ[(3 + a) * 6 + 3 + b] = T2[a * 3 + b];
+            }
+            mat_mul_small(f.sqrt_info, rawJ, J + 36, 6, 6, 6);
+        }
+        cost = cauchy_correct(r, 6, J, 72, JAC);
+        double *o = strip + PR_REL0 + PR_REL_SZ * i;
+        if (JAC) { for (int k = 0; k < 6; k++) o[k] = r[k]; for (int k = 0; k < 72; k++) o[6 + k] = J[k]; }
+    } else {
+        // RollPitchFactor::Evaluate  rollpitch_factor.h:26-57
+        const int m = s - 1 - d.Nvo;
+        double *o = strip + PR_REL0 + PR_REL_SZ * (d.Nvo - 1) + PR_RP_SZ * m;
+        if (m < d.n_rp[w]) {
+            const isv_rollpitch_t &f = d.rollpitch[(size_t)w * d.max_rp + m];
+            const double *p = poseW + f.index * 7;
+            Quat Ri = q_normalized(q_from_pose(p)), Rm = q_from_R(f.R);
+            double nZ[3] = {0, 0, -1.0}, v[3], raw[2], r[2];
+            q_rot(so3_mul(Rm, q_conj(Ri)), nZ, v);
+            raw[0] = v[0]; raw[1] = v[1];
+            r[0] = f.sqrt_info[0] * raw[0] + f.sqrt_info[1] * raw[1];
+            r[1] = f.sqrt_info[2] * raw[0] + f.sqrt_info[3] * raw[1];
+            double J[12];
+            if (JAC) {
+                double S[9], Rmm[9], Bm[9], rawJ[12];
+                skew3(v, S); q_to_R(Rm, Rmm); m3_mul(S, Rmm, Bm);
+                for (int k = 0; k < 12; k++) rawJ[k] = 0;
+                for (int a = 0; a < 2; a++) for (int b = 0; b < 3; b++) rawJ[a * 6 + 3 + b] = Bm[a * 3 + b];
+                mat_mul_small(f.sqrt_info, rawJ, J, 2, 2, 6);
+            }
+            cost = cauchy_correct(r, 2, J, 12, JAC);
+            if (JAC) { o[0] = r[0]; o[1] = r[1]; for (int k = 0; k < 12; k++) o[2 + k] = J[k]; }
+        } else if (JAC) {
+            for (int k = 0; k < PR_RP_SZ; k++) o[k] = 0.0;
+        }
+    }
+    cost_out[(size_t)w * slots + s] = cost;
+}
+template __global__ void k_prior_linearize<true>(DevBatch, const double *, const double *, double *);
+template __global__ void k_prior_linearize<false>(DevBatch, const double *, const double *, double *);
+
+// ------------------------------------------------------------------------------------------
+// cost of one window = sum over its residual blocks, fixed-shape tree (bitwise reproducible):
+// per-thread strided partial sums, then a 256-wide LDS tree.
+__global__ __launch_bounds__(256) void k_cost_reduce(DevBatch d, const double *fcost, const double *imu_cost,
+                                                     const double *prior_cost, double *out) {
+    __shared__ double red[256];
+    const int w = blockIdx.x, t = threadIdx.x;
+    double s = 0;
+    for (int f = d.f_off[w] + t; f < d.f_off[w + 1]; f += 256) s += fcost[f];
+    for (int i = t; i < d.N - 1; i += 256) s += imu_cost[(size_t)w * (d.N - 1) + i];
+    for (int i = t; i < d.n_prior_slots; i += 256) s += prior_cost[(size_t)w * d.n_prior_slots + i];
+    red[t] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (t < off) red[t] += red[t + off];
+        __syncthreads();
+    }
+    if (t == 0) out[w] = red[0];
+}

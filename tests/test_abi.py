@@ -1,0 +1,67 @@
+"""CPU checks of the drop-in boundary: the C-ABI library builds for gfx950, loads, exports every
+symbol include/isvins_backend.h declares, and the ctypes mirror has the header's struct sizes.
+No compute call is made here (no GPU in this container)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+from isvins_amd import abi, backend
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "isvins_backend.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    backend.build()
+    return backend.load_library()
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(isv_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = declared_functions()
+    assert "isv_backend_optimize" in names and "isv_batch_upload" in names and len(names) >= 14
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/isvins_backend.h but not exported"
+    assert set(names) == set(backend.EXPORTS)
+    assert lib.isv_abi_version() == 1
+
+
+def test_struct_sizes_match_header(tmp_path):
+    """compile a tiny C program against the header and compare sizeof with the ctypes mirror"""
+    names = ["isv_config_t", "isv_imu_t", "isv_se3_prior_t", "isv_linear9_t", "isv_relpose_t", "isv_rollpitch_t",
+             "isv_window_t", "isv_summary_t", "isv_combined_factors_t", "isv_marg_result_t"]
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "isvins_backend.h"\nint main(){' +
+                   "".join(f'printf("%zu\\n", sizeof({n}));' for n in names) + "return 0;}")
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    sizes = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    for n, s in zip(names, sizes):
+        assert C.sizeof(getattr(abi, n)) == s, n
+
+
+def test_create_fails_loudly_without_gpu(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(backend.BackendError):
+        backend.Backend(11, 5)
+
+
+def test_create_rejects_bad_config(lib):
+    cfg = abi.make_config(11, 5)
+    h = C.c_void_p()
+    cfg.n_frames = 2
+    assert lib.isv_backend_create(C.byref(cfg), C.byref(h)) == -1
+    cfg = abi.make_config(11, 5); cfg.estimate_extrinsic = 1
+    assert lib.isv_backend_create(C.byref(cfg), C.byref(h)) == -5
+    assert lib.isv_backend_create(None, C.byref(h)) == -1
