@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X sliding-window VIO backend.
+
+Metric (BASELINE.json): sliding-window solves/sec on synthetic 11-KF / ~300-landmark windows, plus
+ms per optimize().  One STEP = one pass of the hot path (Estimator::backendOptimization():
+vector2double + problemSolve [<= 10 dogleg iterations] + update() + double2vector [+ marginalisation
+where built]) over the rank's device-resident batch of windows.  Inputs are resident in HBM before the
+timed region (the step restores the pristine uploaded state on device first).
+
+  python bench.py --gpus N --steps K --warmup W
+For N > 1 the driver launches one process per GPU with torch.distributed.run (RCCL over xGMI);
+windows are independent, so ranks shard them with no data-path collective ("weak" scaling:
+--windows per rank) and only the timing is max-reduced.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import isvins_loader  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FP64_PEAK_TFLOPS = 78.6        # MI355X FP64 vector = matrix peak
+
+
+def cpu_baseline(windows, cfg, budget_s=12.0):
+    """the CPU oracle (oracle/, a 1-thread C port of the reference algorithm) timed on a bounded sample"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    from isvins_amd import abi
+    lib = oracle_lib.load()
+    n = 0
+    t0 = time.perf_counter()
+    for w in windows:
+        o = w.clone()
+        s = abi.isv_summary_t(); mg = abi.isv_marg_result_t()
+        lib.isvo_optimize(C.byref(cfg), C.byref(o.c()), C.byref(s), C.byref(mg))
+        n += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "windows/s", "cores": 1, "kind": "port",
+            "sample": f"{n} of the benchmark's own 11-KF/300-landmark windows, full backendOptimization(), oracle/libisv_oracle.so (gcc -O2), 1 thread",
+            "ms_per_optimize": 1e3 * dt / n}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--windows", type=int, default=1024, help="windows per GPU (BASELINE config 4 batch)")
+    ap.add_argument("--frames", type=int, default=11)
+    ap.add_argument("--vo", type=int, default=5)
+    ap.add_argument("--landmarks", type=int, default=300)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl")
+    else:
+        torch.cuda.set_device(0)
+    os.environ["HIP_VISIBLE_DEVICES"] = os.environ.get("HIP_VISIBLE_DEVICES", "")
+    isvins_loader.load()
+    from isvins_amd import backend, synth
+    backend.build()
+
+    # the C-ABI library uses the current HIP device of the process: select it before create
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipSetDevice(local_rank if world > 1 else 0)
+
+    W = args.windows
+    ids = range(rank * W, (rank + 1) * W)
+    windows = synth.make_windows(ids, n_frames=args.frames, n_vo=args.vo, n_landmarks=args.landmarks)
+    Ftot = sum(w.n_factors for w in windows)
+    max_obs = max(w.n_obs for w in windows)
+    be = backend.Backend(args.frames, args.vo, max_landmarks=args.landmarks, max_obs=max_obs, max_batch=W)
+    be.upload(windows)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        be.run_optimize(sync=True)
+    barrier()
+    t0 = time.perf_counter()
+    fam = np.zeros(8); cnt = np.zeros(8)
+    for _ in range(args.steps):
+        be.run_optimize(sync=False)
+    be.sync()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    # per-kernel-family HIP-event timing of one more (untimed) step, on the handle's own stream
+    be.run_optimize(sync=True)
+    fam = be.last_timing(); cnt = be.last_counts()
+    sums, _ = be.download([w.clone() for w in windows[:8]]) if W <= 8 else (None, None)
+
+    if rank == 0:
+        ms_step = 1e3 * dt / args.steps
+        value = world * W * args.steps / dt
+        # roofline of the dominant kernel family (largest summed duration in the step)
+        n_lin = max(int(cnt[0]), 1); n_bs = max(int(cnt[1]), 1)
+        lin_ms, bs_ms = float(fam[1]), float(fam[3])
+        N, L = args.frames, args.landmarks
+        Fw = Ftot / W
+        # algorithmic work per k_build_solve launch (all windows of the batch):
+        #   flops: H_pp + Schur 2*36*sum k(k+1)/2 per landmark (~k=4.5), IMU 10*2*15*465, Cholesky (15N)^3/3, solves
+        flops_bs = W * (2 * 36 * L * 12.4 * 2 + (N - 1) * 2 * 15 * 465 + (15 * N) ** 3 / 3 + 2 * (15 * N) ** 2)
+        bytes_lin = Ftot * 292.0
+        roof_lin = {"kernel": "k_proj_linearize<0>", "bound": "hbm", "achieved": bytes_lin / (lin_ms / n_lin * 1e-3) / 1e9 if lin_ms > 0 else None,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
+        if roof_lin["achieved"]:
+            roof_lin["frac"] = roof_lin["achieved"] / HBM_PEAK_GBS
+        roof_bs = {"kernel": "k_build_solve", "bound": "mfma", "achieved": flops_bs / (bs_ms / n_bs * 1e-3) / 1e12 if bs_ms > 0 else None,
+                   "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None}
+        if roof_bs["achieved"]:
+            roof_bs["frac"] = roof_bs["achieved"] / FP64_PEAK_TFLOPS
+        dominant = roof_bs if bs_ms >= lin_ms else roof_lin
+        out = {
+            "metric": "sliding-window solves/sec (11 KF, ~300 landmarks)", "value": value, "unit": "windows/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "ms_per_optimize_batched": ms_step / W,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{W} independent synthetic sliding windows per GPU (N={N} KF, Nvo={args.vo}, L={L} landmarks, F~{Fw:.0f} reprojection factors each; BASELINE config 4 batch of config-2 windows), full backendOptimization() with NUM_ITERATIONS=10",
+                       "windows_per_gpu": W, "frames": N, "landmarks": L, "factors_total": Ftot, "iterations_cap": 10,
+                       "parallelism": f"independent windows sharded over {world} rank(s), no data-path collective"},
+            "roofline": dominant,
+            "roofline_linearize": roof_lin, "roofline_build_solve": roof_bs,
+            "kernel_ms": {"step_total": float(fam[0]), "proj_linearize_sum": lin_ms, "build_solve_sum": bs_ms,
+                          "proj_linearize_launches": int(cnt[0]), "build_solve_launches": int(cnt[1])},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(windows, be.cfg)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -264,16 +264,16 @@ static int enqueue_linearize(isv_backend *h, bool timed) {
     if (timed) HIPCHK(h, hipEventRecord(h->ev[1], st));
     if (d.n_tiles > 0) {
         const size_t lds = 4 * proj_lds_doubles_per_wave(d.N) * sizeof(double);
-        hipLaunchKernelGGL(k_proj_linearize<0>, dim3((d.n_tiles + 3) / 4), dim3(256), lds, st, d, d.pose, d.lam, d.fcost);
+        hipLaunchKernelGGL(k_proj_linearize<0>, dim3((d.n_tiles + 3) / 4), dim3(256), lds, st, d, d.pose, d.lam, d.fcost, 0);
         h->last_counts[0] += 1;
     }
     if (timed) HIPCHK(h, hipEventRecord(h->ev[2], st));
-    if (NI) hipLaunchKernelGGL(k_imu_linearize<true>, dim3((unsigned)NI), dim3(64), 0, st, d, d.pose, d.sb, d.imu_cost);
+    if (NI) hipLaunchKernelGGL(k_imu_linearize<true>, dim3((unsigned)NI), dim3(64), 0, st, d, d.pose, d.sb, d.imu_cost, 0);
     {
         const int tot = d.B * d.n_prior_slots;
-        hipLaunchKernelGGL(k_prior_linearize<true>, dim3((tot + 63) / 64), dim3(64), 0, st, d, d.pose, d.sb, d.prior_cost);
+        hipLaunchKernelGGL(k_prior_linearize<true>, dim3((tot + 63) / 64), dim3(64), 0, st, d, d.pose, d.sb, d.prior_cost, 0);
     }
-    hipLaunchKernelGGL(k_cost_reduce, dim3(d.B), dim3(256), 0, st, d, d.fcost, d.imu_cost, d.prior_cost, d.cost);
+    hipLaunchKernelGGL(k_cost_reduce, dim3(d.B), dim3(256), 0, st, d, d.fcost, d.imu_cost, d.prior_cost, d.cost, 0);
     if (timed) HIPCHK(h, hipEventRecord(h->ev[3], st));
     HIPCHK(h, hipGetLastError());
     return ISV_OK;

@@ -37,9 +37,10 @@ struct FactorRec { int32_t lm; int32_t ij; };   // global landmark index; frame_
 
 // solver scalars of one window (DoglegStrategy + TrustRegionMinimizer state, Ceres 2.0.0)
 struct SolveState {
-    double x_cost, cand_cost, model_cost_change, radius, mu, alpha, dogleg_step_norm;
-    double x_norm, gmax, step_norm, gn_norm, g_norm;
+    double x_cost, initial_cost, radius, mu, alpha, dogleg_step_norm;
+    double x_norm, gmax, step_norm, qT;
     int32_t iteration, termination, reuse, invalid, need_linearize, step_valid, num_successful, ls_fail;
+    int32_t fresh, _pad;
 };
 
 struct DevBatch {
@@ -78,4 +79,18 @@ struct DevBatch {
     double *prior_cost;                 // [B][n_prior_slots]
     double *cost;                       // [B] total cost of the last linearisation
     SolveState *st;                     // [B]
+    // ---- trust-region solve (isv_solver.hip) ----------------------------------------------
+    // tangent vectors, pose/speed-bias part [B][np]; landmark part [Ltot]
+    double *scale_p, *diag_p, *grad_p, *gn_p, *delta_p, *zp, *up;
+    double *lmE, *lmG, *scale_l, *diag_l, *grad_l, *gn_l, *delta_l, *lm_aterm;
+    double *Tglob;                      // [B][N(N+1)/2 * 225] reduced system when it does not fit LDS
+    double *fcost_c, *imu_cost_c, *prior_cost_c, *cost_c;      // candidate-point costs
+    double *fmodel, *imu_model, *prior_model, *model;          // (J d)^T (r + J d / 2) per block
+    double *trace_cost, *trace_radius, *trace_step;            // [B][ISV_MAX_TRACE]
+    int32_t *trace_acc;
+    isv_marg_result_t *marg;            // [B]
+    double *marg_scratch;               // [B][marg_scratch_sz]
+    int32_t *margin_old;                // [B]
+    double *header0;                    // [B]
+    int32_t marg_scratch_sz, lds_T;     // lds_T: reduced system lives in LDS (15N <= 165)
 };

@@ -9,10 +9,10 @@ __host__ __device__ inline size_t proj_lds_doubles_per_wave(int N) { return (siz
 
 __global__ void k_vector2double(DevBatch d);
 __global__ void k_imu_prep(DevBatch d);
-template <int MODE> __global__ void k_proj_linearize(DevBatch d, const double *pose_src, const double *lam_src, double *fcost_out);
-template <bool JAC> __global__ void k_imu_linearize(DevBatch d, const double *pose_src, const double *sb_src, double *cost_out);
-template <bool JAC> __global__ void k_prior_linearize(DevBatch d, const double *pose_src, const double *sb_src, double *cost_out);
-__global__ void k_cost_reduce(DevBatch d, const double *fcost, const double *imu_cost, const double *prior_cost, double *out);
+template <int MODE> __global__ void k_proj_linearize(DevBatch d, const double *pose_src, const double *lam_src, double *fcost_out, int gate);
+template <bool JAC> __global__ void k_imu_linearize(DevBatch d, const double *pose_src, const double *sb_src, double *cost_out, int gate);
+template <bool JAC> __global__ void k_prior_linearize(DevBatch d, const double *pose_src, const double *sb_src, double *cost_out, int gate);
+__global__ void k_cost_reduce(DevBatch d, const double *fcost, const double *imu_cost, const double *prior_cost, double *out, int gate);
 
 // solver stage (isv_solver.hip)
 int isv_solver_alloc(DevBatch &d, size_t B, size_t L, size_t F, std::vector<void *> &allocs, std::string &err);

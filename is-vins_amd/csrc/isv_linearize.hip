@@ -187,11 +187,15 @@ DEV void proj_factor(const double *Ri, const double *Pi, const double *Rj, const
 // (cpose/clam), per-factor candidate cost into fcost_out.
 template <int MODE>
 __global__ __launch_bounds__(256) void k_proj_linearize(DevBatch d, const double *pose_src, const double *lam_src,
-                                                         double *fcost_out) {
+                                                         double *fcost_out, int gate) {
     extern __shared__ __align__(16) double lds[];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int tile = blockIdx.x * 4 + wv;
-    const bool live = tile < d.n_tiles;                // dead waves still reach the barriers
+    bool live = tile < d.n_tiles;                      // dead waves still reach the barriers
+    if (live && gate) {                                // solver schedule: skip windows that do not need this pass
+        const SolveState &ss = d.st[d.tile_win[tile]];
+        live = ss.termination == ISV_TERM_RUNNING && (gate == 1 ? ss.need_linearize != 0 : ss.step_valid != 0);
+    }
     const int N = d.N;
     double *sPose = lds + (size_t)wv * proj_lds_doubles_per_wave(N);
     double *sEx = sPose + N * 12;
@@ -266,8 +270,8 @@ __global__ __launch_bounds__(256) void k_proj_linearize(DevBatch d, const double
         }
     }
 }
-template __global__ void k_proj_linearize<0>(DevBatch, const double *, const double *, double *);
-template __global__ void k_proj_linearize<1>(DevBatch, const double *, const double *, double *);
+template __global__ void k_proj_linearize<0>(DevBatch, const double *, const double *, double *, int);
+template __global__ void k_proj_linearize<1>(DevBatch, const double *, const double *, double *, int);
 
 // ------------------------------------------------------------------------------------------
 // IMU factor: one wavefront per factor.  raw residual (15) and raw Jacobian (15 x 30) are built by
@@ -275,10 +279,14 @@ template __global__ void k_proj_linearize<1>(DevBatch, const double *, const dou
 // JAC=false: residual only (candidate point), cost into cost_out.
 template <bool JAC>
 __global__ __launch_bounds__(64) void k_imu_linearize(DevBatch d, const double *pose_src, const double *sb_src,
-                                                       double *cost_out) {
+                                                       double *cost_out, int gate) {
     __shared__ double sS[225], sRaw[15 * 31], sRes[16];
     const int f = blockIdx.x, t = threadIdx.x;
     const int N = d.N, w = f / (N - 1), i = f % (N - 1);
+    if (gate) {
+        const SolveState &ss = d.st[w];
+        if (!(ss.termination == ISV_TERM_RUNNING && (gate == 1 ? ss.need_linearize != 0 : ss.step_valid != 0))) return;
+    }
     if (d.imu_skip[f]) { if (t == 0) cost_out[f] = 0.0; return; }
     const double *rec = d.imu_in + (size_t)f * ISV_IMU_IN;
     const double *pi = pose_src + ((size_t)w * N + i) * 7, *pj = pi + 7;
@@ -380,8 +388,8 @@ __global__ __launch_bounds__(64) void k_imu_linearize(DevBatch d, const double *
         cost_out[f] = 0.5 * s;                          // no loss function on IMU factors (:1050)
     }
 }
-template __global__ void k_imu_linearize<true>(DevBatch, const double *, const double *, double *);
-template __global__ void k_imu_linearize<false>(DevBatch, const double *, const double *, double *);
+template __global__ void k_imu_linearize<true>(DevBatch, const double *, const double *, double *, int);
+template __global__ void k_imu_linearize<false>(DevBatch, const double *, const double *, double *, int);
 
 // ------------------------------------------------------------------------------------------
 // small row-major helpers for the prior factors (run by single lanes; sizes <= 9)
@@ -405,11 +413,15 @@ DEV double cauchy_correct(double *r, int dim, double *J, int nj, bool jac) {
 
 // One lane per prior factor: slot 0 = SE3 prior, 1 = Linear9, 2..Nvo = relative pose, then roll-pitch.
 template <bool JAC>
-__global__ void k_prior_linearize(DevBatch d, const double *pose_src, const double *sb_src, double *cost_out) {
+__global__ void k_prior_linearize(DevBatch d, const double *pose_src, const double *sb_src, double *cost_out, int gate) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x;
     const int slots = d.n_prior_slots;
     if (gid >= d.B * slots) return;
     const int w = gid / slots, s = gid % slots, N = d.N;
+    if (gate) {
+        const SolveState &ss = d.st[w];
+        if (!(ss.termination == ISV_TERM_RUNNING && (gate == 1 ? ss.need_linearize != 0 : ss.step_valid != 0))) return;
+    }
     double *strip = d.prior_strip + (size_t)w * d.prior_strip_sz;
     const double *poseW = pose_src + (size_t)w * N * 7;
     double cost = 0.0;
@@ -512,16 +524,20 @@ __global__ void k_prior_linearize(DevBatch d, const double *pose_src, const doub
     }
     cost_out[(size_t)w * slots + s] = cost;
 }
-template __global__ void k_prior_linearize<true>(DevBatch, const double *, const double *, double *);
-template __global__ void k_prior_linearize<false>(DevBatch, const double *, const double *, double *);
+template __global__ void k_prior_linearize<true>(DevBatch, const double *, const double *, double *, int);
+template __global__ void k_prior_linearize<false>(DevBatch, const double *, const double *, double *, int);
 
 // ------------------------------------------------------------------------------------------
 // cost of one window = sum over its residual blocks, fixed-shape tree (bitwise reproducible):
 // per-thread strided partial sums, then a 256-wide LDS tree.
 __global__ __launch_bounds__(256) void k_cost_reduce(DevBatch d, const double *fcost, const double *imu_cost,
-                                                     const double *prior_cost, double *out) {
+                                                     const double *prior_cost, double *out, int gate) {
     __shared__ double red[256];
     const int w = blockIdx.x, t = threadIdx.x;
+    if (gate) {
+        const SolveState &ss = d.st[w];
+        if (!(ss.termination == ISV_TERM_RUNNING && ss.need_linearize != 0)) return;
+    }
     double s = 0;
     for (int f = d.f_off[w] + t; f < d.f_off[w + 1]; f += 256) s += fcost[f];
     for (int i = t; i < d.N - 1; i += 256) s += imu_cost[(size_t)w * (d.N - 1) + i];

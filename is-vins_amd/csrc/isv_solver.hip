@@ -1,6 +1,505 @@
-// isv_solver.hip -- (stub, replaced by the on-device trust-region solve)
+// isv_solver.hip -- on-device trust-region loop around k_build_solve: Ceres-Solver 2.0.0's
+// TrustRegionMinimizer + DoglegStrategy(TRADITIONAL_DOGLEG) as problemSolve() configures them
+// (reference src/estimator.cpp:1119-1128: DENSE_SCHUR, DOGLEG, max_num_iterations=NUM_ITERATIONS),
+// then the pseudo-measurement update (:1133-1144) and double2vector (:518-594).
+//
+// No host round trip inside the solve: every kernel reads the per-window SolveState and skips
+// windows that have terminated; the host enqueues a fixed schedule of max_iter iteration slots.
+//   slot:  [linearize if need_linearize] -> k_build_solve -> k_backsub -> k_dogleg
+//          -> candidate evaluation (cost + model cost change) -> k_step_control
+#include <hip/hip_runtime.h>
+#include <cstring>
 #include "isv_kernels.h"
-int isv_solver_alloc(DevBatch &, size_t, size_t, size_t, std::vector<void *> &, std::string &) { return ISV_OK; }
-int isv_solver_enqueue(DevBatch &, hipStream_t, int64_t *, std::string &err) { err = "solver not built"; return ISV_ERR_UNSUPPORTED; }
-int isv_solver_download(DevBatch &, hipStream_t, int, isv_summary_t *, isv_marg_result_t *, std::string &) { return ISV_OK; }
-int isv_solver_debug_read(DevBatch &, hipStream_t, int, double *, int64_t, std::string &) { return ISV_ERR_INVALID_ARG; }
+#include "isv_device_math.h"
+
+extern size_t build_solve_lds_bytes(int N, bool lds_T);
+template <bool LDS_T> __global__ void k_build_solve(DevBatch d);
+
+// ------------------------------------------------------------------------------------------
+__global__ void k_init_state(DevBatch d) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= d.B) return;
+    SolveState s;
+    memset(&s, 0, sizeof(s));
+    s.radius = 1e4; s.mu = 1e-8; s.need_linearize = 1; s.termination = ISV_TERM_RUNNING;
+    d.st[w] = s;
+    for (int k = 0; k < ISV_MAX_TRACE; k++) {
+        d.trace_cost[(size_t)w * ISV_MAX_TRACE + k] = 0; d.trace_radius[(size_t)w * ISV_MAX_TRACE + k] = 0;
+        d.trace_step[(size_t)w * ISV_MAX_TRACE + k] = 0; d.trace_acc[(size_t)w * ISV_MAX_TRACE + k] = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// back-substitution of the eliminated landmarks (schur_eliminator BackSubstitute) + the landmark
+// terms of the Cauchy-point denominator.  One lane per landmark, batch wide.
+__global__ __launch_bounds__(256) void k_backsub(DevBatch d) {
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= d.Ltot) return;
+    // window of this landmark: binary search in lm_off
+    int lo = 0, hi = d.B;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (d.lm_off[mid] <= l) lo = mid; else hi = mid; }
+    const int w = lo;
+    const SolveState &st = d.st[w];
+    if (st.termination != ISV_TERM_RUNNING || !st.fresh || st.ls_fail) return;
+    const int n = d.np, h = d.lm_host[l], k = d.lm_k[l], f0 = d.lm_f0[l];
+    const double *zp = d.zp + (size_t)w * n, *up = d.up + (size_t)w * n;
+    double wz = 0, wu = 0;        // w_l^T z_p, w_l^T u_p
+    double wh[6] = {0, 0, 0, 0, 0, 0};
+    for (int m = 0; m < k - 1; m++) {
+        const double *s = d.strip + (size_t)(f0 + m) * ISV_PROJ_STRIP;
+        const double j0 = s[26], j1 = s[27];
+        const int fj = h + m + 1;
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            wh[c] += s[2 + c] * j0 + s[8 + c] * j1;
+            const double wj = s[14 + c] * j0 + s[20 + c] * j1;
+            wz += wj * zp[15 * fj + c]; wu += wj * up[15 * fj + c];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 6; c++) { wz += wh[c] * zp[15 * h + c]; wu += wh[c] * up[15 * h + c]; }
+    const double sl = d.scale_l[l], E = d.lmE[l], gl = d.lmG[l], Dl = d.diag_l[l];
+    const double Es = sl * sl * E, Dl2 = Dl * Dl;
+    // scaled-space y_l = (g'_l - w'_l^T y_p) / (E'_l + mu D_l^2),  w'^T y_p = s_l w^T (Sc_p y_p) = s_l wz
+    const double yl = (sl * gl - sl * wz) / (Es + st.mu * Dl2);
+    d.gn_l[l] = -Dl * yl;
+    // |J u|^2 landmark terms with u_l = s_l^2 g_l / D_l^2 and c_l = s_l^2 / (E' + mu D_l^2)
+    const double ul = sl * sl * gl / Dl2, cl = sl * sl / (Es + st.mu * Dl2);
+    d.lm_aterm[l] = cl * wu * wu + 2.0 * ul * wu + E * ul * ul;
+}
+
+// ------------------------------------------------------------------------------------------
+// block-wide deterministic sum of per-thread partials
+template <int NT>
+DEV double block_sum(double v, double *red, int t) {
+    red[t] = v;
+    __syncthreads();
+    for (int off = NT / 2; off > 0; off >>= 1) { if (t < off) red[t] += red[t + off]; __syncthreads(); }
+    const double r = red[0];
+    __syncthreads();
+    return r;
+}
+
+// DoglegStrategy::ComputeTraditionalDoglegStep + undo of the scalings + Evaluator::Plus.
+// One workgroup per running window.
+__global__ __launch_bounds__(256) void k_dogleg(DevBatch d) {
+    __shared__ double red[256];
+    const int w = blockIdx.x, t = threadIdx.x;
+    SolveState &st = d.st[w];
+    if (st.termination != ISV_TERM_RUNNING) return;
+    const int n = d.np, N = d.N, l0 = d.lm_off[w], l1 = d.lm_off[w + 1];
+    const double *gp = d.grad_p + (size_t)w * n, *gnp = d.gn_p + (size_t)w * n;
+    const double *Dp = d.diag_p + (size_t)w * n, *scp = d.scale_p + (size_t)w * n;
+    double *dp = d.delta_p + (size_t)w * n;
+    if (st.ls_fail) {
+        if (t == 0) { st.step_valid = 0; st.iteration += 1; st.fresh = 0; }
+        return;
+    }
+    double a = 0, b = 0, c = 0, e = 0;
+    for (int i = t; i < n; i += 256) { a += gp[i] * gp[i]; b += gnp[i] * gnp[i]; c += gp[i] * gnp[i]; }
+    for (int l = l0 + t; l < l1; l += 256) {
+        const double gl = d.grad_l[l], nl = d.gn_l[l];
+        a += gl * gl; b += nl * nl; c += gl * nl; e += d.lm_aterm[l];
+    }
+    const double g2 = block_sum<256>(a, red, t), gn2 = block_sum<256>(b, red, t), gdotgn = block_sum<256>(c, red, t);
+    const double aterm = block_sum<256>(e, red, t);
+    double alpha = st.alpha;
+    if (st.fresh) alpha = g2 / (st.qT + aterm);
+    const double radius = st.radius, gn_norm = sqrt(gn2), g_norm = sqrt(g2);
+    // step = cg * gradient_ + cn * gauss_newton_step_   (scaled coordinates)
+    double cg, cn, step_norm_scaled;
+    bool need_norm = false;
+    if (gn_norm <= radius) { cg = 0; cn = 1; step_norm_scaled = gn_norm; }
+    else if (g_norm * alpha >= radius) { cg = -(radius / g_norm); cn = 0; step_norm_scaled = radius; }
+    else {
+        const double b_dot_a = -alpha * gdotgn;
+        const double a_sq = pow(alpha * g_norm, 2.0);
+        const double bma_sq = a_sq - 2 * b_dot_a + pow(gn_norm, 2.0);
+        const double cc = b_dot_a - a_sq;
+        const double dd = sqrt(cc * cc + bma_sq * (pow(radius, 2.0) - a_sq));
+        const double beta = (cc <= 0) ? (dd - cc) / bma_sq : (radius * radius - a_sq) / (dd + cc);
+        cg = -alpha * (1.0 - beta); cn = beta; step_norm_scaled = 0; need_norm = true;
+    }
+    double sn = 0;
+    for (int i = t; i < n; i += 256) {
+        const double s = cg * gp[i] + cn * gnp[i];
+        sn += s * s;
+        dp[i] = s / Dp[i] * scp[i];
+    }
+    for (int l = l0 + t; l < l1; l += 256) {
+        const double s = cg * d.grad_l[l] + cn * d.gn_l[l];
+        sn += s * s;
+        const double dl = s / d.diag_l[l] * d.scale_l[l];
+        d.delta_l[l] = dl;
+        d.clam[l] = d.lam[l] + dl;
+    }
+    const double sn_tot = block_sum<256>(sn, red, t);
+    if (need_norm) step_norm_scaled = sqrt(sn_tot);
+    __syncthreads();
+    // candidate = Plus(x, delta); ambient step norm and |x|
+    double dn = 0, xn = 0;
+    for (int i = t; i < N; i += 256) {
+        const double *x = d.pose + ((size_t)w * N + i) * 7, *sb = d.sb + ((size_t)w * N + i) * 9;
+        double *xc = d.cpose + ((size_t)w * N + i) * 7, *sc = d.csb + ((size_t)w * N + i) * 9;
+        double xp[7];
+        pose_plus(x, dp + 15 * i, xp);
+        for (int k = 0; k < 7; k++) { xc[k] = xp[k]; const double df = x[k] - xp[k]; dn += df * df; xn += x[k] * x[k]; }
+        for (int k = 0; k < 9; k++) { const double v = sb[k] + dp[15 * i + 6 + k]; sc[k] = v; const double df = sb[k] - v; dn += df * df; xn += sb[k] * sb[k]; }
+    }
+    for (int l = l0 + t; l < l1; l += 256) { const double df = d.lam[l] - d.clam[l]; dn += df * df; xn += d.lam[l] * d.lam[l]; }
+    const double dn_tot = block_sum<256>(dn, red, t), xn_tot = block_sum<256>(xn, red, t);
+    if (t == 0) {
+        st.alpha = alpha; st.dogleg_step_norm = step_norm_scaled;
+        st.step_norm = sqrt(dn_tot); st.x_norm = sqrt(xn_tot);
+        st.step_valid = 1; st.iteration += 1; st.fresh = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// model cost change pieces: (J delta)^T (r + J delta / 2) per residual block, from the strips at x
+__global__ __launch_bounds__(256) void k_model_proj(DevBatch d) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= d.Ftot) return;
+    const FactorRec rec = d.f_rec[f];
+    int lo = 0, hi = d.B;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (d.f_off[mid] <= f) lo = mid; else hi = mid; }
+    const int w = lo;
+    const SolveState &st = d.st[w];
+    if (st.termination != ISV_TERM_RUNNING || !st.step_valid) return;
+    const double *s = d.strip + (size_t)f * ISV_PROJ_STRIP;
+    const double *dp = d.delta_p + (size_t)w * d.np;
+    const int fi = rec.ij & 255, fj = (rec.ij >> 8) & 255;
+    const double dl = d.delta_l[rec.lm];
+    double m0 = s[26] * dl, m1 = s[27] * dl;
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+        m0 += s[2 + c] * dp[15 * fi + c] + s[14 + c] * dp[15 * fj + c];
+        m1 += s[8 + c] * dp[15 * fi + c] + s[20 + c] * dp[15 * fj + c];
+    }
+    d.fmodel[f] = m0 * (s[0] + m0 / 2.0) + m1 * (s[1] + m1 / 2.0);
+}
+
+__global__ __launch_bounds__(64) void k_model_imu_prior(DevBatch d) {
+    __shared__ double sm[16];
+    const int w = blockIdx.x / (d.N - 1 + 1), q = blockIdx.x % (d.N - 1 + 1), t = threadIdx.x;
+    const SolveState &st = d.st[w];
+    if (st.termination != ISV_TERM_RUNNING || !st.step_valid) return;
+    const double *dp = d.delta_p + (size_t)w * d.np;
+    if (q < d.N - 1) {
+        const size_t f = (size_t)w * (d.N - 1) + q;
+        if (d.imu_skip[f]) { if (t == 0) d.imu_model[f] = 0.0; return; }
+        const double *s = d.imu_strip + f * ISV_IMU_STRIP;
+        if (t < 15) {
+            double m = 0;
+            const double *dd = dp + 15 * q;            // 30 contiguous tangent entries
+            for (int c = 0; c < 6; c++) m += s[15 + t * 6 + c] * dd[c];
+            for (int c = 0; c < 9; c++) m += s[105 + t * 9 + c] * dd[6 + c];
+            for (int c = 0; c < 6; c++) m += s[240 + t * 6 + c] * dd[15 + c];
+            for (int c = 0; c < 9; c++) m += s[330 + t * 9 + c] * dd[21 + c];
+            sm[t] = m * (s[t] + m / 2.0);
+        }
+        __syncthreads();
+        if (t == 0) { double a = 0; for (int k = 0; k < 15; k++) a += sm[k]; d.imu_model[f] = a; }
+    } else {
+        // priors of this window: lane per slot
+        const int slots = d.n_prior_slots;
+        if (t < slots) {
+            const double *ps = d.prior_strip + (size_t)w * d.prior_strip_sz;
+            double acc = 0;
+            if (t == 0) {
+                for (int r = 0; r < 6; r++) { double m = 0; for (int c = 0; c < 6; c++) m += ps[PR_SE3 + 6 + r * 6 + c] * dp[c]; acc += m * (ps[PR_SE3 + r] + m / 2.0); }
+            } else if (t == 1) {
+                const double *dd = dp + 15 * (d.Nvo - 1) + 6;
+                for (int r = 0; r < 9; r++) { double m = 0; for (int c = 0; c < 9; c++) m += ps[PR_LIN9 + 9 + r * 9 + c] * dd[c]; acc += m * (ps[PR_LIN9 + r] + m / 2.0); }
+            } else if (t < 1 + d.Nvo) {
+                const int k = t - 2; const double *o = ps + PR_REL0 + PR_REL_SZ * k;
+                for (int r = 0; r < 6; r++) {
+                    double m = 0;
+                    for (int c = 0; c < 6; c++) m += o[6 + r * 6 + c] * dp[15 * k + c] + o[42 + r * 6 + c] * dp[15 * (k + 1) + c];
+                    acc += m * (o[r] + m / 2.0);
+                }
+            } else {
+                const int mm = t - 1 - d.Nvo;
+                if (mm < d.n_rp[w]) {
+                    const double *o = ps + PR_REL0 + PR_REL_SZ * (d.Nvo - 1) + PR_RP_SZ * mm;
+                    const int idx = d.rollpitch[(size_t)w * d.max_rp + mm].index;
+                    for (int r = 0; r < 2; r++) { double m = 0; for (int c = 0; c < 6; c++) m += o[2 + r * 6 + c] * dp[15 * idx + c]; acc += m * (o[r] + m / 2.0); }
+                }
+            }
+            d.prior_model[(size_t)w * slots + t] = acc;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// TrustRegionMinimizer: step validity, tolerances, acceptance, DoglegStrategy radius/mu update.
+__global__ void k_step_control(DevBatch d) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= d.B) return;
+    SolveState &st = d.st[w];
+    if (st.termination != ISV_TERM_RUNNING) return;
+    const int it = st.iteration, N = d.N;
+    double *tc = d.trace_cost + (size_t)w * ISV_MAX_TRACE, *tr = d.trace_radius + (size_t)w * ISV_MAX_TRACE;
+    double *ts = d.trace_step + (size_t)w * ISV_MAX_TRACE; int32_t *ta = d.trace_acc + (size_t)w * ISV_MAX_TRACE;
+    const double model_cost_change = -d.model[w];
+    bool valid = st.step_valid && (model_cost_change > 0.0);
+    if (!valid) {                                       // HandleInvalidStep
+        st.invalid += 1;
+        if (st.invalid >= 5) { st.termination = st.ls_fail ? ISV_TERM_LINEAR_SOLVER : ISV_TERM_INVALID_STEPS; return; }
+        st.mu *= 10.0; st.reuse = 0; st.need_linearize = 1;     // StepIsInvalid: recompute the GN step with a larger mu
+        tc[it] = st.x_cost; tr[it] = st.radius; ts[it] = 0; ta[it] = 0;
+        if (it >= d.max_iter) st.termination = ISV_TERM_MAX_ITERATIONS;
+        return;
+    }
+    st.invalid = 0;
+    const double cand_cost = d.cost_c[w];
+    const double step_norm = st.step_norm;
+    if (step_norm <= 1e-8 * (st.x_norm + 1e-8)) {
+        st.termination = ISV_TERM_PARAMETER_TOL; tc[it] = st.x_cost; tr[it] = st.radius; ts[it] = step_norm; ta[it] = 0; return;
+    }
+    if (fabs(st.x_cost - cand_cost) <= 1e-6 * st.x_cost) {
+        st.termination = ISV_TERM_FUNCTION_TOL; tc[it] = st.x_cost; tr[it] = st.radius; ts[it] = step_norm; ta[it] = 0; return;
+    }
+    const double rel = (st.x_cost - cand_cost) / model_cost_change;
+    if (rel > 1e-3) {                                   // HandleSuccessfulStep
+        const int l0 = d.lm_off[w], l1 = d.lm_off[w + 1];
+        for (int i = 0; i < N * 7; i++) d.pose[(size_t)w * N * 7 + i] = d.cpose[(size_t)w * N * 7 + i];
+        for (int i = 0; i < N * 9; i++) d.sb[(size_t)w * N * 9 + i] = d.csb[(size_t)w * N * 9 + i];
+        for (int l = l0; l < l1; l++) d.lam[l] = d.clam[l];
+        st.x_cost = cand_cost;                           // refreshed by the next linearisation
+        if (rel < 0.25) st.radius *= 0.5;
+        if (rel > 0.75) st.radius = fmax(st.radius, 3.0 * st.dogleg_step_norm);
+        st.mu = fmax(1e-8, 2.0 * st.mu / 10.0);
+        st.reuse = 0; st.need_linearize = 1; st.num_successful += 1;
+        tc[it] = cand_cost; tr[it] = st.radius; ts[it] = step_norm; ta[it] = 1;
+    } else {                                            // StepRejected
+        st.radius *= 0.5; st.reuse = 1;
+        tc[it] = cand_cost; tr[it] = st.radius; ts[it] = step_norm; ta[it] = 0;
+    }
+    // FinalizeIterationAndCheckIfMinimizerCanContinue (gradient tolerance is checked by k_build_solve)
+    if (it >= d.max_iter) st.termination = ISV_TERM_MAX_ITERATIONS;
+    else if (st.radius <= 1e-32) st.termination = ISV_TERM_MIN_RADIUS;
+}
+
+// cost of candidate + model sum, per window (fixed-shape reduction)
+__global__ __launch_bounds__(256) void k_reduce_cand(DevBatch d) {
+    __shared__ double red[256];
+    const int w = blockIdx.x, t = threadIdx.x;
+    const SolveState &st = d.st[w];
+    if (st.termination != ISV_TERM_RUNNING || !st.step_valid) return;
+    double s = 0, m = 0;
+    for (int f = d.f_off[w] + t; f < d.f_off[w + 1]; f += 256) { s += d.fcost_c[f]; m += d.fmodel[f]; }
+    for (int i = t; i < d.N - 1; i += 256) { s += d.imu_cost_c[(size_t)w * (d.N - 1) + i]; m += d.imu_model[(size_t)w * (d.N - 1) + i]; }
+    for (int i = t; i < d.n_prior_slots; i += 256) { s += d.prior_cost_c[(size_t)w * d.n_prior_slots + i]; m += d.prior_model[(size_t)w * d.n_prior_slots + i]; }
+    const double S = block_sum<256>(s, red, t), M = block_sum<256>(m, red, t);
+    if (t == 0) { d.cost_c[w] = S; d.model[w] = M; }
+}
+
+// ------------------------------------------------------------------------------------------
+// after the solve: update() of every prior (estimator.cpp:1133-1144), then double2vector (:518-594)
+__global__ void k_finalize(DevBatch d) {
+    const int w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= d.B) return;
+    const int N = d.N, v = d.Nvo - 1;
+    const double *pose = d.pose + (size_t)w * N * 7, *sb = d.sb + (size_t)w * N * 9;
+    double *Ps = d.Ps + (size_t)w * N * 3, *Rs = d.Rs + (size_t)w * N * 9, *Vs = d.Vs + (size_t)w * N * 3;
+    double *Bas = d.Bas + (size_t)w * N * 3, *Bgs = d.Bgs + (size_t)w * N * 3;
+    // Linear9Factor::update  linear9_factor.h:60-68
+    {
+        isv_linear9_t &f = d.lin9[w];
+        for (int k = 0; k < 3; k++) {
+            f.VB[k] += sb[9 * v + k] - Vs[3 * v + k];
+            f.VB[3 + k] += sb[9 * v + 3 + k] - Bas[3 * v + k];
+            f.VB[6 + k] += sb[9 * v + 6 + k] - Bgs[3 * v + k];
+        }
+    }
+    // SE3PriorFactor::update  se3_prior_factor.h:73-81
+    {
+        isv_se3_prior_t &f = d.se3[w];
+        Quat R0 = q_from_R(Rs), R1 = q_normalized(q_from_pose(pose));
+        double dR[3], E[9], Rn[9];
+        so3_log(so3_mul(q_conj(R1), R0), dR);
+        for (int k = 0; k < 3; k++) f.t[k] += pose[k] - Ps[k];
+        q_to_R(so3_exp(dR), E); m3_mul(f.R, E, Rn);
+        for (int k = 0; k < 9; k++) f.R[k] = Rn[k];
+    }
+    // RelativePoseFactor::update (solver overload)  relative_pose_factor.h:103-117
+    for (int i = 0; i < d.Nvo - 1; i++) {
+        isv_relpose_t &f = d.relpose[(size_t)w * (d.Nvo - 1) + i];
+        const double *PSi = pose + 7 * i, *PSj = pose + 7 * (i + 1);
+        const double *ti = Ps + 3 * i, *tj = Ps + 3 * (i + 1), *Ri = Rs + 9 * i, *Rj = Rs + 9 * (i + 1);
+        Quat Qi = q_from_pose(PSi), Qj = q_from_pose(PSj);
+        double d_tj[3], d_ti[3], A[9], Bm[9], Qm[9];
+        for (int k = 0; k < 3; k++) { d_tj[k] = PSj[k] - tj[k]; d_ti[k] = PSi[k] - ti[k]; }
+        q_to_R(q_inv(Qj), Qm); m3_mul(Qm, Rj, A); Quat d_Rj = q_from_R(A);
+        q_to_R(q_inv(Qi), Qm); m3_mul(Qm, Ri, Bm); Quat d_Ri = q_from_R(Bm);
+        double lgi[3], lgj[3], v1[3], v2[3], S[9], v3[3];
+        so3_log(d_Ri, lgi); so3_log(d_Rj, lgj);
+        m3tv(Ri, d_tj, v1); m3tv(Ri, d_ti, v2);
+        skew3(f.delta_t, S); m3v(S, lgi, v3);
+        for (int k = 0; k < 3; k++) f.delta_t[k] += v1[k] - v2[k] + v3[k];
+        double Ji[9], ww[3], E[9], T[9];
+        q_to_R(q_mul(q_inv(Qj), Qi), Ji);
+        for (int k = 0; k < 9; k++) Ji[k] = -Ji[k];
+        m3v(Ji, lgi, ww);
+        q_to_R(so3_exp(ww), E); m3_mul(f.delta_R, E, T); for (int k = 0; k < 9; k++) f.delta_R[k] = T[k];
+        q_to_R(so3_exp(lgj), E); m3_mul(f.delta_R, E, T); for (int k = 0; k < 9; k++) f.delta_R[k] = T[k];
+    }
+    // RollPitchFactor::update  rollpitch_factor.h:78-83
+    for (int m = 0; m < d.n_rp[w]; m++) {
+        isv_rollpitch_t &f = d.rollpitch[(size_t)w * d.max_rp + m];
+        const int idx = f.index;
+        Quat R0 = q_from_R(Rs + 9 * idx), R1 = q_normalized(q_from_pose(pose + 7 * idx));
+        double dR[3], E[9], T[9];
+        so3_log(so3_mul(q_conj(R1), R0), dR);
+        q_to_R(so3_exp(dR), E); m3_mul(f.R, E, T); for (int k = 0; k < 9; k++) f.R[k] = T[k];
+    }
+    // ---- double2vector ------------------------------------------------------------------
+    double origin_R0[3], origin_P0[3], origin_R00[3], R00[9], rot_diff[9];
+    R2ypr(Rs, origin_R0);
+    for (int k = 0; k < 3; k++) origin_P0[k] = Ps[k];
+    q_to_R(q_from_pose(pose), R00);
+    R2ypr(R00, origin_R00);
+    const double y_diff = origin_R0[0] - origin_R00[0];
+    double ypr[3] = {y_diff, 0, 0};
+    ypr2R(ypr, rot_diff);
+    if (fabs(fabs(origin_R0[1]) - 90) < 1.0 || fabs(fabs(origin_R00[1]) - 90) < 1.0) m3_mul_nt(Rs, R00, rot_diff);
+    {
+        double tt[3], Rn[9];
+        m3v(rot_diff, d.lin9[w].VB + 6, tt); for (int k = 0; k < 3; k++) d.lin9[w].VB[6 + k] = tt[k];     // :549 (gyro-bias slot)
+        m3_mul(rot_diff, d.se3[w].R, Rn); for (int k = 0; k < 9; k++) d.se3[w].R[k] = Rn[k];               // :550
+    }
+    const double p0[3] = {pose[0], pose[1], pose[2]};
+    for (int i = 0; i < N; i++) {
+        double Ri[9], dd[3], tt[3], Ro[9];
+        q_to_R(q_normalized(q_from_pose(pose + 7 * i)), Ri);
+        m3_mul(rot_diff, Ri, Ro);
+        for (int k = 0; k < 9; k++) Rs[9 * i + k] = Ro[k];
+        for (int k = 0; k < 3; k++) dd[k] = pose[7 * i + k] - p0[k];
+        m3v(rot_diff, dd, tt);
+        for (int k = 0; k < 3; k++) Ps[3 * i + k] = tt[k] + origin_P0[k];
+        m3v(rot_diff, sb + 9 * i, tt);
+        for (int k = 0; k < 3; k++) { Vs[3 * i + k] = tt[k]; Bas[3 * i + k] = sb[9 * i + 3 + k]; Bgs[3 * i + k] = sb[9 * i + 6 + k]; }
+    }
+    const double *ex = d.ex + (size_t)w * 7;
+    for (int k = 0; k < 3; k++) d.tic[(size_t)w * 3 + k] = ex[k];
+    q_to_R(q_from_pose(ex), d.ric + (size_t)w * 9);
+    for (int l = d.lm_off[w]; l < d.lm_off[w + 1]; l++) {        // FeatureManager::setDepth :145-163
+        const double dep = 1.0 / d.lam[l];
+        d.depth[l] = dep;
+        d.solve_flag[l] = (dep < 0 || dep > 10) ? 2 : 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+#define HCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { err = std::string(#call) + ": " + hipGetErrorString(e_); return ISV_ERR_DEVICE; } } while (0)
+
+template <typename T>
+static int dal(T **p, size_t n, std::vector<void *> &allocs, std::string &err) {
+    void *q = nullptr;
+    HCHK(hipMalloc(&q, (n ? n : 1) * sizeof(T)));
+    allocs.push_back(q);
+    *p = (T *)q;
+    return ISV_OK;
+}
+#define TRYA(x) do { int rc_ = (x); if (rc_ != ISV_OK) return rc_; } while (0)
+
+int isv_solver_alloc(DevBatch &d, size_t B, size_t L, size_t F, std::vector<void *> &allocs, std::string &err) {
+    const size_t n = d.np, NI = B * (d.N - 1);
+    TRYA(dal(&d.scale_p, B * n, allocs, err)); TRYA(dal(&d.diag_p, B * n, allocs, err)); TRYA(dal(&d.grad_p, B * n, allocs, err));
+    TRYA(dal(&d.gn_p, B * n, allocs, err)); TRYA(dal(&d.delta_p, B * n, allocs, err)); TRYA(dal(&d.zp, B * n, allocs, err)); TRYA(dal(&d.up, B * n, allocs, err));
+    TRYA(dal(&d.lmE, L, allocs, err)); TRYA(dal(&d.lmG, L, allocs, err)); TRYA(dal(&d.scale_l, L, allocs, err)); TRYA(dal(&d.diag_l, L, allocs, err));
+    TRYA(dal(&d.grad_l, L, allocs, err)); TRYA(dal(&d.gn_l, L, allocs, err)); TRYA(dal(&d.delta_l, L, allocs, err)); TRYA(dal(&d.lm_aterm, L, allocs, err));
+    TRYA(dal(&d.fcost_c, F, allocs, err)); TRYA(dal(&d.imu_cost_c, NI, allocs, err)); TRYA(dal(&d.prior_cost_c, B * (size_t)d.n_prior_slots, allocs, err)); TRYA(dal(&d.cost_c, B, allocs, err));
+    TRYA(dal(&d.fmodel, F, allocs, err)); TRYA(dal(&d.imu_model, NI, allocs, err)); TRYA(dal(&d.prior_model, B * (size_t)d.n_prior_slots, allocs, err)); TRYA(dal(&d.model, B, allocs, err));
+    TRYA(dal(&d.trace_cost, B * ISV_MAX_TRACE, allocs, err)); TRYA(dal(&d.trace_radius, B * ISV_MAX_TRACE, allocs, err));
+    TRYA(dal(&d.trace_step, B * ISV_MAX_TRACE, allocs, err)); TRYA(dal(&d.trace_acc, B * ISV_MAX_TRACE, allocs, err));
+    TRYA(dal(&d.marg, B, allocs, err)); TRYA(dal(&d.margin_old, B, allocs, err)); TRYA(dal(&d.header0, B, allocs, err));
+    const size_t nblkT = (size_t)d.N * (d.N + 1) / 2 * 225;
+    d.lds_T = build_solve_lds_bytes(d.N, true) <= 160 * 1024 ? 1 : 0;
+    TRYA(dal(&d.Tglob, d.lds_T ? 1 : B * nblkT, allocs, err));
+    d.marg_scratch_sz = 0;
+    d.marg_scratch = nullptr;
+    if (d.lds_T) HCHK(hipFuncSetAttribute((const void *)k_build_solve<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)build_solve_lds_bytes(d.N, true)));
+    else HCHK(hipFuncSetAttribute((const void *)k_build_solve<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)build_solve_lds_bytes(d.N, false)));
+    return ISV_OK;
+}
+
+int isv_solver_enqueue(DevBatch &d, hipStream_t st, int64_t *counts, std::string &err) {
+    const size_t NI = (size_t)d.B * (d.N - 1);
+    const size_t lds_proj = 4 * proj_lds_doubles_per_wave(d.N) * sizeof(double);
+    const size_t lds_bs = build_solve_lds_bytes(d.N, d.lds_T);
+    hipLaunchKernelGGL(k_init_state, dim3((d.B + 63) / 64), dim3(64), 0, st, d);
+    for (int slot = 0; slot < d.max_iter; slot++) {
+        // linearise where needed (k_*_linearize skip windows whose need_linearize == 0 via the tile/window flags)
+        if (d.n_tiles > 0) { hipLaunchKernelGGL(k_proj_linearize<0>, dim3((d.n_tiles + 3) / 4), dim3(256), lds_proj, st, d, d.pose, d.lam, d.fcost, 1); counts[0]++; }
+        if (NI) hipLaunchKernelGGL(k_imu_linearize<true>, dim3((unsigned)NI), dim3(64), 0, st, d, d.pose, d.sb, d.imu_cost, 1);
+        hipLaunchKernelGGL(k_prior_linearize<true>, dim3((d.B * d.n_prior_slots + 63) / 64), dim3(64), 0, st, d, d.pose, d.sb, d.prior_cost, 1);
+        hipLaunchKernelGGL(k_cost_reduce, dim3(d.B), dim3(256), 0, st, d, d.fcost, d.imu_cost, d.prior_cost, d.cost, 1);
+        if (d.lds_T) hipLaunchKernelGGL(k_build_solve<true>, dim3(d.B), dim3(512), lds_bs, st, d);
+        else hipLaunchKernelGGL(k_build_solve<false>, dim3(d.B), dim3(512), lds_bs, st, d);
+        counts[1]++;
+        if (d.Ltot) hipLaunchKernelGGL(k_backsub, dim3((d.Ltot + 255) / 256), dim3(256), 0, st, d);
+        hipLaunchKernelGGL(k_dogleg, dim3(d.B), dim3(256), 0, st, d);
+        if (d.n_tiles > 0) hipLaunchKernelGGL(k_proj_linearize<1>, dim3((d.n_tiles + 3) / 4), dim3(256), lds_proj, st, d, d.cpose, d.clam, d.fcost_c, 2);
+        if (NI) hipLaunchKernelGGL(k_imu_linearize<false>, dim3((unsigned)NI), dim3(64), 0, st, d, d.cpose, d.csb, d.imu_cost_c, 2);
+        hipLaunchKernelGGL(k_prior_linearize<false>, dim3((d.B * d.n_prior_slots + 63) / 64), dim3(64), 0, st, d, d.cpose, d.csb, d.prior_cost_c, 2);
+        if (d.Ftot) hipLaunchKernelGGL(k_model_proj, dim3((d.Ftot + 255) / 256), dim3(256), 0, st, d);
+        hipLaunchKernelGGL(k_model_imu_prior, dim3(d.B * d.N), dim3(64), 0, st, d);
+        hipLaunchKernelGGL(k_reduce_cand, dim3(d.B), dim3(256), 0, st, d);
+        hipLaunchKernelGGL(k_step_control, dim3((d.B + 63) / 64), dim3(64), 0, st, d);
+    }
+    hipLaunchKernelGGL(k_finalize, dim3((d.B + 63) / 64), dim3(64), 0, st, d);
+    HCHK(hipGetLastError());
+    return ISV_OK;
+}
+
+int isv_solver_download(DevBatch &d, hipStream_t st, int n, isv_summary_t *summary, isv_marg_result_t *marg, std::string &err) {
+    if (!summary && !marg) return ISV_OK;
+    std::vector<SolveState> hs(n);
+    std::vector<double> tc((size_t)n * ISV_MAX_TRACE), tr((size_t)n * ISV_MAX_TRACE), ts((size_t)n * ISV_MAX_TRACE);
+    std::vector<int32_t> ta((size_t)n * ISV_MAX_TRACE);
+    HCHK(hipMemcpyAsync(hs.data(), d.st, sizeof(SolveState) * n, hipMemcpyDeviceToHost, st));
+    HCHK(hipMemcpyAsync(tc.data(), d.trace_cost, sizeof(double) * tc.size(), hipMemcpyDeviceToHost, st));
+    HCHK(hipMemcpyAsync(tr.data(), d.trace_radius, sizeof(double) * tr.size(), hipMemcpyDeviceToHost, st));
+    HCHK(hipMemcpyAsync(ts.data(), d.trace_step, sizeof(double) * ts.size(), hipMemcpyDeviceToHost, st));
+    HCHK(hipMemcpyAsync(ta.data(), d.trace_acc, sizeof(int32_t) * ta.size(), hipMemcpyDeviceToHost, st));
+    if (marg) HCHK(hipMemcpyAsync(marg, d.marg, sizeof(isv_marg_result_t) * n, hipMemcpyDeviceToHost, st));
+    HCHK(hipStreamSynchronize(st));
+    if (summary) {
+        for (int b = 0; b < n; b++) {
+            isv_summary_t &s = summary[b];
+            memset(&s, 0, sizeof(s));
+            s.status = ISV_OK; s.termination = hs[b].termination; s.iterations = hs[b].iteration; s.num_successful = hs[b].num_successful;
+            s.initial_cost = hs[b].initial_cost; s.final_cost = hs[b].x_cost;
+            memcpy(s.trace_cost, &tc[(size_t)b * ISV_MAX_TRACE], sizeof(s.trace_cost));
+            memcpy(s.trace_radius, &tr[(size_t)b * ISV_MAX_TRACE], sizeof(s.trace_radius));
+            memcpy(s.trace_step_norm, &ts[(size_t)b * ISV_MAX_TRACE], sizeof(s.trace_step_norm));
+            memcpy(s.trace_accepted, &ta[(size_t)b * ISV_MAX_TRACE], sizeof(s.trace_accepted));
+            if (!(s.final_cost - s.final_cost == 0.0)) s.status = ISV_ERR_NONFINITE;
+        }
+    }
+    return ISV_OK;
+}
+
+int isv_solver_debug_read(DevBatch &d, hipStream_t st, int what, double *out, int64_t count, std::string &err) {
+    const double *src = nullptr;
+    switch (what) {
+    case 10: src = d.gn_p; break;
+    case 11: src = d.gn_l; break;
+    case 12: src = d.grad_p; break;
+    case 13: src = d.grad_l; break;
+    case 14: src = d.scale_p; break;
+    case 15: src = d.scale_l; break;
+    case 16: src = d.diag_p; break;
+    case 17: src = d.delta_p; break;
+    case 18: src = d.delta_l; break;
+    case 19: src = d.cost_c; break;
+    case 20: src = d.model; break;
+    default: return ISV_ERR_INVALID_ARG;
+    }
+    HCHK(hipMemcpyAsync(out, src, sizeof(double) * count, hipMemcpyDeviceToHost, st));
+    HCHK(hipStreamSynchronize(st));
+    return ISV_OK;
+}
