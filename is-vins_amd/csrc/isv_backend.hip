@@ -34,6 +34,7 @@ struct isv_backend {
         double *Ps, *Rs, *Vs, *Bas, *Bgs, *tic, *ric, *depth, *lm_pts_i, *f_pts_j, *imu_in, *imu_cov;
         int32_t *lm_off, *f_off, *lm_host, *lm_k, *lm_f0, *tile_win, *tile_f0, *tile_n, *imu_skip, *n_rp, *solve_flag;
         FactorRec *f_rec;
+        uint32_t *lm_meta; int32_t *ck_off; int2 *ck_rec;
         isv_se3_prior_t *se3; isv_linear9_t *lin9; isv_relpose_t *relpose; isv_rollpitch_t *rollpitch;
         SolveState *st;
         double *pose, *sb, *ex, *lam;
@@ -113,6 +114,9 @@ static int create_impl(isv_backend *h) {
     TRY(dalloc(h, &d.imu_strip, NI * ISV_IMU_STRIP)); TRY(dalloc(h, &d.imu_cost, NI));
     TRY(dalloc(h, &d.prior_strip, B * (size_t)d.prior_strip_sz)); TRY(dalloc(h, &d.prior_cost, B * (size_t)d.n_prior_slots));
     TRY(dalloc(h, &d.cost, B)); TRY(dalloc(h, &d.st, B));
+    d.prior_H_sz = PH_REL0 + PH_REL_SZ * (c.n_vo - 1) + PH_RP_SZ * c.max_rollpitch;
+    TRY(dalloc(h, &d.imu_H, NI * ISV_IMU_H)); TRY(dalloc(h, &d.prior_H, B * (size_t)d.prior_H_sz));
+    TRY(dalloc(h, &d.lm_meta, L)); TRY(dalloc(h, &d.ck_off, B + 1)); TRY(dalloc(h, &d.ck_rec, L + B + 1));
     TRY(dalloc(h, &h->Ps0, B * N * 3)); TRY(dalloc(h, &h->Rs0, B * N * 9)); TRY(dalloc(h, &h->Vs0, B * N * 3));
     TRY(dalloc(h, &h->Bas0, B * N * 3)); TRY(dalloc(h, &h->Bgs0, B * N * 3)); TRY(dalloc(h, &h->depth0, L));
     TRY(dalloc(h, &h->se30, B)); TRY(dalloc(h, &h->lin90, B)); TRY(dalloc(h, &h->relpose0, B * (c.n_vo - 1))); TRY(dalloc(h, &h->rollpitch0, B * (size_t)c.max_rollpitch));
@@ -124,6 +128,7 @@ static int create_impl(isv_backend *h) {
     TRY(halloc(h, &s.lm_off, B + 1)); TRY(halloc(h, &s.f_off, B + 1)); TRY(halloc(h, &s.lm_host, L)); TRY(halloc(h, &s.lm_k, L)); TRY(halloc(h, &s.lm_f0, L));
     TRY(halloc(h, &s.tile_win, T)); TRY(halloc(h, &s.tile_f0, T)); TRY(halloc(h, &s.tile_n, T)); TRY(halloc(h, &s.imu_skip, NI)); TRY(halloc(h, &s.n_rp, B));
     TRY(halloc(h, &s.f_rec, F));
+    TRY(halloc(h, &s.lm_meta, L)); TRY(halloc(h, &s.ck_off, B + 1)); TRY(halloc(h, &s.ck_rec, L + B + 1));
     TRY(halloc(h, &s.se3, B)); TRY(halloc(h, &s.lin9, B)); TRY(halloc(h, &s.relpose, B * (c.n_vo - 1))); TRY(halloc(h, &s.rollpitch, B * (size_t)c.max_rollpitch));
     TRY(halloc(h, &s.st, B));
     TRY(halloc(h, &s.pose, B * N * 7)); TRY(halloc(h, &s.sb, B * N * 9)); TRY(halloc(h, &s.ex, B * 7)); TRY(halloc(h, &s.lam, L));
@@ -163,7 +168,7 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
     const isv_config_t &c = h->cfg;
     const int N = c.n_frames;
     auto &s = h->h;
-    size_t L = 0, F = 0, T = 0;
+    size_t L = 0, F = 0, T = 0, CK = 0;
     for (int b = 0; b < n; b++) {
         const isv_window_t *w = ws[b];
         if (!w || !w->Ps || !w->Rs || !w->Vs || !w->Bas || !w->Bgs || !w->tic || !w->ric || !w->imu || !w->pose_prior ||
@@ -171,7 +176,8 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
             (w->n_landmarks > 0 && (!w->lm_start_frame || !w->lm_obs_ptr || !w->obs_point || !w->lm_depth)))
             return ISV_ERR_INVALID_ARG;
         if (w->n_landmarks > c.max_landmarks || w->n_obs > c.max_obs || w->n_rollpitch > c.max_rollpitch) { h->err = "window exceeds capacity"; return ISV_ERR_CAPACITY; }
-        s.lm_off[b] = (int32_t)L; s.f_off[b] = (int32_t)F;
+        s.lm_off[b] = (int32_t)L; s.f_off[b] = (int32_t)F; s.ck_off[b] = (int32_t)CK;
+        size_t chunk_nf = 0; bool chunk_open = false;
         memcpy(s.Ps + (size_t)b * N * 3, w->Ps, sizeof(double) * N * 3); memcpy(s.Rs + (size_t)b * N * 9, w->Rs, sizeof(double) * N * 9);
         memcpy(s.Vs + (size_t)b * N * 3, w->Vs, sizeof(double) * N * 3); memcpy(s.Bas + (size_t)b * N * 3, w->Bas, sizeof(double) * N * 3);
         memcpy(s.Bgs + (size_t)b * N * 3, w->Bgs, sizeof(double) * N * 3);
@@ -181,6 +187,12 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
             const int hst = w->lm_start_frame[l], o0 = w->lm_obs_ptr[l], k = w->lm_obs_ptr[l + 1] - o0;
             if (hst < 0 || k < 2 || hst + k > N || o0 < 0 || o0 + k > w->n_obs) { h->err = "bad landmark track"; return ISV_ERR_INVALID_ARG; }
             s.lm_host[L] = hst; s.lm_k[L] = k; s.lm_f0[L] = (int32_t)F;
+            if (F - s.f_off[b] > 65535) { h->err = "more than 65535 factors in one window"; return ISV_ERR_CAPACITY; }
+            s.lm_meta[L] = (uint32_t)hst | ((uint32_t)k << 8) | ((uint32_t)(F - s.f_off[b]) << 16);
+            if (!chunk_open || chunk_nf + (k - 1) > 192) {     // chunks of whole landmarks, <= 192 factors (k_build_solve_lds CHB)
+                s.ck_rec[CK + b] = make_int2((int)L, (int)F); CK++; chunk_nf = 0; chunk_open = true;
+            }
+            chunk_nf += k - 1;
             s.depth[L] = w->lm_depth[l];
             memcpy(s.lm_pts_i + L * 3, w->obs_point + (size_t)o0 * 3, 24);
             for (int o = 1; o < k; o++) {
@@ -190,6 +202,8 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
             }
             L++;
         }
+        s.ck_rec[CK + b] = make_int2((int)L, (int)F);          // sentinel of window b
+        if (h->d.lds_T && CK - s.ck_off[b] > 64) { h->err = "window has more than 64 strip chunks"; return ISV_ERR_CAPACITY; }
         // tiles of <= 64 consecutive factors of this window
         for (size_t f = s.f_off[b]; f < F; f += ISV_TILE) {
             s.tile_win[T] = b; s.tile_f0[T] = (int32_t)f; s.tile_n[T] = (int32_t)((F - f) < ISV_TILE ? (F - f) : ISV_TILE); T++;
@@ -220,7 +234,7 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
         }
         s.n_rp[b] = w->n_rollpitch;
     }
-    s.lm_off[n] = (int32_t)L; s.f_off[n] = (int32_t)F;
+    s.lm_off[n] = (int32_t)L; s.f_off[n] = (int32_t)F; s.ck_off[n] = (int32_t)CK;
     DevBatch &d = h->d;
     d.B = n; d.Ltot = (int32_t)L; d.Ftot = (int32_t)F; d.n_tiles = (int32_t)T;
     hipStream_t st = h->stream;
@@ -231,6 +245,7 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
     H2D(d.depth, s.depth, L); H2D(d.lm_off, s.lm_off, n + 1); H2D(d.f_off, s.f_off, n + 1);
     H2D(d.lm_host, s.lm_host, L); H2D(d.lm_k, s.lm_k, L); H2D(d.lm_f0, s.lm_f0, L); H2D(d.lm_pts_i, s.lm_pts_i, L * 3);
     H2D(d.f_rec, s.f_rec, F); H2D(d.f_pts_j, s.f_pts_j, F * 2);
+    H2D(d.lm_meta, s.lm_meta, L); H2D(d.ck_off, s.ck_off, n + 1); H2D(d.ck_rec, s.ck_rec, CK + n);
     H2D(d.tile_win, s.tile_win, T); H2D(d.tile_f0, s.tile_f0, T); H2D(d.tile_n, s.tile_n, T);
     H2D(d.imu_in, s.imu_in, NI * ISV_IMU_IN); H2D(d.imu_cov, s.imu_cov, NI * 225); H2D(d.imu_skip, s.imu_skip, NI);
     H2D(d.se3, s.se3, n); H2D(d.lin9, s.lin9, n); H2D(d.relpose, s.relpose, (size_t)n * (c.n_vo - 1)); H2D(d.rollpitch, s.rollpitch, (size_t)n * c.max_rollpitch);

@@ -32,6 +32,11 @@ DEV int tblk(int I, int J) { return (I * (I + 1) / 2 + J) * 225; }
 // element (gi, gj) with gi >= gj of the block-packed lower triangle
 DEV int tidx(int gi, int gj) { return tblk(gi / 15, gj / 15) + (gi % 15) * 15 + (gj % 15); }
 
+#ifdef ISV_STAMP
+#define STAMP(k) do { if (t == 0) d.dbg[(size_t)w * 64 + (k)] += (double)(wall_clock64() - t_last); if (t == 0) t_last = wall_clock64(); } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
 #define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
 
 // accumulate J^T J (lower triangle) and J^T r of a staged dense Jacobian Jd[dim][ld] whose column c
@@ -92,12 +97,16 @@ __global__ __launch_bounds__(BS_THREADS) void k_build_solve(DevBatch d) {
     int ls_fail = 0;
     double gmax_l = 0.0;
 
+#ifdef ISV_STAMP
+    unsigned long long t_last = wall_clock64();
+#endif
     for (;;) {
         if (!(mu < 1.0)) { ls_fail = 1; break; }      // while (mu_ < max_mu_) of ComputeGaussNewtonStep
         for (int e = t; e < nblkT; e += BS_THREADS) T[e] = 0.0;
         for (int e = t; e < n; e += BS_THREADS) { g[e] = 0.0; bs[e] = 0.0; hdiag[e] = 0.0; }
         if (t == 0) flag[0] = 0;
         __syncthreads();
+        STAMP(0);
         // ---- P1: IMU factors (no loss) and prior factors, one after the other --------------
         for (int i = 0; i < N - 1; i++) {
             const size_t f = (size_t)w * (N - 1) + i;
@@ -143,6 +152,7 @@ __global__ __launch_bounds__(BS_THREADS) void k_build_solve(DevBatch d) {
                 __syncthreads();
             }
         }
+        STAMP(1);
         // ---- P2: reprojection factors, chunks of whole landmarks -----------------------------
         int lb = l0;
         while (lb < l1) {
@@ -158,6 +168,7 @@ __global__ __launch_bounds__(BS_THREADS) void k_build_solve(DevBatch d) {
                 for (int e = t; e < nf * ISV_PROJ_STRIP; e += BS_THREADS) sS[e] = src[e];
             }
             __syncthreads();
+            STAMP(8);
             // (a) per-landmark scalars + host-frame w, per-factor w
             for (int li = t; li < nlm; li += BS_THREADS) {
                 const int l = lb + li, k = d.lm_k[l], fo = d.lm_f0[l] - fb;
@@ -192,6 +203,7 @@ __global__ __launch_bounds__(BS_THREADS) void k_build_solve(DevBatch d) {
                 for (int c = 0; c < 6; c++) wo[c] = s[14 + c] * j0 + s[20 + c] * j1;
             }
             __syncthreads();
+            STAMP(9);
             // (b) owner-computes: wave wv owns block columns a = wv, wv + 8, ...
             for (int a = wv; a < N; a += BS_WAVES) {
                 for (int li = 0; li < nlm; li++) {
@@ -237,8 +249,10 @@ __global__ __launch_bounds__(BS_THREADS) void k_build_solve(DevBatch d) {
                 }
             }
             __syncthreads();
+            STAMP(10);
             lb = le;
         }
+        STAMP(2);
         // ---- P3: scaling, Cauchy data, reduced system -----------------------------------------
         for (int e = t; e < n; e += BS_THREADS) {
             double s;
@@ -266,6 +280,7 @@ __global__ __launch_bounds__(BS_THREADS) void k_build_solve(DevBatch d) {
             if (t == 0) st.qT = red[0];
             __syncthreads();
         }
+        STAMP(3);
         // scale in place, add the LM diagonal, form the rhs
         for (int e = t; e < nblkT; e += BS_THREADS) {
             // decode block-packed index
@@ -280,6 +295,7 @@ __global__ __launch_bounds__(BS_THREADS) void k_build_solve(DevBatch d) {
         }
         for (int e = t; e < n; e += BS_THREADS) y[e] = sc[e] * (g[e] + bs[e]);
         __syncthreads();
+        STAMP(4);
         // ---- blocked right-looking Cholesky (block = one frame, 15) -----------------------------
         for (int J = 0; J < N; J++) {
             double *Dj = T + tblk(J, J);
@@ -374,6 +390,7 @@ __global__ __launch_bounds__(BS_THREADS) void k_build_solve(DevBatch d) {
             __syncthreads();
             continue;
         }
+        STAMP(5);
         // ---- solve L L^T y = rhs, blocked with the diagonal-block inverses recomputed per block ---
         for (int J = 0; J < N; J++) {                 // forward
             const double *Dj = T + tblk(J, J);
@@ -418,6 +435,7 @@ __global__ __launch_bounds__(BS_THREADS) void k_build_solve(DevBatch d) {
             }
             __syncthreads();
         }
+        STAMP(6);
         break;
     }
     // ---- outputs --------------------------------------------------------------------------------

@@ -32,6 +32,13 @@
 #define PR_REL0 132
 #define PR_REL_SZ 78
 #define PR_RP_SZ 14
+// precomputed J^T J (lower-triangle pairs a>=b at a(a+1)/2+b) and J^T r of the non-visual factors
+#define ISV_IMU_H 495          // 30*31/2 pairs + 30
+#define PH_SE3 0               // 21 + 6
+#define PH_LIN9 27             // 45 + 9
+#define PH_REL0 81             // 78 + 12 each
+#define PH_REL_SZ 90
+#define PH_RP_SZ 27            // 21 + 6 each
 
 struct FactorRec { int32_t lm; int32_t ij; };   // global landmark index; frame_i | frame_j << 8
 
@@ -92,5 +99,12 @@ struct DevBatch {
     double *marg_scratch;               // [B][marg_scratch_sz]
     int32_t *margin_old;                // [B]
     double *header0;                    // [B]
+    double *dbg;                        // [B][64] diagnostic stamps (ISV_STAMP builds)
+    double *imu_H;                      // [B (N-1)][ISV_IMU_H]
+    double *prior_H;                    // [B][prior_H_sz]
+    uint32_t *lm_meta;                  // [Ltot] host | k << 8 | (first factor - f_off[w]) << 16
+    int32_t *ck_off;                    // [B+1] chunk CSR over windows (chunks of whole landmarks, <= 64 factors)
+    int2 *ck_rec;                       // [ck_off[B] + B] {first landmark, first factor} per chunk + sentinel per window
+    int32_t prior_H_sz, _pad2;
     int32_t marg_scratch_sz, lds_T;     // lds_T: reduced system lives in LDS (15N <= 165)
 };

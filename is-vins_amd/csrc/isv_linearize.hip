@@ -280,7 +280,7 @@ template __global__ void k_proj_linearize<1>(DevBatch, const double *, const dou
 template <bool JAC>
 __global__ __launch_bounds__(64) void k_imu_linearize(DevBatch d, const double *pose_src, const double *sb_src,
                                                        double *cost_out, int gate) {
-    __shared__ double sS[225], sRaw[15 * 31], sRes[16];
+    __shared__ double sS[225], sRaw[15 * 31], sRes[16], sJw[JAC ? 15 * 31 : 1];
     const int f = blockIdx.x, t = threadIdx.x;
     const int N = d.N, w = f / (N - 1), i = f % (N - 1);
     if (gate) {
@@ -364,7 +364,7 @@ __global__ __launch_bounds__(64) void k_imu_linearize(DevBatch d, const double *
         double s = 0;
         for (int k = 0; k < 15; k++) s += sS[t * 15 + k] * sRaw[k * 31 + 30];
         sRes[t] = s;
-        if (JAC) d.imu_strip[(size_t)f * ISV_IMU_STRIP + t] = s;
+        if (JAC) { d.imu_strip[(size_t)f * ISV_IMU_STRIP + t] = s; sJw[t * 31 + 30] = s; }
     }
     if (JAC) {
         // strip layout: [r15 | 15x6 | 15x9 | 15x6 | 15x9] row-major blocks
@@ -379,9 +379,22 @@ __global__ __launch_bounds__(64) void k_imu_linearize(DevBatch d, const double *
             double s = 0;
             for (int k = 0; k < 15; k++) s += sS[row * 15 + k] * sRaw[k * 31 + c];
             out[e] = s;
+            sJw[row * 31 + c] = s;
         }
     }
     __syncthreads();
+    if (JAC) {
+        // J^T J (pairs a >= b at a(a+1)/2 + b) and J^T r for k_build_solve: [465 | 30]
+        double *H = d.imu_H + (size_t)f * ISV_IMU_H;
+        for (int e = t; e < ISV_IMU_H; e += 64) {
+            int a, b;
+            if (e < 465) { a = 0; while ((a + 1) * (a + 2) / 2 <= e) a++; b = e - a * (a + 1) / 2; }
+            else { a = e - 465; b = 30; }
+            double s = 0;
+            for (int k = 0; k < 15; k++) s += sJw[k * 31 + a] * sJw[k * 31 + b];
+            H[e] = s;
+        }
+    }
     if (t == 0) {
         double s = 0;
         for (int k = 0; k < 15; k++) s += sRes[k] * sRes[k];
@@ -411,6 +424,28 @@ DEV double cauchy_correct(double *r, int dim, double *J, int nj, bool jac) {
     return 0.5 * log(sum);
 }
 
+// J^T J pairs (a >= b) and J^T r of a prior factor whose Jacobian is one or two row-major blocks of
+// width bw (J[blk][row][col]); ncol = nblk * bw
+DEV void prior_H_block(const double *J, const double *r, int dim, int nblk, int bw, double *H) {
+    const int ncol = nblk * bw;
+    int e = 0;
+    for (int a = 0; a < ncol; a++) {
+        const double *Ja = J + (a / bw) * dim * bw + (a % bw);
+        for (int b = 0; b <= a; b++) {
+            const double *Jb = J + (b / bw) * dim * bw + (b % bw);
+            double s = 0;
+            for (int k = 0; k < dim; k++) s += Ja[k * bw] * Jb[k * bw];
+            H[e++] = s;
+        }
+    }
+    for (int a = 0; a < ncol; a++) {
+        const double *Ja = J + (a / bw) * dim * bw + (a % bw);
+        double s = 0;
+        for (int k = 0; k < dim; k++) s += Ja[k * bw] * r[k];
+        H[e++] = s;
+    }
+}
+
 // One lane per prior factor: slot 0 = SE3 prior, 1 = Linear9, 2..Nvo = relative pose, then roll-pitch.
 template <bool JAC>
 __global__ void k_prior_linearize(DevBatch d, const double *pose_src, const double *sb_src, double *cost_out, int gate) {
@@ -423,6 +458,7 @@ __global__ void k_prior_linearize(DevBatch d, const double *pose_src, const doub
         if (!(ss.termination == ISV_TERM_RUNNING && (gate == 1 ? ss.need_linearize != 0 : ss.step_valid != 0))) return;
     }
     double *strip = d.prior_strip + (size_t)w * d.prior_strip_sz;
+    double *PH = d.prior_H + (size_t)w * d.prior_H_sz;
     const double *poseW = pose_src + (size_t)w * N * 7;
     double cost = 0.0;
     if (s == 0) {
@@ -445,7 +481,8 @@ __global__ void k_prior_linearize(DevBatch d, const double *pose_src, const doub
             mat_mul_small(f.sqrt_info, rawJ, J, 6, 6, 6);
         }
         cost = cauchy_correct(r, 6, J, 36, JAC);
-        if (JAC) { for (int k = 0; k < 6; k++) strip[PR_SE3 + k] = r[k]; for (int k = 0; k < 36; k++) strip[PR_SE3 + 6 + k] = J[k]; }
+        if (JAC) { for (int k = 0; k < 6; k++) strip[PR_SE3 + k] = r[k]; for (int k = 0; k < 36; k++) strip[PR_SE3 + 6 + k] = J[k];
+                   prior_H_block(J, r, 6, 1, 6, PH + PH_SE3); }
     } else if (s == 1) {
         // Linear9Factor::Evaluate  linear9_factor.h:20-44
         const isv_linear9_t &f = d.lin9[w];
@@ -455,7 +492,8 @@ __global__ void k_prior_linearize(DevBatch d, const double *pose_src, const doub
         mat_mul_small(f.sqrt_info, raw, r, 9, 9, 1);
         if (JAC) for (int k = 0; k < 81; k++) J[k] = f.sqrt_info[k];
         cost = cauchy_correct(r, 9, J, 81, JAC);
-        if (JAC) { for (int k = 0; k < 9; k++) strip[PR_LIN9 + k] = r[k]; for (int k = 0; k < 81; k++) strip[PR_LIN9 + 9 + k] = J[k]; }
+        if (JAC) { for (int k = 0; k < 9; k++) strip[PR_LIN9 + k] = r[k]; for (int k = 0; k < 81; k++) strip[PR_LIN9 + 9 + k] = J[k];
+                   prior_H_block(J, r, 9, 1, 9, PH + PH_LIN9); }
     } else if (s < 1 + d.Nvo) {
         // RelativePoseFactor::Evaluate  relative_pose_factor.h:27-70
         const int i = s - 2;
@@ -494,7 +532,8 @@ __global__ void k_prior_linearize(DevBatch d, const double *pose_src, const doub
         }
         cost = cauchy_correct(r, 6, J, 72, JAC);
         double *o = strip + PR_REL0 + PR_REL_SZ * i;
-        if (JAC) { for (int k = 0; k < 6; k++) o[k] = r[k]; for (int k = 0; k < 72; k++) o[6 + k] = J[k]; }
+        if (JAC) { for (int k = 0; k < 6; k++) o[k] = r[k]; for (int k = 0; k < 72; k++) o[6 + k] = J[k];
+                   prior_H_block(J, r, 6, 2, 6, PH + PH_REL0 + PH_REL_SZ * i); }
     } else {
         // RollPitchFactor::Evaluate  rollpitch_factor.h:26-57
         const int m = s - 1 - d.Nvo;
@@ -517,7 +556,8 @@ __global__ void k_prior_linearize(DevBatch d, const double *pose_src, const doub
                 mat_mul_small(f.sqrt_info, rawJ, J, 2, 2, 6);
             }
             cost = cauchy_correct(r, 2, J, 12, JAC);
-            if (JAC) { o[0] = r[0]; o[1] = r[1]; for (int k = 0; k < 12; k++) o[2 + k] = J[k]; }
+            if (JAC) { o[0] = r[0]; o[1] = r[1]; for (int k = 0; k < 12; k++) o[2 + k] = J[k];
+                       prior_H_block(J, r, 2, 1, 6, PH + PH_REL0 + PH_REL_SZ * (d.Nvo - 1) + PH_RP_SZ * m); }
         } else if (JAC) {
             for (int k = 0; k < PR_RP_SZ; k++) o[k] = 0.0;
         }

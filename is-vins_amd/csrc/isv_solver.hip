@@ -13,6 +13,8 @@
 #include "isv_device_math.h"
 
 extern size_t build_solve_lds_bytes(int N, bool lds_T);
+extern size_t build_solve_lds2_bytes(int N);
+__global__ void k_build_solve_lds(DevBatch d);
 template <bool LDS_T> __global__ void k_build_solve(DevBatch d);
 
 // ------------------------------------------------------------------------------------------
@@ -415,13 +417,15 @@ int isv_solver_alloc(DevBatch &d, size_t B, size_t L, size_t F, std::vector<void
     TRYA(dal(&d.fmodel, F, allocs, err)); TRYA(dal(&d.imu_model, NI, allocs, err)); TRYA(dal(&d.prior_model, B * (size_t)d.n_prior_slots, allocs, err)); TRYA(dal(&d.model, B, allocs, err));
     TRYA(dal(&d.trace_cost, B * ISV_MAX_TRACE, allocs, err)); TRYA(dal(&d.trace_radius, B * ISV_MAX_TRACE, allocs, err));
     TRYA(dal(&d.trace_step, B * ISV_MAX_TRACE, allocs, err)); TRYA(dal(&d.trace_acc, B * ISV_MAX_TRACE, allocs, err));
+    TRYA(dal(&d.dbg, B * 64, allocs, err));
+    HCHK(hipMemset(d.dbg, 0, B * 64 * sizeof(double)));
     TRYA(dal(&d.marg, B, allocs, err)); TRYA(dal(&d.margin_old, B, allocs, err)); TRYA(dal(&d.header0, B, allocs, err));
     const size_t nblkT = (size_t)d.N * (d.N + 1) / 2 * 225;
-    d.lds_T = build_solve_lds_bytes(d.N, true) <= 160 * 1024 ? 1 : 0;
+    d.lds_T = (d.N <= 11 && build_solve_lds2_bytes(d.N) <= 160 * 1024) ? 1 : 0;
     TRYA(dal(&d.Tglob, d.lds_T ? 1 : B * nblkT, allocs, err));
     d.marg_scratch_sz = 0;
     d.marg_scratch = nullptr;
-    if (d.lds_T) HCHK(hipFuncSetAttribute((const void *)k_build_solve<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)build_solve_lds_bytes(d.N, true)));
+    if (d.lds_T) HCHK(hipFuncSetAttribute((const void *)k_build_solve_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)build_solve_lds2_bytes(d.N)));
     else HCHK(hipFuncSetAttribute((const void *)k_build_solve<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)build_solve_lds_bytes(d.N, false)));
     return ISV_OK;
 }
@@ -429,7 +433,7 @@ int isv_solver_alloc(DevBatch &d, size_t B, size_t L, size_t F, std::vector<void
 int isv_solver_enqueue(DevBatch &d, hipStream_t st, int64_t *counts, std::string &err) {
     const size_t NI = (size_t)d.B * (d.N - 1);
     const size_t lds_proj = 4 * proj_lds_doubles_per_wave(d.N) * sizeof(double);
-    const size_t lds_bs = build_solve_lds_bytes(d.N, d.lds_T);
+    const size_t lds_bs = d.lds_T ? build_solve_lds2_bytes(d.N) : build_solve_lds_bytes(d.N, false);
     hipLaunchKernelGGL(k_init_state, dim3((d.B + 63) / 64), dim3(64), 0, st, d);
     for (int slot = 0; slot < d.max_iter; slot++) {
         // linearise where needed (k_*_linearize skip windows whose need_linearize == 0 via the tile/window flags)
@@ -437,7 +441,7 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, int64_t *counts, std::string
         if (NI) hipLaunchKernelGGL(k_imu_linearize<true>, dim3((unsigned)NI), dim3(64), 0, st, d, d.pose, d.sb, d.imu_cost, 1);
         hipLaunchKernelGGL(k_prior_linearize<true>, dim3((d.B * d.n_prior_slots + 63) / 64), dim3(64), 0, st, d, d.pose, d.sb, d.prior_cost, 1);
         hipLaunchKernelGGL(k_cost_reduce, dim3(d.B), dim3(256), 0, st, d, d.fcost, d.imu_cost, d.prior_cost, d.cost, 1);
-        if (d.lds_T) hipLaunchKernelGGL(k_build_solve<true>, dim3(d.B), dim3(512), lds_bs, st, d);
+        if (d.lds_T) hipLaunchKernelGGL(k_build_solve_lds, dim3(d.B), dim3(768), lds_bs, st, d);
         else hipLaunchKernelGGL(k_build_solve<false>, dim3(d.B), dim3(512), lds_bs, st, d);
         counts[1]++;
         if (d.Ltot) hipLaunchKernelGGL(k_backsub, dim3((d.Ltot + 255) / 256), dim3(256), 0, st, d);
@@ -497,6 +501,7 @@ int isv_solver_debug_read(DevBatch &d, hipStream_t st, int what, double *out, in
     case 18: src = d.delta_l; break;
     case 19: src = d.cost_c; break;
     case 20: src = d.model; break;
+    case 21: src = d.dbg; break;
     default: return ISV_ERR_INVALID_ARG;
     }
     HCHK(hipMemcpyAsync(out, src, sizeof(double) * count, hipMemcpyDeviceToHost, st));

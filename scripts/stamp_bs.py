@@ -1,0 +1,18 @@
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import isvins_loader; isvins_loader.load()
+from isvins_amd import backend, synth
+import numpy as np
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+ws = synth.make_windows(range(B))
+be = backend.Backend(11, 5, max_landmarks=300, max_obs=1600, max_batch=B)
+be.upload(ws)
+be.run_optimize()
+dbg = be.debug_read(21, B * 64).reshape(B, 64)
+names = {0: "zero", 1: "imu+prior", 2: "visual sweep", 3: "scale+qT", 4: "cholesky", 5: "solve", 6: "outputs", 10: "w4: phase a (to mid barrier)", 11: "w4: phase b", 12: "w4: wait top barrier", 13: "w4: pre-sweep"}
+tot = dbg[:, :7].sum(1)
+print("per build_solve call (us), median over windows; 10 calls/solve; wall_clock64 = 100 MHz")
+for k, nm in names.items():
+    print(f"  {nm:30s} {np.median(dbg[:, k]) / 10 / 100:8.1f} us")
+print("  total           ", np.median(tot) / 10 / 100)
