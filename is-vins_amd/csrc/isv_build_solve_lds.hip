@@ -98,10 +98,11 @@ __global__ __launch_bounds__(LT) void k_build_solve_lds(DevBatch d) {
     if (t == 0) flag[0] = 0;
     __syncthreads();
 
+    int attempt = 0;                           // attempt 0 consumes k_sweep's result; a mu retry re-sweeps in-kernel
     for (;;) {
         if (!(mu < 1.0)) { ls_fail = 1; break; }
         for (int e = t; e < n; e += LT) { g[e] = 0.0; bs[e] = 0.0; hdiag[e] = 0.0; }
-        // ---- P2: reprojection strips ------------------------------------------------------------
+        // ---- P2 (retry path only): reprojection strips -----------------------------------------------
         double acc[12], hd = 0, gacc = 0, bacc = 0;     // acc[6*step + c]: row (bo, r) of block column a
 #pragma unroll
         for (int i = 0; i < 12; i++) acc[i] = 0;
@@ -122,9 +123,10 @@ __global__ __launch_bounds__(LT) void k_build_solve_lds(DevBatch d) {
                 cSl[(c & 1) * CHB + li] = (iteration == 0) ? 0.0 : d.scale_l[r0.x + li];
             }
         };
-        if (loader && nchunks > 0) load_chunk(0);
+        const int nck = (attempt > 0) ? nchunks : 0;
+        if (loader && nck > 0) load_chunk(0);
         STAMPW(13);
-        for (int c = 0; c < nchunks; c++) {
+        for (int c = 0; c < nck; c++) {
             SYNC_LDS();                                        // chunk c staged; chunk c-1 fully consumed
             STAMPW(12);
             const int2 r0 = ckL[c], r1 = ckL[c + 1];
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(LT) void k_build_solve_lds(DevBatch d) {
             const double *sS = sS0 + (size_t)(c & 1) * CHB * 28;
             const unsigned *cMc = cM + (c & 1) * CHB;
             if (loader) {
-                if (c + 1 < nchunks) load_chunk(c + 1);        // streams while the others compute
+                if (c + 1 < nck) load_chunk(c + 1);            // streams while the others compute
             } else if (t < cnlm) {
                 // (a1) per-landmark scalars and the host-frame w
                 const unsigned m0 = cMc[t]; const int k = (m0 >> 8) & 255, fo = (int)(m0 >> 16) - cfb;
@@ -301,7 +303,24 @@ __global__ __launch_bounds__(LT) void k_build_solve_lds(DevBatch d) {
                 __syncthreads();
             }
         }
-        if (a < N) {
+        if (attempt == 0) {
+            // reprojection part from k_sweep (6x6 pose corners of every block, owner = this thread)
+            const double *V = d.Tvis + (size_t)w * d.tvis_sz;
+            const int nblk36 = N * (N + 1) / 2 * 36;
+            for (int e = t; e < nblk36; e += LT) {
+                const int q = e / 36, rc = e - 36 * q, r = rc / 6, c = rc - 6 * r;
+                int ca = 0;
+                while (ca + 1 < N && (ca + 1) * N - (ca + 1) * ca / 2 <= q) ca++;
+                const int bo = q - (ca * N - ca * (ca - 1) / 2);
+                if (bo > 0 || c <= r) T[tblk(ca + bo, ca) + r * 15 + c] += V[e];
+            }
+            for (int e = t; e < 6 * N; e += LT) {
+                const int fa = e / 6, r = e - 6 * fa;
+                hdiag[15 * fa + r] += V[nblk36 + e]; g[15 * fa + r] += V[nblk36 + 6 * N + e]; bs[15 * fa + r] += V[nblk36 + 12 * N + e];
+            }
+            const int l0 = d.lm_off[w], l1 = d.lm_off[w + 1];
+            for (int l = l0 + t; l < l1; l += LT) gmax_l = fmax(gmax_l, fabs(d.lmG[l]));
+        } else if (a < N) {
 #pragma unroll
             for (int step = 0; step < 2; step++) {
                 const int ll = lane + 64 * step, bo = ll / 6, r = ll - 6 * bo;
@@ -430,7 +449,7 @@ __global__ __launch_bounds__(LT) void k_build_solve_lds(DevBatch d) {
         }
         STAMP(4);
         if (flag[0]) {
-            mu *= 10.0;
+            mu *= 10.0; attempt++;
             __syncthreads();
             if (t == 0) flag[0] = 0;
             __syncthreads();

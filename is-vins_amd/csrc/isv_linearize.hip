@@ -246,6 +246,12 @@ __global__ __launch_bounds__(256) void k_proj_linearize(DevBatch d, const double
             Jl[0] *= sc; Jl[1] *= sc;
         }
         fcost_out[f] = cost;
+        if (MODE == 0) {
+            // w of the observing frame for the Schur sweep: J_pose_j^T J_lambda (6), obs slot f + lm + 1
+            double *wo = d.W + (size_t)(f + rec.lm + 1) * 6;
+#pragma unroll
+            for (int c2 = 0; c2 < 6; c2++) wo[c2] = Jj[c2] * Jl[0] + Jj[6 + c2] * Jl[1];
+        }
     }
     if (MODE != 0) return;                            // uniform over the block
     // transpose through LDS: lane l owns row l of sOut[64][TILE_LD]

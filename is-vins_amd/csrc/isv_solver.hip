@@ -15,6 +15,9 @@
 extern size_t build_solve_lds_bytes(int N, bool lds_T);
 extern size_t build_solve_lds2_bytes(int N);
 __global__ void k_build_solve_lds(DevBatch d);
+__global__ void k_lm_prep(DevBatch d);
+__global__ void k_sweep(DevBatch d);
+__global__ void k_backsub(DevBatch d);
 template <bool LDS_T> __global__ void k_build_solve(DevBatch d);
 
 // ------------------------------------------------------------------------------------------
@@ -29,45 +32,6 @@ __global__ void k_init_state(DevBatch d) {
         d.trace_cost[(size_t)w * ISV_MAX_TRACE + k] = 0; d.trace_radius[(size_t)w * ISV_MAX_TRACE + k] = 0;
         d.trace_step[(size_t)w * ISV_MAX_TRACE + k] = 0; d.trace_acc[(size_t)w * ISV_MAX_TRACE + k] = 0;
     }
-}
-
-// ------------------------------------------------------------------------------------------
-// back-substitution of the eliminated landmarks (schur_eliminator BackSubstitute) + the landmark
-// terms of the Cauchy-point denominator.  One lane per landmark, batch wide.
-__global__ __launch_bounds__(256) void k_backsub(DevBatch d) {
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= d.Ltot) return;
-    // window of this landmark: binary search in lm_off
-    int lo = 0, hi = d.B;
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (d.lm_off[mid] <= l) lo = mid; else hi = mid; }
-    const int w = lo;
-    const SolveState &st = d.st[w];
-    if (st.termination != ISV_TERM_RUNNING || !st.fresh || st.ls_fail) return;
-    const int n = d.np, h = d.lm_host[l], k = d.lm_k[l], f0 = d.lm_f0[l];
-    const double *zp = d.zp + (size_t)w * n, *up = d.up + (size_t)w * n;
-    double wz = 0, wu = 0;        // w_l^T z_p, w_l^T u_p
-    double wh[6] = {0, 0, 0, 0, 0, 0};
-    for (int m = 0; m < k - 1; m++) {
-        const double *s = d.strip + (size_t)(f0 + m) * ISV_PROJ_STRIP;
-        const double j0 = s[26], j1 = s[27];
-        const int fj = h + m + 1;
-#pragma unroll
-        for (int c = 0; c < 6; c++) {
-            wh[c] += s[2 + c] * j0 + s[8 + c] * j1;
-            const double wj = s[14 + c] * j0 + s[20 + c] * j1;
-            wz += wj * zp[15 * fj + c]; wu += wj * up[15 * fj + c];
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < 6; c++) { wz += wh[c] * zp[15 * h + c]; wu += wh[c] * up[15 * h + c]; }
-    const double sl = d.scale_l[l], E = d.lmE[l], gl = d.lmG[l], Dl = d.diag_l[l];
-    const double Es = sl * sl * E, Dl2 = Dl * Dl;
-    // scaled-space y_l = (g'_l - w'_l^T y_p) / (E'_l + mu D_l^2),  w'^T y_p = s_l w^T (Sc_p y_p) = s_l wz
-    const double yl = (sl * gl - sl * wz) / (Es + st.mu * Dl2);
-    d.gn_l[l] = -Dl * yl;
-    // |J u|^2 landmark terms with u_l = s_l^2 g_l / D_l^2 and c_l = s_l^2 / (E' + mu D_l^2)
-    const double ul = sl * sl * gl / Dl2, cl = sl * sl / (Es + st.mu * Dl2);
-    d.lm_aterm[l] = cl * wu * wu + 2.0 * ul * wu + E * ul * ul;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -417,6 +381,8 @@ int isv_solver_alloc(DevBatch &d, size_t B, size_t L, size_t F, std::vector<void
     TRYA(dal(&d.fmodel, F, allocs, err)); TRYA(dal(&d.imu_model, NI, allocs, err)); TRYA(dal(&d.prior_model, B * (size_t)d.n_prior_slots, allocs, err)); TRYA(dal(&d.model, B, allocs, err));
     TRYA(dal(&d.trace_cost, B * ISV_MAX_TRACE, allocs, err)); TRYA(dal(&d.trace_radius, B * ISV_MAX_TRACE, allocs, err));
     TRYA(dal(&d.trace_step, B * ISV_MAX_TRACE, allocs, err)); TRYA(dal(&d.trace_acc, B * ISV_MAX_TRACE, allocs, err));
+    d.tvis_sz = 36 * (d.N * (d.N + 1) / 2) + 18 * d.N;
+    TRYA(dal(&d.W, (F + L) * 6, allocs, err)); TRYA(dal(&d.lm_cg, L, allocs, err)); TRYA(dal(&d.Tvis, B * (size_t)d.tvis_sz, allocs, err));
     TRYA(dal(&d.dbg, B * 64, allocs, err));
     HCHK(hipMemset(d.dbg, 0, B * 64 * sizeof(double)));
     TRYA(dal(&d.marg, B, allocs, err)); TRYA(dal(&d.margin_old, B, allocs, err)); TRYA(dal(&d.header0, B, allocs, err));
@@ -441,6 +407,8 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, int64_t *counts, std::string
         if (NI) hipLaunchKernelGGL(k_imu_linearize<true>, dim3((unsigned)NI), dim3(64), 0, st, d, d.pose, d.sb, d.imu_cost, 1);
         hipLaunchKernelGGL(k_prior_linearize<true>, dim3((d.B * d.n_prior_slots + 63) / 64), dim3(64), 0, st, d, d.pose, d.sb, d.prior_cost, 1);
         hipLaunchKernelGGL(k_cost_reduce, dim3(d.B), dim3(256), 0, st, d, d.fcost, d.imu_cost, d.prior_cost, d.cost, 1);
+        if (d.Ltot) hipLaunchKernelGGL(k_lm_prep, dim3((d.Ltot + 255) / 256), dim3(256), 0, st, d);
+        if (d.lds_T) hipLaunchKernelGGL(k_sweep, dim3(d.B, d.N), dim3(64), 0, st, d);
         if (d.lds_T) hipLaunchKernelGGL(k_build_solve_lds, dim3(d.B), dim3(768), lds_bs, st, d);
         else hipLaunchKernelGGL(k_build_solve<false>, dim3(d.B), dim3(512), lds_bs, st, d);
         counts[1]++;
