@@ -34,7 +34,7 @@ struct isv_backend {
         double *Ps, *Rs, *Vs, *Bas, *Bgs, *tic, *ric, *depth, *lm_pts_i, *f_pts_j, *imu_in, *imu_cov;
         int32_t *lm_off, *f_off, *lm_host, *lm_k, *lm_f0, *tile_win, *tile_f0, *tile_n, *imu_skip, *n_rp, *solve_flag;
         FactorRec *f_rec;
-        uint32_t *lm_meta; int32_t *ck_off; int2 *ck_rec;
+        uint32_t *lm_meta; int32_t *ck_off; int2 *ck_rec; int32_t *margin_old; double *header0;
         isv_se3_prior_t *se3; isv_linear9_t *lin9; isv_relpose_t *relpose; isv_rollpitch_t *rollpitch;
         SolveState *st;
         double *pose, *sb, *ex, *lam;
@@ -128,6 +128,7 @@ static int create_impl(isv_backend *h) {
     TRY(halloc(h, &s.lm_off, B + 1)); TRY(halloc(h, &s.f_off, B + 1)); TRY(halloc(h, &s.lm_host, L)); TRY(halloc(h, &s.lm_k, L)); TRY(halloc(h, &s.lm_f0, L));
     TRY(halloc(h, &s.tile_win, T)); TRY(halloc(h, &s.tile_f0, T)); TRY(halloc(h, &s.tile_n, T)); TRY(halloc(h, &s.imu_skip, NI)); TRY(halloc(h, &s.n_rp, B));
     TRY(halloc(h, &s.f_rec, F));
+    TRY(halloc(h, &s.margin_old, B)); TRY(halloc(h, &s.header0, B));
     TRY(halloc(h, &s.lm_meta, L)); TRY(halloc(h, &s.ck_off, B + 1)); TRY(halloc(h, &s.ck_rec, L + B + 1));
     TRY(halloc(h, &s.se3, B)); TRY(halloc(h, &s.lin9, B)); TRY(halloc(h, &s.relpose, B * (c.n_vo - 1))); TRY(halloc(h, &s.rollpitch, B * (size_t)c.max_rollpitch));
     TRY(halloc(h, &s.st, B));
@@ -233,6 +234,7 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
             } else memset(&s.rollpitch[(size_t)b * c.max_rollpitch + i], 0, sizeof(isv_rollpitch_t));
         }
         s.n_rp[b] = w->n_rollpitch;
+        s.margin_old[b] = w->margin_old != 0; s.header0[b] = w->header0;
     }
     s.lm_off[n] = (int32_t)L; s.f_off[n] = (int32_t)F; s.ck_off[n] = (int32_t)CK;
     DevBatch &d = h->d;
@@ -249,7 +251,7 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
     H2D(d.tile_win, s.tile_win, T); H2D(d.tile_f0, s.tile_f0, T); H2D(d.tile_n, s.tile_n, T);
     H2D(d.imu_in, s.imu_in, NI * ISV_IMU_IN); H2D(d.imu_cov, s.imu_cov, NI * 225); H2D(d.imu_skip, s.imu_skip, NI);
     H2D(d.se3, s.se3, n); H2D(d.lin9, s.lin9, n); H2D(d.relpose, s.relpose, (size_t)n * (c.n_vo - 1)); H2D(d.rollpitch, s.rollpitch, (size_t)n * c.max_rollpitch);
-    H2D(d.n_rp, s.n_rp, n);
+    H2D(d.n_rp, s.n_rp, n); H2D(d.margin_old, s.margin_old, n); H2D(d.header0, s.header0, n);
 #undef H2D
 #define D2D(dst, src, cnt) HIPCHK(h, hipMemcpyAsync(dst, src, sizeof(*(src)) * (size_t)(cnt), hipMemcpyDeviceToDevice, st))
     D2D(h->Ps0, d.Ps, (size_t)n * N * 3); D2D(h->Rs0, d.Rs, (size_t)n * N * 9); D2D(h->Vs0, d.Vs, (size_t)n * N * 3);

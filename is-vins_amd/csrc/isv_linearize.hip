@@ -106,77 +106,7 @@ __global__ __launch_bounds__(64) void k_imu_prep(DevBatch d) {
 #pragma clang fp contract(fast)
 
 // ------------------------------------------------------------------------------------------
-// Reprojection factor geometry for one lane.  R*/P* come from LDS (staged per wave).
-template <bool JAC>
-DEV void proj_factor(const double *Ri, const double *Pi, const double *Rj, const double *Pj,
-                     const double *ric, const double *tic, const double *sq, double lam,
-                     double pix, double piy, double piz, double pjx, double pjy,
-                     double &r0, double &r1, double *Ji, double *Jj, double *Jl) {
-    double inv = 1.0 / lam;
-    double pc[3] = {pix * inv, piy * inv, piz * inv};           // pts_camera_i = pts_i / inv_dep_i
-    double pb[3], pw[3], t[3], pbj[3], pcj[3];
-    m3v(ric, pc, pb); pb[0] += tic[0]; pb[1] += tic[1]; pb[2] += tic[2];     // pts_imu_i
-    m3v(Ri, pb, pw);
-    t[0] = pw[0] + Pi[0] - Pj[0]; t[1] = pw[1] + Pi[1] - Pj[1]; t[2] = pw[2] + Pi[2] - Pj[2];
-    m3tv(Rj, t, pbj);                                                        // pts_imu_j
-    t[0] = pbj[0] - tic[0]; t[1] = pbj[1] - tic[1]; t[2] = pbj[2] - tic[2];
-    m3tv(ric, t, pcj);                                                       // pts_camera_j
-    double idep = 1.0 / pcj[2];
-    double u0 = pcj[0] * idep - pjx, u1 = pcj[1] * idep - pjy;
-    r0 = sq[0] * u0 + sq[1] * u1;
-    r1 = sq[2] * u0 + sq[3] * u1;
-    if (!JAC) return;
-    // reduce = sqrt_info * [[1/z, 0, -x/z^2],[0, 1/z, -y/z^2]]
-    double a0 = idep, a2 = -pcj[0] * idep * idep, b2 = -pcj[1] * idep * idep;
-    double red[6] = {sq[0] * a0, sq[1] * a0, sq[0] * a2 + sq[1] * b2,
-                     sq[2] * a0, sq[3] * a0, sq[2] * a2 + sq[3] * b2};
-    double A[9], RA[6];
-    // A := ric^T * Rj^T
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++) A[i * 3 + j] = ric[i] * Rj[j * 3] + ric[3 + i] * Rj[j * 3 + 1] + ric[6 + i] * Rj[j * 3 + 2];
-    // RA = reduce * A   (2x3)
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++) RA[i * 3 + j] = red[i * 3] * A[j] + red[i * 3 + 1] * A[3 + j] + red[i * 3 + 2] * A[6 + j];
-    // J_pose_i = [RA, -RA Ri [pts_imu_i]x]
-    double RB[6];                          // RA * Ri
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++) RB[i * 3 + j] = RA[i * 3] * Ri[j] + RA[i * 3 + 1] * Ri[3 + j] + RA[i * 3 + 2] * Ri[6 + j];
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        Ji[i * 6 + 0] = RA[i * 3 + 0]; Ji[i * 6 + 1] = RA[i * 3 + 1]; Ji[i * 6 + 2] = RA[i * 3 + 2];
-        // -(row) * skew(pb): row*S = [r1*pb2 - r2*pb1, r2*pb0 - r0*pb2, r0*pb1 - r1*pb0]
-        double x = RB[i * 3], y = RB[i * 3 + 1], z = RB[i * 3 + 2];
-        Ji[i * 6 + 3] = -(y * pb[2] - z * pb[1]);
-        Ji[i * 6 + 4] = -(z * pb[0] - x * pb[2]);
-        Ji[i * 6 + 5] = -(x * pb[1] - y * pb[0]);
-    }
-    // J_pose_j = [-RA, reduce ric^T [pts_imu_j]x]
-    double RC[6];                          // reduce * ric^T
-#pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++) RC[i * 3 + j] = red[i * 3] * ric[j * 3] + red[i * 3 + 1] * ric[j * 3 + 1] + red[i * 3 + 2] * ric[j * 3 + 2];
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-        Jj[i * 6 + 0] = -RA[i * 3 + 0]; Jj[i * 6 + 1] = -RA[i * 3 + 1]; Jj[i * 6 + 2] = -RA[i * 3 + 2];
-        double x = RC[i * 3], y = RC[i * 3 + 1], z = RC[i * 3 + 2];
-        Jj[i * 6 + 3] = y * pbj[2] - z * pbj[1];
-        Jj[i * 6 + 4] = z * pbj[0] - x * pbj[2];
-        Jj[i * 6 + 5] = x * pbj[1] - y * pbj[0];
-    }
-    // J_lambda = reduce ric^T Rj^T Ri ric pts_i * -1/lambda^2 = RB * (ric * pts_i) * -inv^2
-    double v[3] = {ric[0] * pix + ric[1] * piy + ric[2] * piz, ric[3] * pix + ric[4] * piy + ric[5] * piz,
-                   ric[6] * pix + ric[7] * piy + ric[8] * piz};
-    double s = -inv * inv;
-    Jl[0] = (RB[0] * v[0] + RB[1] * v[1] + RB[2] * v[2]) * s;
-    Jl[1] = (RB[3] * v[0] + RB[4] * v[1] + RB[5] * v[2]) * s;
-}
+#include "isv_proj_factor.h"
 
 #define TILE_LD 30     // padded strip row in LDS (doubles): 16-B aligned pairs for ds_read_b128
 
@@ -246,6 +176,19 @@ __global__ __launch_bounds__(256) void k_proj_linearize(DevBatch d, const double
             Jl[0] *= sc; Jl[1] *= sc;
         }
         fcost_out[f] = cost;
+        if (MODE == 1) {
+            // model cost change piece (J delta)^T (r + J delta / 2) from this factor's strip at x
+            const double *sx = d.strip + (size_t)f * ISV_PROJ_STRIP;
+            const double *dp = d.delta_p + (size_t)win * d.np;
+            const double dl = d.delta_l[rec.lm];
+            double m0 = sx[26] * dl, m1 = sx[27] * dl;
+#pragma unroll
+            for (int c2 = 0; c2 < 6; c2++) {
+                m0 += sx[2 + c2] * dp[15 * fi + c2] + sx[14 + c2] * dp[15 * fj + c2];
+                m1 += sx[8 + c2] * dp[15 * fi + c2] + sx[20 + c2] * dp[15 * fj + c2];
+            }
+            d.fmodel[f] = m0 * (sx[0] + m0 / 2.0) + m1 * (sx[1] + m1 / 2.0);
+        }
         if (MODE == 0) {
             // w of the observing frame for the Schur sweep: J_pose_j^T J_lambda (6), obs slot f + lm + 1
             double *wo = d.W + (size_t)(f + rec.lm + 1) * 6;
@@ -300,53 +243,61 @@ __global__ __launch_bounds__(64) void k_imu_linearize(DevBatch d, const double *
     for (int e = t; e < 225; e += 64) sS[e] = d.imu_sqrt[(size_t)f * 225 + e];
     for (int e = t; e < 15 * 31; e += 64) sRaw[e] = 0.0;
     __syncthreads();
-    if (t == 0) {
-        // IntegrationBase::evaluate  integration_base.h:160-186 (raw residual -> column 30 of sRaw)
+    if (t < (JAC ? 4 : 1)) {
+        // lanes 0..3 split the raw factor: 0 = residual (IntegrationBase::evaluate, integration_base.h:160-186),
+        // 1 = d/d pose_i, 2 = d/d speedbias_i, 3 = d/d pose_j and speedbias_j (imu_factor.h:66-155).
         Quat Qi = q_from_pose(pi), Qj = q_from_pose(pj);
         Quat Qii = q_inv(Qi);
         const double dt = rec[IMU_DT];
-        double dba[3], dbg[3], tt[3], t2[3];
-        for (int k = 0; k < 3; k++) { dba[k] = si[3 + k] - rec[IMU_LBA + k]; dbg[k] = si[6 + k] - rec[IMU_LBG + k]; }
+        double dbg[3], tt[3], t2[3];
+        for (int k = 0; k < 3; k++) dbg[k] = si[6 + k] - rec[IMU_LBG + k];
         Quat dq = Quat{rec[IMU_DQ + 3], rec[IMU_DQ], rec[IMU_DQ + 1], rec[IMU_DQ + 2]};
         m3v(rec + IMU_DQ_DBG, dbg, tt);
         Quat cdq = q_mul(dq, q_delta(tt));
-        double cdv[3], cdp[3];
-        m3v(rec + IMU_DV_DBA, dba, tt); m3v(rec + IMU_DV_DBG, dbg, t2);
-        for (int k = 0; k < 3; k++) cdv[k] = rec[IMU_DV + k] + tt[k] + t2[k];
-        m3v(rec + IMU_DP_DBA, dba, tt); m3v(rec + IMU_DP_DBG, dbg, t2);
-        for (int k = 0; k < 3; k++) cdp[k] = rec[IMU_DP + k] + tt[k] + t2[k];
-        double u[3], o1[3], o2[3];
-        for (int k = 0; k < 3; k++) u[k] = 0.5 * d.G[k] * dt * dt + pj[k] - pi[k] - si[k] * dt;
-        q_rot(Qii, u, o1);
-        for (int k = 0; k < 3; k++) sRaw[k * 31 + 30] = o1[k] - cdp[k];
-        Quat e = q_mul(q_inv(cdq), q_mul(Qii, Qj));
-        sRaw[3 * 31 + 30] = 2 * e.x; sRaw[4 * 31 + 30] = 2 * e.y; sRaw[5 * 31 + 30] = 2 * e.z;
-        for (int k = 0; k < 3; k++) u[k] = d.G[k] * dt + sj[k] - si[k];
-        q_rot(Qii, u, o2);
-        for (int k = 0; k < 3; k++) sRaw[(6 + k) * 31 + 30] = o2[k] - cdv[k];
-        for (int k = 0; k < 3; k++) { sRaw[(9 + k) * 31 + 30] = sj[3 + k] - si[3 + k]; sRaw[(12 + k) * 31 + 30] = sj[6 + k] - si[6 + k]; }
-        if (JAC) {
+        if (t == 0) {
+            double dba[3], cdv[3], cdp[3], u[3], o1[3], o2[3];
+            for (int k = 0; k < 3; k++) dba[k] = si[3 + k] - rec[IMU_LBA + k];
+            m3v(rec + IMU_DV_DBA, dba, tt); m3v(rec + IMU_DV_DBG, dbg, t2);
+            for (int k = 0; k < 3; k++) cdv[k] = rec[IMU_DV + k] + tt[k] + t2[k];
+            m3v(rec + IMU_DP_DBA, dba, tt); m3v(rec + IMU_DP_DBG, dbg, t2);
+            for (int k = 0; k < 3; k++) cdp[k] = rec[IMU_DP + k] + tt[k] + t2[k];
+            for (int k = 0; k < 3; k++) u[k] = 0.5 * d.G[k] * dt * dt + pj[k] - pi[k] - si[k] * dt;
+            q_rot(Qii, u, o1);
+            for (int k = 0; k < 3; k++) sRaw[k * 31 + 30] = o1[k] - cdp[k];
+            Quat e = q_mul(q_inv(cdq), q_mul(Qii, Qj));
+            sRaw[3 * 31 + 30] = 2 * e.x; sRaw[4 * 31 + 30] = 2 * e.y; sRaw[5 * 31 + 30] = 2 * e.z;
+            for (int k = 0; k < 3; k++) u[k] = d.G[k] * dt + sj[k] - si[k];
+            q_rot(Qii, u, o2);
+            for (int k = 0; k < 3; k++) sRaw[(6 + k) * 31 + 30] = o2[k] - cdv[k];
+            for (int k = 0; k < 3; k++) { sRaw[(9 + k) * 31 + 30] = sj[3 + k] - si[3 + k]; sRaw[(12 + k) * 31 + 30] = sj[6 + k] - si[6 + k]; }
+        } else if (t == 1) {
             // raw Jacobian, tangent columns: pose_i 0..5, sb_i 6..14, pose_j 15..20, sb_j 21..29
-            double RiT[9]; q_to_R(Qii, RiT);
-            double S1[9], S2[9], B1[9], B2[9], L[9], Rr[9], T[9];
+            double RiT[9], u[3], o1[3], o2[3], S1[9], S2[9], B1[9], L[9], Rr[9];
+            q_to_R(Qii, RiT);
+            for (int k = 0; k < 3; k++) u[k] = 0.5 * d.G[k] * dt * dt + pj[k] - pi[k] - si[k] * dt;
+            q_rot(Qii, u, o1);
+            for (int k = 0; k < 3; k++) u[k] = d.G[k] * dt + sj[k] - si[k];
+            q_rot(Qii, u, o2);
             skew3(o1, S1); skew3(o2, S2);
             // -(Qleft(Qj^-1 Qi) Qright(cdq)).bottomRight3x3 : bottom-right of a 4x4 product
-            {
-                Quat a = q_mul(q_inv(Qj), Qi);
-                // (L4 R4)[1+r][1+c] = a_vec[r] * (-b_vec[c]) + sum_k L33[r][k] R33[k][c]
-                qleft33(a, L); qright33(cdq, Rr); m3_mul(L, Rr, B1);
-                double av[3] = {a.x, a.y, a.z}, bv[3] = {cdq.x, cdq.y, cdq.z};
-                for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) B1[r * 3 + c] += av[r] * (-bv[c]);
-            }
-            qleft33(q_mul(q_mul(q_inv(Qj), Qi), dq), L);
-            m3_mul(L, rec + IMU_DQ_DBG, T);                                 // -> -T at [R, bg]
-            qleft33(q_mul(q_mul(q_inv(cdq), Qii), Qj), B2);                 // pose_j [R,R]
+            Quat aq = q_mul(q_inv(Qj), Qi);
+            qleft33(aq, L); qright33(cdq, Rr); m3_mul(L, Rr, B1);
+            const double av[3] = {aq.x, aq.y, aq.z}, bv[3] = {cdq.x, cdq.y, cdq.z};
+            for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) B1[r * 3 + c] += av[r] * (-bv[c]);
             for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) {
                 const int ab = a * 3 + b;
                 sRaw[(0 + a) * 31 + 0 + b] = -RiT[ab];
                 sRaw[(0 + a) * 31 + 3 + b] = S1[ab];
                 sRaw[(3 + a) * 31 + 3 + b] = -B1[ab];
                 sRaw[(6 + a) * 31 + 3 + b] = S2[ab];
+            }
+        } else if (t == 2) {
+            double RiT[9], L[9], T[9];
+            q_to_R(Qii, RiT);
+            qleft33(q_mul(q_mul(q_inv(Qj), Qi), dq), L);
+            m3_mul(L, rec + IMU_DQ_DBG, T);                                 // -> -T at [R, bg]
+            for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) {
+                const int ab = a * 3 + b;
                 sRaw[(0 + a) * 31 + 6 + b] = -RiT[ab] * dt;
                 sRaw[(0 + a) * 31 + 9 + b] = -rec[IMU_DP_DBA + ab];
                 sRaw[(0 + a) * 31 + 12 + b] = -rec[IMU_DP_DBG + ab];
@@ -356,6 +307,13 @@ __global__ __launch_bounds__(64) void k_imu_linearize(DevBatch d, const double *
                 sRaw[(6 + a) * 31 + 12 + b] = -rec[IMU_DV_DBG + ab];
                 sRaw[(9 + a) * 31 + 9 + b] = (a == b) ? -1.0 : 0.0;
                 sRaw[(12 + a) * 31 + 12 + b] = (a == b) ? -1.0 : 0.0;
+            }
+        } else {
+            double RiT[9], B2[9];
+            q_to_R(Qii, RiT);
+            qleft33(q_mul(q_mul(q_inv(cdq), Qii), Qj), B2);                 // pose_j [R,R]
+            for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) {
+                const int ab = a * 3 + b;
                 sRaw[(0 + a) * 31 + 15 + b] = RiT[ab];
                 sRaw[(3 + a) * 31 + 18 + b] = B2[ab];
                 sRaw[(6 + a) * 31 + 21 + b] = RiT[ab];

@@ -1,0 +1,524 @@
+// isv_marg.hip -- k_marg: Estimator::MargForward (reference src/estimator.cpp:1149-1352) and
+// Estimator::MargBackward (:1354-1539) on the device, one wavefront per window (only windows
+// uploaded with margin_old != 0 do work).  All matrices are tiny (<= 30x30) and live in LDS; the
+// wavefront cooperates lane-per-entry.  Runs after k_finalize: it linearises at the para_* arrays
+// (d.pose / d.sb / d.lam, the un-rotated solve output) with the post-update, post-double2vector
+// priors, and takes Ri/ti from the rotated Rs[0]/Ps[0] -- exactly the reference's order of events
+// (SURVEY.md appendix B.2).
+//
+// Restatement notes (mathematically identical to the reference, different elimination order):
+//   * MargForward eliminates [T0, landmarks] with a fullPivLu inverse of the (L0+6)^2 matrix; the
+//     landmark block of that matrix is diagonal, so here the landmarks are eliminated first in closed
+//     form (rank-1 downdates of the 12x12 pose block) and T0 by a 6x6 inverse.
+//   * Eigen's SelfAdjointEigenSolver / BDCSVD are replaced by cyclic Jacobi iterations.
+#include <hip/hip_runtime.h>
+#include "isv_kernels.h"
+#include "isv_device_math.h"
+#include "isv_proj_factor.h"
+
+#define MT 64
+#define SYNC() __syncthreads()
+
+// ---- wave-cooperative dense helpers on LDS matrices (row-major) --------------------------------
+DEV void w_mm(const double *A, const double *B, double *C, int m, int k, int n, int t) {
+    for (int e = t; e < m * n; e += MT) { const int i = e / n, j = e % n; double s = 0; for (int p = 0; p < k; p++) s += A[i * k + p] * B[p * n + j]; C[e] = s; }
+    SYNC();
+}
+DEV void w_mm_tn(const double *A, const double *B, double *C, int m, int k, int n, int t) {    // A is k x m
+    for (int e = t; e < m * n; e += MT) { const int i = e / n, j = e % n; double s = 0; for (int p = 0; p < k; p++) s += A[p * m + i] * B[p * n + j]; C[e] = s; }
+    SYNC();
+}
+DEV void w_mm_nt(const double *A, const double *B, double *C, int m, int k, int n, int t) {    // B is n x k
+    for (int e = t; e < m * n; e += MT) { const int i = e / n, j = e % n; double s = 0; for (int p = 0; p < k; p++) s += A[i * k + p] * B[j * k + p]; C[e] = s; }
+    SYNC();
+}
+// inverse by Gauss-Jordan with partial pivoting on the augmented [A | I]; W is n x 2n scratch
+DEV void w_inv(const double *A, int n, double *Inv, double *W, int *piv, int t) {
+    const int n2 = 2 * n;
+    for (int e = t; e < n * n2; e += MT) { const int i = e / n2, j = e % n2; W[e] = (j < n) ? A[i * n + j] : ((j - n) == i ? 1.0 : 0.0); }
+    SYNC();
+    for (int k = 0; k < n; k++) {
+        if (t == 0) { int p = k; double best = fabs(W[k * n2 + k]); for (int i = k + 1; i < n; i++) if (fabs(W[i * n2 + k]) > best) { best = fabs(W[i * n2 + k]); p = i; } piv[0] = p; }
+        SYNC();
+        const int p = piv[0];
+        if (p != k) for (int j = t; j < n2; j += MT) { const double tmp = W[k * n2 + j]; W[k * n2 + j] = W[p * n2 + j]; W[p * n2 + j] = tmp; }
+        SYNC();
+        const double d = W[k * n2 + k];
+        SYNC();
+        for (int j = t; j < n2; j += MT) W[k * n2 + j] /= d;
+        SYNC();
+        for (int e = t; e < n * n2; e += MT) {
+            const int i = e / n2, j = e % n2;
+            if (i != k && j != k) W[e] -= W[i * n2 + k] * W[k * n2 + j];
+        }
+        SYNC();
+        for (int i = t; i < n; i += MT) if (i != k) W[i * n2 + k] = 0.0;
+        SYNC();
+    }
+    for (int e = t; e < n * n; e += MT) { const int i = e / n, j = e % n; Inv[e] = W[i * n2 + n + j]; }
+    SYNC();
+}
+// U = LLT(M).matrixL().transpose()  (upper triangular), lane-parallel over rows
+DEV void w_chol_upper(const double *M, int n, double *U, double *L, int t) {
+    for (int e = t; e < n * n; e += MT) L[e] = M[e];
+    SYNC();
+    for (int j = 0; j < n; j++) {
+        if (t == 0) { double dd = L[j * n + j]; for (int k = 0; k < j; k++) dd -= L[j * n + k] * L[j * n + k]; L[j * n + j] = sqrt(dd); }
+        SYNC();
+        for (int i = j + 1 + t; i < n; i += MT) { double s = L[i * n + j]; for (int k = 0; k < j; k++) s -= L[i * n + k] * L[j * n + k]; L[i * n + j] = s / L[j * n + j]; }
+        SYNC();
+    }
+    for (int e = t; e < n * n; e += MT) { const int i = e / n, j = e % n; U[e] = (j >= i) ? L[j * n + i] : 0.0; }
+    SYNC();
+}
+// cyclic Jacobi: A (destroyed) = V diag(w) V^T
+DEV void w_jacobi(double *A, int n, double *wv, double *V, double *tmp, int t) {
+    for (int e = t; e < n * n; e += MT) V[e] = (e / n == e % n) ? 1.0 : 0.0;
+    SYNC();
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0, dg = 0;
+        for (int e = t; e < n * n; e += MT) { const int i = e / n, j = e % n; if (j > i) off += A[e] * A[e]; else if (i == j) dg += A[e] * A[e]; }
+        tmp[t] = off; tmp[64 + t] = dg;
+        SYNC();
+        for (int o = 32; o > 0; o >>= 1) { if (t < o) { tmp[t] += tmp[t + o]; tmp[64 + t] += tmp[64 + t + o]; } SYNC(); }
+        const double offs = tmp[0], dgs = tmp[64];
+        SYNC();
+        if (offs <= 1e-60 || offs <= 1e-34 * dgs) break;
+        for (int p = 0; p < n - 1; p++) for (int q = p + 1; q < n; q++) {
+            const double apq = A[p * n + q];
+            if (apq == 0.0) continue;                 // uniform (LDS value)
+            const double app = A[p * n + p], aqq = A[q * n + q];
+            const double theta = (aqq - app) / (2.0 * apq);
+            const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+            const double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
+            SYNC();
+            for (int k = t; k < n; k += MT) { const double akp = A[k * n + p], akq = A[k * n + q]; A[k * n + p] = c * akp - s * akq; A[k * n + q] = s * akp + c * akq; }
+            SYNC();
+            for (int k = t; k < n; k += MT) { const double apk = A[p * n + k], aqk = A[q * n + k]; A[p * n + k] = c * apk - s * aqk; A[q * n + k] = s * apk + c * aqk; }
+            for (int k = t; k < n; k += MT) { const double vkp = V[k * n + p], vkq = V[k * n + q]; V[k * n + p] = c * vkp - s * vkq; V[k * n + q] = s * vkp + c * vkq; }
+            SYNC();
+        }
+    }
+    for (int i = t; i < n; i += MT) wv[i] = A[i * n + i];
+    SYNC();
+}
+// Sigma = (Jk U) D^-1 (Jk U)^T over the kept eigenpairs (keep[i] != 0); Jk is rows x n
+DEV void w_project_cov(const double *Jk, int rows, int n, const double *V, const double *wv, const int *keep, double *JU, double *Sigma, int t) {
+    for (int e = t; e < rows * n; e += MT) { const int a = e / n, k = e % n; double s = 0; for (int c = 0; c < n; c++) s += Jk[a * n + c] * V[c * n + k]; JU[e] = s; }
+    SYNC();
+    for (int e = t; e < rows * rows; e += MT) {
+        const int a = e / rows, b = e % rows; double s = 0;
+        for (int k = 0; k < n; k++) if (keep[k]) s += JU[a * n + k] * (1.0 / wv[k]) * JU[b * n + k];
+        Sigma[e] = s;
+    }
+    SYNC();
+}
+DEV double w_det(const double *A, int n, double *W, int *piv, int t) {     // via LU with partial pivoting (single lane; n <= 21)
+    double det = 1;
+    for (int e = t; e < n * n; e += MT) W[e] = A[e];
+    SYNC();
+    if (t == 0) {
+        for (int k = 0; k < n; k++) {
+            int p = k; double best = fabs(W[k * n + k]);
+            for (int i = k + 1; i < n; i++) if (fabs(W[i * n + k]) > best) { best = fabs(W[i * n + k]); p = i; }
+            if (best == 0.0) { det = 0; break; }
+            if (p != k) { for (int j = 0; j < n; j++) { const double tmp = W[k * n + j]; W[k * n + j] = W[p * n + j]; W[p * n + j] = tmp; } det = -det; }
+            det *= W[k * n + k];
+            for (int i = k + 1; i < n; i++) { const double f = W[i * n + k] / W[k * n + k]; for (int j = k + 1; j < n; j++) W[i * n + j] -= f * W[k * n + j]; }
+        }
+        W[0] = det;
+    }
+    SYNC();
+    det = W[0];
+    SYNC();
+    return det;
+}
+
+// unweighted prior Jacobians at a pose (EvaluateOnlyJacobians of the reference factors), 6-column form
+DEV void relpose_jac(const double *dt, const double *dR, const double *pi, const double *pj, double *res, double *Ji, double *Jj) {
+    Quat Qi = q_from_pose(pi), Qj = q_from_pose(pj);
+    double Ri[9], Rj[9], dd[3], qd[3], M1[9], M2[9], lg[3], Jr[9], S[9], nJ[9], T1[9], T2[9];
+    q_to_R(Qi, Ri); q_to_R(Qj, Rj);
+    for (int k = 0; k < 3; k++) dd[k] = pj[k] - pi[k];
+    q_rot(q_inv(Qi), dd, qd);
+    m3_mul_nt(dR, Rj, M1); m3_mul(M1, Ri, M2);
+    so3_log(q_from_R(M2), lg);
+    for (int k = 0; k < 3; k++) { res[k] = dt[k] - qd[k]; res[3 + k] = lg[k]; }
+    so3_rjac_inv(lg, Jr); skew3(qd, S);
+    for (int k = 0; k < 36; k++) { Ji[k] = 0; Jj[k] = 0; }
+    for (int k = 0; k < 9; k++) nJ[k] = -Jr[k];
+    m3_mul_nt(nJ, Ri, T1); m3_mul(T1, Rj, T2);
+    for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) {
+        Ji[a * 6 + b] = Ri[b * 3 + a]; Ji[a * 6 + 3 + b] = -S[a * 3 + b]; Ji[(3 + a) * 6 + 3 + b] = Jr[a * 3 + b];
+        Jj[a * 6 + b] = -Ri[b * 3 + a]; Jj[(3 + a) * 6 + 3 + b] = T2[a * 3 + b];
+    }
+}
+
+__global__ __launch_bounds__(MT) void k_marg(DevBatch d) {
+    __shared__ double Lam[900], M1[900], M2[900], Wk[1800], Vv[441], wv[32], JU[441], Jr[441], tmp[128];
+    __shared__ double sJ[16 * 36];      // small Jacobian staging
+    __shared__ int keep[32], piv[4];
+    const int w = blockIdx.x, t = threadIdx.x;
+    isv_marg_result_t &out = d.marg[w];
+    {   // clear the record (padding included) so downloads are deterministic
+        double *z = reinterpret_cast<double *>(&out);
+        for (int e = t; e < (int)(sizeof(isv_marg_result_t) / sizeof(double)); e += MT) z[e] = 0.0;
+    }
+    SYNC();
+    if (!d.margin_old[w]) return;
+    const int N = d.N, v = d.Nvo;
+    const double *pose = d.pose + (size_t)w * N * 7, *sb = d.sb + (size_t)w * N * 9, *ex = d.ex + (size_t)w * 7;
+    const int l0 = d.lm_off[w], l1 = d.lm_off[w + 1];
+    // ================= MargForward =================
+    // landmarks hosted in frame 0 (forwardProjectiontoSparsify / MargPointIdx, estimator.cpp:1082-1087)
+    double *Jw = d.marg_scratch + (size_t)l0 * 26;          // [n0][26] weighted [J_T1(2x6) | J_T0(2x6) | J_l(2)] rows interleaved
+    int n0 = 0;
+    {
+        double Ri[9], Rj[9], ric[9];
+        q_to_R(q_from_pose(pose), Ri); q_to_R(q_from_pose(pose + 7), Rj); q_to_R(q_from_pose(ex), ric);
+        const double ident[4] = {1, 0, 0, 1};
+        for (int base = l0; base < l1; base += MT) {
+            const int l = base + t;
+            const bool is0 = l < l1 && d.lm_host[l] == 0;
+            const unsigned long long m = __ballot(is0);
+            if (is0) {
+                const int slot = n0 + __popcll(m & ((1ull << t) - 1));
+                const int f = d.lm_f0[l];                     // factor 0 -> 1
+                double r0, r1, Ji[12], Jj[12], Jl[2];
+                const double *pi3 = d.lm_pts_i + (size_t)l * 3;
+                proj_factor<true>(Ri, pose, Rj, pose + 7, ric, ex, ident, d.lam[l], pi3[0], pi3[1], pi3[2],
+                                  d.f_pts_j[(size_t)f * 2], d.f_pts_j[(size_t)f * 2 + 1], r0, r1, Ji, Jj, Jl);
+                // weight with sqrt_info (infoMatrix = sqrt_info^T sqrt_info, estimator.cpp:1173)
+                const double *sq = d.proj_sqrt_info;
+                double *o = Jw + (size_t)slot * 26;
+                for (int c = 0; c < 6; c++) {
+                    o[c] = sq[0] * Jj[c] + sq[1] * Jj[6 + c];        o[13 + c] = sq[2] * Jj[c] + sq[3] * Jj[6 + c];          // T1 = frame 1
+                    o[6 + c] = sq[0] * Ji[c] + sq[1] * Ji[6 + c];    o[13 + 6 + c] = sq[2] * Ji[c] + sq[3] * Ji[6 + c];      // T0 = frame 0
+                }
+                o[12] = sq[0] * Jl[0] + sq[1] * Jl[1]; o[25] = sq[2] * Jl[0] + sq[3] * Jl[1];
+            }
+            n0 += __popcll(m);
+        }
+    }
+    __threadfence_block();
+    SYNC();
+    // raw pose block Hraw (12x12, order [T1, T0]) in Lam[0..143]; Schur-reduced over the landmarks in M1[0..143]
+    for (int e = t; e < 144; e += MT) {
+        const int a = e / 12, b = e % 12;
+        double hr = 0, hs = 0;
+        for (int m = 0; m < n0; m++) {
+            const double *o = Jw + (size_t)m * 26;
+            const double h = o[a] * o[b] + o[13 + a] * o[13 + b];
+            const double ba = o[a] * o[12] + o[13 + a] * o[25], bb = o[b] * o[12] + o[13 + b] * o[25];
+            const double dm = o[12] * o[12] + o[25] * o[25];
+            hr += h; hs += h - ba * bb / dm;
+        }
+        Lam[e] = hr; M1[e] = hs;
+    }
+    SYNC();
+    // pose prior on T0 and relative-pose edge (0,1): unweighted Jacobians, info = S^T S
+    if (t == 0) {
+        const isv_se3_prior_t &f = d.se3[w];
+        Quat rr = so3_mul(q_conj(q_from_R(f.R)), q_normalized(q_from_pose(pose)));
+        double lg[3], J3[9];
+        so3_log(rr, lg); so3_rjac_inv(lg, J3);
+        for (int k = 0; k < 36; k++) sJ[k] = 0;
+        sJ[0] = sJ[7] = sJ[14] = 1.0;
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) sJ[(3 + a) * 6 + 3 + b] = J3[a * 3 + b];
+        double r6[6];
+        relpose_jac(d.relpose[(size_t)w * (v - 1)].delta_t, d.relpose[(size_t)w * (v - 1)].delta_R, pose, pose + 7, r6, sJ + 36, sJ + 72);
+    }
+    SYNC();
+    {   // SJ = S * J (6x6) for the se3 prior -> M2[0..35]; add (SJ)^T (SJ) to the T0 block
+        w_mm(d.se3[w].sqrt_info, sJ, M2, 6, 6, 6, t);
+        for (int e = t; e < 36; e += MT) { const int a = e / 6, b = e % 6; double s = 0; for (int k = 0; k < 6; k++) s += M2[k * 6 + a] * M2[k * 6 + b]; Lam[(6 + a) * 12 + 6 + b] += s; M1[(6 + a) * 12 + 6 + b] += s; }
+        SYNC();
+        // relpose: J12 = [Jj (T1 cols 0..5) | Ji (T0 cols 6..11)], SJ12 = S * J12 (6x12) in M2
+        const double *S = d.relpose[(size_t)w * (v - 1)].sqrt_info;
+        for (int e = t; e < 72; e += MT) { const int a = e / 12, c = e % 12; double s = 0; for (int k = 0; k < 6; k++) s += S[a * 6 + k] * (c < 6 ? sJ[72 + k * 6 + c] : sJ[36 + k * 6 + c - 6]); M2[e] = s; }
+        SYNC();
+        for (int e = t; e < 144; e += MT) { const int a = e / 12, b = e % 12; double s = 0; for (int k = 0; k < 6; k++) s += M2[k * 12 + a] * M2[k * 12 + b]; Lam[e] += s; M1[e] += s; }
+        SYNC();
+    }
+    // (i) pose-graph edge (estimator.cpp:1240-1283)
+    isv_relpose_t &pg = out.combined.relative_pose;
+    if (t == 0) {
+        Quat Qi = q_from_pose(pose), Qj = q_from_pose(pose + 7);
+        double dd[3] = {pose[7] - pose[0], pose[8] - pose[1], pose[9] - pose[2]};
+        q_rot(q_inv(Qi), dd, pg.delta_t);
+        q_to_R(q_mul(q_inv(Qi), Qj), pg.delta_R);
+        pg.imu_i = 0; pg.imu_j = 1;
+        double r6[6];
+        relpose_jac(pg.delta_t, pg.delta_R, pose, pose + 7, r6, sJ + 36, sJ + 72);
+        // J (6x12) = [jacobians[0] | jacobians[1]] = [d/d pose0 | d/d pose1]  (reference column order, :1253-1255)
+        for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) { M2[a * 12 + b] = sJ[36 + a * 6 + b]; M2[a * 12 + 6 + b] = sJ[72 + a * 6 + b]; }
+    }
+    SYNC();
+    {   // pseudo-inverse through the eigen-decomposition of J J^T (6x6), threshold 1e-8 * 12 on singular values
+        double *G = Wk, *Gi = Wk + 64, *Jp = Wk + 128;            // Jp: 12 x 6
+        w_mm_nt(M2, M2, G, 6, 12, 6, t);
+        for (int e = t; e < 36; e += MT) JU[e] = G[e];
+        SYNC();
+        w_jacobi(JU, 6, wv, Vv, tmp, t);
+        double smax2 = 0; for (int k = 0; k < 6; k++) smax2 = fmax(smax2, wv[k]);
+        const double thr = 1e-8 * 12;
+        for (int e = t; e < 36; e += MT) {
+            const int a = e / 6, b = e % 6; double s = 0;
+            for (int k = 0; k < 6; k++) { const double sv = sqrt(fmax(wv[k], 0.0)); if (sv > thr * sqrt(smax2)) s += Vv[a * 6 + k] * Vv[b * 6 + k] / wv[k]; }
+            Gi[e] = s;
+        }
+        SYNC();
+        w_mm_tn(M2, Gi, Jp, 12, 6, 6, t);                       // J^T Ginv : 12 x 6
+        double *Tm = Wk + 256, *Om = Wk + 400, *cov = Wk + 448;
+        w_mm_tn(Jp, Lam, Tm, 6, 12, 12, t);                      // Jp^T Lam_rp : 6 x 12
+        w_mm(Tm, Jp, Om, 6, 12, 6, t);
+        w_inv(Om, 6, cov, Wk + 600, piv, t);
+        w_chol_upper(Om, 6, JU, Wk + 800, t);
+        for (int e = t; e < 36; e += MT) { pg.sqrt_info[e] = JU[e]; out.combined.covRel[e] = cov[e]; }
+        SYNC();
+    }
+    if (t == 0) {
+        out.combined.has_rollpitch = 0;
+        if (d.n_rp[w] > 0 && d.rollpitch[(size_t)w * d.max_rp].index == 0) {
+            out.combined.has_rollpitch = 1;
+            out.combined.rollpitch = d.rollpitch[(size_t)w * d.max_rp];
+            const double *s = out.combined.rollpitch.sqrt_info;
+            const double a = s[0] * s[0] + s[2] * s[2], b = s[0] * s[1] + s[2] * s[3], c = s[1] * s[1] + s[3] * s[3], det = a * c - b * b;
+            out.combined.covAbs[0] = c / det; out.combined.covAbs[1] = -b / det; out.combined.covAbs[2] = -b / det; out.combined.covAbs[3] = a / det;
+        }
+        out.combined.distance = sqrt(pg.delta_t[0] * pg.delta_t[0] + pg.delta_t[1] * pg.delta_t[1] + pg.delta_t[2] * pg.delta_t[2]);
+        out.combined.ts = d.header0[w];
+        for (int k = 0; k < 9; k++) out.combined.Ri[k] = d.Rs[(size_t)w * N * 9 + k];
+        for (int k = 0; k < 3; k++) out.combined.ti[k] = d.Ps[(size_t)w * N * 3 + k];
+    }
+    // (ii) new pose prior on T1: eliminate T0 from the landmark-reduced block M1
+    {
+        double *A66 = Wk, *Ainv = Wk + 64, *Lp = Wk + 128, *cov = Wk + 192, *covi = Wk + 256, *X = Wk + 320, *T = Wk + 384;
+        for (int e = t; e < 36; e += MT) A66[e] = M1[(6 + e / 6) * 12 + 6 + e % 6];
+        SYNC();
+        w_inv(A66, 6, Ainv, Wk + 600, piv, t);
+        for (int e = t; e < 36; e += MT) {
+            const int a = e / 6, b = e % 6; double s = M1[a * 12 + b];
+            for (int p = 0; p < 6; p++) { double tt = 0; for (int q = 0; q < 6; q++) tt += Ainv[p * 6 + q] * M1[b * 12 + 6 + q]; s -= M1[a * 12 + 6 + p] * tt; }
+            Lp[e] = s;
+        }
+        SYNC();
+        isv_se3_prior_t &fp = out.forward_pose_prior;
+        if (t == 0) {
+            for (int k = 0; k < 3; k++) fp.t[k] = pose[7 + k];
+            q_to_R(q_from_pose(pose + 7), fp.R);
+            fp.index = 0;
+            // Jr = SE3PriorFactor(P1,Q1)::EvaluateOnlyJacobians(para_Pose[1])
+            Quat rr = so3_mul(q_conj(q_from_R(fp.R)), q_normalized(q_from_pose(pose + 7)));
+            double lg[3], J3[9];
+            so3_log(rr, lg); so3_rjac_inv(lg, J3);
+            for (int k = 0; k < 36; k++) sJ[k] = 0;
+            sJ[0] = sJ[7] = sJ[14] = 1.0;
+            for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) sJ[(3 + a) * 6 + 3 + b] = J3[a * 3 + b];
+        }
+        SYNC();
+        // rank of Lp with threshold 1e-16 (FullPivHouseholderQR, estimator.cpp:8,1304): pivots of a full-pivot elimination
+        int rank = 6;
+        if (t == 0) {
+            double Aq[36]; for (int k = 0; k < 36; k++) Aq[k] = Lp[k];
+            double pv[6], maxp = 0; rank = 0;
+            for (int k = 0; k < 6; k++) pv[k] = 0;
+            for (int k = 0; k < 6; k++) {
+                int pi = k, pj = k; double best = 0;
+                for (int i = k; i < 6; i++) for (int j = k; j < 6; j++) if (fabs(Aq[i * 6 + j]) > best) { best = fabs(Aq[i * 6 + j]); pi = i; pj = j; }
+                pv[k] = best; if (best > maxp) maxp = best;
+                if (best == 0) break;
+                for (int j = 0; j < 6; j++) { const double tmp2 = Aq[k * 6 + j]; Aq[k * 6 + j] = Aq[pi * 6 + j]; Aq[pi * 6 + j] = tmp2; }
+                for (int i = 0; i < 6; i++) { const double tmp2 = Aq[i * 6 + k]; Aq[i * 6 + k] = Aq[i * 6 + pj]; Aq[i * 6 + pj] = tmp2; }
+                for (int i = k + 1; i < 6; i++) { const double f = Aq[i * 6 + k] / Aq[k * 6 + k]; for (int j = k; j < 6; j++) Aq[i * 6 + j] -= f * Aq[k * 6 + j]; }
+            }
+            for (int k = 0; k < 6; k++) if (pv[k] > 1e-16 * maxp) rank++;
+            piv[1] = rank;
+        }
+        SYNC();
+        rank = piv[1];
+        if (rank == 6) {
+            w_inv(Lp, 6, cov, Wk + 600, piv, t);
+            w_mm(sJ, cov, T, 6, 6, 6, t);
+            w_mm_nt(T, sJ, covi, 6, 6, 6, t);
+        } else {
+            for (int e = t; e < 36; e += MT) JU[e] = Lp[e];
+            SYNC();
+            w_jacobi(JU, 6, wv, Vv, tmp, t);
+            if (t < 6) keep[t] = wv[t] > d.alpha_cut;
+            SYNC();
+            w_project_cov(sJ, 6, 6, Vv, wv, keep, JU, covi, t);
+        }
+        w_inv(covi, 6, X, Wk + 600, piv, t);
+        double kld = 0;
+        if (rank == 6) {
+            double *phi = Wk + 448, *pc = Wk + 512;
+            w_mm_tn(sJ, X, T, 6, 6, 6, t);
+            w_mm(T, sJ, phi, 6, 6, 6, t);
+            w_mm(phi, cov, pc, 6, 6, 6, t);
+            const double dphi = w_det(phi, 6, Wk + 900, piv, t), dcov = w_det(cov, 6, Wk + 900, piv, t);
+            double a = 0; for (int k = 0; k < 6; k++) a += pc[k * 6 + k];
+            kld = 0.5 * (a - log(dphi) - log(dcov) - 6);
+        }
+        w_chol_upper(X, 6, JU, Wk + 800, t);
+        for (int e = t; e < 36; e += MT) fp.sqrt_info[e] = JU[e];
+        if (t == 0) { out.forward_kld = kld; out.n_marg_landmarks = n0; out.valid = 1; }
+        SYNC();
+    }
+    // ================= MargBackward =================
+    // order: T1 = frame v (@0), VB1 (@6), T0 = frame v-1 (@15), VB0 (@21)
+    for (int e = t; e < 900; e += MT) Lam[e] = 0.0;
+    SYNC();
+    {
+        const double *S = d.lin9[w].sqrt_info;            // VB prior on sb[v-1]: J = I, info = S^T S
+        for (int e = t; e < 81; e += MT) { const int a = e / 9, b = e % 9; double s = 0; for (int k = 0; k < 9; k++) s += S[k * 9 + a] * S[k * 9 + b]; Lam[(21 + a) * 30 + 21 + b] += s; }
+        SYNC();
+        // IMU factor v-1 -> v: weighted Jacobian = strip's J if the strips were taken at this point; they were not
+        // (the last accepted point was never re-linearised), so rebuild: raw J through the linearise kernel's layout.
+    }
+    // raw (unweighted) IMU Jacobian 15x30 in M1 (columns: pose_i 0..5, sb_i 6..14, pose_j 15..20, sb_j 21..29)
+    for (int e = t; e < 450; e += MT) M1[e] = 0.0;
+    SYNC();
+    if (t == 0) {
+        const size_t f = (size_t)w * (N - 1) + (v - 1);
+        const double *rec = d.imu_in + f * ISV_IMU_IN;
+        const double *pi = pose + 7 * (v - 1), *pj = pi + 7, *si = sb + 9 * (v - 1), *sj = si + 9;
+        Quat Qi = q_from_pose(pi), Qj = q_from_pose(pj), Qii = q_inv(Qi);
+        const double dt = rec[IMU_DT];
+        double dbg[3], tt[3], u[3], o1[3], o2[3], RiT[9], S1[9], S2[9], B1[9], B2[9], L[9], Rr[9], T[9];
+        for (int k = 0; k < 3; k++) dbg[k] = si[6 + k] - rec[IMU_LBG + k];
+        Quat dq = Quat{rec[IMU_DQ + 3], rec[IMU_DQ], rec[IMU_DQ + 1], rec[IMU_DQ + 2]};
+        m3v(rec + IMU_DQ_DBG, dbg, tt);
+        Quat cdq = q_mul(dq, q_delta(tt));
+        q_to_R(Qii, RiT);
+        for (int k = 0; k < 3; k++) u[k] = 0.5 * d.G[k] * dt * dt + pj[k] - pi[k] - si[k] * dt;
+        q_rot(Qii, u, o1);
+        for (int k = 0; k < 3; k++) u[k] = d.G[k] * dt + sj[k] - si[k];
+        q_rot(Qii, u, o2);
+        skew3(o1, S1); skew3(o2, S2);
+        Quat aq = q_mul(q_inv(Qj), Qi);
+        qleft33(aq, L); qright33(cdq, Rr); m3_mul(L, Rr, B1);
+        const double av[3] = {aq.x, aq.y, aq.z}, bv[3] = {cdq.x, cdq.y, cdq.z};
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) B1[r * 3 + c] += av[r] * (-bv[c]);
+        qleft33(q_mul(q_mul(q_inv(Qj), Qi), dq), L);
+        m3_mul(L, rec + IMU_DQ_DBG, T);
+        qleft33(q_mul(q_mul(q_inv(cdq), Qii), Qj), B2);
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) {
+            const int ab = a * 3 + b;
+            M1[(0 + a) * 30 + 0 + b] = -RiT[ab]; M1[(0 + a) * 30 + 3 + b] = S1[ab]; M1[(3 + a) * 30 + 3 + b] = -B1[ab]; M1[(6 + a) * 30 + 3 + b] = S2[ab];
+            M1[(0 + a) * 30 + 6 + b] = -RiT[ab] * dt; M1[(0 + a) * 30 + 9 + b] = -rec[IMU_DP_DBA + ab]; M1[(0 + a) * 30 + 12 + b] = -rec[IMU_DP_DBG + ab];
+            M1[(3 + a) * 30 + 12 + b] = -T[ab]; M1[(6 + a) * 30 + 6 + b] = -RiT[ab]; M1[(6 + a) * 30 + 9 + b] = -rec[IMU_DV_DBA + ab];
+            M1[(6 + a) * 30 + 12 + b] = -rec[IMU_DV_DBG + ab];
+            M1[(9 + a) * 30 + 9 + b] = (a == b) ? -1.0 : 0.0; M1[(12 + a) * 30 + 12 + b] = (a == b) ? -1.0 : 0.0;
+            M1[(0 + a) * 30 + 15 + b] = RiT[ab]; M1[(3 + a) * 30 + 18 + b] = B2[ab]; M1[(6 + a) * 30 + 21 + b] = RiT[ab];
+            M1[(9 + a) * 30 + 24 + b] = (a == b) ? 1.0 : 0.0; M1[(12 + a) * 30 + 27 + b] = (a == b) ? 1.0 : 0.0;
+        }
+    }
+    SYNC();
+    {   // SJ = sqrt_info (15x15) * J (15x30) -> M2; Lam += (SJ)^T (SJ) with the column permutation to [T1 VB1 T0 VB0]
+        const double *S = d.imu_sqrt + ((size_t)w * (N - 1) + (v - 1)) * 225;
+        for (int e = t; e < 450; e += MT) { const int a = e / 30, c = e % 30; double s = 0; for (int k = 0; k < 15; k++) s += S[a * 15 + k] * M1[k * 30 + c]; M2[e] = s; }
+        SYNC();
+        for (int e = t; e < 900; e += MT) {
+            const int a = e / 30, b = e % 30;            // factor column order: [pose_i sb_i pose_j sb_j] -> Lam index: i-part at 15.., j-part at 0..
+            const int ga = (a < 15) ? 15 + a : a - 15, gb = (b < 15) ? 15 + b : b - 15;
+            double s = 0; for (int k = 0; k < 15; k++) s += M2[k * 30 + a] * M2[k * 30 + b];
+            Lam[ga * 30 + gb] += s;
+        }
+        SYNC();
+    }
+    double *Lp = M1;                                     // 21 x 21
+    {
+        double *A99 = Wk, *Ainv = Wk + 100;
+        for (int e = t; e < 81; e += MT) A99[e] = Lam[(21 + e / 9) * 30 + 21 + e % 9];
+        SYNC();
+        w_inv(A99, 9, Ainv, Wk + 200, piv, t);
+        for (int e = t; e < 441; e += MT) {
+            const int a = e / 21, b = e % 21; double s = Lam[a * 30 + b];
+            for (int p = 0; p < 9; p++) { double tt = 0; for (int q = 0; q < 9; q++) tt += Ainv[p * 9 + q] * Lam[b * 30 + 21 + q]; s -= Lam[a * 30 + 21 + p] * tt; }
+            Lp[e] = s;
+        }
+        SYNC();
+    }
+    // recovered factors at the current estimate
+    isv_relpose_t &rp = out.backward_relpose; isv_linear9_t &vb = out.backward_vb; isv_rollpitch_t &gp = out.backward_rollpitch;
+    for (int e = t; e < 441; e += MT) Jr[e] = 0.0;
+    SYNC();
+    if (t == 0) {
+        const double *PSi = pose + 7 * (v - 1), *PSj = pose + 7 * v;
+        Quat Qi = q_from_pose(PSi), Qj = q_from_pose(PSj);
+        double dd[3] = {PSj[0] - PSi[0], PSj[1] - PSi[1], PSj[2] - PSi[2]};
+        q_rot(q_inv(Qi), dd, rp.delta_t); q_to_R(q_mul(q_inv(Qi), Qj), rp.delta_R);
+        rp.imu_i = v - 1; rp.imu_j = v;
+        double r6[6];
+        relpose_jac(rp.delta_t, rp.delta_R, PSi, PSj, r6, sJ, sJ + 36);
+        for (int k = 0; k < 9; k++) vb.VB[k] = sb[9 * v + k];
+        vb.index = v;
+        q_to_R(Qi, gp.R); gp.index = v - 1;
+        // RollPitchFactor(Qw)::EvaluateOnlyJacobians, YawFactor(Qw)::EvaluateOnlyJacobians at pose v-1
+        Quat Ri = q_normalized(Qi), Rm = q_from_R(gp.R);
+        double nZ[3] = {0, 0, -1.0}, vv[3], S[9], Rmm[9], Bm[9];
+        q_rot(so3_mul(Rm, q_conj(Ri)), nZ, vv);
+        skew3(vv, S); q_to_R(Rm, Rmm); m3_mul(S, Rmm, Bm);
+        double exv[3] = {1, 0, 0}, ym[3], Rr[9], Sy[9], By[9];
+        q_rot(q_inv(Qi), exv, ym);
+        q_to_R(Ri, Rr); skew3(ym, Sy);
+        for (int k = 0; k < 9; k++) Rr[k] = -Rr[k];
+        m3_mul(Rr, Sy, By);
+        for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) { Jr[a * 21 + 15 + b] += sJ[a * 6 + b]; Jr[a * 21 + b] += sJ[36 + a * 6 + b]; }
+        for (int a = 0; a < 9; a++) Jr[(6 + a) * 21 + 6 + a] += 1.0;
+        for (int a = 0; a < 2; a++) for (int b = 0; b < 3; b++) Jr[(15 + a) * 21 + 18 + b] += Bm[a * 3 + b];
+        for (int a = 0; a < 3; a++) Jr[(17 + a) * 21 + 15 + a] += 1.0;
+        for (int b = 0; b < 3; b++) Jr[20 * 21 + 18 + b] += By[3 + b];
+    }
+    SYNC();
+    // eigen-truncate Lp at ALPHA
+    for (int e = t; e < 441; e += MT) M2[e] = Lp[e];
+    SYNC();
+    w_jacobi(M2, 21, wv, Vv, tmp, t);
+    if (t < 21) keep[t] = wv[t] > d.alpha_cut;
+    SYNC();
+    {
+        double *Sg = Wk, *Xi = Wk + 100, *Xall = Wk + 1000;      // Xall: 21x21 block-diagonal information
+        for (int e = t; e < 441; e += MT) Xall[e] = 0.0;
+        SYNC();
+        const int r0[5] = {0, 6, 15, 17, 20}, nr[5] = {6, 9, 2, 3, 1};
+        for (int q = 0; q < 5; q++) {
+            w_project_cov(Jr + r0[q] * 21, nr[q], 21, Vv, wv, keep, JU, Sg, t);
+            w_inv(Sg, nr[q], Xi, Wk + 300, piv, t);
+            for (int e = t; e < nr[q] * nr[q]; e += MT) Xall[(r0[q] + e / nr[q]) * 21 + r0[q] + e % nr[q]] = Xi[e];
+            SYNC();
+            if (q < 3) {
+                w_chol_upper(Xi, nr[q], Sg, Wk + 200, t);
+                double *dst = (q == 0) ? rp.sqrt_info : (q == 1) ? vb.sqrt_info : gp.sqrt_info;
+                for (int e = t; e < nr[q] * nr[q]; e += MT) dst[e] = Sg[e];
+                SYNC();
+            }
+        }
+        // zero test / KLD (estimator.cpp:1519-1534): A = (Jr U)^T X (Jr U) over the kept eigenpairs vs D
+        int rank = 0; for (int k = 0; k < 21; k++) rank += keep[k];
+        double *JUa = Wk, *XJU = Wk + 450, *A = M2;
+        for (int e = t; e < 21 * 21; e += MT) {
+            const int a = e / 21, k = e % 21; double s = 0;
+            for (int c = 0; c < 21; c++) s += Jr[a * 21 + c] * Vv[c * 21 + k];
+            JUa[e] = s;                                   // all 21 columns; kept ones selected below
+        }
+        SYNC();
+        w_mm(Xall, JUa, XJU, 21, 21, 21, t);
+        for (int e = t; e < 441; e += MT) { const int a = e / 21, b = e % 21; double s = 0; for (int k = 0; k < 21; k++) s += JUa[k * 21 + a] * XJU[k * 21 + b]; A[e] = s; }
+        SYNC();
+        // restrict A to kept indices (rank x rank) in Wk+1000.. and evaluate trace / determinants
+        double *Ak = Wk + 1000;
+        if (t == 0) {
+            int ia = 0;
+            for (int a = 0; a < 21; a++) if (keep[a]) { int ib = 0; for (int b = 0; b < 21; b++) if (keep[b]) { Ak[ia * rank + ib] = A[a * 21 + b]; ib++; } ia++; }
+        }
+        SYNC();
+        const double detA = w_det(Ak, rank, Lam, piv, t);
+        if (t == 0) {
+            double tr = 0, ldinv = 0; int ia = 0;
+            for (int a = 0; a < 21; a++) if (keep[a]) { tr += Ak[ia * rank + ia] / wv[a]; ldinv += log(1.0 / wv[a]); ia++; }
+            out.backward_kld = 0.5 * (tr - log(detA) - ldinv - 21);
+        }
+    }
+}

@@ -1,0 +1,77 @@
+// isv_proj_factor.h -- ProjectionFactor::Evaluate geometry for one lane
+// (reference src/factor/projection_factor.cpp:24-122), shared by the linearise and marginalisation kernels.
+#pragma once
+#include "isv_device_math.h"
+
+// Reprojection factor geometry for one lane.  R*/P* come from LDS (staged per wave).
+template <bool JAC>
+DEV void proj_factor(const double *Ri, const double *Pi, const double *Rj, const double *Pj,
+                     const double *ric, const double *tic, const double *sq, double lam,
+                     double pix, double piy, double piz, double pjx, double pjy,
+                     double &r0, double &r1, double *Ji, double *Jj, double *Jl) {
+    double inv = 1.0 / lam;
+    double pc[3] = {pix * inv, piy * inv, piz * inv};           // pts_camera_i = pts_i / inv_dep_i
+    double pb[3], pw[3], t[3], pbj[3], pcj[3];
+    m3v(ric, pc, pb); pb[0] += tic[0]; pb[1] += tic[1]; pb[2] += tic[2];     // pts_imu_i
+    m3v(Ri, pb, pw);
+    t[0] = pw[0] + Pi[0] - Pj[0]; t[1] = pw[1] + Pi[1] - Pj[1]; t[2] = pw[2] + Pi[2] - Pj[2];
+    m3tv(Rj, t, pbj);                                                        // pts_imu_j
+    t[0] = pbj[0] - tic[0]; t[1] = pbj[1] - tic[1]; t[2] = pbj[2] - tic[2];
+    m3tv(ric, t, pcj);                                                       // pts_camera_j
+    double idep = 1.0 / pcj[2];
+    double u0 = pcj[0] * idep - pjx, u1 = pcj[1] * idep - pjy;
+    r0 = sq[0] * u0 + sq[1] * u1;
+    r1 = sq[2] * u0 + sq[3] * u1;
+    if (!JAC) return;
+    // reduce = sqrt_info * [[1/z, 0, -x/z^2],[0, 1/z, -y/z^2]]
+    double a0 = idep, a2 = -pcj[0] * idep * idep, b2 = -pcj[1] * idep * idep;
+    double red[6] = {sq[0] * a0, sq[1] * a0, sq[0] * a2 + sq[1] * b2,
+                     sq[2] * a0, sq[3] * a0, sq[2] * a2 + sq[3] * b2};
+    double A[9], RA[6];
+    // A := ric^T * Rj^T
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) A[i * 3 + j] = ric[i] * Rj[j * 3] + ric[3 + i] * Rj[j * 3 + 1] + ric[6 + i] * Rj[j * 3 + 2];
+    // RA = reduce * A   (2x3)
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) RA[i * 3 + j] = red[i * 3] * A[j] + red[i * 3 + 1] * A[3 + j] + red[i * 3 + 2] * A[6 + j];
+    // J_pose_i = [RA, -RA Ri [pts_imu_i]x]
+    double RB[6];                          // RA * Ri
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) RB[i * 3 + j] = RA[i * 3] * Ri[j] + RA[i * 3 + 1] * Ri[3 + j] + RA[i * 3 + 2] * Ri[6 + j];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        Ji[i * 6 + 0] = RA[i * 3 + 0]; Ji[i * 6 + 1] = RA[i * 3 + 1]; Ji[i * 6 + 2] = RA[i * 3 + 2];
+        // -(row) * skew(pb): row*S = [r1*pb2 - r2*pb1, r2*pb0 - r0*pb2, r0*pb1 - r1*pb0]
+        double x = RB[i * 3], y = RB[i * 3 + 1], z = RB[i * 3 + 2];
+        Ji[i * 6 + 3] = -(y * pb[2] - z * pb[1]);
+        Ji[i * 6 + 4] = -(z * pb[0] - x * pb[2]);
+        Ji[i * 6 + 5] = -(x * pb[1] - y * pb[0]);
+    }
+    // J_pose_j = [-RA, reduce ric^T [pts_imu_j]x]
+    double RC[6];                          // reduce * ric^T
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) RC[i * 3 + j] = red[i * 3] * ric[j * 3] + red[i * 3 + 1] * ric[j * 3 + 1] + red[i * 3 + 2] * ric[j * 3 + 2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        Jj[i * 6 + 0] = -RA[i * 3 + 0]; Jj[i * 6 + 1] = -RA[i * 3 + 1]; Jj[i * 6 + 2] = -RA[i * 3 + 2];
+        double x = RC[i * 3], y = RC[i * 3 + 1], z = RC[i * 3 + 2];
+        Jj[i * 6 + 3] = y * pbj[2] - z * pbj[1];
+        Jj[i * 6 + 4] = z * pbj[0] - x * pbj[2];
+        Jj[i * 6 + 5] = x * pbj[1] - y * pbj[0];
+    }
+    // J_lambda = reduce ric^T Rj^T Ri ric pts_i * -1/lambda^2 = RB * (ric * pts_i) * -inv^2
+    double v[3] = {ric[0] * pix + ric[1] * piy + ric[2] * piz, ric[3] * pix + ric[4] * piy + ric[5] * piz,
+                   ric[6] * pix + ric[7] * piy + ric[8] * piz};
+    double s = -inv * inv;
+    Jl[0] = (RB[0] * v[0] + RB[1] * v[1] + RB[2] * v[2]) * s;
+    Jl[1] = (RB[3] * v[0] + RB[4] * v[1] + RB[5] * v[2]) * s;
+}
+

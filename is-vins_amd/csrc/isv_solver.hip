@@ -18,6 +18,7 @@ __global__ void k_build_solve_lds(DevBatch d);
 __global__ void k_lm_prep(DevBatch d);
 __global__ void k_sweep(DevBatch d);
 __global__ void k_backsub(DevBatch d);
+__global__ void k_marg(DevBatch d);
 template <bool LDS_T> __global__ void k_build_solve(DevBatch d);
 
 // ------------------------------------------------------------------------------------------
@@ -123,28 +124,7 @@ __global__ __launch_bounds__(256) void k_dogleg(DevBatch d) {
 
 // ------------------------------------------------------------------------------------------
 // model cost change pieces: (J delta)^T (r + J delta / 2) per residual block, from the strips at x
-__global__ __launch_bounds__(256) void k_model_proj(DevBatch d) {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= d.Ftot) return;
-    const FactorRec rec = d.f_rec[f];
-    int lo = 0, hi = d.B;
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (d.f_off[mid] <= f) lo = mid; else hi = mid; }
-    const int w = lo;
-    const SolveState &st = d.st[w];
-    if (st.termination != ISV_TERM_RUNNING || !st.step_valid) return;
-    const double *s = d.strip + (size_t)f * ISV_PROJ_STRIP;
-    const double *dp = d.delta_p + (size_t)w * d.np;
-    const int fi = rec.ij & 255, fj = (rec.ij >> 8) & 255;
-    const double dl = d.delta_l[rec.lm];
-    double m0 = s[26] * dl, m1 = s[27] * dl;
-#pragma unroll
-    for (int c = 0; c < 6; c++) {
-        m0 += s[2 + c] * dp[15 * fi + c] + s[14 + c] * dp[15 * fj + c];
-        m1 += s[8 + c] * dp[15 * fi + c] + s[20 + c] * dp[15 * fj + c];
-    }
-    d.fmodel[f] = m0 * (s[0] + m0 / 2.0) + m1 * (s[1] + m1 / 2.0);
-}
-
+// (the reprojection factors' part is fused into k_proj_linearize<1>)
 __global__ __launch_bounds__(64) void k_model_imu_prior(DevBatch d) {
     __shared__ double sm[16];
     const int w = blockIdx.x / (d.N - 1 + 1), q = blockIdx.x % (d.N - 1 + 1), t = threadIdx.x;
@@ -198,67 +178,73 @@ __global__ __launch_bounds__(64) void k_model_imu_prior(DevBatch d) {
 }
 
 // ------------------------------------------------------------------------------------------
-// TrustRegionMinimizer: step validity, tolerances, acceptance, DoglegStrategy radius/mu update.
-__global__ void k_step_control(DevBatch d) {
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= d.B) return;
+// Candidate cost + model cost change (fixed-shape reductions), then TrustRegionMinimizer's step
+// validity / tolerances / acceptance and DoglegStrategy's radius / mu update.  One workgroup per window.
+__global__ __launch_bounds__(256) void k_step_control(DevBatch d) {
+    __shared__ double red[256];
+    __shared__ int s_accept;
+    const int w = blockIdx.x, t = threadIdx.x;
     SolveState &st = d.st[w];
     if (st.termination != ISV_TERM_RUNNING) return;
-    const int it = st.iteration, N = d.N;
-    double *tc = d.trace_cost + (size_t)w * ISV_MAX_TRACE, *tr = d.trace_radius + (size_t)w * ISV_MAX_TRACE;
-    double *ts = d.trace_step + (size_t)w * ISV_MAX_TRACE; int32_t *ta = d.trace_acc + (size_t)w * ISV_MAX_TRACE;
-    const double model_cost_change = -d.model[w];
-    bool valid = st.step_valid && (model_cost_change > 0.0);
-    if (!valid) {                                       // HandleInvalidStep
-        st.invalid += 1;
-        if (st.invalid >= 5) { st.termination = st.ls_fail ? ISV_TERM_LINEAR_SOLVER : ISV_TERM_INVALID_STEPS; return; }
-        st.mu *= 10.0; st.reuse = 0; st.need_linearize = 1;     // StepIsInvalid: recompute the GN step with a larger mu
-        tc[it] = st.x_cost; tr[it] = st.radius; ts[it] = 0; ta[it] = 0;
-        if (it >= d.max_iter) st.termination = ISV_TERM_MAX_ITERATIONS;
-        return;
+    const int N = d.N;
+    double S = 0, M = 0;
+    if (st.step_valid) {
+        double s = 0, m = 0;
+        for (int f = d.f_off[w] + t; f < d.f_off[w + 1]; f += 256) { s += d.fcost_c[f]; m += d.fmodel[f]; }
+        for (int i = t; i < N - 1; i += 256) { s += d.imu_cost_c[(size_t)w * (N - 1) + i]; m += d.imu_model[(size_t)w * (N - 1) + i]; }
+        for (int i = t; i < d.n_prior_slots; i += 256) { s += d.prior_cost_c[(size_t)w * d.n_prior_slots + i]; m += d.prior_model[(size_t)w * d.n_prior_slots + i]; }
+        S = block_sum<256>(s, red, t); M = block_sum<256>(m, red, t);
     }
-    st.invalid = 0;
-    const double cand_cost = d.cost_c[w];
-    const double step_norm = st.step_norm;
-    if (step_norm <= 1e-8 * (st.x_norm + 1e-8)) {
-        st.termination = ISV_TERM_PARAMETER_TOL; tc[it] = st.x_cost; tr[it] = st.radius; ts[it] = step_norm; ta[it] = 0; return;
+    if (t == 0) {
+        s_accept = 0;
+        const int it = st.iteration;
+        double *tc = d.trace_cost + (size_t)w * ISV_MAX_TRACE, *tr = d.trace_radius + (size_t)w * ISV_MAX_TRACE;
+        double *ts = d.trace_step + (size_t)w * ISV_MAX_TRACE; int32_t *ta = d.trace_acc + (size_t)w * ISV_MAX_TRACE;
+        const double model_cost_change = -M;
+        const bool valid = st.step_valid && (model_cost_change > 0.0);
+        d.cost_c[w] = S; d.model[w] = M;
+        if (!valid) {                                       // HandleInvalidStep
+            st.invalid += 1;
+            if (st.invalid >= 5) st.termination = st.ls_fail ? ISV_TERM_LINEAR_SOLVER : ISV_TERM_INVALID_STEPS;
+            else {
+                st.mu *= 10.0; st.reuse = 0; st.need_linearize = 1;     // StepIsInvalid: redo the GN solve with a larger mu
+                tc[it] = st.x_cost; tr[it] = st.radius; ts[it] = 0; ta[it] = 0;
+                if (it >= d.max_iter) st.termination = ISV_TERM_MAX_ITERATIONS;
+            }
+        } else {
+            st.invalid = 0;
+            const double cand_cost = S, step_norm = st.step_norm;
+            if (step_norm <= 1e-8 * (st.x_norm + 1e-8)) {
+                st.termination = ISV_TERM_PARAMETER_TOL; tc[it] = st.x_cost; tr[it] = st.radius; ts[it] = step_norm; ta[it] = 0;
+            } else if (fabs(st.x_cost - cand_cost) <= 1e-6 * st.x_cost) {
+                st.termination = ISV_TERM_FUNCTION_TOL; tc[it] = st.x_cost; tr[it] = st.radius; ts[it] = step_norm; ta[it] = 0;
+            } else {
+                const double rel = (st.x_cost - cand_cost) / model_cost_change;
+                if (rel > 1e-3) {                           // HandleSuccessfulStep
+                    s_accept = 1;
+                    st.x_cost = cand_cost;                   // refreshed by the next linearisation
+                    if (rel < 0.25) st.radius *= 0.5;
+                    if (rel > 0.75) st.radius = fmax(st.radius, 3.0 * st.dogleg_step_norm);
+                    st.mu = fmax(1e-8, 2.0 * st.mu / 10.0);
+                    st.reuse = 0; st.need_linearize = 1; st.num_successful += 1;
+                    tc[it] = cand_cost; tr[it] = st.radius; ts[it] = step_norm; ta[it] = 1;
+                } else {                                    // StepRejected
+                    st.radius *= 0.5; st.reuse = 1;
+                    tc[it] = cand_cost; tr[it] = st.radius; ts[it] = step_norm; ta[it] = 0;
+                }
+                // FinalizeIterationAndCheckIfMinimizerCanContinue (gradient tolerance: k_build_solve)
+                if (it >= d.max_iter) st.termination = ISV_TERM_MAX_ITERATIONS;
+                else if (st.radius <= 1e-32) st.termination = ISV_TERM_MIN_RADIUS;
+            }
+        }
     }
-    if (fabs(st.x_cost - cand_cost) <= 1e-6 * st.x_cost) {
-        st.termination = ISV_TERM_FUNCTION_TOL; tc[it] = st.x_cost; tr[it] = st.radius; ts[it] = step_norm; ta[it] = 0; return;
-    }
-    const double rel = (st.x_cost - cand_cost) / model_cost_change;
-    if (rel > 1e-3) {                                   // HandleSuccessfulStep
+    __syncthreads();
+    if (s_accept) {
         const int l0 = d.lm_off[w], l1 = d.lm_off[w + 1];
-        for (int i = 0; i < N * 7; i++) d.pose[(size_t)w * N * 7 + i] = d.cpose[(size_t)w * N * 7 + i];
-        for (int i = 0; i < N * 9; i++) d.sb[(size_t)w * N * 9 + i] = d.csb[(size_t)w * N * 9 + i];
-        for (int l = l0; l < l1; l++) d.lam[l] = d.clam[l];
-        st.x_cost = cand_cost;                           // refreshed by the next linearisation
-        if (rel < 0.25) st.radius *= 0.5;
-        if (rel > 0.75) st.radius = fmax(st.radius, 3.0 * st.dogleg_step_norm);
-        st.mu = fmax(1e-8, 2.0 * st.mu / 10.0);
-        st.reuse = 0; st.need_linearize = 1; st.num_successful += 1;
-        tc[it] = cand_cost; tr[it] = st.radius; ts[it] = step_norm; ta[it] = 1;
-    } else {                                            // StepRejected
-        st.radius *= 0.5; st.reuse = 1;
-        tc[it] = cand_cost; tr[it] = st.radius; ts[it] = step_norm; ta[it] = 0;
+        for (int i = t; i < N * 7; i += 256) d.pose[(size_t)w * N * 7 + i] = d.cpose[(size_t)w * N * 7 + i];
+        for (int i = t; i < N * 9; i += 256) d.sb[(size_t)w * N * 9 + i] = d.csb[(size_t)w * N * 9 + i];
+        for (int l = l0 + t; l < l1; l += 256) d.lam[l] = d.clam[l];
     }
-    // FinalizeIterationAndCheckIfMinimizerCanContinue (gradient tolerance is checked by k_build_solve)
-    if (it >= d.max_iter) st.termination = ISV_TERM_MAX_ITERATIONS;
-    else if (st.radius <= 1e-32) st.termination = ISV_TERM_MIN_RADIUS;
-}
-
-// cost of candidate + model sum, per window (fixed-shape reduction)
-__global__ __launch_bounds__(256) void k_reduce_cand(DevBatch d) {
-    __shared__ double red[256];
-    const int w = blockIdx.x, t = threadIdx.x;
-    const SolveState &st = d.st[w];
-    if (st.termination != ISV_TERM_RUNNING || !st.step_valid) return;
-    double s = 0, m = 0;
-    for (int f = d.f_off[w] + t; f < d.f_off[w + 1]; f += 256) { s += d.fcost_c[f]; m += d.fmodel[f]; }
-    for (int i = t; i < d.N - 1; i += 256) { s += d.imu_cost_c[(size_t)w * (d.N - 1) + i]; m += d.imu_model[(size_t)w * (d.N - 1) + i]; }
-    for (int i = t; i < d.n_prior_slots; i += 256) { s += d.prior_cost_c[(size_t)w * d.n_prior_slots + i]; m += d.prior_model[(size_t)w * d.n_prior_slots + i]; }
-    const double S = block_sum<256>(s, red, t), M = block_sum<256>(m, red, t);
-    if (t == 0) { d.cost_c[w] = S; d.model[w] = M; }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -389,8 +375,8 @@ int isv_solver_alloc(DevBatch &d, size_t B, size_t L, size_t F, std::vector<void
     const size_t nblkT = (size_t)d.N * (d.N + 1) / 2 * 225;
     d.lds_T = (d.N <= 11 && build_solve_lds2_bytes(d.N) <= 160 * 1024) ? 1 : 0;
     TRYA(dal(&d.Tglob, d.lds_T ? 1 : B * nblkT, allocs, err));
-    d.marg_scratch_sz = 0;
-    d.marg_scratch = nullptr;
+    d.marg_scratch_sz = 26;
+    TRYA(dal(&d.marg_scratch, L * 26, allocs, err));
     if (d.lds_T) HCHK(hipFuncSetAttribute((const void *)k_build_solve_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)build_solve_lds2_bytes(d.N)));
     else HCHK(hipFuncSetAttribute((const void *)k_build_solve<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)build_solve_lds_bytes(d.N, false)));
     return ISV_OK;
@@ -417,12 +403,11 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, int64_t *counts, std::string
         if (d.n_tiles > 0) hipLaunchKernelGGL(k_proj_linearize<1>, dim3((d.n_tiles + 3) / 4), dim3(256), lds_proj, st, d, d.cpose, d.clam, d.fcost_c, 2);
         if (NI) hipLaunchKernelGGL(k_imu_linearize<false>, dim3((unsigned)NI), dim3(64), 0, st, d, d.cpose, d.csb, d.imu_cost_c, 2);
         hipLaunchKernelGGL(k_prior_linearize<false>, dim3((d.B * d.n_prior_slots + 63) / 64), dim3(64), 0, st, d, d.cpose, d.csb, d.prior_cost_c, 2);
-        if (d.Ftot) hipLaunchKernelGGL(k_model_proj, dim3((d.Ftot + 255) / 256), dim3(256), 0, st, d);
         hipLaunchKernelGGL(k_model_imu_prior, dim3(d.B * d.N), dim3(64), 0, st, d);
-        hipLaunchKernelGGL(k_reduce_cand, dim3(d.B), dim3(256), 0, st, d);
-        hipLaunchKernelGGL(k_step_control, dim3((d.B + 63) / 64), dim3(64), 0, st, d);
+        hipLaunchKernelGGL(k_step_control, dim3(d.B), dim3(256), 0, st, d);
     }
     hipLaunchKernelGGL(k_finalize, dim3((d.B + 63) / 64), dim3(64), 0, st, d);
+    hipLaunchKernelGGL(k_marg, dim3(d.B), dim3(64), 0, st, d);
     HCHK(hipGetLastError());
     return ISV_OK;
 }

@@ -84,3 +84,55 @@ def test_landmark_free_window(oracle, be):
     o, so, _ = oracle_run(oracle, be.cfg, w0)
     g = w0.clone(); sg, _ = be.optimize(g)
     check_window(o, so, g, sg)
+
+
+def _info(U, n):
+    U = np.asarray(U).reshape(n, n)
+    return U.T @ U
+
+
+def check_marg(mo, mg, Nvo):
+    """MargForward / MargBackward outputs.  The recovered factors' information matrices (sqrt_info^T
+    sqrt_info) are compared, relative to their largest entry: 1e-6 (they go through an
+    eigen-decomposition and several small inverses; the GPU uses Jacobi sweeps + Gauss-Jordan)."""
+    assert mg.valid == 1 and mg.n_marg_landmarks == mo.n_marg_landmarks
+    for name, n in (("forward_pose_prior", 6), ("backward_relpose", 6), ("backward_vb", 9), ("backward_rollpitch", 2)):
+        a, b = _info(getattr(mg, name).sqrt_info, n), _info(getattr(mo, name).sqrt_info, n)
+        assert np.abs(a - b).max() < 1e-6 * np.abs(b).max(), (name, np.abs(a - b).max() / np.abs(b).max())
+        U = np.asarray(getattr(mg, name).sqrt_info).reshape(n, n)
+        assert np.allclose(np.tril(U, -1), 0)
+    a, b = _info(mg.combined.relative_pose.sqrt_info, 6), _info(mo.combined.relative_pose.sqrt_info, 6)
+    assert np.abs(a - b).max() < 1e-6 * np.abs(b).max()
+    for f in ("t", "R"):
+        assert np.allclose(abi.arr(getattr(mg.forward_pose_prior, f)), abi.arr(getattr(mo.forward_pose_prior, f)), atol=1e-7)
+    for obj_g, obj_o in ((mg.backward_relpose, mo.backward_relpose), (mg.combined.relative_pose, mo.combined.relative_pose)):
+        assert np.allclose(abi.arr(obj_g.delta_t), abi.arr(obj_o.delta_t), atol=1e-7)
+        assert np.allclose(abi.arr(obj_g.delta_R), abi.arr(obj_o.delta_R), atol=1e-7)
+        assert (obj_g.imu_i, obj_g.imu_j) == (obj_o.imu_i, obj_o.imu_j)
+    assert np.allclose(abi.arr(mg.backward_vb.VB), abi.arr(mo.backward_vb.VB), atol=1e-7)
+    assert np.allclose(abi.arr(mg.backward_rollpitch.R), abi.arr(mo.backward_rollpitch.R), atol=1e-7)
+    assert mg.backward_rollpitch.index == Nvo - 1 and mg.backward_vb.index == mo.backward_vb.index
+    assert np.allclose(abi.arr(mg.combined.covRel), abi.arr(mo.combined.covRel), rtol=1e-5, atol=1e-6 * np.abs(abi.arr(mo.combined.covRel)).max())
+    assert mg.combined.has_rollpitch == mo.combined.has_rollpitch
+    assert np.allclose(abi.arr(mg.combined.covAbs), abi.arr(mo.combined.covAbs), rtol=1e-6)
+    assert abs(mg.combined.distance - mo.combined.distance) < 1e-7 and mg.combined.ts == mo.combined.ts
+    assert np.allclose(abi.arr(mg.combined.Ri), abi.arr(mo.combined.Ri), atol=1e-7) and np.allclose(abi.arr(mg.combined.ti), abi.arr(mo.combined.ti), atol=1e-7)
+    assert abs(mg.forward_kld - mo.forward_kld) < 1e-6
+    assert abs(mg.backward_kld - mo.backward_kld) < 1e-5 * max(1.0, abs(mo.backward_kld))
+
+
+@pytest.mark.parametrize("wid", [0, 21])
+def test_marginalisation_matches_oracle(oracle, be, wid):
+    w = synth.make_window(wid)                      # margin_old = 1
+    o, so, mo = oracle_run(oracle, be.cfg, w)
+    g = w.clone()
+    sg, mg = be.optimize(g)
+    check_window(o, so, g, sg)
+    check_marg(mo, mg, w.Nvo)
+
+
+def test_margin_new_skips_marginalisation(oracle, be):
+    w = synth.make_window(22, margin_old=0)
+    g = w.clone()
+    sg, mg = be.optimize(g)
+    assert mg.valid == 0 and mg.n_marg_landmarks == 0
