@@ -116,36 +116,44 @@ def main():
     if rank == 0:
         ms_step = 1e3 * dt / args.steps
         value = world * W * args.steps / dt
-        # roofline of the dominant kernel family (largest summed duration in the step)
-        n_lin = max(int(cnt[0]), 1); n_bs = max(int(cnt[1]), 1)
-        lin_ms, bs_ms = float(fam[1]), float(fam[3])
         N, L = args.frames, args.landmarks
         Fw = Ftot / W
-        # algorithmic work per k_build_solve launch (all windows of the batch):
-        #   flops: H_pp + Schur 2*36*sum k(k+1)/2 per landmark (~k=4.5), IMU 10*2*15*465, Cholesky (15N)^3/3, solves
-        flops_bs = W * (2 * 36 * L * 12.4 * 2 + (N - 1) * 2 * 15 * 465 + (15 * N) ** 3 / 3 + 2 * (15 * N) ** 2)
-        bytes_lin = Ftot * 292.0
-        roof_lin = {"kernel": "k_proj_linearize<0>", "bound": "hbm", "achieved": bytes_lin / (lin_ms / n_lin * 1e-3) / 1e9 if lin_ms > 0 else None,
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": None}
-        if roof_lin["achieved"]:
-            roof_lin["frac"] = roof_lin["achieved"] / HBM_PEAK_GBS
-        roof_bs = {"kernel": "k_build_solve", "bound": "mfma", "achieved": flops_bs / (bs_ms / n_bs * 1e-3) / 1e12 if bs_ms > 0 else None,
-                   "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "traffic": None}
-        if roof_bs["achieved"]:
-            roof_bs["frac"] = roof_bs["achieved"] / FP64_PEAK_TFLOPS
-        dominant = roof_bs if bs_ms >= lin_ms else roof_lin
+        obs_tot = Ftot + W * L
+        n_lin, n_bs, n_sw = max(int(cnt[0]), 1), max(int(cnt[1]), 1), max(int(cnt[2]), 1)
+        lin_ms, sw_ms, bs_ms = float(fam[1]), float(fam[2]), float(fam[3])
+        # algorithmic work per launch over the whole batch
+        bytes_lin = Ftot * 292.0 + Ftot * 48.0                      # 60 B in + 232 B strips/cost out + 48 B w vector
+        bytes_sweep = Ftot * 224.0 + obs_tot * 48.0 + W * (36 * N * (N + 1) / 2 + 18 * N) * 8.0
+        flops_bs = W * ((15 * N) ** 3 / 3.0 + 4.0 * (15 * N) ** 2 + 2.0 * (15 * N) ** 2 / 2)   # Cholesky + 2 triangular solves + u^T T u
+        pmc = {}
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+        except Exception:
+            pmc = {}
+
+        def roof(kernel, bound, work, ms_sum, launches, peak, unit, scale):
+            per = ms_sum / launches * 1e-3 if ms_sum > 0 else None
+            ach = work / per / scale if per else None
+            t = pmc.get(kernel, {}).get("hbm_bytes_per_launch") if pmc.get("windows_per_gpu") == W else None
+            return {"kernel": kernel, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
+                    "frac": (ach / peak) if ach else None, "traffic": t,
+                    "avg_launch_us": per * 1e6 if per else None, "launches_per_step": launches}
+
+        roofs = [roof("k_build_solve_lds", "mfma", flops_bs, bs_ms, n_bs, FP64_PEAK_TFLOPS, "TFLOP/s", 1e12),
+                 roof("k_sweep", "hbm", bytes_sweep, sw_ms, n_sw, HBM_PEAK_GBS, "GB/s", 1e9),
+                 roof("k_proj_linearize<0>", "hbm", bytes_lin, lin_ms, n_lin, HBM_PEAK_GBS, "GB/s", 1e9)]
+        sums = {"k_build_solve_lds": bs_ms, "k_sweep": sw_ms, "k_proj_linearize<0>": lin_ms}
+        dominant = max(roofs, key=lambda r: sums[r["kernel"]])
         out = {
             "metric": "sliding-window solves/sec (11 KF, ~300 landmarks)", "value": value, "unit": "windows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "ms_per_optimize_batched": ms_step / W,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{W} independent synthetic sliding windows per GPU (N={N} KF, Nvo={args.vo}, L={L} landmarks, F~{Fw:.0f} reprojection factors each; BASELINE config 4 batch of config-2 windows), full backendOptimization() with NUM_ITERATIONS=10",
+            "config": {"workload": f"{W} independent synthetic sliding windows per GPU (N={N} KF, Nvo={args.vo}, L={L} landmarks, F~{Fw:.0f} reprojection factors each; BASELINE config 4 batch of config-2 windows), full backendOptimization(): NUM_ITERATIONS=10 dogleg iterations + update() + double2vector + MargForward/MargBackward on every window",
                        "windows_per_gpu": W, "frames": N, "landmarks": L, "factors_total": Ftot, "iterations_cap": 10,
                        "parallelism": f"independent windows sharded over {world} rank(s), no data-path collective"},
-            "roofline": dominant,
-            "roofline_linearize": roof_lin, "roofline_build_solve": roof_bs,
-            "kernel_ms": {"step_total": float(fam[0]), "proj_linearize_sum": lin_ms, "build_solve_sum": bs_ms,
-                          "proj_linearize_launches": int(cnt[0]), "build_solve_launches": int(cnt[1])},
+            "roofline": dominant, "roofline_by_kernel": roofs,
+            "kernel_ms": {"step_total_events": float(fam[0]), "proj_linearize_sum": lin_ms, "sweep_sum": sw_ms, "build_solve_sum": bs_ms},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(windows, be.cfg)

@@ -237,7 +237,8 @@ int  isv_batch_download(isv_backend_t *h, int32_t n, isv_window_t *const *w,
                         isv_summary_t *summary, isv_marg_result_t *marg);
 int  isv_batch_sync(isv_backend_t *h);
 /* HIP-event timing of the last isv_batch_* launch sequence, milliseconds, per kernel family:
- * out[0]=total, [1]=proj linearize, [2]=imu+prior linearize, [3]=build+solve, [4]=step/eval,
+ * after isv_batch_linearize: out[0]=total, [1]=k_proj_linearize, [2]=imu+prior+reduce;
+ * after isv_batch_optimize:  out[0]=total, [1]=sum k_proj_linearize<0>, [2]=sum k_sweep, [3]=sum k_build_solve*,
  * [5]=marg.  Events are recorded on the handle's own stream.                              */
 int  isv_batch_last_timing(isv_backend_t *h, double out_ms[8]);
 /* launches of the dominant (projection linearise) kernel in the last run */

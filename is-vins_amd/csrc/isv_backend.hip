@@ -25,6 +25,8 @@ struct isv_backend {
     std::string err;
     hipStream_t stream = nullptr;
     hipEvent_t ev[8] = {};
+    std::vector<hipEvent_t> prof_ev;      // [max_iter][ISV_PROF_FAMILIES][2]
+    int prof_valid = 0;
     DevBatch d{};                 // device pointers
     std::vector<void *> allocs;
     // capacities
@@ -75,6 +77,7 @@ extern "C" void isv_backend_destroy(isv_backend_t *h) {
     for (void *p : h->allocs) (void)hipFree(p);
     for (void *p : h->hallocs) (void)hipHostFree(p);
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
+    for (auto &e : h->prof_ev) if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -86,6 +89,8 @@ static int create_impl(isv_backend *h) {
     if (ndev <= 0) { h->err = "no HIP device"; return ISV_ERR_DEVICE; }
     HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     for (auto &e : h->ev) HIPCHK(h, hipEventCreate(&e));
+    h->prof_ev.assign((size_t)c.num_iterations * ISV_PROF_FAMILIES * 2, nullptr);
+    for (auto &e : h->prof_ev) HIPCHK(h, hipEventCreate(&e));
     const size_t B = c.max_batch, N = c.n_frames, L = B * (size_t)c.max_landmarks, F = B * (size_t)c.max_obs;
     const size_t T = F / ISV_TILE + B + 1;
     h->capB = B; h->capL = L; h->capF = F; h->capTiles = T;
@@ -307,6 +312,7 @@ extern "C" int isv_batch_linearize(isv_backend_t *h, int32_t sync) {
     DevBatch &d = h->d; hipStream_t st = h->stream;
     memset(h->last_counts, 0, sizeof(h->last_counts));
     HIPCHK(h, hipEventRecord(h->ev[0], st));
+    h->prof_valid = 0;
     TRY(restore_initial(h));
     hipLaunchKernelGGL(k_vector2double, dim3(d.B), dim3(64), 0, st, d);
     TRY(enqueue_linearize(h, true));
@@ -323,7 +329,14 @@ extern "C" int isv_batch_last_timing(isv_backend_t *h, double out_ms[8]) {
     if (hipEventElapsedTime(&ms, h->ev[0], h->ev[4]) == hipSuccess) out_ms[0] = ms;
     if (hipEventElapsedTime(&ms, h->ev[1], h->ev[2]) == hipSuccess) out_ms[1] = ms;
     if (hipEventElapsedTime(&ms, h->ev[2], h->ev[3]) == hipSuccess) out_ms[2] = ms;
-    for (int i = 3; i < 8; i++) out_ms[i] = h->last_ms[i];
+    if (h->prof_valid) {     // optimize path: [1] = sum k_proj_linearize<0>, [2] = sum k_sweep, [3] = sum k_build_solve
+        out_ms[1] = out_ms[2] = out_ms[3] = 0;
+        for (int slot = 0; slot < h->cfg.num_iterations; slot++)
+            for (int fam = 0; fam < ISV_PROF_FAMILIES; fam++) {
+                const size_t b = ((size_t)slot * ISV_PROF_FAMILIES + fam) * 2;
+                if (hipEventElapsedTime(&ms, h->prof_ev[b], h->prof_ev[b + 1]) == hipSuccess) out_ms[1 + fam] += ms;
+            }
+    }
     return ISV_OK;
 }
 
@@ -340,7 +353,8 @@ extern "C" int isv_batch_optimize(isv_backend_t *h, int32_t sync) {
     HIPCHK(h, hipEventRecord(h->ev[0], st));
     TRY(restore_initial(h));
     hipLaunchKernelGGL(k_vector2double, dim3(d.B), dim3(64), 0, st, d);
-    int rc = isv_solver_enqueue(h->d, st, h->last_counts, h->err);
+    int rc = isv_solver_enqueue(h->d, st, h->last_counts, h->prof_ev.empty() ? nullptr : h->prof_ev.data(), h->err);
+    h->prof_valid = 1;
     if (rc != ISV_OK) return rc;
     HIPCHK(h, hipEventRecord(h->ev[4], st));
     if (sync) HIPCHK(h, hipStreamSynchronize(st));

@@ -17,6 +17,11 @@
 #include "isv_proj_factor.h"
 
 #define MT 64
+#ifdef ISV_STAMP
+#define MSTAMP(k) do { if (t == 0) { unsigned long long now_ = wall_clock64(); d.dbg[(size_t)w * 64 + 32 + (k)] += (double)(now_ - t_last); t_last = now_; } } while (0)
+#else
+#define MSTAMP(k) do {} while (0)
+#endif
 #define SYNC() __syncthreads()
 
 // ---- wave-cooperative dense helpers on LDS matrices (row-major) --------------------------------
@@ -71,10 +76,15 @@ DEV void w_chol_upper(const double *M, int n, double *U, double *L, int t) {
     for (int e = t; e < n * n; e += MT) { const int i = e / n, j = e % n; U[e] = (j >= i) ? L[j * n + i] : 0.0; }
     SYNC();
 }
-// cyclic Jacobi: A (destroyed) = V diag(w) V^T
+// Jacobi eigen-decomposition with a round-robin (tournament) ordering: the floor(n/2) rotations of a
+// round touch disjoint index pairs, so they are computed and applied together (3 barriers per round
+// instead of 3 per rotation).  A (destroyed) = V diag(w) V^T.  rot: scratch [3 * 16] doubles + pairs.
 DEV void w_jacobi(double *A, int n, double *wv, double *V, double *tmp, int t) {
+    __shared__ double rc[16], rs[16];
+    __shared__ int rp[16], rq[16];
     for (int e = t; e < n * n; e += MT) V[e] = (e / n == e % n) ? 1.0 : 0.0;
     SYNC();
+    const int m = n + (n & 1), half = m / 2;
     for (int sweep = 0; sweep < 60; sweep++) {
         double off = 0, dg = 0;
         for (int e = t; e < n * n; e += MT) { const int i = e / n, j = e % n; if (j > i) off += A[e] * A[e]; else if (i == j) dg += A[e] * A[e]; }
@@ -84,23 +94,56 @@ DEV void w_jacobi(double *A, int n, double *wv, double *V, double *tmp, int t) {
         const double offs = tmp[0], dgs = tmp[64];
         SYNC();
         if (offs <= 1e-60 || offs <= 1e-34 * dgs) break;
-        for (int p = 0; p < n - 1; p++) for (int q = p + 1; q < n; q++) {
-            const double apq = A[p * n + q];
-            if (apq == 0.0) continue;                 // uniform (LDS value)
-            const double app = A[p * n + p], aqq = A[q * n + q];
-            const double theta = (aqq - app) / (2.0 * apq);
-            const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-            const double c = 1.0 / sqrt(tt * tt + 1.0), s = tt * c;
+        for (int r = 0; r < m - 1; r++) {
+            if (t < half) {
+                int a = (t == 0) ? m - 1 : (r + t) % (m - 1);
+                int b = (t == 0) ? r : (r + m - 1 - t) % (m - 1);
+                int p = a < b ? a : b, q = a < b ? b : a;
+                double c = 1.0, sn = 0.0;
+                if (q < n) {
+                    const double apq = A[p * n + q];
+                    if (apq != 0.0) {
+                        const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
+                        const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                        c = 1.0 / sqrt(tt * tt + 1.0); sn = tt * c;
+                    }
+                } else { p = 0; q = 0; }           // dummy pairing: identity rotation on (0,0) is skipped below
+                rp[t] = p; rq[t] = q; rc[t] = c; rs[t] = sn;
+            }
             SYNC();
-            for (int k = t; k < n; k += MT) { const double akp = A[k * n + p], akq = A[k * n + q]; A[k * n + p] = c * akp - s * akq; A[k * n + q] = s * akp + c * akq; }
+            for (int e = t; e < half * n; e += MT) {     // columns
+                const int pr = e / n, k = e % n, p = rp[pr], q = rq[pr];
+                if (p != q) { const double c = rc[pr], sn = rs[pr], akp = A[k * n + p], akq = A[k * n + q]; A[k * n + p] = c * akp - sn * akq; A[k * n + q] = sn * akp + c * akq; }
+            }
             SYNC();
-            for (int k = t; k < n; k += MT) { const double apk = A[p * n + k], aqk = A[q * n + k]; A[p * n + k] = c * apk - s * aqk; A[q * n + k] = s * apk + c * aqk; }
-            for (int k = t; k < n; k += MT) { const double vkp = V[k * n + p], vkq = V[k * n + q]; V[k * n + p] = c * vkp - s * vkq; V[k * n + q] = s * vkp + c * vkq; }
+            for (int e = t; e < half * n; e += MT) {     // rows, and the eigenvector columns
+                const int pr = e / n, k = e % n, p = rp[pr], q = rq[pr];
+                if (p != q) {
+                    const double c = rc[pr], sn = rs[pr], apk = A[p * n + k], aqk = A[q * n + k];
+                    A[p * n + k] = c * apk - sn * aqk; A[q * n + k] = sn * apk + c * aqk;
+                    const double vkp = V[k * n + p], vkq = V[k * n + q];
+                    V[k * n + p] = c * vkp - sn * vkq; V[k * n + q] = sn * vkp + c * vkq;
+                }
+            }
             SYNC();
         }
     }
     for (int i = t; i < n; i += MT) wv[i] = A[i * n + i];
     SYNC();
+}
+// log(det(A)) of a symmetric positive-definite matrix by unpivoted elimination (lane-parallel)
+DEV double w_logdet_spd(const double *A, int n, double *W, int t) {
+    for (int e = t; e < n * n; e += MT) W[e] = A[e];
+    SYNC();
+    double ld = 0;
+    for (int k = 0; k < n; k++) {
+        const double d = W[k * n + k];
+        ld += log(d);
+        SYNC();
+        for (int e = t; e < n * n; e += MT) { const int i = e / n, j = e % n; if (i > k && j > k) W[e] -= W[i * n + k] * W[k * n + j] / d; }
+        SYNC();
+    }
+    return ld;
 }
 // Sigma = (Jk U) D^-1 (Jk U)^T over the kept eigenpairs (keep[i] != 0); Jk is rows x n
 DEV void w_project_cov(const double *Jk, int rows, int n, const double *V, const double *wv, const int *keep, double *JU, double *Sigma, int t) {
@@ -166,6 +209,9 @@ __global__ __launch_bounds__(MT) void k_marg(DevBatch d) {
     }
     SYNC();
     if (!d.margin_old[w]) return;
+#ifdef ISV_STAMP
+    unsigned long long t_last = wall_clock64();
+#endif
     const int N = d.N, v = d.Nvo;
     const double *pose = d.pose + (size_t)w * N * 7, *sb = d.sb + (size_t)w * N * 9, *ex = d.ex + (size_t)w * 7;
     const int l0 = d.lm_off[w], l1 = d.lm_off[w + 1];
@@ -202,20 +248,35 @@ __global__ __launch_bounds__(MT) void k_marg(DevBatch d) {
     }
     __threadfence_block();
     SYNC();
+    MSTAMP(0);
     // raw pose block Hraw (12x12, order [T1, T0]) in Lam[0..143]; Schur-reduced over the landmarks in M1[0..143]
-    for (int e = t; e < 144; e += MT) {
-        const int a = e / 12, b = e % 12;
-        double hr = 0, hs = 0;
-        for (int m = 0; m < n0; m++) {
-            const double *o = Jw + (size_t)m * 26;
-            const double h = o[a] * o[b] + o[13 + a] * o[13 + b];
-            const double ba = o[a] * o[12] + o[13 + a] * o[25], bb = o[b] * o[12] + o[13 + b] * o[25];
-            const double dm = o[12] * o[12] + o[25] * o[25];
-            hr += h; hs += h - ba * bb / dm;
+    {
+        double hr[3] = {0, 0, 0}, hs[3] = {0, 0, 0};
+        for (int mb = 0; mb < n0; mb += 64) {
+            const int cnt = (n0 - mb) < 64 ? (n0 - mb) : 64;
+            for (int e = t; e < cnt * 26; e += MT) Wk[e] = Jw[(size_t)mb * 26 + e];
+            SYNC();
+            for (int m = 0; m < cnt; m++) {
+                const double *o = Wk + m * 26;
+                const double dmi = 1.0 / (o[12] * o[12] + o[25] * o[25]);
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    const int e = t + 64 * i;
+                    if (e < 144) {
+                        const int a = e / 12, b = e % 12;
+                        const double h = o[a] * o[b] + o[13 + a] * o[13 + b];
+                        const double ba = o[a] * o[12] + o[13 + a] * o[25], bb = o[b] * o[12] + o[13 + b] * o[25];
+                        hr[i] += h; hs[i] += h - ba * bb * dmi;
+                    }
+                }
+            }
+            SYNC();
         }
-        Lam[e] = hr; M1[e] = hs;
+#pragma unroll
+        for (int i = 0; i < 3; i++) { const int e = t + 64 * i; if (e < 144) { Lam[e] = hr[i]; M1[e] = hs[i]; } }
     }
     SYNC();
+    MSTAMP(1);
     // pose prior on T0 and relative-pose edge (0,1): unweighted Jacobians, info = S^T S
     if (t == 0) {
         const isv_se3_prior_t &f = d.se3[w];
@@ -240,6 +301,7 @@ __global__ __launch_bounds__(MT) void k_marg(DevBatch d) {
         for (int e = t; e < 144; e += MT) { const int a = e / 12, b = e % 12; double s = 0; for (int k = 0; k < 6; k++) s += M2[k * 12 + a] * M2[k * 12 + b]; Lam[e] += s; M1[e] += s; }
         SYNC();
     }
+    MSTAMP(2);
     // (i) pose-graph edge (estimator.cpp:1240-1283)
     isv_relpose_t &pg = out.combined.relative_pose;
     if (t == 0) {
@@ -291,6 +353,7 @@ __global__ __launch_bounds__(MT) void k_marg(DevBatch d) {
         for (int k = 0; k < 9; k++) out.combined.Ri[k] = d.Rs[(size_t)w * N * 9 + k];
         for (int k = 0; k < 3; k++) out.combined.ti[k] = d.Ps[(size_t)w * N * 3 + k];
     }
+    MSTAMP(3);
     // (ii) new pose prior on T1: eliminate T0 from the landmark-reduced block M1
     {
         double *A66 = Wk, *Ainv = Wk + 64, *Lp = Wk + 128, *cov = Wk + 192, *covi = Wk + 256, *X = Wk + 320, *T = Wk + 384;
@@ -365,6 +428,7 @@ __global__ __launch_bounds__(MT) void k_marg(DevBatch d) {
         if (t == 0) { out.forward_kld = kld; out.n_marg_landmarks = n0; out.valid = 1; }
         SYNC();
     }
+    MSTAMP(4);
     // ================= MargBackward =================
     // order: T1 = frame v (@0), VB1 (@6), T0 = frame v-1 (@15), VB0 (@21)
     for (int e = t; e < 900; e += MT) Lam[e] = 0.0;
@@ -472,12 +536,14 @@ __global__ __launch_bounds__(MT) void k_marg(DevBatch d) {
         for (int b = 0; b < 3; b++) Jr[20 * 21 + 18 + b] += By[3 + b];
     }
     SYNC();
+    MSTAMP(5);
     // eigen-truncate Lp at ALPHA
     for (int e = t; e < 441; e += MT) M2[e] = Lp[e];
     SYNC();
     w_jacobi(M2, 21, wv, Vv, tmp, t);
     if (t < 21) keep[t] = wv[t] > d.alpha_cut;
     SYNC();
+    MSTAMP(6);
     {
         double *Sg = Wk, *Xi = Wk + 100, *Xall = Wk + 1000;      // Xall: 21x21 block-diagonal information
         for (int e = t; e < 441; e += MT) Xall[e] = 0.0;
@@ -495,6 +561,7 @@ __global__ __launch_bounds__(MT) void k_marg(DevBatch d) {
                 SYNC();
             }
         }
+        MSTAMP(7);
         // zero test / KLD (estimator.cpp:1519-1534): A = (Jr U)^T X (Jr U) over the kept eigenpairs vs D
         int rank = 0; for (int k = 0; k < 21; k++) rank += keep[k];
         double *JUa = Wk, *XJU = Wk + 450, *A = M2;
@@ -514,11 +581,12 @@ __global__ __launch_bounds__(MT) void k_marg(DevBatch d) {
             for (int a = 0; a < 21; a++) if (keep[a]) { int ib = 0; for (int b = 0; b < 21; b++) if (keep[b]) { Ak[ia * rank + ib] = A[a * 21 + b]; ib++; } ia++; }
         }
         SYNC();
-        const double detA = w_det(Ak, rank, Lam, piv, t);
+        const double ldA = w_logdet_spd(Ak, rank, Lam, t);
         if (t == 0) {
             double tr = 0, ldinv = 0; int ia = 0;
             for (int a = 0; a < 21; a++) if (keep[a]) { tr += Ak[ia * rank + ia] / wv[a]; ldinv += log(1.0 / wv[a]); ia++; }
-            out.backward_kld = 0.5 * (tr - log(detA) - ldinv - 21);
+            out.backward_kld = 0.5 * (tr - ldA - ldinv - 21);
         }
+        MSTAMP(8);
     }
 }

@@ -382,22 +382,31 @@ int isv_solver_alloc(DevBatch &d, size_t B, size_t L, size_t F, std::vector<void
     return ISV_OK;
 }
 
-int isv_solver_enqueue(DevBatch &d, hipStream_t st, int64_t *counts, std::string &err) {
+// prof_ev (optional): [max_iter][ISV_PROF_FAMILIES][2] events recorded around the three dominant
+// kernel families on the solve stream, so bench.py can report per-kernel durations measured live.
+int isv_solver_enqueue(DevBatch &d, hipStream_t st, int64_t *counts, hipEvent_t *prof_ev, std::string &err) {
+#define PROF(slot, fam, which) do { if (prof_ev) (void)hipEventRecord(prof_ev[((slot) * ISV_PROF_FAMILIES + (fam)) * 2 + (which)], st); } while (0)
     const size_t NI = (size_t)d.B * (d.N - 1);
     const size_t lds_proj = 4 * proj_lds_doubles_per_wave(d.N) * sizeof(double);
     const size_t lds_bs = d.lds_T ? build_solve_lds2_bytes(d.N) : build_solve_lds_bytes(d.N, false);
     hipLaunchKernelGGL(k_init_state, dim3((d.B + 63) / 64), dim3(64), 0, st, d);
     for (int slot = 0; slot < d.max_iter; slot++) {
         // linearise where needed (k_*_linearize skip windows whose need_linearize == 0 via the tile/window flags)
+        PROF(slot, 0, 0);
         if (d.n_tiles > 0) { hipLaunchKernelGGL(k_proj_linearize<0>, dim3((d.n_tiles + 3) / 4), dim3(256), lds_proj, st, d, d.pose, d.lam, d.fcost, 1); counts[0]++; }
+        PROF(slot, 0, 1);
         if (NI) hipLaunchKernelGGL(k_imu_linearize<true>, dim3((unsigned)NI), dim3(64), 0, st, d, d.pose, d.sb, d.imu_cost, 1);
         hipLaunchKernelGGL(k_prior_linearize<true>, dim3((d.B * d.n_prior_slots + 63) / 64), dim3(64), 0, st, d, d.pose, d.sb, d.prior_cost, 1);
         hipLaunchKernelGGL(k_cost_reduce, dim3(d.B), dim3(256), 0, st, d, d.fcost, d.imu_cost, d.prior_cost, d.cost, 1);
         if (d.Ltot) hipLaunchKernelGGL(k_lm_prep, dim3((d.Ltot + 255) / 256), dim3(256), 0, st, d);
-        if (d.lds_T) hipLaunchKernelGGL(k_sweep, dim3(d.B, d.N), dim3(64), 0, st, d);
+        PROF(slot, 1, 0);
+        if (d.lds_T) { hipLaunchKernelGGL(k_sweep, dim3(d.B, d.N), dim3(64), 0, st, d); counts[2]++; }
+        PROF(slot, 1, 1);
+        PROF(slot, 2, 0);
         if (d.lds_T) hipLaunchKernelGGL(k_build_solve_lds, dim3(d.B), dim3(768), lds_bs, st, d);
         else hipLaunchKernelGGL(k_build_solve<false>, dim3(d.B), dim3(512), lds_bs, st, d);
         counts[1]++;
+        PROF(slot, 2, 1);
         if (d.Ltot) hipLaunchKernelGGL(k_backsub, dim3((d.Ltot + 255) / 256), dim3(256), 0, st, d);
         hipLaunchKernelGGL(k_dogleg, dim3(d.B), dim3(256), 0, st, d);
         if (d.n_tiles > 0) hipLaunchKernelGGL(k_proj_linearize<1>, dim3((d.n_tiles + 3) / 4), dim3(256), lds_proj, st, d, d.cpose, d.clam, d.fcost_c, 2);

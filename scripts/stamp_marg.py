@@ -1,0 +1,15 @@
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import isvins_loader; isvins_loader.load()
+from isvins_amd import backend, synth
+import numpy as np
+B = 256
+ws = synth.make_windows(range(B))
+be = backend.Backend(11, 5, max_landmarks=300, max_obs=1600, max_batch=B)
+be.upload(ws); be.run_optimize()
+dbg = be.debug_read(21, B * 64).reshape(B, 64)[:, 32:42]
+names = ["fwd landmark jac", "fwd 12x12 sums", "fwd priors", "pg edge (pinv, inv, chol)", "fwd prior (inv, kld, chol)", "bwd build+schur", "bwd jacobi 21", "bwd projections", "bwd kld"]
+for k, nm in enumerate(names):
+    print(f"  {nm:28s} {np.median(dbg[:, k]) / 100:9.1f} us")
+print("  total", np.median(dbg.sum(1)) / 100)
