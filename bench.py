@@ -81,7 +81,8 @@ def main():
     hip.hipSetDevice(local_rank if world > 1 else 0)
 
     W = args.windows
-    ids = range(rank * W, (rank + 1) * W)
+    from isvins_amd import sharding
+    ids = sharding.shard_window_ids(rank, world, W)
     windows = synth.make_windows(ids, n_frames=args.frames, n_vo=args.vo, n_landmarks=args.landmarks)
     Ftot = sum(w.n_factors for w in windows)
     max_obs = max(w.n_obs for w in windows)
@@ -105,9 +106,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = sharding.max_over_ranks(dt, dist, device="cuda")
     # per-kernel-family HIP-event timing of one more (untimed) step, on the handle's own stream
     be.run_optimize(sync=True)
     fam = be.last_timing(); cnt = be.last_counts()

@@ -8,4 +8,4 @@ The directory name carries a hyphen (`is-vins_amd`), so it is imported through
   backend  host-side mirror of the reference call surface over the HIP C-ABI library
   csrc/    hand-written gfx950 kernels + the C ABI (libisvins_hip.so)
 """
-from . import abi, synth  # noqa: F401
+from . import abi, sharding, synth  # noqa: F401

@@ -1,0 +1,58 @@
+"""Golden fixtures (tests/golden/*.npz, produced by tests/golden/make_golden.py from the CPU oracle;
+the reference cannot run in this image).  CPU: the oracle still reproduces them (pins the oracle
+against accidental change, checks the input generator is deterministic).  GPU: the HIP path matches
+them through the C ABI, including the reference's own window shape N = 18 / Nvo = 8 (generic,
+global-scratch variant of k_build_solve)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import make_golden  # noqa: E402
+from isvins_amd import abi, backend, synth  # noqa: E402
+
+CASES = list(make_golden.CASES)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_reproduces_golden(case):
+    g = np.load(os.path.join(HERE, "golden", case + ".npz"))
+    w, d = make_golden.run(case)
+    assert np.array_equal(d["in_obs_sum"], g["in_obs_sum"]), "synthetic generator is not deterministic"
+    for k in ("proj_strips", "imu_strips", "cost0", "trace_cost", "Ps", "Rs", "Vs", "depth", "priors", "fwd_info", "bwd_vb_info"):
+        assert np.allclose(d[k], g[k], rtol=1e-12, atol=1e-12 * max(1.0, np.abs(g[k]).max())), k
+    assert int(d["iterations"][0]) == int(g["iterations"][0]) and int(d["termination"][0]) == int(g["termination"][0])
+    assert np.array_equal(d["trace_accepted"], g["trace_accepted"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES)
+def test_gpu_matches_golden(case):
+    g = np.load(os.path.join(HERE, "golden", case + ".npz"))
+    kw = dict(make_golden.CASES[case]); wid = kw.pop("window_id")
+    w = synth.make_window(wid, **kw)
+    backend.build()
+    be = backend.Backend(w.N, w.Nvo, max_landmarks=64, max_obs=64 * w.N, max_batch=2)
+    ps, im, cost = be.linearize(w)
+    sc = np.maximum(1.0, np.abs(g["proj_strips"]).max(axis=1, keepdims=True))
+    assert (np.abs(ps - g["proj_strips"]) / sc).max() < 1e-9
+    sc = np.maximum(1.0, np.abs(g["imu_strips"]).max(axis=1, keepdims=True))
+    assert (np.abs(im - g["imu_strips"]) / sc).max() < 1e-9
+    assert abs(cost - g["cost0"][0]) < 1e-11 * g["cost0"][0]
+    o = w.clone()
+    s, mg = be.optimize(o)
+    n = int(g["iterations"][0])
+    assert s.iterations == n and s.termination == int(g["termination"][0])
+    assert list(s.trace_accepted[: n + 1]) == list(g["trace_accepted"])
+    assert np.allclose(np.array(s.trace_cost[: n + 1]), g["trace_cost"], rtol=1e-7)
+    for k in ("Ps", "Rs", "Vs", "Bas", "Bgs"):
+        assert np.abs(getattr(o, k) - g[k]).max() < 1e-7, k
+    assert np.abs(o.priors_vector() - g["priors"]).max() < 1e-7
+    assert np.abs(o.lm_depth[: o.L] - g["depth"]).max() < 1e-5 * max(1.0, np.abs(g["depth"]).max())
+    for name, key, nn in (("forward_pose_prior", "fwd_info", 6), ("backward_relpose", "bwd_rel_info", 6), ("backward_vb", "bwd_vb_info", 9), ("backward_rollpitch", "bwd_rp_info", 2)):
+        U = np.array(getattr(mg, name).sqrt_info).reshape(nn, nn); G = g[key]
+        assert np.abs(U.T @ U - G.T @ G).max() < 1e-6 * np.abs(G.T @ G).max(), name
+    be.close()
