@@ -23,7 +23,8 @@
 struct isv_backend {
     isv_config_t cfg;
     std::string err;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, stream2 = nullptr;
+    hipEvent_t fj[4] = {};
     hipEvent_t ev[8] = {};
     std::vector<hipEvent_t> prof_ev;      // [max_iter][ISV_PROF_FAMILIES][2]
     int prof_valid = 0;
@@ -78,6 +79,8 @@ extern "C" void isv_backend_destroy(isv_backend_t *h) {
     for (void *p : h->hallocs) (void)hipHostFree(p);
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : h->prof_ev) if (e) (void)hipEventDestroy(e);
+    for (auto &e : h->fj) if (e) (void)hipEventDestroy(e);
+    if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -88,6 +91,8 @@ static int create_impl(isv_backend *h) {
     HIPCHK(h, hipGetDeviceCount(&ndev));
     if (ndev <= 0) { h->err = "no HIP device"; return ISV_ERR_DEVICE; }
     HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    HIPCHK(h, hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    for (auto &e : h->fj) HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto &e : h->ev) HIPCHK(h, hipEventCreate(&e));
     h->prof_ev.assign((size_t)c.num_iterations * ISV_PROF_FAMILIES * 2, nullptr);
     for (auto &e : h->prof_ev) HIPCHK(h, hipEventCreate(&e));
@@ -353,7 +358,7 @@ extern "C" int isv_batch_optimize(isv_backend_t *h, int32_t sync) {
     HIPCHK(h, hipEventRecord(h->ev[0], st));
     TRY(restore_initial(h));
     hipLaunchKernelGGL(k_vector2double, dim3(d.B), dim3(64), 0, st, d);
-    int rc = isv_solver_enqueue(h->d, st, h->last_counts, h->prof_ev.empty() ? nullptr : h->prof_ev.data(), h->err);
+    int rc = isv_solver_enqueue(h->d, st, h->stream2, h->fj, h->last_counts, h->prof_ev.empty() ? nullptr : h->prof_ev.data(), h->err);
     h->prof_valid = 1;
     if (rc != ISV_OK) return rc;
     HIPCHK(h, hipEventRecord(h->ev[4], st));

@@ -370,83 +370,114 @@ __global__ __launch_bounds__(LT) void k_build_solve_lds(DevBatch d) {
         }
         __syncthreads();
         STAMP(3);
-        // ---- blocked right-looking Cholesky; diagonal blocks in registers of wavefront 0 ------------
-        for (int J = 0; J < N; J++) {
+        // ---- blocked right-looking Cholesky with look-ahead ----------------------------------------
+        // Diagonal blocks are factored AND inverted by wavefront 0 in registers (v_readlane); with
+        // look-ahead the factorisation of block J+1 runs while wavefronts 1..11 finish the trailing
+        // update of block J (only block column J+1 of that update has to be done first).
+        auto diag_block = [&](int J) {                            // wavefront 0 only
             double *Dj = T + tblk(J, J);
             double *Li = LinvAll + J * 225;
-            if (wv == 0) {
-                double row[15], dinv[15];
+            double row[15], dinv[15];
 #pragma unroll
-                for (int k = 0; k < 15; k++) row[k] = (lane < 15) ? Dj[lane * 15 + k] : 0.0;
-                bool bad = false;
+            for (int k = 0; k < 15; k++) row[k] = (lane < 15) ? Dj[lane * 15 + k] : 0.0;
+            bool bad = false;
 #pragma unroll
-                for (int j = 0; j < 15; j++) {
-                    double s = row[j];
+            for (int j = 0; j < 15; j++) {
+                double s = row[j];
 #pragma unroll
-                    for (int k = 0; k < j; k++) s -= row[k] * readlane_d(row[k], j);
-                    const double sj = readlane_d(s, j);           // pivot
-                    if (!(sj > 0.0)) bad = true;
-                    dinv[j] = rsqrt_nr(sj);                        // 1 / L_jj  (wave-uniform)
-                    row[j] = (lane == j) ? sj * dinv[j] : s * dinv[j];
-                }
-                if (lane == 0 && bad) flag[0] = 1;
-                double x[15];                                      // lane c solves L x = e_c
-#pragma unroll
-                for (int i = 0; i < 15; i++) {
-                    double s = (lane == i) ? 1.0 : 0.0;
-#pragma unroll
-                    for (int k = 0; k < i; k++) s -= readlane_d(row[k], i) * x[k];
-                    x[i] = s * dinv[i];
-                }
-                if (lane < 15) {
-#pragma unroll
-                    for (int k = 0; k < 15; k++) { Dj[lane * 15 + k] = (k <= lane) ? row[k] : 0.0; Li[k * 15 + lane] = x[k]; }
-                }
+                for (int k = 0; k < j; k++) s -= row[k] * readlane_d(row[k], j);
+                const double sj = readlane_d(s, j);           // pivot
+                if (!(sj > 0.0)) bad = true;
+                dinv[j] = rsqrt_nr(sj);                        // 1 / L_jj  (wave-uniform)
+                row[j] = (lane == j) ? sj * dinv[j] : s * dinv[j];
             }
-            __syncthreads();
-            if (flag[0]) break;
+            if (lane == 0 && bad) flag[0] = 1;
+            if (lane < 15) {
+#pragma unroll
+                for (int k = 0; k < 15; k++) Dj[lane * 15 + k] = (k <= lane) ? row[k] : 0.0;
+#pragma unroll
+                for (int k = 0; k < 15; k++) if (lane == k) Li[k] = dinv[k];     // 1 / L_kk in the first row of the (later) inverse slot
+            }
+        };
+        auto invert_block = [&](int J) {                          // one wavefront per block, after the factorisation
+            const double *Dj = T + tblk(J, J);
+            double *Li = LinvAll + J * 225;
+            double row[15], dinv[15], x[15];
+#pragma unroll
+            for (int k = 0; k < 15; k++) { row[k] = (lane < 15) ? Dj[lane * 15 + k] : 0.0; dinv[k] = Li[k]; }
+#pragma unroll
+            for (int i = 0; i < 15; i++) {                         // lane c solves L x = e_c
+                double s = (lane == i) ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 0; k < i; k++) s -= readlane_d(row[k], i) * x[k];
+                x[i] = s * dinv[i];
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 15) {
+#pragma unroll
+                for (int k = 0; k < 15; k++) Li[k * 15 + lane] = x[k];
+            }
+        };
+        auto trailing_tile = [&](int J, int I, int K, int tt) {  // 3x3 tile tt of T[I,K] -= L[I,J] L[K,J]^T
+            const int tr = (tt / 5) * 3, tc = (tt % 5) * 3;
+            const double *LI = T + tblk(I, J) + tr * 15, *LK = T + tblk(K, J) + tc * 15;
+            double a00 = 0, a01 = 0, a02 = 0, a10 = 0, a11 = 0, a12 = 0, a20 = 0, a21 = 0, a22 = 0;
+#pragma unroll
+            for (int k = 0; k < 15; k++) {
+                const double x0 = LI[k], x1 = LI[15 + k], x2 = LI[30 + k];
+                const double z0 = LK[k], z1 = LK[15 + k], z2 = LK[30 + k];
+                a00 += x0 * z0; a01 += x0 * z1; a02 += x0 * z2;
+                a10 += x1 * z0; a11 += x1 * z1; a12 += x1 * z2;
+                a20 += x2 * z0; a21 += x2 * z1; a22 += x2 * z2;
+            }
+            double *C = T + tblk(I, K) + tr * 15 + tc;
+            C[0] -= a00; C[1] -= a01; C[2] -= a02;
+            C[15] -= a10; C[16] -= a11; C[17] -= a12;
+            C[30] -= a20; C[31] -= a21; C[32] -= a22;
+        };
+        if (wv == 0) diag_block(0);
+        __syncthreads();
+        for (int J = 0; J < N && !flag[0]; J++) {
+            const double *Li = LinvAll + J * 225;
             const int prow = (N - J - 1) * 15;
-            for (int rr = t; rr < prow; rr += LT) {             // panel: L[I,J] = A[I,J] Linv^T
+            const double *Ljj = T + tblk(J, J);
+            for (int rr = t; rr < prow; rr += LT) {             // panel: solve x L_JJ^T = a per row
                 const int I = J + 1 + rr / 15, r = rr % 15;
                 double *A = T + tblk(I, J) + r * 15;
-                double av[15], ov[15];
-#pragma unroll
-                for (int k = 0; k < 15; k++) av[k] = A[k];
+                double xv[15];
 #pragma unroll
                 for (int c = 0; c < 15; c++) {
-                    double s2 = 0;
+                    double s2 = A[c];
 #pragma unroll
-                    for (int k = 0; k <= c; k++) s2 += av[k] * Li[c * 15 + k];
-                    ov[c] = s2;
+                    for (int k = 0; k < c; k++) s2 -= xv[k] * Ljj[c * 15 + k];
+                    xv[c] = s2 * Li[c];
                 }
 #pragma unroll
-                for (int c = 0; c < 15; c++) A[c] = ov[c];
+                for (int c = 0; c < 15; c++) A[c] = xv[c];
             }
             __syncthreads();
-            const int m = N - J - 1, nb = m * (m + 1) / 2;       // trailing update, 3x3 register tiles
-            for (int tile = t; tile < nb * 25; tile += LT) {
-                const int q = tile / 25, tt = tile - 25 * q, tr = (tt / 5) * 3, tc = (tt % 5) * 3;
-                int ii = 0;
-                while ((ii + 1) * (ii + 2) / 2 <= q) ii++;
-                const int kk = q - ii * (ii + 1) / 2;
-                const int I = J + 1 + ii, K = J + 1 + kk;
-                const double *LI = T + tblk(I, J) + tr * 15, *LK = T + tblk(K, J) + tc * 15;
-                double a00 = 0, a01 = 0, a02 = 0, a10 = 0, a11 = 0, a12 = 0, a20 = 0, a21 = 0, a22 = 0;
-#pragma unroll
-                for (int k = 0; k < 15; k++) {
-                    const double x0 = LI[k], x1 = LI[15 + k], x2 = LI[30 + k];
-                    const double z0 = LK[k], z1 = LK[15 + k], z2 = LK[30 + k];
-                    a00 += x0 * z0; a01 += x0 * z1; a02 += x0 * z2;
-                    a10 += x1 * z0; a11 += x1 * z1; a12 += x1 * z2;
-                    a20 += x2 * z0; a21 += x2 * z1; a22 += x2 * z2;
+            const int m = N - J - 1;
+            if (m == 0) break;
+            // part 1: block column J+1 of the trailing update (all threads)
+            for (int tile = t; tile < m * 25; tile += LT) trailing_tile(J, J + 1 + tile / 25, J + 1, tile % 25);
+            __syncthreads();
+            // part 2: wavefront 0 factors block J+1 while the others update the remaining columns
+            if (wv == 0) diag_block(J + 1);
+            else {
+                const int nb2 = m * (m - 1) / 2;                // blocks (I, K) with I >= K >= J+2
+                for (int tile = t - 64; tile < nb2 * 25; tile += LT - 64) {
+                    const int q = tile / 25;
+                    int ii = 0;
+                    while ((ii + 1) * (ii + 2) / 2 <= q) ii++;
+                    const int kk = q - ii * (ii + 1) / 2;
+                    trailing_tile(J, J + 2 + ii, J + 2 + kk, tile - 25 * q);
                 }
-                double *C = T + tblk(I, K) + tr * 15 + tc;
-                C[0] -= a00; C[1] -= a01; C[2] -= a02;
-                C[15] -= a10; C[16] -= a11; C[17] -= a12;
-                C[30] -= a20; C[31] -= a21; C[32] -= a22;
             }
             __syncthreads();
         }
+        __syncthreads();
+        if (!flag[0] && wv < N) invert_block(wv);               // all diagonal-block inverses in parallel
+        __syncthreads();
         STAMP(4);
         if (flag[0]) {
             mu *= 10.0; attempt++;

@@ -16,7 +16,7 @@ __global__ void k_cost_reduce(DevBatch d, const double *fcost, const double *imu
 
 // solver stage (isv_solver.hip)
 int isv_solver_alloc(DevBatch &d, size_t B, size_t L, size_t F, std::vector<void *> &allocs, std::string &err);
-int isv_solver_enqueue(DevBatch &d, hipStream_t st, int64_t *counts, hipEvent_t *prof_ev, std::string &err);
+int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t *fj, int64_t *counts, hipEvent_t *prof_ev, std::string &err);
 #define ISV_PROF_FAMILIES 3      // 0 = k_proj_linearize<0>, 1 = k_sweep, 2 = k_build_solve*
 int isv_solver_download(DevBatch &d, hipStream_t st, int n, isv_summary_t *summary, isv_marg_result_t *marg, std::string &err);
 int isv_solver_debug_read(DevBatch &d, hipStream_t st, int what, double *out, int64_t count, std::string &err);

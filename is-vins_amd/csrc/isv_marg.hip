@@ -24,6 +24,9 @@
 #endif
 #define SYNC() __syncthreads()
 
+DEV double m_rsqrt(double x) { double r = __builtin_amdgcn_rsq(x); r = r * (1.5 - 0.5 * x * r * r); r = r * (1.5 - 0.5 * x * r * r); return r; }
+DEV double m_rcp(double x) { double r = __builtin_amdgcn_rcp(x); r = r * (2.0 - x * r); r = r * (2.0 - x * r); return r; }
+
 // ---- wave-cooperative dense helpers on LDS matrices (row-major) --------------------------------
 DEV void w_mm(const double *A, const double *B, double *C, int m, int k, int n, int t) {
     for (int e = t; e < m * n; e += MT) { const int i = e / n, j = e % n; double s = 0; for (int p = 0; p < k; p++) s += A[i * k + p] * B[p * n + j]; C[e] = s; }
@@ -103,9 +106,12 @@ DEV void w_jacobi(double *A, int n, double *wv, double *V, double *tmp, int t) {
                 if (q < n) {
                     const double apq = A[p * n + q];
                     if (apq != 0.0) {
-                        const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
-                        const double tt = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-                        c = 1.0 / sqrt(tt * tt + 1.0); sn = tt * c;
+                        // Newton-refined rcp / rsq instead of IEEE div / sqrt: the rotation only has to be orthogonal
+                        // to rounding, which c = rsqrt(1 + t^2), s = t c guarantees independently of t's accuracy
+                        const double theta = (A[q * n + q] - A[p * n + p]) * 0.5 * m_rcp(apq);
+                        const double th2 = theta * theta + 1.0;
+                        const double tt = (theta >= 0 ? 1.0 : -1.0) * m_rcp(fabs(theta) + th2 * m_rsqrt(th2));
+                        c = m_rsqrt(tt * tt + 1.0); sn = tt * c;
                     }
                 } else { p = 0; q = 0; }           // dummy pairing: identity rotation on (0,0) is skipped below
                 rp[t] = p; rq[t] = q; rc[t] = c; rs[t] = sn;

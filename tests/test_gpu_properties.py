@@ -1,0 +1,81 @@
+"""Size-independent properties at BASELINE.json's full sizes (GPU), where running the CPU oracle on
+everything would take too long:
+  - config 4 batch (1024 x 11-KF/300-landmark windows): every solve finite and cost-decreasing;
+    a random sample equals the same windows solved alone BITWISE (owner-computes sums, no atomics);
+    reversing the batch order permutes the results and changes nothing else; a sample matches the oracle
+  - re-running the resident batch is idempotent (state restored on device)
+  - config 5 shape (20 KF / 2000 landmarks / 30 000 factors, generic global-scratch kernel): runs, cost
+    decreases; a reduced-size stress window (20 KF / 300 landmarks) matches the oracle"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from isvins_amd import abi, backend, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_run(oracle, cfg, w):
+    o = w.clone(); s = abi.isv_summary_t(); mg = abi.isv_marg_result_t()
+    assert oracle.isvo_optimize(C.byref(cfg), C.byref(o.c()), C.byref(s), C.byref(mg)) == 0
+    return o, s, mg
+
+
+def test_config4_batch_properties(oracle):
+    B = 1024
+    ws = synth.make_windows(range(B))
+    backend.build()
+    be = backend.Backend(11, 5, max_landmarks=300, max_obs=max(w.n_obs for w in ws), max_batch=B)
+    out = [w.clone() for w in ws]
+    sums, margs = be.optimize_batch(out)
+    fin = np.array([s.final_cost for s in sums]); ini = np.array([s.initial_cost for s in sums])
+    assert np.all(np.isfinite(fin)) and np.all(fin < ini) and all(s.status == 0 for s in sums)
+    assert all(1 <= s.iterations <= 10 for s in sums) and all(m.valid == 1 for m in margs)
+    state = np.stack([o.state_vector() for o in out])
+    assert np.all(np.isfinite(state))
+    # idempotence: the resident batch re-run from the restored state gives the same bits
+    be.run_optimize()
+    again = [w.clone() for w in ws]
+    be.download(again)
+    assert np.array_equal(np.stack([o.state_vector() for o in again]), state)
+    # reversed batch order: pure permutation
+    rev = [w.clone() for w in ws[::-1]]
+    be.optimize_batch(rev)
+    assert np.array_equal(np.stack([o.state_vector() for o in rev[::-1]]), state)
+    # a sample solved alone is bitwise identical; and matches the oracle
+    be1 = backend.Backend(11, 5, max_landmarks=300, max_obs=max(w.n_obs for w in ws), max_batch=1)
+    rng = np.random.default_rng(0)
+    for b in rng.choice(B, 6, replace=False):
+        g = ws[b].clone(); sg, _ = be1.optimize(g)
+        assert np.array_equal(g.state_vector(), out[b].state_vector())
+        assert sg.final_cost == sums[b].final_cost and sg.iterations == sums[b].iterations
+    for b in rng.choice(B, 3, replace=False):
+        o, so, _ = oracle_run(oracle, be.cfg, ws[b])
+        assert sums[b].iterations == so.iterations and sums[b].termination == so.termination
+        assert abs(sums[b].final_cost - so.final_cost) < 1e-8 * so.final_cost
+        assert np.abs(out[b].Ps - o.Ps).max() < 1e-7 and np.abs(out[b].Rs - o.Rs).max() < 1e-7
+    be.close(); be1.close()
+
+
+def test_config5_stress_shape(oracle):
+    backend.build()
+    w = synth.make_window(0, n_frames=20, n_vo=8, n_landmarks=2000, target_factors=30000)
+    assert w.n_factors == 30000
+    be = backend.Backend(20, 8, max_landmarks=2000, max_obs=w.n_obs, max_batch=1)
+    g = w.clone(); s, mg = be.optimize(g)
+    assert s.status == 0 and np.isfinite(s.final_cost) and s.final_cost < 1e-2 * s.initial_cost
+    tc = np.array(s.trace_cost[: s.iterations + 1]); acc = np.array(s.trace_accepted[: s.iterations + 1])
+    assert np.all(np.diff(tc[np.r_[True, acc[1:] == 1]]) < 0)          # accepted steps decrease the cost
+    be.close()
+    # reduced stress window against the oracle (same N / Nvo, generic kernel path)
+    w = synth.make_window(1, n_frames=20, n_vo=8, n_landmarks=300)
+    be = backend.Backend(20, 8, max_landmarks=300, max_obs=w.n_obs, max_batch=1)
+    o, so, mo = oracle_run(oracle, be.cfg, w)
+    g = w.clone(); sg, mg = be.optimize(g)
+    assert sg.iterations == so.iterations and sg.termination == so.termination
+    assert list(sg.trace_accepted[: so.iterations + 1]) == list(so.trace_accepted[: so.iterations + 1])
+    assert np.allclose(np.array(sg.trace_cost[: so.iterations + 1]), np.array(so.trace_cost[: so.iterations + 1]), rtol=1e-7)
+    for name in ("Ps", "Rs", "Vs", "Bas", "Bgs"):
+        assert np.abs(getattr(g, name) - getattr(o, name)).max() < 1e-7, name
+    be.close()
