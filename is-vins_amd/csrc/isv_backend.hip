@@ -44,7 +44,7 @@ struct isv_backend {
     } h{};
     std::vector<void *> hallocs;
     // pristine copies for isv_batch_optimize restore
-    double *Ps0 = nullptr, *Rs0 = nullptr, *Vs0 = nullptr, *Bas0 = nullptr, *Bgs0 = nullptr, *depth0 = nullptr;
+    double *Ps0 = nullptr, *Rs0 = nullptr, *Vs0 = nullptr, *Bas0 = nullptr, *Bgs0 = nullptr, *depth0 = nullptr, *tic0 = nullptr, *ric0 = nullptr;
     isv_se3_prior_t *se30 = nullptr; isv_linear9_t *lin90 = nullptr; isv_relpose_t *relpose0 = nullptr; isv_rollpitch_t *rollpitch0 = nullptr;
     int resident = 0;
     double last_ms[8] = {};
@@ -129,6 +129,7 @@ static int create_impl(isv_backend *h) {
     TRY(dalloc(h, &d.lm_meta, L)); TRY(dalloc(h, &d.ck_off, B + 1)); TRY(dalloc(h, &d.ck_rec, L + B + 1));
     TRY(dalloc(h, &h->Ps0, B * N * 3)); TRY(dalloc(h, &h->Rs0, B * N * 9)); TRY(dalloc(h, &h->Vs0, B * N * 3));
     TRY(dalloc(h, &h->Bas0, B * N * 3)); TRY(dalloc(h, &h->Bgs0, B * N * 3)); TRY(dalloc(h, &h->depth0, L));
+    TRY(dalloc(h, &h->tic0, B * 3)); TRY(dalloc(h, &h->ric0, B * 9));
     TRY(dalloc(h, &h->se30, B)); TRY(dalloc(h, &h->lin90, B)); TRY(dalloc(h, &h->relpose0, B * (c.n_vo - 1))); TRY(dalloc(h, &h->rollpitch0, B * (size_t)c.max_rollpitch));
     auto &s = h->h;
     TRY(halloc(h, &s.Ps, B * N * 3)); TRY(halloc(h, &s.Rs, B * N * 9)); TRY(halloc(h, &s.Vs, B * N * 3));
@@ -266,6 +267,7 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
 #define D2D(dst, src, cnt) HIPCHK(h, hipMemcpyAsync(dst, src, sizeof(*(src)) * (size_t)(cnt), hipMemcpyDeviceToDevice, st))
     D2D(h->Ps0, d.Ps, (size_t)n * N * 3); D2D(h->Rs0, d.Rs, (size_t)n * N * 9); D2D(h->Vs0, d.Vs, (size_t)n * N * 3);
     D2D(h->Bas0, d.Bas, (size_t)n * N * 3); D2D(h->Bgs0, d.Bgs, (size_t)n * N * 3); D2D(h->depth0, d.depth, L);
+    D2D(h->tic0, d.tic, (size_t)n * 3); D2D(h->ric0, d.ric, (size_t)n * 9);
     D2D(h->se30, d.se3, n); D2D(h->lin90, d.lin9, n); D2D(h->relpose0, d.relpose, (size_t)n * (c.n_vo - 1)); D2D(h->rollpitch0, d.rollpitch, (size_t)n * c.max_rollpitch);
     // IMU sqrt_info once per upload (the covariances do not change during a solve)
     if (NI) hipLaunchKernelGGL(k_imu_prep, dim3((unsigned)NI), dim3(64), 0, st, d);
@@ -280,6 +282,7 @@ static int restore_initial(isv_backend *h) {
     const size_t n = d.B, N = d.N, L = d.Ltot;
     D2D(d.Ps, h->Ps0, n * N * 3); D2D(d.Rs, h->Rs0, n * N * 9); D2D(d.Vs, h->Vs0, n * N * 3);
     D2D(d.Bas, h->Bas0, n * N * 3); D2D(d.Bgs, h->Bgs0, n * N * 3); D2D(d.depth, h->depth0, L);
+    D2D(d.tic, h->tic0, n * 3); D2D(d.ric, h->ric0, n * 9);
     D2D(d.se3, h->se30, n); D2D(d.lin9, h->lin90, n); D2D(d.relpose, h->relpose0, n * (c.n_vo - 1)); D2D(d.rollpitch, h->rollpitch0, n * c.max_rollpitch);
     return ISV_OK;
 }
