@@ -106,8 +106,10 @@ struct DevBatch {
     int32_t *ck_off;                    // [B+1] chunk CSR over windows (chunks of whole landmarks, <= 64 factors)
     int2 *ck_rec;                       // [ck_off[B] + B] {first landmark, first factor} per chunk + sentinel per window
     double *W;                          // [Ftot + Ltot][6]  w = J_pose^T J_lambda per observation (obs index = factor + landmark [+1])
+    double *Wd;                         // [Ltot][wd_ld] the same w vectors dense over the 6N pose columns (zero where a
+                                        // frame does not see the landmark; zero-filled at upload, pattern is static)
     double2 *lm_cg;                     // [Ltot]  {c_l = s_l^2 / (s_l^2 E_l + mu D_l^2), g_l}
     double *Tvis;                       // [B][tvis_sz] reprojection part of the reduced system (6x6 pose corners), hd, g, bs
-    int32_t prior_H_sz, tvis_sz;
+    int32_t prior_H_sz, tvis_sz, wd_ld, _pad3;
     int32_t marg_scratch_sz, lds_T;     // lds_T: reduced system lives in LDS (15N <= 165)
 };

@@ -192,8 +192,9 @@ __global__ __launch_bounds__(256) void k_proj_linearize(DevBatch d, const double
         if (MODE == 0) {
             // w of the observing frame for the Schur sweep: J_pose_j^T J_lambda (6), obs slot f + lm + 1
             double *wo = d.W + (size_t)(f + rec.lm + 1) * 6;
+            double *wd = d.Wd + (size_t)rec.lm * d.wd_ld + 6 * fj;      // dense copy for the MFMA panels
 #pragma unroll
-            for (int c2 = 0; c2 < 6; c2++) wo[c2] = Jj[c2] * Jl[0] + Jj[6 + c2] * Jl[1];
+            for (int c2 = 0; c2 < 6; c2++) { const double v = Jj[c2] * Jl[0] + Jj[6 + c2] * Jl[1]; wo[c2] = v; wd[c2] = v; }
         }
     }
     if (MODE != 0) return;                            // uniform over the block

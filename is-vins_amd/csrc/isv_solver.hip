@@ -17,6 +17,7 @@ extern size_t build_solve_lds2_bytes(int N);
 __global__ void k_build_solve_lds(DevBatch d);
 __global__ void k_lm_prep(DevBatch d);
 __global__ void k_sweep(DevBatch d);
+__global__ void k_rank1_mfma(DevBatch d);
 __global__ void k_backsub(DevBatch d);
 __global__ void k_marg(DevBatch d);
 template <bool LDS_T> __global__ void k_build_solve(DevBatch d);
@@ -368,7 +369,9 @@ int isv_solver_alloc(DevBatch &d, size_t B, size_t L, size_t F, std::vector<void
     TRYA(dal(&d.trace_cost, B * ISV_MAX_TRACE, allocs, err)); TRYA(dal(&d.trace_radius, B * ISV_MAX_TRACE, allocs, err));
     TRYA(dal(&d.trace_step, B * ISV_MAX_TRACE, allocs, err)); TRYA(dal(&d.trace_acc, B * ISV_MAX_TRACE, allocs, err));
     d.tvis_sz = 36 * (d.N * (d.N + 1) / 2) + 18 * d.N;
-    TRYA(dal(&d.W, (F + L) * 6, allocs, err)); TRYA(dal(&d.lm_cg, L, allocs, err)); TRYA(dal(&d.Tvis, B * (size_t)d.tvis_sz, allocs, err));
+    TRYA(dal(&d.W, (F + L) * 6, allocs, err)); TRYA(dal(&d.lm_cg, L, allocs, err));
+    d.wd_ld = 16 * ((6 * d.N + 15) / 16);
+    TRYA(dal(&d.Wd, L * (size_t)d.wd_ld, allocs, err)); TRYA(dal(&d.Tvis, B * (size_t)d.tvis_sz, allocs, err));
     TRYA(dal(&d.dbg, B * 64, allocs, err));
     HCHK(hipMemset(d.dbg, 0, B * 64 * sizeof(double)));
     TRYA(dal(&d.marg, B, allocs, err)); TRYA(dal(&d.margin_old, B, allocs, err)); TRYA(dal(&d.header0, B, allocs, err));
@@ -403,7 +406,12 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
         PROF(slot, 0, 1);
         if (d.Ltot) hipLaunchKernelGGL(k_lm_prep, dim3((d.Ltot + 255) / 256), dim3(256), 0, st, d);
         PROF(slot, 1, 0);
-        if (d.lds_T) { hipLaunchKernelGGL(k_sweep, dim3(d.B, d.N), dim3(64), 0, st, d); counts[2]++; }
+        if (d.lds_T) {
+            hipLaunchKernelGGL(k_sweep, dim3(d.B, d.N), dim3(64), 0, st, d); counts[2]++;
+            const int nt = d.wd_ld / 16;
+            // one workgroup per window: nt(nt+1)/2 tile wavefronts + 1 rhs wavefront, W panels staged through LDS
+            hipLaunchKernelGGL(k_rank1_mfma, dim3(d.B), dim3(64 * (nt * (nt + 1) / 2 + 1)), (64 * (d.wd_ld + 4) + 128) * sizeof(double), st, d);
+        }
         PROF(slot, 1, 1);
         HCHK(hipStreamWaitEvent(st, fj[1], 0));
         hipLaunchKernelGGL(k_cost_reduce, dim3(d.B), dim3(256), 0, st, d, d.fcost, d.imu_cost, d.prior_cost, d.cost, 1);

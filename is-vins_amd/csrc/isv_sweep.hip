@@ -45,94 +45,110 @@ __global__ __launch_bounds__(256) void k_lm_prep(DevBatch d) {
     d.lm_cg[l] = make_double2(sl * sl / (Es + st.mu * Dl2), gl);
     d.lmE[l] = E; d.lmG[l] = gl; d.diag_l[l] = Dl; d.grad_l[l] = sl * gl / Dl;
     double *wo = d.W + (size_t)(f0 + l) * 6;           // host observation slot
+    double *wd = d.Wd + (size_t)l * d.wd_ld + 6 * d.lm_host[l];
 #pragma unroll
-    for (int c = 0; c < 6; c++) wo[c] = wh[c];
+    for (int c = 0; c < 6; c++) { wo[c] = wh[c]; wd[c] = wh[c]; }
 }
 
 // Tvis layout of one window: block column a at 36 * (a N - a (a-1) / 2), block (a+bo, a) = 36 doubles
 // row-major 6x6; then hd[6N] (diag of the direct part), g[6N], bs[6N].
 __host__ __device__ inline int tvis_col(int a, int N) { return 36 * (a * N - a * (a - 1) / 2); }
 
+// DIRECT part of block column a: sum over the reprojection factors of J_p^T J_p (no landmark coupling;
+// the rank-1 downdates - c_l w w^T come from k_rank1_mfma).  Lane = (group g = lane/6, row r = lane%6):
+//   * a landmark hosted in frame a ("host" pair): group g >= 1 works on factor g-1: block (a+g, a) +=
+//     J_j^T J_i, and the partial J_i^T J_i of the host block (a, a);
+//   * landmarks that merely observe frame a: TEN of them per iteration, group g takes the g-th one and
+//     adds its J_j^T J_j to its partial of block (a, a).
+// The per-group partials of block (a, a) are folded in ascending group order at the end (fixed order =>
+// bitwise reproducible).
 __global__ __launch_bounds__(64) void k_sweep(DevBatch d) {
     const int w = blockIdx.x, a = blockIdx.y, lane = threadIdx.x;
     const SolveState &st = d.st[w];
     if (st.termination != ISV_TERM_RUNNING || !st.need_linearize) return;
     const int N = d.N, l0 = d.lm_off[w], l1 = d.lm_off[w + 1], fw0 = d.f_off[w];
-    // lane = block row (bo, r) of column a, two steps cover bo <= 20.  Every lane touches at most ONE
-    // factor per landmark, so all loads of a landmark are issued as one batch:
-    //   acc : rows of block (a+bo, a);   hh : per-factor partials of the host block (a, a), summed over
-    //   bo in fixed order at the end (lanes bo >= 1 hold the partial of factor bo-1).
-    double acc[12], hh[12], hdp[2] = {0, 0}, ghp[2] = {0, 0}, hd = 0, gacc = 0, bacc = 0;
+    double acc[12], dgp[12], hdp[2] = {0, 0}, ghp[2] = {0, 0};
 #pragma unroll
-    for (int i = 0; i < 12; i++) { acc[i] = 0; hh[i] = 0; }
-    const int bo0 = lane / 6, r0 = lane - 6 * bo0;                 // step 0
-    const int bo1 = (lane + 64) / 6, r1 = (lane + 64) - 6 * bo1;   // step 1
+    for (int i = 0; i < 12; i++) { acc[i] = 0; dgp[i] = 0; }
+    const int g0 = lane / 6, r0 = lane - 6 * g0;
+    const int g1 = (lane + 64) / 6, r1 = (lane + 64) - 6 * g1;
+
+    auto factor_update = [&](const double *s, int rofs, int cofs, int r, bool on, double *blk, double *dg, double &hd, double &gh, bool host) {
+        // rows: J[rofs + r], J[rofs + 6 + r]; column block at cofs (2 x 6); host: also the J_i^T J_i partial
+        const double x0 = s[rofs + r], x1 = s[rofs + 6 + r];
+        const double y0 = s[2 + r], y1 = s[8 + r];                 // J_i rows (host partial)
+        const double2 c01 = *reinterpret_cast<const double2 *>(s + cofs), c23 = *reinterpret_cast<const double2 *>(s + cofs + 2),
+                      c45 = *reinterpret_cast<const double2 *>(s + cofs + 4), d01 = *reinterpret_cast<const double2 *>(s + cofs + 6),
+                      d23 = *reinterpret_cast<const double2 *>(s + cofs + 8), d45 = *reinterpret_cast<const double2 *>(s + cofs + 10);
+        const double2 rs = *reinterpret_cast<const double2 *>(s);
+        const double f0 = on ? x0 : 0.0, f1 = on ? x1 : 0.0;
+        if (host) {
+            const double h0 = on ? y0 : 0.0, h1 = on ? y1 : 0.0;
+            blk[0] += f0 * c01.x + f1 * d01.x; blk[1] += f0 * c01.y + f1 * d01.y; blk[2] += f0 * c23.x + f1 * d23.x;
+            blk[3] += f0 * c23.y + f1 * d23.y; blk[4] += f0 * c45.x + f1 * d45.x; blk[5] += f0 * c45.y + f1 * d45.y;
+            dg[0] += h0 * c01.x + h1 * d01.x; dg[1] += h0 * c01.y + h1 * d01.y; dg[2] += h0 * c23.x + h1 * d23.x;
+            dg[3] += h0 * c23.y + h1 * d23.y; dg[4] += h0 * c45.x + h1 * d45.x; dg[5] += h0 * c45.y + h1 * d45.y;
+            hd += h0 * h0 + h1 * h1; gh += h0 * rs.x + h1 * rs.y;
+        } else {
+            dg[0] += f0 * c01.x + f1 * d01.x; dg[1] += f0 * c01.y + f1 * d01.y; dg[2] += f0 * c23.x + f1 * d23.x;
+            dg[3] += f0 * c23.y + f1 * d23.y; dg[4] += f0 * c45.x + f1 * d45.x; dg[5] += f0 * c45.y + f1 * d45.y;
+            hd += f0 * f0 + f1 * f1; gh += f0 * rs.x + f1 * rs.y;
+        }
+    };
+
     for (int base = l0; base < l1; base += 64) {
         const unsigned mm = (base + lane < l1) ? d.lm_meta[base + lane] : 0u;
         const int hh_ = mm & 255, kk = (mm >> 8) & 255;
-        unsigned long long mask = __ballot(base + lane < l1 && a >= hh_ && a < hh_ + kk);
-        while (mask) {
-            const int bit = __builtin_ctzll(mask);
-            mask &= mask - 1;
+        const bool cover = base + lane < l1 && a >= hh_ && a < hh_ + kk;
+        unsigned long long maskH = __ballot(cover && hh_ == a), maskN = __ballot(cover && hh_ != a);
+        while (maskH) {                                   // landmarks hosted in frame a, one per iteration
+            const int bit = __builtin_ctzll(maskH);
+            maskH &= maskH - 1;
             const unsigned m0 = __builtin_amdgcn_readlane(mm, bit);
-            const int l = base + bit, h = m0 & 255, k = (m0 >> 8) & 255;
-            const int f0 = fw0 + (int)(m0 >> 16), pa = a - h, nb = k - pa;
-            const double *wa = d.W + (size_t)(f0 + l + pa) * 6;
-            const bool host = (pa == 0);
-            const int cofs = host ? 2 : 14;              // column block: Ji (host column) or Jj
-#pragma unroll
-            for (int step = 0; step < 2; step++) {
-                if (step == 0 || 64 < 6 * nb) {          // step 1 only for > 10-frame tracks (wave-uniform)
-                    const int bo = step ? bo1 : bo0, r = step ? r1 : r0;
-                    // branch-free body: every load is issued up front (clamped addresses), the lane's role
-                    // enters through zeroed multipliers, so one memory round trip per landmark
-                    const bool act = bo < nb;
-                    const bool has_f = act && (host ? (bo > 0) : (bo == 0));
-                    const int fidx = has_f ? (host ? bo - 1 : pa - 1) : 0;
-                    const double *s = d.strip + (size_t)(f0 + fidx) * ISV_PROJ_STRIP;
-                    const double2 cg = d.lm_cg[l];
-                    const double2 wa01 = *reinterpret_cast<const double2 *>(wa), wa23 = *reinterpret_cast<const double2 *>(wa + 2),
-                                  wa45 = *reinterpret_cast<const double2 *>(wa + 4);
-                    const double wbr = wa[(act ? bo : 0) * 6 + r];
-                    const double jj0 = s[14 + r], jj1 = s[20 + r], ji0 = s[2 + r], ji1 = s[8 + r];
-                    const double2 c01 = *reinterpret_cast<const double2 *>(s + cofs), c23 = *reinterpret_cast<const double2 *>(s + cofs + 2),
-                                  c45 = *reinterpret_cast<const double2 *>(s + cofs + 4), d01 = *reinterpret_cast<const double2 *>(s + cofs + 6),
-                                  d23 = *reinterpret_cast<const double2 *>(s + cofs + 8), d45 = *reinterpret_cast<const double2 *>(s + cofs + 10);
-                    const double2 rs = *reinterpret_cast<const double2 *>(s);
-                    const double coef = act ? -cg.x * wbr : 0.0;
-                    const double fj0 = has_f ? jj0 : 0.0, fj1 = has_f ? jj1 : 0.0;
-                    const double hi0 = (has_f && host) ? ji0 : 0.0, hi1 = (has_f && host) ? ji1 : 0.0;
-                    const double dj0 = host ? 0.0 : fj0, dj1 = host ? 0.0 : fj1;
-                    double *ac = acc + 6 * step, *hp = hh + 6 * step;
-                    ac[0] += coef * wa01.x + fj0 * c01.x + fj1 * d01.x; ac[1] += coef * wa01.y + fj0 * c01.y + fj1 * d01.y;
-                    ac[2] += coef * wa23.x + fj0 * c23.x + fj1 * d23.x; ac[3] += coef * wa23.y + fj0 * c23.y + fj1 * d23.y;
-                    ac[4] += coef * wa45.x + fj0 * c45.x + fj1 * d45.x; ac[5] += coef * wa45.y + fj0 * c45.y + fj1 * d45.y;
-                    hp[0] += hi0 * c01.x + hi1 * d01.x; hp[1] += hi0 * c01.y + hi1 * d01.y;
-                    hp[2] += hi0 * c23.x + hi1 * d23.x; hp[3] += hi0 * c23.y + hi1 * d23.y;
-                    hp[4] += hi0 * c45.x + hi1 * d45.x; hp[5] += hi0 * c45.y + hi1 * d45.y;
-                    hdp[step] += hi0 * hi0 + hi1 * hi1;
-                    ghp[step] += hi0 * rs.x + hi1 * rs.y;
-                    hd += dj0 * dj0 + dj1 * dj1;
-                    gacc += dj0 * rs.x + dj1 * rs.y;
-                    bacc += (act && bo == 0) ? coef * cg.y : 0.0;
-                }
+            const int k = (m0 >> 8) & 255, f0 = fw0 + (int)(m0 >> 16);
+            {
+                const bool on = g0 >= 1 && g0 < k;
+                const double *s = d.strip + (size_t)(f0 + (on ? g0 - 1 : 0)) * ISV_PROJ_STRIP;
+                factor_update(s, 14, 2, r0, on, acc, dgp, hdp[0], ghp[0], true);
+            }
+            if (k > 10) {                                  // groups 10.. live in the second lane set
+                const bool on = g1 >= 1 && g1 < k;
+                const double *s = d.strip + (size_t)(f0 + (on ? g1 - 1 : 0)) * ISV_PROJ_STRIP;
+                factor_update(s, 14, 2, r1, on, acc + 6, dgp + 6, hdp[1], ghp[1], true);
             }
         }
+        while (maskN) {                                   // observers of frame a, ten per iteration
+            int mybit = 0; bool on = false;
+#pragma unroll
+            for (int sl = 0; sl < 10; sl++) {
+                if (maskN) {
+                    const int bit = __builtin_ctzll(maskN);
+                    maskN &= maskN - 1;
+                    if (g0 == sl) { mybit = bit; on = true; }
+                }
+            }
+            const unsigned m0 = __shfl(mm, mybit);
+            const int h = m0 & 255, f0 = fw0 + (int)(m0 >> 16);
+            const double *s = d.strip + (size_t)(on ? f0 + (a - h) - 1 : fw0) * ISV_PROJ_STRIP;
+            factor_update(s, 14, 14, r0, on, acc, dgp, hdp[0], ghp[0], false);
+        }
     }
-    // fold the host-block partials (lanes bo >= 1) into the lanes bo == 0, in ascending bo
-    __shared__ double red[2 * 64 * 8];
+    // fold the per-group partials of block (a, a), its diagonal and the gradient into group 0
+    __shared__ double red[128 * 8];
 #pragma unroll
     for (int step = 0; step < 2; step++) {
         double *o = red + (step * 64 + lane) * 8;
 #pragma unroll
-        for (int c = 0; c < 6; c++) o[c] = hh[6 * step + c];
+        for (int c = 0; c < 6; c++) o[c] = dgp[6 * step + c];
         o[6] = hdp[step]; o[7] = ghp[step];
     }
     __syncthreads();
-    if (bo0 == 0) {
-        for (int bo = 1; a + bo < N; bo++) {
-            const int ll = 6 * bo + r0;
-            const double *o = red + ll * 8;              // ll < 128: (step, lane) laid out contiguously
+    double hd = 0, gacc = 0;
+    if (g0 == 0) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) acc[c] = 0;             // group 0 has no off-diagonal block of its own
+        for (int g = 0; g < 21; g++) {                       // 126 lane slots = 21 groups
+            const double *o = red + (6 * g + r0) * 8;
 #pragma unroll
             for (int c = 0; c < 6; c++) acc[c] += o[c];
             hd += o[6]; gacc += o[7];
@@ -142,14 +158,85 @@ __global__ __launch_bounds__(64) void k_sweep(DevBatch d) {
     const int colbase = tvis_col(a, N), tail = 36 * (N * (N + 1) / 2);
 #pragma unroll
     for (int step = 0; step < 2; step++) {
-        const int bo = step ? bo1 : bo0, r = step ? r1 : r0;
+        const int bo = step ? g1 : g0, r = step ? r1 : r0;
         if (a + bo < N) {
             double *o = out + colbase + bo * 36 + r * 6;
 #pragma unroll
             for (int c = 0; c < 6; c++) o[c] = acc[6 * step + c];
-            if (bo == 0) { out[tail + 6 * a + r] = hd; out[tail + 6 * N + 6 * a + r] = gacc; out[tail + 12 * N + 6 * a + r] = bacc; }
+            if (bo == 0) { out[tail + 6 * a + r] = hd; out[tail + 6 * N + 6 * a + r] = gacc; }
         }
     }
+}
+
+// Rank-1 landmark downdates as FP64 MFMA panels:  Tvis -= Wd^T diag(c) Wd  over the window's landmarks,
+// one wavefront per 16x16 output tile (lower triangle of the 6N x 6N pose block, zero padded to 16s),
+// v_mfma_f64_16x16x4: A = (c_l * Wd[l][16I + i]) for 4 landmarks, B = Wd[l][16J + j].  The dense panels
+// multiply structural zeros, but one MFMA replaces ~1000 scalar lane-FMAs with their address arithmetic
+// (the scalar sweep was issue bound).  blockIdx.y == ntiles: the reduced right-hand side
+// bs = - Wd^T (c .* g_l).
+typedef double double4v __attribute__((ext_vector_type(4)));
+#define R1_CHUNK 64                       // landmarks staged per pass (64 x wd_ld doubles of LDS)
+__global__ __launch_bounds__(1024) void k_rank1_mfma(DevBatch d) {
+    extern __shared__ __align__(16) double lds[];
+    const int w = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6, nw = blockDim.x >> 6;
+    const SolveState &st = d.st[w];
+    if (st.termination != ISV_TERM_RUNNING || !st.need_linearize) return;
+    const int N = d.N, n6 = 6 * N, ld = d.wd_ld, nt = ld / 16, ntiles = nt * (nt + 1) / 2;
+    const int l0 = d.lm_off[w], l1 = d.lm_off[w + 1];
+    double *sW = lds;                      // [R1_CHUNK][ld + 4] (padded rows: the 4 k-rows of an operand hit distinct banks)
+    double *sC = lds + R1_CHUNK * (ld + 4);   // c_l
+    double *sG = sC + R1_CHUNK;               // c_l g_l
+    const int lds_ld = ld + 4;
+    double *out = d.Tvis + (size_t)w * d.tvis_sz;
+    const int tail = 36 * (N * (N + 1) / 2);
+    // wave wv < ntiles owns output tile (I, J); wave ntiles accumulates the reduced rhs bs
+    int I = 0;
+    while ((I + 1) * (I + 2) / 2 <= wv) I++;
+    const int J = wv - I * (I + 1) / 2;
+    const bool tile_wave = wv < ntiles, rhs_wave = (wv == ntiles);
+    const int i = lane & 15, kq = lane >> 4;
+    double4v acc = {0, 0, 0, 0};
+    double rhs0 = 0, rhs1 = 0;             // rows lane and lane + 64 of bs
+    for (int lb = l0; lb < l1; lb += R1_CHUNK) {
+        const int cnt = (l1 - lb) < R1_CHUNK ? (l1 - lb) : R1_CHUNK;
+        __syncthreads();
+        const double *src = d.Wd + (size_t)lb * ld;
+        for (int e = t; e < R1_CHUNK * ld; e += blockDim.x) {
+            const int r = e / ld, c = e - r * ld;
+            sW[r * lds_ld + c] = (r < cnt) ? src[e] : 0.0;     // coalesced; zero rows beyond the window's landmarks
+        }
+        if (t < R1_CHUNK) { const double2 cg = (t < cnt) ? d.lm_cg[lb + t] : make_double2(0.0, 0.0); sC[t] = cg.x; sG[t] = cg.x * cg.y; }
+        __syncthreads();
+        if (tile_wave) {
+#pragma unroll 4
+            for (int k4 = 0; k4 < R1_CHUNK; k4 += 4) {
+                const int l = k4 + kq;
+                const double av = sW[l * lds_ld + 16 * I + i] * sC[l], bv = sW[l * lds_ld + 16 * J + i];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+            }
+        } else if (rhs_wave) {
+            for (int l = 0; l < cnt; l++) {
+                const double cgl = sG[l];
+                if (lane < n6) rhs0 += cgl * sW[l * lds_ld + lane];
+                if (lane + 64 < n6) rhs1 += cgl * sW[l * lds_ld + lane + 64];
+            }
+        }
+    }
+    if (tile_wave) {
+        // C/D layout of v_mfma_f64_16x16x4: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int R = 16 * I + kq + 4 * reg, Cc = 16 * J + i;
+            if (R < n6 && Cc < n6 && R >= Cc) {
+                const int fa = Cc / 6, c = Cc - 6 * fa, fb = R / 6, r = R - 6 * fb, bo = fb - fa;
+                if (bo > 0 || c <= r) out[tvis_col(fa, N) + bo * 36 + r * 6 + c] -= acc[reg];
+            }
+        }
+    } else if (rhs_wave) {
+        if (lane < n6) out[tail + 12 * N + lane] = -rhs0;
+        if (lane + 64 < n6) out[tail + 12 * N + lane + 64] = -rhs1;
+    }
+    (void)nw;
 }
 
 // back-substitution of the eliminated landmarks (schur_eliminator BackSubstitute) + the landmark
