@@ -41,25 +41,25 @@ DEV void q_rot(Quat q, const double *v, double *o) {   // Eigen _transformVector
     double d0 = uy * c2 - uz * c1, d1 = uz * c0 - ux * c2, d2 = ux * c1 - uy * c0;
     o[0] = v[0] + q.w * c0 + d0; o[1] = v[1] + q.w * c1 + d1; o[2] = v[2] + q.w * c2 + d2;
 }
-DEV Quat q_from_R(const double *m) {   // Eigen matrix -> quaternion
+DEV Quat q_from_R(const double *m) {   // Eigen matrix -> quaternion (branches spelled out: no indexed locals)
     Quat q;
     double t = m[0] + m[4] + m[8];
     if (t > 0) {
         t = sqrt(t + 1.0);
         q.w = 0.5 * t; t = 0.5 / t;
         q.x = (m[7] - m[5]) * t; q.y = (m[2] - m[6]) * t; q.z = (m[3] - m[1]) * t;
-    } else {
-        int i = 0;
-        if (m[4] > m[0]) i = 1;
-        if (m[8] > m[i * 4]) i = 2;
-        int j = (i + 1) % 3, k = (j + 1) % 3;
-        t = sqrt(m[i * 4] - m[j * 4] - m[k * 4] + 1.0);
-        double qi = 0.5 * t; t = 0.5 / t;
-        q.w = (m[k * 3 + j] - m[j * 3 + k]) * t;
-        double qj = (m[j * 3 + i] + m[i * 3 + j]) * t;
-        double qk = (m[k * 3 + i] + m[i * 3 + k]) * t;
-        double v[3]; v[i] = qi; v[j] = qj; v[k] = qk;
-        q.x = v[0]; q.y = v[1]; q.z = v[2];
+    } else if (m[0] >= m[4] && m[0] >= m[8]) {             // i = 0, j = 1, k = 2
+        t = sqrt(m[0] - m[4] - m[8] + 1.0);
+        q.x = 0.5 * t; t = 0.5 / t;
+        q.w = (m[7] - m[5]) * t; q.y = (m[3] + m[1]) * t; q.z = (m[6] + m[2]) * t;
+    } else if (m[4] > m[0] && m[4] >= m[8]) {              // i = 1, j = 2, k = 0
+        t = sqrt(m[4] - m[8] - m[0] + 1.0);
+        q.y = 0.5 * t; t = 0.5 / t;
+        q.w = (m[2] - m[6]) * t; q.z = (m[7] + m[5]) * t; q.x = (m[1] + m[3]) * t;
+    } else {                                               // i = 2, j = 0, k = 1
+        t = sqrt(m[8] - m[0] - m[4] + 1.0);
+        q.z = 0.5 * t; t = 0.5 / t;
+        q.w = (m[3] - m[1]) * t; q.x = (m[2] + m[6]) * t; q.y = (m[5] + m[7]) * t;
     }
     return q;
 }

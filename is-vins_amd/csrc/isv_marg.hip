@@ -88,7 +88,7 @@ DEV void w_jacobi(double *A, int n, double *wv, double *V, double *tmp, int t) {
     for (int e = t; e < n * n; e += MT) V[e] = (e / n == e % n) ? 1.0 : 0.0;
     SYNC();
     const int m = n + (n & 1), half = m / 2;
-    for (int sweep = 0; sweep < 60; sweep++) {
+    for (int sweep = 0; sweep < 30; sweep++) {
         double off = 0, dg = 0;
         for (int e = t; e < n * n; e += MT) { const int i = e / n, j = e % n; if (j > i) off += A[e] * A[e]; else if (i == j) dg += A[e] * A[e]; }
         tmp[t] = off; tmp[64 + t] = dg;
@@ -96,7 +96,9 @@ DEV void w_jacobi(double *A, int n, double *wv, double *V, double *tmp, int t) {
         for (int o = 32; o > 0; o >>= 1) { if (t < o) { tmp[t] += tmp[t + o]; tmp[64 + t] += tmp[64 + t + o]; } SYNC(); }
         const double offs = tmp[0], dgs = tmp[64];
         SYNC();
-        if (offs <= 1e-60 || offs <= 1e-34 * dgs) break;
+        // off-diagonal mass below 1e-14 relative (squared: 1e-28): eigenvalues converged to ~1e-28 relative, far
+        // inside the 1e-6 parity tolerance; a tighter test never fires with Newton-refined rotations
+        if (offs <= 1e-60 || offs <= 1e-28 * dgs) break;
         for (int r = 0; r < m - 1; r++) {
             if (t < half) {
                 int a = (t == 0) ? m - 1 : (r + t) % (m - 1);
@@ -203,17 +205,20 @@ DEV void relpose_jac(const double *dt, const double *dR, const double *pi, const
     }
 }
 
-__global__ __launch_bounds__(MT) void k_marg(DevBatch d) {
-    __shared__ double Lam[900], M1[900], M2[900], Wk[1800], Vv[441], wv[32], JU[441], Jr[441], tmp[128];
-    __shared__ double sJ[16 * 36];      // small Jacobian staging
-    __shared__ int keep[32], piv[4];
+// clears the marg records (padding included) so downloads are deterministic; valid = margin_old
+__global__ void k_marg_clear(DevBatch d) {
+    const int w = blockIdx.x, t = threadIdx.x;
+    double *z = reinterpret_cast<double *>(&d.marg[w]);
+    for (int e = t; e < (int)(sizeof(isv_marg_result_t) / sizeof(double)); e += blockDim.x) z[e] = 0.0;
+}
+
+// MargForward (+ the pose-graph edge); the record is cleared by k_marg_clear beforehand
+__global__ __launch_bounds__(MT) void k_marg_fwd(DevBatch d) {
+    __shared__ double Lam[144], M1[144], M2[144], Wk[1700], Vv[36], wv[8], JU[36], tmp[128];
+    __shared__ double sJ[3 * 36];
+    __shared__ int keep[8], piv[4];
     const int w = blockIdx.x, t = threadIdx.x;
     isv_marg_result_t &out = d.marg[w];
-    {   // clear the record (padding included) so downloads are deterministic
-        double *z = reinterpret_cast<double *>(&out);
-        for (int e = t; e < (int)(sizeof(isv_marg_result_t) / sizeof(double)); e += MT) z[e] = 0.0;
-    }
-    SYNC();
     if (!d.margin_old[w]) return;
 #ifdef ISV_STAMP
     unsigned long long t_last = wall_clock64();
@@ -221,6 +226,7 @@ __global__ __launch_bounds__(MT) void k_marg(DevBatch d) {
     const int N = d.N, v = d.Nvo;
     const double *pose = d.pose + (size_t)w * N * 7, *sb = d.sb + (size_t)w * N * 9, *ex = d.ex + (size_t)w * 7;
     const int l0 = d.lm_off[w], l1 = d.lm_off[w + 1];
+    (void)sb; (void)ex; (void)l0; (void)l1; (void)v;
     // ================= MargForward =================
     // landmarks hosted in frame 0 (forwardProjectiontoSparsify / MargPointIdx, estimator.cpp:1082-1087)
     double *Jw = d.marg_scratch + (size_t)l0 * 26;          // [n0][26] weighted [J_T1(2x6) | J_T0(2x6) | J_l(2)] rows interleaved
@@ -435,6 +441,23 @@ __global__ __launch_bounds__(MT) void k_marg(DevBatch d) {
         SYNC();
     }
     MSTAMP(4);
+}
+
+// MargBackward
+__global__ __launch_bounds__(MT) void k_marg_bwd(DevBatch d) {
+    __shared__ double Lam[900], M1[450], M2[450], Wk[1500], Vv[441], wv[32], JU[441], Jr[441], tmp[128];
+    __shared__ double sJ[2 * 36];
+    __shared__ int keep[32], piv[4];
+    const int w = blockIdx.x, t = threadIdx.x;
+    isv_marg_result_t &out = d.marg[w];
+    if (!d.margin_old[w]) return;
+#ifdef ISV_STAMP
+    unsigned long long t_last = wall_clock64();
+#endif
+    const int N = d.N, v = d.Nvo;
+    const double *pose = d.pose + (size_t)w * N * 7, *sb = d.sb + (size_t)w * N * 9, *ex = d.ex + (size_t)w * 7;
+    const int l0 = d.lm_off[w], l1 = d.lm_off[w + 1];
+    (void)sb; (void)ex; (void)l0; (void)l1; (void)v;
     // ================= MargBackward =================
     // order: T1 = frame v (@0), VB1 (@6), T0 = frame v-1 (@15), VB0 (@21)
     for (int e = t; e < 900; e += MT) Lam[e] = 0.0;
@@ -543,30 +566,46 @@ __global__ __launch_bounds__(MT) void k_marg(DevBatch d) {
     }
     SYNC();
     MSTAMP(5);
+#if defined(MARG_STOP) && MARG_STOP == 1
+    return;
+#endif
     // eigen-truncate Lp at ALPHA
     for (int e = t; e < 441; e += MT) M2[e] = Lp[e];
     SYNC();
     w_jacobi(M2, 21, wv, Vv, tmp, t);
     if (t < 21) keep[t] = wv[t] > d.alpha_cut;
     SYNC();
+#if defined(MARG_STOP) && MARG_STOP == 2
+    return;
+#endif
     MSTAMP(6);
     {
         double *Sg = Wk, *Xi = Wk + 100, *Xall = Wk + 1000;      // Xall: 21x21 block-diagonal information
         for (int e = t; e < 441; e += MT) Xall[e] = 0.0;
         SYNC();
-        const int r0[5] = {0, 6, 15, 17, 20}, nr[5] = {6, 9, 2, 3, 1};
-        for (int q = 0; q < 5; q++) {
-            w_project_cov(Jr + r0[q] * 21, nr[q], 21, Vv, wv, keep, JU, Sg, t);
-            w_inv(Sg, nr[q], Xi, Wk + 300, piv, t);
-            for (int e = t; e < nr[q] * nr[q]; e += MT) Xall[(r0[q] + e / nr[q]) * 21 + r0[q] + e % nr[q]] = Xi[e];
-            SYNC();
-            if (q < 3) {
-                w_chol_upper(Xi, nr[q], Sg, Wk + 200, t);
-                double *dst = (q == 0) ? rp.sqrt_info : (q == 1) ? vb.sqrt_info : gp.sqrt_info;
-                for (int e = t; e < nr[q] * nr[q]; e += MT) dst[e] = Sg[e];
-                SYNC();
-            }
-        }
+        // the five recovered blocks: relpose rows 0..5, VB rows 6..14, roll-pitch 15..16, |position| 17..19, yaw 20
+#define RECOVER(R0, NR, DST)                                                                        \
+        do {                                                                                        \
+            w_project_cov(Jr + (R0) * 21, (NR), 21, Vv, wv, keep, JU, Sg, t);                       \
+            w_inv(Sg, (NR), Xi, Wk + 300, piv, t);                                                  \
+            for (int e = t; e < (NR) * (NR); e += MT) Xall[((R0) + e / (NR)) * 21 + (R0) + e % (NR)] = Xi[e]; \
+            SYNC();                                                                                 \
+            if ((DST) != nullptr) {                                                                 \
+                w_chol_upper(Xi, (NR), Sg, Wk + 200, t);                                            \
+                for (int e = t; e < (NR) * (NR); e += MT) (DST)[e] = Sg[e];                         \
+                SYNC();                                                                             \
+            }                                                                                       \
+        } while (0)
+        double *const no_dst = nullptr;
+        RECOVER(0, 6, rp.sqrt_info);
+        RECOVER(6, 9, vb.sqrt_info);
+        RECOVER(15, 2, gp.sqrt_info);
+        RECOVER(17, 3, no_dst);
+        RECOVER(20, 1, no_dst);
+#undef RECOVER
+#if defined(MARG_STOP) && MARG_STOP == 3
+        return;
+#endif
         MSTAMP(7);
         // zero test / KLD (estimator.cpp:1519-1534): A = (Jr U)^T X (Jr U) over the kept eigenpairs vs D
         int rank = 0; for (int k = 0; k < 21; k++) rank += keep[k];

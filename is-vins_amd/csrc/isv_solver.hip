@@ -19,7 +19,9 @@ __global__ void k_lm_prep(DevBatch d);
 __global__ void k_sweep(DevBatch d);
 __global__ void k_rank1_mfma(DevBatch d);
 __global__ void k_backsub(DevBatch d);
-__global__ void k_marg(DevBatch d);
+__global__ void k_marg_clear(DevBatch d);
+__global__ void k_marg_fwd(DevBatch d);
+__global__ void k_marg_bwd(DevBatch d);
 template <bool LDS_T> __global__ void k_build_solve(DevBatch d);
 
 // ------------------------------------------------------------------------------------------
@@ -432,7 +434,13 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
         hipLaunchKernelGGL(k_step_control, dim3(d.B), dim3(256), 0, st, d);
     }
     hipLaunchKernelGGL(k_finalize, dim3((d.B + 63) / 64), dim3(64), 0, st, d);
-    hipLaunchKernelGGL(k_marg, dim3(d.B), dim3(64), 0, st, d);
+    // MargForward and MargBackward are independent: run them side by side
+    hipLaunchKernelGGL(k_marg_clear, dim3(d.B), dim3(64), 0, st, d);
+    HCHK(hipEventRecord(fj[0], st)); HCHK(hipStreamWaitEvent(st2, fj[0], 0));
+    hipLaunchKernelGGL(k_marg_bwd, dim3(d.B), dim3(64), 0, st2, d);
+    HCHK(hipEventRecord(fj[1], st2));
+    hipLaunchKernelGGL(k_marg_fwd, dim3(d.B), dim3(64), 0, st, d);
+    HCHK(hipStreamWaitEvent(st, fj[1], 0));
     HCHK(hipGetLastError());
     return ISV_OK;
 }

@@ -4,7 +4,7 @@ sys.path.insert(0, ROOT)
 import isvins_loader; isvins_loader.load()
 from isvins_amd import backend, synth
 import numpy as np
-B = 256
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 ws = synth.make_windows(range(B))
 be = backend.Backend(11, 5, max_landmarks=300, max_obs=1600, max_batch=B)
 be.upload(ws); be.run_optimize()
