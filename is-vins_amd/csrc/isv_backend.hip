@@ -97,7 +97,7 @@ static int create_impl(isv_backend *h) {
     h->prof_ev.assign((size_t)c.num_iterations * ISV_PROF_FAMILIES * 2, nullptr);
     for (auto &e : h->prof_ev) HIPCHK(h, hipEventCreate(&e));
     const size_t B = c.max_batch, N = c.n_frames, L = B * (size_t)c.max_landmarks, F = B * (size_t)c.max_obs;
-    const size_t T = F / ISV_TILE + B + 1;
+    const size_t T = F / (ISV_TILE / 2) + B + 1;      // tiles hold whole landmarks: >= 33 factors each when N <= 32
     h->capB = B; h->capL = L; h->capF = F; h->capTiles = T;
     DevBatch &d = h->d;
     d.N = c.n_frames; d.Nvo = c.n_vo; d.np = 15 * c.n_frames; d.max_rp = c.max_rollpitch; d.max_iter = c.num_iterations;
@@ -216,9 +216,16 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
         }
         s.ck_rec[CK + b] = make_int2((int)L, (int)F);          // sentinel of window b
         if (h->d.lds_T && CK - s.ck_off[b] > 64) { h->err = "window has more than 64 strip chunks"; return ISV_ERR_CAPACITY; }
-        // tiles of <= 64 consecutive factors of this window
-        for (size_t f = s.f_off[b]; f < F; f += ISV_TILE) {
-            s.tile_win[T] = b; s.tile_f0[T] = (int32_t)f; s.tile_n[T] = (int32_t)((F - f) < ISV_TILE ? (F - f) : ISV_TILE); T++;
+        // tiles of <= 64 consecutive factors made of WHOLE landmarks (the linearise kernel reduces a
+        // landmark's factors inside one wavefront)
+        {
+            size_t tf0 = s.f_off[b], tn = 0;
+            for (size_t l = s.lm_off[b]; l < L; l++) {
+                const size_t kf = (size_t)s.lm_k[l] - 1;
+                if (tn + kf > ISV_TILE) { s.tile_win[T] = b; s.tile_f0[T] = (int32_t)tf0; s.tile_n[T] = (int32_t)tn; T++; tf0 += tn; tn = 0; }
+                tn += kf;
+            }
+            if (tn) { s.tile_win[T] = b; s.tile_f0[T] = (int32_t)tf0; s.tile_n[T] = (int32_t)tn; T++; }
         }
         for (int i = 0; i < N - 1; i++) {
             const isv_imu_t &im = w->imu[i];
@@ -294,15 +301,14 @@ static int enqueue_linearize(isv_backend *h, bool timed) {
     const size_t NI = (size_t)d.B * (d.N - 1);
     if (timed) HIPCHK(h, hipEventRecord(h->ev[1], st));
     if (d.n_tiles > 0) {
-        const size_t lds = 4 * proj_lds_doubles_per_wave(d.N) * sizeof(double);
+        const size_t lds = 4 * proj_lds_doubles_per_wave(d.N, 0) * sizeof(double);
         hipLaunchKernelGGL(k_proj_linearize<0>, dim3((d.n_tiles + 3) / 4), dim3(256), lds, st, d, d.pose, d.lam, d.fcost, 0);
         h->last_counts[0] += 1;
     }
     if (timed) HIPCHK(h, hipEventRecord(h->ev[2], st));
     if (NI) hipLaunchKernelGGL(k_imu_linearize<true>, dim3((unsigned)NI), dim3(64), 0, st, d, d.pose, d.sb, d.imu_cost, 0);
     {
-        const int tot = d.B * d.n_prior_slots;
-        hipLaunchKernelGGL(k_prior_linearize<true>, dim3((tot + 63) / 64), dim3(64), 0, st, d, d.pose, d.sb, d.prior_cost, 0);
+        hipLaunchKernelGGL(k_prior_linearize<true>, dim3(d.B), dim3(64), prior_lds_bytes(d.n_prior_slots), st, d, d.pose, d.sb, d.prior_cost, 0);
     }
     hipLaunchKernelGGL(k_cost_reduce, dim3(d.B), dim3(256), 0, st, d, d.fcost, d.imu_cost, d.prior_cost, d.cost, 0);
     if (timed) HIPCHK(h, hipEventRecord(h->ev[3], st));

@@ -1,0 +1,663 @@
+// isv_build_solve_sb.hip -- k_build_solve_sb: structure-aware reduced-system solve (the DENSE_SCHUR
+// linear solve of one trust-region iteration, after the landmarks were eliminated by k_sweep /
+// k_rank1_mfma).  Same mathematics and outputs as k_build_solve (isv_build_solve.hip header), but the
+// 15N x 15N reduced camera matrix is never formed densely:
+//
+//   * unknowns are split into the 6-dof pose blocks (dense among themselves: every frame pair shares
+//     landmarks) and the 9-dof speed/bias blocks, which only couple along the IMU chain
+//     (sb_i -- sb_i+1, sb_i -- pose_i-1..i+1).  The speed/bias blocks are eliminated FIRST, from both
+//     ends of the window towards the middle frame M = N/2 (two independent chains, one wavefront each,
+//     no block barriers), which bounds the fill to sb_i x pose[0..i+1] (i < M), sb_i x pose[i-1..N-1]
+//     (i > M), sb_M x all poses.  The remaining 6N x 6N pose system gets a blocked Cholesky (6x6
+//     blocks, diagonal blocks factored and inverted in registers by one wavefront).
+//   * LDS per window: 6x6 pose blocks (packed lower block triangle, same layout as Tvis) + 9x9
+//     chain blocks + the pose/speed-bias fill = 68.6 KB for N = 11 instead of 118.8 KB for the dense
+//     lower triangle, so TWO windows are resident per CU (160 KB LDS) and hide each other's
+//     barrier / latency stalls; ~4x fewer flops than the dense factorisation as well.
+//   * triangular solves run on one wavefront with wave-level LDS ordering only (no block barriers in
+//     the 2 x (N + N) dependent steps).
+//   * a failed factorisation (mu too small) retries with mu x 10 like ceres' dogleg strategy
+//     (dogleg_strategy.cc ComputeGaussNewtonStep); the landmark part is then corrected in place:
+//     T' = T - sum_l (c_l(mu') - c_l(mu)) w_l w_l^T from the dense w panels (Wd).
+//
+// Outputs (unchanged): zp, gn_p, up, diag_p, grad_p, scale_p, st.qT / gmax / mu / ls_fail / flags.
+#include <hip/hip_runtime.h>
+#include "isv_kernels.h"
+#include "isv_device_math.h"
+
+#define LS 512                     // threads (8 wavefronts); two workgroups per CU
+#define RCH 32                     // landmarks per staged chunk of the retry correction
+
+DEV int sblk(int I, int J, int N) { return (J * N - J * (J - 1) / 2 + (I - J)) * 36; }   // I >= J
+DEV int pairidx2(int a, int b) { return a * (a + 1) / 2 + b; }      // a >= b
+DEV int nlo(int i, int M) { return i > M ? i - 1 : 0; }
+DEV int nhi(int i, int M, int N) { return i < M ? i + 1 : N - 1; }
+DEV int npar(int i, int M) { return i < M ? i + 1 : (i > M ? i - 1 : -1); }
+
+DEV double readlane_d2(double v, int lane) {
+    union { double d; int i[2]; } u; u.d = v;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], lane);
+    u.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
+    return u.d;
+}
+DEV double rsqrt_nr2(double x) {   // 1/sqrt(x) to ~1 ulp: hardware estimate + two Newton steps
+    double r = __builtin_amdgcn_rsq(x);
+    r = r * (1.5 - 0.5 * x * r * r);
+    r = r * (1.5 - 0.5 * x * r * r);
+    return r;
+}
+// wave-level ordering of LDS traffic (LDS executes one wavefront's accesses in issue order)
+#define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
+// Factor the BS x BS SPD block at A (row-major, leading dimension BS, lower part valid) in registers and
+// overwrite it with the INVERSE of its Cholesky factor (lower, upper part zeroed).  One wavefront.
+template <int BS>
+DEV bool chol_inv_block(double *A, int lane) {
+    double row[BS], dinv[BS], x[BS];
+#pragma unroll
+    for (int k = 0; k < BS; k++) row[k] = (lane < BS) ? A[lane * BS + k] : 0.0;
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < BS; j++) {
+        double s = row[j];
+#pragma unroll
+        for (int k = 0; k < j; k++) s -= row[k] * readlane_d2(row[k], j);
+        const double sj = readlane_d2(s, j);               // pivot
+        if (!(sj > 0.0)) bad = true;
+        dinv[j] = rsqrt_nr2(sj);                            // 1 / L_jj (wave-uniform)
+        row[j] = (lane == j) ? sj * dinv[j] : s * dinv[j];
+    }
+#pragma unroll
+    for (int i = 0; i < BS; i++) {                          // lane c solves L x = e_c
+        double s = (lane == i) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < i; k++) s -= readlane_d2(row[k], i) * x[k];
+        x[i] = s * dinv[i];
+    }
+    WSYNC();
+    if (lane < BS) {
+#pragma unroll
+        for (int k = 0; k < BS; k++) A[k * BS + lane] = x[k];   // x[k] = Linv[k][lane], zero for k < lane
+    }
+    WSYNC();
+    return bad;
+}
+
+__global__ __launch_bounds__(LS, 4) void k_build_solve_sb(DevBatch d) {
+    extern __shared__ __align__(16) double lds[];
+    const int w = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    SolveState &st = d.st[w];
+    if (st.termination != ISV_TERM_RUNNING || !st.need_linearize) return;
+    const int N = d.N, n = 15 * N, M = N / 2, n6 = 6 * N, nS = N * (N + 1) / 2 * 36;
+    double *p = lds;
+    double *g = p; p += n;
+    double *bs = p; p += n;
+    double *hdiag = p; p += n;
+    double *sc = p; p += n;
+    double *D = p; p += n;
+    double *y = p; p += n;
+    double *u = p; p += n;
+    double *red = p; p += LS;
+    int *yo = (int *)p; p += 8;              // yo[0..N]: offsets of the fill blocks of each chain node (N <= 15)
+    int *flag = (int *)p; p += 2;
+    double *Spp = p; p += nS;                // pose-pose, packed lower block triangle of 6x6 blocks (Tvis layout)
+    double *Dss = p; p += N * 81;            // speed/bias diagonal blocks -> inverse Cholesky factors
+    double *Css = p; p += N * 81;            // coupling of node i to its parent: rows parent, cols i
+    double *Ysb = p;                         // pose x speed/bias blocks incl. fill: node i, poses nlo..nhi, [6][9]
+
+    if (t == 0) {
+        int o = 0;
+        for (int i = 0; i < N; i++) { yo[i] = o; o += (nhi(i, M, N) - nlo(i, M) + 1) * 54; }
+        yo[N] = o; flag[0] = 0;
+    }
+    __syncthreads();
+    const int ytot = yo[N];
+    const int iteration = st.iteration;
+    double mu = st.mu;
+    int ls_fail = 0, attempt = 0;
+    double gmax_l = 0.0;
+    const int l0 = d.lm_off[w], l1 = d.lm_off[w + 1];
+    const double *V = d.Tvis + (size_t)w * d.tvis_sz;
+
+    // decode a packed Spp entry index into (I, J, r, c)
+    auto spp_decode = [&](int e, int &I, int &J, int &r, int &c) {
+        const int q = e / 36, rc = e - 36 * q;
+        r = rc / 6; c = rc - 6 * r;
+        int ca = 0;
+        while (ca + 1 < N && (ca + 1) * N - (ca + 1) * ca / 2 <= q) ca++;
+        J = ca; I = ca + (q - (ca * N - ca * (ca - 1) / 2));
+    };
+
+    for (;;) {
+        if (!(mu < 1.0)) { ls_fail = 1; break; }
+        for (int e = t; e < n; e += LS) { g[e] = 0.0; bs[e] = 0.0; hdiag[e] = 0.0; }
+        // ---- reprojection part from k_sweep / k_rank1_mfma (same packed layout) ----------------------
+        for (int e = t; e < nS; e += LS) Spp[e] = V[e];
+        __syncthreads();
+        for (int e = t; e < n6; e += LS) {
+            const int fa = e / 6, r = e - 6 * fa;
+            hdiag[15 * fa + r] = V[nS + e]; g[15 * fa + r] = V[nS + n6 + e]; bs[15 * fa + r] = V[nS + 2 * n6 + e];
+        }
+        if (attempt == 0) {
+            for (int l = l0 + t; l < l1; l += LS) gmax_l = fmax(gmax_l, fabs(d.lmG[l]));
+        } else {
+            // ---- mu retry: T -= sum_l (c_l(mu) - c_l(mu0)) w_l w_l^T, bs -= sum_l dc_l g_l w_l --------
+            double *wS = Dss;                               // [RCH][67] staging (Dss/Css/Ysb are rebuilt below)
+            double *dC = red, *dG = red + RCH;
+            int ra[5], cb[5];
+            double accs[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const int e = t + k * LS;
+                int I = 0, J = 0, r = 0, c = 0;
+                if (e < nS) spp_decode(e, I, J, r, c);
+                ra[k] = 6 * I + r; cb[k] = 6 * J + c; accs[k] = 0;
+            }
+            double accb = 0;
+            const int ld = d.wd_ld;
+            for (int lb = l0; lb < l1; lb += RCH) {
+                const int cnt = (l1 - lb) < RCH ? (l1 - lb) : RCH;
+                __syncthreads();
+                const double *src = d.Wd + (size_t)lb * ld;
+                for (int e = t; e < cnt * ld; e += LS) {
+                    const int r = e / ld, c = e - r * ld;
+                    if (c < n6) wS[r * 67 + c] = src[e];
+                }
+                if (t < cnt) {
+                    const int l = lb + t;
+                    const double2 cg = d.lm_cg[l];
+                    const double sl = d.scale_l[l], Es = sl * sl * d.lmE[l];
+                    const double Dl2 = fmin(fmax(Es, 1e-6), 1e32);
+                    const double dc = sl * sl / (Es + mu * Dl2) - cg.x;
+                    dC[t] = dc; dG[t] = dc * cg.y;
+                }
+                __syncthreads();
+                for (int l = 0; l < cnt; l++) {
+                    const double *wr = wS + l * 67;
+                    const double dc = dC[l];
+#pragma unroll
+                    for (int k = 0; k < 5; k++) accs[k] += dc * wr[ra[k]] * wr[cb[k]];
+                    if (t < n6) accb += dG[l] * wr[t];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 5; k++) { const int e = t + k * LS; if (e < nS) Spp[e] -= accs[k]; }
+            if (t < n6) bs[15 * (t / 6) + t % 6] -= accb;
+            __syncthreads();
+        }
+        for (int e = t; e < 162 * N + ytot; e += LS) Dss[e] = 0.0;      // Dss, Css, Ysb are contiguous
+        __syncthreads();
+        // ---- IMU factors (precomputed J^T J, local order pose_i sb_i pose_j sb_j) ---------------------
+        {
+            const double *H = d.imu_H + (size_t)w * (N - 1) * ISV_IMU_H;
+            const int *skip = d.imu_skip + (size_t)w * (N - 1);
+            for (int e = t; e < N * 120; e += LS) {         // per frame: pose diag (21), sb diag (45), pose x sb (54)
+                const int I = e / 120;
+                int q = e - 120 * I;
+                const bool hasA = I >= 1 && !skip[I - 1], hasB = I <= N - 2 && !skip[I];
+                const double *HA = H + (size_t)(I - 1) * ISV_IMU_H, *HB = H + (size_t)I * ISV_IMU_H;
+                if (q < 21) {
+                    int r = 0; while ((r + 1) * (r + 2) / 2 <= q) r++;
+                    const int c = q - r * (r + 1) / 2;
+                    double v = 0;
+                    if (hasA) v += HA[pairidx2(15 + r, 15 + c)];
+                    if (hasB) v += HB[pairidx2(r, c)];
+                    Spp[sblk(I, I, N) + r * 6 + c] += v;
+                    if (r == c) hdiag[15 * I + r] += v;
+                } else if (q < 66) {
+                    q -= 21;
+                    int r = 0; while ((r + 1) * (r + 2) / 2 <= q) r++;
+                    const int c = q - r * (r + 1) / 2;
+                    double v = 0;
+                    if (hasA) v += HA[pairidx2(21 + r, 21 + c)];
+                    if (hasB) v += HB[pairidx2(6 + r, 6 + c)];
+                    Dss[I * 81 + r * 9 + c] = v;
+                    if (r == c) hdiag[15 * I + 6 + r] = v;
+                } else {
+                    q -= 66;
+                    const int r = q / 9, c = q - 9 * r;     // pose row r, speed/bias column c of frame I
+                    double v = 0;
+                    if (hasA) v += HA[pairidx2(21 + c, 15 + r)];
+                    if (hasB) v += HB[pairidx2(6 + c, r)];
+                    Ysb[yo[I] + (I - nlo(I, M)) * 54 + q] = v;
+                }
+            }
+            for (int e = t; e < (N - 1) * 225; e += LS) {   // per factor: the blocks between frames I and I + 1
+                const int I = e / 225;
+                int q = e - 225 * I;
+                if (skip[I]) continue;
+                const double *HB = H + (size_t)I * ISV_IMU_H;
+                if (q < 36) {
+                    const int r = q / 6, c = q - 6 * r;
+                    Spp[sblk(I + 1, I, N) + q] += HB[pairidx2(15 + r, c)];
+                } else if (q < 90) {
+                    q -= 36;
+                    const int r = q / 9, c = q - 9 * r;     // pose_{I+1} x sb_I
+                    Ysb[yo[I] + (I + 1 - nlo(I, M)) * 54 + q] = HB[pairidx2(15 + r, 6 + c)];
+                } else if (q < 144) {
+                    q -= 90;
+                    const int r = q / 9, c = q - 9 * r;     // pose_I x sb_{I+1}
+                    Ysb[yo[I + 1] + (I - nlo(I + 1, M)) * 54 + q] = HB[pairidx2(21 + c, r)];
+                } else {
+                    q -= 144;
+                    const int r = q / 9, c = q - 9 * r;     // sb_{I+1} (r) x sb_I (c): rows = parent, cols = child
+                    const double v = HB[pairidx2(21 + r, 6 + c)];
+                    if (I < M) Css[I * 81 + r * 9 + c] = v; else Css[(I + 1) * 81 + c * 9 + r] = v;
+                }
+            }
+            for (int e = t; e < n; e += LS) {
+                const int I = e / 15, r = e - 15 * I;
+                double v = 0;
+                if (I >= 1 && !skip[I - 1]) v += H[(size_t)(I - 1) * ISV_IMU_H + 465 + 15 + r];
+                if (I <= N - 2 && !skip[I]) v += H[(size_t)I * ISV_IMU_H + 465 + r];
+                g[e] += v;
+            }
+        }
+        __syncthreads();
+        // ---- prior factors (precomputed J^T J) -------------------------------------------------------
+        {
+            const double *PH = d.prior_H + (size_t)w * d.prior_H_sz;
+            const int nprior = 2 + (d.Nvo - 1) + d.n_rp[w];
+            for (int q = 0; q < nprior; q++) {
+                int ncol, off, c0, c1 = 0;
+                if (q == 0) { ncol = 6; off = PH_SE3; c0 = 0; }
+                else if (q == 1) { ncol = 9; off = PH_LIN9; c0 = 15 * (d.Nvo - 1) + 6; }
+                else if (q < 1 + d.Nvo) { const int k = q - 2; ncol = 12; off = PH_REL0 + PH_REL_SZ * k; c0 = 15 * k; c1 = 15 * (k + 1); }
+                else { const int m = q - 1 - d.Nvo; ncol = 6; off = PH_REL0 + PH_REL_SZ * (d.Nvo - 1) + PH_RP_SZ * m; c0 = 15 * d.rollpitch[(size_t)w * d.max_rp + m].index; }
+                const int np2 = ncol * (ncol + 1) / 2;
+                for (int e = t; e < np2 + ncol; e += LS) {
+                    if (e < np2) {
+                        int aa = 0;
+                        while ((aa + 1) * (aa + 2) / 2 <= e) aa++;
+                        const int bb = e - aa * (aa + 1) / 2;
+                        const int ga = (aa < 6 || ncol != 12) ? c0 + aa : c1 + aa - 6;
+                        const int gb = (bb < 6 || ncol != 12) ? c0 + bb : c1 + bb - 6;
+                        const double v = PH[off + e];
+                        const int Ia = ga / 15, ra = ga - 15 * Ia, Ib = gb / 15, rb = gb - 15 * Ib;
+                        if (ra < 6) Spp[sblk(Ia, Ib, N) + ra * 6 + rb] += v;
+                        else Dss[Ia * 81 + (ra - 6) * 9 + (rb - 6)] += v;
+                        if (aa == bb) hdiag[ga] += v;
+                    } else {
+                        const int aa = e - np2;
+                        const int ga = (aa < 6 || ncol != 12) ? c0 + aa : c1 + aa - 6;
+                        g[ga] += PH[off + e];
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        // ---- Jacobi scaling, LM diagonal, Cauchy data -------------------------------------------------
+        for (int e = t; e < n; e += LS) {
+            double s;
+            if (iteration == 0) { s = 1.0 / (1.0 + sqrt(hdiag[e])); d.scale_p[(size_t)w * n + e] = s; }
+            else s = d.scale_p[(size_t)w * n + e];
+            const double D2 = fmin(fmax(s * s * hdiag[e], 1e-6), 1e32);
+            sc[e] = s; D[e] = sqrt(D2);
+            d.diag_p[(size_t)w * n + e] = D[e];
+            d.grad_p[(size_t)w * n + e] = s * g[e] / D[e];
+            u[e] = s * s * g[e] / D2;
+            d.up[(size_t)w * n + e] = u[e];
+            y[e] = s * (g[e] + bs[e]);
+        }
+        __syncthreads();
+        {   // qT = u^T T u on the unscaled blocks, then scale in place and add the LM diagonal
+            double accq = 0;
+            for (int e = t; e < nS; e += LS) {
+                int I, J, r, c;
+                spp_decode(e, I, J, r, c);
+                if (I == J && r < c) continue;
+                const int gi = 15 * I + r, gj = 15 * J + c;
+                const double v = Spp[e];
+                accq += (gi == gj ? 1.0 : 2.0) * v * u[gi] * u[gj];
+                double sv = v * sc[gi] * sc[gj];
+                if (gi == gj) sv += mu * D[gi] * D[gi];
+                Spp[e] = sv;
+            }
+            for (int e = t; e < 81 * N; e += LS) {
+                const int I = e / 81, rc = e - 81 * I, r = rc / 9, c = rc - 9 * r;
+                if (r < c) continue;
+                const int gi = 15 * I + 6 + r, gj = 15 * I + 6 + c;
+                const double v = Dss[e];
+                accq += (gi == gj ? 1.0 : 2.0) * v * u[gi] * u[gj];
+                double sv = v * sc[gi] * sc[gj];
+                if (gi == gj) sv += mu * D[gi] * D[gi];
+                Dss[e] = sv;
+            }
+            for (int e = t; e < 81 * N; e += LS) {
+                const int i = e / 81, rc = e - 81 * i, r = rc / 9, c = rc - 9 * r, pp = npar(i, M);
+                if (pp < 0) continue;
+                const int gi = 15 * pp + 6 + r, gj = 15 * i + 6 + c;
+                const double v = Css[e];
+                accq += 2.0 * v * u[gi] * u[gj];
+                Css[e] = v * sc[gi] * sc[gj];
+            }
+            for (int e = t; e < ytot; e += LS) {
+                int i = 0;
+                while (yo[i + 1] <= e) i++;
+                const int q = e - yo[i], ai = q / 54, rc = q - 54 * ai, r = rc / 9, c = rc - 9 * r;
+                const int gi = 15 * (nlo(i, M) + ai) + r, gj = 15 * i + 6 + c;
+                const double v = Ysb[e];
+                accq += 2.0 * v * u[gi] * u[gj];
+                Ysb[e] = v * sc[gi] * sc[gj];
+            }
+            red[t] = accq;
+            __syncthreads();
+            for (int off = LS / 2; off > 0; off >>= 1) { if (t < off) red[t] += red[t + off]; __syncthreads(); }
+            if (t == 0) st.qT = red[0];
+        }
+        __syncthreads();
+        // ---- speed/bias chains: wavefront 0 forward (0 .. M-1), wavefront 1 backward (N-1 .. M+1) ----
+        // node i: (1) D_i -> inverse Cholesky factor; (2) rows of [C_i ; Y_i] times L_i^-T;
+        //         (3) downdate the parent's diagonal block and pose coupling (not for children of M here:
+        //             both chains end in M, those two downdates are applied after the join).
+        auto node_rows = [&](int i, bool has_par) {            // step (2), executed by one wavefront
+            const int nr = nhi(i, M, N) - nlo(i, M) + 1, nrows = (has_par ? 9 : 0) + 6 * nr;
+            const double *Li = Dss + i * 81;
+            for (int rho = lane; rho < nrows; rho += 64) {
+                double *ptr = (has_par && rho < 9) ? Css + i * 81 + rho * 9 : Ysb + yo[i] + (rho - (has_par ? 9 : 0)) * 9;
+                double v[9], o[9];
+#pragma unroll
+                for (int k = 0; k < 9; k++) v[k] = ptr[k];
+#pragma unroll
+                for (int c = 0; c < 9; c++) {
+                    double s = 0;
+#pragma unroll
+                    for (int k = 0; k <= c; k++) s += v[k] * Li[c * 9 + k];
+                    o[c] = s;
+                }
+#pragma unroll
+                for (int k = 0; k < 9; k++) ptr[k] = o[k];
+            }
+            WSYNC();
+        };
+        auto node_downdate = [&](int i, int lid, int nl) {     // step (3) with nl lanes, lane id lid
+            const int pp = npar(i, M), lo = nlo(i, M), nr = nhi(i, M, N) - lo + 1;
+            const double *C = Css + i * 81, *Yi = Ysb + yo[i];
+            double *Yp = Ysb + yo[pp] + (lo - nlo(pp, M)) * 54;
+            for (int e = lid; e < 45 + 54 * nr; e += nl) {
+                if (e < 45) {
+                    int r = 0; while ((r + 1) * (r + 2) / 2 <= e) r++;
+                    const int c = e - r * (r + 1) / 2;
+                    double s = 0;
+#pragma unroll
+                    for (int k = 0; k < 9; k++) s += C[r * 9 + k] * C[c * 9 + k];
+                    Dss[pp * 81 + r * 9 + c] -= s;
+                } else {
+                    const int q = e - 45, row = q / 9, c = q - 9 * row;     // row = (a - lo) * 6 + r
+                    double s = 0;
+#pragma unroll
+                    for (int k = 0; k < 9; k++) s += Yi[row * 9 + k] * C[c * 9 + k];
+                    Yp[row * 9 + c] -= s;
+                }
+            }
+        };
+        if (wv < 2) {
+            const int cnt = wv == 0 ? M : N - 1 - M;
+            for (int k = 0; k < cnt; k++) {
+                const int i = wv == 0 ? k : N - 1 - k;
+                if (chol_inv_block<9>(Dss + i * 81, lane)) { if (lane == 0) flag[0] = 1; break; }
+                node_rows(i, true);
+                if (npar(i, M) != M) { node_downdate(i, lane, 64); WSYNC(); }
+            }
+        }
+        __syncthreads();
+        if (!flag[0]) {
+            if (M >= 1) node_downdate(M - 1, t, LS);
+            __syncthreads();
+            if (M + 1 <= N - 1) node_downdate(M + 1, t, LS);
+            __syncthreads();
+            if (wv == 0) {
+                if (chol_inv_block<9>(Dss + M * 81, lane)) { if (lane == 0) flag[0] = 1; }
+                else node_rows(M, false);
+            }
+            __syncthreads();
+        }
+        if (!flag[0]) {
+            // ---- pose system: Spp -= sum_i Y_i Y_i^T ---------------------------------------------------
+            for (int e = t; e < nS; e += LS) {
+                int I, J, r, c;
+                spp_decode(e, I, J, r, c);
+                if (I == J && r < c) continue;
+                double s = 0;
+                for (int i = 0; i < N; i++) {
+                    const int lo = nlo(i, M), hi = nhi(i, M, N);
+                    if (J >= lo && I <= hi) {
+                        const double *YI = Ysb + yo[i] + (I - lo) * 54 + r * 9, *YJ = Ysb + yo[i] + (J - lo) * 54 + c * 9;
+#pragma unroll
+                        for (int k = 0; k < 9; k++) s += YI[k] * YJ[k];
+                    }
+                }
+                Spp[e] -= s;
+            }
+            __syncthreads();
+            // ---- blocked Cholesky of the pose system (6x6 blocks; diagonal blocks hold L_JJ^-1 afterwards)
+            for (int J = 0; J < N; J++) {
+                if (wv == 0 && chol_inv_block<6>(Spp + sblk(J, J, N), lane)) { if (lane == 0) flag[0] = 1; }
+                __syncthreads();
+                if (flag[0]) break;
+                const int m = N - J - 1;
+                if (m == 0) break;
+                const double *Li = Spp + sblk(J, J, N);
+                for (int rr = t; rr < m * 6; rr += LS) {        // panel rows: X = A L_JJ^-T
+                    double *A = Spp + sblk(J + 1, J, N) + rr * 6;   // blocks (J+1.., J) are contiguous
+                    double v[6], o[6];
+#pragma unroll
+                    for (int k = 0; k < 6; k++) v[k] = A[k];
+#pragma unroll
+                    for (int c = 0; c < 6; c++) {
+                        double s = 0;
+#pragma unroll
+                        for (int k = 0; k <= c; k++) s += v[k] * Li[c * 6 + k];
+                        o[c] = s;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 6; k++) A[k] = o[k];
+                }
+                __syncthreads();
+                // trailing update: S[I,K] -= X_I X_K^T for I >= K > J (packed columns J+1.. are contiguous)
+                const int e0 = sblk(J + 1, J + 1, N), cntT = m * (m + 1) / 2 * 36;
+                const double *X = Spp + sblk(J + 1, J, N);       // X_I at (I - J - 1) * 36
+                for (int e = t; e < cntT; e += LS) {
+                    const int q = e / 36, rc = e - 36 * q, r = rc / 6, c = rc - 6 * r;
+                    int ca = 0;                                  // column within the trailing triangle
+                    while (ca + 1 < m && (ca + 1) * m - (ca + 1) * ca / 2 <= q) ca++;
+                    const int ia = ca + (q - (ca * m - ca * (ca - 1) / 2));
+                    if (ia == ca && r < c) continue;
+                    const double *XI = X + ia * 36 + r * 6, *XK = X + ca * 36 + c * 6;
+                    double s = 0;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) s += XI[k] * XK[k];
+                    Spp[e0 + e] -= s;
+                }
+                __syncthreads();
+            }
+        }
+        __syncthreads();
+        if (flag[0]) {
+            mu *= 10.0; attempt++;
+            __syncthreads();
+            if (t == 0) flag[0] = 0;
+            __syncthreads();
+            continue;
+        }
+        // ---- forward substitution: chains (elimination order), then the pose block ---------------------
+        const int nlev = M > N - 1 - M ? M : N - 1 - M;
+        if (wv == 0) {
+            for (int k = 0; k <= nlev; k++) {
+                for (int side = 0; side < 2; side++) {
+                    int i;
+                    if (k == nlev) { if (side) break; i = M; }
+                    else { i = side == 0 ? k : N - 1 - k; if (side == 0 ? i >= M : i <= M) continue; }
+                    const double *Li = Dss + i * 81;
+                    double yin[9], z = 0;
+#pragma unroll
+                    for (int kk = 0; kk < 9; kk++) yin[kk] = y[15 * i + 6 + kk];
+                    if (lane < 9) {
+#pragma unroll
+                        for (int kk = 0; kk < 9; kk++) if (kk <= lane) z += Li[lane * 9 + kk] * yin[kk];
+                    }
+                    WSYNC();
+                    if (lane < 9) y[15 * i + 6 + lane] = z;
+                    WSYNC();
+                    const int pp = npar(i, M);
+                    if (pp >= 0 && lane < 9) {
+                        double s = 0;
+#pragma unroll
+                        for (int kk = 0; kk < 9; kk++) s += Css[i * 81 + lane * 9 + kk] * y[15 * i + 6 + kk];
+                        y[15 * pp + 6 + lane] -= s;
+                    }
+                    WSYNC();
+                }
+            }
+        }
+        __syncthreads();
+        if (t < n6) {                                           // pose rhs -= sum_i Y_i z_i
+            const int a = t / 6, r = t - 6 * a;
+            double s = 0;
+            for (int i = 0; i < N; i++) {
+                const int lo = nlo(i, M);
+                if (a >= lo && a <= nhi(i, M, N)) {
+                    const double *Yr = Ysb + yo[i] + (a - lo) * 54 + r * 9;
+#pragma unroll
+                    for (int k = 0; k < 9; k++) s += Yr[k] * y[15 * i + 6 + k];
+                }
+            }
+            y[15 * a + r] -= s;
+        }
+        __syncthreads();
+        if (wv == 0) {
+            for (int J = 0; J < N; J++) {                       // forward, pose block
+                const double *Li = Spp + sblk(J, J, N);
+                double yin[6], z = 0;
+#pragma unroll
+                for (int k = 0; k < 6; k++) yin[k] = y[15 * J + k];
+                if (lane < 6) {
+#pragma unroll
+                    for (int k = 0; k < 6; k++) if (k <= lane) z += Li[lane * 6 + k] * yin[k];
+                }
+                WSYNC();
+                if (lane < 6) y[15 * J + lane] = z;
+                WSYNC();
+                for (int rho = 6 * (J + 1) + lane; rho < n6; rho += 64) {
+                    const int I = rho / 6, r = rho - 6 * I;
+                    const double *Lr = Spp + sblk(I, J, N) + r * 6;
+                    double s = 0;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) s += Lr[k] * y[15 * J + k];
+                    y[15 * I + r] -= s;
+                }
+                WSYNC();
+            }
+            for (int J = N - 1; J >= 0; J--) {                  // backward, pose block (right-looking)
+                const double *Li = Spp + sblk(J, J, N);
+                double xin[6], x = 0;
+#pragma unroll
+                for (int k = 0; k < 6; k++) xin[k] = y[15 * J + k];
+                if (lane < 6) {
+#pragma unroll
+                    for (int k = 0; k < 6; k++) if (k >= lane) x += Li[k * 6 + lane] * xin[k];
+                }
+                WSYNC();
+                if (lane < 6) y[15 * J + lane] = x;
+                WSYNC();
+                for (int rho = lane; rho < 6 * J; rho += 64) {
+                    const int K = rho / 6, c = rho - 6 * K;
+                    const double *Lb = Spp + sblk(J, K, N) + c;
+                    double s = 0;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) s += Lb[k * 6] * y[15 * J + k];
+                    y[15 * K + c] -= s;
+                }
+                WSYNC();
+            }
+        }
+        __syncthreads();
+        if (t < 9 * N) {                                        // chain rhs -= Y_i^T x_pose
+            const int i = t / 9, c = t - 9 * i, lo = nlo(i, M), nr = nhi(i, M, N) - lo + 1;
+            const double *Yc = Ysb + yo[i] + c;
+            double s = 0;
+            for (int row = 0; row < 6 * nr; row++) s += Yc[row * 9] * y[15 * (lo + row / 6) + row % 6];
+            y[15 * i + 6 + c] -= s;
+        }
+        __syncthreads();
+        if (wv == 0) {
+            for (int k = nlev; k >= 0; k--) {                   // backward, chains (reverse elimination order)
+                for (int side = 0; side < 2; side++) {
+                    int i;
+                    if (k == nlev) { if (side) break; i = M; }
+                    else { i = side == 0 ? k : N - 1 - k; if (side == 0 ? i >= M : i <= M) continue; }
+                    const double *Li = Dss + i * 81;
+                    const int pp = npar(i, M);
+                    double s = 0;
+                    if (lane < 9) {
+                        s = y[15 * i + 6 + lane];
+                        if (pp >= 0) {
+#pragma unroll
+                            for (int kk = 0; kk < 9; kk++) s -= Css[i * 81 + kk * 9 + lane] * y[15 * pp + 6 + kk];
+                        }
+                    }
+                    WSYNC();
+                    if (lane < 9) y[15 * i + 6 + lane] = s;
+                    WSYNC();
+                    double x = 0;
+                    if (lane < 9) {
+#pragma unroll
+                        for (int kk = 0; kk < 9; kk++) if (kk >= lane) x += Li[kk * 9 + lane] * y[15 * i + 6 + kk];
+                    }
+                    WSYNC();
+                    if (lane < 9) y[15 * i + 6 + lane] = x;
+                    WSYNC();
+                }
+            }
+        }
+        __syncthreads();
+        break;
+    }
+    if (!ls_fail) {
+        for (int e = t; e < n; e += LS) {
+            d.zp[(size_t)w * n + e] = sc[e] * y[e];
+            d.gn_p[(size_t)w * n + e] = -D[e] * y[e];
+        }
+    }
+    {
+        double m = gmax_l;
+        for (int i = t; i < N; i += LS) {
+            const double *x = d.pose + ((size_t)w * N + i) * 7;
+            double ng[6], xp[7];
+            for (int k = 0; k < 6; k++) ng[k] = -g[15 * i + k];
+            pose_plus(x, ng, xp);
+            for (int k = 0; k < 7; k++) m = fmax(m, fabs(x[k] - xp[k]));
+            for (int k = 0; k < 9; k++) m = fmax(m, fabs(g[15 * i + 6 + k]));
+        }
+        __syncthreads();
+        red[t] = m;
+        __syncthreads();
+        for (int off = LS / 2; off > 0; off >>= 1) { if (t < off) red[t] = fmax(red[t], red[t + off]); __syncthreads(); }
+    }
+    if (t == 0) {
+        st.gmax = red[0];
+        st.mu = mu;
+        st.ls_fail = ls_fail;
+        st.need_linearize = 0;
+        st.fresh = 1;
+        st.x_cost = d.cost[w];
+        if (iteration == 0) {
+            st.initial_cost = d.cost[w];
+            d.trace_cost[(size_t)w * ISV_MAX_TRACE] = d.cost[w];
+            d.trace_radius[(size_t)w * ISV_MAX_TRACE] = st.radius;
+        }
+        if (st.gmax <= 1e-10) st.termination = ISV_TERM_GRADIENT_TOL;
+    }
+}
+
+size_t build_solve_sb_bytes(int N) {
+    const int M = N / 2;
+    size_t ytot = 0;
+    for (int i = 0; i < N; i++) ytot += (size_t)((i < M ? i + 1 : N - 1) - (i > M ? i - 1 : 0) + 1) * 54;
+    const size_t n = 15 * (size_t)N, nS = (size_t)N * (N + 1) / 2 * 36;
+    size_t tail = 162 * (size_t)N + ytot;
+    const size_t stage = (size_t)RCH * 67;                      // retry staging lives in the Dss/Css/Ysb region
+    if (tail < stage) tail = stage;
+    return (7 * n + LS + 8 + 2 + nS + tail + 2) * sizeof(double);
+}

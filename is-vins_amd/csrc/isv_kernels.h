@@ -5,7 +5,8 @@
 #include <vector>
 #include "isv_device_types.h"
 
-__host__ __device__ inline size_t proj_lds_doubles_per_wave(int N) { return (size_t)N * 12 + 12 + 64 * 30; }
+// per-wave LDS of k_proj_linearize<MODE>: R,P per frame + extrinsic; MODE 0 adds a 64 x 15 transpose buffer
+__host__ __device__ inline size_t proj_lds_doubles_per_wave(int N, int mode) { return (size_t)N * 12 + 12 + (mode == 0 ? 64 * 15 : 0); }
 
 __global__ void k_vector2double(DevBatch d);
 __global__ void k_imu_prep(DevBatch d);
@@ -17,6 +18,7 @@ __global__ void k_cost_reduce(DevBatch d, const double *fcost, const double *imu
 // solver stage (isv_solver.hip)
 int isv_solver_alloc(DevBatch &d, size_t B, size_t L, size_t F, std::vector<void *> &allocs, std::string &err);
 int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t *fj, int64_t *counts, hipEvent_t *prof_ev, std::string &err);
+static inline size_t prior_lds_bytes(int slots) { return (size_t)slots * (82 + 90 + 82) * sizeof(double); }
 #define ISV_PROF_FAMILIES 3      // 0 = k_proj_linearize<0>, 1 = k_sweep, 2 = k_build_solve*
 int isv_solver_download(DevBatch &d, hipStream_t st, int n, isv_summary_t *summary, isv_marg_result_t *marg, std::string &err);
 int isv_solver_debug_read(DevBatch &d, hipStream_t st, int what, double *out, int64_t count, std::string &err);

@@ -108,9 +108,9 @@ __global__ __launch_bounds__(64) void k_imu_prep(DevBatch d) {
 // ------------------------------------------------------------------------------------------
 #include "isv_proj_factor.h"
 
-#define TILE_LD 30     // padded strip row in LDS (doubles): 16-B aligned pairs for ds_read_b128
+#define TILE_LD 15     // LDS row of the half-strip transpose (14 doubles + 1: odd stride, conflict-free)
 
-// LDS per wave: N*12 (R,P per frame) + 12 (ric,tic) + 64*TILE_LD doubles
+// LDS per wave: N*12 (R,P per frame) + 12 (ric,tic) [+ 64*TILE_LD doubles in MODE 0]
 #include "isv_kernels.h"
 
 // MODE 0: linearise at x (strips + per-factor cost).  MODE 1: cost only at the candidate point
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void k_proj_linearize(DevBatch d, const double
         live = ss.termination == ISV_TERM_RUNNING && (gate == 1 ? ss.need_linearize != 0 : ss.step_valid != 0);
     }
     const int N = d.N;
-    double *sPose = lds + (size_t)wv * proj_lds_doubles_per_wave(N);
+    double *sPose = lds + (size_t)wv * proj_lds_doubles_per_wave(N, MODE);
     double *sEx = sPose + N * 12;
     double *sOut = sEx + 12;
     const int win = live ? d.tile_win[tile] : 0, f0 = live ? d.tile_f0[tile] : 0, n = live ? d.tile_n[tile] : 0;
@@ -149,6 +149,8 @@ __global__ __launch_bounds__(256) void k_proj_linearize(DevBatch d, const double
     __syncthreads();
 
     double r0 = 0, r1 = 0, Ji[12], Jj[12], Jl[2], cost = 0;
+    double lm_e = 0, lm_g = 0, lm_wh[6] = {0, 0, 0, 0, 0, 0};     // per-factor pieces of the landmark scalars
+    int lm_id = -1;
     const bool active = lane < n;
     if (active) {
         const int f = f0 + lane;
@@ -190,6 +192,10 @@ __global__ __launch_bounds__(256) void k_proj_linearize(DevBatch d, const double
             d.fmodel[f] = m0 * (sx[0] + m0 / 2.0) + m1 * (sx[1] + m1 / 2.0);
         }
         if (MODE == 0) {
+            lm_e = Jl[0] * Jl[0] + Jl[1] * Jl[1]; lm_g = Jl[0] * r0 + Jl[1] * r1;
+#pragma unroll
+            for (int c2 = 0; c2 < 6; c2++) lm_wh[c2] = Ji[c2] * Jl[0] + Ji[6 + c2] * Jl[1];
+            lm_id = rec.lm;
             // w of the observing frame for the Schur sweep: J_pose_j^T J_lambda (6), obs slot f + lm + 1
             double *wo = d.W + (size_t)(f + rec.lm + 1) * 6;
             double *wd = d.Wd + (size_t)rec.lm * d.wd_ld + 6 * fj;      // dense copy for the MFMA panels
@@ -198,26 +204,69 @@ __global__ __launch_bounds__(256) void k_proj_linearize(DevBatch d, const double
         }
     }
     if (MODE != 0) return;                            // uniform over the block
-    // transpose through LDS: lane l owns row l of sOut[64][TILE_LD]
-    {
-        double *row = sOut + lane * TILE_LD;
-        row[0] = r0; row[1] = r1;
+    if (gate == 1) {
+        // Landmark scalars (what SchurEliminator needs per e-block), fused here: a landmark's factors are
+        // adjacent lanes of this wavefront (tiles hold whole landmarks), so its first lane sums the pieces
+        // of the following lanes in factor order: E = J_l^T J_l, g_l = J_l^T r, host-frame w = sum J_i^T J_l.
+        const int prev = __shfl_up(lm_id, 1);
+        const bool first = active && (lane == 0 || prev != lm_id);
+        const int cnt = first ? d.lm_k[lm_id] - 1 : 0;
+        for (int m = 1; m < ISV_MAX_FRAMES; m++) {
+            if (!__ballot(first && m < cnt)) break;            // wave-uniform
+            const double e_m = __shfl_down(lm_e, m), g_m = __shfl_down(lm_g, m);
+            double w_m[6];
 #pragma unroll
-        for (int k = 0; k < 12; k++) { row[2 + k] = Ji[k]; row[14 + k] = Jj[k]; }
-        row[26] = Jl[0]; row[27] = Jl[1];
-    }
-    __syncthreads();
-    // 14 coalesced 16-B/lane stores: element pair e = it*128 + 2*lane of the tile's n*28 doubles
-    double *gout = d.strip + (size_t)f0 * ISV_PROJ_STRIP;
-    const int total = n * ISV_PROJ_STRIP;
+            for (int c2 = 0; c2 < 6; c2++) w_m[c2] = __shfl_down(lm_wh[c2], m);
+            if (first && m < cnt) {
+                lm_e += e_m; lm_g += g_m;
 #pragma unroll
-    for (int it = 0; it < 14; it++) {
-        const int e = it * 128 + 2 * lane;
-        if (e < total) {
-            const int ff = e / ISV_PROJ_STRIP, c = e - ff * ISV_PROJ_STRIP;
-            const double2 v = *reinterpret_cast<const double2 *>(sOut + ff * TILE_LD + c);
-            *reinterpret_cast<double2 *>(gout + e) = v;
+                for (int c2 = 0; c2 < 6; c2++) lm_wh[c2] += w_m[c2];
+            }
         }
+        if (first) {
+            const SolveState &ss = d.st[win];
+            const int l = lm_id;
+            double sl;
+            if (ss.iteration == 0) { sl = 1.0 / (1.0 + sqrt(lm_e)); d.scale_l[l] = sl; }
+            else sl = d.scale_l[l];
+            const double Es = sl * sl * lm_e;
+            const double Dl2 = fmin(fmax(Es, 1e-6), 1e32);
+            const double Dl = sqrt(Dl2);
+            d.lm_cg[l] = make_double2(sl * sl / (Es + ss.mu * Dl2), lm_g);
+            d.lmE[l] = lm_e; d.lmG[l] = lm_g; d.diag_l[l] = Dl; d.grad_l[l] = sl * lm_g / Dl;
+            double *wo = d.W + (size_t)(d.lm_f0[l] + l) * 6;                      // host observation slot
+            double *wd = d.Wd + (size_t)l * d.wd_ld + 6 * d.lm_host[l];
+#pragma unroll
+            for (int c2 = 0; c2 < 6; c2++) { wo[c2] = lm_wh[c2]; wd[c2] = lm_wh[c2]; }
+        }
+    }
+    // transpose through this wave's LDS buffer in two halves of 14 columns: lane l owns row l of
+    // sOut[64][TILE_LD]; then coalesced 8-B/lane stores of the half rows (the buffer is wave-private,
+    // so wave-level ordering is enough)
+    double *gout = d.strip + (size_t)f0 * ISV_PROJ_STRIP;
+    const int total = n * 14;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        double *row = sOut + lane * TILE_LD;
+        if (h == 0) {
+            row[0] = r0; row[1] = r1;
+#pragma unroll
+            for (int k = 0; k < 12; k++) row[2 + k] = Ji[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 12; k++) row[k] = Jj[k];
+            row[12] = Jl[0]; row[13] = Jl[1];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int it = 0; it < 14; it++) {
+            const int e = it * 64 + lane;
+            if (e < total) {
+                const int ff = e / 14, c = e - ff * 14;
+                gout[ff * ISV_PROJ_STRIP + 14 * h + c] = sOut[ff * TILE_LD + c];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 template __global__ void k_proj_linearize<0>(DevBatch, const double *, const double *, double *, int);
@@ -370,164 +419,245 @@ template __global__ void k_imu_linearize<true>(DevBatch, const double *, const d
 template __global__ void k_imu_linearize<false>(DevBatch, const double *, const double *, double *, int);
 
 // ------------------------------------------------------------------------------------------
-// small row-major helpers for the prior factors (run by single lanes; sizes <= 9)
-DEV void mat_mul_small(const double *A, const double *B, double *C, int m, int k, int n) {
-    for (int i = 0; i < m; i++) for (int j = 0; j < n; j++) {
-        double s = 0;
-        for (int p = 0; p < k; p++) s += A[i * k + p] * B[p * n + j];
-        C[i * n + j] = s;
+// Prior factors: one wavefront per window.  Slot 0 = SE3 prior, 1 = Linear9, 2..Nvo = relative pose, then
+// roll-pitch.  Phase 1: one lane per prior forms the raw residual and raw Jacobian blocks in LDS (the
+// SO(3) log / right-Jacobian calls are shared by the SE3 and relative-pose lanes).  Phase 2: all lanes form
+// sqrt_info * [raw r | raw J] entry by entry.  Phase 3: CauchyLoss corrector and strips.  Phase 4: J^T J
+// pairs and J^T r for k_build_solve.  Same operation order per entry as a scalar evaluation, so the
+// numbers do not depend on the lane split.
+#define PRL_RAW 82      // per-slot LDS: raw r (9) | raw J (72)
+#define PRL_W 90        // per-slot LDS: r (9) | J (81)
+#define PRL_S 82        // per-slot LDS: sqrt_info (<= 81)
+struct PriorDesc { int kind, strip_off, H_off, valid; const double *S; };   // kind 0 SE3, 1 Linear9, 2 relpose, 3 rollpitch
+DEV PriorDesc prior_desc(const DevBatch &d, int w, int s, int n_rp) {
+    PriorDesc p;
+    if (s == 0) { p.kind = 0; p.strip_off = PR_SE3; p.H_off = PH_SE3; p.valid = 1; p.S = d.se3[w].sqrt_info; }
+    else if (s == 1) { p.kind = 1; p.strip_off = PR_LIN9; p.H_off = PH_LIN9; p.valid = 1; p.S = d.lin9[w].sqrt_info; }
+    else if (s < 1 + d.Nvo) {
+        const int i = s - 2;
+        p.kind = 2; p.strip_off = PR_REL0 + PR_REL_SZ * i; p.H_off = PH_REL0 + PH_REL_SZ * i; p.valid = 1;
+        p.S = d.relpose[(size_t)w * (d.Nvo - 1) + i].sqrt_info;
+    } else {
+        const int m = s - 1 - d.Nvo;
+        p.kind = 3; p.strip_off = PR_REL0 + PR_REL_SZ * (d.Nvo - 1) + PR_RP_SZ * m;
+        p.H_off = PH_REL0 + PH_REL_SZ * (d.Nvo - 1) + PH_RP_SZ * m; p.valid = m < n_rp;
+        p.S = d.rollpitch[(size_t)w * d.max_rp + (p.valid ? m : 0)].sqrt_info;
     }
+    return p;
 }
-// apply CauchyLoss corrector to r (dim) and n Jacobian entries, return 0.5 rho(s)
-DEV double cauchy_correct(double *r, int dim, double *J, int nj, bool jac) {
-    double s = 0;
-    for (int k = 0; k < dim; k++) s += r[k] * r[k];
-    const double sum = 1.0 + s;
-    const double sc = sqrt(fmax(1.0 / sum, 2.2250738585072014e-308));
-    for (int k = 0; k < dim; k++) r[k] *= sc;
-    if (jac) for (int k = 0; k < nj; k++) J[k] *= sc;
-    return 0.5 * log(sum);
-}
-
-// J^T J pairs (a >= b) and J^T r of a prior factor whose Jacobian is one or two row-major blocks of
-// width bw (J[blk][row][col]); ncol = nblk * bw
-DEV void prior_H_block(const double *J, const double *r, int dim, int nblk, int bw, double *H) {
-    const int ncol = nblk * bw;
-    int e = 0;
-    for (int a = 0; a < ncol; a++) {
-        const double *Ja = J + (a / bw) * dim * bw + (a % bw);
-        for (int b = 0; b <= a; b++) {
-            const double *Jb = J + (b / bw) * dim * bw + (b % bw);
-            double s = 0;
-            for (int k = 0; k < dim; k++) s += Ja[k * bw] * Jb[k * bw];
-            H[e++] = s;
+// phase 2 for one prior of shape DIM x (NBLK blocks of BW): wr = [S raw | S rawJ]
+template <int DIM, int NBLK, int BW, bool COPY_S, bool JAC>
+DEV void prior_weight(const double *S, const double *raw, const double *rawJ, double *wr, int t) {
+    constexpr int per = 1 + (JAC ? NBLK * BW : 0);
+    for (int e = t; e < DIM * per; e += 64) {
+        const int row = e / per, c = e - row * per;
+        double v = 0;
+        if (c == 0) {
+#pragma unroll
+            for (int k = 0; k < DIM; k++) v += S[row * DIM + k] * raw[k];
+            wr[row] = v;
+        } else {
+            const int col = c - 1, blk = col / BW, cc = col - blk * BW;
+            if (COPY_S) v = S[row * DIM + cc];
+            else {
+#pragma unroll
+                for (int k = 0; k < DIM; k++) v += S[row * DIM + k] * rawJ[blk * DIM * BW + k * BW + cc];
+            }
+            wr[9 + blk * DIM * BW + row * BW + cc] = v;
         }
     }
-    for (int a = 0; a < ncol; a++) {
-        const double *Ja = J + (a / bw) * dim * bw + (a % bw);
-        double s = 0;
-        for (int k = 0; k < dim; k++) s += Ja[k * bw] * r[k];
-        H[e++] = s;
+}
+// phase 3: corrector scale of r and J in place + strip; returns 0.5 rho
+template <int DIM, int NBLK, int BW, bool JAC>
+DEV double prior_correct(double *wr, double *strip_o, int t) {
+    double ssum = 0;
+#pragma unroll
+    for (int k = 0; k < DIM; k++) ssum += wr[k] * wr[k];
+    const double sum = 1.0 + ssum;
+    if (JAC) {
+        const double sc = sqrt(fmax(1.0 / sum, 2.2250738585072014e-308));
+        __syncthreads();                                   // every lane has read r before it is rescaled
+        constexpr int nj = DIM * NBLK * BW;
+        for (int e = t; e < DIM + nj; e += 64) {
+            double *q = e < DIM ? wr + e : wr + 9 + (e - DIM);
+            const double v = *q * sc;
+            *q = v; strip_o[e] = v;
+        }
+    }
+    return 0.5 * log(sum);
+}
+// phase 4: J^T J pairs (a >= b at a(a+1)/2 + b) then J^T r
+template <int DIM, int NBLK, int BW>
+DEV void prior_H(const double *wr, double *H, int t) {
+    constexpr int ncol = NBLK * BW, npair = ncol * (ncol + 1) / 2;
+    const double *J = wr + 9;
+    for (int e = t; e < npair + ncol; e += 64) {
+        double v = 0;
+        if (e < npair) {
+            int a = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+            if ((a + 1) * (a + 2) / 2 <= e) a++;
+            if (a * (a + 1) / 2 > e) a--;
+            const int b = e - a * (a + 1) / 2;
+            const double *Ja = J + (a / BW) * DIM * BW + (a % BW), *Jb = J + (b / BW) * DIM * BW + (b % BW);
+#pragma unroll
+            for (int k = 0; k < DIM; k++) v += Ja[k * BW] * Jb[k * BW];
+        } else {
+            const int a = e - npair;
+            const double *Ja = J + (a / BW) * DIM * BW + (a % BW);
+#pragma unroll
+            for (int k = 0; k < DIM; k++) v += Ja[k * BW] * wr[k];
+        }
+        H[e] = v;
     }
 }
 
-// One lane per prior factor: slot 0 = SE3 prior, 1 = Linear9, 2..Nvo = relative pose, then roll-pitch.
 template <bool JAC>
-__global__ void k_prior_linearize(DevBatch d, const double *pose_src, const double *sb_src, double *cost_out, int gate) {
-    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const int slots = d.n_prior_slots;
-    if (gid >= d.B * slots) return;
-    const int w = gid / slots, s = gid % slots, N = d.N;
+__global__ __launch_bounds__(64) void k_prior_linearize(DevBatch d, const double *pose_src, const double *sb_src, double *cost_out, int gate) {
+    extern __shared__ __align__(16) double lds[];
+    const int w = blockIdx.x, t = threadIdx.x;
+    const int slots = d.n_prior_slots, N = d.N;
     if (gate) {
         const SolveState &ss = d.st[w];
         if (!(ss.termination == ISV_TERM_RUNNING && (gate == 1 ? ss.need_linearize != 0 : ss.step_valid != 0))) return;
     }
+    const int n_rp = d.n_rp[w];
+    double *sRaw = lds, *sW = lds + (size_t)slots * PRL_RAW, *sS = sW + (size_t)slots * PRL_W;
     double *strip = d.prior_strip + (size_t)w * d.prior_strip_sz;
     double *PH = d.prior_H + (size_t)w * d.prior_H_sz;
     const double *poseW = pose_src + (size_t)w * N * 7;
-    double cost = 0.0;
-    if (s == 0) {
-        // SE3PriorFactor::Evaluate  se3_prior_factor.h:21-53
-        const isv_se3_prior_t &f = d.se3[w];
-        const double *p = poseW;
-        Quat ri = q_normalized(q_from_pose(p)), rp = q_from_R(f.R);
-        Quat rr = so3_mul(q_conj(rp), ri);
-        double raw[6], lg[3], r[6];
+    // stage every sqrt_info
+    for (int s = 0; s < slots; s++) {
+        const PriorDesc p = prior_desc(d, w, s, n_rp);
+        const int n = p.kind == 1 ? 81 : (p.kind == 3 ? 4 : 36);
+        if (p.valid) for (int e = t; e < n; e += 64) sS[s * PRL_S + e] = p.S[e];
+    }
+    // ---- phase 1: raw residual / raw Jacobian blocks, one lane per prior ----
+    for (int s = t; s < slots; s += 64) {
+        double *raw = sRaw + s * PRL_RAW, *rawJ = raw + 9;
+        const int kind = s == 0 ? 0 : (s == 1 ? 1 : (s < 1 + d.Nvo ? 2 : 3));
+        Quat rr = Quat{1, 0, 0, 0};
+        double Ri[9], Rj[9], qd[3], lg[3], Jr[9];
+        const double *pi = poseW;
+        if (kind == 0) {
+            // SE3PriorFactor::Evaluate  se3_prior_factor.h:21-53
+            Quat ri = q_normalized(q_from_pose(poseW)), rp = q_from_R(d.se3[w].R);
+            rr = so3_mul(q_conj(rp), ri);
+        } else if (kind == 2) {
+            // RelativePoseFactor::Evaluate  relative_pose_factor.h:27-70
+            const isv_relpose_t &f = d.relpose[(size_t)w * (d.Nvo - 1) + (s - 2)];
+            pi = poseW + (s - 2) * 7;
+            const double *pj = pi + 7;
+            Quat Qi = q_from_pose(pi), Qj = q_from_pose(pj);
+            double dd[3], M1[9], M2[9];
+            q_to_R(Qi, Ri); q_to_R(Qj, Rj);
+#pragma unroll
+            for (int k = 0; k < 3; k++) dd[k] = pj[k] - pi[k];
+            q_rot(q_inv(Qi), dd, qd);
+            m3_mul_nt(f.delta_R, Rj, M1); m3_mul(M1, Ri, M2);
+            rr = q_from_R(M2);
+        }
         so3_log(rr, lg);
-        for (int k = 0; k < 3; k++) { raw[k] = p[k] - f.t[k]; raw[3 + k] = lg[k]; }
-        mat_mul_small(f.sqrt_info, raw, r, 6, 6, 1);
-        double J[36];
-        if (JAC) {
-            double Jr[9], rawJ[36];
-            so3_rjac_inv(lg, Jr);
-            for (int k = 0; k < 36; k++) rawJ[k] = 0;
-            rawJ[0] = rawJ[7] = rawJ[14] = 1.0;
-            for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) rawJ[(3 + a) * 6 + 3 + b] = Jr[a * 3 + b];
-            mat_mul_small(f.sqrt_info, rawJ, J, 6, 6, 6);
-        }
-        cost = cauchy_correct(r, 6, J, 36, JAC);
-        if (JAC) { for (int k = 0; k < 6; k++) strip[PR_SE3 + k] = r[k]; for (int k = 0; k < 36; k++) strip[PR_SE3 + 6 + k] = J[k];
-                   prior_H_block(J, r, 6, 1, 6, PH + PH_SE3); }
-    } else if (s == 1) {
-        // Linear9Factor::Evaluate  linear9_factor.h:20-44
-        const isv_linear9_t &f = d.lin9[w];
-        const double *sb = sb_src + ((size_t)w * N + (d.Nvo - 1)) * 9;
-        double raw[9], r[9], J[81];
-        for (int k = 0; k < 9; k++) raw[k] = sb[k] - f.VB[k];
-        mat_mul_small(f.sqrt_info, raw, r, 9, 9, 1);
-        if (JAC) for (int k = 0; k < 81; k++) J[k] = f.sqrt_info[k];
-        cost = cauchy_correct(r, 9, J, 81, JAC);
-        if (JAC) { for (int k = 0; k < 9; k++) strip[PR_LIN9 + k] = r[k]; for (int k = 0; k < 81; k++) strip[PR_LIN9 + 9 + k] = J[k];
-                   prior_H_block(J, r, 9, 1, 9, PH + PH_LIN9); }
-    } else if (s < 1 + d.Nvo) {
-        // RelativePoseFactor::Evaluate  relative_pose_factor.h:27-70
-        const int i = s - 2;
-        const isv_relpose_t &f = d.relpose[(size_t)w * (d.Nvo - 1) + i];
-        const double *pi = poseW + i * 7, *pj = pi + 7;
-        Quat Qi = q_from_pose(pi), Qj = q_from_pose(pj);
-        double Ri[9], Rj[9], dd[3], qd[3], M1[9], M2[9], lg[3], raw[6], r[6];
-        q_to_R(Qi, Ri); q_to_R(Qj, Rj);
-        for (int k = 0; k < 3; k++) dd[k] = pj[k] - pi[k];
-        q_rot(q_inv(Qi), dd, qd);
-        m3_mul_nt(f.delta_R, Rj, M1); m3_mul(M1, Ri, M2);
-        so3_log(q_from_R(M2), lg);
-        for (int k = 0; k < 3; k++) { raw[k] = f.delta_t[k] - qd[k]; raw[3 + k] = lg[k]; }
-        mat_mul_small(f.sqrt_info, raw, r, 6, 6, 1);
-        double J[72];
-        if (JAC) {
-            double Jr[9], rawJ[36], S[9], T1[9], T2[9];
-            so3_rjac_inv(lg, Jr); skew3(qd, S);
-            for (int k = 0; k < 36; k++) rawJ[k] = 0;
-            for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) {
-                rawJ[a * 6 + b] = Ri[b * 3 + a];                 // Ri^T
-                rawJ[a * 6 + 3 + b] = -S[a * 3 + b];
-                rawJ[(3 + a) * 6 + 3 + b] = Jr[a * 3 + b];
-            }
-            mat_mul_small(f.sqrt_info, rawJ, J, 6, 6, 6);
-            for (int k = 0; k < 36; k++) rawJ[k] = 0;
-            double nJ[9]; for (int k = 0; k < 9; k++) nJ[k] = -Jr[k];
-            m3_mul_nt(nJ, Ri, T1);                               // -J Ri^T  (A B^T with B = Ri)
-            // m3_mul_nt computes A * B^T: here B^T must be Ri^T -> B = Ri  OK
-            m3_mul(T1, Rj, T2);
-            for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) {
-                rawJ[a * 6 + b] = -Ri[b * 3 + a];
-                rawJ[(3 + a) * 6 + 3 + b] = T2[a * 3 + b];
-            }
-            mat_mul_small(f.sqrt_info, rawJ, J + 36, 6, 6, 6);
-        }
-        cost = cauchy_correct(r, 6, J, 72, JAC);
-        double *o = strip + PR_REL0 + PR_REL_SZ * i;
-        if (JAC) { for (int k = 0; k < 6; k++) o[k] = r[k]; for (int k = 0; k < 72; k++) o[6 + k] = J[k];
-                   prior_H_block(J, r, 6, 2, 6, PH + PH_REL0 + PH_REL_SZ * i); }
-    } else {
-        // RollPitchFactor::Evaluate  rollpitch_factor.h:26-57
-        const int m = s - 1 - d.Nvo;
-        double *o = strip + PR_REL0 + PR_REL_SZ * (d.Nvo - 1) + PR_RP_SZ * m;
-        if (m < d.n_rp[w]) {
-            const isv_rollpitch_t &f = d.rollpitch[(size_t)w * d.max_rp + m];
-            const double *p = poseW + f.index * 7;
-            Quat Ri = q_normalized(q_from_pose(p)), Rm = q_from_R(f.R);
-            double nZ[3] = {0, 0, -1.0}, v[3], raw[2], r[2];
-            q_rot(so3_mul(Rm, q_conj(Ri)), nZ, v);
-            raw[0] = v[0]; raw[1] = v[1];
-            r[0] = f.sqrt_info[0] * raw[0] + f.sqrt_info[1] * raw[1];
-            r[1] = f.sqrt_info[2] * raw[0] + f.sqrt_info[3] * raw[1];
-            double J[12];
+        if (JAC) so3_rjac_inv(lg, Jr);
+        if (kind == 0) {
+            const isv_se3_prior_t &f = d.se3[w];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { raw[k] = poseW[k] - f.t[k]; raw[3 + k] = lg[k]; }
             if (JAC) {
-                double S[9], Rmm[9], Bm[9], rawJ[12];
-                skew3(v, S); q_to_R(Rm, Rmm); m3_mul(S, Rmm, Bm);
-                for (int k = 0; k < 12; k++) rawJ[k] = 0;
-                for (int a = 0; a < 2; a++) for (int b = 0; b < 3; b++) rawJ[a * 6 + 3 + b] = Bm[a * 3 + b];
-                mat_mul_small(f.sqrt_info, rawJ, J, 2, 2, 6);
+#pragma unroll
+                for (int k = 0; k < 36; k++) rawJ[k] = 0;
+                rawJ[0] = rawJ[7] = rawJ[14] = 1.0;
+#pragma unroll
+                for (int a = 0; a < 3; a++)
+#pragma unroll
+                    for (int b = 0; b < 3; b++) rawJ[(3 + a) * 6 + 3 + b] = Jr[a * 3 + b];
             }
-            cost = cauchy_correct(r, 2, J, 12, JAC);
-            if (JAC) { o[0] = r[0]; o[1] = r[1]; for (int k = 0; k < 12; k++) o[2 + k] = J[k];
-                       prior_H_block(J, r, 2, 1, 6, PH + PH_REL0 + PH_REL_SZ * (d.Nvo - 1) + PH_RP_SZ * m); }
-        } else if (JAC) {
-            for (int k = 0; k < PR_RP_SZ; k++) o[k] = 0.0;
+        } else if (kind == 1) {
+            // Linear9Factor::Evaluate  linear9_factor.h:20-44 (Jacobian = sqrt_info)
+            const isv_linear9_t &f = d.lin9[w];
+            const double *sb = sb_src + ((size_t)w * N + (d.Nvo - 1)) * 9;
+#pragma unroll
+            for (int k = 0; k < 9; k++) raw[k] = sb[k] - f.VB[k];
+        } else if (kind == 2) {
+            const isv_relpose_t &f = d.relpose[(size_t)w * (d.Nvo - 1) + (s - 2)];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { raw[k] = f.delta_t[k] - qd[k]; raw[3 + k] = lg[k]; }
+            if (JAC) {
+                double S[9], T1[9], T2[9], nJ[9];
+                skew3(qd, S);
+#pragma unroll
+                for (int k = 0; k < 72; k++) rawJ[k] = 0;
+#pragma unroll
+                for (int k = 0; k < 9; k++) nJ[k] = -Jr[k];
+                m3_mul_nt(nJ, Ri, T1);                               // -J Ri^T
+                m3_mul(T1, Rj, T2);
+#pragma unroll
+                for (int a = 0; a < 3; a++)
+#pragma unroll
+                    for (int b = 0; b < 3; b++) {
+                        rawJ[a * 6 + b] = Ri[b * 3 + a];                 // Ri^T
+                        rawJ[a * 6 + 3 + b] = -S[a * 3 + b];
+                        rawJ[(3 + a) * 6 + 3 + b] = Jr[a * 3 + b];
+                        rawJ[36 + a * 6 + b] = -Ri[b * 3 + a];
+                        rawJ[36 + (3 + a) * 6 + 3 + b] = T2[a * 3 + b];
+                    }
+            }
+        } else if (s - 1 - d.Nvo < n_rp) {
+            // RollPitchFactor::Evaluate  rollpitch_factor.h:26-57
+            const isv_rollpitch_t &f = d.rollpitch[(size_t)w * d.max_rp + (s - 1 - d.Nvo)];
+            const double *p = poseW + f.index * 7;
+            Quat Rq = q_normalized(q_from_pose(p)), Rm = q_from_R(f.R);
+            double nZ[3] = {0, 0, -1.0}, v[3];
+            q_rot(so3_mul(Rm, q_conj(Rq)), nZ, v);
+            raw[0] = v[0]; raw[1] = v[1];
+            if (JAC) {
+                double S[9], Rmm[9], Bm[9];
+                skew3(v, S); q_to_R(Rm, Rmm); m3_mul(S, Rmm, Bm);
+#pragma unroll
+                for (int k = 0; k < 12; k++) rawJ[k] = 0;
+#pragma unroll
+                for (int a = 0; a < 2; a++)
+#pragma unroll
+                    for (int b = 0; b < 3; b++) rawJ[a * 6 + 3 + b] = Bm[a * 3 + b];
+            }
         }
     }
-    cost_out[(size_t)w * slots + s] = cost;
+    __syncthreads();
+    // ---- phase 2: sqrt_info * [raw r | raw J] ----
+    for (int s = 0; s < slots; s++) {
+        const PriorDesc p = prior_desc(d, w, s, n_rp);
+        if (!p.valid) continue;
+        const double *raw = sRaw + s * PRL_RAW, *rawJ = raw + 9, *S = sS + s * PRL_S;
+        double *wr = sW + s * PRL_W;
+        if (p.kind == 0) prior_weight<6, 1, 6, false, JAC>(S, raw, rawJ, wr, t);
+        else if (p.kind == 1) prior_weight<9, 1, 9, true, JAC>(S, raw, rawJ, wr, t);
+        else if (p.kind == 2) prior_weight<6, 2, 6, false, JAC>(S, raw, rawJ, wr, t);
+        else prior_weight<2, 1, 6, false, JAC>(S, raw, rawJ, wr, t);
+    }
+    __syncthreads();
+    // ---- phase 3: CauchyLoss corrector (scale r and J by sqrt(rho')), cost, strips ----
+    for (int s = 0; s < slots; s++) {
+        const PriorDesc p = prior_desc(d, w, s, n_rp);
+        double *wr = sW + s * PRL_W, *so = strip + p.strip_off;
+        double cost = 0.0;
+        if (!p.valid) { if (JAC) for (int e = t; e < PR_RP_SZ; e += 64) so[e] = 0.0; }
+        else if (p.kind == 0) cost = prior_correct<6, 1, 6, JAC>(wr, so, t);
+        else if (p.kind == 1) cost = prior_correct<9, 1, 9, JAC>(wr, so, t);
+        else if (p.kind == 2) cost = prior_correct<6, 2, 6, JAC>(wr, so, t);
+        else cost = prior_correct<2, 1, 6, JAC>(wr, so, t);
+        if (t == 0) cost_out[(size_t)w * slots + s] = cost;
+    }
+    if (!JAC) return;
+    __syncthreads();
+    // ---- phase 4: J^T J and J^T r ----
+    for (int s = 0; s < slots; s++) {
+        const PriorDesc p = prior_desc(d, w, s, n_rp);
+        if (!p.valid) continue;
+        const double *wr = sW + s * PRL_W;
+        if (p.kind == 0) prior_H<6, 1, 6>(wr, PH + p.H_off, t);
+        else if (p.kind == 1) prior_H<9, 1, 9>(wr, PH + p.H_off, t);
+        else if (p.kind == 2) prior_H<6, 2, 6>(wr, PH + p.H_off, t);
+        else prior_H<2, 1, 6>(wr, PH + p.H_off, t);
+    }
 }
 template __global__ void k_prior_linearize<true>(DevBatch, const double *, const double *, double *, int);
 template __global__ void k_prior_linearize<false>(DevBatch, const double *, const double *, double *, int);

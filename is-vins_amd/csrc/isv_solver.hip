@@ -15,6 +15,8 @@
 extern size_t build_solve_lds_bytes(int N, bool lds_T);
 extern size_t build_solve_lds2_bytes(int N);
 __global__ void k_build_solve_lds(DevBatch d);
+__global__ void k_build_solve_sb(DevBatch d);
+extern size_t build_solve_sb_bytes(int N);
 __global__ void k_lm_prep(DevBatch d);
 __global__ void k_sweep(DevBatch d);
 __global__ void k_rank1_mfma(DevBatch d);
@@ -382,7 +384,10 @@ int isv_solver_alloc(DevBatch &d, size_t B, size_t L, size_t F, std::vector<void
     TRYA(dal(&d.Tglob, d.lds_T ? 1 : B * nblkT, allocs, err));
     d.marg_scratch_sz = 26;
     TRYA(dal(&d.marg_scratch, L * 26, allocs, err));
-    if (d.lds_T) HCHK(hipFuncSetAttribute((const void *)k_build_solve_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)build_solve_lds2_bytes(d.N)));
+    if (d.lds_T) {
+        HCHK(hipFuncSetAttribute((const void *)k_build_solve_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)build_solve_lds2_bytes(d.N)));
+        HCHK(hipFuncSetAttribute((const void *)k_build_solve_sb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)build_solve_sb_bytes(d.N)));
+    }
     else HCHK(hipFuncSetAttribute((const void *)k_build_solve<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)build_solve_lds_bytes(d.N, false)));
     return ISV_OK;
 }
@@ -394,19 +399,27 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
     // independent of the reprojection pipeline, so they run beside it and are joined before their consumers
 #define PROF(slot, fam, which) do { if (prof_ev) (void)hipEventRecord(prof_ev[((slot) * ISV_PROF_FAMILIES + (fam)) * 2 + (which)], st); } while (0)
     const size_t NI = (size_t)d.B * (d.N - 1);
-    const size_t lds_proj = 4 * proj_lds_doubles_per_wave(d.N) * sizeof(double);
+    const size_t lds_proj = 4 * proj_lds_doubles_per_wave(d.N, 0) * sizeof(double), lds_proj1 = 4 * proj_lds_doubles_per_wave(d.N, 1) * sizeof(double);
+    if (getenv("ISV_ONE_STREAM")) st2 = st;            // diagnostics: serialise everything on one stream
     const size_t lds_bs = d.lds_T ? build_solve_lds2_bytes(d.N) : build_solve_lds_bytes(d.N, false);
     hipLaunchKernelGGL(k_init_state, dim3((d.B + 63) / 64), dim3(64), 0, st, d);
     for (int slot = 0; slot < d.max_iter; slot++) {
         // linearise where needed (k_*_linearize skip windows whose need_linearize == 0 via the tile/window flags)
-        HCHK(hipEventRecord(fj[0], st)); HCHK(hipStreamWaitEvent(st2, fj[0], 0));
-        if (NI) hipLaunchKernelGGL(k_imu_linearize<true>, dim3((unsigned)NI), dim3(64), 0, st2, d, d.pose, d.sb, d.imu_cost, 1);
-        hipLaunchKernelGGL(k_prior_linearize<true>, dim3((d.B * d.n_prior_slots + 63) / 64), dim3(64), 0, st2, d, d.pose, d.sb, d.prior_cost, 1);
-        HCHK(hipEventRecord(fj[1], st2));
+        static const int fork_late = getenv("ISV_FORK_LATE") ? atoi(getenv("ISV_FORK_LATE")) : 0;
+        if (fork_late) {
         PROF(slot, 0, 0);
         if (d.n_tiles > 0) { hipLaunchKernelGGL(k_proj_linearize<0>, dim3((d.n_tiles + 3) / 4), dim3(256), lds_proj, st, d, d.pose, d.lam, d.fcost, 1); counts[0]++; }
         PROF(slot, 0, 1);
-        if (d.Ltot) hipLaunchKernelGGL(k_lm_prep, dim3((d.Ltot + 255) / 256), dim3(256), 0, st, d);
+        }
+        HCHK(hipEventRecord(fj[0], st)); HCHK(hipStreamWaitEvent(st2, fj[0], 0));
+        if (NI) hipLaunchKernelGGL(k_imu_linearize<true>, dim3((unsigned)NI), dim3(64), 0, st2, d, d.pose, d.sb, d.imu_cost, 1);
+        hipLaunchKernelGGL(k_prior_linearize<true>, dim3(d.B), dim3(64), prior_lds_bytes(d.n_prior_slots), st2, d, d.pose, d.sb, d.prior_cost, 1);
+        HCHK(hipEventRecord(fj[1], st2));
+        if (!fork_late) {
+        PROF(slot, 0, 0);
+        if (d.n_tiles > 0) { hipLaunchKernelGGL(k_proj_linearize<0>, dim3((d.n_tiles + 3) / 4), dim3(256), lds_proj, st, d, d.pose, d.lam, d.fcost, 1); counts[0]++; }
+        PROF(slot, 0, 1);
+        }
         PROF(slot, 1, 0);
         if (d.lds_T) {
             hipLaunchKernelGGL(k_sweep, dim3(d.B, d.N), dim3(64), 0, st, d); counts[2]++;
@@ -418,7 +431,9 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
         HCHK(hipStreamWaitEvent(st, fj[1], 0));
         hipLaunchKernelGGL(k_cost_reduce, dim3(d.B), dim3(256), 0, st, d, d.fcost, d.imu_cost, d.prior_cost, d.cost, 1);
         PROF(slot, 2, 0);
-        if (d.lds_T) hipLaunchKernelGGL(k_build_solve_lds, dim3(d.B), dim3(768), lds_bs, st, d);
+        static const int bs_old = getenv("ISV_BS_OLD") ? 1 : 0;
+        if (d.lds_T && !bs_old) hipLaunchKernelGGL(k_build_solve_sb, dim3(d.B), dim3(512), build_solve_sb_bytes(d.N), st, d);
+        else if (d.lds_T) hipLaunchKernelGGL(k_build_solve_lds, dim3(d.B), dim3(768), lds_bs, st, d);
         else hipLaunchKernelGGL(k_build_solve<false>, dim3(d.B), dim3(512), lds_bs, st, d);
         counts[1]++;
         PROF(slot, 2, 1);
@@ -426,10 +441,10 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
         hipLaunchKernelGGL(k_dogleg, dim3(d.B), dim3(256), 0, st, d);
         HCHK(hipEventRecord(fj[2], st)); HCHK(hipStreamWaitEvent(st2, fj[2], 0));
         if (NI) hipLaunchKernelGGL(k_imu_linearize<false>, dim3((unsigned)NI), dim3(64), 0, st2, d, d.cpose, d.csb, d.imu_cost_c, 2);
-        hipLaunchKernelGGL(k_prior_linearize<false>, dim3((d.B * d.n_prior_slots + 63) / 64), dim3(64), 0, st2, d, d.cpose, d.csb, d.prior_cost_c, 2);
+        hipLaunchKernelGGL(k_prior_linearize<false>, dim3(d.B), dim3(64), prior_lds_bytes(d.n_prior_slots), st2, d, d.cpose, d.csb, d.prior_cost_c, 2);
         hipLaunchKernelGGL(k_model_imu_prior, dim3(d.B * d.N), dim3(64), 0, st2, d);
         HCHK(hipEventRecord(fj[3], st2));
-        if (d.n_tiles > 0) hipLaunchKernelGGL(k_proj_linearize<1>, dim3((d.n_tiles + 3) / 4), dim3(256), lds_proj, st, d, d.cpose, d.clam, d.fcost_c, 2);
+        if (d.n_tiles > 0) hipLaunchKernelGGL(k_proj_linearize<1>, dim3((d.n_tiles + 3) / 4), dim3(256), lds_proj1, st, d, d.cpose, d.clam, d.fcost_c, 2);
         HCHK(hipStreamWaitEvent(st, fj[3], 0));
         hipLaunchKernelGGL(k_step_control, dim3(d.B), dim3(256), 0, st, d);
     }
