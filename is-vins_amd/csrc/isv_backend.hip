@@ -35,7 +35,7 @@ struct isv_backend {
     // host staging (pinned)
     struct Host {
         double *Ps, *Rs, *Vs, *Bas, *Bgs, *tic, *ric, *depth, *lm_pts_i, *f_pts_j, *imu_in, *imu_cov;
-        int32_t *lm_off, *f_off, *lm_host, *lm_k, *lm_f0, *tile_win, *tile_f0, *tile_n, *imu_skip, *n_rp, *solve_flag;
+        int32_t *lm_off, *f_off, *lm_host, *lm_k, *lm_f0, *tile_win, *tile_f0, *tile_n, *imu_skip, *n_rp, *solve_flag, *pg_perm, *pg_off;
         FactorRec *f_rec;
         uint32_t *lm_meta; int32_t *ck_off; int2 *ck_rec; int32_t *margin_old; double *header0;
         isv_se3_prior_t *se3; isv_linear9_t *lin9; isv_relpose_t *relpose; isv_rollpitch_t *rollpitch;
@@ -116,6 +116,7 @@ static int create_impl(isv_backend *h) {
     TRY(dalloc(h, &d.lm_host, L)); TRY(dalloc(h, &d.lm_k, L)); TRY(dalloc(h, &d.lm_f0, L)); TRY(dalloc(h, &d.lm_pts_i, L * 3));
     TRY(dalloc(h, &d.f_rec, F)); TRY(dalloc(h, &d.f_pts_j, F * 2));
     TRY(dalloc(h, &d.tile_win, T)); TRY(dalloc(h, &d.tile_f0, T)); TRY(dalloc(h, &d.tile_n, T));
+    TRY(dalloc(h, &d.pg_perm, F)); TRY(dalloc(h, &d.pg_off, B * ((size_t)c.n_frames * (c.n_frames - 1) / 2 + 1)));
     TRY(dalloc(h, &d.imu_in, NI * ISV_IMU_IN)); TRY(dalloc(h, &d.imu_cov, NI * 225)); TRY(dalloc(h, &d.imu_sqrt, NI * 225));
     TRY(dalloc(h, &d.imu_skip, NI));
     TRY(dalloc(h, &d.se3, B)); TRY(dalloc(h, &d.lin9, B)); TRY(dalloc(h, &d.relpose, B * (c.n_vo - 1))); TRY(dalloc(h, &d.rollpitch, B * (size_t)c.max_rollpitch));
@@ -137,7 +138,8 @@ static int create_impl(isv_backend *h) {
     TRY(halloc(h, &s.depth, L)); TRY(halloc(h, &s.solve_flag, L)); TRY(halloc(h, &s.lm_pts_i, L * 3)); TRY(halloc(h, &s.f_pts_j, F * 2));
     TRY(halloc(h, &s.imu_in, NI * ISV_IMU_IN)); TRY(halloc(h, &s.imu_cov, NI * 225));
     TRY(halloc(h, &s.lm_off, B + 1)); TRY(halloc(h, &s.f_off, B + 1)); TRY(halloc(h, &s.lm_host, L)); TRY(halloc(h, &s.lm_k, L)); TRY(halloc(h, &s.lm_f0, L));
-    TRY(halloc(h, &s.tile_win, T)); TRY(halloc(h, &s.tile_f0, T)); TRY(halloc(h, &s.tile_n, T)); TRY(halloc(h, &s.imu_skip, NI)); TRY(halloc(h, &s.n_rp, B));
+    TRY(halloc(h, &s.tile_win, T)); TRY(halloc(h, &s.tile_f0, T)); TRY(halloc(h, &s.tile_n, T));
+    TRY(halloc(h, &s.pg_perm, F)); TRY(halloc(h, &s.pg_off, B * ((size_t)c.n_frames * (c.n_frames - 1) / 2 + 1))); TRY(halloc(h, &s.imu_skip, NI)); TRY(halloc(h, &s.n_rp, B));
     TRY(halloc(h, &s.f_rec, F));
     TRY(halloc(h, &s.margin_old, B)); TRY(halloc(h, &s.header0, B));
     TRY(halloc(h, &s.lm_meta, L)); TRY(halloc(h, &s.ck_off, B + 1)); TRY(halloc(h, &s.ck_rec, L + B + 1));
@@ -227,6 +229,20 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
             }
             if (tn) { s.tile_win[T] = b; s.tile_f0[T] = (int32_t)tf0; s.tile_n[T] = (int32_t)tn; T++; }
         }
+        // factors sorted by (host, observer) pair for the MFMA sweep: counting sort, stable in landmark order
+        {
+            const int NP = N * (N - 1) / 2;
+            int32_t *off = s.pg_off + (size_t)b * (NP + 1);
+            auto pidx = [N](int hh, int jj) { return hh * N - hh * (hh + 1) / 2 + (jj - hh - 1); };
+            for (int p = 0; p <= NP; p++) off[p] = 0;
+            for (size_t f = s.f_off[b]; f < F; f++) off[pidx(s.f_rec[f].ij & 255, (s.f_rec[f].ij >> 8) & 255) + 1]++;
+            for (int p = 0; p < NP; p++) off[p + 1] += off[p];
+            std::vector<int32_t> cur(off, off + NP);
+            for (size_t f = s.f_off[b]; f < F; f++) {
+                const int p = pidx(s.f_rec[f].ij & 255, (s.f_rec[f].ij >> 8) & 255);
+                s.pg_perm[s.f_off[b] + cur[p]++] = (int32_t)(f - s.f_off[b]);
+            }
+        }
         for (int i = 0; i < N - 1; i++) {
             const isv_imu_t &im = w->imu[i];
             double *r = s.imu_in + ((size_t)b * (N - 1) + i) * ISV_IMU_IN;
@@ -267,6 +283,7 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
     H2D(d.f_rec, s.f_rec, F); H2D(d.f_pts_j, s.f_pts_j, F * 2);
     H2D(d.lm_meta, s.lm_meta, L); H2D(d.ck_off, s.ck_off, n + 1); H2D(d.ck_rec, s.ck_rec, CK + n);
     H2D(d.tile_win, s.tile_win, T); H2D(d.tile_f0, s.tile_f0, T); H2D(d.tile_n, s.tile_n, T);
+    H2D(d.pg_perm, s.pg_perm, F); H2D(d.pg_off, s.pg_off, (size_t)n * ((size_t)N * (N - 1) / 2 + 1));
     H2D(d.imu_in, s.imu_in, NI * ISV_IMU_IN); H2D(d.imu_cov, s.imu_cov, NI * 225); H2D(d.imu_skip, s.imu_skip, NI);
     H2D(d.se3, s.se3, n); H2D(d.lin9, s.lin9, n); H2D(d.relpose, s.relpose, (size_t)n * (c.n_vo - 1)); H2D(d.rollpitch, s.rollpitch, (size_t)n * c.max_rollpitch);
     H2D(d.n_rp, s.n_rp, n); H2D(d.margin_old, s.margin_old, n); H2D(d.header0, s.header0, n);

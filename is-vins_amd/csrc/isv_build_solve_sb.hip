@@ -25,6 +25,11 @@
 #include "isv_kernels.h"
 #include "isv_device_math.h"
 
+#ifdef ISV_STAMP
+#define STAMP(k) do { if (t == 0) { unsigned long long now_ = wall_clock64(); d.dbg[(size_t)w * 64 + (k)] += (double)(now_ - t_last); t_last = now_; } } while (0)
+#else
+#define STAMP(k) do {} while (0)
+#endif
 #define LS 512                     // threads (8 wavefronts); two workgroups per CU
 #define RCH 32                     // landmarks per staged chunk of the retry correction
 
@@ -97,8 +102,10 @@ __global__ __launch_bounds__(LS, 4) void k_build_solve_sb(DevBatch d) {
     double *D = p; p += n;
     double *y = p; p += n;
     double *u = p; p += n;
-    double *red = p; p += LS;
+    const int nred = d.prior_H_sz > LS ? ((d.prior_H_sz + 1) & ~1) : LS;    // reductions; also stages the prior blocks
+    double *red = p; p += nred;
     int *yo = (int *)p; p += 8;              // yo[0..N]: offsets of the fill blocks of each chain node (N <= 15)
+    int *skipL = (int *)p; p += 8;           // imu_skip flags of this window
     int *flag = (int *)p; p += 2;
     double *Spp = p; p += nS;                // pose-pose, packed lower block triangle of 6x6 blocks (Tvis layout)
     double *Dss = p; p += N * 81;            // speed/bias diagonal blocks -> inverse Cholesky factors
@@ -110,8 +117,12 @@ __global__ __launch_bounds__(LS, 4) void k_build_solve_sb(DevBatch d) {
         for (int i = 0; i < N; i++) { yo[i] = o; o += (nhi(i, M, N) - nlo(i, M) + 1) * 54; }
         yo[N] = o; flag[0] = 0;
     }
+    if (t < N - 1) skipL[t] = d.imu_skip[(size_t)w * (N - 1) + t];
     __syncthreads();
     const int ytot = yo[N];
+#ifdef ISV_STAMP
+    unsigned long long t_last = wall_clock64();
+#endif
     const int iteration = st.iteration;
     double mu = st.mu;
     int ls_fail = 0, attempt = 0;
@@ -128,15 +139,107 @@ __global__ __launch_bounds__(LS, 4) void k_build_solve_sb(DevBatch d) {
         J = ca; I = ca + (q - (ca * N - ca * (ca - 1) / 2));
     };
 
+    const int t_outer = t;
     for (;;) {
         if (!(mu < 1.0)) { ls_fail = 1; break; }
-        for (int e = t; e < n; e += LS) { g[e] = 0.0; bs[e] = 0.0; hdiag[e] = 0.0; }
+        // the retry loop almost never iterates: keep the compiler from hoisting per-thread index math out of
+        // it (the hoisted values stay live across the whole body and spill)
+        int t = t_outer;
+        asm volatile("" : "+v"(t));
+        // ---- issue every global load of the assembly up front (one memory latency instead of five) ----
+        const double *H = d.imu_H + (size_t)w * (N - 1) * ISV_IMU_H;
+        const double *PH = d.prior_H + (size_t)w * d.prior_H_sz;
+        double vS[5], vT[3] = {0, 0, 0}, vF[3], vX[5], vG = 0, vP[2] = {0, 0};
+#pragma unroll
+        for (int k = 0; k < 5; k++) { const int e = t + k * LS; vS[k] = e < nS ? V[e] : 0.0; }
+        if (t < n6) { vT[0] = V[nS + t]; vT[1] = V[nS + n6 + t]; vT[2] = V[nS + 2 * n6 + t]; }
+        if (t < d.prior_H_sz) vP[0] = PH[t];
+        if (t + LS < d.prior_H_sz) vP[1] = PH[t + LS];
+        // IMU factors (precomputed J^T J, local order pose_i sb_i pose_j sb_j)
+        auto imu_frame_fetch = [&](int e) -> double {       // per frame: pose diag (21), sb diag (45), pose x sb (54)
+            const int I = e / 120;
+            int q = e - 120 * I;
+            const bool hasA = I >= 1 && !skipL[I - 1], hasB = I <= N - 2 && !skipL[I];
+            const double *HA = H + (size_t)(I - 1) * ISV_IMU_H, *HB = H + (size_t)I * ISV_IMU_H;
+            int ia, ib;
+            if (q < 21) {
+                int r = 0; while ((r + 1) * (r + 2) / 2 <= q) r++;
+                const int c = q - r * (r + 1) / 2;
+                ia = pairidx2(15 + r, 15 + c); ib = pairidx2(r, c);
+            } else if (q < 66) {
+                q -= 21;
+                int r = 0; while ((r + 1) * (r + 2) / 2 <= q) r++;
+                const int c = q - r * (r + 1) / 2;
+                ia = pairidx2(21 + r, 21 + c); ib = pairidx2(6 + r, 6 + c);
+            } else {
+                q -= 66;
+                const int r = q / 9, c = q - 9 * r;         // pose row r, speed/bias column c of frame I
+                ia = pairidx2(21 + c, 15 + r); ib = pairidx2(6 + c, r);
+            }
+            double v = 0;
+            if (hasA) v += HA[ia];
+            if (hasB) v += HB[ib];
+            return v;
+        };
+        auto imu_frame_apply = [&](int e, double v) {
+            const int I = e / 120;
+            int q = e - 120 * I;
+            if (q < 21) {
+                int r = 0; while ((r + 1) * (r + 2) / 2 <= q) r++;
+                const int c = q - r * (r + 1) / 2;
+                Spp[sblk(I, I, N) + r * 6 + c] += v;
+                if (r == c) hdiag[15 * I + r] += v;
+            } else if (q < 66) {
+                q -= 21;
+                int r = 0; while ((r + 1) * (r + 2) / 2 <= q) r++;
+                const int c = q - r * (r + 1) / 2;
+                Dss[I * 81 + r * 9 + c] = v;
+                if (r == c) hdiag[15 * I + 6 + r] = v;
+            } else {
+                Ysb[yo[I] + (I - nlo(I, M)) * 54 + (q - 66)] = v;
+            }
+        };
+        auto imu_pair_fetch = [&](int e) -> double {        // per factor: the blocks between frames I and I + 1
+            const int I = e / 225;
+            int q = e - 225 * I;
+            if (skipL[I]) return 0.0;
+            const double *HB = H + (size_t)I * ISV_IMU_H;
+            int ib;
+            if (q < 36) { const int r = q / 6, c = q - 6 * r; ib = pairidx2(15 + r, c); }
+            else if (q < 90) { q -= 36; const int r = q / 9, c = q - 9 * r; ib = pairidx2(15 + r, 6 + c); }      // pose_{I+1} x sb_I
+            else if (q < 144) { q -= 90; const int r = q / 9, c = q - 9 * r; ib = pairidx2(21 + c, r); }          // pose_I x sb_{I+1}
+            else { q -= 144; const int r = q / 9, c = q - 9 * r; ib = pairidx2(21 + r, 6 + c); }                  // sb_{I+1} (r) x sb_I (c)
+            return HB[ib];
+        };
+        auto imu_pair_apply = [&](int e, double v) {
+            const int I = e / 225;
+            int q = e - 225 * I;
+            if (q < 36) Spp[sblk(I + 1, I, N) + q] += v;
+            else if (q < 90) Ysb[yo[I] + (I + 1 - nlo(I, M)) * 54 + (q - 36)] = v;
+            else if (q < 144) Ysb[yo[I + 1] + (I - nlo(I + 1, M)) * 54 + (q - 90)] = v;
+            else {
+                q -= 144;
+                const int r = q / 9, c = q - 9 * r;         // rows = parent, cols = child
+                if (I < M) Css[I * 81 + r * 9 + c] = v; else Css[(I + 1) * 81 + c * 9 + r] = v;
+            }
+        };
+#pragma unroll
+        for (int k = 0; k < 3; k++) { const int e = t + k * LS; vF[k] = e < N * 120 ? imu_frame_fetch(e) : 0.0; }
+#pragma unroll
+        for (int k = 0; k < 5; k++) { const int e = t + k * LS; vX[k] = e < (N - 1) * 225 ? imu_pair_fetch(e) : 0.0; }
+        if (t < n) {
+            const int I = t / 15, r = t - 15 * I;
+            if (I >= 1 && !skipL[I - 1]) vG += H[(size_t)(I - 1) * ISV_IMU_H + 465 + 15 + r];
+            if (I <= N - 2 && !skipL[I]) vG += H[(size_t)I * ISV_IMU_H + 465 + r];
+        }
         // ---- reprojection part from k_sweep / k_rank1_mfma (same packed layout) ----------------------
-        for (int e = t; e < nS; e += LS) Spp[e] = V[e];
+        for (int e = t; e < n; e += LS) { g[e] = 0.0; bs[e] = 0.0; hdiag[e] = 0.0; }
+#pragma unroll
+        for (int k = 0; k < 5; k++) { const int e = t + k * LS; if (e < nS) Spp[e] = vS[k]; }
         __syncthreads();
-        for (int e = t; e < n6; e += LS) {
-            const int fa = e / 6, r = e - 6 * fa;
-            hdiag[15 * fa + r] = V[nS + e]; g[15 * fa + r] = V[nS + n6 + e]; bs[15 * fa + r] = V[nS + 2 * n6 + e];
+        if (t < n6) {
+            const int fa = t / 6, r = t - 6 * fa;
+            hdiag[15 * fa + r] = vT[0]; g[15 * fa + r] = vT[1]; bs[15 * fa + r] = vT[2];
         }
         if (attempt == 0) {
             for (int l = l0 + t; l < l1; l += LS) gmax_l = fmax(gmax_l, fabs(d.lmG[l]));
@@ -187,77 +290,19 @@ __global__ __launch_bounds__(LS, 4) void k_build_solve_sb(DevBatch d) {
             __syncthreads();
         }
         for (int e = t; e < 162 * N + ytot; e += LS) Dss[e] = 0.0;      // Dss, Css, Ysb are contiguous
+        red[t] = vP[0];                                                  // prior blocks staged in LDS
+        if (t + LS < nred) red[t + LS] = vP[1];
         __syncthreads();
-        // ---- IMU factors (precomputed J^T J, local order pose_i sb_i pose_j sb_j) ---------------------
-        {
-            const double *H = d.imu_H + (size_t)w * (N - 1) * ISV_IMU_H;
-            const int *skip = d.imu_skip + (size_t)w * (N - 1);
-            for (int e = t; e < N * 120; e += LS) {         // per frame: pose diag (21), sb diag (45), pose x sb (54)
-                const int I = e / 120;
-                int q = e - 120 * I;
-                const bool hasA = I >= 1 && !skip[I - 1], hasB = I <= N - 2 && !skip[I];
-                const double *HA = H + (size_t)(I - 1) * ISV_IMU_H, *HB = H + (size_t)I * ISV_IMU_H;
-                if (q < 21) {
-                    int r = 0; while ((r + 1) * (r + 2) / 2 <= q) r++;
-                    const int c = q - r * (r + 1) / 2;
-                    double v = 0;
-                    if (hasA) v += HA[pairidx2(15 + r, 15 + c)];
-                    if (hasB) v += HB[pairidx2(r, c)];
-                    Spp[sblk(I, I, N) + r * 6 + c] += v;
-                    if (r == c) hdiag[15 * I + r] += v;
-                } else if (q < 66) {
-                    q -= 21;
-                    int r = 0; while ((r + 1) * (r + 2) / 2 <= q) r++;
-                    const int c = q - r * (r + 1) / 2;
-                    double v = 0;
-                    if (hasA) v += HA[pairidx2(21 + r, 21 + c)];
-                    if (hasB) v += HB[pairidx2(6 + r, 6 + c)];
-                    Dss[I * 81 + r * 9 + c] = v;
-                    if (r == c) hdiag[15 * I + 6 + r] = v;
-                } else {
-                    q -= 66;
-                    const int r = q / 9, c = q - 9 * r;     // pose row r, speed/bias column c of frame I
-                    double v = 0;
-                    if (hasA) v += HA[pairidx2(21 + c, 15 + r)];
-                    if (hasB) v += HB[pairidx2(6 + c, r)];
-                    Ysb[yo[I] + (I - nlo(I, M)) * 54 + q] = v;
-                }
-            }
-            for (int e = t; e < (N - 1) * 225; e += LS) {   // per factor: the blocks between frames I and I + 1
-                const int I = e / 225;
-                int q = e - 225 * I;
-                if (skip[I]) continue;
-                const double *HB = H + (size_t)I * ISV_IMU_H;
-                if (q < 36) {
-                    const int r = q / 6, c = q - 6 * r;
-                    Spp[sblk(I + 1, I, N) + q] += HB[pairidx2(15 + r, c)];
-                } else if (q < 90) {
-                    q -= 36;
-                    const int r = q / 9, c = q - 9 * r;     // pose_{I+1} x sb_I
-                    Ysb[yo[I] + (I + 1 - nlo(I, M)) * 54 + q] = HB[pairidx2(15 + r, 6 + c)];
-                } else if (q < 144) {
-                    q -= 90;
-                    const int r = q / 9, c = q - 9 * r;     // pose_I x sb_{I+1}
-                    Ysb[yo[I + 1] + (I - nlo(I + 1, M)) * 54 + q] = HB[pairidx2(21 + c, r)];
-                } else {
-                    q -= 144;
-                    const int r = q / 9, c = q - 9 * r;     // sb_{I+1} (r) x sb_I (c): rows = parent, cols = child
-                    const double v = HB[pairidx2(21 + r, 6 + c)];
-                    if (I < M) Css[I * 81 + r * 9 + c] = v; else Css[(I + 1) * 81 + c * 9 + r] = v;
-                }
-            }
-            for (int e = t; e < n; e += LS) {
-                const int I = e / 15, r = e - 15 * I;
-                double v = 0;
-                if (I >= 1 && !skip[I - 1]) v += H[(size_t)(I - 1) * ISV_IMU_H + 465 + 15 + r];
-                if (I <= N - 2 && !skip[I]) v += H[(size_t)I * ISV_IMU_H + 465 + r];
-                g[e] += v;
-            }
-        }
+        STAMP(0);
+#pragma unroll
+        for (int k = 0; k < 3; k++) { const int e = t + k * LS; if (e < N * 120) imu_frame_apply(e, vF[k]); }
+#pragma unroll
+        for (int k = 0; k < 5; k++) { const int e = t + k * LS; if (e < (N - 1) * 225 && !skipL[e / 225]) imu_pair_apply(e, vX[k]); }
+        if (t < n) g[t] += vG;
         __syncthreads();
-        // ---- prior factors (precomputed J^T J) -------------------------------------------------------
+        STAMP(1);
+        // ---- prior factors (precomputed J^T J, staged in red[]) ---------------------------------------
         {
-            const double *PH = d.prior_H + (size_t)w * d.prior_H_sz;
             const int nprior = 2 + (d.Nvo - 1) + d.n_rp[w];
             for (int q = 0; q < nprior; q++) {
                 int ncol, off, c0, c1 = 0;
@@ -267,13 +312,13 @@ __global__ __launch_bounds__(LS, 4) void k_build_solve_sb(DevBatch d) {
                 else { const int m = q - 1 - d.Nvo; ncol = 6; off = PH_REL0 + PH_REL_SZ * (d.Nvo - 1) + PH_RP_SZ * m; c0 = 15 * d.rollpitch[(size_t)w * d.max_rp + m].index; }
                 const int np2 = ncol * (ncol + 1) / 2;
                 for (int e = t; e < np2 + ncol; e += LS) {
+                    const double v = red[off + e];
                     if (e < np2) {
                         int aa = 0;
                         while ((aa + 1) * (aa + 2) / 2 <= e) aa++;
                         const int bb = e - aa * (aa + 1) / 2;
                         const int ga = (aa < 6 || ncol != 12) ? c0 + aa : c1 + aa - 6;
                         const int gb = (bb < 6 || ncol != 12) ? c0 + bb : c1 + bb - 6;
-                        const double v = PH[off + e];
                         const int Ia = ga / 15, ra = ga - 15 * Ia, Ib = gb / 15, rb = gb - 15 * Ib;
                         if (ra < 6) Spp[sblk(Ia, Ib, N) + ra * 6 + rb] += v;
                         else Dss[Ia * 81 + (ra - 6) * 9 + (rb - 6)] += v;
@@ -281,12 +326,13 @@ __global__ __launch_bounds__(LS, 4) void k_build_solve_sb(DevBatch d) {
                     } else {
                         const int aa = e - np2;
                         const int ga = (aa < 6 || ncol != 12) ? c0 + aa : c1 + aa - 6;
-                        g[ga] += PH[off + e];
+                        g[ga] += v;
                     }
                 }
                 __syncthreads();
             }
         }
+        STAMP(2);
         // ---- Jacobi scaling, LM diagonal, Cauchy data -------------------------------------------------
         for (int e = t; e < n; e += LS) {
             double s;
@@ -347,6 +393,7 @@ __global__ __launch_bounds__(LS, 4) void k_build_solve_sb(DevBatch d) {
             if (t == 0) st.qT = red[0];
         }
         __syncthreads();
+        STAMP(3);
         // ---- speed/bias chains: wavefront 0 forward (0 .. M-1), wavefront 1 backward (N-1 .. M+1) ----
         // node i: (1) D_i -> inverse Cholesky factor; (2) rows of [C_i ; Y_i] times L_i^-T;
         //         (3) downdate the parent's diagonal block and pose coupling (not for children of M here:
@@ -413,6 +460,7 @@ __global__ __launch_bounds__(LS, 4) void k_build_solve_sb(DevBatch d) {
             }
             __syncthreads();
         }
+        STAMP(4);
         if (!flag[0]) {
             // ---- pose system: Spp -= sum_i Y_i Y_i^T ---------------------------------------------------
             for (int e = t; e < nS; e += LS) {
@@ -431,6 +479,7 @@ __global__ __launch_bounds__(LS, 4) void k_build_solve_sb(DevBatch d) {
                 Spp[e] -= s;
             }
             __syncthreads();
+            STAMP(5);
             // ---- blocked Cholesky of the pose system (6x6 blocks; diagonal blocks hold L_JJ^-1 afterwards)
             for (int J = 0; J < N; J++) {
                 if (wv == 0 && chol_inv_block<6>(Spp + sblk(J, J, N), lane)) { if (lane == 0) flag[0] = 1; }
@@ -474,6 +523,7 @@ __global__ __launch_bounds__(LS, 4) void k_build_solve_sb(DevBatch d) {
             }
         }
         __syncthreads();
+        STAMP(6);
         if (flag[0]) {
             mu *= 10.0; attempt++;
             __syncthreads();
@@ -481,137 +531,164 @@ __global__ __launch_bounds__(LS, 4) void k_build_solve_sb(DevBatch d) {
             __syncthreads();
             continue;
         }
-        // ---- forward substitution: chains (elimination order), then the pose block ---------------------
+        // ---- triangular solves: one wavefront, the right-hand side lives in REGISTERS ------------------
+        // speed/bias rows: register ys0 holds the nodes 0..M (lane = 9 node + c), ys1 the nodes M+1..N-1
+        // (lane = 9 (node - M - 1) + c); pose rows: yp0 holds frames 0..9 (lane = 6 frame + r), yp1 frames
+        // 10.. .  A node / frame never straddles registers, pivot vectors travel by v_readlane, every lane
+        // forms its own row's dot product: the 4N dependent steps need no LDS round trip and no barrier.
+        // z / x cross LDS only for the two pose <-> chain gathers.
         const int nlev = M > N - 1 - M ? M : N - 1 - M;
         if (wv == 0) {
-            for (int k = 0; k <= nlev; k++) {
-                for (int side = 0; side < 2; side++) {
-                    int i;
-                    if (k == nlev) { if (side) break; i = M; }
-                    else { i = side == 0 ? k : N - 1 - k; if (side == 0 ? i >= M : i <= M) continue; }
-                    const double *Li = Dss + i * 81;
-                    double yin[9], z = 0;
+            const int q9 = lane / 9, c9 = lane - 9 * q9, q6 = lane / 6, c6 = lane - 6 * q6;
+            const int sA = q9, sB = M + 1 + q9;                 // my speed/bias node in ys0 / ys1
+            const bool hasA = sA <= M, hasB = sB <= N - 1;
+            const int fA = q6, fB = 10 + q6;                    // my frame in yp0 / yp1
+            const bool hasPA = q6 < 10 && fA < N, hasPB = q6 < 10 && fB < N;
+            double ys0 = hasA ? y[15 * sA + 6 + c9] : 0.0, ys1 = hasB ? y[15 * sB + 6 + c9] : 0.0;
+            double yp0 = hasPA ? y[15 * fA + c6] : 0.0, yp1 = hasPB ? y[15 * fB + c6] : 0.0;
+            auto sb_base = [&](int i) { return i > M ? 9 * (i - M - 1) : 9 * i; };
+            // forward step of chain node i (register yn), parent in register ypr
+            auto node_fwd = [&](int i, double &yn, double &ypr, int pp) {
+                const int b = sb_base(i);
+                double v[9];
 #pragma unroll
-                    for (int kk = 0; kk < 9; kk++) yin[kk] = y[15 * i + 6 + kk];
-                    if (lane < 9) {
+                for (int k = 0; k < 9; k++) v[k] = readlane_d2(yn, b + k);
+                const double *Lr = Dss + i * 81 + c9 * 9;       // row c9 of L_i^-1 (upper part is zero)
+                double z = 0;
 #pragma unroll
-                        for (int kk = 0; kk < 9; kk++) if (kk <= lane) z += Li[lane * 9 + kk] * yin[kk];
-                    }
-                    WSYNC();
-                    if (lane < 9) y[15 * i + 6 + lane] = z;
-                    WSYNC();
-                    const int pp = npar(i, M);
-                    if (pp >= 0 && lane < 9) {
-                        double s = 0;
+                for (int k = 0; k < 9; k++) z += Lr[k] * v[k];
+                if (9 * q9 == b && q9 < 7) yn = z;
+                if (pp >= 0) {
 #pragma unroll
-                        for (int kk = 0; kk < 9; kk++) s += Css[i * 81 + lane * 9 + kk] * y[15 * i + 6 + kk];
-                        y[15 * pp + 6 + lane] -= s;
-                    }
-                    WSYNC();
-                }
-            }
-        }
-        __syncthreads();
-        if (t < n6) {                                           // pose rhs -= sum_i Y_i z_i
-            const int a = t / 6, r = t - 6 * a;
-            double s = 0;
-            for (int i = 0; i < N; i++) {
-                const int lo = nlo(i, M);
-                if (a >= lo && a <= nhi(i, M, N)) {
-                    const double *Yr = Ysb + yo[i] + (a - lo) * 54 + r * 9;
-#pragma unroll
-                    for (int k = 0; k < 9; k++) s += Yr[k] * y[15 * i + 6 + k];
-                }
-            }
-            y[15 * a + r] -= s;
-        }
-        __syncthreads();
-        if (wv == 0) {
-            for (int J = 0; J < N; J++) {                       // forward, pose block
-                const double *Li = Spp + sblk(J, J, N);
-                double yin[6], z = 0;
-#pragma unroll
-                for (int k = 0; k < 6; k++) yin[k] = y[15 * J + k];
-                if (lane < 6) {
-#pragma unroll
-                    for (int k = 0; k < 6; k++) if (k <= lane) z += Li[lane * 6 + k] * yin[k];
-                }
-                WSYNC();
-                if (lane < 6) y[15 * J + lane] = z;
-                WSYNC();
-                for (int rho = 6 * (J + 1) + lane; rho < n6; rho += 64) {
-                    const int I = rho / 6, r = rho - 6 * I;
-                    const double *Lr = Spp + sblk(I, J, N) + r * 6;
+                    for (int k = 0; k < 9; k++) v[k] = readlane_d2(yn, b + k);
+                    const double *Cr = Css + i * 81 + c9 * 9;   // row c9 of C_i (rows = parent)
                     double s = 0;
 #pragma unroll
-                    for (int k = 0; k < 6; k++) s += Lr[k] * y[15 * J + k];
-                    y[15 * I + r] -= s;
+                    for (int k = 0; k < 9; k++) s += Cr[k] * v[k];
+                    if (9 * q9 == sb_base(pp) && q9 < 7) ypr -= s;
                 }
-                WSYNC();
+            };
+            // backward step: x_i = L_i^-T (z_i - C_i^T x_parent)
+            auto node_bwd = [&](int i, double &yn, double &ypr, int pp) {
+                const int b = sb_base(i);
+                double v[9];
+                const bool mine = 9 * q9 == b && q9 < 7;
+                if (pp >= 0) {
+                    const int bp = sb_base(pp);
+#pragma unroll
+                    for (int k = 0; k < 9; k++) v[k] = readlane_d2(ypr, bp + k);
+                    const double *Cc = Css + i * 81 + c9;       // column c9 of C_i
+                    double s = 0;
+#pragma unroll
+                    for (int k = 0; k < 9; k++) s += Cc[k * 9] * v[k];
+                    if (mine) yn -= s;
+                }
+#pragma unroll
+                for (int k = 0; k < 9; k++) v[k] = readlane_d2(yn, b + k);
+                const double *Lc = Dss + i * 81 + c9;           // column c9 of L_i^-1
+                double x = 0;
+#pragma unroll
+                for (int k = 0; k < 9; k++) x += Lc[k * 9] * v[k];
+                if (mine) yn = x;
+            };
+            for (int k = 0; k < nlev; k++) {                    // forward, chains in elimination order
+                if (k < M) node_fwd(k, ys0, ys0, k + 1);
+                const int ib = N - 1 - k;
+                if (ib > M) { if (ib - 1 == M) node_fwd(ib, ys1, ys0, M); else node_fwd(ib, ys1, ys1, ib - 1); }
+            }
+            node_fwd(M, ys0, ys0, -1);
+            if (hasA) y[15 * sA + 6 + c9] = ys0;
+            if (hasB) y[15 * sB + 6 + c9] = ys1;
+            WSYNC();
+            // pose rhs -= sum_i Y_i z_i
+            auto pose_gather = [&](int a, int r) {
+                double s = 0;
+                for (int i = 0; i < N; i++) {
+                    const int lo = nlo(i, M);
+                    if (a >= lo && a <= nhi(i, M, N)) {
+                        const double *Yr = Ysb + yo[i] + (a - lo) * 54 + r * 9, *zi = y + 15 * i + 6;
+#pragma unroll
+                        for (int kk = 0; kk < 9; kk++) s += Yr[kk] * zi[kk];
+                    }
+                }
+                return s;
+            };
+            if (hasPA) yp0 -= pose_gather(fA, c6);
+            if (N > 10 && hasPB) yp1 -= pose_gather(fB, c6);
+            for (int J = 0; J < N; J++) {                       // forward, pose block
+                const int b = 6 * (J % 10);
+                double v[6];
+#pragma unroll
+                for (int k = 0; k < 6; k++) v[k] = J < 10 ? readlane_d2(yp0, b + k) : readlane_d2(yp1, b + k);
+                const double *Lr = Spp + sblk(J, J, N) + c6 * 6;
+                double z = 0;
+#pragma unroll
+                for (int k = 0; k < 6; k++) z += Lr[k] * v[k];
+                if (J < 10) { if (hasPA && fA == J) yp0 = z; } else { if (hasPB && fB == J) yp1 = z; }
+#pragma unroll
+                for (int k = 0; k < 6; k++) v[k] = J < 10 ? readlane_d2(yp0, b + k) : readlane_d2(yp1, b + k);
+                if (hasPA && fA > J) {
+                    const double *Lb = Spp + sblk(fA, J, N) + c6 * 6;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) yp0 -= Lb[k] * v[k];
+                }
+                if (N > 10 && hasPB && fB > J) {
+                    const double *Lb = Spp + sblk(fB, J, N) + c6 * 6;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) yp1 -= Lb[k] * v[k];
+                }
             }
             for (int J = N - 1; J >= 0; J--) {                  // backward, pose block (right-looking)
-                const double *Li = Spp + sblk(J, J, N);
-                double xin[6], x = 0;
+                const int b = 6 * (J % 10);
+                double v[6];
 #pragma unroll
-                for (int k = 0; k < 6; k++) xin[k] = y[15 * J + k];
-                if (lane < 6) {
+                for (int k = 0; k < 6; k++) v[k] = J < 10 ? readlane_d2(yp0, b + k) : readlane_d2(yp1, b + k);
+                const double *Lc = Spp + sblk(J, J, N) + c6;    // column c6 of L_JJ^-1
+                double x = 0;
 #pragma unroll
-                    for (int k = 0; k < 6; k++) if (k >= lane) x += Li[k * 6 + lane] * xin[k];
+                for (int k = 0; k < 6; k++) x += Lc[k * 6] * v[k];
+                if (J < 10) { if (hasPA && fA == J) yp0 = x; } else { if (hasPB && fB == J) yp1 = x; }
+#pragma unroll
+                for (int k = 0; k < 6; k++) v[k] = J < 10 ? readlane_d2(yp0, b + k) : readlane_d2(yp1, b + k);
+                if (hasPA && fA < J) {
+                    const double *Lb = Spp + sblk(J, fA, N) + c6;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) yp0 -= Lb[k * 6] * v[k];
                 }
-                WSYNC();
-                if (lane < 6) y[15 * J + lane] = x;
-                WSYNC();
-                for (int rho = lane; rho < 6 * J; rho += 64) {
-                    const int K = rho / 6, c = rho - 6 * K;
-                    const double *Lb = Spp + sblk(J, K, N) + c;
-                    double s = 0;
+                if (N > 10 && hasPB && fB < J) {
+                    const double *Lb = Spp + sblk(J, fB, N) + c6;
 #pragma unroll
-                    for (int k = 0; k < 6; k++) s += Lb[k * 6] * y[15 * J + k];
-                    y[15 * K + c] -= s;
-                }
-                WSYNC();
-            }
-        }
-        __syncthreads();
-        if (t < 9 * N) {                                        // chain rhs -= Y_i^T x_pose
-            const int i = t / 9, c = t - 9 * i, lo = nlo(i, M), nr = nhi(i, M, N) - lo + 1;
-            const double *Yc = Ysb + yo[i] + c;
-            double s = 0;
-            for (int row = 0; row < 6 * nr; row++) s += Yc[row * 9] * y[15 * (lo + row / 6) + row % 6];
-            y[15 * i + 6 + c] -= s;
-        }
-        __syncthreads();
-        if (wv == 0) {
-            for (int k = nlev; k >= 0; k--) {                   // backward, chains (reverse elimination order)
-                for (int side = 0; side < 2; side++) {
-                    int i;
-                    if (k == nlev) { if (side) break; i = M; }
-                    else { i = side == 0 ? k : N - 1 - k; if (side == 0 ? i >= M : i <= M) continue; }
-                    const double *Li = Dss + i * 81;
-                    const int pp = npar(i, M);
-                    double s = 0;
-                    if (lane < 9) {
-                        s = y[15 * i + 6 + lane];
-                        if (pp >= 0) {
-#pragma unroll
-                            for (int kk = 0; kk < 9; kk++) s -= Css[i * 81 + kk * 9 + lane] * y[15 * pp + 6 + kk];
-                        }
-                    }
-                    WSYNC();
-                    if (lane < 9) y[15 * i + 6 + lane] = s;
-                    WSYNC();
-                    double x = 0;
-                    if (lane < 9) {
-#pragma unroll
-                        for (int kk = 0; kk < 9; kk++) if (kk >= lane) x += Li[kk * 9 + lane] * y[15 * i + 6 + kk];
-                    }
-                    WSYNC();
-                    if (lane < 9) y[15 * i + 6 + lane] = x;
-                    WSYNC();
+                    for (int k = 0; k < 6; k++) yp1 -= Lb[k * 6] * v[k];
                 }
             }
+            if (hasPA) y[15 * fA + c6] = yp0;
+            if (hasPB) y[15 * fB + c6] = yp1;
+            WSYNC();
+            // chain rhs -= Y_i^T x_pose
+            auto chain_gather = [&](int i, int c) {
+                const int lo = nlo(i, M), nr = nhi(i, M, N) - lo + 1;
+                const double *Yc = Ysb + yo[i] + c;
+                double s = 0;
+                for (int a = 0; a < nr; a++) {
+                    const double *xa = y + 15 * (lo + a);
+#pragma unroll
+                    for (int r = 0; r < 6; r++) s += Yc[(a * 6 + r) * 9] * xa[r];
+                }
+                return s;
+            };
+            if (hasA) ys0 -= chain_gather(sA, c9);
+            if (hasB) ys1 -= chain_gather(sB, c9);
+            node_bwd(M, ys0, ys0, -1);                          // backward, chains (reverse elimination order)
+            for (int k = nlev - 1; k >= 0; k--) {
+                if (k < M) node_bwd(k, ys0, ys0, k + 1);
+                const int ib = N - 1 - k;
+                if (ib > M) { if (ib - 1 == M) node_bwd(ib, ys1, ys0, M); else node_bwd(ib, ys1, ys1, ib - 1); }
+            }
+            if (hasA) y[15 * sA + 6 + c9] = ys0;
+            if (hasB) y[15 * sB + 6 + c9] = ys1;
         }
         __syncthreads();
+        STAMP(7);
         break;
     }
     if (!ls_fail) {
@@ -649,9 +726,10 @@ __global__ __launch_bounds__(LS, 4) void k_build_solve_sb(DevBatch d) {
         }
         if (st.gmax <= 1e-10) st.termination = ISV_TERM_GRADIENT_TOL;
     }
+    STAMP(8);
 }
 
-size_t build_solve_sb_bytes(int N) {
+size_t build_solve_sb_bytes(int N, int prior_H_sz) {
     const int M = N / 2;
     size_t ytot = 0;
     for (int i = 0; i < N; i++) ytot += (size_t)((i < M ? i + 1 : N - 1) - (i > M ? i - 1 : 0) + 1) * 54;
@@ -659,5 +737,6 @@ size_t build_solve_sb_bytes(int N) {
     size_t tail = 162 * (size_t)N + ytot;
     const size_t stage = (size_t)RCH * 67;                      // retry staging lives in the Dss/Css/Ysb region
     if (tail < stage) tail = stage;
-    return (7 * n + LS + 8 + 2 + nS + tail + 2) * sizeof(double);
+    const size_t nred = prior_H_sz > LS ? (size_t)((prior_H_sz + 1) & ~1) : LS;
+    return (7 * n + nred + 8 + 8 + 2 + nS + tail + 2) * sizeof(double);
 }

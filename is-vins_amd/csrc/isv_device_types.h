@@ -69,6 +69,7 @@ struct DevBatch {
     FactorRec *f_rec;                   // [Ftot]
     double *f_pts_j;                    // [Ftot][2]
     int32_t *tile_win, *tile_f0, *tile_n;   // [n_tiles]
+    int32_t *pg_perm, *pg_off;              // factors of a window sorted by (host, observer) frame pair: [Ftot] window-relative ids, [B][N(N-1)/2 + 1] group starts
     // IMU
     double *imu_in;                     // [B (N-1)][ISV_IMU_IN]
     double *imu_cov;                    // [B (N-1)][225]

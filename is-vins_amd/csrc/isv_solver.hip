@@ -16,9 +16,10 @@ extern size_t build_solve_lds_bytes(int N, bool lds_T);
 extern size_t build_solve_lds2_bytes(int N);
 __global__ void k_build_solve_lds(DevBatch d);
 __global__ void k_build_solve_sb(DevBatch d);
-extern size_t build_solve_sb_bytes(int N);
+extern size_t build_solve_sb_bytes(int N, int prior_H_sz);
 __global__ void k_lm_prep(DevBatch d);
 __global__ void k_sweep(DevBatch d);
+__global__ void k_sweep_mfma(DevBatch d);
 __global__ void k_rank1_mfma(DevBatch d);
 __global__ void k_backsub(DevBatch d);
 __global__ void k_marg_clear(DevBatch d);
@@ -380,13 +381,13 @@ int isv_solver_alloc(DevBatch &d, size_t B, size_t L, size_t F, std::vector<void
     HCHK(hipMemset(d.dbg, 0, B * 64 * sizeof(double)));
     TRYA(dal(&d.marg, B, allocs, err)); TRYA(dal(&d.margin_old, B, allocs, err)); TRYA(dal(&d.header0, B, allocs, err));
     const size_t nblkT = (size_t)d.N * (d.N + 1) / 2 * 225;
-    d.lds_T = (d.N <= 11 && build_solve_lds2_bytes(d.N) <= 160 * 1024) ? 1 : 0;
+    d.lds_T = (d.N <= 11 && d.prior_H_sz <= 1024 && build_solve_lds2_bytes(d.N) <= 160 * 1024) ? 1 : 0;
     TRYA(dal(&d.Tglob, d.lds_T ? 1 : B * nblkT, allocs, err));
     d.marg_scratch_sz = 26;
     TRYA(dal(&d.marg_scratch, L * 26, allocs, err));
     if (d.lds_T) {
         HCHK(hipFuncSetAttribute((const void *)k_build_solve_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)build_solve_lds2_bytes(d.N)));
-        HCHK(hipFuncSetAttribute((const void *)k_build_solve_sb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)build_solve_sb_bytes(d.N)));
+        HCHK(hipFuncSetAttribute((const void *)k_build_solve_sb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)build_solve_sb_bytes(d.N, d.prior_H_sz)));
     }
     else HCHK(hipFuncSetAttribute((const void *)k_build_solve<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)build_solve_lds_bytes(d.N, false)));
     return ISV_OK;
@@ -422,7 +423,10 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
         }
         PROF(slot, 1, 0);
         if (d.lds_T) {
-            hipLaunchKernelGGL(k_sweep, dim3(d.B, d.N), dim3(64), 0, st, d); counts[2]++;
+            static const int sweep_old = getenv("ISV_SWEEP_OLD") ? 1 : 0;
+            if (sweep_old) hipLaunchKernelGGL(k_sweep, dim3(d.B, d.N), dim3(64), 0, st, d);
+            else hipLaunchKernelGGL(k_sweep_mfma, dim3(d.B), dim3(64 * (d.N - 1)), (size_t)(d.N * (d.N - 1) / 2 + d.N) * 42 * sizeof(double), st, d);
+            counts[2]++;
             const int nt = d.wd_ld / 16;
             // one workgroup per window: nt(nt+1)/2 tile wavefronts + 1 rhs wavefront, W panels staged through LDS
             hipLaunchKernelGGL(k_rank1_mfma, dim3(d.B), dim3(64 * (nt * (nt + 1) / 2 + 1)), (64 * (d.wd_ld + 4) + 128) * sizeof(double), st, d);
@@ -432,7 +436,7 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
         hipLaunchKernelGGL(k_cost_reduce, dim3(d.B), dim3(256), 0, st, d, d.fcost, d.imu_cost, d.prior_cost, d.cost, 1);
         PROF(slot, 2, 0);
         static const int bs_old = getenv("ISV_BS_OLD") ? 1 : 0;
-        if (d.lds_T && !bs_old) hipLaunchKernelGGL(k_build_solve_sb, dim3(d.B), dim3(512), build_solve_sb_bytes(d.N), st, d);
+        if (d.lds_T && !bs_old) hipLaunchKernelGGL(k_build_solve_sb, dim3(d.B), dim3(512), build_solve_sb_bytes(d.N, d.prior_H_sz), st, d);
         else if (d.lds_T) hipLaunchKernelGGL(k_build_solve_lds, dim3(d.B), dim3(768), lds_bs, st, d);
         else hipLaunchKernelGGL(k_build_solve<false>, dim3(d.B), dim3(512), lds_bs, st, d);
         counts[1]++;

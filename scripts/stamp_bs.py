@@ -10,9 +10,9 @@ be = backend.Backend(11, 5, max_landmarks=300, max_obs=1600, max_batch=B)
 be.upload(ws)
 be.run_optimize()
 dbg = be.debug_read(21, B * 64).reshape(B, 64)
-names = {0: "zero", 1: "imu+prior", 2: "visual sweep", 3: "scale+qT", 4: "cholesky", 5: "solve", 6: "outputs", 10: "w4: phase a (to mid barrier)", 11: "w4: phase b", 12: "w4: wait top barrier", 13: "w4: pre-sweep"}
-tot = dbg[:, :7].sum(1)
-print("per build_solve call (us), median over windows; 10 calls/solve; wall_clock64 = 100 MHz")
+names = {0: "load Tvis + zero", 1: "imu gather", 2: "priors", 3: "scale+qT", 4: "sb chains", 5: "Y Y^T", 6: "pose cholesky", 7: "solves", 8: "outputs"}
+tot = dbg[:, :9].sum(1)
+print("per k_build_solve_sb call (us), median over windows; 10 calls/solve; wall_clock64 = 100 MHz")
 for k, nm in names.items():
     print(f"  {nm:30s} {np.median(dbg[:, k]) / 10 / 100:8.1f} us")
 print("  total           ", np.median(tot) / 10 / 100)
