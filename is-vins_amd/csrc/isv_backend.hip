@@ -8,6 +8,7 @@
 #include <cstring>
 #include <string>
 #include <vector>
+#include <algorithm>
 #include "isv_device_types.h"
 #include "isv_kernels.h"
 
@@ -35,7 +36,7 @@ struct isv_backend {
     // host staging (pinned)
     struct Host {
         double *Ps, *Rs, *Vs, *Bas, *Bgs, *tic, *ric, *depth, *lm_pts_i, *f_pts_j, *imu_in, *imu_cov;
-        int32_t *lm_off, *f_off, *lm_host, *lm_k, *lm_f0, *tile_win, *tile_f0, *tile_n, *imu_skip, *n_rp, *solve_flag, *pg_perm, *pg_off;
+        int32_t *lm_off, *f_off, *lm_host, *lm_k, *lm_f0, *tile_win, *tile_f0, *tile_n, *imu_skip, *n_rp, *solve_flag, *pg_perm, *pg_off, *pg_sched, *pg_sched_off;
         FactorRec *f_rec;
         uint32_t *lm_meta; int32_t *ck_off; int2 *ck_rec; int32_t *margin_old; double *header0;
         isv_se3_prior_t *se3; isv_linear9_t *lin9; isv_relpose_t *relpose; isv_rollpitch_t *rollpitch;
@@ -117,6 +118,7 @@ static int create_impl(isv_backend *h) {
     TRY(dalloc(h, &d.f_rec, F)); TRY(dalloc(h, &d.f_pts_j, F * 2));
     TRY(dalloc(h, &d.tile_win, T)); TRY(dalloc(h, &d.tile_f0, T)); TRY(dalloc(h, &d.tile_n, T));
     TRY(dalloc(h, &d.pg_perm, F)); TRY(dalloc(h, &d.pg_off, B * ((size_t)c.n_frames * (c.n_frames - 1) / 2 + 1)));
+    TRY(dalloc(h, &d.pg_sched, B * ((size_t)c.n_frames * (c.n_frames - 1) / 2))); TRY(dalloc(h, &d.pg_sched_off, B * (ISV_SWEEP_WAVES + 1)));
     TRY(dalloc(h, &d.imu_in, NI * ISV_IMU_IN)); TRY(dalloc(h, &d.imu_cov, NI * 225)); TRY(dalloc(h, &d.imu_sqrt, NI * 225));
     TRY(dalloc(h, &d.imu_skip, NI));
     TRY(dalloc(h, &d.se3, B)); TRY(dalloc(h, &d.lin9, B)); TRY(dalloc(h, &d.relpose, B * (c.n_vo - 1))); TRY(dalloc(h, &d.rollpitch, B * (size_t)c.max_rollpitch));
@@ -139,7 +141,8 @@ static int create_impl(isv_backend *h) {
     TRY(halloc(h, &s.imu_in, NI * ISV_IMU_IN)); TRY(halloc(h, &s.imu_cov, NI * 225));
     TRY(halloc(h, &s.lm_off, B + 1)); TRY(halloc(h, &s.f_off, B + 1)); TRY(halloc(h, &s.lm_host, L)); TRY(halloc(h, &s.lm_k, L)); TRY(halloc(h, &s.lm_f0, L));
     TRY(halloc(h, &s.tile_win, T)); TRY(halloc(h, &s.tile_f0, T)); TRY(halloc(h, &s.tile_n, T));
-    TRY(halloc(h, &s.pg_perm, F)); TRY(halloc(h, &s.pg_off, B * ((size_t)c.n_frames * (c.n_frames - 1) / 2 + 1))); TRY(halloc(h, &s.imu_skip, NI)); TRY(halloc(h, &s.n_rp, B));
+    TRY(halloc(h, &s.pg_perm, F)); TRY(halloc(h, &s.pg_off, B * ((size_t)c.n_frames * (c.n_frames - 1) / 2 + 1)));
+    TRY(halloc(h, &s.pg_sched, B * ((size_t)c.n_frames * (c.n_frames - 1) / 2))); TRY(halloc(h, &s.pg_sched_off, B * (ISV_SWEEP_WAVES + 1))); TRY(halloc(h, &s.imu_skip, NI)); TRY(halloc(h, &s.n_rp, B));
     TRY(halloc(h, &s.f_rec, F));
     TRY(halloc(h, &s.margin_old, B)); TRY(halloc(h, &s.header0, B));
     TRY(halloc(h, &s.lm_meta, L)); TRY(halloc(h, &s.ck_off, B + 1)); TRY(halloc(h, &s.ck_rec, L + B + 1));
@@ -242,6 +245,25 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
                 const int p = pidx(s.f_rec[f].ij & 255, (s.f_rec[f].ij >> 8) & 255);
                 s.pg_perm[s.f_off[b] + cur[p]++] = (int32_t)(f - s.f_off[b]);
             }
+            // balanced schedule of the pair groups over the sweep wavefronts: longest group first onto the
+            // least loaded wavefront (cost = MFMA slots: 4 per 8 factors)
+            std::vector<int> order(NP), wave_of(NP);
+            for (int p = 0; p < NP; p++) order[p] = p;
+            std::stable_sort(order.begin(), order.end(), [&](int a2, int b2) { return off[a2 + 1] - off[a2] > off[b2 + 1] - off[b2]; });
+            int load[ISV_SWEEP_WAVES] = {0}, cntw[ISV_SWEEP_WAVES] = {0};
+            for (int q = 0; q < NP; q++) {
+                const int p = order[q];
+                int best = 0;
+                for (int v = 1; v < ISV_SWEEP_WAVES; v++) if (load[v] < load[best]) best = v;
+                load[best] += 1 + 4 * ((off[p + 1] - off[p] + 7) / 8);
+                wave_of[p] = best; cntw[best]++;
+            }
+            int32_t *soff = s.pg_sched_off + (size_t)b * (ISV_SWEEP_WAVES + 1), *sched = s.pg_sched + (size_t)b * NP;
+            soff[0] = 0;
+            for (int v = 0; v < ISV_SWEEP_WAVES; v++) soff[v + 1] = soff[v] + cntw[v];
+            int fill[ISV_SWEEP_WAVES] = {0};
+            for (int hh = 0, p = 0; hh < N - 1; hh++)
+                for (int jj = hh + 1; jj < N; jj++, p++) { const int v = wave_of[p]; sched[soff[v] + fill[v]++] = hh | (jj << 8) | (p << 16); }
         }
         for (int i = 0; i < N - 1; i++) {
             const isv_imu_t &im = w->imu[i];
@@ -284,6 +306,7 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
     H2D(d.lm_meta, s.lm_meta, L); H2D(d.ck_off, s.ck_off, n + 1); H2D(d.ck_rec, s.ck_rec, CK + n);
     H2D(d.tile_win, s.tile_win, T); H2D(d.tile_f0, s.tile_f0, T); H2D(d.tile_n, s.tile_n, T);
     H2D(d.pg_perm, s.pg_perm, F); H2D(d.pg_off, s.pg_off, (size_t)n * ((size_t)N * (N - 1) / 2 + 1));
+    H2D(d.pg_sched, s.pg_sched, (size_t)n * ((size_t)N * (N - 1) / 2)); H2D(d.pg_sched_off, s.pg_sched_off, (size_t)n * (ISV_SWEEP_WAVES + 1));
     H2D(d.imu_in, s.imu_in, NI * ISV_IMU_IN); H2D(d.imu_cov, s.imu_cov, NI * 225); H2D(d.imu_skip, s.imu_skip, NI);
     H2D(d.se3, s.se3, n); H2D(d.lin9, s.lin9, n); H2D(d.relpose, s.relpose, (size_t)n * (c.n_vo - 1)); H2D(d.rollpitch, s.rollpitch, (size_t)n * c.max_rollpitch);
     H2D(d.n_rp, s.n_rp, n); H2D(d.margin_old, s.margin_old, n); H2D(d.header0, s.header0, n);

@@ -27,6 +27,7 @@
 #define IMU_DV_DBG 53
 
 // per-window prior strip layout (doubles): [se3: r6 J36][lin9: r9 J81][relpose k: r6 Ji36 Jj36]...[rollpitch m: r2 J12]
+#define ISV_SWEEP_WAVES 8
 #define PR_SE3 0
 #define PR_LIN9 42
 #define PR_REL0 132
@@ -69,6 +70,7 @@ struct DevBatch {
     FactorRec *f_rec;                   // [Ftot]
     double *f_pts_j;                    // [Ftot][2]
     int32_t *tile_win, *tile_f0, *tile_n;   // [n_tiles]
+    int32_t *pg_sched, *pg_sched_off;       // balanced pair -> wavefront schedule of k_sweep_mfma: [B][NP] (h | j << 8 | p << 16), [B][ISV_SWEEP_WAVES + 1]
     int32_t *pg_perm, *pg_off;              // factors of a window sorted by (host, observer) frame pair: [Ftot] window-relative ids, [B][N(N-1)/2 + 1] group starts
     // IMU
     double *imu_in;                     // [B (N-1)][ISV_IMU_IN]

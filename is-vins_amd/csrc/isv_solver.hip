@@ -425,7 +425,7 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
         if (d.lds_T) {
             static const int sweep_old = getenv("ISV_SWEEP_OLD") ? 1 : 0;
             if (sweep_old) hipLaunchKernelGGL(k_sweep, dim3(d.B, d.N), dim3(64), 0, st, d);
-            else hipLaunchKernelGGL(k_sweep_mfma, dim3(d.B), dim3(64 * (d.N - 1)), (size_t)(d.N * (d.N - 1) / 2 + d.N) * 42 * sizeof(double), st, d);
+            else hipLaunchKernelGGL(k_sweep_mfma, dim3(d.B), dim3(64 * ISV_SWEEP_WAVES), ((size_t)(d.N * (d.N - 1) / 2) * 84 + (size_t)(d.N * (d.N - 1) / 2 + 2) / 2 + 1) * sizeof(double), st, d);
             counts[2]++;
             const int nt = d.wd_ld / 16;
             // one workgroup per window: nt(nt+1)/2 tile wavefronts + 1 rhs wavefront, W panels staged through LDS

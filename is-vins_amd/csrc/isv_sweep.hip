@@ -174,83 +174,100 @@ __global__ __launch_bounds__(64) void k_sweep(DevBatch d) {
 // instruction, A and B operands are the same register):
 //     G[0:6, 0:6] = sum J_i^T J_i  (part of block (h,h))     G[6:12, 0:6]  = sum J_j^T J_i = block (j,h)
 //     G[6:12,6:12] = sum J_j^T J_j (part of block (j,j))     G[0:6,12], G[6:12,12] = J_i^T r, J_j^T r
-// Wavefront h of the workgroup owns host frame h and walks its pairs (h, h+1..N-1); rows 0..5 keep
-// accumulating over the pairs, rows 6..11 are flushed per pair.  The (j,j) / gradient partials meet in
-// LDS and are folded in ascending host order (fixed order => bitwise reproducible, no atomics).
+// The pair groups are spread over the 16 wavefronts of the workgroup by a longest-first schedule built
+// at upload (pg_sched); every group leaves its five pieces in LDS / Tvis, then the (a,a) blocks, the
+// Jacobi diagonal and the gradient are folded in a fixed order (bitwise reproducible, no atomics).
 // Every strip is read exactly once (the scalar k_sweep read it twice and was issue / latency bound).
 typedef double double4s __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(1024) void k_sweep_mfma(DevBatch d) {
+__global__ __launch_bounds__(64 * ISV_SWEEP_WAVES) void k_sweep_mfma(DevBatch d) {
     extern __shared__ __align__(16) double lds[];
-    const int w = blockIdx.x, t = threadIdx.x, lane = t & 63, h = t >> 6;
+    const int w = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const SolveState &st = d.st[w];
     if (st.termination != ISV_TERM_RUNNING || !st.need_linearize) return;
     const int N = d.N, NP = N * (N - 1) / 2;
     double *Pjj = lds;                     // [NP][36]  sum J_j^T J_j of pair p
-    double *Pg = Pjj + NP * 36;            // [NP][6]   sum J_j^T r of pair p
-    double *Phh = Pg + NP * 6;             // [N][36]   sum J_i^T J_i of host h
-    double *Pgh = Phh + N * 36;            // [N][6]    sum J_i^T r of host h
-    const int *off = d.pg_off + (size_t)w * (NP + 1);
+    double *Phh = Pjj + NP * 36;           // [NP][36]  sum J_i^T J_i of pair p
+    double *Pgj = Phh + NP * 36;           // [NP][6]   sum J_j^T r
+    double *Pgh = Pgj + NP * 6;            // [NP][6]   sum J_i^T r
+    int *offL = (int *)(Pgh + NP * 6);     // [NP + 1] group starts, staged once
     const int *perm = d.pg_perm + d.f_off[w];
+    const int *sched = d.pg_sched + (size_t)w * NP, *soff = d.pg_sched_off + (size_t)w * (ISV_SWEEP_WAVES + 1);
     const double *strip = d.strip + (size_t)d.f_off[w] * ISV_PROJ_STRIP;
     double *out = d.Tvis + (size_t)w * d.tvis_sz;
     const int i = lane & 15, kq = lane >> 4, row2 = kq & 1, fsel = kq >> 1;
     const int eoff = i < 6 ? 2 + row2 * 6 + i : (i < 12 ? 14 + row2 * 6 + (i - 6) : row2);   // strip element of operand column i
     const bool colok = i < 13;
-    double4s acc = {0, 0, 0, 0};
-    const int p0 = h * N - h * (h + 1) / 2;
-    for (int j = h + 1; j < N; j++) {
-        const int p = p0 + (j - h - 1), b0 = off[p], b1 = off[p + 1];
+#ifdef ISV_STAMP
+    unsigned long long t_last = wall_clock64();
+#define SWSTAMP(k) do { if (t == 0) { unsigned long long now_ = wall_clock64(); d.dbg[(size_t)w * 64 + (k)] += (double)(now_ - t_last); t_last = now_; } } while (0)
+#else
+#define SWSTAMP(k) do {} while (0)
+#endif
+    const int q0 = soff[wv], q1 = soff[wv + 1];
+    const int myrec = (q0 + lane < q1) ? sched[q0 + lane] : 0;         // this wavefront's groups (<= 64)
+    for (int e = t; e <= NP; e += blockDim.x) offL[e] = d.pg_off[(size_t)w * (NP + 1) + e];
+    __syncthreads();
+    SWSTAMP(40);
+    // first chunk of the first group; the next group's chunk is prefetched while the current one is consumed
+    int nxt = 0;
+    if (q0 < q1) { const int p = __shfl(myrec, 0) >> 16; const int b0 = offL[p], c0 = offL[p + 1] - b0; nxt = lane < c0 ? perm[b0 + lane] : 0; }
+    for (int q = q0; q < q1; q++) {
+        const int rec = __shfl(myrec, q - q0), h = rec & 255, j = (rec >> 8) & 255, p = rec >> 16;
+        const int b0 = offL[p], b1 = offL[p + 1];
+        int myf = nxt;
+        if (q + 1 < q1) { const int p2 = __shfl(myrec, q + 1 - q0) >> 16; const int b2 = offL[p2], c2 = offL[p2 + 1] - b2; nxt = lane < c2 ? perm[b2 + lane] : 0; }
+        double4s acc = {0, 0, 0, 0};
         for (int base = b0; base < b1; base += 64) {
             const int cnt = (b1 - base) < 64 ? (b1 - base) : 64;
-            const int myf = lane < cnt ? perm[base + lane] : 0;
-            for (int s2 = 0; s2 < cnt; s2 += 8) {
-                double v[4];
+            if (base > b0) myf = lane < cnt ? perm[base + lane] : 0;
+            for (int s2 = 0; s2 < cnt; s2 += 16) {                     // 16 factors: 8 loads in flight, then 8 MFMAs
+                double v[8];
 #pragma unroll
-                for (int u2 = 0; u2 < 4; u2++) {
+                for (int u2 = 0; u2 < 8; u2++) {
                     const int src = s2 + 2 * u2 + fsel;
                     const int f = __shfl(myf, src & 63);
                     v[u2] = (colok && src < cnt) ? strip[(size_t)f * ISV_PROJ_STRIP + eoff] : 0.0;
                 }
 #pragma unroll
-                for (int u2 = 0; u2 < 4; u2++)
+                for (int u2 = 0; u2 < 8; u2++)
                     if (s2 + 2 * u2 < cnt) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v[u2], v[u2], acc, 0, 0, 0);
             }
         }
-        // flush rows 6..11 (C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg)
+        // C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
-        for (int reg = 1; reg <= 2; reg++) {
+        for (int reg = 0; reg <= 2; reg++) {
             const int row = kq + 4 * reg;
-            if (row >= 6 && row < 12) {
+            if (row < 6) {
+                if (i < 6) Phh[p * 36 + row * 6 + i] = acc[reg];
+                else if (i == 12) Pgh[p * 6 + row] = acc[reg];
+            } else if (row < 12) {
                 const int rr = row - 6;
                 if (i < 6) out[tvis_col(h, N) + (j - h) * 36 + rr * 6 + i] = acc[reg];        // block (j, h)
                 else if (i < 12) Pjj[p * 36 + rr * 6 + (i - 6)] = acc[reg];
-                else if (i == 12) Pg[p * 6 + rr] = acc[reg];
+                else if (i == 12) Pgj[p * 6 + rr] = acc[reg];
             }
         }
-        acc[1] = kq >= 2 ? 0.0 : acc[1]; acc[2] = 0.0; acc[3] = 0.0;       // rows 0..5 keep accumulating
     }
-#pragma unroll
-    for (int reg = 0; reg <= 1; reg++) {
-        const int row = kq + 4 * reg;
-        if (row < 6) {
-            if (i < 6) Phh[h * 36 + row * 6 + i] = acc[reg];
-            else if (i == 12) Pgh[h * 6 + row] = acc[reg];
-        }
-    }
+    SWSTAMP(41);
     __syncthreads();
+    SWSTAMP(42);
     const int tail = 36 * (N * (N + 1) / 2);
+    auto pidx = [N](int hh, int jj) { return hh * N - hh * (hh + 1) / 2 + (jj - hh - 1); };
     if (t < N * 36) {                      // diagonal blocks and the Jacobi-scaling diagonal
         const int a = t / 36, rc = t - 36 * a, r = rc / 6, c = rc - 6 * r;
-        double s = a < N - 1 ? Phh[a * 36 + rc] : 0.0;
-        for (int h2 = 0; h2 < a; h2++) s += Pjj[(h2 * N - h2 * (h2 + 1) / 2 + (a - h2 - 1)) * 36 + rc];
+        double s = 0.0;
+        for (int j2 = a + 1; j2 < N; j2++) s += Phh[pidx(a, j2) * 36 + rc];
+        for (int h2 = 0; h2 < a; h2++) s += Pjj[pidx(h2, a) * 36 + rc];
         out[tvis_col(a, N) + rc] = s;
         if (r == c) out[tail + 6 * a + r] = s;
     } else if (t < N * 42) {               // gradient
         const int q = t - N * 36, a = q / 6, r = q - 6 * a;
-        double s = a < N - 1 ? Pgh[a * 6 + r] : 0.0;
-        for (int h2 = 0; h2 < a; h2++) s += Pg[(h2 * N - h2 * (h2 + 1) / 2 + (a - h2 - 1)) * 6 + r];
+        double s = 0.0;
+        for (int j2 = a + 1; j2 < N; j2++) s += Pgh[pidx(a, j2) * 6 + r];
+        for (int h2 = 0; h2 < a; h2++) s += Pgj[pidx(h2, a) * 6 + r];
         out[tail + 6 * N + 6 * a + r] = s;
     }
+    SWSTAMP(43);
 }
 
 // Rank-1 landmark downdates as FP64 MFMA panels:  Tvis -= Wd^T diag(c) Wd  over the window's landmarks,
