@@ -399,10 +399,12 @@ __global__ __launch_bounds__(LS, 4) void k_build_solve_sb(DevBatch d) {
         //         (3) downdate the parent's diagonal block and pose coupling (not for children of M here:
         //             both chains end in M, those two downdates are applied after the join).
         auto node_rows = [&](int i, bool has_par) {            // step (2), executed by one wavefront
-            const int nr = nhi(i, M, N) - nlo(i, M) + 1, nrows = (has_par ? 9 : 0) + 6 * nr;
+            // the right-hand side rides along as one more row: z_i^T = y_i^T L_i^-T (forward substitution)
+            const int nr = nhi(i, M, N) - nlo(i, M) + 1, nrows = (has_par ? 9 : 0) + 6 * nr + 1;
             const double *Li = Dss + i * 81;
             for (int rho = lane; rho < nrows; rho += 64) {
-                double *ptr = (has_par && rho < 9) ? Css + i * 81 + rho * 9 : Ysb + yo[i] + (rho - (has_par ? 9 : 0)) * 9;
+                double *ptr = (has_par && rho < 9) ? Css + i * 81 + rho * 9
+                            : (rho == nrows - 1 ? y + 15 * i + 6 : Ysb + yo[i] + (rho - (has_par ? 9 : 0)) * 9);
                 double v[9], o[9];
 #pragma unroll
                 for (int k = 0; k < 9; k++) v[k] = ptr[k];
@@ -422,8 +424,14 @@ __global__ __launch_bounds__(LS, 4) void k_build_solve_sb(DevBatch d) {
             const int pp = npar(i, M), lo = nlo(i, M), nr = nhi(i, M, N) - lo + 1;
             const double *C = Css + i * 81, *Yi = Ysb + yo[i];
             double *Yp = Ysb + yo[pp] + (lo - nlo(pp, M)) * 54;
-            for (int e = lid; e < 45 + 54 * nr; e += nl) {
-                if (e < 45) {
+            for (int e = lid; e < 45 + 54 * nr + 9; e += nl) {
+                if (e >= 45 + 54 * nr) {                      // right-hand side of the parent: y_p -= C_i z_i
+                    const int r = e - 45 - 54 * nr;
+                    double s = 0;
+#pragma unroll
+                    for (int k = 0; k < 9; k++) s += C[r * 9 + k] * y[15 * i + 6 + k];
+                    y[15 * pp + 6 + r] -= s;
+                } else if (e < 45) {
                     int r = 0; while ((r + 1) * (r + 2) / 2 <= e) r++;
                     const int c = e - r * (r + 1) / 2;
                     double s = 0;
@@ -478,6 +486,19 @@ __global__ __launch_bounds__(LS, 4) void k_build_solve_sb(DevBatch d) {
                 }
                 Spp[e] -= s;
             }
+            if (t >= LS - n6) {                                 // pose right-hand side -= sum_i Y_i z_i
+                const int rho = t - (LS - n6), a = rho / 6, r = rho - 6 * a;
+                double s = 0;
+                for (int i = 0; i < N; i++) {
+                    const int lo = nlo(i, M);
+                    if (a >= lo && a <= nhi(i, M, N)) {
+                        const double *Yr = Ysb + yo[i] + (a - lo) * 54 + r * 9, *zi = y + 15 * i + 6;
+#pragma unroll
+                        for (int kk = 0; kk < 9; kk++) s += Yr[kk] * zi[kk];
+                    }
+                }
+                y[15 * a + r] -= s;
+            }
             __syncthreads();
             STAMP(5);
             // ---- blocked Cholesky of the pose system (6x6 blocks; diagonal blocks hold L_JJ^-1 afterwards)
@@ -486,10 +507,9 @@ __global__ __launch_bounds__(LS, 4) void k_build_solve_sb(DevBatch d) {
                 __syncthreads();
                 if (flag[0]) break;
                 const int m = N - J - 1;
-                if (m == 0) break;
                 const double *Li = Spp + sblk(J, J, N);
-                for (int rr = t; rr < m * 6; rr += LS) {        // panel rows: X = A L_JJ^-T
-                    double *A = Spp + sblk(J + 1, J, N) + rr * 6;   // blocks (J+1.., J) are contiguous
+                for (int rr = t; rr < m * 6 + 1; rr += LS) {    // panel rows: X = A L_JJ^-T; last row = rhs (z_J)
+                    double *A = rr < m * 6 ? Spp + sblk(J + 1, J, N) + rr * 6 : y + 15 * J;   // blocks (J+1.., J) are contiguous
                     double v[6], o[6];
 #pragma unroll
                     for (int k = 0; k < 6; k++) v[k] = A[k];
@@ -504,10 +524,20 @@ __global__ __launch_bounds__(LS, 4) void k_build_solve_sb(DevBatch d) {
                     for (int k = 0; k < 6; k++) A[k] = o[k];
                 }
                 __syncthreads();
+                if (m == 0) break;
                 // trailing update: S[I,K] -= X_I X_K^T for I >= K > J (packed columns J+1.. are contiguous)
                 const int e0 = sblk(J + 1, J + 1, N), cntT = m * (m + 1) / 2 * 36;
                 const double *X = Spp + sblk(J + 1, J, N);       // X_I at (I - J - 1) * 36
-                for (int e = t; e < cntT; e += LS) {
+                for (int e = t; e < cntT + m * 6; e += LS) {
+                    if (e >= cntT) {                             // rhs rows: y_I -= X_I z_J
+                        const int rr = e - cntT;
+                        const double *XI = X + rr * 6;
+                        double s = 0;
+#pragma unroll
+                        for (int k = 0; k < 6; k++) s += XI[k] * y[15 * J + k];
+                        y[15 * (J + 1 + rr / 6) + rr % 6] -= s;
+                        continue;
+                    }
                     const int q = e / 36, rc = e - 36 * q, r = rc / 6, c = rc - 6 * r;
                     int ca = 0;                                  // column within the trailing triangle
                     while (ca + 1 < m && (ca + 1) * m - (ca + 1) * ca / 2 <= q) ca++;
@@ -531,114 +561,16 @@ __global__ __launch_bounds__(LS, 4) void k_build_solve_sb(DevBatch d) {
             __syncthreads();
             continue;
         }
-        // ---- triangular solves: one wavefront, the right-hand side lives in REGISTERS ------------------
-        // speed/bias rows: register ys0 holds the nodes 0..M (lane = 9 node + c), ys1 the nodes M+1..N-1
-        // (lane = 9 (node - M - 1) + c); pose rows: yp0 holds frames 0..9 (lane = 6 frame + r), yp1 frames
-        // 10.. .  A node / frame never straddles registers, pivot vectors travel by v_readlane, every lane
-        // forms its own row's dot product: the 4N dependent steps need no LDS round trip and no barrier.
-        // z / x cross LDS only for the two pose <-> chain gathers.
-        const int nlev = M > N - 1 - M ? M : N - 1 - M;
+        // ---- backward substitution (the forward one rode along with the factorisation) ---------------
+        // pose block: one wavefront, right-hand side in REGISTERS: yp0 holds frames 0..9 (lane = 6 frame
+        // + r), yp1 frames 10.. ; pivot vectors travel by v_readlane, every lane forms its own row's dot
+        // product: the N dependent steps need no LDS round trip and no barrier.
         if (wv == 0) {
-            const int q9 = lane / 9, c9 = lane - 9 * q9, q6 = lane / 6, c6 = lane - 6 * q6;
-            const int sA = q9, sB = M + 1 + q9;                 // my speed/bias node in ys0 / ys1
-            const bool hasA = sA <= M, hasB = sB <= N - 1;
+            const int q6 = lane / 6, c6 = lane - 6 * q6;
             const int fA = q6, fB = 10 + q6;                    // my frame in yp0 / yp1
             const bool hasPA = q6 < 10 && fA < N, hasPB = q6 < 10 && fB < N;
-            double ys0 = hasA ? y[15 * sA + 6 + c9] : 0.0, ys1 = hasB ? y[15 * sB + 6 + c9] : 0.0;
             double yp0 = hasPA ? y[15 * fA + c6] : 0.0, yp1 = hasPB ? y[15 * fB + c6] : 0.0;
-            auto sb_base = [&](int i) { return i > M ? 9 * (i - M - 1) : 9 * i; };
-            // forward step of chain node i (register yn), parent in register ypr
-            auto node_fwd = [&](int i, double &yn, double &ypr, int pp) {
-                const int b = sb_base(i);
-                double v[9];
-#pragma unroll
-                for (int k = 0; k < 9; k++) v[k] = readlane_d2(yn, b + k);
-                const double *Lr = Dss + i * 81 + c9 * 9;       // row c9 of L_i^-1 (upper part is zero)
-                double z = 0;
-#pragma unroll
-                for (int k = 0; k < 9; k++) z += Lr[k] * v[k];
-                if (9 * q9 == b && q9 < 7) yn = z;
-                if (pp >= 0) {
-#pragma unroll
-                    for (int k = 0; k < 9; k++) v[k] = readlane_d2(yn, b + k);
-                    const double *Cr = Css + i * 81 + c9 * 9;   // row c9 of C_i (rows = parent)
-                    double s = 0;
-#pragma unroll
-                    for (int k = 0; k < 9; k++) s += Cr[k] * v[k];
-                    if (9 * q9 == sb_base(pp) && q9 < 7) ypr -= s;
-                }
-            };
-            // backward step: x_i = L_i^-T (z_i - C_i^T x_parent)
-            auto node_bwd = [&](int i, double &yn, double &ypr, int pp) {
-                const int b = sb_base(i);
-                double v[9];
-                const bool mine = 9 * q9 == b && q9 < 7;
-                if (pp >= 0) {
-                    const int bp = sb_base(pp);
-#pragma unroll
-                    for (int k = 0; k < 9; k++) v[k] = readlane_d2(ypr, bp + k);
-                    const double *Cc = Css + i * 81 + c9;       // column c9 of C_i
-                    double s = 0;
-#pragma unroll
-                    for (int k = 0; k < 9; k++) s += Cc[k * 9] * v[k];
-                    if (mine) yn -= s;
-                }
-#pragma unroll
-                for (int k = 0; k < 9; k++) v[k] = readlane_d2(yn, b + k);
-                const double *Lc = Dss + i * 81 + c9;           // column c9 of L_i^-1
-                double x = 0;
-#pragma unroll
-                for (int k = 0; k < 9; k++) x += Lc[k * 9] * v[k];
-                if (mine) yn = x;
-            };
-            for (int k = 0; k < nlev; k++) {                    // forward, chains in elimination order
-                if (k < M) node_fwd(k, ys0, ys0, k + 1);
-                const int ib = N - 1 - k;
-                if (ib > M) { if (ib - 1 == M) node_fwd(ib, ys1, ys0, M); else node_fwd(ib, ys1, ys1, ib - 1); }
-            }
-            node_fwd(M, ys0, ys0, -1);
-            if (hasA) y[15 * sA + 6 + c9] = ys0;
-            if (hasB) y[15 * sB + 6 + c9] = ys1;
-            WSYNC();
-            // pose rhs -= sum_i Y_i z_i
-            auto pose_gather = [&](int a, int r) {
-                double s = 0;
-                for (int i = 0; i < N; i++) {
-                    const int lo = nlo(i, M);
-                    if (a >= lo && a <= nhi(i, M, N)) {
-                        const double *Yr = Ysb + yo[i] + (a - lo) * 54 + r * 9, *zi = y + 15 * i + 6;
-#pragma unroll
-                        for (int kk = 0; kk < 9; kk++) s += Yr[kk] * zi[kk];
-                    }
-                }
-                return s;
-            };
-            if (hasPA) yp0 -= pose_gather(fA, c6);
-            if (N > 10 && hasPB) yp1 -= pose_gather(fB, c6);
-            for (int J = 0; J < N; J++) {                       // forward, pose block
-                const int b = 6 * (J % 10);
-                double v[6];
-#pragma unroll
-                for (int k = 0; k < 6; k++) v[k] = J < 10 ? readlane_d2(yp0, b + k) : readlane_d2(yp1, b + k);
-                const double *Lr = Spp + sblk(J, J, N) + c6 * 6;
-                double z = 0;
-#pragma unroll
-                for (int k = 0; k < 6; k++) z += Lr[k] * v[k];
-                if (J < 10) { if (hasPA && fA == J) yp0 = z; } else { if (hasPB && fB == J) yp1 = z; }
-#pragma unroll
-                for (int k = 0; k < 6; k++) v[k] = J < 10 ? readlane_d2(yp0, b + k) : readlane_d2(yp1, b + k);
-                if (hasPA && fA > J) {
-                    const double *Lb = Spp + sblk(fA, J, N) + c6 * 6;
-#pragma unroll
-                    for (int k = 0; k < 6; k++) yp0 -= Lb[k] * v[k];
-                }
-                if (N > 10 && hasPB && fB > J) {
-                    const double *Lb = Spp + sblk(fB, J, N) + c6 * 6;
-#pragma unroll
-                    for (int k = 0; k < 6; k++) yp1 -= Lb[k] * v[k];
-                }
-            }
-            for (int J = N - 1; J >= 0; J--) {                  // backward, pose block (right-looking)
+            for (int J = N - 1; J >= 0; J--) {                  // right-looking
                 const int b = 6 * (J % 10);
                 double v[6];
 #pragma unroll
@@ -663,29 +595,92 @@ __global__ __launch_bounds__(LS, 4) void k_build_solve_sb(DevBatch d) {
             }
             if (hasPA) y[15 * fA + c6] = yp0;
             if (hasPB) y[15 * fB + c6] = yp1;
-            WSYNC();
-            // chain rhs -= Y_i^T x_pose
-            auto chain_gather = [&](int i, int c) {
-                const int lo = nlo(i, M), nr = nhi(i, M, N) - lo + 1;
-                const double *Yc = Ysb + yo[i] + c;
-                double s = 0;
-                for (int a = 0; a < nr; a++) {
-                    const double *xa = y + 15 * (lo + a);
+        }
+        __syncthreads();
+        // chain rhs -= Y_i^T x_pose: thread = (speed/bias row, quarter of the pose blocks), folded in fixed order
+        if (t < 36 * N) {
+            const int o = t >> 2, part = t & 3, i = o / 9, c = o - 9 * i, lo = nlo(i, M), nr = nhi(i, M, N) - lo + 1;
+            const double *Yc = Ysb + yo[i] + c;
+            double s = 0;
+            for (int a = part; a < nr; a += 4) {
+                const double *xa = y + 15 * (lo + a);
 #pragma unroll
-                    for (int r = 0; r < 6; r++) s += Yc[(a * 6 + r) * 9] * xa[r];
-                }
-                return s;
-            };
-            if (hasA) ys0 -= chain_gather(sA, c9);
-            if (hasB) ys1 -= chain_gather(sB, c9);
-            node_bwd(M, ys0, ys0, -1);                          // backward, chains (reverse elimination order)
-            for (int k = nlev - 1; k >= 0; k--) {
-                if (k < M) node_bwd(k, ys0, ys0, k + 1);
-                const int ib = N - 1 - k;
-                if (ib > M) { if (ib - 1 == M) node_bwd(ib, ys1, ys0, M); else node_bwd(ib, ys1, ys1, ib - 1); }
+                for (int r = 0; r < 6; r++) s += Yc[(a * 6 + r) * 9] * xa[r];
             }
-            if (hasA) y[15 * sA + 6 + c9] = ys0;
-            if (hasB) y[15 * sB + 6 + c9] = ys1;
+            red[t] = s;
+        }
+        __syncthreads();
+        if (t < 9 * N) {
+            const int i = t / 9, c = t - 9 * i;
+            y[15 * i + 6 + c] -= (red[4 * t] + red[4 * t + 1]) + (red[4 * t + 2] + red[4 * t + 3]);
+        }
+        __syncthreads();
+        // chains, reverse elimination order: x_i = L_i^-T (z_i - C_i^T x_parent); wavefront 0 takes M and the
+        // forward chain (lane = 9 i + c), wavefront 1 the backward chain (lane = 9 (i - M - 1) + c)
+        if (wv < 2) {
+            const int q9 = lane / 9, c9 = lane - 9 * q9;
+            const int mynode = wv == 0 ? q9 : M + 1 + q9;
+            const bool has = q9 < 7 && (wv == 0 ? mynode <= M : mynode <= N - 1);
+            double ys = has ? y[15 * mynode + 6 + c9] : 0.0;
+            auto sb_base = [&](int i) { return i > M ? 9 * (i - M - 1) : 9 * i; };
+            auto node_bwd = [&](int i, int pp, bool par_in_lds) {
+                const int b = sb_base(i);
+                const bool mine = has && mynode == i;
+                double v[9];
+                if (pp >= 0) {
+#pragma unroll
+                    for (int k = 0; k < 9; k++) v[k] = par_in_lds ? y[15 * pp + 6 + k] : readlane_d2(ys, sb_base(pp) + k);
+                    const double *Cc = Css + i * 81 + c9;       // column c9 of C_i
+                    double s = 0;
+#pragma unroll
+                    for (int k = 0; k < 9; k++) s += Cc[k * 9] * v[k];
+                    if (mine) ys -= s;
+                }
+#pragma unroll
+                for (int k = 0; k < 9; k++) v[k] = readlane_d2(ys, b + k);
+                const double *Lc = Dss + i * 81 + c9;           // column c9 of L_i^-1
+                double x = 0;
+#pragma unroll
+                for (int k = 0; k < 9; k++) x += Lc[k * 9] * v[k];
+                if (mine) ys = x;
+            };
+            if (wv == 0) {
+                node_bwd(M, -1, false);
+                if (has && mynode == M) y[15 * M + 6 + c9] = ys;
+            }
+            // x_M crosses to wavefront 1 through LDS
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        }
+        __syncthreads();
+        if (wv < 2) {
+            // (re-declared: the block barrier above must be reached by every wavefront)
+            const int q9 = lane / 9, c9 = lane - 9 * q9;
+            const int mynode = wv == 0 ? q9 : M + 1 + q9;
+            const bool has = q9 < 7 && (wv == 0 ? mynode <= M : mynode <= N - 1);
+            double ys = has ? y[15 * mynode + 6 + c9] : 0.0;
+            auto sb_base = [&](int i) { return i > M ? 9 * (i - M - 1) : 9 * i; };
+            auto node_bwd = [&](int i, int pp, bool par_in_lds) {
+                const int b = sb_base(i);
+                const bool mine = has && mynode == i;
+                double v[9];
+#pragma unroll
+                for (int k = 0; k < 9; k++) v[k] = par_in_lds ? y[15 * pp + 6 + k] : readlane_d2(ys, sb_base(pp) + k);
+                const double *Cc = Css + i * 81 + c9;           // column c9 of C_i
+                double s = 0;
+#pragma unroll
+                for (int k = 0; k < 9; k++) s += Cc[k * 9] * v[k];
+                if (mine) ys -= s;
+#pragma unroll
+                for (int k = 0; k < 9; k++) v[k] = readlane_d2(ys, b + k);
+                const double *Lc = Dss + i * 81 + c9;           // column c9 of L_i^-1
+                double x = 0;
+#pragma unroll
+                for (int k = 0; k < 9; k++) x += Lc[k * 9] * v[k];
+                if (mine) ys = x;
+            };
+            if (wv == 0) { for (int i = M - 1; i >= 0; i--) node_bwd(i, i + 1, false); }
+            else { for (int i = M + 1; i <= N - 1; i++) node_bwd(i, i - 1, i - 1 == M); }
+            if (has) y[15 * mynode + 6 + c9] = ys;
         }
         __syncthreads();
         STAMP(7);
