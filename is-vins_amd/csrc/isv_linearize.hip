@@ -197,10 +197,10 @@ __global__ __launch_bounds__(256) void k_proj_linearize(DevBatch d, const double
             for (int c2 = 0; c2 < 6; c2++) lm_wh[c2] = Ji[c2] * Jl[0] + Ji[6 + c2] * Jl[1];
             lm_id = rec.lm;
             // w of the observing frame for the Schur sweep: J_pose_j^T J_lambda (6), obs slot f + lm + 1
-            double *wo = d.W + (size_t)(f + rec.lm + 1) * 6;
-            double *wd = d.Wd + (size_t)rec.lm * d.wd_ld + 6 * fj;      // dense copy for the MFMA panels
+            // (the dense panel row Wd[lm][6 * frame ..] serves the MFMA downdates AND the back-substitution)
+            double *wd = d.Wd + (size_t)rec.lm * d.wd_ld + 6 * fj;
 #pragma unroll
-            for (int c2 = 0; c2 < 6; c2++) { const double v = Jj[c2] * Jl[0] + Jj[6 + c2] * Jl[1]; wo[c2] = v; wd[c2] = v; }
+            for (int c2 = 0; c2 < 6; c2++) wd[c2] = Jj[c2] * Jl[0] + Jj[6 + c2] * Jl[1];
         }
     }
     if (MODE != 0) return;                            // uniform over the block
@@ -234,10 +234,9 @@ __global__ __launch_bounds__(256) void k_proj_linearize(DevBatch d, const double
             const double Dl = sqrt(Dl2);
             d.lm_cg[l] = make_double2(sl * sl / (Es + ss.mu * Dl2), lm_g);
             d.lmE[l] = lm_e; d.lmG[l] = lm_g; d.diag_l[l] = Dl; d.grad_l[l] = sl * lm_g / Dl;
-            double *wo = d.W + (size_t)(d.lm_f0[l] + l) * 6;                      // host observation slot
-            double *wd = d.Wd + (size_t)l * d.wd_ld + 6 * d.lm_host[l];
+            double *wd = d.Wd + (size_t)l * d.wd_ld + 6 * d.lm_host[l];            // host observation slot
 #pragma unroll
-            for (int c2 = 0; c2 < 6; c2++) { wo[c2] = lm_wh[c2]; wd[c2] = lm_wh[c2]; }
+            for (int c2 = 0; c2 < 6; c2++) wd[c2] = lm_wh[c2];
         }
     }
     // transpose through this wave's LDS buffer in two halves of 14 columns: lane l owns row l of

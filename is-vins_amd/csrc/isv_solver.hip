@@ -57,6 +57,7 @@ DEV double block_sum(double v, double *red, int t) {
 // One workgroup per running window.
 __global__ __launch_bounds__(256) void k_dogleg(DevBatch d) {
     __shared__ double red[256];
+    __shared__ double sdz[2 * ISV_MAX_FRAMES * 15];
     const int w = blockIdx.x, t = threadIdx.x;
     SolveState &st = d.st[w];
     if (st.termination != ISV_TERM_RUNNING) return;
@@ -70,6 +71,33 @@ __global__ __launch_bounds__(256) void k_dogleg(DevBatch d) {
     }
     double a = 0, b = 0, c = 0, e = 0;
     for (int i = t; i < n; i += 256) { a += gp[i] * gp[i]; b += gnp[i] * gnp[i]; c += gp[i] * gnp[i]; }
+    if (st.fresh) {
+        // back-substitution of the eliminated landmarks (schur_eliminator BackSubstitute) + the landmark
+        // terms of the Cauchy-point denominator, from the w vectors (one landmark per thread and pass)
+        double *zs = sdz, *us = sdz + ISV_MAX_FRAMES * 15;
+        for (int i = t; i < n; i += 256) { zs[i] = d.zp[(size_t)w * n + i]; us[i] = d.up[(size_t)w * n + i]; }
+        __syncthreads();
+        const double mu = st.mu;
+        for (int l = l0 + t; l < l1; l += 256) {
+            const int h = d.lm_host[l], k = d.lm_k[l];
+            const double *wv = d.Wd + (size_t)l * d.wd_ld + 6 * h;     // frames h .. h + k - 1 are contiguous
+            double wz = 0, wu = 0;        // w_l^T z_p, w_l^T u_p
+            for (int o = 0; o < k; o++) {
+                const double2 w01 = *reinterpret_cast<const double2 *>(wv + 6 * o), w23 = *reinterpret_cast<const double2 *>(wv + 6 * o + 2),
+                              w45 = *reinterpret_cast<const double2 *>(wv + 6 * o + 4);
+                const double *z = zs + 15 * (h + o), *u = us + 15 * (h + o);
+                wz += w01.x * z[0] + w01.y * z[1] + w23.x * z[2] + w23.y * z[3] + w45.x * z[4] + w45.y * z[5];
+                wu += w01.x * u[0] + w01.y * u[1] + w23.x * u[2] + w23.y * u[3] + w45.x * u[4] + w45.y * u[5];
+            }
+            const double sl = d.scale_l[l], E = d.lmE[l], gl = d.lmG[l], Dl = d.diag_l[l];
+            const double Es = sl * sl * E, Dl2 = Dl * Dl;
+            // scaled-space y_l = (g'_l - w'_l^T y_p) / (E'_l + mu D_l^2),  w'^T y_p = s_l w^T (Sc_p y_p) = s_l wz
+            const double yl = (sl * gl - sl * wz) / (Es + mu * Dl2);
+            d.gn_l[l] = -Dl * yl;
+            const double ul = sl * sl * gl / Dl2, cl = sl * sl / (Es + mu * Dl2);
+            d.lm_aterm[l] = cl * wu * wu + 2.0 * ul * wu + E * ul * ul;
+        }
+    }
     for (int l = l0 + t; l < l1; l += 256) {
         const double gl = d.grad_l[l], nl = d.gn_l[l];
         a += gl * gl; b += nl * nl; c += gl * nl; e += d.lm_aterm[l];
@@ -441,7 +469,6 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
         else hipLaunchKernelGGL(k_build_solve<false>, dim3(d.B), dim3(512), lds_bs, st, d);
         counts[1]++;
         PROF(slot, 2, 1);
-        if (d.Ltot) hipLaunchKernelGGL(k_backsub, dim3((d.Ltot + 255) / 256), dim3(256), 0, st, d);
         hipLaunchKernelGGL(k_dogleg, dim3(d.B), dim3(256), 0, st, d);
         HCHK(hipEventRecord(fj[2], st)); HCHK(hipStreamWaitEvent(st2, fj[2], 0));
         if (NI) hipLaunchKernelGGL(k_imu_linearize<false>, dim3((unsigned)NI), dim3(64), 0, st2, d, d.cpose, d.csb, d.imu_cost_c, 2);

@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void k_backsub(DevBatch d) {
     if (st.termination != ISV_TERM_RUNNING || !st.fresh || st.ls_fail) return;
     const int n = d.np, h = d.lm_host[l], k = d.lm_k[l], f0 = d.lm_f0[l];
     const double *zp = d.zp + (size_t)w * n, *up = d.up + (size_t)w * n;
-    const double *wv = d.W + (size_t)(f0 + l) * 6;
+    const double *wv = d.Wd + (size_t)l * d.wd_ld + 6 * h;     // the landmark's w vectors: frames h .. h + k - 1 are contiguous
     double wz = 0, wu = 0;        // w_l^T z_p, w_l^T u_p
     for (int o = 0; o < k; o++) {
         const double2 w01 = *reinterpret_cast<const double2 *>(wv + 6 * o), w23 = *reinterpret_cast<const double2 *>(wv + 6 * o + 2),
