@@ -120,6 +120,14 @@ __global__ __launch_bounds__(LS, 4) void k_build_solve_sb(DevBatch d) {
     if (t < N - 1) skipL[t] = d.imu_skip[(size_t)w * (N - 1) + t];
     __syncthreads();
     const int ytot = yo[N];
+    // cost of the window at x = sum over its residual blocks (fixed-shape strided partials + tree below)
+    double cpart = 0;
+    {
+        const int f0w = d.f_off[w], f1w = d.f_off[w + 1];
+        for (int f = f0w + t; f < f1w; f += LS) cpart += d.fcost[f];
+        for (int i = t; i < N - 1; i += LS) cpart += d.imu_cost[(size_t)w * (N - 1) + i];
+        for (int i = t; i < d.n_prior_slots; i += LS) cpart += d.prior_cost[(size_t)w * d.n_prior_slots + i];
+    }
 #ifdef ISV_STAMP
     unsigned long long t_last = wall_clock64();
 #endif
@@ -692,6 +700,7 @@ __global__ __launch_bounds__(LS, 4) void k_build_solve_sb(DevBatch d) {
             d.gn_p[(size_t)w * n + e] = -D[e] * y[e];
         }
     }
+    double cost_w = 0.0;
     {
         double m = gmax_l;
         for (int i = t; i < N; i += LS) {
@@ -703,9 +712,15 @@ __global__ __launch_bounds__(LS, 4) void k_build_solve_sb(DevBatch d) {
             for (int k = 0; k < 9; k++) m = fmax(m, fabs(g[15 * i + 6 + k]));
         }
         __syncthreads();
+        red[t] = cpart;
+        __syncthreads();
+        for (int off = LS / 2; off > 0; off >>= 1) { if (t < off) red[t] += red[t + off]; __syncthreads(); }
+        cost_w = red[0];
+        __syncthreads();
         red[t] = m;
         __syncthreads();
         for (int off = LS / 2; off > 0; off >>= 1) { if (t < off) red[t] = fmax(red[t], red[t + off]); __syncthreads(); }
+        if (t == 0) d.cost[w] = cost_w;
     }
     if (t == 0) {
         st.gmax = red[0];
@@ -713,10 +728,10 @@ __global__ __launch_bounds__(LS, 4) void k_build_solve_sb(DevBatch d) {
         st.ls_fail = ls_fail;
         st.need_linearize = 0;
         st.fresh = 1;
-        st.x_cost = d.cost[w];
+        st.x_cost = cost_w;
         if (iteration == 0) {
-            st.initial_cost = d.cost[w];
-            d.trace_cost[(size_t)w * ISV_MAX_TRACE] = d.cost[w];
+            st.initial_cost = cost_w;
+            d.trace_cost[(size_t)w * ISV_MAX_TRACE] = cost_w;
             d.trace_radius[(size_t)w * ISV_MAX_TRACE] = st.radius;
         }
         if (st.gmax <= 1e-10) st.termination = ISV_TERM_GRADIENT_TOL;

@@ -275,11 +275,12 @@ template __global__ void k_proj_linearize<1>(DevBatch, const double *, const dou
 // IMU factor: one wavefront per factor.  raw residual (15) and raw Jacobian (15 x 30) are built by
 // a few lanes in LDS, then every lane forms rows of sqrt_info * [r | J] (15-term dot products).
 // JAC=false: residual only (candidate point), cost into cost_out.
+#define IMU_LDS_DOUBLES (225 + 15 * 31 + 16 + 15 * 31 + 2)
 template <bool JAC>
-__global__ __launch_bounds__(64) void k_imu_linearize(DevBatch d, const double *pose_src, const double *sb_src,
-                                                       double *cost_out, int gate) {
-    __shared__ double sS[225], sRaw[15 * 31], sRes[16], sJw[JAC ? 15 * 31 : 1];
-    const int f = blockIdx.x, t = threadIdx.x;
+DEV void imu_linearize_body(const DevBatch &d, const double *pose_src, const double *sb_src, double *cost_out, int gate,
+                            int f, double *lds) {
+    double *sS = lds, *sRaw = sS + 226, *sRes = sRaw + 15 * 31 + 1, *sJw = sRes + 16;    // 225 | 465 | 16 | 465
+    const int t = threadIdx.x;
     const int N = d.N, w = f / (N - 1), i = f % (N - 1);
     if (gate) {
         const SolveState &ss = d.st[w];
@@ -414,8 +415,197 @@ __global__ __launch_bounds__(64) void k_imu_linearize(DevBatch d, const double *
         cost_out[f] = 0.5 * s;                          // no loss function on IMU factors (:1050)
     }
 }
+template <bool JAC>
+__global__ __launch_bounds__(64) void k_imu_linearize(DevBatch d, const double *pose_src, const double *sb_src,
+                                                       double *cost_out, int gate) {
+    __shared__ __align__(16) double lds[IMU_LDS_DOUBLES];
+    imu_linearize_body<JAC>(d, pose_src, sb_src, cost_out, gate, blockIdx.x, lds);
+}
 template __global__ void k_imu_linearize<true>(DevBatch, const double *, const double *, double *, int);
 template __global__ void k_imu_linearize<false>(DevBatch, const double *, const double *, double *, int);
+
+
+// ------------------------------------------------------------------------------------------
+// IMU factors at x with Jacobians (solver schedule), two kernels:
+//   k_imu_raw     raw residual (15) and raw Jacobian blocks (15 x 30) of 64 factors per workgroup; wavefront p
+//                 computes part p (0 residual, 1 d/d pose_i, 2 d/d speedbias_i, 3 d/d pose_j, speedbias_j)
+//                 with one FACTOR PER LANE, so no wavefront diverges over the four bodies; output is the
+//                 dense [15][32] matrix [J | r | 0] per factor in HBM (zero pattern static, set at create).
+//   k_imu_weight  one wavefront per factor, FP64 MFMA (v_mfma_f64_16x16x4): Jw = sqrt_info * [J | r]
+//                 (2 tiles x 4 k-steps), then H = Jw^T Jw (3 lower tiles x 4 k-steps) whose row 30 is J^T r;
+//                 strips, packed J^T J and cost leave through LDS as coalesced stores.
+__global__ __launch_bounds__(256) void k_imu_raw(DevBatch d, const double *pose_src, const double *sb_src, int gate) {
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int N = d.N, NI = d.B * (N - 1);
+    const int f = blockIdx.x * 64 + lane;
+    if (f >= NI) return;
+    const int w = f / (N - 1), i = f - w * (N - 1);
+    if (gate) {
+        const SolveState &ss = d.st[w];
+        if (!(ss.termination == ISV_TERM_RUNNING && (gate == 1 ? ss.need_linearize != 0 : ss.step_valid != 0))) return;
+    }
+    if (d.imu_skip[f]) return;
+    const double *rec = d.imu_in + (size_t)f * ISV_IMU_IN;
+    const double *pi = pose_src + ((size_t)w * N + i) * 7, *pj = pi + 7;
+    const double *si = sb_src + ((size_t)w * N + i) * 9, *sj = si + 9;
+    double *raw = d.imu_raw + (size_t)f * 480;
+#define RAW(r, c) raw[(r) * 32 + (c)]
+    Quat Qi = q_from_pose(pi), Qj = q_from_pose(pj);
+    Quat Qii = q_inv(Qi);
+    const double dt = rec[IMU_DT];
+    double dbg[3], tt[3], t2[3];
+    for (int k = 0; k < 3; k++) dbg[k] = si[6 + k] - rec[IMU_LBG + k];
+    Quat dq = Quat{rec[IMU_DQ + 3], rec[IMU_DQ], rec[IMU_DQ + 1], rec[IMU_DQ + 2]};
+    m3v(rec + IMU_DQ_DBG, dbg, tt);
+    Quat cdq = q_mul(dq, q_delta(tt));
+    if (part == 0) {
+        // residual: IntegrationBase::evaluate  integration_base.h:160-186
+        double dba[3], cdv[3], cdp[3], u[3], o1[3], o2[3];
+        for (int k = 0; k < 3; k++) dba[k] = si[3 + k] - rec[IMU_LBA + k];
+        m3v(rec + IMU_DV_DBA, dba, tt); m3v(rec + IMU_DV_DBG, dbg, t2);
+        for (int k = 0; k < 3; k++) cdv[k] = rec[IMU_DV + k] + tt[k] + t2[k];
+        m3v(rec + IMU_DP_DBA, dba, tt); m3v(rec + IMU_DP_DBG, dbg, t2);
+        for (int k = 0; k < 3; k++) cdp[k] = rec[IMU_DP + k] + tt[k] + t2[k];
+        for (int k = 0; k < 3; k++) u[k] = 0.5 * d.G[k] * dt * dt + pj[k] - pi[k] - si[k] * dt;
+        q_rot(Qii, u, o1);
+        for (int k = 0; k < 3; k++) RAW(k, 30) = o1[k] - cdp[k];
+        Quat e = q_mul(q_inv(cdq), q_mul(Qii, Qj));
+        RAW(3, 30) = 2 * e.x; RAW(4, 30) = 2 * e.y; RAW(5, 30) = 2 * e.z;
+        for (int k = 0; k < 3; k++) u[k] = d.G[k] * dt + sj[k] - si[k];
+        q_rot(Qii, u, o2);
+        for (int k = 0; k < 3; k++) RAW(6 + k, 30) = o2[k] - cdv[k];
+        for (int k = 0; k < 3; k++) { RAW(9 + k, 30) = sj[3 + k] - si[3 + k]; RAW(12 + k, 30) = sj[6 + k] - si[6 + k]; }
+    } else if (part == 1) {
+        // raw Jacobian (imu_factor.h:66-155), tangent columns: pose_i 0..5, sb_i 6..14, pose_j 15..20, sb_j 21..29
+        double RiT[9], u[3], o1[3], o2[3], S1[9], S2[9], B1[9], L[9], Rr[9];
+        q_to_R(Qii, RiT);
+        for (int k = 0; k < 3; k++) u[k] = 0.5 * d.G[k] * dt * dt + pj[k] - pi[k] - si[k] * dt;
+        q_rot(Qii, u, o1);
+        for (int k = 0; k < 3; k++) u[k] = d.G[k] * dt + sj[k] - si[k];
+        q_rot(Qii, u, o2);
+        skew3(o1, S1); skew3(o2, S2);
+        Quat aq = q_mul(q_inv(Qj), Qi);
+        qleft33(aq, L); qright33(cdq, Rr); m3_mul(L, Rr, B1);
+        const double av[3] = {aq.x, aq.y, aq.z}, bv[3] = {cdq.x, cdq.y, cdq.z};
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) B1[r * 3 + c] += av[r] * (-bv[c]);
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) {
+                const int ab = a * 3 + b;
+                RAW(0 + a, 0 + b) = -RiT[ab];
+                RAW(0 + a, 3 + b) = S1[ab];
+                RAW(3 + a, 3 + b) = -B1[ab];
+                RAW(6 + a, 3 + b) = S2[ab];
+            }
+    } else if (part == 2) {
+        double RiT[9], L[9], T[9];
+        q_to_R(Qii, RiT);
+        qleft33(q_mul(q_mul(q_inv(Qj), Qi), dq), L);
+        m3_mul(L, rec + IMU_DQ_DBG, T);
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) {
+                const int ab = a * 3 + b;
+                RAW(0 + a, 6 + b) = -RiT[ab] * dt;
+                RAW(0 + a, 9 + b) = -rec[IMU_DP_DBA + ab];
+                RAW(0 + a, 12 + b) = -rec[IMU_DP_DBG + ab];
+                RAW(3 + a, 12 + b) = -T[ab];
+                RAW(6 + a, 6 + b) = -RiT[ab];
+                RAW(6 + a, 9 + b) = -rec[IMU_DV_DBA + ab];
+                RAW(6 + a, 12 + b) = -rec[IMU_DV_DBG + ab];
+                RAW(9 + a, 9 + b) = (a == b) ? -1.0 : 0.0;
+                RAW(12 + a, 12 + b) = (a == b) ? -1.0 : 0.0;
+            }
+    } else {
+        double RiT[9], B2[9];
+        q_to_R(Qii, RiT);
+        qleft33(q_mul(q_mul(q_inv(cdq), Qii), Qj), B2);
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) {
+                const int ab = a * 3 + b;
+                RAW(0 + a, 15 + b) = RiT[ab];
+                RAW(3 + a, 18 + b) = B2[ab];
+                RAW(6 + a, 21 + b) = RiT[ab];
+                RAW(9 + a, 24 + b) = (a == b) ? 1.0 : 0.0;
+                RAW(12 + a, 27 + b) = (a == b) ? 1.0 : 0.0;
+            }
+    }
+#undef RAW
+}
+
+typedef double double4i __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(64) void k_imu_weight(DevBatch d, double *cost_out, int gate) {
+    __shared__ __align__(16) double sS[16 * 17], sRaw[16 * 32], sJw[16 * 32], sH[ISV_IMU_H + 1];
+    const int f = blockIdx.x, t = threadIdx.x;
+    const int N = d.N, w = f / (N - 1);
+    if (gate) {
+        const SolveState &ss = d.st[w];
+        if (!(ss.termination == ISV_TERM_RUNNING && (gate == 1 ? ss.need_linearize != 0 : ss.step_valid != 0))) return;
+    }
+    if (d.imu_skip[f]) { if (t == 0) cost_out[f] = 0.0; return; }
+    const double *Sg = d.imu_sqrt + (size_t)f * 225, *Rg = d.imu_raw + (size_t)f * 480;
+    for (int e = t; e < 16 * 17; e += 64) { const int r = e / 17, c = e - 17 * r; sS[e] = (r < 15 && c < 15) ? Sg[r * 15 + c] : 0.0; }
+    for (int e = t; e < 512; e += 64) sRaw[e] = e < 480 ? Rg[e] : 0.0;
+    __syncthreads();
+    const int i = t & 15, kq = t >> 4;
+    double4i a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; s4++) {                        // Jw = S * raw: output tiles cols 0..15 and 16..31
+        const int k = 4 * s4 + kq;
+        const double av = sS[i * 17 + k], b0 = sRaw[k * 32 + i], b1 = sRaw[k * 32 + 16 + i];
+        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b0, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b1, a1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) {                     // C/D layout: col = lane & 15, row = (lane >> 4) + 4 reg
+        const int row = kq + 4 * reg;
+        sJw[row * 32 + i] = a0[reg]; sJw[row * 32 + 16 + i] = a1[reg];
+    }
+    __syncthreads();
+    double4i h00 = {0, 0, 0, 0}, h10 = {0, 0, 0, 0}, h11 = {0, 0, 0, 0};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; s4++) {                        // H = Jw^T Jw, lower tiles
+        const int k = 4 * s4 + kq;
+        const double x0 = sJw[k * 32 + i], x1 = sJw[k * 32 + 16 + i];
+        h00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, h00, 0, 0, 0);
+        h10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x0, h10, 0, 0, 0);
+        h11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, h11, 0, 0, 0);
+    }
+    // packed J^T J (pairs a >= b at a(a+1)/2 + b, a, b < 30) then J^T r (row 30 of H)
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) {
+        const int row = kq + 4 * reg;
+        { const int a = row, b = i; if (b <= a) sH[a * (a + 1) / 2 + b] = h00[reg]; }
+        { const int a = 16 + row, b = i; if (a < 30) sH[a * (a + 1) / 2 + b] = h10[reg]; else if (a == 30) sH[465 + b] = h10[reg]; }
+        { const int a = 16 + row, b = 16 + i; if (a < 30) { if (b <= a) sH[a * (a + 1) / 2 + b] = h11[reg]; } else if (a == 30 && b < 30) sH[465 + b] = h11[reg]; }
+    }
+    __syncthreads();
+    double *H = d.imu_H + (size_t)f * ISV_IMU_H;
+    for (int e = t; e < ISV_IMU_H; e += 64) H[e] = sH[e];
+    // strip layout: [r15 | 15x6 | 15x9 | 15x6 | 15x9] row-major blocks
+    double *out = d.imu_strip + (size_t)f * ISV_IMU_STRIP;
+    if (t < 15) out[t] = sJw[t * 32 + 30];
+    for (int e = t; e < 450; e += 64) {
+        int row, c;
+        if (e < 90) { row = e / 6; c = e - 6 * row; }
+        else if (e < 225) { const int q = e - 90; row = q / 9; c = 6 + (q - 9 * row); }
+        else if (e < 315) { const int q = e - 225; row = q / 6; c = 15 + (q - 6 * row); }
+        else { const int q = e - 315; row = q / 9; c = 21 + (q - 9 * row); }
+        out[15 + e] = sJw[row * 32 + c];
+    }
+    if (t == 0) {
+        double s = 0;
+        for (int k = 0; k < 15; k++) s += sJw[k * 32 + 30] * sJw[k * 32 + 30];
+        cost_out[f] = 0.5 * s;                              // no loss function on IMU factors (:1050)
+    }
+}
 
 // ------------------------------------------------------------------------------------------
 // Prior factors: one wavefront per window.  Slot 0 = SE3 prior, 1 = Linear9, 2..Nvo = relative pose, then
@@ -511,9 +701,8 @@ DEV void prior_H(const double *wr, double *H, int t) {
 }
 
 template <bool JAC>
-__global__ __launch_bounds__(64) void k_prior_linearize(DevBatch d, const double *pose_src, const double *sb_src, double *cost_out, int gate) {
-    extern __shared__ __align__(16) double lds[];
-    const int w = blockIdx.x, t = threadIdx.x;
+DEV void prior_linearize_body(const DevBatch &d, const double *pose_src, const double *sb_src, double *cost_out, int gate, int w, double *lds) {
+    const int t = threadIdx.x;
     const int slots = d.n_prior_slots, N = d.N;
     if (gate) {
         const SolveState &ss = d.st[w];
@@ -658,8 +847,72 @@ __global__ __launch_bounds__(64) void k_prior_linearize(DevBatch d, const double
         else prior_H<2, 1, 6>(wr, PH + p.H_off, t);
     }
 }
+template <bool JAC>
+__global__ __launch_bounds__(64) void k_prior_linearize(DevBatch d, const double *pose_src, const double *sb_src, double *cost_out, int gate) {
+    extern __shared__ __align__(16) double lds[];
+    prior_linearize_body<JAC>(d, pose_src, sb_src, cost_out, gate, blockIdx.x, lds);
+}
 template __global__ void k_prior_linearize<true>(DevBatch, const double *, const double *, double *, int);
 template __global__ void k_prior_linearize<false>(DevBatch, const double *, const double *, double *, int);
+
+// ------------------------------------------------------------------------------------------
+// model cost change pieces: (J delta)^T (r + J delta / 2) per residual block, from the strips at x
+// (the reprojection factors' part is fused into k_proj_linearize<1>)
+DEV void model_imu_prior_body(const DevBatch &d, int bid, double *sm) {
+    const int w = bid / (d.N - 1 + 1), q = bid % (d.N - 1 + 1), t = threadIdx.x;
+    const SolveState &st = d.st[w];
+    if (st.termination != ISV_TERM_RUNNING || !st.step_valid) return;
+    const double *dp = d.delta_p + (size_t)w * d.np;
+    if (q < d.N - 1) {
+        const size_t f = (size_t)w * (d.N - 1) + q;
+        if (d.imu_skip[f]) { if (t == 0) d.imu_model[f] = 0.0; return; }
+        const double *s = d.imu_strip + f * ISV_IMU_STRIP;
+        if (t < 15) {
+            double m = 0;
+            const double *dd = dp + 15 * q;            // 30 contiguous tangent entries
+            for (int c = 0; c < 6; c++) m += s[15 + t * 6 + c] * dd[c];
+            for (int c = 0; c < 9; c++) m += s[105 + t * 9 + c] * dd[6 + c];
+            for (int c = 0; c < 6; c++) m += s[240 + t * 6 + c] * dd[15 + c];
+            for (int c = 0; c < 9; c++) m += s[330 + t * 9 + c] * dd[21 + c];
+            sm[t] = m * (s[t] + m / 2.0);
+        }
+        __syncthreads();
+        if (t == 0) { double a = 0; for (int k = 0; k < 15; k++) a += sm[k]; d.imu_model[f] = a; }
+    } else {
+        // priors of this window: lane per slot
+        const int slots = d.n_prior_slots;
+        if (t < slots) {
+            const double *ps = d.prior_strip + (size_t)w * d.prior_strip_sz;
+            double acc = 0;
+            if (t == 0) {
+                for (int r = 0; r < 6; r++) { double m = 0; for (int c = 0; c < 6; c++) m += ps[PR_SE3 + 6 + r * 6 + c] * dp[c]; acc += m * (ps[PR_SE3 + r] + m / 2.0); }
+            } else if (t == 1) {
+                const double *dd = dp + 15 * (d.Nvo - 1) + 6;
+                for (int r = 0; r < 9; r++) { double m = 0; for (int c = 0; c < 9; c++) m += ps[PR_LIN9 + 9 + r * 9 + c] * dd[c]; acc += m * (ps[PR_LIN9 + r] + m / 2.0); }
+            } else if (t < 1 + d.Nvo) {
+                const int k = t - 2; const double *o = ps + PR_REL0 + PR_REL_SZ * k;
+                for (int r = 0; r < 6; r++) {
+                    double m = 0;
+                    for (int c = 0; c < 6; c++) m += o[6 + r * 6 + c] * dp[15 * k + c] + o[42 + r * 6 + c] * dp[15 * (k + 1) + c];
+                    acc += m * (o[r] + m / 2.0);
+                }
+            } else {
+                const int mm = t - 1 - d.Nvo;
+                if (mm < d.n_rp[w]) {
+                    const double *o = ps + PR_REL0 + PR_REL_SZ * (d.Nvo - 1) + PR_RP_SZ * mm;
+                    const int idx = d.rollpitch[(size_t)w * d.max_rp + mm].index;
+                    for (int r = 0; r < 2; r++) { double m = 0; for (int c = 0; c < 6; c++) m += o[2 + r * 6 + c] * dp[15 * idx + c]; acc += m * (o[r] + m / 2.0); }
+                }
+            }
+            d.prior_model[(size_t)w * slots + t] = acc;
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_model_imu_prior(DevBatch d) {
+    __shared__ double sm[16];
+    model_imu_prior_body(d, blockIdx.x, sm);
+}
 
 // ------------------------------------------------------------------------------------------
 // cost of one window = sum over its residual blocks, fixed-shape tree (bitwise reproducible):

@@ -19,6 +19,9 @@ __global__ void k_build_solve_sb(DevBatch d);
 extern size_t build_solve_sb_bytes(int N, int prior_H_sz);
 __global__ void k_lm_prep(DevBatch d);
 __global__ void k_sweep(DevBatch d);
+__global__ void k_model_imu_prior(DevBatch d);
+__global__ void k_imu_raw(DevBatch d, const double *pose_src, const double *sb_src, int gate);
+__global__ void k_imu_weight(DevBatch d, double *cost_out, int gate);
 __global__ void k_sweep_mfma(DevBatch d);
 __global__ void k_rank1_mfma(DevBatch d);
 __global__ void k_backsub(DevBatch d);
@@ -156,60 +159,6 @@ __global__ __launch_bounds__(256) void k_dogleg(DevBatch d) {
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// model cost change pieces: (J delta)^T (r + J delta / 2) per residual block, from the strips at x
-// (the reprojection factors' part is fused into k_proj_linearize<1>)
-__global__ __launch_bounds__(64) void k_model_imu_prior(DevBatch d) {
-    __shared__ double sm[16];
-    const int w = blockIdx.x / (d.N - 1 + 1), q = blockIdx.x % (d.N - 1 + 1), t = threadIdx.x;
-    const SolveState &st = d.st[w];
-    if (st.termination != ISV_TERM_RUNNING || !st.step_valid) return;
-    const double *dp = d.delta_p + (size_t)w * d.np;
-    if (q < d.N - 1) {
-        const size_t f = (size_t)w * (d.N - 1) + q;
-        if (d.imu_skip[f]) { if (t == 0) d.imu_model[f] = 0.0; return; }
-        const double *s = d.imu_strip + f * ISV_IMU_STRIP;
-        if (t < 15) {
-            double m = 0;
-            const double *dd = dp + 15 * q;            // 30 contiguous tangent entries
-            for (int c = 0; c < 6; c++) m += s[15 + t * 6 + c] * dd[c];
-            for (int c = 0; c < 9; c++) m += s[105 + t * 9 + c] * dd[6 + c];
-            for (int c = 0; c < 6; c++) m += s[240 + t * 6 + c] * dd[15 + c];
-            for (int c = 0; c < 9; c++) m += s[330 + t * 9 + c] * dd[21 + c];
-            sm[t] = m * (s[t] + m / 2.0);
-        }
-        __syncthreads();
-        if (t == 0) { double a = 0; for (int k = 0; k < 15; k++) a += sm[k]; d.imu_model[f] = a; }
-    } else {
-        // priors of this window: lane per slot
-        const int slots = d.n_prior_slots;
-        if (t < slots) {
-            const double *ps = d.prior_strip + (size_t)w * d.prior_strip_sz;
-            double acc = 0;
-            if (t == 0) {
-                for (int r = 0; r < 6; r++) { double m = 0; for (int c = 0; c < 6; c++) m += ps[PR_SE3 + 6 + r * 6 + c] * dp[c]; acc += m * (ps[PR_SE3 + r] + m / 2.0); }
-            } else if (t == 1) {
-                const double *dd = dp + 15 * (d.Nvo - 1) + 6;
-                for (int r = 0; r < 9; r++) { double m = 0; for (int c = 0; c < 9; c++) m += ps[PR_LIN9 + 9 + r * 9 + c] * dd[c]; acc += m * (ps[PR_LIN9 + r] + m / 2.0); }
-            } else if (t < 1 + d.Nvo) {
-                const int k = t - 2; const double *o = ps + PR_REL0 + PR_REL_SZ * k;
-                for (int r = 0; r < 6; r++) {
-                    double m = 0;
-                    for (int c = 0; c < 6; c++) m += o[6 + r * 6 + c] * dp[15 * k + c] + o[42 + r * 6 + c] * dp[15 * (k + 1) + c];
-                    acc += m * (o[r] + m / 2.0);
-                }
-            } else {
-                const int mm = t - 1 - d.Nvo;
-                if (mm < d.n_rp[w]) {
-                    const double *o = ps + PR_REL0 + PR_REL_SZ * (d.Nvo - 1) + PR_RP_SZ * mm;
-                    const int idx = d.rollpitch[(size_t)w * d.max_rp + mm].index;
-                    for (int r = 0; r < 2; r++) { double m = 0; for (int c = 0; c < 6; c++) m += o[2 + r * 6 + c] * dp[15 * idx + c]; acc += m * (o[r] + m / 2.0); }
-                }
-            }
-            d.prior_model[(size_t)w * slots + t] = acc;
-        }
-    }
-}
 
 // ------------------------------------------------------------------------------------------
 // Candidate cost + model cost change (fixed-shape reductions), then TrustRegionMinimizer's step
@@ -441,7 +390,10 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
         PROF(slot, 0, 1);
         }
         HCHK(hipEventRecord(fj[0], st)); HCHK(hipStreamWaitEvent(st2, fj[0], 0));
-        if (NI) hipLaunchKernelGGL(k_imu_linearize<true>, dim3((unsigned)NI), dim3(64), 0, st2, d, d.pose, d.sb, d.imu_cost, 1);
+        if (NI) {
+            hipLaunchKernelGGL(k_imu_raw, dim3((unsigned)(NI + 63) / 64), dim3(256), 0, st2, d, d.pose, d.sb, 1);
+            hipLaunchKernelGGL(k_imu_weight, dim3((unsigned)NI), dim3(64), 0, st2, d, d.imu_cost, 1);
+        }
         hipLaunchKernelGGL(k_prior_linearize<true>, dim3(d.B), dim3(64), prior_lds_bytes(d.n_prior_slots), st2, d, d.pose, d.sb, d.prior_cost, 1);
         HCHK(hipEventRecord(fj[1], st2));
         if (!fork_late) {
@@ -461,7 +413,8 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
         }
         PROF(slot, 1, 1);
         HCHK(hipStreamWaitEvent(st, fj[1], 0));
-        hipLaunchKernelGGL(k_cost_reduce, dim3(d.B), dim3(256), 0, st, d, d.fcost, d.imu_cost, d.prior_cost, d.cost, 1);
+        static const int bs_old0 = getenv("ISV_BS_OLD") ? 1 : 0;
+        if (!d.lds_T || bs_old0) hipLaunchKernelGGL(k_cost_reduce, dim3(d.B), dim3(256), 0, st, d, d.fcost, d.imu_cost, d.prior_cost, d.cost, 1);   // (k_build_solve_sb sums the cost itself)
         PROF(slot, 2, 0);
         static const int bs_old = getenv("ISV_BS_OLD") ? 1 : 0;
         if (d.lds_T && !bs_old) hipLaunchKernelGGL(k_build_solve_sb, dim3(d.B), dim3(512), build_solve_sb_bytes(d.N, d.prior_H_sz), st, d);
