@@ -317,7 +317,6 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
     D2D(h->Bas0, d.Bas, (size_t)n * N * 3); D2D(h->Bgs0, d.Bgs, (size_t)n * N * 3); D2D(h->depth0, d.depth, L);
     D2D(h->tic0, d.tic, (size_t)n * 3); D2D(h->ric0, d.ric, (size_t)n * 9);
     D2D(h->se30, d.se3, n); D2D(h->lin90, d.lin9, n); D2D(h->relpose0, d.relpose, (size_t)n * (c.n_vo - 1)); D2D(h->rollpitch0, d.rollpitch, (size_t)n * c.max_rollpitch);
-    HIPCHK(h, hipMemsetAsync(d.Wd, 0, sizeof(double) * L * (size_t)d.wd_ld, st));   // static zero pattern of the dense w panels
     // IMU sqrt_info once per upload (the covariances do not change during a solve)
     if (NI) hipLaunchKernelGGL(k_imu_prep, dim3((unsigned)NI), dim3(64), 0, st, d);
     HIPCHK(h, hipGetLastError());

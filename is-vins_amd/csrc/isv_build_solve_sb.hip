@@ -18,7 +18,7 @@
 //     the 2 x (N + N) dependent steps).
 //   * a failed factorisation (mu too small) retries with mu x 10 like ceres' dogleg strategy
 //     (dogleg_strategy.cc ComputeGaussNewtonStep); the landmark part is then corrected in place:
-//     T' = T - sum_l (c_l(mu') - c_l(mu)) w_l w_l^T from the dense w panels (Wd).
+//     T' = T - sum_l (c_l(mu') - c_l(mu)) w_l w_l^T from the w vectors.
 //
 // Outputs (unchanged): zp, gn_p, up, diag_p, grad_p, scale_p, st.qT / gmax / mu / ls_fail / flags.
 #include <hip/hip_runtime.h>
@@ -265,14 +265,14 @@ __global__ __launch_bounds__(LS, 4) void k_build_solve_sb(DevBatch d) {
                 ra[k] = 6 * I + r; cb[k] = 6 * J + c; accs[k] = 0;
             }
             double accb = 0;
-            const int ld = d.wd_ld;
             for (int lb = l0; lb < l1; lb += RCH) {
                 const int cnt = (l1 - lb) < RCH ? (l1 - lb) : RCH;
                 __syncthreads();
-                const double *src = d.Wd + (size_t)lb * ld;
-                for (int e = t; e < cnt * ld; e += LS) {
-                    const int r = e / ld, c = e - r * ld;
-                    if (c < n6) wS[r * 67 + c] = src[e];
+                for (int e = t; e < cnt * n6; e += LS) {         // expand the packed w vectors to dense rows
+                    const int r = e / n6, c = e - r * n6;
+                    const unsigned m0 = d.lm_meta[lb + r];
+                    const int h6 = 6 * (int)(m0 & 255), k6 = 6 * (int)((m0 >> 8) & 255);
+                    wS[r * 67 + c] = (c >= h6 && c < h6 + k6) ? d.W[(size_t)(d.f_off[w] + (int)(m0 >> 16) + lb + r) * 6 + (c - h6)] : 0.0;
                 }
                 if (t < cnt) {
                     const int l = lb + t;

@@ -197,8 +197,9 @@ __global__ __launch_bounds__(256) void k_proj_linearize(DevBatch d, const double
             for (int c2 = 0; c2 < 6; c2++) lm_wh[c2] = Ji[c2] * Jl[0] + Ji[6 + c2] * Jl[1];
             lm_id = rec.lm;
             // w of the observing frame for the Schur sweep: J_pose_j^T J_lambda (6), obs slot f + lm + 1
-            // (the dense panel row Wd[lm][6 * frame ..] serves the MFMA downdates AND the back-substitution)
-            double *wd = d.Wd + (size_t)rec.lm * d.wd_ld + 6 * fj;
+            // packed per landmark: slot 0 = host frame, slot o = frame host + o (contiguous 6 k doubles); the MFMA
+            // downdates expand it to dense panel rows in LDS, the back-substitution reads it as it is
+            double *wd = d.W + (size_t)(f + rec.lm + 1) * 6;
 #pragma unroll
             for (int c2 = 0; c2 < 6; c2++) wd[c2] = Jj[c2] * Jl[0] + Jj[6 + c2] * Jl[1];
         }
@@ -234,7 +235,7 @@ __global__ __launch_bounds__(256) void k_proj_linearize(DevBatch d, const double
             const double Dl = sqrt(Dl2);
             d.lm_cg[l] = make_double2(sl * sl / (Es + ss.mu * Dl2), lm_g);
             d.lmE[l] = lm_e; d.lmG[l] = lm_g; d.diag_l[l] = Dl; d.grad_l[l] = sl * lm_g / Dl;
-            double *wd = d.Wd + (size_t)l * d.wd_ld + 6 * d.lm_host[l];            // host observation slot
+            double *wd = d.W + (size_t)(d.lm_f0[l] + l) * 6;                       // host observation slot
 #pragma unroll
             for (int c2 = 0; c2 < 6; c2++) wd[c2] = lm_wh[c2];
         }

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void k_dogleg(DevBatch d) {
         const double mu = st.mu;
         for (int l = l0 + t; l < l1; l += 256) {
             const int h = d.lm_host[l], k = d.lm_k[l];
-            const double *wv = d.Wd + (size_t)l * d.wd_ld + 6 * h;     // frames h .. h + k - 1 are contiguous
+            const double *wv = d.W + (size_t)(d.lm_f0[l] + l) * 6;     // slots of frames h .. h + k - 1
             double wz = 0, wu = 0;        // w_l^T z_p, w_l^T u_p
             for (int o = 0; o < k; o++) {
                 const double2 w01 = *reinterpret_cast<const double2 *>(wv + 6 * o), w23 = *reinterpret_cast<const double2 *>(wv + 6 * o + 2),
@@ -353,7 +353,8 @@ int isv_solver_alloc(DevBatch &d, size_t B, size_t L, size_t F, std::vector<void
     d.tvis_sz = 36 * (d.N * (d.N + 1) / 2) + 18 * d.N;
     TRYA(dal(&d.W, (F + L) * 6, allocs, err)); TRYA(dal(&d.lm_cg, L, allocs, err));
     d.wd_ld = 16 * ((6 * d.N + 15) / 16);
-    TRYA(dal(&d.Wd, L * (size_t)d.wd_ld, allocs, err)); TRYA(dal(&d.Tvis, B * (size_t)d.tvis_sz, allocs, err));
+    d.Wd = nullptr;
+    TRYA(dal(&d.Tvis, B * (size_t)d.tvis_sz, allocs, err));
     TRYA(dal(&d.dbg, B * 64, allocs, err));
     HCHK(hipMemset(d.dbg, 0, B * 64 * sizeof(double)));
     TRYA(dal(&d.marg, B, allocs, err)); TRYA(dal(&d.margin_old, B, allocs, err)); TRYA(dal(&d.header0, B, allocs, err));
@@ -409,7 +410,7 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
             counts[2]++;
             const int nt = d.wd_ld / 16;
             // one workgroup per window: nt(nt+1)/2 tile wavefronts + 1 rhs wavefront, W panels staged through LDS
-            hipLaunchKernelGGL(k_rank1_mfma, dim3(d.B), dim3(64 * (nt * (nt + 1) / 2 + 1)), (64 * (d.wd_ld + 4) + 128) * sizeof(double), st, d);
+            hipLaunchKernelGGL(k_rank1_mfma, dim3(d.B), dim3(64 * (nt * (nt + 1) / 2 + 1)), (64 * (d.wd_ld + 4) + 128 + 32) * sizeof(double), st, d);
         }
         PROF(slot, 1, 1);
         HCHK(hipStreamWaitEvent(st, fj[1], 0));

@@ -288,6 +288,8 @@ __global__ __launch_bounds__(1024) void k_rank1_mfma(DevBatch d) {
     double *sW = lds;                      // [R1_CHUNK][ld + 4] (padded rows: the 4 k-rows of an operand hit distinct banks)
     double *sC = lds + R1_CHUNK * (ld + 4);   // c_l
     double *sG = sC + R1_CHUNK;               // c_l g_l
+    unsigned *sM = (unsigned *)(sG + R1_CHUNK);   // landmark metadata of the chunk
+    const int fw0 = d.f_off[w];
     const int lds_ld = ld + 4;
     double *out = d.Tvis + (size_t)w * d.tvis_sz;
     const int tail = 36 * (N * (N + 1) / 2);
@@ -302,10 +304,16 @@ __global__ __launch_bounds__(1024) void k_rank1_mfma(DevBatch d) {
     for (int lb = l0; lb < l1; lb += R1_CHUNK) {
         const int cnt = (l1 - lb) < R1_CHUNK ? (l1 - lb) : R1_CHUNK;
         __syncthreads();
-        const double *src = d.Wd + (size_t)lb * ld;
+        // expand the packed w vectors of this chunk to dense, zero-filled panel rows
+        if (t < R1_CHUNK) sM[t] = t < cnt ? d.lm_meta[lb + t] : 0u;
+        __syncthreads();
         for (int e = t; e < R1_CHUNK * ld; e += blockDim.x) {
             const int r = e / ld, c = e - r * ld;
-            sW[r * lds_ld + c] = (r < cnt) ? src[e] : 0.0;     // coalesced; zero rows beyond the window's landmarks
+            const unsigned m0 = sM[r];
+            const int h6 = 6 * (int)(m0 & 255), k6 = 6 * (int)((m0 >> 8) & 255);
+            double v = 0.0;
+            if (c >= h6 && c < h6 + k6) v = d.W[(size_t)(fw0 + (int)(m0 >> 16) + lb + r) * 6 + (c - h6)];
+            sW[r * lds_ld + c] = v;
         }
         if (t < R1_CHUNK) { const double2 cg = (t < cnt) ? d.lm_cg[lb + t] : make_double2(0.0, 0.0); sC[t] = cg.x; sG[t] = cg.x * cg.y; }
         __syncthreads();
@@ -351,7 +359,7 @@ __global__ __launch_bounds__(256) void k_backsub(DevBatch d) {
     if (st.termination != ISV_TERM_RUNNING || !st.fresh || st.ls_fail) return;
     const int n = d.np, h = d.lm_host[l], k = d.lm_k[l], f0 = d.lm_f0[l];
     const double *zp = d.zp + (size_t)w * n, *up = d.up + (size_t)w * n;
-    const double *wv = d.Wd + (size_t)l * d.wd_ld + 6 * h;     // the landmark's w vectors: frames h .. h + k - 1 are contiguous
+    const double *wv = d.W + (size_t)(f0 + l) * 6;
     double wz = 0, wu = 0;        // w_l^T z_p, w_l^T u_p
     for (int o = 0; o < k; o++) {
         const double2 w01 = *reinterpret_cast<const double2 *>(wv + 6 * o), w23 = *reinterpret_cast<const double2 *>(wv + 6 * o + 2),
