@@ -23,7 +23,7 @@ __global__ void k_model_imu_prior(DevBatch d);
 __global__ void k_imu_raw(DevBatch d, const double *pose_src, const double *sb_src, int gate);
 __global__ void k_imu_weight(DevBatch d, double *cost_out, int gate);
 __global__ void k_sweep_mfma(DevBatch d);
-__global__ void k_rank1_mfma(DevBatch d);
+template <int NT> __global__ void k_rank1_mfma(DevBatch d);
 __global__ void k_backsub(DevBatch d);
 __global__ void k_marg_clear(DevBatch d);
 __global__ void k_marg_fwd(DevBatch d);
@@ -352,19 +352,28 @@ int isv_solver_alloc(DevBatch &d, size_t B, size_t L, size_t F, std::vector<void
     TRYA(dal(&d.trace_step, B * ISV_MAX_TRACE, allocs, err)); TRYA(dal(&d.trace_acc, B * ISV_MAX_TRACE, allocs, err));
     d.tvis_sz = 36 * (d.N * (d.N + 1) / 2) + 18 * d.N;
     TRYA(dal(&d.W, (F + L) * 6, allocs, err)); TRYA(dal(&d.lm_cg, L, allocs, err));
-    d.wd_ld = 16 * ((6 * d.N + 15) / 16);
+    d.wd_ld = 16 * ((6 * d.N + 16) / 16);          // 6N pose columns + the g_l column, rounded up to 16
     d.Wd = nullptr;
     TRYA(dal(&d.Tvis, B * (size_t)d.tvis_sz, allocs, err));
     TRYA(dal(&d.dbg, B * 64, allocs, err));
     HCHK(hipMemset(d.dbg, 0, B * 64 * sizeof(double)));
     TRYA(dal(&d.marg, B, allocs, err)); TRYA(dal(&d.margin_old, B, allocs, err)); TRYA(dal(&d.header0, B, allocs, err));
     const size_t nblkT = (size_t)d.N * (d.N + 1) / 2 * 225;
-    d.lds_T = (d.N <= 11 && d.prior_H_sz <= 1024 && build_solve_lds2_bytes(d.N) <= 160 * 1024) ? 1 : 0;
+    d.lds_T = (d.N <= 11 && d.prior_H_sz <= 1024 && build_solve_lds2_bytes(d.N) <= 160 * 1024 &&
+               (64 * (d.wd_ld + 4) + (size_t)d.max_lm * 3 + 2) * sizeof(double) <= 160 * 1024) ? 1 : 0;
     TRYA(dal(&d.Tglob, d.lds_T ? 1 : B * nblkT, allocs, err));
     d.marg_scratch_sz = 26;
     TRYA(dal(&d.marg_scratch, L * 26, allocs, err));
     if (d.lds_T) {
         HCHK(hipFuncSetAttribute((const void *)k_build_solve_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)build_solve_lds2_bytes(d.N)));
+        {
+            const int lds_r1 = (int)((64 * (d.wd_ld + 4) + (size_t)d.max_lm * 3 + 2) * sizeof(double));
+            HCHK(hipFuncSetAttribute((const void *)k_rank1_mfma<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_r1));
+            HCHK(hipFuncSetAttribute((const void *)k_rank1_mfma<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_r1));
+            HCHK(hipFuncSetAttribute((const void *)k_rank1_mfma<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_r1));
+            HCHK(hipFuncSetAttribute((const void *)k_rank1_mfma<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_r1));
+            HCHK(hipFuncSetAttribute((const void *)k_rank1_mfma<5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_r1));
+        }
         HCHK(hipFuncSetAttribute((const void *)k_build_solve_sb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)build_solve_sb_bytes(d.N, d.prior_H_sz)));
     }
     else HCHK(hipFuncSetAttribute((const void *)k_build_solve<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)build_solve_lds_bytes(d.N, false)));
@@ -410,7 +419,16 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
             counts[2]++;
             const int nt = d.wd_ld / 16;
             // one workgroup per window: nt(nt+1)/2 tile wavefronts + 1 rhs wavefront, W panels staged through LDS
-            hipLaunchKernelGGL(k_rank1_mfma, dim3(d.B), dim3(64 * (nt * (nt + 1) / 2 + 1)), (64 * (d.wd_ld + 4) + 128 + 32) * sizeof(double), st, d);
+            // one workgroup per window: nt(nt+1)/2 tile wavefronts, w vectors expanded to panel rows in LDS
+            const size_t lds_r1 = (64 * (d.wd_ld + 4) + (size_t)d.max_lm * 3 + 2) * sizeof(double);
+            const dim3 blk(64 * (nt * (nt + 1) / 2));
+            switch (nt) {
+            case 1: hipLaunchKernelGGL(k_rank1_mfma<1>, dim3(d.B), blk, lds_r1, st, d); break;
+            case 2: hipLaunchKernelGGL(k_rank1_mfma<2>, dim3(d.B), blk, lds_r1, st, d); break;
+            case 3: hipLaunchKernelGGL(k_rank1_mfma<3>, dim3(d.B), blk, lds_r1, st, d); break;
+            case 4: hipLaunchKernelGGL(k_rank1_mfma<4>, dim3(d.B), blk, lds_r1, st, d); break;
+            default: hipLaunchKernelGGL(k_rank1_mfma<5>, dim3(d.B), blk, lds_r1, st, d); break;
+            }
         }
         PROF(slot, 1, 1);
         HCHK(hipStreamWaitEvent(st, fj[1], 0));

@@ -270,84 +270,93 @@ __global__ __launch_bounds__(64 * ISV_SWEEP_WAVES) void k_sweep_mfma(DevBatch d)
     SWSTAMP(43);
 }
 
-// Rank-1 landmark downdates as FP64 MFMA panels:  Tvis -= Wd^T diag(c) Wd  over the window's landmarks,
-// one wavefront per 16x16 output tile (lower triangle of the 6N x 6N pose block, zero padded to 16s),
-// v_mfma_f64_16x16x4: A = (c_l * Wd[l][16I + i]) for 4 landmarks, B = Wd[l][16J + j].  The dense panels
-// multiply structural zeros, but one MFMA replaces ~1000 scalar lane-FMAs with their address arithmetic
-// (the scalar sweep was issue bound).  blockIdx.y == ntiles: the reduced right-hand side
-// bs = - Wd^T (c .* g_l).
+// Rank-1 landmark downdates as FP64 MFMA panels:  Tvis -= P^T diag(c) P  over the window's landmarks,
+// where row l of the panel P is the landmark's w vector dense over the 6N pose columns (zero where a frame
+// does not see it) with g_l appended in column 6N.  One wavefront per 16x16 output tile (lower triangle,
+// zero padded to 16s), v_mfma_f64_16x16x4: A = c_l * P[l][16I + i] for 4 landmarks, B = P[l][16J + j].
+// The dense panels multiply structural zeros, but one MFMA replaces ~1000 scalar lane-FMAs with their
+// address arithmetic (the scalar sweep was issue bound).  Row 6N of the product is sum c_l g_l w_l = -bs,
+// the reduced right-hand side.  The packed w vectors (HBM) are expanded to panel rows in LDS, 64 landmarks
+// per pass; the loads of the next pass are in flight while the current one is multiplied.
 typedef double double4v __attribute__((ext_vector_type(4)));
 #define R1_CHUNK 64                       // landmarks staged per pass (64 x wd_ld doubles of LDS)
-__global__ __launch_bounds__(1024) void k_rank1_mfma(DevBatch d) {
+// NT = panel width / 16 (compile time: cheap index arithmetic, right-sized prefetch registers)
+template <int NT>
+__global__ __launch_bounds__(64 * NT * (NT + 1) / 2) void k_rank1_mfma(DevBatch d) {
+    constexpr int R1_PF = (32 + NT) / (NT + 1);            // panel elements per thread and pass: 64 * ld / threads = 32 / (NT + 1)
     extern __shared__ __align__(16) double lds[];
-    const int w = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6, nw = blockDim.x >> 6;
+    const int w = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const SolveState &st = d.st[w];
     if (st.termination != ISV_TERM_RUNNING || !st.need_linearize) return;
-    const int N = d.N, n6 = 6 * N, ld = d.wd_ld, nt = ld / 16, ntiles = nt * (nt + 1) / 2;
-    const int l0 = d.lm_off[w], l1 = d.lm_off[w + 1];
-    double *sW = lds;                      // [R1_CHUNK][ld + 4] (padded rows: the 4 k-rows of an operand hit distinct banks)
-    double *sC = lds + R1_CHUNK * (ld + 4);   // c_l
-    double *sG = sC + R1_CHUNK;               // c_l g_l
-    unsigned *sM = (unsigned *)(sG + R1_CHUNK);   // landmark metadata of the chunk
+    constexpr int ld = 16 * NT, nthr = 64 * NT * (NT + 1) / 2;
+    const int N = d.N, n6 = 6 * N;
+    const int l0 = d.lm_off[w], l1 = d.lm_off[w + 1], Lw = l1 - l0;
+    constexpr int lds_ld = ld + 4;             // padded rows: the 4 k-rows of an operand hit distinct banks
+    double *sW = lds;                      // [R1_CHUNK][ld + 4]
+    double2 *sCG = (double2 *)(lds + R1_CHUNK * lds_ld);       // [max_lm] {c_l, g_l}
+    unsigned *sM = (unsigned *)(sCG + d.max_lm);               // [max_lm] landmark metadata
     const int fw0 = d.f_off[w];
-    const int lds_ld = ld + 4;
     double *out = d.Tvis + (size_t)w * d.tvis_sz;
     const int tail = 36 * (N * (N + 1) / 2);
-    // wave wv < ntiles owns output tile (I, J); wave ntiles accumulates the reduced rhs bs
+    // wavefront wv owns output tile (I, J), I >= J
     int I = 0;
     while ((I + 1) * (I + 2) / 2 <= wv) I++;
     const int J = wv - I * (I + 1) / 2;
-    const bool tile_wave = wv < ntiles, rhs_wave = (wv == ntiles);
     const int i = lane & 15, kq = lane >> 4;
-    double4v acc = {0, 0, 0, 0};
-    double rhs0 = 0, rhs1 = 0;             // rows lane and lane + 64 of bs
-    for (int lb = l0; lb < l1; lb += R1_CHUNK) {
-        const int cnt = (l1 - lb) < R1_CHUNK ? (l1 - lb) : R1_CHUNK;
-        __syncthreads();
-        // expand the packed w vectors of this chunk to dense, zero-filled panel rows
-        if (t < R1_CHUNK) sM[t] = t < cnt ? d.lm_meta[lb + t] : 0u;
-        __syncthreads();
-        for (int e = t; e < R1_CHUNK * ld; e += blockDim.x) {
-            const int r = e / ld, c = e - r * ld;
-            const unsigned m0 = sM[r];
-            const int h6 = 6 * (int)(m0 & 255), k6 = 6 * (int)((m0 >> 8) & 255);
-            double v = 0.0;
-            if (c >= h6 && c < h6 + k6) v = d.W[(size_t)(fw0 + (int)(m0 >> 16) + lb + r) * 6 + (c - h6)];
-            sW[r * lds_ld + c] = v;
-        }
-        if (t < R1_CHUNK) { const double2 cg = (t < cnt) ? d.lm_cg[lb + t] : make_double2(0.0, 0.0); sC[t] = cg.x; sG[t] = cg.x * cg.y; }
-        __syncthreads();
-        if (tile_wave) {
-#pragma unroll 4
-            for (int k4 = 0; k4 < R1_CHUNK; k4 += 4) {
-                const int l = k4 + kq;
-                const double av = sW[l * lds_ld + 16 * I + i] * sC[l], bv = sW[l * lds_ld + 16 * J + i];
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-            }
-        } else if (rhs_wave) {
-            for (int l = 0; l < cnt; l++) {
-                const double cgl = sG[l];
-                if (lane < n6) rhs0 += cgl * sW[l * lds_ld + lane];
-                if (lane + 64 < n6) rhs1 += cgl * sW[l * lds_ld + lane + 64];
-            }
-        }
-    }
-    if (tile_wave) {
-        // C/D layout of v_mfma_f64_16x16x4: col = lane & 15, row = (lane >> 4) + 4 * reg
+    for (int l = t; l < Lw; l += nthr) { sM[l] = d.lm_meta[l0 + l]; sCG[l] = d.lm_cg[l0 + l]; }
+    __syncthreads();
+    // panel element e of a pass: row r = e / ld (landmark lb + r), column c = e % ld
+    double pf[R1_PF];
+    auto fetch = [&](int lb) {
 #pragma unroll
-        for (int reg = 0; reg < 4; reg++) {
-            const int R = 16 * I + kq + 4 * reg, Cc = 16 * J + i;
-            if (R < n6 && Cc < n6 && R >= Cc) {
-                const int fa = Cc / 6, c = Cc - 6 * fa, fb = R / 6, r = R - 6 * fb, bo = fb - fa;
-                if (bo > 0 || c <= r) out[tvis_col(fa, N) + bo * 36 + r * 6 + c] -= acc[reg];
+        for (int u2 = 0; u2 < R1_PF; u2++) {
+            const int e = t + u2 * nthr, r = e / ld, c = e - r * ld, l = lb - l0 + r;
+            double v = 0.0;
+            if (e < R1_CHUNK * ld && l < Lw) {
+                const unsigned m0 = sM[l];
+                const int h6 = 6 * (int)(m0 & 255), k6 = 6 * (int)((m0 >> 8) & 255);
+                if (c >= h6 && c < h6 + k6) v = d.W[(size_t)(fw0 + (int)(m0 >> 16) + l0 + l) * 6 + (c - h6)];
+                else if (c == n6) v = sCG[l].y;
             }
+            pf[u2] = v;
         }
-    } else if (rhs_wave) {
-        if (lane < n6) out[tail + 12 * N + lane] = -rhs0;
-        if (lane + 64 < n6) out[tail + 12 * N + lane + 64] = -rhs1;
+    };
+    double4v acc = {0, 0, 0, 0};
+    fetch(l0);
+    for (int lb = l0; lb < l1; lb += R1_CHUNK) {
+        __syncthreads();                                   // the previous pass has been consumed
+#pragma unroll
+        for (int u2 = 0; u2 < R1_PF; u2++) {
+            const int e = t + u2 * nthr, r = e / ld, c = e - r * ld;
+            if (e < R1_CHUNK * ld) sW[r * lds_ld + c] = pf[u2];
+        }
+        __syncthreads();
+        if (lb + R1_CHUNK < l1) fetch(lb + R1_CHUNK);      // in flight during the MFMAs below
+#pragma unroll 4
+        for (int k4 = 0; k4 < R1_CHUNK; k4 += 4) {
+            const int l = k4 + kq, lg = lb - l0 + l;
+            const double cl = lg < Lw ? sCG[lg].x : 0.0;
+            const double av = sW[l * lds_ld + 16 * I + i] * cl, bv = sW[l * lds_ld + 16 * J + i];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+        }
     }
-    (void)nw;
+    // C/D layout of v_mfma_f64_16x16x4: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) {
+        const int R = 16 * I + kq + 4 * reg, Cc = 16 * J + i;
+        if (R < n6 && Cc < n6 && R >= Cc) {
+            const int fa = Cc / 6, c = Cc - 6 * fa, fb = R / 6, r = R - 6 * fb, bo = fb - fa;
+            if (bo > 0 || c <= r) out[tvis_col(fa, N) + bo * 36 + r * 6 + c] -= acc[reg];
+        } else if (R == n6 && Cc < n6) {
+            out[tail + 12 * N + Cc] = -acc[reg];           // reduced right-hand side bs = -sum c_l g_l w_l
+        }
+    }
 }
+template __global__ void k_rank1_mfma<1>(DevBatch);
+template __global__ void k_rank1_mfma<2>(DevBatch);
+template __global__ void k_rank1_mfma<3>(DevBatch);
+template __global__ void k_rank1_mfma<4>(DevBatch);
+template __global__ void k_rank1_mfma<5>(DevBatch);
 
 // back-substitution of the eliminated landmarks (schur_eliminator BackSubstitute) + the landmark
 // terms of the Cauchy-point denominator, from the w vectors (48 B per observation).
