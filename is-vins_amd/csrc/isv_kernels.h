@@ -5,8 +5,8 @@
 #include <vector>
 #include "isv_device_types.h"
 
-// per-wave LDS of k_proj_linearize<MODE>: R,P per frame + extrinsic; MODE 0 adds a 64 x 15 transpose buffer
-__host__ __device__ inline size_t proj_lds_doubles_per_wave(int N, int mode) { return (size_t)N * 12 + 12 + (mode == 0 ? 64 * 15 : 0); }
+// per-wave LDS of k_proj_linearize<MODE>: R,P per frame + extrinsic; MODE 0 adds a 64 x 15 transpose buffer, MODE 1 the poses at x and the tangent step
+__host__ __device__ inline size_t proj_lds_doubles_per_wave(int N, int mode) { return (size_t)N * 12 + 12 + (mode == 0 ? 64 * 15 : (size_t)N * 18); }
 
 __global__ void k_vector2double(DevBatch d);
 __global__ void k_imu_prep(DevBatch d);

@@ -146,6 +146,19 @@ __global__ __launch_bounds__(256) void k_proj_linearize(DevBatch d, const double
         for (int k = 0; k < 9; k++) sEx[k] = R[k];
         sEx[9] = e[0]; sEx[10] = e[1]; sEx[11] = e[2];
     }
+    if (MODE == 1 && live && lane < N) {
+        // MODE 1 also needs the poses at x and the tangent step (model cost change, see below)
+        const int fr = lane;
+        const double *p = d.pose + ((size_t)win * N + fr) * 7;
+        double R[9]; q_to_R(q_from_pose(p), R);
+        double *o = sOut + fr * 12;
+#pragma unroll
+        for (int k = 0; k < 9; k++) o[k] = R[k];
+        o[9] = p[0]; o[10] = p[1]; o[11] = p[2];
+        const double *dp = d.delta_p + (size_t)win * d.np + 15 * fr;
+#pragma unroll
+        for (int k = 0; k < 6; k++) sOut[N * 12 + fr * 6 + k] = dp[k];
+    }
     __syncthreads();
 
     double r0 = 0, r1 = 0, Ji[12], Jj[12], Jl[2], cost = 0;
@@ -179,17 +192,18 @@ __global__ __launch_bounds__(256) void k_proj_linearize(DevBatch d, const double
         }
         fcost_out[f] = cost;
         if (MODE == 1) {
-            // model cost change piece (J delta)^T (r + J delta / 2) from this factor's strip at x
-            const double *sx = d.strip + (size_t)f * ISV_PROJ_STRIP;
-            const double *dp = d.delta_p + (size_t)win * d.np;
-            const double dl = d.delta_l[rec.lm];
-            double m0 = sx[26] * dl, m1 = sx[27] * dl;
+            // model cost change piece (J delta)^T (r + J delta / 2) at x: the residual and J delta are
+            // re-derived from the poses at x (directional derivative), no strip is read
+            const double *sX = sOut, *sD = sOut + N * 12;
+            double RiX[9], RjX[9], PiX[3], PjX[3], rx0, rx1, m0, m1;
 #pragma unroll
-            for (int c2 = 0; c2 < 6; c2++) {
-                m0 += sx[2 + c2] * dp[15 * fi + c2] + sx[14 + c2] * dp[15 * fj + c2];
-                m1 += sx[8 + c2] * dp[15 * fi + c2] + sx[20 + c2] * dp[15 * fj + c2];
-            }
-            d.fmodel[f] = m0 * (sx[0] + m0 / 2.0) + m1 * (sx[1] + m1 / 2.0);
+            for (int k = 0; k < 9; k++) { RiX[k] = sX[fi * 12 + k]; RjX[k] = sX[fj * 12 + k]; }
+#pragma unroll
+            for (int k = 0; k < 3; k++) { PiX[k] = sX[fi * 12 + 9 + k]; PjX[k] = sX[fj * 12 + 9 + k]; }
+            proj_residual_dir(RiX, PiX, RjX, PjX, ric, tic, d.proj_sqrt_info, d.lam[rec.lm], pi3[0], pi3[1], pi3[2], pj.x, pj.y,
+                              sD + fi * 6, sD + fj * 6, d.delta_l[rec.lm], rx0, rx1, m0, m1);
+            const double rp = 1.0 / (1.0 + (rx0 * rx0 + rx1 * rx1));       // CauchyLoss corrector: r, J scaled by sqrt(rho')
+            d.fmodel[f] = rp * (m0 * (rx0 + m0 / 2.0) + m1 * (rx1 + m1 / 2.0));
         }
         if (MODE == 0) {
             lm_e = Jl[0] * Jl[0] + Jl[1] * Jl[1]; lm_g = Jl[0] * r0 + Jl[1] * r1;

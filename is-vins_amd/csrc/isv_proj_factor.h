@@ -75,3 +75,46 @@ DEV void proj_factor(const double *Ri, const double *Pi, const double *Rj, const
     Jl[1] = (RB[3] * v[0] + RB[4] * v[1] + RB[5] * v[2]) * s;
 }
 
+
+// Residual at x and its directional derivative m = J delta along the tangent step (delta P_i, delta theta_i,
+// delta P_j, delta theta_j, delta lambda), WITHOUT forming the Jacobian blocks: the chain rule is applied to
+// the step itself (a handful of 3-vector products instead of the 2x6 / 2x6 / 2x1 blocks and their dot
+// products).  Same perturbation conventions as proj_factor / PoseLocalParameterization (R <- R Exp(dtheta)).
+DEV void proj_residual_dir(const double *Ri, const double *Pi, const double *Rj, const double *Pj,
+                           const double *ric, const double *tic, const double *sq, double lam,
+                           double pix, double piy, double piz, double pjx, double pjy,
+                           const double *di, const double *dj, double dlam,
+                           double &r0, double &r1, double &m0, double &m1) {
+    const double inv = 1.0 / lam;
+    double pc[3] = {pix * inv, piy * inv, piz * inv};
+    double pb[3], pw[3], t[3], pbj[3], pcj[3];
+    m3v(ric, pc, pb); pb[0] += tic[0]; pb[1] += tic[1]; pb[2] += tic[2];
+    m3v(Ri, pb, pw);
+    t[0] = pw[0] + Pi[0] - Pj[0]; t[1] = pw[1] + Pi[1] - Pj[1]; t[2] = pw[2] + Pi[2] - Pj[2];
+    m3tv(Rj, t, pbj);
+    t[0] = pbj[0] - tic[0]; t[1] = pbj[1] - tic[1]; t[2] = pbj[2] - tic[2];
+    m3tv(ric, t, pcj);
+    const double idep = 1.0 / pcj[2];
+    const double u0 = pcj[0] * idep - pjx, u1 = pcj[1] * idep - pjy;
+    r0 = sq[0] * u0 + sq[1] * u1;
+    r1 = sq[2] * u0 + sq[3] * u1;
+    // d pc = -pc dlam / lam;  d pb = ric d pc;  d pw = Ri (d pb + dtheta_i x pb) + dP_i
+    const double sl = -dlam * inv;
+    double dpc[3] = {pc[0] * sl, pc[1] * sl, pc[2] * sl}, dpb[3], dw[3], dbj[3], dcj[3];
+    m3v(ric, dpc, dpb);
+    dpb[0] += di[4] * pb[2] - di[5] * pb[1];
+    dpb[1] += di[5] * pb[0] - di[3] * pb[2];
+    dpb[2] += di[3] * pb[1] - di[4] * pb[0];
+    m3v(Ri, dpb, dw);
+    dw[0] += di[0] - dj[0]; dw[1] += di[1] - dj[1]; dw[2] += di[2] - dj[2];
+    // d pbj = Rj^T dw + pbj x dtheta_j;  d pcj = ric^T d pbj
+    m3tv(Rj, dw, dbj);
+    dbj[0] += pbj[1] * dj[5] - pbj[2] * dj[4];
+    dbj[1] += pbj[2] * dj[3] - pbj[0] * dj[5];
+    dbj[2] += pbj[0] * dj[4] - pbj[1] * dj[3];
+    m3tv(ric, dbj, dcj);
+    // d u = [[1/z, 0, -x/z^2], [0, 1/z, -y/z^2]] d pcj
+    const double du0 = (dcj[0] - pcj[0] * idep * dcj[2]) * idep, du1 = (dcj[1] - pcj[1] * idep * dcj[2]) * idep;
+    m0 = sq[0] * du0 + sq[1] * du1;
+    m1 = sq[2] * du0 + sq[3] * du1;
+}
