@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 
 #define DEV __device__ __forceinline__
+// wave-level ordering of LDS traffic (LDS executes one wavefront's accesses in issue order)
+#define ISV_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
 struct Quat { double w, x, y, z; };
 

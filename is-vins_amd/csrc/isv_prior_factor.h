@@ -1,0 +1,247 @@
+// isv_prior_factor.h -- the prior factors of a window (SE3Prior / Linear9 / RelativePose / RollPitch) as one
+// wavefront-sized routine, shared by k_prior_linearize (isv_linearize.hip) and k_dogleg (isv_solver.hip).
+#pragma once
+#include "isv_device_types.h"
+#include "isv_device_math.h"
+
+// ------------------------------------------------------------------------------------------
+// Prior factors: one wavefront per window.  Slot 0 = SE3 prior, 1 = Linear9, 2..Nvo = relative pose, then
+// roll-pitch.  Phase 1: one lane per prior forms the raw residual and raw Jacobian blocks in LDS (the
+// SO(3) log / right-Jacobian calls are shared by the SE3 and relative-pose lanes).  Phase 2: all lanes form
+// sqrt_info * [raw r | raw J] entry by entry.  Phase 3: CauchyLoss corrector and strips.  Phase 4: J^T J
+// pairs and J^T r for k_build_solve.  Same operation order per entry as a scalar evaluation, so the
+// numbers do not depend on the lane split.
+#define PRL_RAW 82      // per-slot LDS: raw r (9) | raw J (72)
+#define PRL_W 90        // per-slot LDS: r (9) | J (81)
+#define PRL_S 82        // per-slot LDS: sqrt_info (<= 81)
+struct PriorDesc { int kind, strip_off, H_off, valid; const double *S; };   // kind 0 SE3, 1 Linear9, 2 relpose, 3 rollpitch
+DEV PriorDesc prior_desc(const DevBatch &d, int w, int s, int n_rp) {
+    PriorDesc p;
+    if (s == 0) { p.kind = 0; p.strip_off = PR_SE3; p.H_off = PH_SE3; p.valid = 1; p.S = d.se3[w].sqrt_info; }
+    else if (s == 1) { p.kind = 1; p.strip_off = PR_LIN9; p.H_off = PH_LIN9; p.valid = 1; p.S = d.lin9[w].sqrt_info; }
+    else if (s < 1 + d.Nvo) {
+        const int i = s - 2;
+        p.kind = 2; p.strip_off = PR_REL0 + PR_REL_SZ * i; p.H_off = PH_REL0 + PH_REL_SZ * i; p.valid = 1;
+        p.S = d.relpose[(size_t)w * (d.Nvo - 1) + i].sqrt_info;
+    } else {
+        const int m = s - 1 - d.Nvo;
+        p.kind = 3; p.strip_off = PR_REL0 + PR_REL_SZ * (d.Nvo - 1) + PR_RP_SZ * m;
+        p.H_off = PH_REL0 + PH_REL_SZ * (d.Nvo - 1) + PH_RP_SZ * m; p.valid = m < n_rp;
+        p.S = d.rollpitch[(size_t)w * d.max_rp + (p.valid ? m : 0)].sqrt_info;
+    }
+    return p;
+}
+// phase 2 for one prior of shape DIM x (NBLK blocks of BW): wr = [S raw | S rawJ]
+template <int DIM, int NBLK, int BW, bool COPY_S, bool JAC>
+DEV void prior_weight(const double *S, const double *raw, const double *rawJ, double *wr, int t) {
+    constexpr int per = 1 + (JAC ? NBLK * BW : 0);
+    for (int e = t; e < DIM * per; e += 64) {
+        const int row = e / per, c = e - row * per;
+        double v = 0;
+        if (c == 0) {
+#pragma unroll
+            for (int k = 0; k < DIM; k++) v += S[row * DIM + k] * raw[k];
+            wr[row] = v;
+        } else {
+            const int col = c - 1, blk = col / BW, cc = col - blk * BW;
+            if (COPY_S) v = S[row * DIM + cc];
+            else {
+#pragma unroll
+                for (int k = 0; k < DIM; k++) v += S[row * DIM + k] * rawJ[blk * DIM * BW + k * BW + cc];
+            }
+            wr[9 + blk * DIM * BW + row * BW + cc] = v;
+        }
+    }
+}
+// phase 3: corrector scale of r and J in place + strip; returns 0.5 rho
+template <int DIM, int NBLK, int BW, bool JAC, bool WAVE>
+DEV double prior_correct(double *wr, double *strip_o, int t) {
+    double ssum = 0;
+#pragma unroll
+    for (int k = 0; k < DIM; k++) ssum += wr[k] * wr[k];
+    const double sum = 1.0 + ssum;
+    if (JAC) {
+        const double sc = sqrt(fmax(1.0 / sum, 2.2250738585072014e-308));
+        if (WAVE) ISV_WSYNC(); else __syncthreads();          // every lane has read r before it is rescaled
+        constexpr int nj = DIM * NBLK * BW;
+        for (int e = t; e < DIM + nj; e += 64) {
+            double *q = e < DIM ? wr + e : wr + 9 + (e - DIM);
+            const double v = *q * sc;
+            *q = v; strip_o[e] = v;
+        }
+    }
+    return 0.5 * log(sum);
+}
+// phase 4: J^T J pairs (a >= b at a(a+1)/2 + b) then J^T r
+template <int DIM, int NBLK, int BW>
+DEV void prior_H(const double *wr, double *H, int t) {
+    constexpr int ncol = NBLK * BW, npair = ncol * (ncol + 1) / 2;
+    const double *J = wr + 9;
+    for (int e = t; e < npair + ncol; e += 64) {
+        double v = 0;
+        if (e < npair) {
+            int a = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+            if ((a + 1) * (a + 2) / 2 <= e) a++;
+            if (a * (a + 1) / 2 > e) a--;
+            const int b = e - a * (a + 1) / 2;
+            const double *Ja = J + (a / BW) * DIM * BW + (a % BW), *Jb = J + (b / BW) * DIM * BW + (b % BW);
+#pragma unroll
+            for (int k = 0; k < DIM; k++) v += Ja[k * BW] * Jb[k * BW];
+        } else {
+            const int a = e - npair;
+            const double *Ja = J + (a / BW) * DIM * BW + (a % BW);
+#pragma unroll
+            for (int k = 0; k < DIM; k++) v += Ja[k * BW] * wr[k];
+        }
+        H[e] = v;
+    }
+}
+
+// WAVE: executed by ONE wavefront of a larger workgroup (lane ids, wave-level LDS ordering instead of barriers)
+template <bool JAC, bool WAVE>
+DEV void prior_linearize_body(const DevBatch &d, const double *pose_src, const double *sb_src, double *cost_out, int gate, int w, double *lds) {
+    const int t = WAVE ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
+    const int slots = d.n_prior_slots, N = d.N;
+    if (gate) {
+        const SolveState &ss = d.st[w];
+        if (!(ss.termination == ISV_TERM_RUNNING && (gate == 1 ? ss.need_linearize != 0 : ss.step_valid != 0))) return;
+    }
+    const int n_rp = d.n_rp[w];
+    double *sRaw = lds, *sW = lds + (size_t)slots * PRL_RAW, *sS = sW + (size_t)slots * PRL_W;
+    double *strip = d.prior_strip + (size_t)w * d.prior_strip_sz;
+    double *PH = d.prior_H + (size_t)w * d.prior_H_sz;
+    const double *poseW = pose_src + (size_t)w * N * 7;
+    // stage every sqrt_info
+    for (int s = 0; s < slots; s++) {
+        const PriorDesc p = prior_desc(d, w, s, n_rp);
+        const int n = p.kind == 1 ? 81 : (p.kind == 3 ? 4 : 36);
+        if (p.valid) for (int e = t; e < n; e += 64) sS[s * PRL_S + e] = p.S[e];
+    }
+    // ---- phase 1: raw residual / raw Jacobian blocks, one lane per prior ----
+    for (int s = t; s < slots; s += 64) {
+        double *raw = sRaw + s * PRL_RAW, *rawJ = raw + 9;
+        const int kind = s == 0 ? 0 : (s == 1 ? 1 : (s < 1 + d.Nvo ? 2 : 3));
+        Quat rr = Quat{1, 0, 0, 0};
+        double Ri[9], Rj[9], qd[3], lg[3], Jr[9];
+        const double *pi = poseW;
+        if (kind == 0) {
+            // SE3PriorFactor::Evaluate  se3_prior_factor.h:21-53
+            Quat ri = q_normalized(q_from_pose(poseW)), rp = q_from_R(d.se3[w].R);
+            rr = so3_mul(q_conj(rp), ri);
+        } else if (kind == 2) {
+            // RelativePoseFactor::Evaluate  relative_pose_factor.h:27-70
+            const isv_relpose_t &f = d.relpose[(size_t)w * (d.Nvo - 1) + (s - 2)];
+            pi = poseW + (s - 2) * 7;
+            const double *pj = pi + 7;
+            Quat Qi = q_from_pose(pi), Qj = q_from_pose(pj);
+            double dd[3], M1[9], M2[9];
+            q_to_R(Qi, Ri); q_to_R(Qj, Rj);
+#pragma unroll
+            for (int k = 0; k < 3; k++) dd[k] = pj[k] - pi[k];
+            q_rot(q_inv(Qi), dd, qd);
+            m3_mul_nt(f.delta_R, Rj, M1); m3_mul(M1, Ri, M2);
+            rr = q_from_R(M2);
+        }
+        so3_log(rr, lg);
+        if (JAC) so3_rjac_inv(lg, Jr);
+        if (kind == 0) {
+            const isv_se3_prior_t &f = d.se3[w];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { raw[k] = poseW[k] - f.t[k]; raw[3 + k] = lg[k]; }
+            if (JAC) {
+#pragma unroll
+                for (int k = 0; k < 36; k++) rawJ[k] = 0;
+                rawJ[0] = rawJ[7] = rawJ[14] = 1.0;
+#pragma unroll
+                for (int a = 0; a < 3; a++)
+#pragma unroll
+                    for (int b = 0; b < 3; b++) rawJ[(3 + a) * 6 + 3 + b] = Jr[a * 3 + b];
+            }
+        } else if (kind == 1) {
+            // Linear9Factor::Evaluate  linear9_factor.h:20-44 (Jacobian = sqrt_info)
+            const isv_linear9_t &f = d.lin9[w];
+            const double *sb = sb_src + ((size_t)w * N + (d.Nvo - 1)) * 9;
+#pragma unroll
+            for (int k = 0; k < 9; k++) raw[k] = sb[k] - f.VB[k];
+        } else if (kind == 2) {
+            const isv_relpose_t &f = d.relpose[(size_t)w * (d.Nvo - 1) + (s - 2)];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { raw[k] = f.delta_t[k] - qd[k]; raw[3 + k] = lg[k]; }
+            if (JAC) {
+                double S[9], T1[9], T2[9], nJ[9];
+                skew3(qd, S);
+#pragma unroll
+                for (int k = 0; k < 72; k++) rawJ[k] = 0;
+#pragma unroll
+                for (int k = 0; k < 9; k++) nJ[k] = -Jr[k];
+                m3_mul_nt(nJ, Ri, T1);                               // -J Ri^T
+                m3_mul(T1, Rj, T2);
+#pragma unroll
+                for (int a = 0; a < 3; a++)
+#pragma unroll
+                    for (int b = 0; b < 3; b++) {
+                        rawJ[a * 6 + b] = Ri[b * 3 + a];                 // Ri^T
+                        rawJ[a * 6 + 3 + b] = -S[a * 3 + b];
+                        rawJ[(3 + a) * 6 + 3 + b] = Jr[a * 3 + b];
+                        rawJ[36 + a * 6 + b] = -Ri[b * 3 + a];
+                        rawJ[36 + (3 + a) * 6 + 3 + b] = T2[a * 3 + b];
+                    }
+            }
+        } else if (s - 1 - d.Nvo < n_rp) {
+            // RollPitchFactor::Evaluate  rollpitch_factor.h:26-57
+            const isv_rollpitch_t &f = d.rollpitch[(size_t)w * d.max_rp + (s - 1 - d.Nvo)];
+            const double *p = poseW + f.index * 7;
+            Quat Rq = q_normalized(q_from_pose(p)), Rm = q_from_R(f.R);
+            double nZ[3] = {0, 0, -1.0}, v[3];
+            q_rot(so3_mul(Rm, q_conj(Rq)), nZ, v);
+            raw[0] = v[0]; raw[1] = v[1];
+            if (JAC) {
+                double S[9], Rmm[9], Bm[9];
+                skew3(v, S); q_to_R(Rm, Rmm); m3_mul(S, Rmm, Bm);
+#pragma unroll
+                for (int k = 0; k < 12; k++) rawJ[k] = 0;
+#pragma unroll
+                for (int a = 0; a < 2; a++)
+#pragma unroll
+                    for (int b = 0; b < 3; b++) rawJ[a * 6 + 3 + b] = Bm[a * 3 + b];
+            }
+        }
+    }
+    if (WAVE) ISV_WSYNC(); else __syncthreads();
+    // ---- phase 2: sqrt_info * [raw r | raw J] ----
+    for (int s = 0; s < slots; s++) {
+        const PriorDesc p = prior_desc(d, w, s, n_rp);
+        if (!p.valid) continue;
+        const double *raw = sRaw + s * PRL_RAW, *rawJ = raw + 9, *S = sS + s * PRL_S;
+        double *wr = sW + s * PRL_W;
+        if (p.kind == 0) prior_weight<6, 1, 6, false, JAC>(S, raw, rawJ, wr, t);
+        else if (p.kind == 1) prior_weight<9, 1, 9, true, JAC>(S, raw, rawJ, wr, t);
+        else if (p.kind == 2) prior_weight<6, 2, 6, false, JAC>(S, raw, rawJ, wr, t);
+        else prior_weight<2, 1, 6, false, JAC>(S, raw, rawJ, wr, t);
+    }
+    if (WAVE) ISV_WSYNC(); else __syncthreads();
+    // ---- phase 3: CauchyLoss corrector (scale r and J by sqrt(rho')), cost, strips ----
+    for (int s = 0; s < slots; s++) {
+        const PriorDesc p = prior_desc(d, w, s, n_rp);
+        double *wr = sW + s * PRL_W, *so = strip + p.strip_off;
+        double cost = 0.0;
+        if (!p.valid) { if (JAC) for (int e = t; e < PR_RP_SZ; e += 64) so[e] = 0.0; }
+        else if (p.kind == 0) cost = prior_correct<6, 1, 6, JAC, WAVE>(wr, so, t);
+        else if (p.kind == 1) cost = prior_correct<9, 1, 9, JAC, WAVE>(wr, so, t);
+        else if (p.kind == 2) cost = prior_correct<6, 2, 6, JAC, WAVE>(wr, so, t);
+        else cost = prior_correct<2, 1, 6, JAC, WAVE>(wr, so, t);
+        if (t == 0) cost_out[(size_t)w * slots + s] = cost;
+    }
+    if (!JAC) return;
+    if (WAVE) ISV_WSYNC(); else __syncthreads();
+    // ---- phase 4: J^T J and J^T r ----
+    for (int s = 0; s < slots; s++) {
+        const PriorDesc p = prior_desc(d, w, s, n_rp);
+        if (!p.valid) continue;
+        const double *wr = sW + s * PRL_W;
+        if (p.kind == 0) prior_H<6, 1, 6>(wr, PH + p.H_off, t);
+        else if (p.kind == 1) prior_H<9, 1, 9>(wr, PH + p.H_off, t);
+        else if (p.kind == 2) prior_H<6, 2, 6>(wr, PH + p.H_off, t);
+        else prior_H<2, 1, 6>(wr, PH + p.H_off, t);
+    }
+}

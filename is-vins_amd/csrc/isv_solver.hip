@@ -11,6 +11,8 @@
 #include <cstring>
 #include "isv_kernels.h"
 #include "isv_device_math.h"
+#include "isv_prior_factor.h"
+#include "isv_imu_factor.h"
 
 extern size_t build_solve_lds_bytes(int N, bool lds_T);
 extern size_t build_solve_lds2_bytes(int N);
@@ -156,6 +158,94 @@ __global__ __launch_bounds__(256) void k_dogleg(DevBatch d) {
         st.alpha = alpha; st.dogleg_step_norm = step_norm_scaled;
         st.step_norm = sqrt(dn_tot); st.x_norm = sqrt(xn_tot);
         st.step_valid = 1; st.iteration += 1; st.fresh = 0;
+    }
+    if (!d.lds_T) return;                  // (generic path: separate candidate kernels on the side stream)
+    // ---- IMU and prior factors at the candidate point + their model cost change, in this workgroup:
+    //      wavefront 0: raw IMU residuals (lane per factor); wavefront 1: the prior factors;
+    //      wavefronts 2, 3: model pieces  delta^T g + delta^T H delta / 2  from the J^T J blocks at x.
+    extern __shared__ __align__(16) double dyn[];
+    const int NIw = N - 1, slots = d.n_prior_slots;
+    double *sImu = dyn;                            // [NIw][16] raw residual
+    double *sMod = sImu + ISV_MAX_FRAMES * 16;     // [NIw][32] model pieces per tangent row
+    double *sPm = sMod + ISV_MAX_FRAMES * 32;      // [slots][16]
+    double *sPrior = sPm + (size_t)slots * 16;     // prior_linearize_body scratch
+    __syncthreads();                               // candidate states and delta_p are visible to the workgroup
+    const int lane = t & 63, wv = t >> 6;
+    if (wv == 0) {
+        if (lane < NIw) {
+            const size_t f = (size_t)w * NIw + lane;
+            if (!d.imu_skip[f]) {
+                const double *pi = d.cpose + ((size_t)w * N + lane) * 7, *si = d.csb + ((size_t)w * N + lane) * 9;
+                double r15[15];
+                imu_raw_residual(d.G, d.imu_in + f * ISV_IMU_IN, pi, pi + 7, si, si + 9, r15);
+#pragma unroll
+                for (int k = 0; k < 15; k++) sImu[lane * 16 + k] = r15[k];
+            }
+        }
+    } else if (wv == 1) {
+        prior_linearize_body<false, true>(d, d.cpose, d.csb, d.prior_cost_c, 0, w, sPrior);
+    } else {
+        const int tt = t - 128;
+        // IMU factor q, tangent row a (30 per factor): H row dot delta, packed pairs (max, min)
+        for (int e = tt; e < NIw * 30; e += 128) {
+            const int q = e / 30, a = e - 30 * q;
+            const double *H = d.imu_H + ((size_t)w * NIw + q) * ISV_IMU_H, *dd = dp + 15 * q;
+            double s = 0;
+            for (int b = 0; b < 30; b++) s += H[a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a] * dd[b];
+            sMod[q * 32 + a] = dd[a] * (H[465 + a] + 0.5 * s);
+        }
+        const double *PH = d.prior_H + (size_t)w * d.prior_H_sz;
+        for (int e = tt; e < slots * 12; e += 128) {
+            const int q = e / 12, a = e - 12 * q;
+            int ncol, off, c0, c1 = 0;
+            bool valid = true;
+            if (q == 0) { ncol = 6; off = PH_SE3; c0 = 0; }
+            else if (q == 1) { ncol = 9; off = PH_LIN9; c0 = 15 * (d.Nvo - 1) + 6; }
+            else if (q < 1 + d.Nvo) { const int k = q - 2; ncol = 12; off = PH_REL0 + PH_REL_SZ * k; c0 = 15 * k; c1 = 15 * (k + 1); }
+            else {
+                const int m = q - 1 - d.Nvo; ncol = 6; off = PH_REL0 + PH_REL_SZ * (d.Nvo - 1) + PH_RP_SZ * m;
+                valid = m < d.n_rp[w]; c0 = valid ? 15 * d.rollpitch[(size_t)w * d.max_rp + m].index : 0;
+            }
+            double v = 0;
+            if (valid && a < ncol) {
+                const int np2 = ncol * (ncol + 1) / 2;
+                double s = 0;
+                for (int b = 0; b < ncol; b++) {
+                    const int gb = (b < 6 || ncol != 12) ? c0 + b : c1 + b - 6;
+                    s += PH[off + (a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a)] * dp[gb];
+                }
+                const int ga = (a < 6 || ncol != 12) ? c0 + a : c1 + a - 6;
+                v = dp[ga] * (PH[off + np2 + a] + 0.5 * s);
+            }
+            sPm[q * 16 + a] = v;
+        }
+    }
+    __syncthreads();
+    // sqrt_info-weighted IMU residuals -> cost; fixed-order sums of the model pieces
+    if (t < NIw * 15) {
+        const int q = t / 15, row = t - 15 * q;
+        const size_t f = (size_t)w * NIw + q;
+        const double *S = d.imu_sqrt + f * 225 + row * 15;
+        double r = 0;
+#pragma unroll
+        for (int k = 0; k < 15; k++) r += S[k] * sImu[q * 16 + k];
+        red[t] = r * r;
+    }
+    __syncthreads();
+    if (t < NIw) {
+        const size_t f = (size_t)w * NIw + t;
+        double c2 = 0, m = 0;
+        if (!d.imu_skip[f]) {
+            for (int k = 0; k < 15; k++) c2 += red[t * 15 + k];
+            for (int a = 0; a < 30; a++) m += sMod[t * 32 + a];
+        }
+        d.imu_cost_c[f] = 0.5 * c2;                 // no loss function on IMU factors
+        d.imu_model[f] = m;
+    } else if (t >= 64 && t < 64 + slots) {
+        const int q = t - 64;
+        double m = 0;
+        for (int a = 0; a < 12; a++) m += sPm[q * 16 + a];
+        d.prior_model[(size_t)w * slots + q] = m;
     }
 }
 
@@ -441,14 +531,16 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
         else hipLaunchKernelGGL(k_build_solve<false>, dim3(d.B), dim3(512), lds_bs, st, d);
         counts[1]++;
         PROF(slot, 2, 1);
-        hipLaunchKernelGGL(k_dogleg, dim3(d.B), dim3(256), 0, st, d);
-        HCHK(hipEventRecord(fj[2], st)); HCHK(hipStreamWaitEvent(st2, fj[2], 0));
-        if (NI) hipLaunchKernelGGL(k_imu_linearize<false>, dim3((unsigned)NI), dim3(64), 0, st2, d, d.cpose, d.csb, d.imu_cost_c, 2);
-        hipLaunchKernelGGL(k_prior_linearize<false>, dim3(d.B), dim3(64), prior_lds_bytes(d.n_prior_slots), st2, d, d.cpose, d.csb, d.prior_cost_c, 2);
-        hipLaunchKernelGGL(k_model_imu_prior, dim3(d.B * d.N), dim3(64), 0, st2, d);
-        HCHK(hipEventRecord(fj[3], st2));
+        hipLaunchKernelGGL(k_dogleg, dim3(d.B), dim3(256), d.lds_T ? (ISV_MAX_FRAMES * 48 + (size_t)d.n_prior_slots * 16) * sizeof(double) + prior_lds_bytes(d.n_prior_slots) : 0, st, d);
+        if (!d.lds_T) {                    // (the LDS path evaluates these inside k_dogleg)
+            HCHK(hipEventRecord(fj[2], st)); HCHK(hipStreamWaitEvent(st2, fj[2], 0));
+            if (NI) hipLaunchKernelGGL(k_imu_linearize<false>, dim3((unsigned)NI), dim3(64), 0, st2, d, d.cpose, d.csb, d.imu_cost_c, 2);
+            hipLaunchKernelGGL(k_prior_linearize<false>, dim3(d.B), dim3(64), prior_lds_bytes(d.n_prior_slots), st2, d, d.cpose, d.csb, d.prior_cost_c, 2);
+            hipLaunchKernelGGL(k_model_imu_prior, dim3(d.B * d.N), dim3(64), 0, st2, d);
+            HCHK(hipEventRecord(fj[3], st2));
+        }
         if (d.n_tiles > 0) hipLaunchKernelGGL(k_proj_linearize<1>, dim3((d.n_tiles + 3) / 4), dim3(256), lds_proj1, st, d, d.cpose, d.clam, d.fcost_c, 2);
-        HCHK(hipStreamWaitEvent(st, fj[3], 0));
+        if (!d.lds_T) HCHK(hipStreamWaitEvent(st, fj[3], 0));
         hipLaunchKernelGGL(k_step_control, dim3(d.B), dim3(256), 0, st, d);
     }
     hipLaunchKernelGGL(k_finalize, dim3((d.B + 63) / 64), dim3(64), 0, st, d);
