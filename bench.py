@@ -107,41 +107,68 @@ def main():
     dt = time.perf_counter() - t0
     if world > 1:
         dt = sharding.max_over_ranks(dt, dist, device="cuda")
-    # per-kernel-family HIP-event timing of one more (untimed) step, on the handle's own stream
-    be.run_optimize(sync=True)
+    # per-kernel-family HIP-event timing of one more (untimed, profiled) step, on the handle's own stream
+    be.run_optimize(sync=True, profile=True)
     fam = be.last_timing(); cnt = be.last_counts()
-    sums, _ = be.download([w.clone() for w in windows[:8]]) if W <= 8 else (None, None)
 
     if rank == 0:
         ms_step = 1e3 * dt / args.steps
         value = world * W * args.steps / dt
         N, L = args.frames, args.landmarks
         Fw = Ftot / W
-        obs_tot = Ftot + W * L
+        Lw = sum(w.L for w in windows) / W
         n_lin, n_bs, n_sw = max(int(cnt[0]), 1), max(int(cnt[1]), 1), max(int(cnt[2]), 1)
-        lin_ms, sw_ms, bs_ms = float(fam[1]), float(fam[2]), float(fam[3])
-        # algorithmic work per launch over the whole batch
-        bytes_lin = Ftot * 292.0 + Ftot * 48.0                      # 60 B in + 232 B strips/cost out + 48 B w vector
-        bytes_sweep = Ftot * 224.0 + obs_tot * 48.0 + W * (36 * N * (N + 1) / 2 + 18 * N) * 8.0
-        flops_bs = W * ((15 * N) ** 3 / 3.0 + 4.0 * (15 * N) ** 2 + 2.0 * (15 * N) ** 2 / 2)   # Cholesky + 2 triangular solves + u^T T u
+        win_iters = max(int(cnt[3]), 1)                 # window-iterations that were linearised + solved (gated windows excluded)
+        lin_ms, sw_ms, r1_ms, bs_ms = float(fam[1]), float(fam[2]), float(fam[3]), float(fam[4])
+        # ALGORITHMIC work of one window-iteration
+        tvis = (36 * N * (N + 1) // 2 + 18 * N) * 8.0
+        bytes_lin = Fw * (24.0 + 280.0) + Lw * (32.0 + 104.0)      # in: factor record, observation (+ landmark depth / host point); out: 224 B strip, cost, 48 B w (+ landmark scalars, host w)
+        bytes_sweep = Fw * (26 * 8.0 + 4.0) + tvis                 # [J_i | J_j | r] of every factor once + the permutation; out: packed pose blocks, gradient, diagonal
+        bytes_rank1 = (Fw + Lw) * 48.0 + Lw * 20.0 + 2.0 * tvis    # packed w vectors, {c_l, g_l}, metadata; read-modify-write of the packed blocks
+
+        def bs_flops(N):
+            M = N // 2
+            lo = lambda i: i - 1 if i > M else 0
+            hi = lambda i: i + 1 if i < M else N - 1
+            par = lambda i: i + 1 if i < M else (i - 1 if i > M else -1)
+            fl = 0.0
+            for i in range(N):
+                nr = hi(i) - lo(i) + 1
+                fl += 2 * 9 ** 3 / 6.0 * 2                                   # Cholesky + inverse of the 9x9 block
+                fl += ((9 if par(i) >= 0 else 0) + 6 * nr + 1) * 45 * 2      # [C; Y; y^T] L^-T
+                if par(i) >= 0:
+                    fl += (45 + 54 * nr + 9) * 9 * 2                         # parent downdates
+            for I in range(N):
+                for J in range(I + 1):
+                    cover = sum(1 for i in range(N) if lo(i) <= J and I <= hi(i))
+                    fl += cover * (21 if I == J else 36) * 9 * 2             # Spp -= Y Y^T
+            for J in range(N):
+                m = N - J - 1
+                fl += 2 * 6 ** 3 / 6.0 * 2 + (6 * m + 1) * 21 * 2 + (m * (m + 1) / 2 * 36 + 6 * m) * 6 * 2
+            fl += 2 * (6 * N) ** 2 + 4 * N * 81 * 2 + 4 * sum((hi(i) - lo(i) + 1) * 54 for i in range(N)) * 2   # triangular solves + gathers
+            fl += 6.0 * (N * (N + 1) / 2 * 36 + 162 * N + sum((hi(i) - lo(i) + 1) * 54 for i in range(N)))     # scaling, u^T T u, LM diagonal
+            return fl
+        flops_bs = bs_flops(N)
         pmc = {}
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
         except Exception:
             pmc = {}
 
-        def roof(kernel, bound, work, ms_sum, launches, peak, unit, scale):
-            per = ms_sum / launches * 1e-3 if ms_sum > 0 else None
-            ach = work / per / scale if per else None
+        def roof(kernel, bound, work_per_winiter, ms_sum, launches, peak, unit, scale):
+            # achieved = algorithmic work of all launches / their total duration (gated windows do no work)
+            ach = work_per_winiter * win_iters / (ms_sum * 1e-3) / scale if ms_sum > 0 else None
             t = pmc.get(kernel, {}).get("hbm_bytes_per_launch") if pmc.get("windows_per_gpu") == W else None
             return {"kernel": kernel, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
                     "frac": (ach / peak) if ach else None, "traffic": t,
-                    "avg_launch_us": per * 1e6 if per else None, "launches_per_step": launches}
+                    "avg_launch_us": ms_sum / launches * 1e3 if ms_sum > 0 else None, "launches_per_step": launches,
+                    "algorithmic_work_per_window_iteration": work_per_winiter}
 
-        roofs = [roof("k_build_solve_lds", "mfma", flops_bs, bs_ms, n_bs, FP64_PEAK_TFLOPS, "TFLOP/s", 1e12),
-                 roof("k_sweep", "hbm", bytes_sweep, sw_ms, n_sw, HBM_PEAK_GBS, "GB/s", 1e9),
-                 roof("k_proj_linearize<0>", "hbm", bytes_lin, lin_ms, n_lin, HBM_PEAK_GBS, "GB/s", 1e9)]
-        sums = {"k_build_solve_lds": bs_ms, "k_sweep": sw_ms, "k_proj_linearize<0>": lin_ms}
+        roofs = [roof("k_build_solve_sb", "mfma", flops_bs, bs_ms, n_bs, FP64_PEAK_TFLOPS, "TFLOP/s", 1e12),
+                 roof("k_proj_linearize<0>", "hbm", bytes_lin, lin_ms, n_lin, HBM_PEAK_GBS, "GB/s", 1e9),
+                 roof("k_sweep_mfma", "hbm", bytes_sweep, sw_ms, n_sw, HBM_PEAK_GBS, "GB/s", 1e9),
+                 roof("k_rank1_mfma", "hbm", bytes_rank1, r1_ms, n_sw, HBM_PEAK_GBS, "GB/s", 1e9)]
+        sums = {"k_build_solve_sb": bs_ms, "k_proj_linearize<0>": lin_ms, "k_sweep_mfma": sw_ms, "k_rank1_mfma": r1_ms}
         dominant = max(roofs, key=lambda r: sums[r["kernel"]])
         out = {
             "metric": "sliding-window solves/sec (11 KF, ~300 landmarks)", "value": value, "unit": "windows/s",
@@ -152,7 +179,7 @@ def main():
                        "windows_per_gpu": W, "frames": N, "landmarks": L, "factors_total": Ftot, "iterations_cap": 10,
                        "parallelism": f"independent windows sharded over {world} rank(s), no data-path collective"},
             "roofline": dominant, "roofline_by_kernel": roofs,
-            "kernel_ms": {"step_total_events": float(fam[0]), "proj_linearize_sum": lin_ms, "sweep_sum": sw_ms, "build_solve_sum": bs_ms},
+            "kernel_ms": {"profiled_step_total_events": float(fam[0]), "proj_linearize_sum": lin_ms, "sweep_mfma_sum": sw_ms, "rank1_mfma_sum": r1_ms, "build_solve_sum": bs_ms, "window_iterations": win_iters},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(windows, be.cfg)

@@ -228,8 +228,10 @@ int  isv_backend_linearize(isv_backend_t *h, const isv_window_t *w,
 
 /* Device-resident batch: upload once, run many times (what bench.py times) -------------- */
 int  isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const *w);
-/* restore the uploaded initial state, then run backendOptimization on every resident window;
- * asynchronous on the handle's stream unless sync != 0                                   */
+/* restore the uploaded initial state, then run backendOptimization on every resident window.
+ * sync bit 0: wait for completion (otherwise asynchronous on the handle's stream);
+ * sync bit 1: record HIP events around the dominant kernels of every iteration (isv_batch_last_timing);
+ *             a profiling pass, a few percent slower than a plain one.                      */
 int  isv_batch_optimize(isv_backend_t *h, int32_t sync);
 /* only the factor-linearisation kernels over the resident batch */
 int  isv_batch_linearize(isv_backend_t *h, int32_t sync);
@@ -238,10 +240,12 @@ int  isv_batch_download(isv_backend_t *h, int32_t n, isv_window_t *const *w,
 int  isv_batch_sync(isv_backend_t *h);
 /* HIP-event timing of the last isv_batch_* launch sequence, milliseconds, per kernel family:
  * after isv_batch_linearize: out[0]=total, [1]=k_proj_linearize, [2]=imu+prior+reduce;
- * after isv_batch_optimize:  out[0]=total, [1]=sum k_proj_linearize<0>, [2]=sum k_sweep, [3]=sum k_build_solve*,
- * [5]=marg.  Events are recorded on the handle's own stream.                              */
+ * after isv_batch_optimize:  out[0]=total; after a profiling pass (sync bit 1) also the sums over the
+ * iterations of [1]=k_proj_linearize<0>, [2]=k_sweep_mfma, [3]=k_rank1_mfma, [4]=k_build_solve*.
+ * Events are recorded on the handle's own stream.                                          */
 int  isv_batch_last_timing(isv_backend_t *h, double out_ms[8]);
-/* launches of the dominant (projection linearise) kernel in the last run */
+/* last optimize: [0] k_proj_linearize<0> launches, [1] k_build_solve* launches, [2] k_sweep_mfma / k_rank1_mfma launches,
+ * [3] window-iterations that were linearised and solved (windows gated out of an iteration do no work) */
 int  isv_batch_last_counts(isv_backend_t *h, int64_t out[8]);
 
 #ifdef __cplusplus

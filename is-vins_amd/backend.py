@@ -124,8 +124,9 @@ class Backend:
         self._check(self.lib.isv_batch_upload(self.h, len(windows), self._ptrs(windows)), "upload")
         self._n = len(windows)
 
-    def run_optimize(self, sync=True):
-        self._check(self.lib.isv_batch_optimize(self.h, 1 if sync else 0), "batch_optimize")
+    def run_optimize(self, sync=True, profile=False):
+        """profile=True: record HIP events around the dominant kernels (read with last_timing())"""
+        self._check(self.lib.isv_batch_optimize(self.h, (1 if sync else 0) | (2 if profile else 0)), "batch_optimize")
 
     def run_linearize(self, sync=True):
         self._check(self.lib.isv_batch_linearize(self.h, 1 if sync else 0), "batch_linearize")

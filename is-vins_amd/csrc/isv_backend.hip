@@ -38,7 +38,7 @@ struct isv_backend {
         double *Ps, *Rs, *Vs, *Bas, *Bgs, *tic, *ric, *depth, *lm_pts_i, *f_pts_j, *imu_in, *imu_cov;
         int32_t *lm_off, *f_off, *lm_host, *lm_k, *lm_f0, *tile_win, *tile_f0, *tile_n, *imu_skip, *n_rp, *solve_flag, *pg_perm, *pg_off, *pg_sched, *pg_sched_off;
         FactorRec *f_rec;
-        uint32_t *lm_meta; int32_t *ck_off; int2 *ck_rec; int32_t *margin_old; double *header0;
+        uint32_t *lm_meta; int32_t *margin_old; double *header0;
         isv_se3_prior_t *se3; isv_linear9_t *lin9; isv_relpose_t *relpose; isv_rollpitch_t *rollpitch;
         SolveState *st;
         double *pose, *sb, *ex, *lam;
@@ -131,7 +131,7 @@ static int create_impl(isv_backend *h) {
     TRY(dalloc(h, &d.cost, B)); TRY(dalloc(h, &d.st, B));
     d.prior_H_sz = PH_REL0 + PH_REL_SZ * (c.n_vo - 1) + PH_RP_SZ * c.max_rollpitch;
     TRY(dalloc(h, &d.imu_H, NI * ISV_IMU_H)); TRY(dalloc(h, &d.prior_H, B * (size_t)d.prior_H_sz));
-    TRY(dalloc(h, &d.lm_meta, L)); TRY(dalloc(h, &d.ck_off, B + 1)); TRY(dalloc(h, &d.ck_rec, L + B + 1));
+    TRY(dalloc(h, &d.lm_meta, L));
     TRY(dalloc(h, &h->Ps0, B * N * 3)); TRY(dalloc(h, &h->Rs0, B * N * 9)); TRY(dalloc(h, &h->Vs0, B * N * 3));
     TRY(dalloc(h, &h->Bas0, B * N * 3)); TRY(dalloc(h, &h->Bgs0, B * N * 3)); TRY(dalloc(h, &h->depth0, L));
     TRY(dalloc(h, &h->tic0, B * 3)); TRY(dalloc(h, &h->ric0, B * 9));
@@ -147,7 +147,7 @@ static int create_impl(isv_backend *h) {
     TRY(halloc(h, &s.pg_sched, B * ((size_t)c.n_frames * (c.n_frames - 1) / 2))); TRY(halloc(h, &s.pg_sched_off, B * (ISV_SWEEP_WAVES + 1))); TRY(halloc(h, &s.imu_skip, NI)); TRY(halloc(h, &s.n_rp, B));
     TRY(halloc(h, &s.f_rec, F));
     TRY(halloc(h, &s.margin_old, B)); TRY(halloc(h, &s.header0, B));
-    TRY(halloc(h, &s.lm_meta, L)); TRY(halloc(h, &s.ck_off, B + 1)); TRY(halloc(h, &s.ck_rec, L + B + 1));
+    TRY(halloc(h, &s.lm_meta, L));
     TRY(halloc(h, &s.se3, B)); TRY(halloc(h, &s.lin9, B)); TRY(halloc(h, &s.relpose, B * (c.n_vo - 1))); TRY(halloc(h, &s.rollpitch, B * (size_t)c.max_rollpitch));
     TRY(halloc(h, &s.st, B));
     TRY(halloc(h, &s.pose, B * N * 7)); TRY(halloc(h, &s.sb, B * N * 9)); TRY(halloc(h, &s.ex, B * 7)); TRY(halloc(h, &s.lam, L));
@@ -187,7 +187,7 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
     const isv_config_t &c = h->cfg;
     const int N = c.n_frames;
     auto &s = h->h;
-    size_t L = 0, F = 0, T = 0, CK = 0;
+    size_t L = 0, F = 0, T = 0;
     for (int b = 0; b < n; b++) {
         const isv_window_t *w = ws[b];
         if (!w || !w->Ps || !w->Rs || !w->Vs || !w->Bas || !w->Bgs || !w->tic || !w->ric || !w->imu || !w->pose_prior ||
@@ -195,8 +195,7 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
             (w->n_landmarks > 0 && (!w->lm_start_frame || !w->lm_obs_ptr || !w->obs_point || !w->lm_depth)))
             return ISV_ERR_INVALID_ARG;
         if (w->n_landmarks > c.max_landmarks || w->n_obs > c.max_obs || w->n_rollpitch > c.max_rollpitch) { h->err = "window exceeds capacity"; return ISV_ERR_CAPACITY; }
-        s.lm_off[b] = (int32_t)L; s.f_off[b] = (int32_t)F; s.ck_off[b] = (int32_t)CK;
-        size_t chunk_nf = 0; bool chunk_open = false;
+        s.lm_off[b] = (int32_t)L; s.f_off[b] = (int32_t)F;
         memcpy(s.Ps + (size_t)b * N * 3, w->Ps, sizeof(double) * N * 3); memcpy(s.Rs + (size_t)b * N * 9, w->Rs, sizeof(double) * N * 9);
         memcpy(s.Vs + (size_t)b * N * 3, w->Vs, sizeof(double) * N * 3); memcpy(s.Bas + (size_t)b * N * 3, w->Bas, sizeof(double) * N * 3);
         memcpy(s.Bgs + (size_t)b * N * 3, w->Bgs, sizeof(double) * N * 3);
@@ -208,10 +207,6 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
             s.lm_host[L] = hst; s.lm_k[L] = k; s.lm_f0[L] = (int32_t)F;
             if (F - s.f_off[b] > 65535) { h->err = "more than 65535 factors in one window"; return ISV_ERR_CAPACITY; }
             s.lm_meta[L] = (uint32_t)hst | ((uint32_t)k << 8) | ((uint32_t)(F - s.f_off[b]) << 16);
-            if (!chunk_open || chunk_nf + (k - 1) > 192) {     // chunks of whole landmarks, <= 192 factors (k_build_solve_lds CHB)
-                s.ck_rec[CK + b] = make_int2((int)L, (int)F); CK++; chunk_nf = 0; chunk_open = true;
-            }
-            chunk_nf += k - 1;
             s.depth[L] = w->lm_depth[l];
             memcpy(s.lm_pts_i + L * 3, w->obs_point + (size_t)o0 * 3, 24);
             for (int o = 1; o < k; o++) {
@@ -221,8 +216,6 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
             }
             L++;
         }
-        s.ck_rec[CK + b] = make_int2((int)L, (int)F);          // sentinel of window b
-        if (h->d.lds_T && CK - s.ck_off[b] > 64) { h->err = "window has more than 64 strip chunks"; return ISV_ERR_CAPACITY; }
         // tiles of <= 64 consecutive factors made of WHOLE landmarks (the linearise kernel reduces a
         // landmark's factors inside one wavefront)
         {
@@ -294,7 +287,7 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
         s.n_rp[b] = w->n_rollpitch;
         s.margin_old[b] = w->margin_old != 0; s.header0[b] = w->header0;
     }
-    s.lm_off[n] = (int32_t)L; s.f_off[n] = (int32_t)F; s.ck_off[n] = (int32_t)CK;
+    s.lm_off[n] = (int32_t)L; s.f_off[n] = (int32_t)F;
     DevBatch &d = h->d;
     d.B = n; d.Ltot = (int32_t)L; d.Ftot = (int32_t)F; d.n_tiles = (int32_t)T;
     hipStream_t st = h->stream;
@@ -305,7 +298,7 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
     H2D(d.depth, s.depth, L); H2D(d.lm_off, s.lm_off, n + 1); H2D(d.f_off, s.f_off, n + 1);
     H2D(d.lm_host, s.lm_host, L); H2D(d.lm_k, s.lm_k, L); H2D(d.lm_f0, s.lm_f0, L); H2D(d.lm_pts_i, s.lm_pts_i, L * 3);
     H2D(d.f_rec, s.f_rec, F); H2D(d.f_pts_j, s.f_pts_j, F * 2);
-    H2D(d.lm_meta, s.lm_meta, L); H2D(d.ck_off, s.ck_off, n + 1); H2D(d.ck_rec, s.ck_rec, CK + n);
+    H2D(d.lm_meta, s.lm_meta, L);
     H2D(d.tile_win, s.tile_win, T); H2D(d.tile_f0, s.tile_f0, T); H2D(d.tile_n, s.tile_n, T);
     H2D(d.pg_perm, s.pg_perm, F); H2D(d.pg_off, s.pg_off, (size_t)n * ((size_t)N * (N - 1) / 2 + 1));
     H2D(d.pg_sched, s.pg_sched, (size_t)n * ((size_t)N * (N - 1) / 2)); H2D(d.pg_sched_off, s.pg_sched_off, (size_t)n * (ISV_SWEEP_WAVES + 1));
@@ -388,8 +381,8 @@ extern "C" int isv_batch_last_timing(isv_backend_t *h, double out_ms[8]) {
     if (hipEventElapsedTime(&ms, h->ev[0], h->ev[4]) == hipSuccess) out_ms[0] = ms;
     if (hipEventElapsedTime(&ms, h->ev[1], h->ev[2]) == hipSuccess) out_ms[1] = ms;
     if (hipEventElapsedTime(&ms, h->ev[2], h->ev[3]) == hipSuccess) out_ms[2] = ms;
-    if (h->prof_valid) {     // optimize path: [1] = sum k_proj_linearize<0>, [2] = sum k_sweep, [3] = sum k_build_solve
-        out_ms[1] = out_ms[2] = out_ms[3] = 0;
+    if (h->prof_valid) {     // profiled optimize: [1] = sum k_proj_linearize<0>, [2] = sum k_sweep_mfma, [3] = sum k_rank1_mfma, [4] = sum k_build_solve*
+        out_ms[1] = out_ms[2] = out_ms[3] = out_ms[4] = 0;
         for (int slot = 0; slot < h->cfg.num_iterations; slot++)
             for (int fam = 0; fam < ISV_PROF_FAMILIES; fam++) {
                 const size_t b = ((size_t)slot * ISV_PROF_FAMILIES + fam) * 2;
@@ -402,6 +395,12 @@ extern "C" int isv_batch_last_timing(isv_backend_t *h, double out_ms[8]) {
 extern "C" int isv_batch_last_counts(isv_backend_t *h, int64_t out[8]) {
     if (!h || !out) return ISV_ERR_INVALID_ARG;
     memcpy(out, h->last_counts, sizeof(h->last_counts));
+    if (h->d.lds_T && h->d.act) {          // [3] = window-iterations that were linearised and solved in the last optimize
+        int32_t act[ISV_MAX_TRACE];
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipMemcpy(act, h->d.act, sizeof(act), hipMemcpyDeviceToHost));
+        for (int i = 0; i < ISV_MAX_TRACE; i++) out[3] += act[i];
+    }
     return ISV_OK;
 }
 
@@ -409,14 +408,16 @@ extern "C" int isv_batch_optimize(isv_backend_t *h, int32_t sync) {
     if (!h || !h->resident) return ISV_ERR_INVALID_ARG;
     DevBatch &d = h->d; hipStream_t st = h->stream;
     memset(h->last_counts, 0, sizeof(h->last_counts));
+    HIPCHK(h, hipMemsetAsync(d.act, 0, sizeof(int32_t) * ISV_MAX_TRACE, st));
     HIPCHK(h, hipEventRecord(h->ev[0], st));
     TRY(restore_initial(h));
     hipLaunchKernelGGL(k_vector2double, dim3(d.B), dim3(64), 0, st, d);
-    int rc = isv_solver_enqueue(h->d, st, h->stream2, h->fj, h->last_counts, h->prof_ev.empty() ? nullptr : h->prof_ev.data(), h->err);
-    h->prof_valid = 1;
+    const bool profile = (sync & 2) != 0 && !h->prof_ev.empty();       // per-kernel-family events only on request
+    int rc = isv_solver_enqueue(h->d, st, h->stream2, h->fj, h->last_counts, profile ? h->prof_ev.data() : nullptr, h->err);
+    h->prof_valid = profile ? 1 : 0;
     if (rc != ISV_OK) return rc;
     HIPCHK(h, hipEventRecord(h->ev[4], st));
-    if (sync) HIPCHK(h, hipStreamSynchronize(st));
+    if (sync & 1) HIPCHK(h, hipStreamSynchronize(st));
     return ISV_OK;
 }
 

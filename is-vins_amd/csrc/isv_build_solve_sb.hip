@@ -723,6 +723,7 @@ __global__ __launch_bounds__(LS, 4) void k_build_solve_sb(DevBatch d) {
         if (t == 0) d.cost[w] = cost_w;
     }
     if (t == 0) {
+        atomicAdd(&d.act[iteration], 1);
         st.gmax = red[0];
         st.mu = mu;
         st.ls_fail = ls_fail;

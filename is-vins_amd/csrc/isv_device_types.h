@@ -107,11 +107,8 @@ struct DevBatch {
     double *imu_H;                      // [B (N-1)][ISV_IMU_H]
     double *prior_H;                    // [B][prior_H_sz]
     uint32_t *lm_meta;                  // [Ltot] host | k << 8 | (first factor - f_off[w]) << 16
-    int32_t *ck_off;                    // [B+1] chunk CSR over windows (chunks of whole landmarks, <= 64 factors)
-    int2 *ck_rec;                       // [ck_off[B] + B] {first landmark, first factor} per chunk + sentinel per window
     double *W;                          // [Ftot + Ltot][6]  w = J_pose^T J_lambda per observation (obs index = factor + landmark [+1])
-    double *Wd;                         // [Ltot][wd_ld] the same w vectors dense over the 6N pose columns (zero where a
-                                        // frame does not see the landmark; zero-filled at upload, pattern is static)
+    int32_t *act;                       // [ISV_MAX_TRACE] windows that linearised / solved in iteration i (bench bookkeeping)
     double2 *lm_cg;                     // [Ltot]  {c_l = s_l^2 / (s_l^2 E_l + mu D_l^2), g_l}
     double *Tvis;                       // [B][tvis_sz] reprojection part of the reduced system (6x6 pose corners), hd, g, bs
     int32_t prior_H_sz, tvis_sz, wd_ld, max_lm;   // wd_ld: panel width of k_rank1_mfma (6N + 1 rounded up to 16); max_lm: landmarks per window cap

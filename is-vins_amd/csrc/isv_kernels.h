@@ -21,6 +21,6 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
 static inline size_t prior_lds_bytes(int slots) { return (size_t)slots * (82 + 90 + 82) * sizeof(double); }
 __global__ void k_imu_raw(DevBatch d, const double *pose_src, const double *sb_src, int gate);
 __global__ void k_imu_weight(DevBatch d, double *cost_out, int gate);
-#define ISV_PROF_FAMILIES 3      // 0 = k_proj_linearize<0>, 1 = k_sweep, 2 = k_build_solve*
+#define ISV_PROF_FAMILIES 4      // 0 = k_proj_linearize<0>, 1 = k_sweep_mfma, 2 = k_rank1_mfma, 3 = k_build_solve*
 int isv_solver_download(DevBatch &d, hipStream_t st, int n, isv_summary_t *summary, isv_marg_result_t *marg, std::string &err);
 int isv_solver_debug_read(DevBatch &d, hipStream_t st, int what, double *out, int64_t count, std::string &err);

@@ -470,7 +470,7 @@ __global__ __launch_bounds__(256) void k_imu_raw(DevBatch d, const double *pose_
     Quat Qi = q_from_pose(pi), Qj = q_from_pose(pj);
     Quat Qii = q_inv(Qi);
     const double dt = rec[IMU_DT];
-    double dbg[3], tt[3], t2[3];
+    double dbg[3], tt[3];
     for (int k = 0; k < 3; k++) dbg[k] = si[6 + k] - rec[IMU_LBG + k];
     Quat dq = Quat{rec[IMU_DQ + 3], rec[IMU_DQ], rec[IMU_DQ + 1], rec[IMU_DQ + 2]};
     m3v(rec + IMU_DQ_DBG, dbg, tt);

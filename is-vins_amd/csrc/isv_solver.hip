@@ -5,7 +5,7 @@
 //
 // No host round trip inside the solve: every kernel reads the per-window SolveState and skips
 // windows that have terminated; the host enqueues a fixed schedule of max_iter iteration slots.
-//   slot:  [linearize if need_linearize] -> k_build_solve -> k_backsub -> k_dogleg
+//   slot:  [linearize if need_linearize] -> k_sweep_mfma -> k_rank1_mfma -> k_build_solve_sb -> k_dogleg (incl. back-substitution)
 //          -> candidate evaluation (cost + model cost change) -> k_step_control
 #include <hip/hip_runtime.h>
 #include <cstring>
@@ -15,18 +15,13 @@
 #include "isv_imu_factor.h"
 
 extern size_t build_solve_lds_bytes(int N, bool lds_T);
-extern size_t build_solve_lds2_bytes(int N);
-__global__ void k_build_solve_lds(DevBatch d);
 __global__ void k_build_solve_sb(DevBatch d);
 extern size_t build_solve_sb_bytes(int N, int prior_H_sz);
-__global__ void k_lm_prep(DevBatch d);
-__global__ void k_sweep(DevBatch d);
 __global__ void k_model_imu_prior(DevBatch d);
 __global__ void k_imu_raw(DevBatch d, const double *pose_src, const double *sb_src, int gate);
 __global__ void k_imu_weight(DevBatch d, double *cost_out, int gate);
 __global__ void k_sweep_mfma(DevBatch d);
 template <int NT> __global__ void k_rank1_mfma(DevBatch d);
-__global__ void k_backsub(DevBatch d);
 __global__ void k_marg_clear(DevBatch d);
 __global__ void k_marg_fwd(DevBatch d);
 __global__ void k_marg_bwd(DevBatch d);
@@ -443,19 +438,17 @@ int isv_solver_alloc(DevBatch &d, size_t B, size_t L, size_t F, std::vector<void
     d.tvis_sz = 36 * (d.N * (d.N + 1) / 2) + 18 * d.N;
     TRYA(dal(&d.W, (F + L) * 6, allocs, err)); TRYA(dal(&d.lm_cg, L, allocs, err));
     d.wd_ld = 16 * ((6 * d.N + 16) / 16);          // 6N pose columns + the g_l column, rounded up to 16
-    d.Wd = nullptr;
     TRYA(dal(&d.Tvis, B * (size_t)d.tvis_sz, allocs, err));
-    TRYA(dal(&d.dbg, B * 64, allocs, err));
+    TRYA(dal(&d.dbg, B * 64, allocs, err)); TRYA(dal(&d.act, ISV_MAX_TRACE, allocs, err));
     HCHK(hipMemset(d.dbg, 0, B * 64 * sizeof(double)));
     TRYA(dal(&d.marg, B, allocs, err)); TRYA(dal(&d.margin_old, B, allocs, err)); TRYA(dal(&d.header0, B, allocs, err));
     const size_t nblkT = (size_t)d.N * (d.N + 1) / 2 * 225;
-    d.lds_T = (d.N <= 11 && d.prior_H_sz <= 1024 && build_solve_lds2_bytes(d.N) <= 160 * 1024 &&
+    d.lds_T = (d.N <= 11 && d.prior_H_sz <= 1024 && build_solve_sb_bytes(d.N, d.prior_H_sz) <= 80 * 1024 &&
                (64 * (d.wd_ld + 4) + (size_t)d.max_lm * 3 + 2) * sizeof(double) <= 160 * 1024) ? 1 : 0;
     TRYA(dal(&d.Tglob, d.lds_T ? 1 : B * nblkT, allocs, err));
     d.marg_scratch_sz = 26;
     TRYA(dal(&d.marg_scratch, L * 26, allocs, err));
     if (d.lds_T) {
-        HCHK(hipFuncSetAttribute((const void *)k_build_solve_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)build_solve_lds2_bytes(d.N)));
         {
             const int lds_r1 = (int)((64 * (d.wd_ld + 4) + (size_t)d.max_lm * 3 + 2) * sizeof(double));
             HCHK(hipFuncSetAttribute((const void *)k_rank1_mfma<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_r1));
@@ -478,17 +471,11 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
 #define PROF(slot, fam, which) do { if (prof_ev) (void)hipEventRecord(prof_ev[((slot) * ISV_PROF_FAMILIES + (fam)) * 2 + (which)], st); } while (0)
     const size_t NI = (size_t)d.B * (d.N - 1);
     const size_t lds_proj = 4 * proj_lds_doubles_per_wave(d.N, 0) * sizeof(double), lds_proj1 = 4 * proj_lds_doubles_per_wave(d.N, 1) * sizeof(double);
-    if (getenv("ISV_ONE_STREAM")) st2 = st;            // diagnostics: serialise everything on one stream
-    const size_t lds_bs = d.lds_T ? build_solve_lds2_bytes(d.N) : build_solve_lds_bytes(d.N, false);
+    if (getenv("ISV_ONE_STREAM")) st2 = st;            // diagnostics: serialise everything on one stream (per-kernel timelines)
+    const size_t lds_bs = build_solve_lds_bytes(d.N, false);
     hipLaunchKernelGGL(k_init_state, dim3((d.B + 63) / 64), dim3(64), 0, st, d);
     for (int slot = 0; slot < d.max_iter; slot++) {
         // linearise where needed (k_*_linearize skip windows whose need_linearize == 0 via the tile/window flags)
-        static const int fork_late = getenv("ISV_FORK_LATE") ? atoi(getenv("ISV_FORK_LATE")) : 0;
-        if (fork_late) {
-        PROF(slot, 0, 0);
-        if (d.n_tiles > 0) { hipLaunchKernelGGL(k_proj_linearize<0>, dim3((d.n_tiles + 3) / 4), dim3(256), lds_proj, st, d, d.pose, d.lam, d.fcost, 1); counts[0]++; }
-        PROF(slot, 0, 1);
-        }
         HCHK(hipEventRecord(fj[0], st)); HCHK(hipStreamWaitEvent(st2, fj[0], 0));
         if (NI) {
             hipLaunchKernelGGL(k_imu_raw, dim3((unsigned)(NI + 63) / 64), dim3(256), 0, st2, d, d.pose, d.sb, 1);
@@ -496,22 +483,20 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
         }
         hipLaunchKernelGGL(k_prior_linearize<true>, dim3(d.B), dim3(64), prior_lds_bytes(d.n_prior_slots), st2, d, d.pose, d.sb, d.prior_cost, 1);
         HCHK(hipEventRecord(fj[1], st2));
-        if (!fork_late) {
         PROF(slot, 0, 0);
         if (d.n_tiles > 0) { hipLaunchKernelGGL(k_proj_linearize<0>, dim3((d.n_tiles + 3) / 4), dim3(256), lds_proj, st, d, d.pose, d.lam, d.fcost, 1); counts[0]++; }
         PROF(slot, 0, 1);
-        }
-        PROF(slot, 1, 0);
         if (d.lds_T) {
-            static const int sweep_old = getenv("ISV_SWEEP_OLD") ? 1 : 0;
-            if (sweep_old) hipLaunchKernelGGL(k_sweep, dim3(d.B, d.N), dim3(64), 0, st, d);
-            else hipLaunchKernelGGL(k_sweep_mfma, dim3(d.B), dim3(64 * ISV_SWEEP_WAVES), ((size_t)(d.N * (d.N - 1) / 2) * 84 + (size_t)(d.N * (d.N - 1) / 2 + 2) / 2 + 1) * sizeof(double), st, d);
+            // landmark elimination: Gram products of the pose Jacobians, then the rank-1 downdates (both FP64 MFMA)
+            PROF(slot, 1, 0);
+            hipLaunchKernelGGL(k_sweep_mfma, dim3(d.B), dim3(64 * ISV_SWEEP_WAVES), ((size_t)(d.N * (d.N - 1) / 2) * 84 + (size_t)(d.N * (d.N - 1) / 2 + 2) / 2 + 1) * sizeof(double), st, d);
             counts[2]++;
+            PROF(slot, 1, 1);
             const int nt = d.wd_ld / 16;
-            // one workgroup per window: nt(nt+1)/2 tile wavefronts + 1 rhs wavefront, W panels staged through LDS
             // one workgroup per window: nt(nt+1)/2 tile wavefronts, w vectors expanded to panel rows in LDS
             const size_t lds_r1 = (64 * (d.wd_ld + 4) + (size_t)d.max_lm * 3 + 2) * sizeof(double);
             const dim3 blk(64 * (nt * (nt + 1) / 2));
+            PROF(slot, 2, 0);
             switch (nt) {
             case 1: hipLaunchKernelGGL(k_rank1_mfma<1>, dim3(d.B), blk, lds_r1, st, d); break;
             case 2: hipLaunchKernelGGL(k_rank1_mfma<2>, dim3(d.B), blk, lds_r1, st, d); break;
@@ -519,18 +504,15 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
             case 4: hipLaunchKernelGGL(k_rank1_mfma<4>, dim3(d.B), blk, lds_r1, st, d); break;
             default: hipLaunchKernelGGL(k_rank1_mfma<5>, dim3(d.B), blk, lds_r1, st, d); break;
             }
+            PROF(slot, 2, 1);
         }
-        PROF(slot, 1, 1);
         HCHK(hipStreamWaitEvent(st, fj[1], 0));
-        static const int bs_old0 = getenv("ISV_BS_OLD") ? 1 : 0;
-        if (!d.lds_T || bs_old0) hipLaunchKernelGGL(k_cost_reduce, dim3(d.B), dim3(256), 0, st, d, d.fcost, d.imu_cost, d.prior_cost, d.cost, 1);   // (k_build_solve_sb sums the cost itself)
-        PROF(slot, 2, 0);
-        static const int bs_old = getenv("ISV_BS_OLD") ? 1 : 0;
-        if (d.lds_T && !bs_old) hipLaunchKernelGGL(k_build_solve_sb, dim3(d.B), dim3(512), build_solve_sb_bytes(d.N, d.prior_H_sz), st, d);
-        else if (d.lds_T) hipLaunchKernelGGL(k_build_solve_lds, dim3(d.B), dim3(768), lds_bs, st, d);
+        if (!d.lds_T) hipLaunchKernelGGL(k_cost_reduce, dim3(d.B), dim3(256), 0, st, d, d.fcost, d.imu_cost, d.prior_cost, d.cost, 1);   // (k_build_solve_sb sums the cost itself)
+        PROF(slot, 3, 0);
+        if (d.lds_T) hipLaunchKernelGGL(k_build_solve_sb, dim3(d.B), dim3(512), build_solve_sb_bytes(d.N, d.prior_H_sz), st, d);
         else hipLaunchKernelGGL(k_build_solve<false>, dim3(d.B), dim3(512), lds_bs, st, d);
         counts[1]++;
-        PROF(slot, 2, 1);
+        PROF(slot, 3, 1);
         hipLaunchKernelGGL(k_dogleg, dim3(d.B), dim3(256), d.lds_T ? (ISV_MAX_FRAMES * 48 + (size_t)d.n_prior_slots * 16) * sizeof(double) + prior_lds_bytes(d.n_prior_slots) : 0, st, d);
         if (!d.lds_T) {                    // (the LDS path evaluates these inside k_dogleg)
             HCHK(hipEventRecord(fj[2], st)); HCHK(hipStreamWaitEvent(st2, fj[2], 0));

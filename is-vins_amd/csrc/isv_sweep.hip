@@ -1,172 +1,18 @@
-// isv_sweep.hip -- batch-wide landmark elimination kernels (the SchurEliminator part of Ceres'
-// DENSE_SCHUR, for the problem problemSolve() builds, reference src/estimator.cpp:1057-1092).
-//
-//   k_lm_prep   one lane per landmark: E_l = J_l^T J_l, g_l = J_l^T r, host-frame w, Jacobi scale
-//               (iteration 0), dogleg diagonal, scaled gradient and the elimination weight
-//               c_l = s_l^2 / (s_l^2 E_l + mu D_l^2)  (stored with g_l as one 16-byte record).
-//   k_sweep     one WAVEFRONT per (window, frame a): block column a of the reprojection part of the
-//               reduced matrix,  sum_l [ J_p^T J_p - c_l w w^T ],  kept in registers (lane = block row
-//               (bo, r), 6 entries per lane) over all landmarks covering frame a, in landmark order
-//               (owner-computes => bitwise reproducible), then written once (6x6 pose corners only:
-//               19 KB per 11-frame window).  B*N independent wavefronts keep every SIMD busy, unlike a
-//               per-window workgroup sweep that is bound by one CU's issue rate.
-//   k_backsub   one lane per landmark: back-substitution + Cauchy-point terms from the w vectors.
+// isv_sweep.hip -- elimination of the landmarks of every window (the e-block work of ceres'
+// SchurEliminator, internal/ceres/schur_eliminator_impl.h Eliminate()), as two FP64-MFMA kernels:
+//   k_sweep_mfma   DIRECT part of the reduced camera matrix: sum over the reprojection factors of
+//                  J_p^T J_p (pose blocks), their gradient and the Jacobi-scaling diagonal, as Gram products
+//                  over (host, observer) frame-pair groups.
+//   k_rank1_mfma   the rank-1 downdates  - c_l w_l w_l^T  and the reduced right-hand side, as dense panels.
+// Both write the packed lower block triangle Tvis (6x6 pose blocks) that k_build_solve_sb assembles from.
+// The landmark scalars (E_l, g_l, Jacobi scale, w of the host frame) come from k_proj_linearize<0>; the
+// back-substitution lives in k_dogleg.
 #include <hip/hip_runtime.h>
 #include "isv_kernels.h"
 #include "isv_device_math.h"
 
-DEV int win_of_landmark(const DevBatch &d, int l) {
-    int lo = 0, hi = d.B;
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (d.lm_off[mid] <= l) lo = mid; else hi = mid; }
-    return lo;
-}
-
-__global__ __launch_bounds__(256) void k_lm_prep(DevBatch d) {
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= d.Ltot) return;
-    const int w = win_of_landmark(d, l);
-    const SolveState &st = d.st[w];
-    if (st.termination != ISV_TERM_RUNNING || !st.need_linearize) return;
-    const int k = d.lm_k[l], f0 = d.lm_f0[l];
-    double E = 0, gl = 0, wh[6] = {0, 0, 0, 0, 0, 0};
-    for (int m = 0; m < k - 1; m++) {
-        const double *s = d.strip + (size_t)(f0 + m) * ISV_PROJ_STRIP;
-        const double2 rs = *reinterpret_cast<const double2 *>(s), jl = *reinterpret_cast<const double2 *>(s + 26);
-        E += jl.x * jl.x + jl.y * jl.y; gl += jl.x * rs.x + jl.y * rs.y;
-#pragma unroll
-        for (int c = 0; c < 6; c++) wh[c] += s[2 + c] * jl.x + s[8 + c] * jl.y;
-    }
-    double sl;
-    if (st.iteration == 0) { sl = 1.0 / (1.0 + sqrt(E)); d.scale_l[l] = sl; }
-    else sl = d.scale_l[l];
-    const double Es = sl * sl * E;
-    const double Dl2 = fmin(fmax(Es, 1e-6), 1e32);
-    const double Dl = sqrt(Dl2);
-    d.lm_cg[l] = make_double2(sl * sl / (Es + st.mu * Dl2), gl);
-    d.lmE[l] = E; d.lmG[l] = gl; d.diag_l[l] = Dl; d.grad_l[l] = sl * gl / Dl;
-    double *wo = d.W + (size_t)(f0 + l) * 6;           // host observation slot
-    double *wd = d.Wd + (size_t)l * d.wd_ld + 6 * d.lm_host[l];
-#pragma unroll
-    for (int c = 0; c < 6; c++) { wo[c] = wh[c]; wd[c] = wh[c]; }
-}
-
 // Tvis layout of one window: block column a at 36 * (a N - a (a-1) / 2), block (a+bo, a) = 36 doubles
-// row-major 6x6; then hd[6N] (diag of the direct part), g[6N], bs[6N].
 __host__ __device__ inline int tvis_col(int a, int N) { return 36 * (a * N - a * (a - 1) / 2); }
-
-// DIRECT part of block column a: sum over the reprojection factors of J_p^T J_p (no landmark coupling;
-// the rank-1 downdates - c_l w w^T come from k_rank1_mfma).  Lane = (group g = lane/6, row r = lane%6):
-//   * a landmark hosted in frame a ("host" pair): group g >= 1 works on factor g-1: block (a+g, a) +=
-//     J_j^T J_i, and the partial J_i^T J_i of the host block (a, a);
-//   * landmarks that merely observe frame a: TEN of them per iteration, group g takes the g-th one and
-//     adds its J_j^T J_j to its partial of block (a, a).
-// The per-group partials of block (a, a) are folded in ascending group order at the end (fixed order =>
-// bitwise reproducible).
-__global__ __launch_bounds__(64) void k_sweep(DevBatch d) {
-    const int w = blockIdx.x, a = blockIdx.y, lane = threadIdx.x;
-    const SolveState &st = d.st[w];
-    if (st.termination != ISV_TERM_RUNNING || !st.need_linearize) return;
-    const int N = d.N, l0 = d.lm_off[w], l1 = d.lm_off[w + 1], fw0 = d.f_off[w];
-    double acc[12], dgp[12], hdp[2] = {0, 0}, ghp[2] = {0, 0};
-#pragma unroll
-    for (int i = 0; i < 12; i++) { acc[i] = 0; dgp[i] = 0; }
-    const int g0 = lane / 6, r0 = lane - 6 * g0;
-    const int g1 = (lane + 64) / 6, r1 = (lane + 64) - 6 * g1;
-
-    auto factor_update = [&](const double *s, int rofs, int cofs, int r, bool on, double *blk, double *dg, double &hd, double &gh, bool host) {
-        // rows: J[rofs + r], J[rofs + 6 + r]; column block at cofs (2 x 6); host: also the J_i^T J_i partial
-        const double x0 = s[rofs + r], x1 = s[rofs + 6 + r];
-        const double y0 = s[2 + r], y1 = s[8 + r];                 // J_i rows (host partial)
-        const double2 c01 = *reinterpret_cast<const double2 *>(s + cofs), c23 = *reinterpret_cast<const double2 *>(s + cofs + 2),
-                      c45 = *reinterpret_cast<const double2 *>(s + cofs + 4), d01 = *reinterpret_cast<const double2 *>(s + cofs + 6),
-                      d23 = *reinterpret_cast<const double2 *>(s + cofs + 8), d45 = *reinterpret_cast<const double2 *>(s + cofs + 10);
-        const double2 rs = *reinterpret_cast<const double2 *>(s);
-        const double f0 = on ? x0 : 0.0, f1 = on ? x1 : 0.0;
-        if (host) {
-            const double h0 = on ? y0 : 0.0, h1 = on ? y1 : 0.0;
-            blk[0] += f0 * c01.x + f1 * d01.x; blk[1] += f0 * c01.y + f1 * d01.y; blk[2] += f0 * c23.x + f1 * d23.x;
-            blk[3] += f0 * c23.y + f1 * d23.y; blk[4] += f0 * c45.x + f1 * d45.x; blk[5] += f0 * c45.y + f1 * d45.y;
-            dg[0] += h0 * c01.x + h1 * d01.x; dg[1] += h0 * c01.y + h1 * d01.y; dg[2] += h0 * c23.x + h1 * d23.x;
-            dg[3] += h0 * c23.y + h1 * d23.y; dg[4] += h0 * c45.x + h1 * d45.x; dg[5] += h0 * c45.y + h1 * d45.y;
-            hd += h0 * h0 + h1 * h1; gh += h0 * rs.x + h1 * rs.y;
-        } else {
-            dg[0] += f0 * c01.x + f1 * d01.x; dg[1] += f0 * c01.y + f1 * d01.y; dg[2] += f0 * c23.x + f1 * d23.x;
-            dg[3] += f0 * c23.y + f1 * d23.y; dg[4] += f0 * c45.x + f1 * d45.x; dg[5] += f0 * c45.y + f1 * d45.y;
-            hd += f0 * f0 + f1 * f1; gh += f0 * rs.x + f1 * rs.y;
-        }
-    };
-
-    for (int base = l0; base < l1; base += 64) {
-        const unsigned mm = (base + lane < l1) ? d.lm_meta[base + lane] : 0u;
-        const int hh_ = mm & 255, kk = (mm >> 8) & 255;
-        const bool cover = base + lane < l1 && a >= hh_ && a < hh_ + kk;
-        unsigned long long maskH = __ballot(cover && hh_ == a), maskN = __ballot(cover && hh_ != a);
-        while (maskH) {                                   // landmarks hosted in frame a, one per iteration
-            const int bit = __builtin_ctzll(maskH);
-            maskH &= maskH - 1;
-            const unsigned m0 = __builtin_amdgcn_readlane(mm, bit);
-            const int k = (m0 >> 8) & 255, f0 = fw0 + (int)(m0 >> 16);
-            {
-                const bool on = g0 >= 1 && g0 < k;
-                const double *s = d.strip + (size_t)(f0 + (on ? g0 - 1 : 0)) * ISV_PROJ_STRIP;
-                factor_update(s, 14, 2, r0, on, acc, dgp, hdp[0], ghp[0], true);
-            }
-            if (k > 10) {                                  // groups 10.. live in the second lane set
-                const bool on = g1 >= 1 && g1 < k;
-                const double *s = d.strip + (size_t)(f0 + (on ? g1 - 1 : 0)) * ISV_PROJ_STRIP;
-                factor_update(s, 14, 2, r1, on, acc + 6, dgp + 6, hdp[1], ghp[1], true);
-            }
-        }
-        while (maskN) {                                   // observers of frame a, ten per iteration
-            int mybit = 0; bool on = false;
-#pragma unroll
-            for (int sl = 0; sl < 10; sl++) {
-                if (maskN) {
-                    const int bit = __builtin_ctzll(maskN);
-                    maskN &= maskN - 1;
-                    if (g0 == sl) { mybit = bit; on = true; }
-                }
-            }
-            const unsigned m0 = __shfl(mm, mybit);
-            const int h = m0 & 255, f0 = fw0 + (int)(m0 >> 16);
-            const double *s = d.strip + (size_t)(on ? f0 + (a - h) - 1 : fw0) * ISV_PROJ_STRIP;
-            factor_update(s, 14, 14, r0, on, acc, dgp, hdp[0], ghp[0], false);
-        }
-    }
-    // fold the per-group partials of block (a, a), its diagonal and the gradient into group 0
-    __shared__ double red[128 * 8];
-#pragma unroll
-    for (int step = 0; step < 2; step++) {
-        double *o = red + (step * 64 + lane) * 8;
-#pragma unroll
-        for (int c = 0; c < 6; c++) o[c] = dgp[6 * step + c];
-        o[6] = hdp[step]; o[7] = ghp[step];
-    }
-    __syncthreads();
-    double hd = 0, gacc = 0;
-    if (g0 == 0) {
-#pragma unroll
-        for (int c = 0; c < 6; c++) acc[c] = 0;             // group 0 has no off-diagonal block of its own
-        for (int g = 0; g < 21; g++) {                       // 126 lane slots = 21 groups
-            const double *o = red + (6 * g + r0) * 8;
-#pragma unroll
-            for (int c = 0; c < 6; c++) acc[c] += o[c];
-            hd += o[6]; gacc += o[7];
-        }
-    }
-    double *out = d.Tvis + (size_t)w * d.tvis_sz;
-    const int colbase = tvis_col(a, N), tail = 36 * (N * (N + 1) / 2);
-#pragma unroll
-    for (int step = 0; step < 2; step++) {
-        const int bo = step ? g1 : g0, r = step ? r1 : r0;
-        if (a + bo < N) {
-            double *o = out + colbase + bo * 36 + r * 6;
-#pragma unroll
-            for (int c = 0; c < 6; c++) o[c] = acc[6 * step + c];
-            if (bo == 0) { out[tail + 6 * a + r] = hd; out[tail + 6 * N + 6 * a + r] = gacc; }
-        }
-    }
-}
 
 // DIRECT part as FP64 MFMA Gram products.  The factors of a window are sorted by (host h, observer j)
 // frame pair at upload (pg_perm / pg_off).  For one pair the stacked rows X = [J_i | J_j | r] (2 rows
@@ -174,10 +20,10 @@ __global__ __launch_bounds__(64) void k_sweep(DevBatch d) {
 // instruction, A and B operands are the same register):
 //     G[0:6, 0:6] = sum J_i^T J_i  (part of block (h,h))     G[6:12, 0:6]  = sum J_j^T J_i = block (j,h)
 //     G[6:12,6:12] = sum J_j^T J_j (part of block (j,j))     G[0:6,12], G[6:12,12] = J_i^T r, J_j^T r
-// The pair groups are spread over the 16 wavefronts of the workgroup by a longest-first schedule built
+// The pair groups are spread over the ISV_SWEEP_WAVES wavefronts of the workgroup by a longest-first schedule built
 // at upload (pg_sched); every group leaves its five pieces in LDS / Tvis, then the (a,a) blocks, the
 // Jacobi diagonal and the gradient are folded in a fixed order (bitwise reproducible, no atomics).
-// Every strip is read exactly once (the scalar k_sweep read it twice and was issue / latency bound).
+// Every strip is read exactly once.
 typedef double double4s __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(64 * ISV_SWEEP_WAVES) void k_sweep_mfma(DevBatch d) {
     extern __shared__ __align__(16) double lds[];
@@ -358,30 +204,3 @@ template __global__ void k_rank1_mfma<3>(DevBatch);
 template __global__ void k_rank1_mfma<4>(DevBatch);
 template __global__ void k_rank1_mfma<5>(DevBatch);
 
-// back-substitution of the eliminated landmarks (schur_eliminator BackSubstitute) + the landmark
-// terms of the Cauchy-point denominator, from the w vectors (48 B per observation).
-__global__ __launch_bounds__(256) void k_backsub(DevBatch d) {
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l >= d.Ltot) return;
-    const int w = win_of_landmark(d, l);
-    const SolveState &st = d.st[w];
-    if (st.termination != ISV_TERM_RUNNING || !st.fresh || st.ls_fail) return;
-    const int n = d.np, h = d.lm_host[l], k = d.lm_k[l], f0 = d.lm_f0[l];
-    const double *zp = d.zp + (size_t)w * n, *up = d.up + (size_t)w * n;
-    const double *wv = d.W + (size_t)(f0 + l) * 6;
-    double wz = 0, wu = 0;        // w_l^T z_p, w_l^T u_p
-    for (int o = 0; o < k; o++) {
-        const double2 w01 = *reinterpret_cast<const double2 *>(wv + 6 * o), w23 = *reinterpret_cast<const double2 *>(wv + 6 * o + 2),
-                      w45 = *reinterpret_cast<const double2 *>(wv + 6 * o + 4);
-        const double *z = zp + 15 * (h + o), *u = up + 15 * (h + o);
-        wz += w01.x * z[0] + w01.y * z[1] + w23.x * z[2] + w23.y * z[3] + w45.x * z[4] + w45.y * z[5];
-        wu += w01.x * u[0] + w01.y * u[1] + w23.x * u[2] + w23.y * u[3] + w45.x * u[4] + w45.y * u[5];
-    }
-    const double sl = d.scale_l[l], E = d.lmE[l], gl = d.lmG[l], Dl = d.diag_l[l];
-    const double Es = sl * sl * E, Dl2 = Dl * Dl;
-    // scaled-space y_l = (g'_l - w'_l^T y_p) / (E'_l + mu D_l^2),  w'^T y_p = s_l w^T (Sc_p y_p) = s_l wz
-    const double yl = (sl * gl - sl * wz) / (Es + st.mu * Dl2);
-    d.gn_l[l] = -Dl * yl;
-    const double ul = sl * sl * gl / Dl2, cl = sl * sl / (Es + st.mu * Dl2);
-    d.lm_aterm[l] = cl * wu * wu + 2.0 * ul * wu + E * ul * ul;
-}
