@@ -445,9 +445,14 @@ __global__ __launch_bounds__(MT) void k_marg_fwd(DevBatch d) {
 
 // MargBackward
 __global__ __launch_bounds__(MT) void k_marg_bwd(DevBatch d) {
-    __shared__ double Lam[900], M1[450], M2[450], Wk[1500], Vv[441], wv[32], JU[441], Jr[441], tmp[128];
+    // LDS is what limits residency (one wavefront per window, all windows should be resident at once next to
+    // k_marg_fwd's): Lam (30x30) is dead once the 21x21 marginal Lp exists, so the recovered-factor Jacobian Jr
+    // and the projection scratch JU live in its space; M1 (Lp) is dead after the eigen-decomposition copy and
+    // then holds the block-diagonal information Xall; Vv is dead once (Jr U) is formed and then holds Ak.
+    __shared__ double Lam[900], M1[450], M2[450], Wk[900], Vv[441], wv[32], tmp[128];
     __shared__ double sJ[2 * 36];
     __shared__ int keep[32], piv[4];
+    double *const Jr = Lam, *const JU = Lam + 441;
     const int w = blockIdx.x, t = threadIdx.x;
     isv_marg_result_t &out = d.marg[w];
     if (!d.margin_old[w]) return;
@@ -580,7 +585,7 @@ __global__ __launch_bounds__(MT) void k_marg_bwd(DevBatch d) {
 #endif
     MSTAMP(6);
     {
-        double *Sg = Wk, *Xi = Wk + 100, *Xall = Wk + 1000;      // Xall: 21x21 block-diagonal information
+        double *Sg = Wk, *Xi = Wk + 100, *Xall = M1;             // Xall: 21x21 block-diagonal information (M1 is free now)
         for (int e = t; e < 441; e += MT) Xall[e] = 0.0;
         SYNC();
         // the five recovered blocks: relpose rows 0..5, VB rows 6..14, roll-pitch 15..16, |position| 17..19, yaw 20
@@ -620,13 +625,13 @@ __global__ __launch_bounds__(MT) void k_marg_bwd(DevBatch d) {
         for (int e = t; e < 441; e += MT) { const int a = e / 21, b = e % 21; double s = 0; for (int k = 0; k < 21; k++) s += JUa[k * 21 + a] * XJU[k * 21 + b]; A[e] = s; }
         SYNC();
         // restrict A to kept indices (rank x rank) in Wk+1000.. and evaluate trace / determinants
-        double *Ak = Wk + 1000;
+        double *Ak = Vv;                                  // (Vv was consumed by JUa above)
         if (t == 0) {
             int ia = 0;
             for (int a = 0; a < 21; a++) if (keep[a]) { int ib = 0; for (int b = 0; b < 21; b++) if (keep[b]) { Ak[ia * rank + ib] = A[a * 21 + b]; ib++; } ia++; }
         }
         SYNC();
-        const double ldA = w_logdet_spd(Ak, rank, Lam, t);
+        const double ldA = w_logdet_spd(Ak, rank, JU, t);
         if (t == 0) {
             double tr = 0, ldinv = 0; int ia = 0;
             for (int a = 0; a < 21; a++) if (keep[a]) { tr += Ak[ia * rank + ia] / wv[a]; ldinv += log(1.0 / wv[a]); ia++; }
