@@ -317,24 +317,36 @@ __global__ __launch_bounds__(256) void k_step_control(DevBatch d) {
 
 // ------------------------------------------------------------------------------------------
 // after the solve: update() of every prior (estimator.cpp:1133-1144), then double2vector (:518-594)
-__global__ void k_finalize(DevBatch d) {
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= d.B) return;
+__global__ __launch_bounds__(64) void k_finalize(DevBatch d) {
+    // one wavefront per window: lane roles for the prior updates, lane per frame for double2vector, lanes over
+    // the landmarks for the depths
+    const int w = blockIdx.x, lane = threadIdx.x;
     const int N = d.N, v = d.Nvo - 1;
     const double *pose = d.pose + (size_t)w * N * 7, *sb = d.sb + (size_t)w * N * 9;
     double *Ps = d.Ps + (size_t)w * N * 3, *Rs = d.Rs + (size_t)w * N * 9, *Vs = d.Vs + (size_t)w * N * 3;
     double *Bas = d.Bas + (size_t)w * N * 3, *Bgs = d.Bgs + (size_t)w * N * 3;
-    // Linear9Factor::update  linear9_factor.h:60-68
-    {
+    // ---- double2vector, part 1: the yaw re-anchoring rotation from the OLD Rs[0] / Ps[0] (every lane) ----
+    double origin_R0[3], origin_P0[3], origin_R00[3], R00[9], rot_diff[9], Rs0[9];
+    for (int k = 0; k < 9; k++) Rs0[k] = Rs[k];
+    R2ypr(Rs0, origin_R0);
+    for (int k = 0; k < 3; k++) origin_P0[k] = Ps[k];
+    q_to_R(q_from_pose(pose), R00);
+    R2ypr(R00, origin_R00);
+    const double y_diff = origin_R0[0] - origin_R00[0];
+    double ypr[3] = {y_diff, 0, 0};
+    ypr2R(ypr, rot_diff);
+    if (fabs(fabs(origin_R0[1]) - 90) < 1.0 || fabs(fabs(origin_R00[1]) - 90) < 1.0) m3_mul_nt(Rs0, R00, rot_diff);
+    // ---- update() of the prior factors (pseudo-measurement shift), one lane each; they read the old Ps / Rs ----
+    if (lane == 0) {
+        // Linear9Factor::update  linear9_factor.h:60-68
         isv_linear9_t &f = d.lin9[w];
         for (int k = 0; k < 3; k++) {
             f.VB[k] += sb[9 * v + k] - Vs[3 * v + k];
             f.VB[3 + k] += sb[9 * v + 3 + k] - Bas[3 * v + k];
             f.VB[6 + k] += sb[9 * v + 6 + k] - Bgs[3 * v + k];
         }
-    }
-    // SE3PriorFactor::update  se3_prior_factor.h:73-81
-    {
+    } else if (lane == 1) {
+        // SE3PriorFactor::update  se3_prior_factor.h:73-81
         isv_se3_prior_t &f = d.se3[w];
         Quat R0 = q_from_R(Rs), R1 = q_normalized(q_from_pose(pose));
         double dR[3], E[9], Rn[9];
@@ -342,55 +354,55 @@ __global__ void k_finalize(DevBatch d) {
         for (int k = 0; k < 3; k++) f.t[k] += pose[k] - Ps[k];
         q_to_R(so3_exp(dR), E); m3_mul(f.R, E, Rn);
         for (int k = 0; k < 9; k++) f.R[k] = Rn[k];
+    } else if (lane < 32) {
+        // RelativePoseFactor::update (solver overload)  relative_pose_factor.h:103-117
+        for (int i = lane - 2; i < d.Nvo - 1; i += 30) {
+            isv_relpose_t &f = d.relpose[(size_t)w * (d.Nvo - 1) + i];
+            const double *PSi = pose + 7 * i, *PSj = pose + 7 * (i + 1);
+            const double *ti = Ps + 3 * i, *tj = Ps + 3 * (i + 1), *Ri = Rs + 9 * i, *Rj = Rs + 9 * (i + 1);
+            Quat Qi = q_from_pose(PSi), Qj = q_from_pose(PSj);
+            double d_tj[3], d_ti[3], A[9], Bm[9], Qm[9];
+            for (int k = 0; k < 3; k++) { d_tj[k] = PSj[k] - tj[k]; d_ti[k] = PSi[k] - ti[k]; }
+            q_to_R(q_inv(Qj), Qm); m3_mul(Qm, Rj, A); Quat d_Rj = q_from_R(A);
+            q_to_R(q_inv(Qi), Qm); m3_mul(Qm, Ri, Bm); Quat d_Ri = q_from_R(Bm);
+            double lgi[3], lgj[3], v1[3], v2[3], S[9], v3[3];
+            so3_log(d_Ri, lgi); so3_log(d_Rj, lgj);
+            m3tv(Ri, d_tj, v1); m3tv(Ri, d_ti, v2);
+            skew3(f.delta_t, S); m3v(S, lgi, v3);
+            for (int k = 0; k < 3; k++) f.delta_t[k] += v1[k] - v2[k] + v3[k];
+            double Ji[9], ww[3], E[9], T[9];
+            q_to_R(q_mul(q_inv(Qj), Qi), Ji);
+            for (int k = 0; k < 9; k++) Ji[k] = -Ji[k];
+            m3v(Ji, lgi, ww);
+            q_to_R(so3_exp(ww), E); m3_mul(f.delta_R, E, T); for (int k = 0; k < 9; k++) f.delta_R[k] = T[k];
+            q_to_R(so3_exp(lgj), E); m3_mul(f.delta_R, E, T); for (int k = 0; k < 9; k++) f.delta_R[k] = T[k];
+        }
+    } else {
+        // RollPitchFactor::update  rollpitch_factor.h:78-83
+        for (int m = lane - 32; m < d.n_rp[w]; m += 32) {
+            isv_rollpitch_t &f = d.rollpitch[(size_t)w * d.max_rp + m];
+            const int idx = f.index;
+            Quat R0 = q_from_R(Rs + 9 * idx), R1 = q_normalized(q_from_pose(pose + 7 * idx));
+            double dR[3], E[9], T[9];
+            so3_log(so3_mul(q_conj(R1), R0), dR);
+            q_to_R(so3_exp(dR), E); m3_mul(f.R, E, T); for (int k = 0; k < 9; k++) f.R[k] = T[k];
+        }
     }
-    // RelativePoseFactor::update (solver overload)  relative_pose_factor.h:103-117
-    for (int i = 0; i < d.Nvo - 1; i++) {
-        isv_relpose_t &f = d.relpose[(size_t)w * (d.Nvo - 1) + i];
-        const double *PSi = pose + 7 * i, *PSj = pose + 7 * (i + 1);
-        const double *ti = Ps + 3 * i, *tj = Ps + 3 * (i + 1), *Ri = Rs + 9 * i, *Rj = Rs + 9 * (i + 1);
-        Quat Qi = q_from_pose(PSi), Qj = q_from_pose(PSj);
-        double d_tj[3], d_ti[3], A[9], Bm[9], Qm[9];
-        for (int k = 0; k < 3; k++) { d_tj[k] = PSj[k] - tj[k]; d_ti[k] = PSi[k] - ti[k]; }
-        q_to_R(q_inv(Qj), Qm); m3_mul(Qm, Rj, A); Quat d_Rj = q_from_R(A);
-        q_to_R(q_inv(Qi), Qm); m3_mul(Qm, Ri, Bm); Quat d_Ri = q_from_R(Bm);
-        double lgi[3], lgj[3], v1[3], v2[3], S[9], v3[3];
-        so3_log(d_Ri, lgi); so3_log(d_Rj, lgj);
-        m3tv(Ri, d_tj, v1); m3tv(Ri, d_ti, v2);
-        skew3(f.delta_t, S); m3v(S, lgi, v3);
-        for (int k = 0; k < 3; k++) f.delta_t[k] += v1[k] - v2[k] + v3[k];
-        double Ji[9], ww[3], E[9], T[9];
-        q_to_R(q_mul(q_inv(Qj), Qi), Ji);
-        for (int k = 0; k < 9; k++) Ji[k] = -Ji[k];
-        m3v(Ji, lgi, ww);
-        q_to_R(so3_exp(ww), E); m3_mul(f.delta_R, E, T); for (int k = 0; k < 9; k++) f.delta_R[k] = T[k];
-        q_to_R(so3_exp(lgj), E); m3_mul(f.delta_R, E, T); for (int k = 0; k < 9; k++) f.delta_R[k] = T[k];
-    }
-    // RollPitchFactor::update  rollpitch_factor.h:78-83
-    for (int m = 0; m < d.n_rp[w]; m++) {
-        isv_rollpitch_t &f = d.rollpitch[(size_t)w * d.max_rp + m];
-        const int idx = f.index;
-        Quat R0 = q_from_R(Rs + 9 * idx), R1 = q_normalized(q_from_pose(pose + 7 * idx));
-        double dR[3], E[9], T[9];
-        so3_log(so3_mul(q_conj(R1), R0), dR);
-        q_to_R(so3_exp(dR), E); m3_mul(f.R, E, T); for (int k = 0; k < 9; k++) f.R[k] = T[k];
-    }
-    // ---- double2vector ------------------------------------------------------------------
-    double origin_R0[3], origin_P0[3], origin_R00[3], R00[9], rot_diff[9];
-    R2ypr(Rs, origin_R0);
-    for (int k = 0; k < 3; k++) origin_P0[k] = Ps[k];
-    q_to_R(q_from_pose(pose), R00);
-    R2ypr(R00, origin_R00);
-    const double y_diff = origin_R0[0] - origin_R00[0];
-    double ypr[3] = {y_diff, 0, 0};
-    ypr2R(ypr, rot_diff);
-    if (fabs(fabs(origin_R0[1]) - 90) < 1.0 || fabs(fabs(origin_R00[1]) - 90) < 1.0) m3_mul_nt(Rs, R00, rot_diff);
-    {
-        double tt[3], Rn[9];
+    __syncthreads();                       // every update has read the old window states and written its prior
+    // ---- double2vector, part 2 ----------------------------------------------------------------
+    if (lane == 0) {
+        double tt[3];
         m3v(rot_diff, d.lin9[w].VB + 6, tt); for (int k = 0; k < 3; k++) d.lin9[w].VB[6 + k] = tt[k];     // :549 (gyro-bias slot)
+    } else if (lane == 1) {
+        double Rn[9];
         m3_mul(rot_diff, d.se3[w].R, Rn); for (int k = 0; k < 9; k++) d.se3[w].R[k] = Rn[k];               // :550
+    } else if (lane == 2) {
+        const double *ex = d.ex + (size_t)w * 7;
+        for (int k = 0; k < 3; k++) d.tic[(size_t)w * 3 + k] = ex[k];
+        q_to_R(q_from_pose(ex), d.ric + (size_t)w * 9);
     }
     const double p0[3] = {pose[0], pose[1], pose[2]};
-    for (int i = 0; i < N; i++) {
+    for (int i = lane; i < N; i += 64) {
         double Ri[9], dd[3], tt[3], Ro[9];
         q_to_R(q_normalized(q_from_pose(pose + 7 * i)), Ri);
         m3_mul(rot_diff, Ri, Ro);
@@ -401,10 +413,7 @@ __global__ void k_finalize(DevBatch d) {
         m3v(rot_diff, sb + 9 * i, tt);
         for (int k = 0; k < 3; k++) { Vs[3 * i + k] = tt[k]; Bas[3 * i + k] = sb[9 * i + 3 + k]; Bgs[3 * i + k] = sb[9 * i + 6 + k]; }
     }
-    const double *ex = d.ex + (size_t)w * 7;
-    for (int k = 0; k < 3; k++) d.tic[(size_t)w * 3 + k] = ex[k];
-    q_to_R(q_from_pose(ex), d.ric + (size_t)w * 9);
-    for (int l = d.lm_off[w]; l < d.lm_off[w + 1]; l++) {        // FeatureManager::setDepth :145-163
+    for (int l = d.lm_off[w] + lane; l < d.lm_off[w + 1]; l += 64) {        // FeatureManager::setDepth :145-163
         const double dep = 1.0 / d.lam[l];
         d.depth[l] = dep;
         d.solve_flag[l] = (dep < 0 || dep > 10) ? 2 : 1;
@@ -525,7 +534,7 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
         if (!d.lds_T) HCHK(hipStreamWaitEvent(st, fj[3], 0));
         hipLaunchKernelGGL(k_step_control, dim3(d.B), dim3(256), 0, st, d);
     }
-    hipLaunchKernelGGL(k_finalize, dim3((d.B + 63) / 64), dim3(64), 0, st, d);
+    hipLaunchKernelGGL(k_finalize, dim3(d.B), dim3(64), 0, st, d);
     // MargForward and MargBackward are independent: run them side by side
     hipLaunchKernelGGL(k_marg_clear, dim3(d.B), dim3(64), 0, st, d);
     HCHK(hipEventRecord(fj[0], st)); HCHK(hipStreamWaitEvent(st2, fj[0], 0));
