@@ -104,6 +104,7 @@ static int create_impl(isv_backend *h) {
     d.N = c.n_frames; d.Nvo = c.n_vo; d.np = 15 * c.n_frames; d.max_rp = c.max_rollpitch; d.max_iter = c.num_iterations;
     d.n_prior_slots = 2 + (c.n_vo - 1) + c.max_rollpitch;
     d.max_lm = c.max_landmarks > 1 ? c.max_landmarks : 1;
+    d.force_retry = getenv("ISV_DEBUG_FORCE_RETRY") ? atoi(getenv("ISV_DEBUG_FORCE_RETRY")) : 0;
     d.prior_strip_sz = PR_REL0 + PR_REL_SZ * (c.n_vo - 1) + PR_RP_SZ * c.max_rollpitch;
     memcpy(d.proj_sqrt_info, c.proj_sqrt_info, sizeof(d.proj_sqrt_info));
     memcpy(d.G, c.gravity, sizeof(d.G));

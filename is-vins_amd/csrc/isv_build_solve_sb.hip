@@ -562,7 +562,7 @@ __global__ __launch_bounds__(LS, 4) void k_build_solve_sb(DevBatch d) {
         }
         __syncthreads();
         STAMP(6);
-        if (flag[0]) {
+        if (flag[0] || attempt < d.force_retry) {
             mu *= 10.0; attempt++;
             __syncthreads();
             if (t == 0) flag[0] = 0;

@@ -111,6 +111,7 @@ struct DevBatch {
     int32_t *act;                       // [ISV_MAX_TRACE] windows that linearised / solved in iteration i (bench bookkeeping)
     double2 *lm_cg;                     // [Ltot]  {c_l = s_l^2 / (s_l^2 E_l + mu D_l^2), g_l}
     double *Tvis;                       // [B][tvis_sz] reprojection part of the reduced system (6x6 pose corners), hd, g, bs
+    int32_t force_retry, _pad4;            // test hook (env ISV_DEBUG_FORCE_RETRY): treat the first n factorisations of an iteration as failed
     int32_t prior_H_sz, tvis_sz, wd_ld, max_lm;   // wd_ld: panel width of k_rank1_mfma (6N + 1 rounded up to 16); max_lm: landmarks per window cap
     int32_t marg_scratch_sz, lds_T;     // lds_T: reduced system lives in LDS (15N <= 165)
 };

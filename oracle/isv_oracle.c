@@ -237,6 +237,11 @@ static void jac_left_mul(const problem_t *P, const double *r_in, double *g /* nc
 
 /* DENSE_SCHUR: min |J y - r|^2 + |D y|^2 with the landmarks eliminated (schur_eliminator_impl.h,
  * dense Cholesky on the reduced system, back substitution).  Returns 0 ok, 1 = LINEAR_SOLVER_FAILURE */
+/* test hook: treat the first n linear solves of every iteration as failed (exercises the mu x 10 retry of
+ * DoglegStrategy::ComputeGaussNewtonStep, which well-posed windows never reach) */
+static int g_force_retry = 0;
+void isvo_debug_force_retry(int n) { g_force_retry = n; }
+
 static int dense_schur_solve(const problem_t *P, const double *D, double *y) {
     int np = P->np, L = P->L, N = P->N;
     double *S = (double *)calloc((size_t)np * np, 8), *g = (double *)calloc(np, 8);
@@ -371,7 +376,9 @@ static void minimize(problem_t *P, int max_iter, isv_summary_t *sum) {
             jac_right_mul(P, tmp, Jg);
             alpha = dotn(gradient, gradient, n) / dotn(Jg, Jg, P->nres);
             ls_fail = 1;
+            int forced = g_force_retry;
             while (mu < max_mu) {
+                if (forced > 0) { forced--; mu *= mu_inc; continue; }
                 for (int i = 0; i < n; i++) lmD[i] = diag[i] * sqrt(mu);
                 if (dense_schur_solve(P, lmD, gn)) { mu *= mu_inc; continue; }
                 ls_fail = 0; break;

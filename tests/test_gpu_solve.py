@@ -136,3 +136,41 @@ def test_margin_new_skips_marginalisation(oracle, be):
     g = w.clone()
     sg, mg = be.optimize(g)
     assert mg.valid == 0 and mg.n_marg_landmarks == 0
+
+
+@pytest.mark.parametrize("n_frames,n_vo,n_lm", [(4, 2, 40), (6, 3, 80), (7, 4, 90), (8, 4, 100), (10, 6, 120), (11, 8, 150)])
+def test_window_geometries_match_oracle(oracle, n_frames, n_vo, n_lm):
+    """other window shapes on the LDS path: odd / even N (the two speed/bias chains have equal / unequal
+    length), small N (fewer MFMA panel tiles, k_rank1_mfma<NT> variants), Nvo != 5 (more / fewer prior slots)"""
+    b = backend.Backend(n_frames, n_vo, max_landmarks=n_lm, max_obs=n_lm * n_frames, max_batch=4)
+    try:
+        ws = synth.make_windows([40, 41], n_frames=n_frames, n_vo=n_vo, n_landmarks=n_lm)
+        batch = [w.clone() for w in ws]
+        sums, margs = b.optimize_batch(batch)
+        for w, g, s, m in zip(ws, batch, sums, margs):
+            o, so, mo = oracle_run(oracle, b.cfg, w)
+            check_window(o, so, g, s)
+            check_marg(mo, m, w.Nvo)
+    finally:
+        b.close()
+
+
+@pytest.mark.parametrize("n_forced", [1, 2])
+def test_forced_mu_retry_matches_oracle(oracle, monkeypatch, n_forced):
+    """the mu x 10 retry of the Gauss-Newton solve (a failed factorisation) is never reached by well-posed windows,
+    so both sides get the same fault injected: the first n factorisations of every iteration count as failed.  On
+    the GPU the retry corrects the landmark part of the reduced system in place (T' = T - sum dc_l w_l w_l^T)
+    instead of re-eliminating; the oracle re-eliminates from scratch like ceres."""
+    monkeypatch.setenv("ISV_DEBUG_FORCE_RETRY", str(n_forced))
+    b = backend.Backend(11, 5, max_landmarks=300, max_obs=3300, max_batch=2)      # the hook is read at create
+    monkeypatch.delenv("ISV_DEBUG_FORCE_RETRY")
+    oracle.isvo_debug_force_retry(n_forced)
+    try:
+        w = synth.make_window(7)
+        o, so, _ = oracle_run(oracle, b.cfg, w)
+        g = w.clone()
+        sg, _ = b.optimize(g)
+        check_window(o, so, g, sg)
+    finally:
+        oracle.isvo_debug_force_retry(0)
+        b.close()
