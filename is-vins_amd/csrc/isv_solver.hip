@@ -55,9 +55,13 @@ DEV double block_sum(double v, double *red, int t) {
 
 // DoglegStrategy::ComputeTraditionalDoglegStep + undo of the scalings + Evaluator::Plus.
 // One workgroup per running window.
-__global__ __launch_bounds__(256) void k_dogleg(DevBatch d) {
+#ifdef ISV_STAMP
+#define DSTAMP(k) do { if (t == (k >= 56 ? 64 : 0)) { unsigned long long now_ = wall_clock64(); d.dbg[(size_t)w * 64 + (k)] += (double)(now_ - (k >= 56 ? t1_last : t_last)); if (k >= 56) t1_last = now_; else t_last = now_; } } while (0)
+#else
+#define DSTAMP(k) do {} while (0)
+#endif
+__global__ __launch_bounds__(256, 4) void k_dogleg(DevBatch d) {
     __shared__ double red[256];
-    __shared__ double sdz[2 * ISV_MAX_FRAMES * 15];
     const int w = blockIdx.x, t = threadIdx.x;
     SolveState &st = d.st[w];
     if (st.termination != ISV_TERM_RUNNING) return;
@@ -69,12 +73,16 @@ __global__ __launch_bounds__(256) void k_dogleg(DevBatch d) {
         if (t == 0) { st.step_valid = 0; st.iteration += 1; st.fresh = 0; }
         return;
     }
+#ifdef ISV_STAMP
+    unsigned long long t_last = wall_clock64(), t1_last = t_last;
+#endif
     double a = 0, b = 0, c = 0, e = 0;
     for (int i = t; i < n; i += 256) { a += gp[i] * gp[i]; b += gnp[i] * gnp[i]; c += gp[i] * gnp[i]; }
     if (st.fresh) {
         // back-substitution of the eliminated landmarks (schur_eliminator BackSubstitute) + the landmark
         // terms of the Cauchy-point denominator, from the w vectors (one landmark per thread and pass)
-        double *zs = sdz, *us = sdz + ISV_MAX_FRAMES * 15;
+        extern __shared__ __align__(16) double dyn0[];
+        double *zs = dyn0, *us = dyn0 + n;       // (this space is reused by the candidate evaluation below)
         for (int i = t; i < n; i += 256) { zs[i] = d.zp[(size_t)w * n + i]; us[i] = d.up[(size_t)w * n + i]; }
         __syncthreads();
         const double mu = st.mu;
@@ -102,6 +110,7 @@ __global__ __launch_bounds__(256) void k_dogleg(DevBatch d) {
         const double gl = d.grad_l[l], nl = d.gn_l[l];
         a += gl * gl; b += nl * nl; c += gl * nl; e += d.lm_aterm[l];
     }
+    DSTAMP(48);
     const double g2 = block_sum<256>(a, red, t), gn2 = block_sum<256>(b, red, t), gdotgn = block_sum<256>(c, red, t);
     const double aterm = block_sum<256>(e, red, t);
     double alpha = st.alpha;
@@ -148,6 +157,7 @@ __global__ __launch_bounds__(256) void k_dogleg(DevBatch d) {
         for (int k = 0; k < 9; k++) { const double v = sb[k] + dp[15 * i + 6 + k]; sc[k] = v; const double df = sb[k] - v; dn += df * df; xn += sb[k] * sb[k]; }
     }
     for (int l = l0 + t; l < l1; l += 256) { const double df = d.lam[l] - d.clam[l]; dn += df * df; xn += d.lam[l] * d.lam[l]; }
+    DSTAMP(49);
     const double dn_tot = block_sum<256>(dn, red, t), xn_tot = block_sum<256>(xn, red, t);
     if (t == 0) {
         st.alpha = alpha; st.dogleg_step_norm = step_norm_scaled;
@@ -161,10 +171,14 @@ __global__ __launch_bounds__(256) void k_dogleg(DevBatch d) {
     extern __shared__ __align__(16) double dyn[];
     const int NIw = N - 1, slots = d.n_prior_slots;
     double *sImu = dyn;                            // [NIw][16] raw residual
-    double *sMod = sImu + ISV_MAX_FRAMES * 16;     // [NIw][32] model pieces per tangent row
-    double *sPm = sMod + ISV_MAX_FRAMES * 32;      // [slots][16]
+    double *sMod = sImu + NIw * 16;                // [NIw][32] model pieces per tangent row
+    double *sPm = sMod + NIw * 32;                 // [slots][16]
     double *sPrior = sPm + (size_t)slots * 16;     // prior_linearize_body scratch
     __syncthreads();                               // candidate states and delta_p are visible to the workgroup
+    DSTAMP(50);
+#ifdef ISV_STAMP
+    t1_last = wall_clock64();
+#endif
     const int lane = t & 63, wv = t >> 6;
     if (wv == 0) {
         if (lane < NIw) {
@@ -215,7 +229,10 @@ __global__ __launch_bounds__(256) void k_dogleg(DevBatch d) {
             sPm[q * 16 + a] = v;
         }
     }
+    DSTAMP(51);
+    DSTAMP(56);
     __syncthreads();
+    DSTAMP(52);
     // sqrt_info-weighted IMU residuals -> cost; fixed-order sums of the model pieces
     if (t < NIw * 15) {
         const int q = t / 15, row = t - 15 * q;
@@ -242,6 +259,7 @@ __global__ __launch_bounds__(256) void k_dogleg(DevBatch d) {
         for (int a = 0; a < 12; a++) m += sPm[q * 16 + a];
         d.prior_model[(size_t)w * slots + q] = m;
     }
+    DSTAMP(53);
 }
 
 
@@ -522,7 +540,7 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
         else hipLaunchKernelGGL(k_build_solve<false>, dim3(d.B), dim3(512), lds_bs, st, d);
         counts[1]++;
         PROF(slot, 3, 1);
-        hipLaunchKernelGGL(k_dogleg, dim3(d.B), dim3(256), d.lds_T ? (ISV_MAX_FRAMES * 48 + (size_t)d.n_prior_slots * 16) * sizeof(double) + prior_lds_bytes(d.n_prior_slots) : 0, st, d);
+        hipLaunchKernelGGL(k_dogleg, dim3(d.B), dim3(256), (d.lds_T ? ((size_t)(d.N - 1) * 48 + (size_t)d.n_prior_slots * 16) * sizeof(double) + prior_lds_bytes(d.n_prior_slots) : 0) + 2 * (size_t)d.np * sizeof(double), st, d);
         if (!d.lds_T) {                    // (the LDS path evaluates these inside k_dogleg)
             HCHK(hipEventRecord(fj[2], st)); HCHK(hipStreamWaitEvent(st2, fj[2], 0));
             if (NI) hipLaunchKernelGGL(k_imu_linearize<false>, dim3((unsigned)NI), dim3(64), 0, st2, d, d.cpose, d.csb, d.imu_cost_c, 2);
