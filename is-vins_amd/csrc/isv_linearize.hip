@@ -594,10 +594,13 @@ __global__ __launch_bounds__(64) void k_imu_weight(DevBatch d, double *cost_out,
     __syncthreads();
     double *H = d.imu_H + (size_t)f * ISV_IMU_H;
     for (int e = t; e < ISV_IMU_H; e += 64) H[e] = sH[e];
-    // strip layout: [r15 | 15x6 | 15x9 | 15x6 | 15x9] row-major blocks
+    // strip layout: [r15 | 15x6 | 15x9 | 15x6 | 15x9] row-major blocks.  The LDS solver path works from the J^T J
+    // blocks alone (k_build_solve_sb, k_dogleg), so the strips are only written for the linearise API (gate 0)
+    // and for the generic path
     double *out = d.imu_strip + (size_t)f * ISV_IMU_STRIP;
-    if (t < 15) out[t] = sJw[t * 32 + 30];
-    for (int e = t; e < 450; e += 64) {
+    const bool want_strip = gate == 0 || !d.lds_T;
+    if (want_strip && t < 15) out[t] = sJw[t * 32 + 30];
+    for (int e = t; want_strip && e < 450; e += 64) {
         int row, c;
         if (e < 90) { row = e / 6; c = e - 6 * row; }
         else if (e < 225) { const int q = e - 90; row = q / 9; c = 6 + (q - 9 * row); }
