@@ -31,6 +31,12 @@
 #define STAMP(k) do {} while (0)
 #endif
 #define LS 512                     // threads (8 wavefronts); two workgroups per CU
+__host__ __device__ inline int sb_nred(int N, int prior_H_sz) {   // doubles in the shared reduction / staging buffer
+    int m = LS;
+    if (prior_H_sz > m) m = prior_H_sz;
+    if (36 * N > m) m = 36 * N;
+    return (m + 1) & ~1;
+}
 #define RCH 32                     // landmarks per staged chunk of the retry correction
 
 DEV int sblk(int I, int J, int N) { return (J * N - J * (J - 1) / 2 + (I - J)) * 36; }   // I >= J
@@ -88,7 +94,12 @@ DEV bool chol_inv_block(double *A, int lane) {
     return bad;
 }
 
-__global__ __launch_bounds__(LS, 4) void k_build_solve_sb(DevBatch d) {
+// BIG = false: N <= 11, two workgroups per CU (<= 128 VGPRs), register prefetch of the assembly, chain back-
+//               substitution with all nodes of a chain in one register;
+// BIG = true:  N <= 20 (one workgroup per CU: the system needs up to ~160 KB of LDS), plain loops instead of the
+//               fixed-size register stages.
+template <bool BIG>
+__global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) {
     extern __shared__ __align__(16) double lds[];
     const int w = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
     SolveState &st = d.st[w];
@@ -102,10 +113,10 @@ __global__ __launch_bounds__(LS, 4) void k_build_solve_sb(DevBatch d) {
     double *D = p; p += n;
     double *y = p; p += n;
     double *u = p; p += n;
-    const int nred = d.prior_H_sz > LS ? ((d.prior_H_sz + 1) & ~1) : LS;    // reductions; also stages the prior blocks
+    const int nred = sb_nred(N, d.prior_H_sz);     // reductions; also stages the prior blocks and the chain gather partials
     double *red = p; p += nred;
-    int *yo = (int *)p; p += 8;              // yo[0..N]: offsets of the fill blocks of each chain node (N <= 15)
-    int *skipL = (int *)p; p += 8;           // imu_skip flags of this window
+    int *yo = (int *)p; p += 16;             // yo[0..N]: offsets of the fill blocks of each chain node (N <= 31)
+    int *skipL = (int *)p; p += 16;          // imu_skip flags of this window
     int *flag = (int *)p; p += 2;
     double *Spp = p; p += nS;                // pose-pose, packed lower block triangle of 6x6 blocks (Tvis layout)
     double *Dss = p; p += N * 81;            // speed/bias diagonal blocks -> inverse Cholesky factors
@@ -158,8 +169,10 @@ __global__ __launch_bounds__(LS, 4) void k_build_solve_sb(DevBatch d) {
         const double *H = d.imu_H + (size_t)w * (N - 1) * ISV_IMU_H;
         const double *PH = d.prior_H + (size_t)w * d.prior_H_sz;
         double vS[5], vT[3] = {0, 0, 0}, vF[3], vX[5], vG = 0, vP[2] = {0, 0};
+        if (!BIG) {
 #pragma unroll
-        for (int k = 0; k < 5; k++) { const int e = t + k * LS; vS[k] = e < nS ? V[e] : 0.0; }
+            for (int k = 0; k < 5; k++) { const int e = t + k * LS; vS[k] = e < nS ? V[e] : 0.0; }
+        }
         if (t < n6) { vT[0] = V[nS + t]; vT[1] = V[nS + n6 + t]; vT[2] = V[nS + 2 * n6 + t]; }
         if (t < d.prior_H_sz) vP[0] = PH[t];
         if (t + LS < d.prior_H_sz) vP[1] = PH[t + LS];
@@ -231,10 +244,12 @@ __global__ __launch_bounds__(LS, 4) void k_build_solve_sb(DevBatch d) {
                 if (I < M) Css[I * 81 + r * 9 + c] = v; else Css[(I + 1) * 81 + c * 9 + r] = v;
             }
         };
+        if (!BIG) {
 #pragma unroll
-        for (int k = 0; k < 3; k++) { const int e = t + k * LS; vF[k] = e < N * 120 ? imu_frame_fetch(e) : 0.0; }
+            for (int k = 0; k < 3; k++) { const int e = t + k * LS; vF[k] = e < N * 120 ? imu_frame_fetch(e) : 0.0; }
 #pragma unroll
-        for (int k = 0; k < 5; k++) { const int e = t + k * LS; vX[k] = e < (N - 1) * 225 ? imu_pair_fetch(e) : 0.0; }
+            for (int k = 0; k < 5; k++) { const int e = t + k * LS; vX[k] = e < (N - 1) * 225 ? imu_pair_fetch(e) : 0.0; }
+        }
         if (t < n) {
             const int I = t / 15, r = t - 15 * I;
             if (I >= 1 && !skipL[I - 1]) vG += H[(size_t)(I - 1) * ISV_IMU_H + 465 + 15 + r];
@@ -242,8 +257,11 @@ __global__ __launch_bounds__(LS, 4) void k_build_solve_sb(DevBatch d) {
         }
         // ---- reprojection part from k_sweep / k_rank1_mfma (same packed layout) ----------------------
         for (int e = t; e < n; e += LS) { g[e] = 0.0; bs[e] = 0.0; hdiag[e] = 0.0; }
+        if (BIG) { for (int e = t; e < nS; e += LS) Spp[e] = V[e]; }
+        else {
 #pragma unroll
-        for (int k = 0; k < 5; k++) { const int e = t + k * LS; if (e < nS) Spp[e] = vS[k]; }
+            for (int k = 0; k < 5; k++) { const int e = t + k * LS; if (e < nS) Spp[e] = vS[k]; }
+        }
         __syncthreads();
         if (t < n6) {
             const int fa = t / 6, r = t - 6 * fa;
@@ -253,18 +271,9 @@ __global__ __launch_bounds__(LS, 4) void k_build_solve_sb(DevBatch d) {
             for (int l = l0 + t; l < l1; l += LS) gmax_l = fmax(gmax_l, fabs(d.lmG[l]));
         } else {
             // ---- mu retry: T -= sum_l (c_l(mu) - c_l(mu0)) w_l w_l^T, bs -= sum_l dc_l g_l w_l --------
-            double *wS = Dss;                               // [RCH][67] staging (Dss/Css/Ysb are rebuilt below)
+            double *wS = Dss;                               // [RCH][n6 + 1] staging (Dss/Css/Ysb are rebuilt below)
             double *dC = red, *dG = red + RCH;
-            int ra[5], cb[5];
-            double accs[5];
-#pragma unroll
-            for (int k = 0; k < 5; k++) {
-                const int e = t + k * LS;
-                int I = 0, J = 0, r = 0, c = 0;
-                if (e < nS) spp_decode(e, I, J, r, c);
-                ra[k] = 6 * I + r; cb[k] = 6 * J + c; accs[k] = 0;
-            }
-            double accb = 0;
+            const int wld = n6 + 1;
             for (int lb = l0; lb < l1; lb += RCH) {
                 const int cnt = (l1 - lb) < RCH ? (l1 - lb) : RCH;
                 __syncthreads();
@@ -272,7 +281,7 @@ __global__ __launch_bounds__(LS, 4) void k_build_solve_sb(DevBatch d) {
                     const int r = e / n6, c = e - r * n6;
                     const unsigned m0 = d.lm_meta[lb + r];
                     const int h6 = 6 * (int)(m0 & 255), k6 = 6 * (int)((m0 >> 8) & 255);
-                    wS[r * 67 + c] = (c >= h6 && c < h6 + k6) ? d.W[(size_t)(d.f_off[w] + (int)(m0 >> 16) + lb + r) * 6 + (c - h6)] : 0.0;
+                    wS[r * wld + c] = (c >= h6 && c < h6 + k6) ? d.W[(size_t)(d.f_off[w] + (int)(m0 >> 16) + lb + r) * 6 + (c - h6)] : 0.0;
                 }
                 if (t < cnt) {
                     const int l = lb + t;
@@ -283,18 +292,20 @@ __global__ __launch_bounds__(LS, 4) void k_build_solve_sb(DevBatch d) {
                     dC[t] = dc; dG[t] = dc * cg.y;
                 }
                 __syncthreads();
-                for (int l = 0; l < cnt; l++) {
-                    const double *wr = wS + l * 67;
-                    const double dc = dC[l];
-#pragma unroll
-                    for (int k = 0; k < 5; k++) accs[k] += dc * wr[ra[k]] * wr[cb[k]];
-                    if (t < n6) accb += dG[l] * wr[t];
+                for (int e = t; e < nS; e += LS) {               // owner-computes: entry e of the packed pose blocks
+                    int I, J, r, c;
+                    spp_decode(e, I, J, r, c);
+                    const int ra = 6 * I + r, cb = 6 * J + c;
+                    double acc = 0;
+                    for (int l = 0; l < cnt; l++) acc += dC[l] * wS[l * wld + ra] * wS[l * wld + cb];
+                    Spp[e] -= acc;
+                }
+                if (t < n6) {
+                    double accb = 0;
+                    for (int l = 0; l < cnt; l++) accb += dG[l] * wS[l * wld + t];
+                    bs[15 * (t / 6) + t % 6] -= accb;
                 }
             }
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < 5; k++) { const int e = t + k * LS; if (e < nS) Spp[e] -= accs[k]; }
-            if (t < n6) bs[15 * (t / 6) + t % 6] -= accb;
             __syncthreads();
         }
         for (int e = t; e < 162 * N + ytot; e += LS) Dss[e] = 0.0;      // Dss, Css, Ysb are contiguous
@@ -302,10 +313,15 @@ __global__ __launch_bounds__(LS, 4) void k_build_solve_sb(DevBatch d) {
         if (t + LS < nred) red[t + LS] = vP[1];
         __syncthreads();
         STAMP(0);
+        if (BIG) {
+            for (int e = t; e < N * 120; e += LS) imu_frame_apply(e, imu_frame_fetch(e));
+            for (int e = t; e < (N - 1) * 225; e += LS) if (!skipL[e / 225]) imu_pair_apply(e, imu_pair_fetch(e));
+        } else {
 #pragma unroll
-        for (int k = 0; k < 3; k++) { const int e = t + k * LS; if (e < N * 120) imu_frame_apply(e, vF[k]); }
+            for (int k = 0; k < 3; k++) { const int e = t + k * LS; if (e < N * 120) imu_frame_apply(e, vF[k]); }
 #pragma unroll
-        for (int k = 0; k < 5; k++) { const int e = t + k * LS; if (e < (N - 1) * 225 && !skipL[e / 225]) imu_pair_apply(e, vX[k]); }
+            for (int k = 0; k < 5; k++) { const int e = t + k * LS; if (e < (N - 1) * 225 && !skipL[e / 225]) imu_pair_apply(e, vX[k]); }
+        }
         if (t < n) g[t] += vG;
         __syncthreads();
         STAMP(1);
@@ -606,8 +622,8 @@ __global__ __launch_bounds__(LS, 4) void k_build_solve_sb(DevBatch d) {
         }
         __syncthreads();
         // chain rhs -= Y_i^T x_pose: thread = (speed/bias row, quarter of the pose blocks), folded in fixed order
-        if (t < 36 * N) {
-            const int o = t >> 2, part = t & 3, i = o / 9, c = o - 9 * i, lo = nlo(i, M), nr = nhi(i, M, N) - lo + 1;
+        for (int tq = t; tq < 36 * N; tq += LS) {
+            const int o = tq >> 2, part = tq & 3, i = o / 9, c = o - 9 * i, lo = nlo(i, M), nr = nhi(i, M, N) - lo + 1;
             const double *Yc = Ysb + yo[i] + c;
             double s = 0;
             for (int a = part; a < nr; a += 4) {
@@ -615,7 +631,7 @@ __global__ __launch_bounds__(LS, 4) void k_build_solve_sb(DevBatch d) {
 #pragma unroll
                 for (int r = 0; r < 6; r++) s += Yc[(a * 6 + r) * 9] * xa[r];
             }
-            red[t] = s;
+            red[tq] = s;
         }
         __syncthreads();
         if (t < 9 * N) {
@@ -625,6 +641,27 @@ __global__ __launch_bounds__(LS, 4) void k_build_solve_sb(DevBatch d) {
         __syncthreads();
         // chains, reverse elimination order: x_i = L_i^-T (z_i - C_i^T x_parent); wavefront 0 takes M and the
         // forward chain (lane = 9 i + c), wavefront 1 the backward chain (lane = 9 (i - M - 1) + c)
+        if (BIG) {
+            // long windows: one node at a time on lanes 0..8, the parent's x through LDS
+            auto node_bwd_lds = [&](int i, int pp) {
+                const int cl = lane < 9 ? lane : 0;
+                double sv = y[15 * i + 6 + cl];
+                if (pp >= 0) {
+#pragma unroll
+                    for (int k = 0; k < 9; k++) sv -= Css[i * 81 + k * 9 + cl] * y[15 * pp + 6 + k];
+                }
+                double x = 0;
+#pragma unroll
+                for (int k = 0; k < 9; k++) x += Dss[i * 81 + k * 9 + cl] * readlane_d2(sv, k);
+                WSYNC();
+                if (lane < 9) y[15 * i + 6 + lane] = x;
+                WSYNC();
+            };
+            if (wv == 0) node_bwd_lds(M, -1);
+            __syncthreads();
+            if (wv == 0) { for (int i = M - 1; i >= 0; i--) node_bwd_lds(i, i + 1); }
+            else if (wv == 1) { for (int i = M + 1; i <= N - 1; i++) node_bwd_lds(i, i - 1); }
+        } else {
         if (wv < 2) {
             const int q9 = lane / 9, c9 = lane - 9 * q9;
             const int mynode = wv == 0 ? q9 : M + 1 + q9;
@@ -690,6 +727,7 @@ __global__ __launch_bounds__(LS, 4) void k_build_solve_sb(DevBatch d) {
             else { for (int i = M + 1; i <= N - 1; i++) node_bwd(i, i - 1, i - 1 == M); }
             if (has) y[15 * mynode + 6 + c9] = ys;
         }
+        }
         __syncthreads();
         STAMP(7);
         break;
@@ -740,14 +778,17 @@ __global__ __launch_bounds__(LS, 4) void k_build_solve_sb(DevBatch d) {
     STAMP(8);
 }
 
+template __global__ void k_build_solve_sb<false>(DevBatch);
+template __global__ void k_build_solve_sb<true>(DevBatch);
+
 size_t build_solve_sb_bytes(int N, int prior_H_sz) {
     const int M = N / 2;
     size_t ytot = 0;
     for (int i = 0; i < N; i++) ytot += (size_t)((i < M ? i + 1 : N - 1) - (i > M ? i - 1 : 0) + 1) * 54;
     const size_t n = 15 * (size_t)N, nS = (size_t)N * (N + 1) / 2 * 36;
     size_t tail = 162 * (size_t)N + ytot;
-    const size_t stage = (size_t)RCH * 67;                      // retry staging lives in the Dss/Css/Ysb region
+    const size_t stage = (size_t)RCH * (6 * (size_t)N + 1);     // retry staging lives in the Dss/Css/Ysb region
     if (tail < stage) tail = stage;
-    const size_t nred = prior_H_sz > LS ? (size_t)((prior_H_sz + 1) & ~1) : LS;
-    return (7 * n + nred + 8 + 8 + 2 + nS + tail + 2) * sizeof(double);
+    const size_t nred = (size_t)sb_nred(N, prior_H_sz);
+    return (7 * n + nred + 16 + 16 + 2 + nS + tail + 2) * sizeof(double);
 }

@@ -15,13 +15,13 @@
 #include "isv_imu_factor.h"
 
 extern size_t build_solve_lds_bytes(int N, bool lds_T);
-__global__ void k_build_solve_sb(DevBatch d);
+template <bool BIG> __global__ void k_build_solve_sb(DevBatch d);
 extern size_t build_solve_sb_bytes(int N, int prior_H_sz);
 __global__ void k_model_imu_prior(DevBatch d);
 __global__ void k_imu_raw(DevBatch d, const double *pose_src, const double *sb_src, int gate);
 __global__ void k_imu_weight(DevBatch d, double *cost_out, int gate);
 __global__ void k_sweep_mfma(DevBatch d);
-template <int NT> __global__ void k_rank1_mfma(DevBatch d);
+template <int NT, int TPW> __global__ void k_rank1_mfma(DevBatch d);
 __global__ void k_marg_clear(DevBatch d);
 __global__ void k_marg_fwd(DevBatch d);
 __global__ void k_marg_bwd(DevBatch d);
@@ -234,21 +234,22 @@ __global__ __launch_bounds__(256, 4) void k_dogleg(DevBatch d) {
     __syncthreads();
     DSTAMP(52);
     // sqrt_info-weighted IMU residuals -> cost; fixed-order sums of the model pieces
-    if (t < NIw * 15) {
-        const int q = t / 15, row = t - 15 * q;
+    double *sR2 = sPrior;                          // (the prior scratch is free again)
+    for (int tq = t; tq < NIw * 15; tq += 256) {
+        const int q = tq / 15, row = tq - 15 * q;
         const size_t f = (size_t)w * NIw + q;
         const double *S = d.imu_sqrt + f * 225 + row * 15;
         double r = 0;
 #pragma unroll
         for (int k = 0; k < 15; k++) r += S[k] * sImu[q * 16 + k];
-        red[t] = r * r;
+        sR2[tq] = r * r;
     }
     __syncthreads();
     if (t < NIw) {
         const size_t f = (size_t)w * NIw + t;
         double c2 = 0, m = 0;
         if (!d.imu_skip[f]) {
-            for (int k = 0; k < 15; k++) c2 += red[t * 15 + k];
+            for (int k = 0; k < 15; k++) c2 += sR2[t * 15 + k];
             for (int a = 0; a < 30; a++) m += sMod[t * 32 + a];
         }
         d.imu_cost_c[f] = 0.5 * c2;                 // no loss function on IMU factors
@@ -470,21 +471,24 @@ int isv_solver_alloc(DevBatch &d, size_t B, size_t L, size_t F, std::vector<void
     HCHK(hipMemset(d.dbg, 0, B * 64 * sizeof(double)));
     TRYA(dal(&d.marg, B, allocs, err)); TRYA(dal(&d.margin_old, B, allocs, err)); TRYA(dal(&d.header0, B, allocs, err));
     const size_t nblkT = (size_t)d.N * (d.N + 1) / 2 * 225;
-    d.lds_T = (d.N <= 11 && d.prior_H_sz <= 1024 && build_solve_sb_bytes(d.N, d.prior_H_sz) <= 80 * 1024 &&
-               (64 * (d.wd_ld + 4) + (size_t)d.max_lm * 3 + 2) * sizeof(double) <= 160 * 1024) ? 1 : 0;
+    // LDS-resident fast path: the structure-aware solve (two windows per CU up to N = 11, one beyond), the pair
+    // partials of k_sweep_mfma and the panel + landmark tables of k_rank1_mfma must fit the 160 KB of a CU
+    const size_t lds_r1 = (64 * (size_t)(d.wd_ld + 4) + (size_t)d.max_lm * 3 + 2) * sizeof(double);
+    const size_t lds_sw = ((size_t)(d.N * (d.N - 1) / 2) * 84 + (size_t)(d.N * (d.N - 1) / 2 + 2) / 2 + 1) * sizeof(double);
+    const size_t lds_sb = build_solve_sb_bytes(d.N, d.prior_H_sz);
+    d.lds_T = (d.N <= 20 && d.wd_ld <= 128 && d.prior_H_sz <= 1024 && lds_sb <= (d.N <= 11 ? 80u : 160u) * 1024 &&
+               lds_r1 <= 160 * 1024 && lds_sw <= 160 * 1024) ? 1 : 0;
     TRYA(dal(&d.Tglob, d.lds_T ? 1 : B * nblkT, allocs, err));
     d.marg_scratch_sz = 26;
     TRYA(dal(&d.marg_scratch, L * 26, allocs, err));
     if (d.lds_T) {
-        {
-            const int lds_r1 = (int)((64 * (d.wd_ld + 4) + (size_t)d.max_lm * 3 + 2) * sizeof(double));
-            HCHK(hipFuncSetAttribute((const void *)k_rank1_mfma<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_r1));
-            HCHK(hipFuncSetAttribute((const void *)k_rank1_mfma<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_r1));
-            HCHK(hipFuncSetAttribute((const void *)k_rank1_mfma<3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_r1));
-            HCHK(hipFuncSetAttribute((const void *)k_rank1_mfma<4>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_r1));
-            HCHK(hipFuncSetAttribute((const void *)k_rank1_mfma<5>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_r1));
-        }
-        HCHK(hipFuncSetAttribute((const void *)k_build_solve_sb, hipFuncAttributeMaxDynamicSharedMemorySize, (int)build_solve_sb_bytes(d.N, d.prior_H_sz)));
+#define SETLDS(K, BYTES) HCHK(hipFuncSetAttribute((const void *)K, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES)))
+        SETLDS((k_rank1_mfma<1, 1>), lds_r1); SETLDS((k_rank1_mfma<2, 1>), lds_r1); SETLDS((k_rank1_mfma<3, 1>), lds_r1);
+        SETLDS((k_rank1_mfma<4, 1>), lds_r1); SETLDS((k_rank1_mfma<5, 1>), lds_r1); SETLDS((k_rank1_mfma<6, 2>), lds_r1);
+        SETLDS((k_rank1_mfma<7, 2>), lds_r1); SETLDS((k_rank1_mfma<8, 3>), lds_r1);
+        SETLDS(k_sweep_mfma, lds_sw);
+        if (d.N <= 11) SETLDS(k_build_solve_sb<false>, lds_sb); else SETLDS(k_build_solve_sb<true>, lds_sb);
+#undef SETLDS
     }
     else HCHK(hipFuncSetAttribute((const void *)k_build_solve<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)build_solve_lds_bytes(d.N, false)));
     return ISV_OK;
@@ -522,21 +526,23 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
             const int nt = d.wd_ld / 16;
             // one workgroup per window: nt(nt+1)/2 tile wavefronts, w vectors expanded to panel rows in LDS
             const size_t lds_r1 = (64 * (d.wd_ld + 4) + (size_t)d.max_lm * 3 + 2) * sizeof(double);
-            const dim3 blk(64 * (nt * (nt + 1) / 2));
-            PROF(slot, 2, 0);
             switch (nt) {
-            case 1: hipLaunchKernelGGL(k_rank1_mfma<1>, dim3(d.B), blk, lds_r1, st, d); break;
-            case 2: hipLaunchKernelGGL(k_rank1_mfma<2>, dim3(d.B), blk, lds_r1, st, d); break;
-            case 3: hipLaunchKernelGGL(k_rank1_mfma<3>, dim3(d.B), blk, lds_r1, st, d); break;
-            case 4: hipLaunchKernelGGL(k_rank1_mfma<4>, dim3(d.B), blk, lds_r1, st, d); break;
-            default: hipLaunchKernelGGL(k_rank1_mfma<5>, dim3(d.B), blk, lds_r1, st, d); break;
+            case 1: hipLaunchKernelGGL((k_rank1_mfma<1, 1>), dim3(d.B), dim3(64 * 1), lds_r1, st, d); break;
+            case 2: hipLaunchKernelGGL((k_rank1_mfma<2, 1>), dim3(d.B), dim3(64 * 3), lds_r1, st, d); break;
+            case 3: hipLaunchKernelGGL((k_rank1_mfma<3, 1>), dim3(d.B), dim3(64 * 6), lds_r1, st, d); break;
+            case 4: hipLaunchKernelGGL((k_rank1_mfma<4, 1>), dim3(d.B), dim3(64 * 10), lds_r1, st, d); break;
+            case 5: hipLaunchKernelGGL((k_rank1_mfma<5, 1>), dim3(d.B), dim3(64 * 15), lds_r1, st, d); break;
+            case 6: hipLaunchKernelGGL((k_rank1_mfma<6, 2>), dim3(d.B), dim3(64 * 11), lds_r1, st, d); break;
+            case 7: hipLaunchKernelGGL((k_rank1_mfma<7, 2>), dim3(d.B), dim3(64 * 14), lds_r1, st, d); break;
+            default: hipLaunchKernelGGL((k_rank1_mfma<8, 3>), dim3(d.B), dim3(64 * 12), lds_r1, st, d); break;
             }
             PROF(slot, 2, 1);
         }
         HCHK(hipStreamWaitEvent(st, fj[1], 0));
         if (!d.lds_T) hipLaunchKernelGGL(k_cost_reduce, dim3(d.B), dim3(256), 0, st, d, d.fcost, d.imu_cost, d.prior_cost, d.cost, 1);   // (k_build_solve_sb sums the cost itself)
         PROF(slot, 3, 0);
-        if (d.lds_T) hipLaunchKernelGGL(k_build_solve_sb, dim3(d.B), dim3(512), build_solve_sb_bytes(d.N, d.prior_H_sz), st, d);
+        if (d.lds_T && d.N <= 11) hipLaunchKernelGGL(k_build_solve_sb<false>, dim3(d.B), dim3(512), build_solve_sb_bytes(d.N, d.prior_H_sz), st, d);
+        else if (d.lds_T) hipLaunchKernelGGL(k_build_solve_sb<true>, dim3(d.B), dim3(512), build_solve_sb_bytes(d.N, d.prior_H_sz), st, d);
         else hipLaunchKernelGGL(k_build_solve<false>, dim3(d.B), dim3(512), lds_bs, st, d);
         counts[1]++;
         PROF(slot, 3, 1);

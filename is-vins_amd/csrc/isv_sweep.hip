@@ -99,19 +99,21 @@ __global__ __launch_bounds__(64 * ISV_SWEEP_WAVES) void k_sweep_mfma(DevBatch d)
     SWSTAMP(42);
     const int tail = 36 * (N * (N + 1) / 2);
     auto pidx = [N](int hh, int jj) { return hh * N - hh * (hh + 1) / 2 + (jj - hh - 1); };
-    if (t < N * 36) {                      // diagonal blocks and the Jacobi-scaling diagonal
-        const int a = t / 36, rc = t - 36 * a, r = rc / 6, c = rc - 6 * r;
-        double s = 0.0;
-        for (int j2 = a + 1; j2 < N; j2++) s += Phh[pidx(a, j2) * 36 + rc];
-        for (int h2 = 0; h2 < a; h2++) s += Pjj[pidx(h2, a) * 36 + rc];
-        out[tvis_col(a, N) + rc] = s;
-        if (r == c) out[tail + 6 * a + r] = s;
-    } else if (t < N * 42) {               // gradient
-        const int q = t - N * 36, a = q / 6, r = q - 6 * a;
-        double s = 0.0;
-        for (int j2 = a + 1; j2 < N; j2++) s += Pgh[pidx(a, j2) * 6 + r];
-        for (int h2 = 0; h2 < a; h2++) s += Pgj[pidx(h2, a) * 6 + r];
-        out[tail + 6 * N + 6 * a + r] = s;
+    for (int tq = t; tq < N * 42; tq += blockDim.x) {
+        if (tq < N * 36) {                 // diagonal blocks and the Jacobi-scaling diagonal
+            const int a = tq / 36, rc = tq - 36 * a, r = rc / 6, c = rc - 6 * r;
+            double s = 0.0;
+            for (int j2 = a + 1; j2 < N; j2++) s += Phh[pidx(a, j2) * 36 + rc];
+            for (int h2 = 0; h2 < a; h2++) s += Pjj[pidx(h2, a) * 36 + rc];
+            out[tvis_col(a, N) + rc] = s;
+            if (r == c) out[tail + 6 * a + r] = s;
+        } else {                           // gradient
+            const int q = tq - N * 36, a = q / 6, r = q - 6 * a;
+            double s = 0.0;
+            for (int j2 = a + 1; j2 < N; j2++) s += Pgh[pidx(a, j2) * 6 + r];
+            for (int h2 = 0; h2 < a; h2++) s += Pgj[pidx(h2, a) * 6 + r];
+            out[tail + 6 * N + 6 * a + r] = s;
+        }
     }
     SWSTAMP(43);
 }
@@ -126,28 +128,35 @@ __global__ __launch_bounds__(64 * ISV_SWEEP_WAVES) void k_sweep_mfma(DevBatch d)
 // per pass; the loads of the next pass are in flight while the current one is multiplied.
 typedef double double4v __attribute__((ext_vector_type(4)));
 #define R1_CHUNK 64                       // landmarks staged per pass (64 x wd_ld doubles of LDS)
-// NT = panel width / 16 (compile time: cheap index arithmetic, right-sized prefetch registers)
-template <int NT>
-__global__ __launch_bounds__(64 * NT * (NT + 1) / 2) void k_rank1_mfma(DevBatch d) {
-    constexpr int R1_PF = (32 + NT) / (NT + 1);            // panel elements per thread and pass: 64 * ld / threads = 32 / (NT + 1)
+// NT = panel width / 16, TPW = output tiles per wavefront (compile time: cheap index arithmetic, right-sized
+// prefetch registers; TPW > 1 keeps the workgroup within 1024 threads for long windows)
+template <int NT, int TPW>
+__global__ __launch_bounds__(64 * ((NT * (NT + 1) / 2 + TPW - 1) / TPW)) void k_rank1_mfma(DevBatch d) {
+    constexpr int ntiles = NT * (NT + 1) / 2, nwaves = (ntiles + TPW - 1) / TPW;
+    constexpr int ld = 16 * NT, nthr = 64 * nwaves;
+    constexpr int R1_PF = (R1_CHUNK * ld + nthr - 1) / nthr;   // panel elements per thread and pass
     extern __shared__ __align__(16) double lds[];
     const int w = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const SolveState &st = d.st[w];
     if (st.termination != ISV_TERM_RUNNING || !st.need_linearize) return;
-    constexpr int ld = 16 * NT, nthr = 64 * NT * (NT + 1) / 2;
     const int N = d.N, n6 = 6 * N;
     const int l0 = d.lm_off[w], l1 = d.lm_off[w + 1], Lw = l1 - l0;
-    constexpr int lds_ld = ld + 4;             // padded rows: the 4 k-rows of an operand hit distinct banks
+    constexpr int lds_ld = ld + 4;         // padded rows: the 4 k-rows of an operand hit distinct banks
     double *sW = lds;                      // [R1_CHUNK][ld + 4]
     double2 *sCG = (double2 *)(lds + R1_CHUNK * lds_ld);       // [max_lm] {c_l, g_l}
     unsigned *sM = (unsigned *)(sCG + d.max_lm);               // [max_lm] landmark metadata
     const int fw0 = d.f_off[w];
     double *out = d.Tvis + (size_t)w * d.tvis_sz;
     const int tail = 36 * (N * (N + 1) / 2);
-    // wavefront wv owns output tile (I, J), I >= J
-    int I = 0;
-    while ((I + 1) * (I + 2) / 2 <= wv) I++;
-    const int J = wv - I * (I + 1) / 2;
+    // wavefront wv owns the output tiles wv * TPW .. (I, J), I >= J
+    int TI[TPW], TJ[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; j++) {
+        const int q = wv * TPW + j < ntiles ? wv * TPW + j : ntiles - 1;
+        int I = 0;
+        while ((I + 1) * (I + 2) / 2 <= q) I++;
+        TI[j] = I; TJ[j] = q - I * (I + 1) / 2;
+    }
     const int i = lane & 15, kq = lane >> 4;
     for (int l = t; l < Lw; l += nthr) { sM[l] = d.lm_meta[l0 + l]; sCG[l] = d.lm_cg[l0 + l]; }
     __syncthreads();
@@ -167,7 +176,9 @@ __global__ __launch_bounds__(64 * NT * (NT + 1) / 2) void k_rank1_mfma(DevBatch 
             pf[u2] = v;
         }
     };
-    double4v acc = {0, 0, 0, 0};
+    double4v acc[TPW];
+#pragma unroll
+    for (int j = 0; j < TPW; j++) acc[j] = double4v{0, 0, 0, 0};
     fetch(l0);
     for (int lb = l0; lb < l1; lb += R1_CHUNK) {
         __syncthreads();                                   // the previous pass has been consumed
@@ -182,25 +193,35 @@ __global__ __launch_bounds__(64 * NT * (NT + 1) / 2) void k_rank1_mfma(DevBatch 
         for (int k4 = 0; k4 < R1_CHUNK; k4 += 4) {
             const int l = k4 + kq, lg = lb - l0 + l;
             const double cl = lg < Lw ? sCG[lg].x : 0.0;
-            const double av = sW[l * lds_ld + 16 * I + i] * cl, bv = sW[l * lds_ld + 16 * J + i];
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < TPW; j++) {
+                const double av = sW[l * lds_ld + 16 * TI[j] + i] * cl, bv = sW[l * lds_ld + 16 * TJ[j] + i];
+                acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[j], 0, 0, 0);
+            }
         }
     }
     // C/D layout of v_mfma_f64_16x16x4: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
-    for (int reg = 0; reg < 4; reg++) {
-        const int R = 16 * I + kq + 4 * reg, Cc = 16 * J + i;
-        if (R < n6 && Cc < n6 && R >= Cc) {
-            const int fa = Cc / 6, c = Cc - 6 * fa, fb = R / 6, r = R - 6 * fb, bo = fb - fa;
-            if (bo > 0 || c <= r) out[tvis_col(fa, N) + bo * 36 + r * 6 + c] -= acc[reg];
-        } else if (R == n6 && Cc < n6) {
-            out[tail + 12 * N + Cc] = -acc[reg];           // reduced right-hand side bs = -sum c_l g_l w_l
+    for (int j = 0; j < TPW; j++) {
+        if (wv * TPW + j >= ntiles) continue;
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int R = 16 * TI[j] + kq + 4 * reg, Cc = 16 * TJ[j] + i;
+            if (R < n6 && Cc < n6 && R >= Cc) {
+                const int fa = Cc / 6, c = Cc - 6 * fa, fb = R / 6, r = R - 6 * fb, bo = fb - fa;
+                if (bo > 0 || c <= r) out[tvis_col(fa, N) + bo * 36 + r * 6 + c] -= acc[j][reg];
+            } else if (R == n6 && Cc < n6) {
+                out[tail + 12 * N + Cc] = -acc[j][reg];    // reduced right-hand side bs = -sum c_l g_l w_l
+            }
         }
     }
 }
-template __global__ void k_rank1_mfma<1>(DevBatch);
-template __global__ void k_rank1_mfma<2>(DevBatch);
-template __global__ void k_rank1_mfma<3>(DevBatch);
-template __global__ void k_rank1_mfma<4>(DevBatch);
-template __global__ void k_rank1_mfma<5>(DevBatch);
+template __global__ void k_rank1_mfma<1, 1>(DevBatch);
+template __global__ void k_rank1_mfma<2, 1>(DevBatch);
+template __global__ void k_rank1_mfma<3, 1>(DevBatch);
+template __global__ void k_rank1_mfma<4, 1>(DevBatch);
+template __global__ void k_rank1_mfma<5, 1>(DevBatch);
+template __global__ void k_rank1_mfma<6, 2>(DevBatch);
+template __global__ void k_rank1_mfma<7, 2>(DevBatch);
+template __global__ void k_rank1_mfma<8, 3>(DevBatch);
 

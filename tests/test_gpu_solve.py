@@ -174,3 +174,20 @@ def test_forced_mu_retry_matches_oracle(oracle, monkeypatch, n_forced):
     finally:
         oracle.isvo_debug_force_retry(0)
         b.close()
+
+
+@pytest.mark.parametrize("n_frames,n_vo,n_lm", [(12, 5, 150), (15, 7, 200), (18, 8, 300), (19, 8, 150)])
+def test_long_windows_match_oracle(oracle, n_frames, n_vo, n_lm):
+    """N > 11 on the LDS path (k_build_solve_sb<true>, one window per CU; k_rank1_mfma with several tiles per
+    wavefront): the reference itself is compiled for ALL_BUF_SIZE = 18, Vo_SIZE = 8 (include/parameters.h:35-40)"""
+    b = backend.Backend(n_frames, n_vo, max_landmarks=n_lm, max_obs=n_lm * n_frames, max_batch=4)
+    try:
+        ws = synth.make_windows([50, 51], n_frames=n_frames, n_vo=n_vo, n_landmarks=n_lm)
+        batch = [w.clone() for w in ws]
+        sums, margs = b.optimize_batch(batch)
+        for w, g, s, m in zip(ws, batch, sums, margs):
+            o, so, mo = oracle_run(oracle, b.cfg, w)
+            check_window(o, so, g, s)
+            check_marg(mo, m, w.Nvo)
+    finally:
+        b.close()
