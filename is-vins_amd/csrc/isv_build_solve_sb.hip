@@ -35,6 +35,7 @@ __host__ __device__ inline int sb_nred(int N, int prior_H_sz) {   // doubles in 
     int m = LS;
     if (prior_H_sz > m) m = prior_H_sz;
     if (36 * N > m) m = 36 * N;
+    if (30 * N > m) m = 30 * N;
     return (m + 1) & ~1;
 }
 #define RCH 32                     // landmarks per staged chunk of the retry correction
@@ -109,12 +110,14 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
     double *g = p; p += n;
     double *bs = p; p += n;
     double *hdiag = p; p += n;
-    double *sc = p; p += n;
-    double *D = p; p += n;
-    double *y = p; p += n;
-    double *u = p; p += n;
+    // lifetimes: bs is consumed when y = s (g + bs) is formed, hdiag when the LM diagonal D is; u (Cauchy
+    // direction) and the Jacobi scales only live between the scaling loop and the u^T T u reduction: shared storage
+    double *D = hdiag;
+    double *y = bs;
     const int nred = sb_nred(N, d.prior_H_sz);     // reductions; also stages the prior blocks and the chain gather partials
     double *red = p; p += nred;
+    double *u = red;                         // (2 n <= nred)
+    double *sc = red + n;                    // Jacobi scales while the blocks are scaled; the outputs re-read them from HBM
     int *yo = (int *)p; p += 16;             // yo[0..N]: offsets of the fill blocks of each chain node (N <= 31)
     int *skipL = (int *)p; p += 16;          // imu_skip flags of this window
     int *flag = (int *)p; p += 2;
@@ -411,6 +414,7 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
                 accq += 2.0 * v * u[gi] * u[gj];
                 Ysb[e] = v * sc[gi] * sc[gj];
             }
+            __syncthreads();                               // every thread is done with u (it lives in red)
             red[t] = accq;
             __syncthreads();
             for (int off = LS / 2; off > 0; off >>= 1) { if (t < off) red[t] += red[t + off]; __syncthreads(); }
@@ -734,7 +738,7 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
     }
     if (!ls_fail) {
         for (int e = t; e < n; e += LS) {
-            d.zp[(size_t)w * n + e] = sc[e] * y[e];
+            d.zp[(size_t)w * n + e] = d.scale_p[(size_t)w * n + e] * y[e];
             d.gn_p[(size_t)w * n + e] = -D[e] * y[e];
         }
     }
@@ -790,5 +794,5 @@ size_t build_solve_sb_bytes(int N, int prior_H_sz) {
     const size_t stage = (size_t)RCH * (6 * (size_t)N + 1);     // retry staging lives in the Dss/Css/Ysb region
     if (tail < stage) tail = stage;
     const size_t nred = (size_t)sb_nred(N, prior_H_sz);
-    return (7 * n + nred + 16 + 16 + 2 + nS + tail + 2) * sizeof(double);
+    return (3 * n + nred + 16 + 16 + 2 + nS + tail + 2) * sizeof(double);
 }

@@ -9,6 +9,7 @@
 //          -> candidate evaluation (cost + model cost change) -> k_step_control
 #include <hip/hip_runtime.h>
 #include <cstring>
+#include <cstdio>
 #include "isv_kernels.h"
 #include "isv_device_math.h"
 #include "isv_prior_factor.h"
@@ -478,6 +479,7 @@ int isv_solver_alloc(DevBatch &d, size_t B, size_t L, size_t F, std::vector<void
     const size_t lds_sb = build_solve_sb_bytes(d.N, d.prior_H_sz);
     d.lds_T = (d.N <= 20 && d.wd_ld <= 128 && d.prior_H_sz <= 1024 && lds_sb <= (d.N <= 11 ? 80u : 160u) * 1024 &&
                lds_r1 <= 160 * 1024 && lds_sw <= 160 * 1024) ? 1 : 0;
+    if (getenv("ISV_DEBUG_PATH")) fprintf(stderr, "isv: N=%d wd_ld=%d prior_H_sz=%d lds_sb=%zu lds_r1=%zu lds_sw=%zu -> lds_T=%d\n", d.N, d.wd_ld, d.prior_H_sz, lds_sb, lds_r1, lds_sw, d.lds_T);
     TRYA(dal(&d.Tglob, d.lds_T ? 1 : B * nblkT, allocs, err));
     d.marg_scratch_sz = 26;
     TRYA(dal(&d.marg_scratch, L * 26, allocs, err));

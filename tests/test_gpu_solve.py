@@ -176,7 +176,7 @@ def test_forced_mu_retry_matches_oracle(oracle, monkeypatch, n_forced):
         b.close()
 
 
-@pytest.mark.parametrize("n_frames,n_vo,n_lm", [(12, 5, 150), (15, 7, 200), (18, 8, 300), (19, 8, 150)])
+@pytest.mark.parametrize("n_frames,n_vo,n_lm", [(12, 5, 150), (15, 7, 200), (18, 8, 300), (19, 8, 150), (20, 8, 120)])
 def test_long_windows_match_oracle(oracle, n_frames, n_vo, n_lm):
     """N > 11 on the LDS path (k_build_solve_sb<true>, one window per CU; k_rank1_mfma with several tiles per
     wavefront): the reference itself is compiled for ALL_BUF_SIZE = 18, Vo_SIZE = 8 (include/parameters.h:35-40)"""
