@@ -44,6 +44,13 @@ def load_library():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise BackendError(f"HIP extension missing: {LIB_PATH} (run __graft_entry__.build())")
+    # PyTorch-ROCm bundles its own libamdhip64.  If this process is going to use torch as well (bench.py, smoke()),
+    # torch's copy has to be mapped FIRST so that libisvins_hip.so binds to the same HIP runtime: with the system
+    # runtime mapped first, the process ends up with two runtimes and the second one to initialise sees no device.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     lib = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     wpp = C.POINTER(C.POINTER(abi.isv_window_t))

@@ -27,10 +27,11 @@ traffic = {"windows_per_gpu": W,
                    "bench's achieved figure); hbm_bytes_per_launch = (FETCH_SIZE + WRITE_SIZE) * 1024.  MI355X_MICROARCH.md: "
                    "FETCH_SIZE is exact-by-half only for 16-B/lane streaming reads; these kernels read 8 B/lane (f64 elements), "
                    "a width the guide calls uncalibrated, so no factor is applied; WRITE_SIZE is taken as is"}
-for n in ("k_build_solve_sb", "k_proj_linearize<0>", "k_sweep_mfma", "k_rank1_mfma<5>", "k_dogleg", "k_proj_linearize<1>"):
-    if n in fetch or n in write:
+for n in names:
+    base = n.split("<")[0] if not n.startswith("k_proj_linearize") else n
+    if base in ("k_build_solve_sb", "k_proj_linearize<0>", "k_sweep_mfma", "k_rank1_mfma", "k_dogleg", "k_proj_linearize<1>"):
         fv, wv = fetch.get(n, [0.0]), write.get(n, [0.0])
-        key = "k_rank1_mfma" if n.startswith("k_rank1_mfma") else n
+        key = base
         traffic[key] = {"FETCH_SIZE_KB_mean": sum(fv) / len(fv), "WRITE_SIZE_KB_mean": sum(wv) / len(wv),
                         "hbm_bytes_per_launch": (sum(fv) / len(fv) + sum(wv) / len(wv)) * 1024.0}
 json.dump(traffic, open(f"{out}/r01_pmc_traffic.json", "w"), indent=1)
