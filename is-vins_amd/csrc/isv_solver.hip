@@ -528,6 +528,7 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
             const int nt = d.wd_ld / 16;
             // one workgroup per window: nt(nt+1)/2 tile wavefronts, w vectors expanded to panel rows in LDS
             const size_t lds_r1 = (64 * (d.wd_ld + 4) + (size_t)d.max_lm * 3 + 2) * sizeof(double);
+            PROF(slot, 2, 0);
             switch (nt) {
             case 1: hipLaunchKernelGGL((k_rank1_mfma<1, 1>), dim3(d.B), dim3(64 * 1), lds_r1, st, d); break;
             case 2: hipLaunchKernelGGL((k_rank1_mfma<2, 1>), dim3(d.B), dim3(64 * 3), lds_r1, st, d); break;
