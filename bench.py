@@ -76,9 +76,11 @@ def main():
     from isvins_amd import backend, synth
     backend.build()
 
-    # the C-ABI library uses the current HIP device of the process: select it before create
-    hip = C.CDLL("libamdhip64.so")
-    hip.hipSetDevice(local_rank if world > 1 else 0)
+    # The C-ABI library allocates on the calling thread's current HIP device.  backend.load_library() maps torch's
+    # HIP runtime first, so the library and torch share ONE runtime and torch.cuda.set_device() above selects the
+    # device for both; the free-memory check below verifies that the batch really landed on this rank's GPU.
+    dev = local_rank if world > 1 else 0
+    free_before = torch.cuda.mem_get_info(dev)[0]
 
     W = args.windows
     from isvins_amd import sharding
@@ -88,6 +90,9 @@ def main():
     max_obs = max(w.n_obs for w in windows)
     be = backend.Backend(args.frames, args.vo, max_landmarks=args.landmarks, max_obs=max_obs, max_batch=W)
     be.upload(windows)
+    free_after = torch.cuda.mem_get_info(dev)[0]
+    if W >= 64 and free_before - free_after < (64 << 20):
+        raise RuntimeError(f"rank {rank}: the backend did not allocate on cuda:{dev} (free memory moved by {free_before - free_after} B)")
 
     def barrier():
         torch.cuda.synchronize()
