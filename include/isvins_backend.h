@@ -223,6 +223,11 @@ int  isv_backend_optimize_batch(isv_backend_t *h, int32_t n, isv_window_t *const
  * (src/estimator.cpp:1022-1117): ProjectionFactor::Evaluate (projection_factor.cpp:24-122),
  * IMUFactor::Evaluate (imu_factor.h:23-159), the four prior factors, CauchyLoss(1.0) corrector.
  * proj_strips [F][28], imu_strips [N-1][465], cost (1/2 sum rho) may each be NULL.       */
+/* FeatureManager::triangulate (src/feature_tracker/feature_manager.cpp:206-258), the step solveOdometry() runs right
+ * before backendOptimization(): every landmark of the n windows whose lm_depth is not positive gets the DLT depth over
+ * all its views (smallest right singular vector, host-camera frame), replaced by INIT_DEPTH outside [0.1, 8].
+ * lm_depth is updated in place; landmarks that already have a depth are left alone.           */
+int  isv_backend_triangulate(isv_backend_t *h, int32_t n, isv_window_t *const *w);
 int  isv_backend_linearize(isv_backend_t *h, const isv_window_t *w,
                            double *proj_strips, double *imu_strips, double *cost);
 

@@ -21,7 +21,7 @@ _lib = None
 STATUS = {0: "ISV_OK", -1: "ISV_ERR_INVALID_ARG", -2: "ISV_ERR_CAPACITY", -3: "ISV_ERR_NONFINITE",
           -4: "ISV_ERR_DEVICE", -5: "ISV_ERR_UNSUPPORTED"}
 EXPORTS = ["isv_abi_version", "isv_backend_create", "isv_backend_destroy", "isv_backend_last_error",
-           "isv_backend_optimize", "isv_backend_optimize_batch", "isv_backend_linearize",
+           "isv_backend_optimize", "isv_backend_optimize_batch", "isv_backend_triangulate", "isv_backend_linearize",
            "isv_batch_upload", "isv_batch_optimize", "isv_batch_linearize", "isv_batch_download",
            "isv_batch_sync", "isv_batch_last_timing", "isv_batch_last_counts"]
 
@@ -61,6 +61,7 @@ def load_library():
     lib.isv_backend_last_error.argtypes = [vp]; lib.isv_backend_last_error.restype = C.c_char_p
     lib.isv_backend_optimize.argtypes = [vp, C.POINTER(abi.isv_window_t), C.POINTER(abi.isv_summary_t), C.POINTER(abi.isv_marg_result_t)]
     lib.isv_backend_optimize_batch.argtypes = [vp, C.c_int32, wpp, C.POINTER(abi.isv_summary_t), C.POINTER(abi.isv_marg_result_t)]
+    lib.isv_backend_triangulate.argtypes = [vp, C.c_int32, wpp]
     lib.isv_backend_linearize.argtypes = [vp, C.POINTER(abi.isv_window_t), dp, dp, dp]
     lib.isv_batch_upload.argtypes = [vp, C.c_int32, wpp]
     lib.isv_batch_optimize.argtypes = [vp, C.c_int32]
@@ -125,6 +126,10 @@ class Backend:
         cw = window.c()
         self._check(self.lib.isv_backend_linearize(self.h, C.byref(cw), abi._p(ps), abi._p(im), abi._p(cost)), "linearize")
         return ps[:F], im, float(cost[0])
+
+    def triangulate(self, windows):
+        """FeatureManager::triangulate for the landmarks without a positive depth (lm_depth updated in place)"""
+        self._check(self.lib.isv_backend_triangulate(self.h, len(windows), self._ptrs(windows)), "triangulate")
 
     # ---- device-resident batch (bench) -----------------------------------------------------
     def upload(self, windows):

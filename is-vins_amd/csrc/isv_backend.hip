@@ -35,7 +35,7 @@ struct isv_backend {
     size_t capB = 0, capL = 0, capF = 0, capTiles = 0;
     // host staging (pinned)
     struct Host {
-        double *Ps, *Rs, *Vs, *Bas, *Bgs, *tic, *ric, *depth, *lm_pts_i, *f_pts_j, *imu_in, *imu_cov;
+        double *Ps, *Rs, *Vs, *Bas, *Bgs, *tic, *ric, *depth, *lm_pts_i, *f_pts_j, *f_pts_z, *imu_in, *imu_cov;
         int32_t *lm_off, *f_off, *lm_host, *lm_k, *lm_f0, *tile_win, *tile_f0, *tile_n, *imu_skip, *n_rp, *solve_flag, *pg_perm, *pg_off, *pg_sched, *pg_sched_off;
         FactorRec *f_rec;
         uint32_t *lm_meta; int32_t *margin_old; double *header0;
@@ -109,6 +109,7 @@ static int create_impl(isv_backend *h) {
     memcpy(d.proj_sqrt_info, c.proj_sqrt_info, sizeof(d.proj_sqrt_info));
     memcpy(d.G, c.gravity, sizeof(d.G));
     d.alpha_cut = c.alpha;
+    d.init_depth = c.init_depth;
     const size_t NI = B * (N - 1);
     TRY(dalloc(h, &d.Ps, B * N * 3)); TRY(dalloc(h, &d.Rs, B * N * 9)); TRY(dalloc(h, &d.Vs, B * N * 3));
     TRY(dalloc(h, &d.Bas, B * N * 3)); TRY(dalloc(h, &d.Bgs, B * N * 3)); TRY(dalloc(h, &d.tic, B * 3)); TRY(dalloc(h, &d.ric, B * 9));
@@ -117,7 +118,7 @@ static int create_impl(isv_backend *h) {
     TRY(dalloc(h, &d.cpose, B * N * 7)); TRY(dalloc(h, &d.csb, B * N * 9)); TRY(dalloc(h, &d.clam, L));
     TRY(dalloc(h, &d.lm_off, B + 1)); TRY(dalloc(h, &d.f_off, B + 1));
     TRY(dalloc(h, &d.lm_host, L)); TRY(dalloc(h, &d.lm_k, L)); TRY(dalloc(h, &d.lm_f0, L)); TRY(dalloc(h, &d.lm_pts_i, L * 3));
-    TRY(dalloc(h, &d.f_rec, F)); TRY(dalloc(h, &d.f_pts_j, F * 2));
+    TRY(dalloc(h, &d.f_rec, F)); TRY(dalloc(h, &d.f_pts_j, F * 2)); TRY(dalloc(h, &d.f_pts_z, F));
     TRY(dalloc(h, &d.tile_win, T)); TRY(dalloc(h, &d.tile_f0, T)); TRY(dalloc(h, &d.tile_n, T));
     TRY(dalloc(h, &d.pg_perm, F)); TRY(dalloc(h, &d.pg_off, B * ((size_t)c.n_frames * (c.n_frames - 1) / 2 + 1)));
     TRY(dalloc(h, &d.pg_sched, B * ((size_t)c.n_frames * (c.n_frames - 1) / 2))); TRY(dalloc(h, &d.pg_sched_off, B * (ISV_SWEEP_WAVES + 1)));
@@ -140,7 +141,7 @@ static int create_impl(isv_backend *h) {
     auto &s = h->h;
     TRY(halloc(h, &s.Ps, B * N * 3)); TRY(halloc(h, &s.Rs, B * N * 9)); TRY(halloc(h, &s.Vs, B * N * 3));
     TRY(halloc(h, &s.Bas, B * N * 3)); TRY(halloc(h, &s.Bgs, B * N * 3)); TRY(halloc(h, &s.tic, B * 3)); TRY(halloc(h, &s.ric, B * 9));
-    TRY(halloc(h, &s.depth, L)); TRY(halloc(h, &s.solve_flag, L)); TRY(halloc(h, &s.lm_pts_i, L * 3)); TRY(halloc(h, &s.f_pts_j, F * 2));
+    TRY(halloc(h, &s.depth, L)); TRY(halloc(h, &s.solve_flag, L)); TRY(halloc(h, &s.lm_pts_i, L * 3)); TRY(halloc(h, &s.f_pts_j, F * 2)); TRY(halloc(h, &s.f_pts_z, F));
     TRY(halloc(h, &s.imu_in, NI * ISV_IMU_IN)); TRY(halloc(h, &s.imu_cov, NI * 225));
     TRY(halloc(h, &s.lm_off, B + 1)); TRY(halloc(h, &s.f_off, B + 1)); TRY(halloc(h, &s.lm_host, L)); TRY(halloc(h, &s.lm_k, L)); TRY(halloc(h, &s.lm_f0, L));
     TRY(halloc(h, &s.tile_win, T)); TRY(halloc(h, &s.tile_f0, T)); TRY(halloc(h, &s.tile_n, T));
@@ -213,6 +214,7 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
             for (int o = 1; o < k; o++) {
                 s.f_rec[F].lm = (int32_t)L; s.f_rec[F].ij = hst | ((hst + o) << 8);
                 s.f_pts_j[F * 2] = w->obs_point[(size_t)(o0 + o) * 3]; s.f_pts_j[F * 2 + 1] = w->obs_point[(size_t)(o0 + o) * 3 + 1];
+                s.f_pts_z[F] = w->obs_point[(size_t)(o0 + o) * 3 + 2];
                 F++;
             }
             L++;
@@ -298,7 +300,7 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
     H2D(d.Bas, s.Bas, (size_t)n * N * 3); H2D(d.Bgs, s.Bgs, (size_t)n * N * 3); H2D(d.tic, s.tic, (size_t)n * 3); H2D(d.ric, s.ric, (size_t)n * 9);
     H2D(d.depth, s.depth, L); H2D(d.lm_off, s.lm_off, n + 1); H2D(d.f_off, s.f_off, n + 1);
     H2D(d.lm_host, s.lm_host, L); H2D(d.lm_k, s.lm_k, L); H2D(d.lm_f0, s.lm_f0, L); H2D(d.lm_pts_i, s.lm_pts_i, L * 3);
-    H2D(d.f_rec, s.f_rec, F); H2D(d.f_pts_j, s.f_pts_j, F * 2);
+    H2D(d.f_rec, s.f_rec, F); H2D(d.f_pts_j, s.f_pts_j, F * 2); H2D(d.f_pts_z, s.f_pts_z, F);
     H2D(d.lm_meta, s.lm_meta, L);
     H2D(d.tile_win, s.tile_win, T); H2D(d.tile_f0, s.tile_f0, T); H2D(d.tile_n, s.tile_n, T);
     H2D(d.pg_perm, s.pg_perm, F); H2D(d.pg_off, s.pg_off, (size_t)n * ((size_t)N * (N - 1) / 2 + 1));
@@ -468,6 +470,23 @@ extern "C" int isv_backend_optimize_batch(isv_backend_t *h, int32_t n, isv_windo
 extern "C" int isv_backend_optimize(isv_backend_t *h, isv_window_t *w, isv_summary_t *summary, isv_marg_result_t *marg) {
     isv_window_t *ws[1] = {w};
     return isv_backend_optimize_batch(h, 1, ws, summary, marg);
+}
+
+// FeatureManager::triangulate (src/feature_tracker/feature_manager.cpp:206-258) for every landmark of the n windows whose
+// estimated depth is not positive: DLT over all its views, smallest right singular vector, clamp to INIT_DEPTH.
+extern "C" int isv_backend_triangulate(isv_backend_t *h, int32_t n, isv_window_t *const *ws) {
+    TRY(isv_batch_upload(h, n, ws));
+    DevBatch &d = h->d; hipStream_t st = h->stream; auto &s = h->h;
+    if (d.Ltot) hipLaunchKernelGGL(k_triangulate, dim3((d.Ltot + 63) / 64), dim3(64), 0, st, d);
+    HIPCHK(h, hipGetLastError());
+    D2H(s.depth, d.depth, (size_t)d.Ltot);
+    HIPCHK(h, hipStreamSynchronize(st));
+    for (int b = 0; b < n; b++) {
+        isv_window_t *w = ws[b];
+        for (int l = 0; l < w->n_landmarks; l++) w->lm_depth[l] = s.depth[s.lm_off[b] + l];
+    }
+    h->resident = 0;                   // the resident copy no longer matches the caller's depths' origin; re-upload to solve
+    return ISV_OK;
 }
 
 extern "C" int isv_backend_linearize(isv_backend_t *h, const isv_window_t *w, double *proj_strips, double *imu_strips,

@@ -57,6 +57,7 @@ struct DevBatch {
     double proj_sqrt_info[4];
     double G[3];
     double alpha_cut;
+    double init_depth;                  // INIT_DEPTH (k_triangulate clamps to it)
     // Eigen-level state, in/out
     double *Ps, *Rs, *Vs, *Bas, *Bgs, *tic, *ric, *depth;
     int32_t *solve_flag;
@@ -69,6 +70,7 @@ struct DevBatch {
     double *lm_pts_i;                   // [Ltot][3]
     FactorRec *f_rec;                   // [Ftot]
     double *f_pts_j;                    // [Ftot][2]
+    double *f_pts_z;                        // [Ftot] third component of the observing view's point (triangulation only)
     int32_t *tile_win, *tile_f0, *tile_n;   // [n_tiles]
     int32_t *pg_sched, *pg_sched_off;       // balanced pair -> wavefront schedule of k_sweep_mfma: [B][NP] (h | j << 8 | p << 16), [B][ISV_SWEEP_WAVES + 1]
     int32_t *pg_perm, *pg_off;              // factors of a window sorted by (host, observer) frame pair: [Ftot] window-relative ids, [B][N(N-1)/2 + 1] group starts

@@ -289,6 +289,98 @@ template __global__ void k_proj_linearize<0>(DevBatch, const double *, const dou
 template __global__ void k_proj_linearize<1>(DevBatch, const double *, const double *, double *, int);
 
 // ------------------------------------------------------------------------------------------
+// FeatureManager::triangulate (src/feature_tracker/feature_manager.cpp:206-258), one lane per landmark that has no
+// positive depth yet: the DLT rows of all its views, expressed in the host camera frame, are accumulated as the 4x4
+// Gram matrix A^T A (the right singular vectors of A are its eigenvectors); a cyclic Jacobi eigen-solve in
+// registers gives the vector of the smallest singular value, depth = v[2] / v[3], clamped to INIT_DEPTH outside
+// [0.1, 8] like the reference.
+__global__ __launch_bounds__(64) void k_triangulate(DevBatch d) {
+    const int l = blockIdx.x * 64 + threadIdx.x;
+    if (l >= d.Ltot) return;
+    if (d.depth[l] > 0.0) return;
+    int lo = 0, hi = d.B;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (d.lm_off[mid] <= l) lo = mid; else hi = mid; }
+    const int w = lo, N = d.N, h = d.lm_host[l], k = d.lm_k[l], f0 = d.lm_f0[l];
+    const double *Ps = d.Ps + (size_t)w * N * 3, *Rs = d.Rs + (size_t)w * N * 9, *tic = d.tic + (size_t)w * 3, *ric = d.ric + (size_t)w * 9;
+    double R0[9], t0[3], tt[3];
+    m3_mul(Rs + 9 * h, ric, R0);
+    m3v(Rs + 9 * h, tic, tt);
+    for (int c = 0; c < 3; c++) t0[c] = Ps[3 * h + c] + tt[c];
+    double M[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};     // upper triangle of A^T A: (0,0) (0,1) (0,2) (0,3) (1,1) (1,2) (1,3) (2,2) (2,3) (3,3)
+    for (int o = 0; o < k; o++) {
+        const int j = h + o;
+        double R1[9], t1[3], dt[3], tr[3], R[9], P[12];
+        m3_mul(Rs + 9 * j, ric, R1);
+        m3v(Rs + 9 * j, tic, tt);
+        for (int c = 0; c < 3; c++) { t1[c] = Ps[3 * j + c] + tt[c]; dt[c] = t1[c] - t0[c]; }
+        m3tv(R0, dt, tr);                                // t = R0^T (t1 - t0)
+        m3_mul_tn(R0, R1, R);                            // R = R0^T R1
+        // P = [R^T | -R^T t]
+        double mt[3];
+        m3tv(R, tr, mt);
+        for (int a = 0; a < 3; a++) { for (int c = 0; c < 3; c++) P[a * 4 + c] = R[c * 3 + a]; P[a * 4 + 3] = -mt[a]; }
+        double fx, fy, fz;
+        if (o == 0) { fx = d.lm_pts_i[(size_t)l * 3]; fy = d.lm_pts_i[(size_t)l * 3 + 1]; fz = d.lm_pts_i[(size_t)l * 3 + 2]; }
+        else { const int f = f0 + o - 1; fx = d.f_pts_j[(size_t)f * 2]; fy = d.f_pts_j[(size_t)f * 2 + 1]; fz = d.f_pts_z[f]; }
+        const double nrm = sqrt(fx * fx + fy * fy + fz * fz);
+        fx /= nrm; fy /= nrm; fz /= nrm;
+        double ra[4], rb[4];
+        for (int c = 0; c < 4; c++) { ra[c] = fx * P[8 + c] - fz * P[c]; rb[c] = fy * P[8 + c] - fz * P[4 + c]; }
+        int e = 0;
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int c = a; c < 4; c++) M[e++] += ra[a] * ra[c] + rb[a] * rb[c];
+    }
+    // cyclic Jacobi on the symmetric 4x4 (static indices only: everything stays in registers)
+    double A[4][4], V[4][4];
+    {
+        int e = 0;
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int c = a; c < 4; c++) { A[a][c] = M[e]; A[c][a] = M[e]; e++; }
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int c = 0; c < 4; c++) V[a][c] = a == c ? 1.0 : 0.0;
+    }
+    for (int sweep = 0; sweep < 30; sweep++) {
+        double off = 0, dg = 0;
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            dg += A[a][a] * A[a][a];
+#pragma unroll
+            for (int c = a + 1; c < 4; c++) off += A[a][c] * A[a][c];
+        }
+        if (off <= 1e-32 * dg || off == 0.0) break;
+#pragma unroll
+        for (int p = 0; p < 3; p++)
+#pragma unroll
+            for (int q = p + 1; q < 4; q++) {
+                const double apq = A[p][q];
+                if (apq != 0.0) {
+                    const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
+                    const double tq = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                    const double c = 1.0 / sqrt(tq * tq + 1.0), sn = tq * c;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) { const double akp = A[r][p], akq = A[r][q]; A[r][p] = c * akp - sn * akq; A[r][q] = sn * akp + c * akq; }
+#pragma unroll
+                    for (int r = 0; r < 4; r++) { const double apk = A[p][r], aqk = A[q][r]; A[p][r] = c * apk - sn * aqk; A[q][r] = sn * apk + c * aqk; }
+#pragma unroll
+                    for (int r = 0; r < 4; r++) { const double vkp = V[r][p], vkq = V[r][q]; V[r][p] = c * vkp - sn * vkq; V[r][q] = sn * vkp + c * vkq; }
+                }
+            }
+    }
+    double best = A[0][0], v2 = V[2][0], v3 = V[3][0];
+#pragma unroll
+    for (int c = 1; c < 4; c++) if (A[c][c] < best) { best = A[c][c]; v2 = V[2][c]; v3 = V[3][c]; }
+    double dep = v2 / v3;
+    if (dep < 0.1 || dep > 8.0) dep = d.init_depth;
+    d.depth[l] = dep;
+}
+
+// ------------------------------------------------------------------------------------------
 // IMU factor: one wavefront per factor.  raw residual (15) and raw Jacobian (15 x 30) are built by
 // a few lanes in LDS, then every lane forms rows of sqrt_info * [r | J] (15-term dot products).
 // JAC=false: residual only (candidate point), cost into cost_out.

@@ -824,6 +824,60 @@ int isvo_optimize(const isv_config_t *cfg, isv_window_t *w, isv_summary_t *sum, 
     return ISV_OK;
 }
 
+/* FeatureManager::triangulate  src/feature_tracker/feature_manager.cpp:206-258.  For every landmark without a positive
+ * depth: DLT matrix A (2k x 4) over all k views in the host camera frame (:219-242), V = right singular vector of the
+ * smallest singular value (Eigen::JacobiSVD, :244), depth = V[2] / V[3] (:245), INIT_DEPTH outside [0.1, 8] (:252-255).
+ * The SVD here is a one-sided (Hestenes) Jacobi on the columns of A: A V = U S, V accumulated from the rotations. */
+int isvo_triangulate(const isv_config_t *cfg, isv_window_t *w) {
+    for (int l = 0; l < w->n_landmarks; l++) {
+        if (w->lm_depth[l] > 0) continue;
+        const int h = w->lm_start_frame[l], o0 = w->lm_obs_ptr[l], k = w->lm_obs_ptr[l + 1] - o0;
+        double A[64][4], V[4][4];                      /* k <= 32 views */
+        double R0[9], t0[3], tmp[3];
+        mm(w->Rs + 9 * h, w->ric, R0, 3, 3, 3);
+        m3v(w->Rs + 9 * h, w->tic, tmp);
+        for (int c = 0; c < 3; c++) t0[c] = w->Ps[3 * h + c] + tmp[c];
+        for (int o = 0; o < k; o++) {
+            const int j = h + o;
+            double R1[9], t1[3], dt[3], t[3], R[9], P[12], mt[3];
+            mm(w->Rs + 9 * j, w->ric, R1, 3, 3, 3);
+            m3v(w->Rs + 9 * j, w->tic, tmp);
+            for (int c = 0; c < 3; c++) { t1[c] = w->Ps[3 * j + c] + tmp[c]; dt[c] = t1[c] - t0[c]; }
+            m3tv(R0, dt, t);
+            for (int a = 0; a < 3; a++) for (int c = 0; c < 3; c++) { double s = 0; for (int q = 0; q < 3; q++) s += R0[q * 3 + a] * R1[q * 3 + c]; R[a * 3 + c] = s; }
+            m3tv(R, t, mt);
+            for (int a = 0; a < 3; a++) { for (int c = 0; c < 3; c++) P[a * 4 + c] = R[c * 3 + a]; P[a * 4 + 3] = -mt[a]; }
+            const double *pt = w->obs_point + (size_t)(o0 + o) * 3;
+            const double nrm = sqrt(pt[0] * pt[0] + pt[1] * pt[1] + pt[2] * pt[2]);
+            const double f[3] = {pt[0] / nrm, pt[1] / nrm, pt[2] / nrm};
+            for (int c = 0; c < 4; c++) { A[2 * o][c] = f[0] * P[8 + c] - f[2] * P[c]; A[2 * o + 1][c] = f[1] * P[8 + c] - f[2] * P[4 + c]; }
+        }
+        const int m = 2 * k;
+        for (int a = 0; a < 4; a++) for (int c = 0; c < 4; c++) V[a][c] = a == c;
+        for (int sweep = 0; sweep < 60; sweep++) {
+            int rotated = 0;
+            for (int p = 0; p < 3; p++) for (int q = p + 1; q < 4; q++) {
+                double app = 0, aqq = 0, apq = 0;
+                for (int r = 0; r < m; r++) { app += A[r][p] * A[r][p]; aqq += A[r][q] * A[r][q]; apq += A[r][p] * A[r][q]; }
+                if (fabs(apq) <= 1e-17 * sqrt(app * aqq) || apq == 0.0) continue;
+                rotated = 1;
+                const double theta = (aqq - app) / (2.0 * apq);
+                const double tq = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(tq * tq + 1.0), s = tq * c;
+                for (int r = 0; r < m; r++) { const double x = A[r][p], y = A[r][q]; A[r][p] = c * x - s * y; A[r][q] = s * x + c * y; }
+                for (int r = 0; r < 4; r++) { const double x = V[r][p], y = V[r][q]; V[r][p] = c * x - s * y; V[r][q] = s * x + c * y; }
+            }
+            if (!rotated) break;
+        }
+        int best = 0; double bn = 1e300;
+        for (int c = 0; c < 4; c++) { double nn = 0; for (int r = 0; r < m; r++) nn += A[r][c] * A[r][c]; if (nn < bn) { bn = nn; best = c; } }
+        double dep = V[2][best] / V[3][best];
+        if (dep < 0.1 || dep > 8.0) dep = cfg->init_depth;
+        w->lm_depth[l] = dep;
+    }
+    return 0;
+}
+
 /* one ceres::Problem::Evaluate at the window's current state -> strips in the product's layout */
 int isvo_linearize(const isv_config_t *cfg, const isv_window_t *w, double *proj_strips, double *imu_strips,
                    double *prior_res, double *cost) {
