@@ -223,6 +223,14 @@ int  isv_backend_optimize_batch(isv_backend_t *h, int32_t n, isv_window_t *const
  * (src/estimator.cpp:1022-1117): ProjectionFactor::Evaluate (projection_factor.cpp:24-122),
  * IMUFactor::Evaluate (imu_factor.h:23-159), the four prior factors, CauchyLoss(1.0) corrector.
  * proj_strips [F][28], imu_strips [N-1][465], cost (1/2 sum rho) may each be NULL.       */
+/* Estimator::initFactorGraph (src/estimator.cpp:667-1001), the one-time INITIAL_STRUCTURE -> NON_LINEAR step of
+ * backendOptimization(): solve the window WITHOUT prior factors (IMU + reprojection factors, 3 x num_iterations dogleg
+ * iterations; the reference's 1 s wall-clock cap is not restated), derive the first prior factors from the solved
+ * estimate (relative poses (i, i+1) for i < n_vo - 1, SE3 prior on pose 0, Linear9 prior on speed/bias n_vo - 1:
+ * marginal of the first n_vo - 1 IMU factors, eigen-truncated at alpha), then double2vector.
+ * w->pose_prior, w->vb_prior, w->relpose[n_vo - 1] are OUTPUTS; w->n_rollpitch becomes 0.  *kld (may be NULL) receives
+ * the Kullback-Leibler divergence of the recovered factors against the truncated marginal (:976-989).          */
+int  isv_backend_init_factor_graph(isv_backend_t *h, isv_window_t *w, isv_summary_t *summary, double *kld);
 /* FeatureManager::triangulate (src/feature_tracker/feature_manager.cpp:206-258), the step solveOdometry() runs right
  * before backendOptimization(): every landmark of the n windows whose lm_depth is not positive gets the DLT depth over
  * all its views (smallest right singular vector, host-camera frame), replaced by INIT_DEPTH outside [0.1, 8].

@@ -146,3 +146,65 @@ inline void Estimator_backendOptimization_isv(Estimator &e) {
     }
     e.MargPointIdx.clear(); e.features2Marg.clear();
 }
+
+// ---- Estimator::initFactorGraph() (src/estimator.cpp:667-1001), the INITIAL_STRUCTURE branch -------------------
+// Same marshalling as above without prior factors; the backend solves the prior-free window, derives the first
+// prior factors and runs double2vector.  The reference's factor objects are created here from the returned PODs.
+inline void Estimator_initFactorGraph_isv(Estimator &e) {
+    using namespace isvins;
+    const int N = ALL_BUF_SIZE;
+    std::vector<double> Ps(N * 3), Rs(N * 9), Vs(N * 3), Bas(N * 3), Bgs(N * 3), tic(3), ric(9);
+    for (int i = 0; i < N; i++) {
+        for (int k = 0; k < 3; k++) { Ps[3 * i + k] = e.Ps[i](k); Vs[3 * i + k] = e.Vs[i](k); Bas[3 * i + k] = e.Bas[i](k); Bgs[3 * i + k] = e.Bgs[i](k); }
+        to_row_major(e.Rs[i], &Rs[9 * i]);
+    }
+    for (int k = 0; k < 3; k++) tic[k] = e.tic[0](k);
+    to_row_major(e.ric[0], ric.data());
+    std::vector<int32_t> start, ptr(1, 0), flag;
+    std::vector<double> obs, depth;
+    std::vector<IDFeatures *> good;
+    for (auto &f : e.f_manager.IDsfeatures) {
+        f.used_num = f.idfeatures.size();
+        if (!e.f_manager.goodFeature(f)) continue;
+        good.push_back(&f); start.push_back(f.start_frame);
+        for (auto &o : f.idfeatures) { obs.push_back(o.point.x()); obs.push_back(o.point.y()); obs.push_back(o.point.z()); }
+        ptr.push_back((int32_t)(obs.size() / 3)); depth.push_back(f.estimated_depth);
+    }
+    flag.assign(good.size(), 0);
+    std::vector<isv_imu_t> imu(N - 1);
+    for (int j = 1; j < N; j++) {
+        const IntegrationBase &p = *e.pre_integrations[j]; isv_imu_t &o = imu[j - 1];
+        for (int k = 0; k < 3; k++) { o.delta_p[k] = p.delta_p(k); o.delta_v[k] = p.delta_v(k); o.linearized_ba[k] = p.linearized_ba(k); o.linearized_bg[k] = p.linearized_bg(k); }
+        o.delta_q[0] = p.delta_q.x(); o.delta_q[1] = p.delta_q.y(); o.delta_q[2] = p.delta_q.z(); o.delta_q[3] = p.delta_q.w();
+        o.sum_dt = p.sum_dt; to_row_major(Eigen::MatrixXd(p.jacobian), o.jacobian); to_row_major(Eigen::MatrixXd(p.covariance), o.covariance);
+    }
+    isv_se3_prior_t pp{}; isv_linear9_t vb{}; std::vector<isv_relpose_t> rel(Vo_SIZE - 1);
+    isv_window_t w{};
+    w.Ps = Ps.data(); w.Rs = Rs.data(); w.Vs = Vs.data(); w.Bas = Bas.data(); w.Bgs = Bgs.data(); w.tic = tic.data(); w.ric = ric.data();
+    w.n_landmarks = (int32_t)good.size(); w.n_obs = ptr.back();
+    w.lm_start_frame = start.data(); w.lm_obs_ptr = ptr.data(); w.obs_point = obs.data(); w.lm_depth = depth.data(); w.lm_solve_flag = flag.data();
+    w.imu = imu.data(); w.pose_prior = &pp; w.vb_prior = &vb; w.relpose = rel.data(); w.rollpitch = nullptr; w.n_rollpitch = 0;
+    w.header0 = e.Headers[0];
+    w.para_Pose = &e.para_Pose[0][0]; w.para_SpeedBias = &e.para_SpeedBias[0][0]; w.para_Ex_Pose = &e.para_Ex_Pose[0][0]; w.para_Feature = &e.para_Feature[0][0];
+    isv_summary_t sum; double kld = 0;
+    if (isv_backend_init_factor_graph(e.isv_handle, &w, &sum, &kld) != ISV_OK) { std::cerr << "isv_backend_init_factor_graph: " << isv_backend_last_error(e.isv_handle) << std::endl; return; }
+    for (int i = 0; i < N; i++) {
+        for (int k = 0; k < 3; k++) { e.Ps[i](k) = Ps[3 * i + k]; e.Vs[i](k) = Vs[3 * i + k]; e.Bas[i](k) = Bas[3 * i + k]; e.Bgs[i](k) = Bgs[3 * i + k]; }
+        e.Rs[i] = from_row_major3(&Rs[9 * i]);
+    }
+    for (int k = 0; k < 3; k++) e.tic[0](k) = tic[k];
+    e.ric[0] = from_row_major3(ric.data());
+    for (size_t l = 0; l < good.size(); l++) { good[l]->estimated_depth = depth[l]; good[l]->solve_flag = flag[l]; }
+    // the first prior factors (src/estimator.cpp:821-864, 944-974)
+    e.vioRelativePoseEdges[0] = nullptr;
+    for (int i = 0; i < Vo_SIZE - 1; i++) {
+        auto *f = new RelativePoseFactor(Eigen::Vector3d(rel[i].delta_t), from_row_major3(rel[i].delta_R));
+        f->setIndex(i, i + 1); f->sqrt_info = from_row_major(rel[i].sqrt_info, 6, 6);
+        e.vioRelativePoseEdges[i + 1] = f;
+    }
+    auto *se3 = new SE3PriorFactor(Eigen::Vector3d(pp.t), Eigen::Quaterniond(from_row_major3(pp.R)));
+    se3->setIndex(0); se3->sqrt_info = from_row_major(pp.sqrt_info, 6, 6); e.vioPosePriorEdge = se3;
+    Eigen::Matrix<double, 9, 1> vbv; for (int k = 0; k < 9; k++) vbv(k) = vb.VB[k];
+    auto *l9 = new Linear9Factor(vbv); l9->setIndex(Vo_SIZE - 1); l9->sqrt_info = from_row_major(vb.sqrt_info, 9, 9); e.vioVBPrior = l9;
+}
+

@@ -21,7 +21,7 @@ _lib = None
 STATUS = {0: "ISV_OK", -1: "ISV_ERR_INVALID_ARG", -2: "ISV_ERR_CAPACITY", -3: "ISV_ERR_NONFINITE",
           -4: "ISV_ERR_DEVICE", -5: "ISV_ERR_UNSUPPORTED"}
 EXPORTS = ["isv_abi_version", "isv_backend_create", "isv_backend_destroy", "isv_backend_last_error",
-           "isv_backend_optimize", "isv_backend_optimize_batch", "isv_backend_triangulate", "isv_backend_linearize",
+           "isv_backend_optimize", "isv_backend_optimize_batch", "isv_backend_init_factor_graph", "isv_backend_triangulate", "isv_backend_linearize",
            "isv_batch_upload", "isv_batch_optimize", "isv_batch_linearize", "isv_batch_download",
            "isv_batch_sync", "isv_batch_last_timing", "isv_batch_last_counts"]
 
@@ -61,6 +61,7 @@ def load_library():
     lib.isv_backend_last_error.argtypes = [vp]; lib.isv_backend_last_error.restype = C.c_char_p
     lib.isv_backend_optimize.argtypes = [vp, C.POINTER(abi.isv_window_t), C.POINTER(abi.isv_summary_t), C.POINTER(abi.isv_marg_result_t)]
     lib.isv_backend_optimize_batch.argtypes = [vp, C.c_int32, wpp, C.POINTER(abi.isv_summary_t), C.POINTER(abi.isv_marg_result_t)]
+    lib.isv_backend_init_factor_graph.argtypes = [vp, C.POINTER(abi.isv_window_t), C.POINTER(abi.isv_summary_t), dp]
     lib.isv_backend_triangulate.argtypes = [vp, C.c_int32, wpp]
     lib.isv_backend_linearize.argtypes = [vp, C.POINTER(abi.isv_window_t), dp, dp, dp]
     lib.isv_batch_upload.argtypes = [vp, C.c_int32, wpp]
@@ -126,6 +127,13 @@ class Backend:
         cw = window.c()
         self._check(self.lib.isv_backend_linearize(self.h, C.byref(cw), abi._p(ps), abi._p(im), abi._p(cost)), "linearize")
         return ps[:F], im, float(cost[0])
+
+    def init_factor_graph(self, window):
+        """Estimator::initFactorGraph: prior-free solve + first prior factors (written into the window); returns (summary, kld)"""
+        s = abi.isv_summary_t(); kld = np.zeros(1)
+        self._check(self.lib.isv_backend_init_factor_graph(self.h, C.byref(window.c()), C.byref(s), abi._p(kld)), "init_factor_graph")
+        window.n_rollpitch = 0; window.margin_old = 0        # (the C side reset them in its view of the window)
+        return s, float(kld[0])
 
     def triangulate(self, windows):
         """FeatureManager::triangulate for the landmarks without a positive depth (lm_depth updated in place)"""

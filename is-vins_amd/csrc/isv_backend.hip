@@ -472,6 +472,50 @@ extern "C" int isv_backend_optimize(isv_backend_t *h, isv_window_t *w, isv_summa
     return isv_backend_optimize_batch(h, 1, ws, summary, marg);
 }
 
+// Estimator::initFactorGraph (src/estimator.cpp:667-1001): solve the window without prior factors (3 x NUM_ITERATIONS
+// dogleg iterations), derive the first prior factors from the solved estimate, double2vector.  The window's prior
+// structs are outputs.
+extern size_t init_priors_scratch_doubles(int Vo);
+extern "C" int isv_backend_init_factor_graph(isv_backend_t *h, isv_window_t *w, isv_summary_t *summary, double *kld) {
+    if (!h || !w || !w->pose_prior || !w->vb_prior || !w->relpose) return ISV_ERR_INVALID_ARG;
+    const isv_config_t &c = h->cfg;
+    if (6 * c.n_vo + 9 > 64) { h->err = "initFactorGraph: 6 Vo + 9 > 64 is not built"; return ISV_ERR_UNSUPPORTED; }
+    // the initial graph has no prior factors: zero information, identity rotations so that the residuals stay finite
+    static const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    memset(w->pose_prior, 0, sizeof(*w->pose_prior)); memcpy(w->pose_prior->R, I3, sizeof(I3));
+    memset(w->vb_prior, 0, sizeof(*w->vb_prior)); w->vb_prior->index = c.n_vo - 1;
+    for (int i = 0; i < c.n_vo - 1; i++) { memset(&w->relpose[i], 0, sizeof(isv_relpose_t)); memcpy(w->relpose[i].delta_R, I3, sizeof(I3)); w->relpose[i].imu_i = i; w->relpose[i].imu_j = i + 1; }
+    w->n_rollpitch = 0; w->margin_old = 0;
+    isv_window_t *ws[1] = {w};
+    TRY(isv_batch_upload(h, 1, ws));
+    DevBatch &d = h->d; hipStream_t st = h->stream;
+    const size_t per = init_priors_scratch_doubles(c.n_vo);
+    double *scratch = nullptr, *kld_dev = nullptr;
+    if (hipMalloc(&scratch, per * sizeof(double)) != hipSuccess || hipMalloc(&kld_dev, sizeof(double)) != hipSuccess) {
+        if (scratch) (void)hipFree(scratch);
+        h->err = "initFactorGraph: scratch allocation failed"; return ISV_ERR_DEVICE;
+    }
+    const int saved_iter = d.max_iter;
+    d.max_iter = 3 * c.num_iterations < ISV_MAX_TRACE - 1 ? 3 * c.num_iterations : ISV_MAX_TRACE - 1;
+    d.init_mode = 1; d.init_scratch = scratch; d.init_per_window = per; d.init_kld = kld_dev;
+    memset(h->last_counts, 0, sizeof(h->last_counts));
+    int rc = ISV_OK;
+    if (hipMemsetAsync(d.act, 0, sizeof(int32_t) * ISV_MAX_TRACE, st) != hipSuccess) rc = ISV_ERR_DEVICE;
+    if (rc == ISV_OK) {
+        hipLaunchKernelGGL(k_vector2double, dim3(d.B), dim3(64), 0, st, d);
+        rc = isv_solver_enqueue(h->d, st, h->stream2, h->fj, h->last_counts, nullptr, h->err);
+    }
+    h->prof_valid = 0;
+    d.max_iter = saved_iter; d.init_mode = 0; d.init_scratch = nullptr; d.init_kld = nullptr;
+    double kv = 0;
+    if (rc == ISV_OK) rc = isv_batch_download(h, 1, ws, summary, nullptr);
+    if (rc == ISV_OK && hipMemcpy(&kv, kld_dev, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = ISV_ERR_DEVICE;
+    (void)hipFree(scratch); (void)hipFree(kld_dev);
+    if (kld) *kld = kv;
+    h->resident = 0;
+    return rc;
+}
+
 // FeatureManager::triangulate (src/feature_tracker/feature_manager.cpp:206-258) for every landmark of the n windows whose
 // estimated depth is not positive: DLT over all its views, smallest right singular vector, clamp to INIT_DEPTH.
 extern "C" int isv_backend_triangulate(isv_backend_t *h, int32_t n, isv_window_t *const *ws) {

@@ -110,10 +110,12 @@ struct DevBatch {
     double *prior_H;                    // [B][prior_H_sz]
     uint32_t *lm_meta;                  // [Ltot] host | k << 8 | (first factor - f_off[w]) << 16
     double *W;                          // [Ftot + Ltot][6]  w = J_pose^T J_lambda per observation (obs index = factor + landmark [+1])
+    double *init_scratch, *init_kld;    // initFactorGraph scratch (per window init_per_window doubles) and its KLD output
+    size_t init_per_window;
     int32_t *act;                       // [ISV_MAX_TRACE] windows that linearised / solved in iteration i (bench bookkeeping)
     double2 *lm_cg;                     // [Ltot]  {c_l = s_l^2 / (s_l^2 E_l + mu D_l^2), g_l}
     double *Tvis;                       // [B][tvis_sz] reprojection part of the reduced system (6x6 pose corners), hd, g, bs
-    int32_t force_retry, _pad4;            // test hook (env ISV_DEBUG_FORCE_RETRY): treat the first n factorisations of an iteration as failed
+    int32_t force_retry, init_mode;       // init_mode: this enqueue is Estimator::initFactorGraph (no update(), no marginalisation)            // test hook (env ISV_DEBUG_FORCE_RETRY): treat the first n factorisations of an iteration as failed
     int32_t prior_H_sz, tvis_sz, wd_ld, max_lm;   // wd_ld: panel width of k_rank1_mfma (6N + 1 rounded up to 16); max_lm: landmarks per window cap
     int32_t marg_scratch_sz, lds_T;     // lds_T: reduced system lives in LDS (15N <= 165)
 };

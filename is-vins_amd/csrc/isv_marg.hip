@@ -83,8 +83,8 @@ DEV void w_chol_upper(const double *M, int n, double *U, double *L, int t) {
 // round touch disjoint index pairs, so they are computed and applied together (3 barriers per round
 // instead of 3 per rotation).  A (destroyed) = V diag(w) V^T.  rot: scratch [3 * 16] doubles + pairs.
 DEV void w_jacobi(double *A, int n, double *wv, double *V, double *tmp, int t) {
-    __shared__ double rc[16], rs[16];
-    __shared__ int rp[16], rq[16];
+    __shared__ double rc[32], rs[32];
+    __shared__ int rp[32], rq[32];                 // floor(n / 2) concurrent rotations, n <= 64
     for (int e = t; e < n * n; e += MT) V[e] = (e / n == e % n) ? 1.0 : 0.0;
     SYNC();
     const int m = n + (n & 1), half = m / 2;
@@ -638,5 +638,184 @@ __global__ __launch_bounds__(MT) void k_marg_bwd(DevBatch d) {
             out.backward_kld = 0.5 * (tr - ldA - ldinv - 21);
         }
         MSTAMP(8);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Estimator::initFactorGraph, the part after its ceres::Solve (src/estimator.cpp:744-999): build the first prior
+// factors from the solved estimate.  One wavefront per window; this runs once per sequence, so the (15 Vo)^2 /
+// (6 Vo + 9)^2 matrices simply live in a global scratch (`per_window` doubles per window) and go through the same
+// wave-cooperative helpers as the marginalisation kernels.
+//   Lambda (15 Vo)^2 from the first Vo-1 IMU factors (unweighted J, omega = sqrt_info^T sqrt_info), order
+//   [T0..T_{Vo-1}, VB_{Vo-1}, VB_0..VB_{Vo-2}] (:744-806); Schur out VB_0..VB_{Vo-2} (:810-817); RelativePose (i, i+1),
+//   SE3 prior on pose 0, Linear9 on speed/bias Vo-1 at the estimate, unweighted Jacobians stacked into Jr (:821-920);
+//   eigen-truncation at ALPHA, Sigma_i = (J_i U) D^-1 (J_i U)^T, sqrt_info = chol(Sigma_i^-1)^T (:927-974); KLD (:976-989).
+size_t init_priors_scratch_doubles(int Vo) {
+    const size_t n = 15 * (size_t)Vo, rr = 6 * (size_t)Vo + 9, mm = 9 * (size_t)(Vo - 1);
+    return n * n + 4 * mm * mm + mm * rr + 9 * rr * rr + 1024;
+}
+__global__ __launch_bounds__(MT) void k_init_priors(DevBatch d, double *scratch, size_t per_window, double *kld_out) {
+    __shared__ double M1[450], M2s[450], wv[64], tmp[128], sJ[72];
+    __shared__ int keep[64], piv[4];
+    const int w = blockIdx.x, t = threadIdx.x;
+    const int N = d.N, V = d.Nvo, n = 15 * V, rr = 6 * V + 9, mm = 9 * (V - 1);
+    const double *pose = d.pose + (size_t)w * N * 7, *sb = d.sb + (size_t)w * N * 9;
+    double *p = scratch + (size_t)w * per_window;
+    double *Lam = p; p += (size_t)n * n;
+    double *Wgj = p; p += 2 * (size_t)mm * mm;
+    double *Linv = p; p += (size_t)mm * mm;
+    double *Lmm = p; p += (size_t)mm * mm;
+    double *T = p; p += (size_t)mm * rr;
+    double *Lp = p; p += rr * rr;
+    double *M2 = p; p += rr * rr;
+    double *Vv = p; p += rr * rr;
+    double *Jr = p; p += rr * rr;
+    double *JU = p; p += rr * rr;
+    double *XJU = p; p += rr * rr;
+    double *A = p; p += rr * rr;
+    double *Xall = p; p += rr * rr;
+    double *Ak = p; p += rr * rr;
+    double *Wk = p;                                    // 1024 doubles of small scratch
+    for (int e = t; e < n * n; e += MT) Lam[e] = 0.0;
+    SYNC();
+    for (int i = 0; i < V - 1; i++) {
+        const size_t f = (size_t)w * (N - 1) + i;
+        if (d.imu_skip[f]) continue;                   // uniform over the block
+        // raw (unweighted) IMU Jacobian 15x30 (columns: pose_i 0..5, sb_i 6..14, pose_j 15..20, sb_j 21..29), imu_factor.h:161-265
+        for (int e = t; e < 450; e += MT) M1[e] = 0.0;
+        SYNC();
+        if (t == 0) {
+            const double *rec = d.imu_in + f * ISV_IMU_IN;
+            const double *pi = pose + 7 * i, *pj = pi + 7, *si = sb + 9 * i, *sj = si + 9;
+            Quat Qi = q_from_pose(pi), Qj = q_from_pose(pj), Qii = q_inv(Qi);
+            const double dt = rec[IMU_DT];
+            double dbg[3], tt[3], u[3], o1[3], o2[3], RiT[9], S1[9], S2[9], B1[9], B2[9], L[9], Rr[9], Tm[9];
+            for (int k = 0; k < 3; k++) dbg[k] = si[6 + k] - rec[IMU_LBG + k];
+            Quat dq = Quat{rec[IMU_DQ + 3], rec[IMU_DQ], rec[IMU_DQ + 1], rec[IMU_DQ + 2]};
+            m3v(rec + IMU_DQ_DBG, dbg, tt);
+            Quat cdq = q_mul(dq, q_delta(tt));
+            q_to_R(Qii, RiT);
+            for (int k = 0; k < 3; k++) u[k] = 0.5 * d.G[k] * dt * dt + pj[k] - pi[k] - si[k] * dt;
+            q_rot(Qii, u, o1);
+            for (int k = 0; k < 3; k++) u[k] = d.G[k] * dt + sj[k] - si[k];
+            q_rot(Qii, u, o2);
+            skew3(o1, S1); skew3(o2, S2);
+            Quat aq = q_mul(q_inv(Qj), Qi);
+            qleft33(aq, L); qright33(cdq, Rr); m3_mul(L, Rr, B1);
+            const double av[3] = {aq.x, aq.y, aq.z}, bv[3] = {cdq.x, cdq.y, cdq.z};
+            for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) B1[r * 3 + c] += av[r] * (-bv[c]);
+            qleft33(q_mul(q_mul(q_inv(Qj), Qi), dq), L);
+            m3_mul(L, rec + IMU_DQ_DBG, Tm);
+            qleft33(q_mul(q_mul(q_inv(cdq), Qii), Qj), B2);
+            for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) {
+                const int ab = a * 3 + b;
+                M1[(0 + a) * 30 + 0 + b] = -RiT[ab]; M1[(0 + a) * 30 + 3 + b] = S1[ab]; M1[(3 + a) * 30 + 3 + b] = -B1[ab]; M1[(6 + a) * 30 + 3 + b] = S2[ab];
+                M1[(0 + a) * 30 + 6 + b] = -RiT[ab] * dt; M1[(0 + a) * 30 + 9 + b] = -rec[IMU_DP_DBA + ab]; M1[(0 + a) * 30 + 12 + b] = -rec[IMU_DP_DBG + ab];
+                M1[(3 + a) * 30 + 12 + b] = -Tm[ab]; M1[(6 + a) * 30 + 6 + b] = -RiT[ab]; M1[(6 + a) * 30 + 9 + b] = -rec[IMU_DV_DBA + ab];
+                M1[(6 + a) * 30 + 12 + b] = -rec[IMU_DV_DBG + ab];
+                M1[(9 + a) * 30 + 9 + b] = (a == b) ? -1.0 : 0.0; M1[(12 + a) * 30 + 12 + b] = (a == b) ? -1.0 : 0.0;
+                M1[(0 + a) * 30 + 15 + b] = RiT[ab]; M1[(3 + a) * 30 + 18 + b] = B2[ab]; M1[(6 + a) * 30 + 21 + b] = RiT[ab];
+                M1[(9 + a) * 30 + 24 + b] = (a == b) ? 1.0 : 0.0; M1[(12 + a) * 30 + 27 + b] = (a == b) ? 1.0 : 0.0;
+            }
+        }
+        SYNC();
+        const double *S = d.imu_sqrt + f * 225;
+        for (int e = t; e < 450; e += MT) { const int a = e / 30, c = e % 30; double s = 0; for (int k = 0; k < 15; k++) s += S[a * 15 + k] * M1[k * 30 + c]; M2s[e] = s; }
+        SYNC();
+        const int j = i + 1;
+        const int si_off = (i == V - 1) ? 6 * V : 6 * V + 9 + 9 * i, sj_off = (j == V - 1) ? 6 * V : 6 * V + 9 + 9 * j;
+        for (int e = t; e < 900; e += MT) {
+            const int a = e / 30, b = e % 30;
+            const int ga = a < 6 ? 6 * i + a : (a < 15 ? si_off + a - 6 : (a < 21 ? 6 * j + a - 15 : sj_off + a - 21));
+            const int gb = b < 6 ? 6 * i + b : (b < 15 ? si_off + b - 6 : (b < 21 ? 6 * j + b - 15 : sj_off + b - 21));
+            double s = 0; for (int k = 0; k < 15; k++) s += M2s[k * 30 + a] * M2s[k * 30 + b];
+            Lam[(size_t)ga * n + gb] += s;
+        }
+        SYNC();
+    }
+    // Schur out VB_0..VB_{Vo-2}: Lambda_prior = L_rr - L_rm L_mm^-1 L_rm^T
+    for (int e = t; e < mm * mm; e += MT) { const int a = e / mm, b = e % mm; Lmm[e] = Lam[(size_t)(rr + a) * n + rr + b]; }
+    SYNC();
+    w_inv(Lmm, mm, Linv, Wgj, piv, t);
+    for (int e = t; e < mm * rr; e += MT) {
+        const int pp = e / rr, b = e % rr; double s = 0;
+        for (int q = 0; q < mm; q++) s += Linv[pp * mm + q] * Lam[(size_t)b * n + rr + q];
+        T[e] = s;
+    }
+    SYNC();
+    for (int e = t; e < rr * rr; e += MT) {
+        const int a = e / rr, b = e % rr; double s = Lam[(size_t)a * n + b];
+        for (int q = 0; q < mm; q++) s -= Lam[(size_t)a * n + rr + q] * T[q * rr + b];
+        Lp[e] = s;
+    }
+    for (int e = t; e < rr * rr; e += MT) { Jr[e] = 0.0; Xall[e] = 0.0; }
+    SYNC();
+    // the recovered factors at the solved estimate (measurements now, information below)
+    if (t == 0) {
+        for (int i = 0; i < V - 1; i++) {
+            isv_relpose_t &f = d.relpose[(size_t)w * (V - 1) + i];
+            const double *PSi = pose + 7 * i, *PSj = pose + 7 * (i + 1);
+            Quat Qi = q_from_pose(PSi), Qj = q_from_pose(PSj);
+            double dd[3] = {PSj[0] - PSi[0], PSj[1] - PSi[1], PSj[2] - PSi[2]}, r6[6];
+            q_rot(q_inv(Qi), dd, f.delta_t); q_to_R(q_mul(q_inv(Qi), Qj), f.delta_R);
+            f.imu_i = i; f.imu_j = i + 1;
+            relpose_jac(f.delta_t, f.delta_R, PSi, PSj, r6, sJ, sJ + 36);
+            for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) { Jr[(6 * i + a) * rr + 6 * i + b] += sJ[a * 6 + b]; Jr[(6 * i + a) * rr + 6 * (i + 1) + b] += sJ[36 + a * 6 + b]; }
+        }
+        isv_se3_prior_t &pp = d.se3[w];
+        for (int k = 0; k < 3; k++) pp.t[k] = pose[k];
+        q_to_R(q_from_pose(pose), pp.R); pp.index = 0; pp._pad = 0;
+        isv_linear9_t &vb = d.lin9[w];
+        for (int k = 0; k < 9; k++) vb.VB[k] = sb[9 * (V - 1) + k];
+        vb.index = V - 1; vb._pad = 0;
+        const int r0 = 6 * (V - 1);
+        // SE3PriorFactor::EvaluateOnlyJacobians at its own measurement: residual 0, J = [I 0; 0 Jr^-1(0)] = I; Linear9: I
+        for (int a = 0; a < 6; a++) Jr[(r0 + a) * rr + a] += 1.0;
+        for (int a = 0; a < 9; a++) Jr[(r0 + 6 + a) * rr + 6 * V + a] += 1.0;
+    }
+    SYNC();
+    // eigen-truncate Lambda_prior at ALPHA
+    for (int e = t; e < rr * rr; e += MT) M2[e] = Lp[e];
+    SYNC();
+    w_jacobi(M2, rr, wv, Vv, tmp, t);
+    if (t < rr) keep[t] = wv[t] > d.alpha_cut;
+    SYNC();
+    {
+        double *Sg = Wk, *Xi = Wk + 100;
+        int hdim = 0;
+        for (int i = 0; i < V + 1; i++) {              // Vo-1 relative poses, the pose prior, the speed/bias prior
+            const int rows = i < V ? 6 : 9;
+            double *dst = i < V - 1 ? d.relpose[(size_t)w * (V - 1) + i].sqrt_info : (i == V - 1 ? d.se3[w].sqrt_info : d.lin9[w].sqrt_info);
+            w_project_cov(Jr + (size_t)hdim * rr, rows, rr, Vv, wv, keep, JU, Sg, t);
+            w_inv(Sg, rows, Xi, Wk + 300, piv, t);
+            for (int e = t; e < rows * rows; e += MT) Xall[(hdim + e / rows) * rr + hdim + e % rows] = Xi[e];
+            SYNC();
+            w_chol_upper(Xi, rows, Sg, Wk + 200, t);
+            for (int e = t; e < rows * rows; e += MT) dst[e] = Sg[e];
+            SYNC();
+            hdim += rows;
+        }
+    }
+    // KLD of the recovered factors against the truncated marginal: A = (Jr U)^T X (Jr U) over the kept eigenpairs vs D
+    int rank = 0; for (int k = 0; k < rr; k++) rank += keep[k];
+    for (int e = t; e < rr * rr; e += MT) {
+        const int a = e / rr, k = e % rr; double s = 0;
+        for (int c = 0; c < rr; c++) s += Jr[a * rr + c] * Vv[c * rr + k];
+        JU[e] = s;
+    }
+    SYNC();
+    w_mm(Xall, JU, XJU, rr, rr, rr, t);
+    for (int e = t; e < rr * rr; e += MT) { const int a = e / rr, b = e % rr; double s = 0; for (int k = 0; k < rr; k++) s += JU[k * rr + a] * XJU[k * rr + b]; A[e] = s; }
+    SYNC();
+    if (t == 0) {
+        int ia = 0;
+        for (int a = 0; a < rr; a++) if (keep[a]) { int ib = 0; for (int b = 0; b < rr; b++) if (keep[b]) { Ak[ia * rank + ib] = A[a * rr + b]; ib++; } ia++; }
+    }
+    SYNC();
+    const double ldA = w_logdet_spd(Ak, rank, M2, t);
+    if (t == 0) {
+        double tr = 0, ldinv = 0; int ia = 0;
+        for (int a = 0; a < rr; a++) if (keep[a]) { tr += Ak[ia * rank + ia] / wv[a]; ldinv += log(1.0 / wv[a]); ia++; }
+        kld_out[w] = 0.5 * (tr - ldA - ldinv - rr);
     }
 }

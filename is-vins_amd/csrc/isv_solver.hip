@@ -19,6 +19,7 @@ extern size_t build_solve_lds_bytes(int N, bool lds_T);
 template <bool BIG> __global__ void k_build_solve_sb(DevBatch d);
 extern size_t build_solve_sb_bytes(int N, int prior_H_sz);
 __global__ void k_model_imu_prior(DevBatch d);
+__global__ void k_init_priors(DevBatch d, double *scratch, size_t per_window, double *kld_out);
 __global__ void k_imu_raw(DevBatch d, const double *pose_src, const double *sb_src, int gate);
 __global__ void k_imu_weight(DevBatch d, double *cost_out, int gate);
 __global__ void k_sweep_mfma(DevBatch d);
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(256) void k_step_control(DevBatch d) {
 
 // ------------------------------------------------------------------------------------------
 // after the solve: update() of every prior (estimator.cpp:1133-1144), then double2vector (:518-594)
-__global__ __launch_bounds__(64) void k_finalize(DevBatch d) {
+__global__ __launch_bounds__(64) void k_finalize(DevBatch d, int do_update) {
     // one wavefront per window: lane roles for the prior updates, lane per frame for double2vector, lanes over
     // the landmarks for the depths
     const int w = blockIdx.x, lane = threadIdx.x;
@@ -357,7 +358,9 @@ __global__ __launch_bounds__(64) void k_finalize(DevBatch d) {
     ypr2R(ypr, rot_diff);
     if (fabs(fabs(origin_R0[1]) - 90) < 1.0 || fabs(fabs(origin_R00[1]) - 90) < 1.0) m3_mul_nt(Rs0, R00, rot_diff);
     // ---- update() of the prior factors (pseudo-measurement shift), one lane each; they read the old Ps / Rs ----
-    if (lane == 0) {
+    // (initFactorGraph creates its priors at the estimate and calls double2vector() only: do_update == 0)
+    if (!do_update) {
+    } else if (lane == 0) {
         // Linear9Factor::update  linear9_factor.h:60-68
         isv_linear9_t &f = d.lin9[w];
         for (int k = 0; k < 3; k++) {
@@ -561,7 +564,13 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
         if (!d.lds_T) HCHK(hipStreamWaitEvent(st, fj[3], 0));
         hipLaunchKernelGGL(k_step_control, dim3(d.B), dim3(256), 0, st, d);
     }
-    hipLaunchKernelGGL(k_finalize, dim3(d.B), dim3(64), 0, st, d);
+    if (d.init_mode) {                     // Estimator::initFactorGraph: first priors from the solved estimate, then double2vector
+        hipLaunchKernelGGL(k_init_priors, dim3(d.B), dim3(64), 0, st, d, d.init_scratch, d.init_per_window, d.init_kld);
+        hipLaunchKernelGGL(k_finalize, dim3(d.B), dim3(64), 0, st, d, 0);
+        HCHK(hipGetLastError());
+        return ISV_OK;
+    }
+    hipLaunchKernelGGL(k_finalize, dim3(d.B), dim3(64), 0, st, d, 1);
     // MargForward and MargBackward are independent: run them side by side
     hipLaunchKernelGGL(k_marg_clear, dim3(d.B), dim3(64), 0, st, d);
     HCHK(hipEventRecord(fj[0], st)); HCHK(hipStreamWaitEvent(st2, fj[0], 0));

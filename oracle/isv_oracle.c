@@ -824,6 +824,110 @@ int isvo_optimize(const isv_config_t *cfg, isv_window_t *w, isv_summary_t *sum, 
     return ISV_OK;
 }
 
+/* Estimator::initFactorGraph  src/estimator.cpp:667-1001 (one-time, INITIAL_STRUCTURE -> NON_LINEAR).
+ *  1. solve the window WITHOUT prior factors: IMU + reprojection factors only, max_num_iterations = 3 NUM_ITERATIONS
+ *     (:677-742; the 1 s wall-clock cap and num_threads = 2 of the reference are not restated);
+ *  2. Lambda (15 Vo)^2 from the first Vo-1 IMU factors, unweighted Jacobians and omega = sqrt_info^T sqrt_info, order
+ *     [T0..T_{Vo-1}, VB_{Vo-1}, VB_0..VB_{Vo-2}] (:744-806); Schur out VB_0..VB_{Vo-2} with a fullPivLu inverse (:810-817);
+ *  3. new factors at the solved estimate: RelativePose (i, i+1) for i < Vo-1, SE3 prior on pose 0, Linear9 on
+ *     speed/bias Vo-1, unweighted Jacobians stacked into Jr (:821-920);
+ *  4. eigen-truncate Lambda_prior at ALPHA, per factor Sigma_i = (J_i U) D^-1 (J_i U)^T, sqrt_info = chol(Sigma_i^-1)^T
+ *     (:927-974); KLD of the recovered factors against the truncated marginal (:976-989);
+ *  5. double2vector() (:999).
+ * The window's prior structs are OUTPUTS (vioRelativePoseEdges[1..], vioPosePriorEdge, vioVBPrior); no roll-pitch edge
+ * exists after initialisation. */
+int isvo_init_factor_graph(const isv_config_t *cfg, isv_window_t *w, isv_summary_t *sum, double *kld_out) {
+    const int V = cfg->n_vo;
+    static const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    memset(w->pose_prior, 0, sizeof(*w->pose_prior)); memcpy(w->pose_prior->R, I3, 72);
+    memset(w->vb_prior, 0, sizeof(*w->vb_prior)); w->vb_prior->index = V - 1;
+    for (int i = 0; i < V - 1; i++) { memset(&w->relpose[i], 0, sizeof(isv_relpose_t)); memcpy(w->relpose[i].delta_R, I3, 72); w->relpose[i].imu_i = i; w->relpose[i].imu_j = i + 1; }
+    w->n_rollpitch = 0;
+    problem_t P; build_problem(&P, cfg, w);
+    vector2double(w, cfg->n_frames, P.pose, P.sb, P.ex, P.lam);
+    isv_summary_t local; if (!sum) sum = &local;
+    minimize(&P, 3 * cfg->num_iterations, sum);
+    const double *pose = P.pose, *sb = P.sb;
+    const int n = 15 * V, rr = 6 * V + 9, mmd = 9 * (V - 1);
+    double *Lam = (double *)calloc((size_t)n * n, 8);
+    for (int i = 0; i < V - 1; i++) {
+        if (w->imu[i].sum_dt > 10.0) continue;
+        double r[15], Jpi7[105], Jsi[135], Jpj7[105], Jsj[135], Jpi[90], Jpj[90], Om[225];
+        isvo_imu_eval(&w->imu[i], cfg->gravity, pose + 7 * i, sb + 9 * i, pose + 7 * (i + 1), sb + 9 * (i + 1), NULL, r, Jpi7, Jsi, Jpj7, Jsj);
+        compact6(Jpi7, 15, Jpi); compact6(Jpj7, 15, Jpj);
+        const double *S = P.imu_sqrt_info + 225 * i;
+        mm_tn(S, S, Om, 15, 15, 15);
+        const int j = i + 1;
+        const int si_off = (i == V - 1) ? 6 * V : 6 * V + 9 + 9 * i, sj_off = (j == V - 1) ? 6 * V : 6 * V + 9 + 9 * j;
+        const double *Jb[4] = {Jpi, Jsi, Jpj, Jsj}; int db[4] = {6, 9, 6, 9}; int ib[4] = {6 * i, si_off, 6 * j, sj_off};
+        for (int a = 0; a < 4; a++) for (int b = a; b < 4; b++) add_hessian(Lam, n, Jb[a], db[a], ib[a], Jb[b], db[b], ib[b], Om, 15);
+    }
+    double *Lmm = (double *)malloc(8 * mmd * mmd), *Lmm_inv = (double *)malloc(8 * mmd * mmd), *T = (double *)malloc(8 * mmd * rr);
+    double *Lp = (double *)malloc(8 * rr * rr);
+    for (int a = 0; a < mmd; a++) for (int b = 0; b < mmd; b++) Lmm[a * mmd + b] = Lam[(size_t)(rr + a) * n + rr + b];
+    inv_full_lu(Lmm, Lmm_inv, mmd);
+    for (int p = 0; p < mmd; p++) for (int b = 0; b < rr; b++) { double s = 0; for (int q = 0; q < mmd; q++) s += Lmm_inv[p * mmd + q] * Lam[(size_t)b * n + rr + q]; T[p * rr + b] = s; }
+    for (int a = 0; a < rr; a++) for (int b = 0; b < rr; b++) { double s = Lam[(size_t)a * n + b]; for (int p = 0; p < mmd; p++) s -= Lam[(size_t)a * n + rr + p] * T[p * rr + b]; Lp[a * rr + b] = s; }
+    /* recovered factors and their stacked unweighted Jacobians */
+    double *Jr = (double *)calloc((size_t)rr * rr, 8);
+    for (int i = 0; i < V - 1; i++) {
+        const double *PSi = pose + 7 * i, *PSj = pose + 7 * (i + 1);
+        quat_t Qi = q_from_pose(PSi), Qj = q_from_pose(PSj);
+        double dd[3] = {PSj[0] - PSi[0], PSj[1] - PSi[1], PSj[2] - PSi[2]};
+        isv_relpose_t *rp = &w->relpose[i]; memset(rp, 0, sizeof(*rp));
+        q_rot(q_inv(Qi), dd, rp->delta_t); q_to_R(q_mul(q_inv(Qi), Qj), rp->delta_R);
+        rp->imu_i = i; rp->imu_j = i + 1;
+        double r6[6], Ji7[42], Jj7[42], Ji[36], Jj[36];
+        isvo_relpose_eval(rp, NULL, PSi, PSj, r6, Ji7, Jj7); compact6(Ji7, 6, Ji); compact6(Jj7, 6, Jj);
+        for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) { Jr[(size_t)(6 * i + a) * rr + 6 * i + b] += Ji[a * 6 + b]; Jr[(size_t)(6 * i + a) * rr + 6 * (i + 1) + b] += Jj[a * 6 + b]; }
+    }
+    {
+        isv_se3_prior_t *pp = w->pose_prior; memset(pp, 0, sizeof(*pp));
+        memcpy(pp->t, pose, 24); q_to_R(q_from_pose(pose), pp->R); pp->index = 0;
+        double r6[6], J7[42], J6[36];
+        isvo_se3prior_eval(pp, NULL, pose, r6, J7); compact6(J7, 6, J6);
+        const int r0 = 6 * (V - 1);
+        for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) Jr[(size_t)(r0 + a) * rr + b] += J6[a * 6 + b];
+        isv_linear9_t *vb = w->vb_prior; memset(vb, 0, sizeof(*vb));
+        memcpy(vb->VB, sb + 9 * (V - 1), 72); vb->index = V - 1;
+        for (int a = 0; a < 9; a++) Jr[(size_t)(r0 + 6 + a) * rr + 6 * V + a] += 1.0;     /* Linear9Factor::EvaluateOnlyJacobians: identity */
+    }
+    double *U = (double *)malloc(8 * rr * rr), *Dv = (double *)malloc(8 * rr);
+    const int rank = eig_truncate(Lp, rr, cfg->alpha, U, Dv);
+    double *X = (double *)calloc((size_t)rr * rr, 8);
+    int hdim = 0;
+    for (int i = 0; i < V + 1; i++) {               /* V-1 relative poses, the pose prior, the speed/bias prior */
+        const int rows = i < V ? 6 : 9;
+        double Sg[81], Xi[81];
+        project_cov(Jr + (size_t)hdim * rr, rows, rr, U, Dv, rank, Sg);
+        inv_partial_lu(Sg, Xi, rows);
+        double *dst = i < V - 1 ? w->relpose[i].sqrt_info : (i == V - 1 ? w->pose_prior->sqrt_info : w->vb_prior->sqrt_info);
+        llt_upper(Xi, rows, dst);
+        for (int a = 0; a < rows; a++) for (int b = 0; b < rows; b++) X[(size_t)(hdim + a) * rr + hdim + b] = Xi[a * rows + b];
+        hdim += rows;
+    }
+    if (kld_out) {                                  /* A = (Jr U)^T X (Jr U) against D (:976-989) */
+        double *JU = (double *)malloc(8 * rr * rank), *XJU = (double *)malloc(8 * rr * rank), *A = (double *)malloc(8 * rank * rank + 8);
+        for (int a = 0; a < rr; a++) for (int k = 0; k < rank; k++) { double s = 0; for (int c = 0; c < rr; c++) s += Jr[(size_t)a * rr + c] * U[c * rr + k]; JU[a * rank + k] = s; }
+        mm(X, JU, XJU, rr, rr, rank);
+        mm_tn(JU, XJU, A, rank, rr, rank);
+        double tr = 0, ldinv = 0;
+        for (int k = 0; k < rank; k++) { tr += A[k * rank + k] / Dv[k]; ldinv += log(1.0 / Dv[k]); }
+        /* the reference takes log(A.determinant()) and log(Dinv.determinant()) (:985-986), which overflow / underflow for
+         * 6 Vo + 9 = 57 eigenvalues around 1e8 (its KLD is only a commented-out print); the log domain gives the intended value */
+        *kld_out = 0.5 * (tr - logabsdet_lu(A, rank) - ldinv - rr);
+        free(JU); free(XJU); free(A);
+    }
+    double2vector(cfg, w, P.pose, P.sb, P.ex, P.lam);
+    if (w->para_Pose) memcpy(w->para_Pose, P.pose, 56 * P.N);
+    if (w->para_SpeedBias) memcpy(w->para_SpeedBias, P.sb, 72 * P.N);
+    if (w->para_Ex_Pose) memcpy(w->para_Ex_Pose, P.ex, 56);
+    if (w->para_Feature) memcpy(w->para_Feature, P.lam, 8 * P.L);
+    free(Lam); free(Lmm); free(Lmm_inv); free(T); free(Lp); free(Jr); free(U); free(Dv); free(X);
+    free_problem(&P);
+    return ISV_OK;
+}
+
 /* FeatureManager::triangulate  src/feature_tracker/feature_manager.cpp:206-258.  For every landmark without a positive
  * depth: DLT matrix A (2k x 4) over all k views in the host camera frame (:219-242), V = right singular vector of the
  * smallest singular value (Eigen::JacobiSVD, :244), depth = V[2] / V[3] (:245), INIT_DEPTH outside [0.1, 8] (:252-255).

@@ -407,4 +407,21 @@ static inline double det_lu(const double *Ain, int n) {
     free(A);
     return det;
 }
+/* log |det A| by the same elimination, accumulated in the log domain (a 57 x 57 information matrix with eigenvalues
+ * around 1e8 overflows a double determinant) */
+static inline double logabsdet_lu(const double *Ain, int n) {
+    double *A = (double *)malloc(sizeof(double) * n * n);
+    memcpy(A, Ain, sizeof(double) * n * n);
+    double ld = 0;
+    for (int k = 0; k < n; k++) {
+        int p = k; double best = fabs(A[k * n + k]);
+        for (int i = k + 1; i < n; i++) if (fabs(A[i * n + k]) > best) { best = fabs(A[i * n + k]); p = i; }
+        if (best == 0.0) { ld = -INFINITY; break; }
+        if (p != k) for (int j = 0; j < n; j++) { double t = A[k * n + j]; A[k * n + j] = A[p * n + j]; A[p * n + j] = t; }
+        ld += log(fabs(A[k * n + k]));
+        for (int i = k + 1; i < n; i++) { double f = A[i * n + k] / A[k * n + k]; for (int j = k + 1; j < n; j++) A[i * n + j] -= f * A[k * n + j]; }
+    }
+    free(A);
+    return ld;
+}
 #endif

@@ -35,6 +35,8 @@ def load():
     lib.isvo_schur_solve.restype = C.c_int
     lib.isvo_cost.argtypes = [C.POINTER(abi.isv_config_t), C.POINTER(abi.isv_window_t)]
     lib.isvo_cost.restype = C.c_double
+    lib.isvo_init_factor_graph.argtypes = [C.POINTER(abi.isv_config_t), C.POINTER(abi.isv_window_t), C.POINTER(abi.isv_summary_t), dp]
+    lib.isvo_init_factor_graph.restype = C.c_int
     lib.isvo_triangulate.argtypes = [C.POINTER(abi.isv_config_t), C.POINTER(abi.isv_window_t)]
     lib.isvo_triangulate.restype = C.c_int
     lib.isvo_debug_force_retry.argtypes = [C.c_int]
