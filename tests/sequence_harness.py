@@ -1,0 +1,405 @@
+"""Host-side window manager of the reference estimator, restated for whole-sequence tests (TEST INFRASTRUCTURE).
+
+Mirrors, with the reference's control flow and quirks:
+  Estimator::processIMU        src/estimator.cpp:91-124     (state propagation + pre-integration feed)
+  Estimator::processImage      src/estimator.cpp:126-215    (NON_LINEAR branch; see `bootstrap` for INITIAL)
+  Estimator::solveOdometry     src/estimator.cpp:461-472    (triangulate -> backendOptimization)
+  Estimator::slideWindow       src/estimator.cpp:1565-1724  (MARGIN_OLD / MARGIN_NEW, prior-factor rotation)
+  FeatureManager::addFeatureAndCheckParallax / compensatedParallax2 / removeBackShiftDepth / removeFront /
+  removeFailures               src/feature_tracker/feature_manager.cpp:52-101, 356-390, 275-313, 335-354, 262-273
+The arithmetic of the hot path itself (triangulate, initFactorGraph, backendOptimization) is NOT here: it is delegated
+to a `solver` object, either the CPU oracle or the MI355X backend, so the same stream of IMU samples and feature
+observations can be pushed through both and the two trajectories compared (ATE).
+
+Not restated: the visual-inertial initialisation (initialStructure: SfM + alignment, out of scope).  `bootstrap`
+replaces it: when the window first fills, the states are set from a (perturbed) reference trajectory, exactly the
+hand-over point at which the reference switches to INITIAL_STRUCTURE (src/estimator.cpp:176-181).
+"""
+import ctypes as C
+
+import numpy as np
+
+from isvins_amd import abi, synth
+
+ACC_N, GYR_N, ACC_W, GYR_W = synth.ACC_N, synth.GYR_N, synth.ACC_W, synth.GYR_W
+MIN_PARALLAX = 10.0 / 460.0            # keyframe_parallax / FOCAL_LENGTH (config/euroc_config.yaml:43, parameters.cpp:82-83)
+
+
+def _delta_q_R(theta):
+    """Utility::deltaQ(theta).toRotationMatrix(): q = [1, theta/2] NOT normalised, Eigen's toRotationMatrix formula"""
+    w, x, y, z = 1.0, theta[0] / 2, theta[1] / 2, theta[2] / 2
+    tx, ty, tz = 2 * x, 2 * y, 2 * z
+    twx, twy, twz = tx * w, ty * w, tz * w
+    txx, txy, txz = tx * x, ty * x, tz * x
+    tyy, tyz, tzz = ty * y, tz * y, tz * z
+    return np.array([[1 - (tyy + tzz), txy - twz, txz + twy],
+                     [txy + twz, 1 - (txx + tzz), tyz - twx],
+                     [txz - twy, tyz + twx, 1 - (txx + tyy)]])
+
+
+class PreInt:
+    """IntegrationBase (include/factor/integration_base.h): the POD the factors read + the raw sample buffers;
+    propagation by the oracle's restated midpoint rule (isvo_x_preint_step)."""
+
+    def __init__(self, lib, acc_0, gyr_0, ba, bg):
+        self.lib = lib
+        self.pod = abi.isv_imu_t()
+        self.acc_0, self.gyr_0 = np.array(acc_0, float), np.array(gyr_0, float)
+        lib.isvo_x_preint_init(C.byref(self.pod), abi._p(np.array(ba, float)), abi._p(np.array(bg, float)))
+        self.noise = np.array([ACC_N, GYR_N, ACC_W, GYR_W])
+
+    def push_back(self, dt, acc, gyr):
+        acc, gyr = np.array(acc, float), np.array(gyr, float)
+        self.lib.isvo_x_preint_step(C.byref(self.pod), C.c_double(float(dt)), abi._p(self.acc_0), abi._p(self.gyr_0), abi._p(acc), abi._p(gyr),
+                                    abi._p(self.noise))
+        self.acc_0, self.gyr_0 = acc, gyr
+
+
+class Track:
+    """IDFeatures: one landmark track (feature_manager.h:44-63)"""
+
+    def __init__(self, fid, start_frame):
+        self.id, self.start_frame = fid, start_frame
+        self.points = []               # Feature::point per frame from start_frame on
+        self.depth = -1.0              # estimated_depth
+        self.solve_flag = 0
+
+    def end_frame(self):
+        return self.start_frame + len(self.points) - 1
+
+
+class OracleSolver:
+    def __init__(self, lib, cfg):
+        self.lib, self.cfg = lib, cfg
+
+    def triangulate(self, w):
+        assert self.lib.isvo_triangulate(C.byref(self.cfg), C.byref(w.c())) == 0
+
+    def init_factor_graph(self, w):
+        s = abi.isv_summary_t(); kld = np.zeros(1)
+        assert self.lib.isvo_init_factor_graph(C.byref(self.cfg), C.byref(w.c()), C.byref(s), abi._p(kld)) == 0
+        w.n_rollpitch = 0
+        return s
+
+    def optimize(self, w):
+        s = abi.isv_summary_t(); m = abi.isv_marg_result_t()
+        assert self.lib.isvo_optimize(C.byref(self.cfg), C.byref(w.c()), C.byref(s), C.byref(m)) == 0
+        return s, m
+
+
+class DeviceSolver:
+    def __init__(self, backend):
+        self.be, self.cfg = backend, backend.cfg
+
+    def triangulate(self, w):
+        self.be.triangulate([w])
+
+    def init_factor_graph(self, w):
+        s, _ = self.be.init_factor_graph(w)
+        return s
+
+    def optimize(self, w):
+        return self.be.optimize(w)
+
+
+class Estimator:
+    def __init__(self, solver, lib, N, Nvo, g_norm=9.81007):
+        self.solver, self.lib, self.N, self.Nvo = solver, lib, N, Nvo
+        self.g = np.array([0, 0, g_norm])
+        self.ric, self.tic = synth.RIC.copy(), synth.TIC.copy()
+        self.Ps, self.Vs = np.zeros((N, 3)), np.zeros((N, 3))
+        self.Rs = np.tile(np.eye(3), (N, 1, 1))
+        self.Bas, self.Bgs = np.zeros((N, 3)), np.zeros((N, 3))
+        self.Headers = np.zeros(N)
+        self.pre = [None] * N
+        self.bufs = [[] for _ in range(N)]           # (dt, acc, gyr) per frame
+        self.frame_count, self.first_imu = 0, True
+        self.acc_0, self.gyr_0 = np.zeros(3), np.zeros(3)
+        self.solver_flag = "INITIAL"
+        self.tracks = []                             # IDsfeatures, insertion order
+        self.pose_prior, self.vb_prior = abi.isv_se3_prior_t(), abi.isv_linear9_t()
+        self.relpose = [abi.isv_relpose_t() for _ in range(Nvo - 1)]      # edge (i, i+1) = vioRelativePoseEdges[i+1]
+        self.rollpitch = []                          # vioRollPitchEdges
+        self.margin_old = True
+        self.to_add = None                           # (forward pose prior, backward relpose, backward vb) from the last MARGIN_OLD solve
+        self.trajectory = []                         # (header, P, R) of the newest frame after every solve
+        self.summaries = []
+
+    # ---- Estimator::processIMU  src/estimator.cpp:91-124 ---------------------------------------
+    def process_imu(self, dt, acc, gyr):
+        acc, gyr = np.array(acc, float), np.array(gyr, float)
+        if self.first_imu:
+            self.first_imu = False
+            self.acc_0, self.gyr_0 = acc, gyr
+        j = self.frame_count
+        if self.pre[j] is None:
+            self.pre[j] = PreInt(self.lib, self.acc_0, self.gyr_0, self.Bas[j], self.Bgs[j])
+        if j != 0:
+            self.pre[j].push_back(dt, acc, gyr)
+            self.bufs[j].append((dt, acc, gyr))
+            un_acc_0 = self.Rs[j] @ (self.acc_0 - self.Bas[j]) - self.g
+            un_gyr = 0.5 * (self.gyr_0 + gyr) - self.Bgs[j]
+            self.Rs[j] = self.Rs[j] @ _delta_q_R(un_gyr * dt)
+            un_acc_1 = self.Rs[j] @ (acc - self.Bas[j]) - self.g
+            un_acc = 0.5 * (un_acc_0 + un_acc_1)
+            self.Ps[j] = self.Ps[j] + dt * self.Vs[j] + 0.5 * dt * dt * un_acc
+            self.Vs[j] = self.Vs[j] + dt * un_acc
+        self.acc_0, self.gyr_0 = acc, gyr
+
+    # ---- FeatureManager::addFeatureAndCheckParallax  feature_manager.cpp:52-101 -----------------
+    def _add_features(self, image):
+        fc = self.frame_count
+        by_id = {t.id: t for t in self.tracks}
+        last_track_num = 0
+        for fid in sorted(image):                    # std::map iteration order
+            pt = np.array(image[fid], float)
+            t = by_id.get(fid)
+            if t is None:
+                t = Track(fid, fc); self.tracks.append(t); by_id[fid] = t
+                t.points.append(pt)
+            else:
+                t.points.append(pt); last_track_num += 1
+        if fc < 2 or last_track_num < 20:
+            return True
+        psum, pnum = 0.0, 0
+        for t in self.tracks:
+            if t.start_frame <= fc - 2 and t.start_frame + len(t.points) - 1 >= fc - 1:
+                p2, p1 = t.points[fc - 2 - t.start_frame], t.points[fc - 1 - t.start_frame]      # compensatedParallax2 :356-390
+                du, dv = p2[0] / p2[2] - p1[0], p2[1] / p2[2] - p1[1]
+                psum += max(0.0, np.sqrt(du * du + dv * dv)); pnum += 1
+        return True if pnum == 0 else psum / pnum >= MIN_PARALLAX
+
+    def _good(self):
+        """goodFeature (feature_manager.cpp:27-31): used_num >= 2 and start_frame < Vo_SIZE, in IDsfeatures order"""
+        return [t for t in self.tracks if len(t.points) >= 2 and t.start_frame < self.Nvo]
+
+    # ---- pack the Estimator members backendOptimization() touches into the ABI window -----------
+    def _window(self):
+        good = self._good()
+        n_obs = sum(len(t.points) for t in good)
+        w = abi.Window(self.N, self.Nvo, len(good), n_obs, len(self.rollpitch))
+        w.Ps[...] = self.Ps.reshape(w.Ps.shape); w.Rs[...] = self.Rs.reshape(w.Rs.shape); w.Vs[...] = self.Vs.reshape(w.Vs.shape)
+        w.Bas[...] = self.Bas.reshape(w.Bas.shape); w.Bgs[...] = self.Bgs.reshape(w.Bgs.shape)
+        w.tic[...] = self.tic.reshape(w.tic.shape); w.ric[...] = self.ric.reshape(w.ric.shape)
+        ptr, obs = [0], []
+        for l, t in enumerate(good):
+            w.lm_start_frame[l] = t.start_frame
+            obs.extend(t.points); ptr.append(len(obs))
+            w.lm_depth[l] = t.depth
+        w.lm_obs_ptr[: len(ptr)] = ptr
+        if obs:
+            w.obs_point.reshape(-1, 3)[: len(obs)] = np.array(obs)
+        for j in range(1, self.N):
+            C.memmove(C.byref(w.imu[j - 1]), C.byref(self.pre[j].pod), C.sizeof(abi.isv_imu_t))
+        C.memmove(C.byref(w.pose_prior), C.byref(self.pose_prior), C.sizeof(abi.isv_se3_prior_t))
+        C.memmove(C.byref(w.vb_prior), C.byref(self.vb_prior), C.sizeof(abi.isv_linear9_t))
+        for i in range(self.Nvo - 1):
+            C.memmove(C.byref(w.relpose[i]), C.byref(self.relpose[i]), C.sizeof(abi.isv_relpose_t))
+        for i, f in enumerate(self.rollpitch):
+            C.memmove(C.byref(w.rollpitch[i]), C.byref(f), C.sizeof(abi.isv_rollpitch_t))
+        w.margin_old = 1 if self.margin_old else 0
+        w.header0 = float(self.Headers[0])
+        return w, good
+
+    def _read_back(self, w, good):
+        self.Ps = w.Ps.reshape(self.N, 3).copy(); self.Rs = w.Rs.reshape(self.N, 3, 3).copy(); self.Vs = w.Vs.reshape(self.N, 3).copy()
+        self.Bas = w.Bas.reshape(self.N, 3).copy(); self.Bgs = w.Bgs.reshape(self.N, 3).copy()
+        for l, t in enumerate(good):
+            t.depth = float(w.lm_depth[l]); t.solve_flag = int(w.lm_solve_flag[l])
+        C.memmove(C.byref(self.pose_prior), C.byref(w.pose_prior), C.sizeof(abi.isv_se3_prior_t))
+        C.memmove(C.byref(self.vb_prior), C.byref(w.vb_prior), C.sizeof(abi.isv_linear9_t))
+        for i in range(self.Nvo - 1):
+            C.memmove(C.byref(self.relpose[i]), C.byref(w.relpose[i]), C.sizeof(abi.isv_relpose_t))
+        for i in range(len(self.rollpitch)):
+            C.memmove(C.byref(self.rollpitch[i]), C.byref(w.rollpitch[i]), C.sizeof(abi.isv_rollpitch_t))
+
+    # ---- solveOdometry  src/estimator.cpp:461-472 + backendOptimization :1541-1562 ------------------
+    @staticmethod
+    def _copy(src, T):
+        o = T()
+        C.memmove(C.byref(o), C.byref(src), C.sizeof(T))
+        return o
+
+    def _solve_odometry(self):
+        w, good = self._window()
+        self.solver.triangulate(w)                   # f_manager.triangulate(Ps, tic, ric)
+        for l, t in enumerate(good):
+            t.depth = float(w.lm_depth[l])
+        if self.solver_flag == "INITIAL_STRUCTURE":  # vector2double(); initFactorGraph(); solver_flag = NON_LINEAR
+            s0 = self.solver.init_factor_graph(w)
+            self.rollpitch = []
+            self._read_back(w, good)
+            self.solver_flag = "NON_LINEAR"
+            self.to_add = None
+            self.summaries.append(s0)
+            w, good = self._window()                 # the NON_LINEAR branch runs in the same call (two `if`s, not else-if)
+        s, m = self.solver.optimize(w)
+        self._read_back(w, good)
+        if self.margin_old and m.valid:
+            self.to_add = (self._copy(m.forward_pose_prior, abi.isv_se3_prior_t), self._copy(m.backward_relpose, abi.isv_relpose_t),
+                           self._copy(m.backward_vb, abi.isv_linear9_t))
+            brp = self._copy(m.backward_rollpitch, abi.isv_rollpitch_t); brp.index = self.Nvo - 1
+            self.rollpitch.append(brp)               # vioRollPitchEdges.push_back (MargBackward :1536-1538)
+        self.summaries.append(s)
+
+    # ---- slideWindow  src/estimator.cpp:1565-1724 --------------------------------------------------
+    def _slide_window(self):
+        N, Nvo = self.N, self.Nvo
+        if self.margin_old:
+            back_R0, back_P0 = self.Rs[0].copy(), self.Ps[0].copy()
+            if self.frame_count != N - 1:
+                return
+            for a in (self.Ps, self.Rs, self.Vs, self.Bas, self.Bgs):
+                a[: N - 1] = a[1:].copy()            # the swaps; the last slot is overwritten below anyway
+            self.Headers[: N - 1] = self.Headers[1:].copy()
+            self.pre = self.pre[1:] + [None]; self.bufs = self.bufs[1:] + [[]]
+            self.Headers[N - 1] = self.Headers[N - 2]
+            for a in (self.Ps, self.Rs, self.Vs, self.Bas, self.Bgs):
+                a[N - 1] = a[N - 2]
+            self.pre[N - 1] = PreInt(self.lib, self.acc_0, self.gyr_0, self.Bas[N - 1], self.Bgs[N - 1])
+            shift_depth = self.solver_flag == "NON_LINEAR"
+            if shift_depth and self.to_add is not None:
+                fwd_prior, bwd_rel, bwd_vb = self.to_add
+                for f in self.relpose:
+                    f.imu_i -= 1; f.imu_j -= 1       # RelativePoseFactor::shift()
+                self.relpose = self.relpose[1:] + [bwd_rel]
+                bwd_rel.imu_i, bwd_rel.imu_j = Nvo - 2, Nvo - 1
+                kept = []
+                for f in self.rollpitch:
+                    f.index -= 1                     # RollPitchFactor::shift()
+                    if f.index >= 0:
+                        kept.append(f)
+                self.rollpitch = kept
+                fwd_prior.index = 0; self.pose_prior = fwd_prior
+                bwd_vb.index = Nvo - 1; self.vb_prior = bwd_vb
+                self.to_add = None
+            # slideWindowOld
+            if shift_depth:
+                R0, R1 = back_R0 @ self.ric, self.Rs[0] @ self.ric
+                P0, P1 = back_P0 + back_R0 @ self.tic, self.Ps[0] + self.Rs[0] @ self.tic
+                keep = []
+                for t in self.tracks:                # removeBackShiftDepth  feature_manager.cpp:275-313
+                    if t.start_frame != 0:
+                        t.start_frame -= 1; keep.append(t); continue
+                    uv = t.points.pop(0)
+                    if len(t.points) < 2:
+                        continue
+                    pj = R1.T @ (R0 @ (uv * t.depth) + P0 - P1)
+                    t.depth = float(pj[2]) if pj[2] > 0 else self.solver.cfg.init_depth
+                    keep.append(t)
+                self.tracks = keep
+            else:
+                keep = []
+                for t in self.tracks:                # removeBack :315-332
+                    if t.start_frame != 0:
+                        t.start_frame -= 1; keep.append(t)
+                    else:
+                        t.points.pop(0)
+                        if t.points:
+                            keep.append(t)
+                self.tracks = keep
+        else:
+            fc = self.frame_count
+            if fc != N - 1:
+                return
+            for (dt, a, g) in self.bufs[fc]:
+                self.pre[fc - 1].push_back(dt, a, g)
+                self.bufs[fc - 1].append((dt, a, g))
+            self.Headers[fc - 1] = self.Headers[fc]
+            for arr in (self.Ps, self.Rs, self.Vs, self.Bas, self.Bgs):
+                arr[fc - 1] = arr[fc]
+            self.pre[N - 1] = PreInt(self.lib, self.acc_0, self.gyr_0, self.Bas[N - 1], self.Bgs[N - 1])
+            self.bufs[N - 1] = []
+            keep = []
+            for t in self.tracks:                    # removeFront  feature_manager.cpp:335-354
+                if t.start_frame == fc:
+                    t.start_frame -= 1; keep.append(t); continue
+                if t.end_frame() < fc - 1:
+                    keep.append(t); continue
+                del t.points[N - 1 - 1 - t.start_frame]
+                if t.points:
+                    keep.append(t)
+            self.tracks = keep
+
+    # ---- processImage  src/estimator.cpp:126-215 ---------------------------------------------------
+    def process_image(self, image, header, bootstrap=None):
+        self.margin_old = self._add_features(image)
+        self.Headers[self.frame_count] = header
+        if self.solver_flag == "INITIAL":
+            if self.frame_count == self.N - 1:
+                # initialStructure() is out of scope: the states come from `bootstrap` (see module docstring)
+                P, R, V = bootstrap
+                self.Ps, self.Rs, self.Vs = P.copy(), R.copy(), V.copy()
+                self.solver_flag = "INITIAL_STRUCTURE"
+                self._solve_odometry()
+                self._slide_window()
+                self.tracks = [t for t in self.tracks if t.solve_flag != 2]      # removeFailures
+            else:
+                self.frame_count += 1
+                return
+        else:
+            self._solve_odometry()
+            self._slide_window()
+            self.tracks = [t for t in self.tracks if t.solve_flag != 2]
+        self.trajectory.append((header, self.Ps[self.N - 1].copy(), self.Rs[self.N - 1].copy()))
+
+
+class Simulator:
+    """a camera-IMU rig on synth.Trajectory: feature observations at 10 Hz with pixel noise 1/460, IMU at 200 Hz"""
+
+    def __init__(self, seed=0, n_points=1500, frame_dt=0.1, imu_per_frame=20):
+        self.rng = np.random.default_rng(seed)
+        self.traj = synth.Trajectory(0.3)
+        # the yaml extrinsic points the camera's optical axis along the body z axis: the landmarks form a ceiling
+        self.points = np.stack([self.rng.uniform(-8.0, 8.0, n_points), self.rng.uniform(-8.0, 8.0, n_points), self.rng.uniform(3.0, 8.0, n_points)], 1)
+        self.frame_dt, self.k = frame_dt, imu_per_frame
+        self.ba, self.bg = self.rng.normal(0, 0.02, 3), self.rng.normal(0, 0.002, 3)
+
+    def frame(self, i):
+        t = i * self.frame_dt
+        R, P = self.traj.R(t), self.traj.p(t)
+        Rc, tc = R @ synth.RIC, P + R @ synth.TIC
+        pc = (self.points - tc) @ Rc                 # points in the camera frame
+        vis = (pc[:, 2] > 0.5) & (np.abs(pc[:, 0] / pc[:, 2]) < 0.7) & (np.abs(pc[:, 1] / pc[:, 2]) < 0.5)
+        image = {}
+        for fid in np.nonzero(vis)[0]:
+            xy = pc[fid, :2] / pc[fid, 2] + self.rng.normal(0, 1.0 / 460.0, 2)
+            image[int(fid)] = (xy[0], xy[1], 1.0)
+        return t, image
+
+    def imu_between(self, i):
+        """samples in (t_{i-1}, t_i]"""
+        out = []
+        dt = self.frame_dt / self.k
+        G = np.array([0, 0, 9.81007])
+        for s in range(1, self.k + 1):
+            t = (i - 1) * self.frame_dt + s * dt
+            acc = self.traj.R(t).T @ (self.traj.acc(t) + G) + self.ba + ACC_N * self.rng.normal(0, 1, 3) * 0.05
+            gyr = self.traj.gyro(t) + self.bg + GYR_N * self.rng.normal(0, 1, 3) * 0.05
+            out.append((dt, acc, gyr))
+        return out
+
+    def truth_window(self, i_last, N):
+        ts = [(i_last - (N - 1) + k) * self.frame_dt for k in range(N)]
+        P = np.array([self.traj.p(t) for t in ts]); R = np.array([self.traj.R(t) for t in ts]); V = np.array([self.traj.vel(t) for t in ts])
+        return P, R, V
+
+
+def run_sequence(solver, lib, N, Nvo, n_frames, seed=0):
+    sim = Simulator(seed)
+    est = Estimator(solver, lib, N, Nvo)
+    for i in range(n_frames):
+        if i > 0:
+            for (dt, a, g) in sim.imu_between(i):
+                est.process_imu(dt, a, g)
+        else:
+            est.process_imu(sim.frame_dt / sim.k, sim.traj.R(0).T @ (sim.traj.acc(0) + np.array([0, 0, 9.81007])) + sim.ba, sim.traj.gyro(0) + sim.bg)
+        t, image = sim.frame(i)
+        boot = None
+        if est.solver_flag == "INITIAL" and est.frame_count == N - 1:
+            P, R, V = sim.truth_window(i, N)
+            nrng = np.random.default_rng(1000 + seed)
+            P = P + nrng.normal(0, 0.01, P.shape); V = V + nrng.normal(0, 0.02, V.shape)
+            boot = (P, R, V)
+        est.process_image(image, t, bootstrap=boot)
+    return est, sim
