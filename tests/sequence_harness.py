@@ -37,6 +37,20 @@ def _delta_q_R(theta):
                      [txz - twy, tyz + twx, 1 - (txx + tyy)]])
 
 
+def _quat_from_R(R):
+    """Eigen::Quaterniond(R): (w, x, y, z) by the trace / largest-diagonal branches"""
+    t = np.trace(R)
+    if t > 0:
+        s = np.sqrt(t + 1.0) * 2
+        return np.array([0.25 * s, (R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s])
+    i = int(np.argmax(np.diag(R))); j = (i + 1) % 3; k = (j + 1) % 3
+    s = np.sqrt(R[i, i] - R[j, j] - R[k, k] + 1.0) * 2
+    q = np.zeros(4)
+    q[1 + i] = 0.25 * s; q[0] = (R[k, j] - R[j, k]) / s
+    q[1 + j] = (R[j, i] + R[i, j]) / s; q[1 + k] = (R[k, i] + R[i, k]) / s
+    return q
+
+
 class PreInt:
     """IntegrationBase (include/factor/integration_base.h): the POD the factors read + the raw sample buffers;
     propagation by the oracle's restated midpoint rule (isvo_x_preint_step)."""
@@ -122,6 +136,7 @@ class Estimator:
         self.rollpitch = []                          # vioRollPitchEdges
         self.margin_old = True
         self.to_add = None                           # (forward pose prior, backward relpose, backward vb) from the last MARGIN_OLD solve
+        self.pose_output = []
         self.trajectory = []                         # (header, P, R) of the newest frame after every solve
         self.summaries = []
 
@@ -342,6 +357,16 @@ class Estimator:
             self._slide_window()
             self.tracks = [t for t in self.tracks if t.solve_flag != 2]
         self.trajectory.append((header, self.Ps[self.N - 1].copy(), self.Rs[self.N - 1].copy()))
+        # the row System::ProcessBackEnd appends to pose_output.txt once NON_LINEAR: the OLDEST frame  src/System.cpp:401-410
+        self.pose_output.append((self.Headers[0], self.Ps[0].copy(), self.Rs[0].copy()))
+
+    def write_pose_output(self, path):
+        """pose_output.txt as the reference writes it (src/System.cpp:408-409): `fixed` stream formatting, so six
+        decimals: stamp px py pz qw qx qy qz"""
+        with open(path, "w") as f:
+            for (t, p, R) in self.pose_output:
+                q = _quat_from_R(R)
+                f.write("%.6f %.6f %.6f %.6f %.6f %.6f %.6f %.6f\n" % (t, p[0], p[1], p[2], q[0], q[1], q[2], q[3]))
 
 
 class Simulator:

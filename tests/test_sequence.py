@@ -24,6 +24,26 @@ def test_sequence_harness_runs_on_the_oracle(oracle):
     assert 200 < len(est._good()) <= 600 and len(est.rollpitch) >= 1
 
 
+def test_pose_output_rows_follow_the_reference_format(oracle, tmp_path):
+    """pose_output.txt (src/System.cpp:401-410): one row per solved frame, `stamp px py pz qw qx qy qz` of the OLDEST
+    window frame, readable by the usual TUM-style evaluation scripts"""
+    N, Nvo = 11, 5
+    cfg = abi.make_config(N, Nvo, max_landmarks=600, max_obs=6600, max_batch=1)
+    est, sim = sh.run_sequence(sh.OracleSolver(oracle, cfg), oracle, N, Nvo, n_frames=14)
+    path = tmp_path / "pose_output.txt"
+    est.write_pose_output(path)
+    rows = np.loadtxt(path)
+    assert rows.shape == (4, 8)
+    assert np.allclose(np.linalg.norm(rows[:, 4:], axis=1), 1.0, atol=1e-5)
+    assert np.all(np.diff(rows[:, 0]) > 0)
+    for row, (t, p, R) in zip(rows, est.pose_output):
+        w, x, y, z = row[4:]
+        Rq = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                       [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                       [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        assert abs(row[0] - t) < 1e-6 and np.abs(row[1:4] - p).max() < 1e-6 and np.abs(Rq - R).max() < 1e-5
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,Nvo,n_frames", [(11, 5, 41), (18, 8, 40)])
 def test_sequence_ate_gpu_vs_oracle(oracle, N, Nvo, n_frames):
