@@ -140,8 +140,13 @@ class Backend:
         self._check(self.lib.isv_backend_triangulate(self.h, len(windows), self._ptrs(windows)), "triangulate")
 
     # ---- device-resident batch (bench) -----------------------------------------------------
-    def upload(self, windows):
-        self._check(self.lib.isv_batch_upload(self.h, len(windows), self._ptrs(windows)), "upload")
+    def marshal(self, windows):
+        """the isv_window_t* array for `windows` (ctypes marshalling costs ~75 us per window in Python; a C++ caller
+        has these pointers for free) - pass it as ptrs= to upload()/download() to keep that out of a timed region"""
+        return self._ptrs(windows)
+
+    def upload(self, windows, ptrs=None):
+        self._check(self.lib.isv_batch_upload(self.h, len(windows), ptrs if ptrs is not None else self._ptrs(windows)), "upload")
         self._n = len(windows)
 
     def run_optimize(self, sync=True, profile=False):
@@ -154,11 +159,11 @@ class Backend:
     def sync(self):
         self._check(self.lib.isv_batch_sync(self.h), "sync")
 
-    def download(self, windows):
+    def download(self, windows, ptrs=None, as_list=True):
         n = len(windows)
         sums = (abi.isv_summary_t * n)(); margs = (abi.isv_marg_result_t * n)()
-        self._check(self.lib.isv_batch_download(self.h, n, self._ptrs(windows), sums, margs), "download")
-        return list(sums), list(margs)
+        self._check(self.lib.isv_batch_download(self.h, n, ptrs if ptrs is not None else self._ptrs(windows), sums, margs), "download")
+        return (list(sums), list(margs)) if as_list else (sums, margs)
 
     def last_timing(self):
         out = np.zeros(8)

@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 #include <algorithm>
 #include "isv_device_types.h"
@@ -182,7 +183,115 @@ static bool finite_all(const double *p, size_t n) {
     return true;
 }
 
-// pack n caller windows into the pinned staging area and copy them to the device
+// pack one caller window into its slice of the pinned staging area (offsets fixed by the caller's first pass)
+static int pack_window(isv_backend *h, int b, const isv_window_t *w, size_t L, size_t F, size_t T, std::string &err) {
+    const isv_config_t &c = h->cfg;
+    const int N = c.n_frames;
+    auto &s = h->h;
+    const size_t f_off = F, lm_off = L;
+    memcpy(s.Ps + (size_t)b * N * 3, w->Ps, sizeof(double) * N * 3); memcpy(s.Rs + (size_t)b * N * 9, w->Rs, sizeof(double) * N * 9);
+    memcpy(s.Vs + (size_t)b * N * 3, w->Vs, sizeof(double) * N * 3); memcpy(s.Bas + (size_t)b * N * 3, w->Bas, sizeof(double) * N * 3);
+    memcpy(s.Bgs + (size_t)b * N * 3, w->Bgs, sizeof(double) * N * 3);
+    memcpy(s.tic + (size_t)b * 3, w->tic, 24); memcpy(s.ric + (size_t)b * 9, w->ric, 72);
+    if (!finite_all(w->Ps, N * 3) || !finite_all(w->Rs, N * 9) || !finite_all(w->Vs, N * 3)) return ISV_ERR_NONFINITE;
+    for (int l = 0; l < w->n_landmarks; l++) {
+        const int hst = w->lm_start_frame[l], o0 = w->lm_obs_ptr[l], k = w->lm_obs_ptr[l + 1] - o0;
+        s.lm_host[L] = hst; s.lm_k[L] = k; s.lm_f0[L] = (int32_t)F;
+        if (F - f_off > 65535) { err = "more than 65535 factors in one window"; return ISV_ERR_CAPACITY; }
+        s.lm_meta[L] = (uint32_t)hst | ((uint32_t)k << 8) | ((uint32_t)(F - f_off) << 16);
+        s.depth[L] = w->lm_depth[l];
+        memcpy(s.lm_pts_i + L * 3, w->obs_point + (size_t)o0 * 3, 24);
+        for (int o = 1; o < k; o++) {
+            s.f_rec[F].lm = (int32_t)L; s.f_rec[F].ij = hst | ((hst + o) << 8);
+            s.f_pts_j[F * 2] = w->obs_point[(size_t)(o0 + o) * 3]; s.f_pts_j[F * 2 + 1] = w->obs_point[(size_t)(o0 + o) * 3 + 1];
+            s.f_pts_z[F] = w->obs_point[(size_t)(o0 + o) * 3 + 2];
+            F++;
+        }
+        L++;
+    }
+    // tiles of <= 64 consecutive factors made of WHOLE landmarks (the linearise kernel reduces a
+    // landmark's factors inside one wavefront); window_tiles() below counts them the same way
+    {
+        size_t tf0 = f_off, tn = 0;
+        for (size_t l = lm_off; l < L; l++) {
+            const size_t kf = (size_t)s.lm_k[l] - 1;
+            if (tn + kf > ISV_TILE) { s.tile_win[T] = b; s.tile_f0[T] = (int32_t)tf0; s.tile_n[T] = (int32_t)tn; T++; tf0 += tn; tn = 0; }
+            tn += kf;
+        }
+        if (tn) { s.tile_win[T] = b; s.tile_f0[T] = (int32_t)tf0; s.tile_n[T] = (int32_t)tn; T++; }
+    }
+    // factors sorted by (host, observer) pair for the MFMA sweep: counting sort, stable in landmark order
+    {
+        const int NP = N * (N - 1) / 2;
+        int32_t *off = s.pg_off + (size_t)b * (NP + 1);
+        auto pidx = [N](int hh, int jj) { return hh * N - hh * (hh + 1) / 2 + (jj - hh - 1); };
+        for (int p = 0; p <= NP; p++) off[p] = 0;
+        for (size_t f = f_off; f < F; f++) off[pidx(s.f_rec[f].ij & 255, (s.f_rec[f].ij >> 8) & 255) + 1]++;
+        for (int p = 0; p < NP; p++) off[p + 1] += off[p];
+        int32_t cur[ISV_MAX_FRAMES * (ISV_MAX_FRAMES - 1) / 2];
+        for (int p = 0; p < NP; p++) cur[p] = off[p];
+        for (size_t f = f_off; f < F; f++) {
+            const int p = pidx(s.f_rec[f].ij & 255, (s.f_rec[f].ij >> 8) & 255);
+            s.pg_perm[f_off + cur[p]++] = (int32_t)(f - f_off);
+        }
+        // balanced schedule of the pair groups over the sweep wavefronts: longest group first onto the
+        // least loaded wavefront (cost = MFMA slots: 4 per 8 factors)
+        int order[ISV_MAX_FRAMES * (ISV_MAX_FRAMES - 1) / 2], wave_of[ISV_MAX_FRAMES * (ISV_MAX_FRAMES - 1) / 2];
+        for (int p = 0; p < NP; p++) order[p] = p;
+        std::stable_sort(order, order + NP, [&](int a2, int b2) { return off[a2 + 1] - off[a2] > off[b2 + 1] - off[b2]; });
+        int load[ISV_SWEEP_WAVES] = {0}, cntw[ISV_SWEEP_WAVES] = {0};
+        for (int q = 0; q < NP; q++) {
+            const int p = order[q];
+            int best = 0;
+            for (int v = 1; v < ISV_SWEEP_WAVES; v++) if (load[v] < load[best]) best = v;
+            load[best] += 1 + 4 * ((off[p + 1] - off[p] + 7) / 8);
+            wave_of[p] = best; cntw[best]++;
+        }
+        int32_t *soff = s.pg_sched_off + (size_t)b * (ISV_SWEEP_WAVES + 1), *sched = s.pg_sched + (size_t)b * NP;
+        soff[0] = 0;
+        for (int v = 0; v < ISV_SWEEP_WAVES; v++) soff[v + 1] = soff[v] + cntw[v];
+        int fill[ISV_SWEEP_WAVES] = {0};
+        for (int hh = 0, p = 0; hh < N - 1; hh++)
+            for (int jj = hh + 1; jj < N; jj++, p++) { const int v = wave_of[p]; sched[soff[v] + fill[v]++] = hh | (jj << 8) | (p << 16); }
+    }
+    for (int i = 0; i < N - 1; i++) {
+        const isv_imu_t &im = w->imu[i];
+        double *r = s.imu_in + ((size_t)b * (N - 1) + i) * ISV_IMU_IN;
+        memset(r, 0, sizeof(double) * ISV_IMU_IN);
+        memcpy(r + IMU_DP, im.delta_p, 24); memcpy(r + IMU_DQ, im.delta_q, 32); memcpy(r + IMU_DV, im.delta_v, 24);
+        memcpy(r + IMU_LBA, im.linearized_ba, 24); memcpy(r + IMU_LBG, im.linearized_bg, 24); r[IMU_DT] = im.sum_dt;
+        for (int a = 0; a < 3; a++) for (int bb = 0; bb < 3; bb++) {
+            r[IMU_DP_DBA + a * 3 + bb] = im.jacobian[(0 + a) * 15 + 9 + bb];
+            r[IMU_DP_DBG + a * 3 + bb] = im.jacobian[(0 + a) * 15 + 12 + bb];
+            r[IMU_DQ_DBG + a * 3 + bb] = im.jacobian[(3 + a) * 15 + 12 + bb];
+            r[IMU_DV_DBA + a * 3 + bb] = im.jacobian[(6 + a) * 15 + 9 + bb];
+            r[IMU_DV_DBG + a * 3 + bb] = im.jacobian[(6 + a) * 15 + 12 + bb];
+        }
+        memcpy(s.imu_cov + ((size_t)b * (N - 1) + i) * 225, im.covariance, sizeof(double) * 225);
+        s.imu_skip[(size_t)b * (N - 1) + i] = im.sum_dt > 10.0;
+    }
+    s.se3[b] = *w->pose_prior; s.lin9[b] = *w->vb_prior;
+    for (int i = 0; i < c.n_vo - 1; i++) s.relpose[(size_t)b * (c.n_vo - 1) + i] = w->relpose[i];
+    for (int i = 0; i < c.max_rollpitch; i++) {
+        if (i < w->n_rollpitch) s.rollpitch[(size_t)b * c.max_rollpitch + i] = w->rollpitch[i];
+        else memset(&s.rollpitch[(size_t)b * c.max_rollpitch + i], 0, sizeof(isv_rollpitch_t));
+    }
+    s.n_rp[b] = w->n_rollpitch;
+    s.margin_old[b] = w->margin_old != 0; s.header0[b] = w->header0;
+    return ISV_OK;
+}
+
+// host threads for the packing pass: ISV_HOST_THREADS, else min(8, hardware threads), one per >= 32 windows
+static int host_threads(int n) {
+    int k = 0;
+    if (const char *e = getenv("ISV_HOST_THREADS")) k = atoi(e);
+    if (k <= 0) { k = (int)std::thread::hardware_concurrency(); if (k > 8) k = 8; }
+    if (k > n / 32) k = n / 32;
+    return k < 1 ? 1 : k;
+}
+
+// pack n caller windows into the pinned staging area and copy them to the device.  Pass 1 (serial) validates the
+// tracks and fixes every window's landmark / factor / tile offsets; pass 2 packs the windows on host threads.
 extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const *ws) {
     if (!h || !ws || n < 1) return ISV_ERR_INVALID_ARG;
     if ((size_t)n > h->capB) { h->err = "batch larger than max_batch"; return ISV_ERR_CAPACITY; }
@@ -190,6 +299,7 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
     const int N = c.n_frames;
     auto &s = h->h;
     size_t L = 0, F = 0, T = 0;
+    std::vector<size_t> t_off((size_t)n + 1);
     for (int b = 0; b < n; b++) {
         const isv_window_t *w = ws[b];
         if (!w || !w->Ps || !w->Rs || !w->Vs || !w->Bas || !w->Bgs || !w->tic || !w->ric || !w->imu || !w->pose_prior ||
@@ -197,98 +307,38 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
             (w->n_landmarks > 0 && (!w->lm_start_frame || !w->lm_obs_ptr || !w->obs_point || !w->lm_depth)))
             return ISV_ERR_INVALID_ARG;
         if (w->n_landmarks > c.max_landmarks || w->n_obs > c.max_obs || w->n_rollpitch > c.max_rollpitch) { h->err = "window exceeds capacity"; return ISV_ERR_CAPACITY; }
-        s.lm_off[b] = (int32_t)L; s.f_off[b] = (int32_t)F;
-        memcpy(s.Ps + (size_t)b * N * 3, w->Ps, sizeof(double) * N * 3); memcpy(s.Rs + (size_t)b * N * 9, w->Rs, sizeof(double) * N * 9);
-        memcpy(s.Vs + (size_t)b * N * 3, w->Vs, sizeof(double) * N * 3); memcpy(s.Bas + (size_t)b * N * 3, w->Bas, sizeof(double) * N * 3);
-        memcpy(s.Bgs + (size_t)b * N * 3, w->Bgs, sizeof(double) * N * 3);
-        memcpy(s.tic + (size_t)b * 3, w->tic, 24); memcpy(s.ric + (size_t)b * 9, w->ric, 72);
-        if (!finite_all(w->Ps, N * 3) || !finite_all(w->Rs, N * 9) || !finite_all(w->Vs, N * 3)) return ISV_ERR_NONFINITE;
+        for (int i = 0; i < w->n_rollpitch; i++) if (w->rollpitch[i].index < 0 || w->rollpitch[i].index >= N) return ISV_ERR_INVALID_ARG;
+        s.lm_off[b] = (int32_t)L; s.f_off[b] = (int32_t)F; t_off[b] = T;
+        size_t tn = 0;
         for (int l = 0; l < w->n_landmarks; l++) {
             const int hst = w->lm_start_frame[l], o0 = w->lm_obs_ptr[l], k = w->lm_obs_ptr[l + 1] - o0;
             if (hst < 0 || k < 2 || hst + k > N || o0 < 0 || o0 + k > w->n_obs) { h->err = "bad landmark track"; return ISV_ERR_INVALID_ARG; }
-            s.lm_host[L] = hst; s.lm_k[L] = k; s.lm_f0[L] = (int32_t)F;
-            if (F - s.f_off[b] > 65535) { h->err = "more than 65535 factors in one window"; return ISV_ERR_CAPACITY; }
-            s.lm_meta[L] = (uint32_t)hst | ((uint32_t)k << 8) | ((uint32_t)(F - s.f_off[b]) << 16);
-            s.depth[L] = w->lm_depth[l];
-            memcpy(s.lm_pts_i + L * 3, w->obs_point + (size_t)o0 * 3, 24);
-            for (int o = 1; o < k; o++) {
-                s.f_rec[F].lm = (int32_t)L; s.f_rec[F].ij = hst | ((hst + o) << 8);
-                s.f_pts_j[F * 2] = w->obs_point[(size_t)(o0 + o) * 3]; s.f_pts_j[F * 2 + 1] = w->obs_point[(size_t)(o0 + o) * 3 + 1];
-                s.f_pts_z[F] = w->obs_point[(size_t)(o0 + o) * 3 + 2];
-                F++;
-            }
-            L++;
+            if (tn + (size_t)(k - 1) > ISV_TILE) { T++; tn = 0; }
+            tn += (size_t)(k - 1);
+            F += (size_t)(k - 1);
         }
-        // tiles of <= 64 consecutive factors made of WHOLE landmarks (the linearise kernel reduces a
-        // landmark's factors inside one wavefront)
-        {
-            size_t tf0 = s.f_off[b], tn = 0;
-            for (size_t l = s.lm_off[b]; l < L; l++) {
-                const size_t kf = (size_t)s.lm_k[l] - 1;
-                if (tn + kf > ISV_TILE) { s.tile_win[T] = b; s.tile_f0[T] = (int32_t)tf0; s.tile_n[T] = (int32_t)tn; T++; tf0 += tn; tn = 0; }
-                tn += kf;
+        if (tn) T++;
+        L += (size_t)w->n_landmarks;
+    }
+    t_off[n] = T;
+    {
+        const int K = host_threads(n);
+        std::vector<int> rcs((size_t)K, ISV_OK);
+        std::vector<std::string> errs((size_t)K);
+        auto work = [&](int k) {
+            for (int b = (int)((int64_t)n * k / K), e = (int)((int64_t)n * (k + 1) / K); b < e; b++) {
+                const int rc = pack_window(h, b, ws[b], (size_t)s.lm_off[b], (size_t)s.f_off[b], t_off[b], errs[k]);
+                if (rc != ISV_OK) { rcs[k] = rc; return; }
             }
-            if (tn) { s.tile_win[T] = b; s.tile_f0[T] = (int32_t)tf0; s.tile_n[T] = (int32_t)tn; T++; }
+        };
+        if (K == 1) work(0);
+        else {
+            std::vector<std::thread> th;
+            for (int k = 1; k < K; k++) th.emplace_back(work, k);
+            work(0);
+            for (auto &t : th) t.join();
         }
-        // factors sorted by (host, observer) pair for the MFMA sweep: counting sort, stable in landmark order
-        {
-            const int NP = N * (N - 1) / 2;
-            int32_t *off = s.pg_off + (size_t)b * (NP + 1);
-            auto pidx = [N](int hh, int jj) { return hh * N - hh * (hh + 1) / 2 + (jj - hh - 1); };
-            for (int p = 0; p <= NP; p++) off[p] = 0;
-            for (size_t f = s.f_off[b]; f < F; f++) off[pidx(s.f_rec[f].ij & 255, (s.f_rec[f].ij >> 8) & 255) + 1]++;
-            for (int p = 0; p < NP; p++) off[p + 1] += off[p];
-            std::vector<int32_t> cur(off, off + NP);
-            for (size_t f = s.f_off[b]; f < F; f++) {
-                const int p = pidx(s.f_rec[f].ij & 255, (s.f_rec[f].ij >> 8) & 255);
-                s.pg_perm[s.f_off[b] + cur[p]++] = (int32_t)(f - s.f_off[b]);
-            }
-            // balanced schedule of the pair groups over the sweep wavefronts: longest group first onto the
-            // least loaded wavefront (cost = MFMA slots: 4 per 8 factors)
-            std::vector<int> order(NP), wave_of(NP);
-            for (int p = 0; p < NP; p++) order[p] = p;
-            std::stable_sort(order.begin(), order.end(), [&](int a2, int b2) { return off[a2 + 1] - off[a2] > off[b2 + 1] - off[b2]; });
-            int load[ISV_SWEEP_WAVES] = {0}, cntw[ISV_SWEEP_WAVES] = {0};
-            for (int q = 0; q < NP; q++) {
-                const int p = order[q];
-                int best = 0;
-                for (int v = 1; v < ISV_SWEEP_WAVES; v++) if (load[v] < load[best]) best = v;
-                load[best] += 1 + 4 * ((off[p + 1] - off[p] + 7) / 8);
-                wave_of[p] = best; cntw[best]++;
-            }
-            int32_t *soff = s.pg_sched_off + (size_t)b * (ISV_SWEEP_WAVES + 1), *sched = s.pg_sched + (size_t)b * NP;
-            soff[0] = 0;
-            for (int v = 0; v < ISV_SWEEP_WAVES; v++) soff[v + 1] = soff[v] + cntw[v];
-            int fill[ISV_SWEEP_WAVES] = {0};
-            for (int hh = 0, p = 0; hh < N - 1; hh++)
-                for (int jj = hh + 1; jj < N; jj++, p++) { const int v = wave_of[p]; sched[soff[v] + fill[v]++] = hh | (jj << 8) | (p << 16); }
-        }
-        for (int i = 0; i < N - 1; i++) {
-            const isv_imu_t &im = w->imu[i];
-            double *r = s.imu_in + ((size_t)b * (N - 1) + i) * ISV_IMU_IN;
-            memset(r, 0, sizeof(double) * ISV_IMU_IN);
-            memcpy(r + IMU_DP, im.delta_p, 24); memcpy(r + IMU_DQ, im.delta_q, 32); memcpy(r + IMU_DV, im.delta_v, 24);
-            memcpy(r + IMU_LBA, im.linearized_ba, 24); memcpy(r + IMU_LBG, im.linearized_bg, 24); r[IMU_DT] = im.sum_dt;
-            for (int a = 0; a < 3; a++) for (int bb = 0; bb < 3; bb++) {
-                r[IMU_DP_DBA + a * 3 + bb] = im.jacobian[(0 + a) * 15 + 9 + bb];
-                r[IMU_DP_DBG + a * 3 + bb] = im.jacobian[(0 + a) * 15 + 12 + bb];
-                r[IMU_DQ_DBG + a * 3 + bb] = im.jacobian[(3 + a) * 15 + 12 + bb];
-                r[IMU_DV_DBA + a * 3 + bb] = im.jacobian[(6 + a) * 15 + 9 + bb];
-                r[IMU_DV_DBG + a * 3 + bb] = im.jacobian[(6 + a) * 15 + 12 + bb];
-            }
-            memcpy(s.imu_cov + ((size_t)b * (N - 1) + i) * 225, im.covariance, sizeof(double) * 225);
-            s.imu_skip[(size_t)b * (N - 1) + i] = im.sum_dt > 10.0;
-        }
-        s.se3[b] = *w->pose_prior; s.lin9[b] = *w->vb_prior;
-        for (int i = 0; i < c.n_vo - 1; i++) s.relpose[(size_t)b * (c.n_vo - 1) + i] = w->relpose[i];
-        for (int i = 0; i < c.max_rollpitch; i++) {
-            if (i < w->n_rollpitch) {
-                if (w->rollpitch[i].index < 0 || w->rollpitch[i].index >= N) return ISV_ERR_INVALID_ARG;
-                s.rollpitch[(size_t)b * c.max_rollpitch + i] = w->rollpitch[i];
-            } else memset(&s.rollpitch[(size_t)b * c.max_rollpitch + i], 0, sizeof(isv_rollpitch_t));
-        }
-        s.n_rp[b] = w->n_rollpitch;
-        s.margin_old[b] = w->margin_old != 0; s.header0[b] = w->header0;
+        for (int k = 0; k < K; k++) if (rcs[k] != ISV_OK) { if (!errs[k].empty()) h->err = errs[k]; return rcs[k]; }
     }
     s.lm_off[n] = (int32_t)L; s.f_off[n] = (int32_t)F;
     DevBatch &d = h->d;
@@ -392,6 +442,7 @@ extern "C" int isv_batch_last_timing(isv_backend_t *h, double out_ms[8]) {
                 if (hipEventElapsedTime(&ms, h->prof_ev[b], h->prof_ev[b + 1]) == hipSuccess) out_ms[1 + fam] += ms;
             }
     }
+    (void)hipGetLastError();      // events that were never recorded answer with an error: do not leave it for the next entry point's check
     return ISV_OK;
 }
 
@@ -438,7 +489,7 @@ extern "C" int isv_batch_download(isv_backend_t *h, int32_t n, isv_window_t *con
     HIPCHK(h, hipStreamSynchronize(st));
     int rcs = isv_solver_download(h->d, st, n, summary, marg, h->err);
     if (rcs != ISV_OK) return rcs;
-    for (int b = 0; b < n; b++) {
+    auto unpack = [&](int b) {
         isv_window_t *w = ws[b];
         memcpy(w->Ps, s.Ps + (size_t)b * N * 3, sizeof(double) * N * 3); memcpy(w->Rs, s.Rs + (size_t)b * N * 9, sizeof(double) * N * 9);
         memcpy(w->Vs, s.Vs + (size_t)b * N * 3, sizeof(double) * N * 3); memcpy(w->Bas, s.Bas + (size_t)b * N * 3, sizeof(double) * N * 3);
@@ -456,6 +507,14 @@ extern "C" int isv_batch_download(isv_backend_t *h, int32_t n, isv_window_t *con
         if (w->para_Pose) memcpy(w->para_Pose, s.pose + (size_t)b * N * 7, sizeof(double) * N * 7);
         if (w->para_SpeedBias) memcpy(w->para_SpeedBias, s.sb + (size_t)b * N * 9, sizeof(double) * N * 9);
         if (w->para_Ex_Pose) memcpy(w->para_Ex_Pose, s.ex + (size_t)b * 7, 56);
+    };
+    {
+        const int K = host_threads(n);
+        auto work = [&](int k) { for (int b = (int)((int64_t)n * k / K), e = (int)((int64_t)n * (k + 1) / K); b < e; b++) unpack(b); };
+        std::vector<std::thread> th;
+        for (int k = 1; k < K; k++) th.emplace_back(work, k);
+        work(0);
+        for (auto &t : th) t.join();
     }
     return ISV_OK;
 }

@@ -79,3 +79,19 @@ def test_config5_stress_shape(oracle):
     for name in ("Ps", "Rs", "Vs", "Bas", "Bgs"):
         assert np.abs(getattr(g, name) - getattr(o, name)).max() < 1e-7, name
     be.close()
+
+
+def test_timing_queries_leave_the_handle_usable():
+    """isv_batch_last_timing asks HIP about events an optimize step never records; that must not surface as an error
+    from the next entry point (it did: upload after a profiled step returned ISV_ERR_DEVICE)"""
+    ws = synth.make_windows(range(4))
+    backend.build()
+    be = backend.Backend(11, 5, max_landmarks=300, max_obs=max(w.n_obs for w in ws), max_batch=4)
+    be.upload(ws)
+    be.run_optimize(sync=True, profile=True)
+    t = be.last_timing(); c = be.last_counts()
+    assert t[4] > 0 and c[3] > 0
+    out = [w.clone() for w in ws]
+    be.upload(out); be.run_optimize(); sums, _ = be.download(out)
+    assert all(s.status == 0 and s.final_cost < s.initial_cost for s in sums)
+    be.close()
