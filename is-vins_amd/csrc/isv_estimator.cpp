@@ -1,0 +1,664 @@
+// isv_estimator.cpp -- the reference's host-side window manager for S sequences in lock step (include/isvins_estimator.h).
+// Host C++ only: every solve goes through the three backend entry points in isv_solver_vtbl_t, which
+// isv_estimator_create binds to the HIP backend (isv_backend_triangulate / _init_factor_graph / _optimize_batch).
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+#include "../../include/isvins_estimator.h"
+
+namespace {
+
+using V3 = std::array<double, 3>;
+using M3 = std::array<double, 9>;      // row-major
+
+inline V3 add(const V3 &a, const V3 &b) { return {a[0] + b[0], a[1] + b[1], a[2] + b[2]}; }
+inline V3 sub(const V3 &a, const V3 &b) { return {a[0] - b[0], a[1] - b[1], a[2] - b[2]}; }
+inline V3 mul(const V3 &a, double s) { return {a[0] * s, a[1] * s, a[2] * s}; }
+inline V3 mv(const M3 &A, const V3 &x) {
+    return {A[0] * x[0] + A[1] * x[1] + A[2] * x[2], A[3] * x[0] + A[4] * x[1] + A[5] * x[2], A[6] * x[0] + A[7] * x[1] + A[8] * x[2]};
+}
+inline V3 mtv(const M3 &A, const V3 &x) {      // A^T x
+    return {A[0] * x[0] + A[3] * x[1] + A[6] * x[2], A[1] * x[0] + A[4] * x[1] + A[7] * x[2], A[2] * x[0] + A[5] * x[1] + A[8] * x[2]};
+}
+inline M3 mm(const M3 &A, const M3 &B) {
+    M3 C;
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) C[r * 3 + c] = A[r * 3] * B[c] + A[r * 3 + 1] * B[3 + c] + A[r * 3 + 2] * B[6 + c];
+    return C;
+}
+inline M3 hat(const V3 &v) { return {0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0}; }
+inline V3 cross(const V3 &a, const V3 &b) { return {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]}; }
+
+struct Quat { double w, x, y, z; };
+inline Quat qmul(const Quat &a, const Quat &b) {
+    return {a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y,
+            a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z, a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x};
+}
+// Eigen's q * v for a quaternion that need not be unit: v + 2w (u x v) + 2 u x (u x v)
+inline V3 qrot(const Quat &q, const V3 &v) {
+    const V3 u = {q.x, q.y, q.z};
+    V3 uv = cross(u, v);
+    uv = add(uv, uv);
+    return add(add(v, mul(uv, q.w)), cross(u, uv));
+}
+// Eigen's toRotationMatrix(), applied as is to a quaternion that need not be unit
+inline M3 qmat(const Quat &q) {
+    const double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
+    const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w, txx = tx * q.x, txy = ty * q.x, txz = tz * q.x;
+    const double tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+    return {1 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1 - (txx + tzz), tyz - twx, txz - twy, tyz + twx, 1 - (txx + tyy)};
+}
+// Eigen::Quaterniond(Matrix3d)
+inline Quat quat_of(const M3 &R) {
+    const double t = R[0] + R[4] + R[8];
+    Quat q;
+    if (t > 0) {
+        double s = std::sqrt(t + 1.0);
+        q.w = 0.5 * s; s = 0.5 / s;
+        q.x = (R[7] - R[5]) * s; q.y = (R[2] - R[6]) * s; q.z = (R[3] - R[1]) * s;
+        return q;
+    }
+    int i = 0;
+    if (R[4] > R[0]) i = 1;
+    if (R[8] > R[i * 4]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    double s = std::sqrt(R[i * 4] - R[j * 4] - R[k * 4] + 1.0);
+    double v[3];
+    v[i] = 0.5 * s; s = 0.5 / s;
+    q.w = (R[k * 3 + j] - R[j * 3 + k]) * s;
+    v[j] = (R[j * 3 + i] + R[i * 3 + j]) * s;
+    v[k] = (R[k * 3 + i] + R[i * 3 + k]) * s;
+    q.x = v[0]; q.y = v[1]; q.z = v[2];
+    return q;
+}
+
+struct Sample { double dt; V3 acc, gyr; };
+
+// IntegrationBase: the POD the factors read (isv_imu_t) + the sample the next step starts from
+struct PreIntegration {
+    isv_imu_t pod;
+    V3 acc_0, gyr_0;
+    double n2[4];        // ACC_N^2, GYR_N^2, ACC_W^2, GYR_W^2
+    PreIntegration(const V3 &a0, const V3 &g0, const V3 &ba, const V3 &bg, const isv_estimator_params_t &p) : acc_0(a0), gyr_0(g0) {
+        std::memset(&pod, 0, sizeof(pod));
+        pod.delta_q[3] = 1.0;
+        for (int i = 0; i < 15; i++) pod.jacobian[i * 15 + i] = 1.0;
+        for (int k = 0; k < 3; k++) { pod.linearized_ba[k] = ba[k]; pod.linearized_bg[k] = bg[k]; }
+        n2[0] = p.acc_n * p.acc_n; n2[1] = p.gyr_n * p.gyr_n; n2[2] = p.acc_w * p.acc_w; n2[3] = p.gyr_w * p.gyr_w;
+    }
+    // push_back -> propagate -> midPointIntegration (integration_base.h:31-158)
+    void push_back(double dt, const V3 &acc_1, const V3 &gyr_1) {
+        const V3 ba = {pod.linearized_ba[0], pod.linearized_ba[1], pod.linearized_ba[2]};
+        const V3 bg = {pod.linearized_bg[0], pod.linearized_bg[1], pod.linearized_bg[2]};
+        const Quat dq = {pod.delta_q[3], pod.delta_q[0], pod.delta_q[1], pod.delta_q[2]};
+        const V3 a0 = sub(acc_0, ba), a1 = sub(acc_1, ba);
+        const V3 w = sub(mul(add(gyr_0, gyr_1), 0.5), bg);
+        const V3 un_acc_0 = qrot(dq, a0);
+        const Quat rq = qmul(dq, Quat{1, w[0] * dt / 2, w[1] * dt / 2, w[2] * dt / 2});
+        const V3 un_acc_1 = qrot(rq, a1);
+        const V3 un_acc = mul(add(un_acc_0, un_acc_1), 0.5);
+        V3 rp, rv;
+        for (int k = 0; k < 3; k++) {
+            rp[k] = pod.delta_p[k] + pod.delta_v[k] * dt + 0.5 * un_acc[k] * dt * dt;
+            rv[k] = pod.delta_v[k] + un_acc[k] * dt;
+        }
+        // F (15x15) and V (15x18) in 3x3 blocks
+        const M3 Rd = qmat(dq), Rr = qmat(rq), Wx = hat(w);
+        M3 ImW;
+        for (int k = 0; k < 9; k++) ImW[k] = -Wx[k] * dt;
+        ImW[0] += 1; ImW[4] += 1; ImW[8] += 1;
+        const M3 RdA0 = mm(Rd, hat(a0)), RrA1 = mm(Rr, hat(a1)), RrA1W = mm(RrA1, ImW);
+        std::vector<double> F(225, 0.0), V(15 * 18, 0.0);
+        auto f = [&](int r, int c, int a, int b) -> double & { return F[(r + a) * 15 + c + b]; };
+        auto v = [&](int r, int c, int a, int b) -> double & { return V[(r + a) * 18 + c + b]; };
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) {
+            const int k = a * 3 + b;
+            const double I = a == b ? 1.0 : 0.0;
+            f(0, 0, a, b) = I;
+            f(0, 3, a, b) = -0.25 * RdA0[k] * dt * dt + -0.25 * RrA1W[k] * dt * dt;
+            f(0, 6, a, b) = I * dt;
+            f(0, 9, a, b) = -0.25 * (Rd[k] + Rr[k]) * dt * dt;
+            f(0, 12, a, b) = -0.25 * RrA1[k] * dt * dt * -dt;
+            f(3, 3, a, b) = ImW[k];
+            f(3, 12, a, b) = -1.0 * I * dt;
+            f(6, 3, a, b) = -0.5 * RdA0[k] * dt + -0.5 * RrA1W[k] * dt;
+            f(6, 6, a, b) = I;
+            f(6, 9, a, b) = -0.5 * (Rd[k] + Rr[k]) * dt;
+            f(6, 12, a, b) = -0.5 * RrA1[k] * dt * -dt;
+            f(9, 9, a, b) = I;
+            f(12, 12, a, b) = I;
+            v(0, 0, a, b) = 0.25 * Rd[k] * dt * dt;
+            v(0, 3, a, b) = 0.25 * -RrA1[k] * dt * dt * 0.5 * dt;
+            v(0, 6, a, b) = 0.25 * Rr[k] * dt * dt;
+            v(0, 9, a, b) = v(0, 3, a, b);
+            v(3, 3, a, b) = 0.5 * I * dt;
+            v(3, 9, a, b) = 0.5 * I * dt;
+            v(6, 0, a, b) = 0.5 * Rd[k] * dt;
+            v(6, 3, a, b) = 0.5 * -RrA1[k] * dt * 0.5 * dt;
+            v(6, 6, a, b) = 0.5 * Rr[k] * dt;
+            v(6, 9, a, b) = v(6, 3, a, b);
+            v(9, 12, a, b) = I * dt;
+            v(12, 15, a, b) = I * dt;
+        }
+        // jacobian = F jacobian;  covariance = F covariance F^T + V noise V^T
+        double Jn[225], FC[225], Cn[225];
+        for (int i = 0; i < 15; i++) for (int j = 0; j < 15; j++) {
+            double s = 0, c = 0;
+            for (int k = 0; k < 15; k++) { s += F[i * 15 + k] * pod.jacobian[k * 15 + j]; c += F[i * 15 + k] * pod.covariance[k * 15 + j]; }
+            Jn[i * 15 + j] = s; FC[i * 15 + j] = c;
+        }
+        const double nd[6] = {n2[0], n2[1], n2[0], n2[1], n2[2], n2[3]};
+        for (int i = 0; i < 15; i++) for (int j = 0; j < 15; j++) {
+            double c = 0, q = 0;
+            for (int k = 0; k < 15; k++) c += FC[i * 15 + k] * F[j * 15 + k];
+            for (int k = 0; k < 18; k++) q += V[i * 18 + k] * nd[k / 3] * V[j * 18 + k];
+            Cn[i * 15 + j] = c + q;
+        }
+        std::memcpy(pod.jacobian, Jn, sizeof(Jn)); std::memcpy(pod.covariance, Cn, sizeof(Cn));
+        const double nq = std::sqrt(rq.w * rq.w + rq.x * rq.x + rq.y * rq.y + rq.z * rq.z);      // delta_q.normalize()
+        pod.delta_q[0] = rq.x / nq; pod.delta_q[1] = rq.y / nq; pod.delta_q[2] = rq.z / nq; pod.delta_q[3] = rq.w / nq;
+        for (int k = 0; k < 3; k++) { pod.delta_p[k] = rp[k]; pod.delta_v[k] = rv[k]; }
+        pod.sum_dt += dt;
+        acc_0 = acc_1; gyr_0 = gyr_1;
+    }
+};
+
+// IDFeatures (include/feature_tracker/feature_manager.h:44-63)
+struct Track {
+    int id, start_frame;
+    std::vector<V3> points;        // Feature::point of frames start_frame, start_frame + 1, ...
+    double depth = -1.0;           // estimated_depth
+    int solve_flag = 0;
+    int end_frame() const { return start_frame + (int)points.size() - 1; }
+};
+
+enum Flag { INITIAL = 0, NON_LINEAR = 1, INITIAL_STRUCTURE = 2 };
+
+struct Sequence {
+    int N = 0, Nvo = 0;
+    std::vector<V3> Ps, Vs, Bas, Bgs;
+    std::vector<M3> Rs;
+    std::vector<double> Headers;
+    std::vector<std::unique_ptr<PreIntegration>> pre;
+    std::vector<std::vector<Sample>> bufs;
+    int frame_count = 0;
+    bool first_imu = true;
+    V3 acc_0{}, gyr_0{};
+    Flag flag = INITIAL;
+    std::vector<Track> tracks;                 // f_manager.IDsfeatures, insertion order
+    isv_se3_prior_t pose_prior{};
+    isv_linear9_t vb_prior{};
+    std::vector<isv_relpose_t> relpose;        // edge (i, i + 1) = vioRelativePoseEdges[i + 1]
+    std::vector<isv_rollpitch_t> rollpitch;    // vioRollPitchEdges
+    bool margin_old = true;
+    bool have_to_add = false;
+    isv_se3_prior_t add_pose_prior{};          // forwardPosePriorEdgeToAdd
+    isv_relpose_t add_relpose{};               // backwardRelativePoseEdgeToAdd
+    isv_linear9_t add_vb{};                    // backwardVBEdgeToAdd
+    // staged input
+    bool staged = false;
+    double staged_header = 0;
+    std::vector<std::pair<int, V3>> staged_image;
+    bool have_boot = false;
+    std::vector<V3> boot_P, boot_V;
+    std::vector<M3> boot_R;
+    // the ABI view handed to the backend
+    isv_window_t w{};
+    std::vector<double> wPs, wRs, wVs, wBas, wBgs, wobs, wdepth, wpose, wsb, wex, wfeat;
+    double wtic[3], wric[9];
+    std::vector<int32_t> wstart, wptr, wflag;
+    std::vector<isv_imu_t> wimu;
+    std::vector<isv_relpose_t> wrel;
+    std::vector<isv_rollpitch_t> wrp;
+    isv_se3_prior_t wpp{};
+    isv_linear9_t wvb{};
+    std::vector<int> good;                     // indices into tracks of the landmarks in `w`
+    // outputs
+    isv_summary_t last_summary{};
+    int n_solves = 0, n_good_last = 0;
+    std::vector<std::array<double, 8>> pose_rows;
+    std::vector<std::array<double, 13>> newest_rows;
+};
+
+}  // namespace
+
+struct isv_estimator {
+    isv_estimator_params_t p{};
+    isv_solver_vtbl_t solver{};
+    isv_backend_t *backend = nullptr;          // owned when created by isv_estimator_create
+    std::vector<Sequence> seq;
+    std::string err;
+};
+
+namespace {
+
+// Utility::deltaQ(theta).toRotationMatrix(): q = [1, theta / 2], not normalised
+M3 delta_q_matrix(const V3 &theta) { return qmat(Quat{1.0, theta[0] / 2, theta[1] / 2, theta[2] / 2}); }
+
+// FeatureManager::addFeatureAndCheckParallax (feature_manager.cpp:52-101) + compensatedParallax2 (:356-390)
+bool add_features(Sequence &s, double min_parallax) {
+    const int fc = s.frame_count;
+    std::unordered_map<int, size_t> by_id;
+    by_id.reserve(s.tracks.size() * 2 + s.staged_image.size());
+    for (size_t i = 0; i < s.tracks.size(); i++) by_id.emplace(s.tracks[i].id, i);
+    std::sort(s.staged_image.begin(), s.staged_image.end(), [](const std::pair<int, V3> &a, const std::pair<int, V3> &b) { return a.first < b.first; });
+    int last_track_num = 0;
+    for (const auto &ob : s.staged_image) {
+        auto it = by_id.find(ob.first);
+        if (it == by_id.end()) {
+            Track t; t.id = ob.first; t.start_frame = fc; t.points.push_back(ob.second);
+            by_id.emplace(ob.first, s.tracks.size());
+            s.tracks.push_back(std::move(t));
+        } else {
+            s.tracks[it->second].points.push_back(ob.second);
+            last_track_num++;
+        }
+    }
+    if (fc < 2 || last_track_num < 20) return true;
+    double parallax_sum = 0;
+    int parallax_num = 0;
+    for (const Track &t : s.tracks) {
+        if (t.start_frame <= fc - 2 && t.end_frame() >= fc - 1) {
+            const V3 &pi = t.points[fc - 2 - t.start_frame], &pj = t.points[fc - 1 - t.start_frame];
+            const double du = pi[0] / pi[2] - pj[0], dv = pi[1] / pi[2] - pj[1];
+            parallax_sum += std::max(0.0, std::sqrt(du * du + dv * dv));
+            parallax_num++;
+        }
+    }
+    if (parallax_num == 0) return true;
+    return parallax_sum / parallax_num >= min_parallax;
+}
+
+// the Estimator members backendOptimization() touches, as an isv_window_t over this sequence's buffers
+int build_window(isv_estimator *e, Sequence &s) {
+    const int N = s.N, Nvo = s.Nvo;
+    s.good.clear();
+    size_t n_obs = 0;
+    for (size_t i = 0; i < s.tracks.size(); i++)            // goodFeature(): used_num >= 2 && start_frame < Vo_SIZE
+        if (s.tracks[i].points.size() >= 2 && s.tracks[i].start_frame < Nvo) { s.good.push_back((int)i); n_obs += s.tracks[i].points.size(); }
+    const size_t L = s.good.size();
+    if ((int)L > e->p.cfg.max_landmarks || (int)n_obs > e->p.cfg.max_obs) { e->err = "window exceeds the landmark / observation capacity"; return ISV_ERR_CAPACITY; }
+    if ((int)s.rollpitch.size() > e->p.cfg.max_rollpitch) { e->err = "more roll/pitch factors than max_rollpitch"; return ISV_ERR_CAPACITY; }
+    s.wPs.resize(N * 3); s.wRs.resize(N * 9); s.wVs.resize(N * 3); s.wBas.resize(N * 3); s.wBgs.resize(N * 3);
+    for (int i = 0; i < N; i++) {
+        std::memcpy(&s.wPs[i * 3], s.Ps[i].data(), 24); std::memcpy(&s.wRs[i * 9], s.Rs[i].data(), 72); std::memcpy(&s.wVs[i * 3], s.Vs[i].data(), 24);
+        std::memcpy(&s.wBas[i * 3], s.Bas[i].data(), 24); std::memcpy(&s.wBgs[i * 3], s.Bgs[i].data(), 24);
+    }
+    std::memcpy(s.wtic, e->p.tic, 24); std::memcpy(s.wric, e->p.ric, 72);
+    s.wstart.assign(std::max<size_t>(L, 1), 0); s.wptr.assign(L + 1, 0); s.wflag.assign(std::max<size_t>(L, 1), 0);
+    s.wobs.assign(std::max<size_t>(n_obs, 1) * 3, 0.0); s.wdepth.assign(std::max<size_t>(L, 1), 0.0); s.wfeat.assign(std::max<size_t>(L, 1), 0.0);
+    size_t o = 0;
+    for (size_t l = 0; l < L; l++) {
+        const Track &t = s.tracks[s.good[l]];
+        s.wstart[l] = t.start_frame; s.wdepth[l] = t.depth;
+        for (const V3 &pt : t.points) { std::memcpy(&s.wobs[o * 3], pt.data(), 24); o++; }
+        s.wptr[l + 1] = (int32_t)o;
+    }
+    s.wimu.resize(N - 1);
+    for (int j = 1; j < N; j++) {
+        if (!s.pre[j]) { e->err = "a window frame has no pre-integration (no IMU samples were fed)"; return ISV_ERR_INVALID_ARG; }
+        s.wimu[j - 1] = s.pre[j]->pod;
+    }
+    s.wpp = s.pose_prior; s.wvb = s.vb_prior;
+    s.wrel = s.relpose;
+    s.wrp = s.rollpitch;
+    if (s.wrp.empty()) s.wrp.resize(1);
+    s.wpose.assign(N * 7, 0.0); s.wsb.assign(N * 9, 0.0); s.wex.assign(7, 0.0);
+    isv_window_t &w = s.w;
+    w.Ps = s.wPs.data(); w.Rs = s.wRs.data(); w.Vs = s.wVs.data(); w.Bas = s.wBas.data(); w.Bgs = s.wBgs.data();
+    w.tic = s.wtic; w.ric = s.wric;
+    w.n_landmarks = (int32_t)L; w.n_obs = (int32_t)n_obs;
+    w.lm_start_frame = s.wstart.data(); w.lm_obs_ptr = s.wptr.data(); w.obs_point = s.wobs.data();
+    w.lm_depth = s.wdepth.data(); w.lm_solve_flag = s.wflag.data();
+    w.imu = s.wimu.data();
+    w.pose_prior = &s.wpp; w.vb_prior = &s.wvb; w.relpose = s.wrel.data(); w.rollpitch = s.wrp.data();
+    w.n_rollpitch = (int32_t)s.rollpitch.size();
+    w.margin_old = s.margin_old ? 1 : 0;
+    w.header0 = s.Headers[0];
+    w.para_Pose = s.wpose.data(); w.para_SpeedBias = s.wsb.data(); w.para_Ex_Pose = s.wex.data(); w.para_Feature = s.wfeat.data();
+    return ISV_OK;
+}
+
+// what double2vector() and update() leave in the Estimator members
+void read_back(Sequence &s) {
+    const int N = s.N;
+    for (int i = 0; i < N; i++) {
+        std::memcpy(s.Ps[i].data(), &s.wPs[i * 3], 24); std::memcpy(s.Rs[i].data(), &s.wRs[i * 9], 72); std::memcpy(s.Vs[i].data(), &s.wVs[i * 3], 24);
+        std::memcpy(s.Bas[i].data(), &s.wBas[i * 3], 24); std::memcpy(s.Bgs[i].data(), &s.wBgs[i * 3], 24);
+    }
+    for (size_t l = 0; l < s.good.size(); l++) { Track &t = s.tracks[s.good[l]]; t.depth = s.wdepth[l]; t.solve_flag = s.wflag[l]; }
+    s.pose_prior = s.wpp; s.vb_prior = s.wvb;
+    s.relpose = s.wrel;
+    for (size_t i = 0; i < s.rollpitch.size(); i++) s.rollpitch[i] = s.wrp[i];
+}
+
+void new_preintegration(const isv_estimator *e, Sequence &s, int j) {
+    s.pre[j].reset(new PreIntegration(s.acc_0, s.gyr_0, s.Bas[j], s.Bgs[j], e->p));
+}
+
+// Estimator::slideWindow  src/estimator.cpp:1565-1724
+void slide_window(const isv_estimator *e, Sequence &s) {
+    const int N = s.N, Nvo = s.Nvo;
+    if (s.margin_old) {
+        const M3 back_R0 = s.Rs[0];
+        const V3 back_P0 = s.Ps[0];
+        if (s.frame_count != N - 1) return;
+        for (int i = 0; i < N - 1; i++) {
+            std::swap(s.Ps[i], s.Ps[i + 1]); std::swap(s.Rs[i], s.Rs[i + 1]); std::swap(s.Vs[i], s.Vs[i + 1]);
+            std::swap(s.Bas[i], s.Bas[i + 1]); std::swap(s.Bgs[i], s.Bgs[i + 1]); std::swap(s.Headers[i], s.Headers[i + 1]);
+            std::swap(s.pre[i], s.pre[i + 1]); std::swap(s.bufs[i], s.bufs[i + 1]);
+        }
+        s.Headers[N - 1] = s.Headers[N - 2];
+        s.Ps[N - 1] = s.Ps[N - 2]; s.Rs[N - 1] = s.Rs[N - 2]; s.Vs[N - 1] = s.Vs[N - 2]; s.Bas[N - 1] = s.Bas[N - 2]; s.Bgs[N - 1] = s.Bgs[N - 2];
+        new_preintegration(e, s, N - 1);
+        s.bufs[N - 1].clear();
+        const bool shift_depth = s.flag == NON_LINEAR;
+        if (shift_depth && s.have_to_add) {            // the prior factors move one frame towards the past (:1607-1645)
+            for (auto &f : s.relpose) { f.imu_i -= 1; f.imu_j -= 1; }                  // RelativePoseFactor::shift()
+            s.relpose.erase(s.relpose.begin());
+            s.add_relpose.imu_i = Nvo - 2; s.add_relpose.imu_j = Nvo - 1;
+            s.relpose.push_back(s.add_relpose);
+            std::vector<isv_rollpitch_t> kept;
+            for (auto &f : s.rollpitch) { f.index -= 1; if (f.index >= 0) kept.push_back(f); }      // RollPitchFactor::shift()
+            s.rollpitch.swap(kept);
+            s.add_pose_prior.index = 0; s.pose_prior = s.add_pose_prior;
+            s.add_vb.index = Nvo - 1; s.vb_prior = s.add_vb;
+            s.have_to_add = false;
+        }
+        std::vector<Track> keep;
+        keep.reserve(s.tracks.size());
+        if (shift_depth) {                             // slideWindowOld -> removeBackShiftDepth  feature_manager.cpp:275-313
+            const M3 ric = {e->p.ric[0], e->p.ric[1], e->p.ric[2], e->p.ric[3], e->p.ric[4], e->p.ric[5], e->p.ric[6], e->p.ric[7], e->p.ric[8]};
+            const V3 tic = {e->p.tic[0], e->p.tic[1], e->p.tic[2]};
+            const M3 R0 = mm(back_R0, ric), R1 = mm(s.Rs[0], ric);
+            const V3 P0 = add(back_P0, mv(back_R0, tic)), P1 = add(s.Ps[0], mv(s.Rs[0], tic));
+            for (Track &t : s.tracks) {
+                if (t.start_frame != 0) { t.start_frame--; keep.push_back(std::move(t)); continue; }
+                const V3 uv = t.points.front();
+                t.points.erase(t.points.begin());
+                if (t.points.size() < 2) continue;
+                const V3 w_pt = add(mv(R0, mul(uv, t.depth)), P0);
+                const V3 pj = mtv(R1, sub(w_pt, P1));
+                t.depth = pj[2] > 0 ? pj[2] : e->p.cfg.init_depth;
+                keep.push_back(std::move(t));
+            }
+        } else {                                       // removeBack  :315-332
+            for (Track &t : s.tracks) {
+                if (t.start_frame != 0) { t.start_frame--; keep.push_back(std::move(t)); continue; }
+                t.points.erase(t.points.begin());
+                if (!t.points.empty()) keep.push_back(std::move(t));
+            }
+        }
+        s.tracks.swap(keep);
+    } else {
+        const int fc = s.frame_count;
+        if (fc != N - 1) return;
+        for (const Sample &smp : s.bufs[fc]) {
+            s.pre[fc - 1]->push_back(smp.dt, smp.acc, smp.gyr);
+            s.bufs[fc - 1].push_back(smp);
+        }
+        s.Headers[fc - 1] = s.Headers[fc];
+        s.Ps[fc - 1] = s.Ps[fc]; s.Rs[fc - 1] = s.Rs[fc]; s.Vs[fc - 1] = s.Vs[fc]; s.Bas[fc - 1] = s.Bas[fc]; s.Bgs[fc - 1] = s.Bgs[fc];
+        new_preintegration(e, s, N - 1);
+        s.bufs[N - 1].clear();
+        std::vector<Track> keep;                       // slideWindowNew -> removeFront  :335-354
+        keep.reserve(s.tracks.size());
+        for (Track &t : s.tracks) {
+            if (t.start_frame == fc) { t.start_frame--; keep.push_back(std::move(t)); continue; }
+            if (t.end_frame() < fc - 1) { keep.push_back(std::move(t)); continue; }
+            t.points.erase(t.points.begin() + (N - 1 - 1 - t.start_frame));
+            if (!t.points.empty()) keep.push_back(std::move(t));
+        }
+        s.tracks.swap(keep);
+    }
+}
+
+void after_solve(const isv_estimator *e, Sequence &s, double header) {
+    slide_window(e, s);
+    s.tracks.erase(std::remove_if(s.tracks.begin(), s.tracks.end(), [](const Track &t) { return t.solve_flag == 2; }), s.tracks.end());      // removeFailures
+    const int N = s.N;
+    std::array<double, 13> nr;
+    nr[0] = header;
+    std::memcpy(&nr[1], s.Ps[N - 1].data(), 24); std::memcpy(&nr[4], s.Rs[N - 1].data(), 72);
+    s.newest_rows.push_back(nr);
+    const Quat q = quat_of(s.Rs[0]);
+    s.pose_rows.push_back({s.Headers[0], s.Ps[0][0], s.Ps[0][1], s.Ps[0][2], q.w, q.x, q.y, q.z});
+}
+
+int hip_triangulate(void *ctx, int32_t n, isv_window_t *const *w) { return isv_backend_triangulate((isv_backend_t *)ctx, n, w); }
+int hip_init(void *ctx, isv_window_t *w, isv_summary_t *s, double *kld) { return isv_backend_init_factor_graph((isv_backend_t *)ctx, w, s, kld); }
+int hip_optimize(void *ctx, int32_t n, isv_window_t *const *w, isv_summary_t *s, isv_marg_result_t *m) {
+    return isv_backend_optimize_batch((isv_backend_t *)ctx, n, w, s, m);
+}
+
+int create_common(const isv_estimator_params_t *p, int32_t n_sequences, isv_estimator **out) {
+    if (!p || !out || n_sequences < 1) return ISV_ERR_INVALID_ARG;
+    const int N = p->cfg.n_frames, Nvo = p->cfg.n_vo;
+    if (N < 3 || Nvo < 2 || Nvo > N - 1) return ISV_ERR_INVALID_ARG;
+    isv_estimator *e = new isv_estimator();
+    e->p = *p;
+    e->p.cfg.max_batch = n_sequences;
+    e->seq.resize(n_sequences);
+    for (Sequence &s : e->seq) {
+        s.N = N; s.Nvo = Nvo;
+        s.Ps.assign(N, V3{0, 0, 0}); s.Vs = s.Ps; s.Bas = s.Ps; s.Bgs = s.Ps;
+        s.Rs.assign(N, M3{1, 0, 0, 0, 1, 0, 0, 0, 1});
+        s.Headers.assign(N, 0.0);
+        s.pre.resize(N); s.bufs.resize(N);
+        s.relpose.assign(Nvo - 1, isv_relpose_t{});
+    }
+    *out = e;
+    return ISV_OK;
+}
+
+}  // namespace
+
+extern "C" int isv_estimator_create(const isv_estimator_params_t *p, int32_t n_sequences, isv_estimator_t **out) {
+    if (out) *out = nullptr;
+    isv_estimator *e = nullptr;
+    int rc = create_common(p, n_sequences, &e);
+    if (rc != ISV_OK) return rc;
+    rc = isv_backend_create(&e->p.cfg, &e->backend);           // fails loudly without a GPU: there is no other solver
+    if (rc != ISV_OK) { delete e; return rc; }
+    e->solver = isv_solver_vtbl_t{e->backend, hip_triangulate, hip_init, hip_optimize};
+    *out = e;
+    return ISV_OK;
+}
+
+extern "C" int isv_estimator_create_with_solver(const isv_estimator_params_t *p, int32_t n_sequences, const isv_solver_vtbl_t *solver,
+                                                isv_estimator_t **out) {
+    if (out) *out = nullptr;
+    if (!solver || !solver->triangulate || !solver->init_factor_graph || !solver->optimize_batch) return ISV_ERR_INVALID_ARG;
+    isv_estimator *e = nullptr;
+    const int rc = create_common(p, n_sequences, &e);
+    if (rc != ISV_OK) return rc;
+    e->solver = *solver;
+    *out = e;
+    return ISV_OK;
+}
+
+extern "C" void isv_estimator_destroy(isv_estimator_t *e) {
+    if (!e) return;
+    if (e->backend) isv_backend_destroy(e->backend);
+    delete e;
+}
+
+extern "C" const char *isv_estimator_last_error(const isv_estimator_t *e) { return e ? e->err.c_str() : "null handle"; }
+
+#define SEQ_OR_FAIL(e, seq) \
+    if (!(e) || (seq) < 0 || (size_t)(seq) >= (e)->seq.size()) return ISV_ERR_INVALID_ARG
+
+// Estimator::processIMU  src/estimator.cpp:91-124
+extern "C" int isv_estimator_process_imu(isv_estimator_t *e, int32_t seq, double dt, const double acc[3], const double gyr[3]) {
+    SEQ_OR_FAIL(e, seq);
+    if (!acc || !gyr) return ISV_ERR_INVALID_ARG;
+    Sequence &s = e->seq[seq];
+    const V3 a = {acc[0], acc[1], acc[2]}, g = {gyr[0], gyr[1], gyr[2]};
+    if (s.first_imu) { s.first_imu = false; s.acc_0 = a; s.gyr_0 = g; }
+    const int j = s.frame_count;
+    if (!s.pre[j]) new_preintegration(e, s, j);
+    if (j != 0) {
+        s.pre[j]->push_back(dt, a, g);
+        s.bufs[j].push_back(Sample{dt, a, g});
+        const V3 G = {e->p.cfg.gravity[0], e->p.cfg.gravity[1], e->p.cfg.gravity[2]};
+        const V3 un_acc_0 = sub(mv(s.Rs[j], sub(s.acc_0, s.Bas[j])), G);
+        const V3 un_gyr = sub(mul(add(s.gyr_0, g), 0.5), s.Bgs[j]);
+        s.Rs[j] = mm(s.Rs[j], delta_q_matrix(mul(un_gyr, dt)));
+        const V3 un_acc_1 = sub(mv(s.Rs[j], sub(a, s.Bas[j])), G);
+        const V3 un_acc = mul(add(un_acc_0, un_acc_1), 0.5);
+        for (int k = 0; k < 3; k++) {
+            s.Ps[j][k] = s.Ps[j][k] + dt * s.Vs[j][k] + 0.5 * dt * dt * un_acc[k];
+            s.Vs[j][k] = s.Vs[j][k] + dt * un_acc[k];
+        }
+    }
+    s.acc_0 = a; s.gyr_0 = g;
+    return ISV_OK;
+}
+
+extern "C" int isv_estimator_push_image(isv_estimator_t *e, int32_t seq, double header, int32_t n, const int32_t *feature_id,
+                                        const double *point) {
+    SEQ_OR_FAIL(e, seq);
+    if (n < 0 || (n > 0 && (!feature_id || !point))) return ISV_ERR_INVALID_ARG;
+    Sequence &s = e->seq[seq];
+    if (s.staged) { e->err = "an image is already staged for this sequence"; return ISV_ERR_INVALID_ARG; }
+    s.staged_image.clear();
+    s.staged_image.reserve(n);
+    for (int i = 0; i < n; i++) s.staged_image.emplace_back(feature_id[i], V3{point[i * 3], point[i * 3 + 1], point[i * 3 + 2]});
+    s.staged_header = header;
+    s.staged = true;
+    return ISV_OK;
+}
+
+extern "C" int isv_estimator_set_bootstrap(isv_estimator_t *e, int32_t seq, const double *Ps, const double *Rs, const double *Vs) {
+    SEQ_OR_FAIL(e, seq);
+    if (!Ps || !Rs || !Vs) return ISV_ERR_INVALID_ARG;
+    Sequence &s = e->seq[seq];
+    s.boot_P.resize(s.N); s.boot_V.resize(s.N); s.boot_R.resize(s.N);
+    for (int i = 0; i < s.N; i++) {
+        std::memcpy(s.boot_P[i].data(), Ps + i * 3, 24); std::memcpy(s.boot_V[i].data(), Vs + i * 3, 24); std::memcpy(s.boot_R[i].data(), Rs + i * 9, 72);
+    }
+    s.have_boot = true;
+    return ISV_OK;
+}
+
+// Estimator::processImage (src/estimator.cpp:126-215) on every staged sequence, the solves batched
+extern "C" int isv_estimator_step(isv_estimator_t *e) {
+    if (!e) return ISV_ERR_INVALID_ARG;
+    std::vector<int> solve;
+    for (size_t si = 0; si < e->seq.size(); si++) {
+        Sequence &s = e->seq[si];
+        if (!s.staged) continue;
+        if (s.flag == INITIAL && s.frame_count == s.N - 1 && !s.have_boot) { e->err = "the window is full: isv_estimator_set_bootstrap first"; return ISV_ERR_INVALID_ARG; }
+        s.margin_old = add_features(s, e->p.min_parallax);
+        s.Headers[s.frame_count] = s.staged_header;
+        s.staged = false;
+        if (s.flag == INITIAL) {
+            if (s.frame_count == s.N - 1) {
+                s.Ps = s.boot_P; s.Rs = s.boot_R; s.Vs = s.boot_V;       // in place of initialStructure()
+                s.flag = INITIAL_STRUCTURE;
+                solve.push_back((int)si);
+            } else s.frame_count++;
+        } else solve.push_back((int)si);
+    }
+    if (solve.empty()) return 0;
+    // solveOdometry (:461-472): f_manager.triangulate(Ps, tic, ric); backendOptimization()
+    std::vector<isv_window_t *> ws(solve.size());
+    for (size_t k = 0; k < solve.size(); k++) {
+        Sequence &s = e->seq[solve[k]];
+        const int rc = build_window(e, s);
+        if (rc != ISV_OK) return rc;
+        ws[k] = &s.w;
+    }
+    int rc = e->solver.triangulate(e->solver.ctx, (int32_t)ws.size(), ws.data());
+    if (rc != ISV_OK) { e->err = "triangulate failed"; return rc; }
+    for (int si : solve) {
+        Sequence &s = e->seq[si];
+        for (size_t l = 0; l < s.good.size(); l++) s.tracks[s.good[l]].depth = s.wdepth[l];
+    }
+    // backendOptimization(), INITIAL_STRUCTURE branch (:1543-1548): vector2double, initFactorGraph, NON_LINEAR.  The
+    // NON_LINEAR branch below runs in the same call (two `if`s in the reference, not else-if).
+    for (int si : solve) {
+        Sequence &s = e->seq[si];
+        if (s.flag != INITIAL_STRUCTURE) continue;
+        isv_summary_t s0;
+        double kld = 0;
+        rc = e->solver.init_factor_graph(e->solver.ctx, &s.w, &s0, &kld);
+        if (rc != ISV_OK) { e->err = "initFactorGraph failed"; return rc; }
+        s.rollpitch.clear();
+        read_back(s);
+        s.flag = NON_LINEAR;
+        s.have_to_add = false;
+        rc = build_window(e, s);
+        if (rc != ISV_OK) return rc;
+    }
+    std::vector<isv_summary_t> sums(solve.size());
+    std::vector<isv_marg_result_t> margs(solve.size());
+    rc = e->solver.optimize_batch(e->solver.ctx, (int32_t)ws.size(), ws.data(), sums.data(), margs.data());
+    if (rc != ISV_OK) { e->err = "backendOptimization failed"; return rc; }
+    for (size_t k = 0; k < solve.size(); k++) {
+        Sequence &s = e->seq[solve[k]];
+        read_back(s);
+        const isv_marg_result_t &m = margs[k];
+        if (s.margin_old && m.valid) {
+            s.add_pose_prior = m.forward_pose_prior; s.add_relpose = m.backward_relpose; s.add_vb = m.backward_vb;
+            s.have_to_add = true;
+            isv_rollpitch_t brp = m.backward_rollpitch;
+            brp.index = s.Nvo - 1;
+            s.rollpitch.push_back(brp);                 // vioRollPitchEdges.push_back  (MargBackward :1536-1538)
+        }
+        s.last_summary = sums[k];
+        s.n_solves++;
+        s.n_good_last = (int)s.good.size();
+        after_solve(e, s, s.Headers[s.N - 1]);
+    }
+    return (int)solve.size();
+}
+
+extern "C" int isv_estimator_status(const isv_estimator_t *e, int32_t seq, int32_t out[8]) {
+    SEQ_OR_FAIL(e, seq);
+    if (!out) return ISV_ERR_INVALID_ARG;
+    const Sequence &s = e->seq[seq];
+    out[0] = s.flag == NON_LINEAR ? 1 : 0; out[1] = s.frame_count; out[2] = s.margin_old ? 1 : 0; out[3] = (int32_t)s.tracks.size();
+    out[4] = s.n_good_last; out[5] = (int32_t)s.rollpitch.size(); out[6] = s.n_solves; out[7] = s.last_summary.iterations;
+    return ISV_OK;
+}
+
+extern "C" int isv_estimator_get_window(const isv_estimator_t *e, int32_t seq, double *Ps, double *Rs, double *Vs, double *Bas,
+                                        double *Bgs, double *Headers) {
+    SEQ_OR_FAIL(e, seq);
+    const Sequence &s = e->seq[seq];
+    for (int i = 0; i < s.N; i++) {
+        if (Ps) std::memcpy(Ps + i * 3, s.Ps[i].data(), 24);
+        if (Rs) std::memcpy(Rs + i * 9, s.Rs[i].data(), 72);
+        if (Vs) std::memcpy(Vs + i * 3, s.Vs[i].data(), 24);
+        if (Bas) std::memcpy(Bas + i * 3, s.Bas[i].data(), 24);
+        if (Bgs) std::memcpy(Bgs + i * 3, s.Bgs[i].data(), 24);
+        if (Headers) Headers[i] = s.Headers[i];
+    }
+    return ISV_OK;
+}
+
+extern "C" int isv_estimator_last_summary(const isv_estimator_t *e, int32_t seq, isv_summary_t *out) {
+    SEQ_OR_FAIL(e, seq);
+    if (!out) return ISV_ERR_INVALID_ARG;
+    *out = e->seq[seq].last_summary;
+    return ISV_OK;
+}
+
+extern "C" int isv_estimator_trajectory(const isv_estimator_t *e, int32_t seq, int32_t which, double *out, int32_t max_rows) {
+    SEQ_OR_FAIL(e, seq);
+    const Sequence &s = e->seq[seq];
+    if (which == 0) {
+        for (int i = 0; out && i < max_rows && i < (int)s.pose_rows.size(); i++) std::memcpy(out + i * 8, s.pose_rows[i].data(), 64);
+        return (int)s.pose_rows.size();
+    }
+    if (which == 1) {
+        for (int i = 0; out && i < max_rows && i < (int)s.newest_rows.size(); i++) std::memcpy(out + i * 13, s.newest_rows[i].data(), 104);
+        return (int)s.newest_rows.size();
+    }
+    return ISV_ERR_INVALID_ARG;
+}

@@ -137,6 +137,7 @@ class Estimator:
         self.margin_old = True
         self.to_add = None                           # (forward pose prior, backward relpose, backward vb) from the last MARGIN_OLD solve
         self.pose_output = []
+        self.margin_history = []
         self.trajectory = []                         # (header, P, R) of the newest frame after every solve
         self.summaries = []
 
@@ -339,6 +340,7 @@ class Estimator:
     # ---- processImage  src/estimator.cpp:126-215 ---------------------------------------------------
     def process_image(self, image, header, bootstrap=None):
         self.margin_old = self._add_features(image)
+        self.margin_history.append(bool(self.margin_old))
         self.Headers[self.frame_count] = header
         if self.solver_flag == "INITIAL":
             if self.frame_count == self.N - 1:
@@ -428,3 +430,57 @@ def run_sequence(solver, lib, N, Nvo, n_frames, seed=0):
             boot = (P, R, V)
         est.process_image(image, t, bootstrap=boot)
     return est, sim
+
+
+# ---- the native window manager (include/isvins_estimator.h) driven by the same simulated streams ------------------
+def oracle_vtbl(oracle, cfg):
+    """isv_solver_vtbl_t whose three entry points are the CPU oracle: the test seam of isv_estimator_create_with_solver,
+    so that the C++ host logic can be checked on a machine without a GPU"""
+    from isvins_amd import estimator as E
+
+    def tri(ctx, n, ws):
+        for i in range(n):
+            if oracle.isvo_triangulate(C.byref(cfg), ws[i]) != 0:
+                return -1
+        return 0
+
+    def init(ctx, w, s, kld):
+        rc = oracle.isvo_init_factor_graph(C.byref(cfg), w, s, kld)
+        w.contents.n_rollpitch = 0
+        return rc
+
+    def opt(ctx, n, ws, sums, margs):
+        for i in range(n):
+            if oracle.isvo_optimize(C.byref(cfg), ws[i], C.byref(sums[i]), C.byref(margs[i])) != 0:
+                return -1
+        return 0
+    return E.isv_solver_vtbl_t(None, E.TRIANGULATE_FN(tri), E.INIT_FN(init), E.OPTIMIZE_FN(opt))
+
+
+def estimator_params(cfg):
+    from isvins_amd import estimator as E
+    return E.make_params(cfg, synth.RIC, synth.TIC, ACC_N, GYR_N, ACC_W, GYR_W, MIN_PARALLAX)
+
+
+def run_sequences_native(est, N, n_frames, seeds):
+    """push len(seeds) simulated streams (Simulator(seed)) through a SequenceEstimator in lock step"""
+    sims = [Simulator(sd) for sd in seeds]
+    for i in range(n_frames):
+        for s, (sim, sd) in enumerate(zip(sims, seeds)):
+            if i > 0:
+                for (dt, a, g) in sim.imu_between(i):
+                    est.process_imu(s, dt, a, g)
+            else:
+                est.process_imu(s, sim.frame_dt / sim.k, sim.traj.R(0).T @ (sim.traj.acc(0) + np.array([0, 0, 9.81007])) + sim.ba, sim.traj.gyro(0) + sim.bg)
+            t, image = sim.frame(i)
+            st = est.status(s)
+            if st["solver_flag"] == 0 and st["frame_count"] == N - 1:
+                P, R, V = sim.truth_window(i, N)
+                nrng = np.random.default_rng(1000 + sd)
+                P = P + nrng.normal(0, 0.01, P.shape); V = V + nrng.normal(0, 0.02, V.shape)
+                est.set_bootstrap(s, P, R, V)
+            ids = np.array(list(image.keys()), np.int32)[::-1]                 # any order: the estimator sorts by id
+            pts = np.array([image[int(k)] for k in ids], float).reshape(-1, 3)
+            est.push_image(s, t, ids, pts)
+        est.step()
+    return sims

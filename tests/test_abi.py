@@ -12,6 +12,7 @@ from isvins_amd import abi, backend
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "isvins_backend.h")
+HEADER_EST = os.path.join(ROOT, "include", "isvins_estimator.h")
 
 
 @pytest.fixture(scope="module")
@@ -20,8 +21,8 @@ def lib():
     return backend.load_library()
 
 
-def declared_functions():
-    src = open(HEADER).read()
+def declared_functions(header=HEADER):
+    src = open(header).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(isv_[a-z0-9_]+)\s*\(", src)))
 
@@ -33,6 +34,25 @@ def test_every_declared_symbol_is_exported(lib):
         assert hasattr(lib, n), f"{n} declared in include/isvins_backend.h but not exported"
     assert set(names) == set(backend.EXPORTS)
     assert lib.isv_abi_version() == 1
+
+
+def test_every_estimator_symbol_is_exported(lib):
+    from isvins_amd import estimator
+    names = [n for n in declared_functions(HEADER_EST) if n.startswith("isv_estimator_")]
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/isvins_estimator.h but not exported"
+    assert set(names) == set(estimator.EXPORTS)
+
+
+def test_estimator_create_fails_loudly_without_gpu(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from isvins_amd import estimator, synth
+    p = estimator.make_params(abi.make_config(11, 5), synth.RIC, synth.TIC, 0.2, 0.004, 0.001, 0.0001, 10.0 / 460.0)
+    with pytest.raises(backend.BackendError):
+        estimator.SequenceEstimator(p, 2)
 
 
 def test_struct_sizes_match_header(tmp_path):

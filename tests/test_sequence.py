@@ -63,3 +63,66 @@ def test_sequence_ate_gpu_vs_oracle(oracle, N, Nvo, n_frames):
     rot = max(np.linalg.norm(a @ b_.T - np.eye(3)) for a, b_ in zip(Rg, Ro))
     print(f"N={N}: {len(Pg)} solved frames, ATE(GPU vs oracle) = {ate:.3e} m, max rotation difference = {rot:.3e}")
     assert ate < 1e-6 and rot < 1e-6
+
+
+def _cmp_native_vs_harness(est, s, eo, tol):
+    """the native window manager against the Python restatement after the same stream: trajectory rows, window states,
+    bookkeeping"""
+    rows = est.trajectory(s, 1); po = est.trajectory(s, 0)
+    Po, Ro = _traj(eo)
+    assert len(rows) == len(Po) == len(eo.pose_output)
+    assert np.abs(rows[:, 1:4] - Po).max() < tol and np.abs(rows[:, 4:].reshape(-1, 3, 3) - Ro).max() < tol
+    assert np.abs(po[:, 0] - np.array([t for (t, _, _) in eo.pose_output])).max() == 0
+    assert np.abs(po[:, 1:4] - np.array([p for (_, p, _) in eo.pose_output])).max() < tol
+    qo = np.array([sh._quat_from_R(R) for (_, _, R) in eo.pose_output])
+    assert np.abs(po[:, 4:] - qo).max() < tol
+    w = est.window(s)
+    assert np.abs(w["Ps"] - eo.Ps).max() < tol and np.abs(w["Rs"] - eo.Rs).max() < tol and np.abs(w["Vs"] - eo.Vs).max() < tol
+    assert np.abs(w["Bas"] - eo.Bas).max() < tol and np.abs(w["Bgs"] - eo.Bgs).max() < tol and np.array_equal(w["Headers"], eo.Headers)
+    st = est.status(s)
+    assert st["solver_flag"] == 1 and st["frame_count"] == eo.frame_count and st["n_tracks"] == len(eo.tracks)
+    assert st["n_rollpitch"] == len(eo.rollpitch) and st["margin_old"] == int(eo.margin_old)
+    assert st["iterations"] == eo.summaries[-1].iterations
+
+
+def test_native_window_manager_matches_the_restatement(oracle):
+    """include/isvins_estimator.h (C++: processIMU, pre-integration, addFeatureAndCheckParallax, slideWindow, prior
+    rotation, removeBackShiftDepth / removeFront / removeFailures) against tests/sequence_harness.py on the same
+    simulated streams, both with the CPU oracle as the solver (injected through isv_estimator_create_with_solver);
+    two sequences in lock step.  Tolerance 1e-9: the two pre-integrations round differently in the last bits."""
+    from isvins_amd import estimator as E
+    N, Nvo, n_frames, seeds = 11, 5, 19, (0, 3)
+    cfg = abi.make_config(N, Nvo, max_landmarks=600, max_obs=6600, max_batch=len(seeds))
+    vt = sh.oracle_vtbl(oracle, cfg)
+    est = E.SequenceEstimator(sh.estimator_params(cfg), len(seeds), solver=vt)
+    sh.run_sequences_native(est, N, n_frames, seeds)
+    margin_flags = set()
+    for s, sd in enumerate(seeds):
+        eo, _ = sh.run_sequence(sh.OracleSolver(oracle, cfg), oracle, N, Nvo, n_frames, seed=sd)
+        _cmp_native_vs_harness(est, s, eo, 1e-9)
+        margin_flags |= set(eo.margin_history[N - 1:])
+    assert margin_flags == {True, False}           # both slideWindow branches were taken after the first solve
+    est.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,Nvo,n_frames,n_seq", [(11, 5, 31, 4), (18, 8, 30, 2)])
+def test_native_sequences_on_gpu_vs_oracle(oracle, N, Nvo, n_frames, n_seq):
+    """S sequences in lock step through the native window manager with every solve on the MI355X (one batched
+    triangulate + backendOptimization per frame) against the Python restatement with the CPU oracle: ATE <= 1e-6 m"""
+    from isvins_amd import estimator as E
+    seeds = tuple(range(n_seq))
+    cfg = abi.make_config(N, Nvo, max_landmarks=800, max_obs=800 * N, max_batch=n_seq)
+    est = E.SequenceEstimator(sh.estimator_params(cfg), n_seq)
+    sh.run_sequences_native(est, N, n_frames, seeds)
+    for s, sd in enumerate(seeds):
+        eo, _ = sh.run_sequence(sh.OracleSolver(oracle, cfg), oracle, N, Nvo, n_frames, seed=sd)
+        rows = est.trajectory(s, 1)
+        Po, Ro = _traj(eo)
+        assert len(rows) == len(Po) == n_frames - (N - 1)
+        ate = np.sqrt(np.mean(np.sum((rows[:, 1:4] - Po) ** 2, axis=1)))
+        rot = np.abs(rows[:, 4:].reshape(-1, 3, 3) - Ro).max()
+        print(f"N={N} seq {s}: {len(Po)} solved frames, ATE(native+GPU vs restatement+oracle) = {ate:.3e} m, rotation {rot:.3e}")
+        assert ate < 1e-6 and rot < 1e-6
+        assert est.status(s)["n_tracks"] == len(eo.tracks)
+    est.close()
