@@ -236,6 +236,10 @@ int  isv_backend_init_factor_graph(isv_backend_t *h, isv_window_t *w, isv_summar
  * all its views (smallest right singular vector, host-camera frame), replaced by INIT_DEPTH outside [0.1, 8].
  * lm_depth is updated in place; landmarks that already have a depth are left alone.           */
 int  isv_backend_triangulate(isv_backend_t *h, int32_t n, isv_window_t *const *w);
+/* Estimator::solveOdometry (src/estimator.cpp:461-472) = triangulate then backendOptimization, for n windows with one
+ * upload and one download (the window manager's per-frame call in steady state).                */
+int  isv_backend_solve_odometry_batch(isv_backend_t *h, int32_t n, isv_window_t *const *w,
+                                      isv_summary_t *summary, isv_marg_result_t *marg);
 int  isv_backend_linearize(isv_backend_t *h, const isv_window_t *w,
                            double *proj_strips, double *imu_strips, double *cost);
 

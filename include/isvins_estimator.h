@@ -47,6 +47,8 @@ typedef struct isv_solver_vtbl {
     int (*triangulate)(void *ctx, int32_t n, isv_window_t *const *w);
     int (*init_factor_graph)(void *ctx, isv_window_t *w, isv_summary_t *summary, double *kld);
     int (*optimize_batch)(void *ctx, int32_t n, isv_window_t *const *w, isv_summary_t *summary, isv_marg_result_t *marg);
+    /* optional (may be NULL): triangulate + optimize_batch in one hand-over; used when no sequence is at its first solve */
+    int (*solve_odometry_batch)(void *ctx, int32_t n, isv_window_t *const *w, isv_summary_t *summary, isv_marg_result_t *marg);
 } isv_solver_vtbl_t;
 
 typedef struct isv_estimator isv_estimator_t;
@@ -60,6 +62,9 @@ const char *isv_estimator_last_error(const isv_estimator_t *e);
 
 /* Estimator::processIMU(dt, linear_acceleration, angular_velocity)  src/estimator.cpp:91-124 */
 int  isv_estimator_process_imu(isv_estimator_t *e, int32_t seq, double dt, const double acc[3], const double gyr[3]);
+
+/* n consecutive processIMU calls: dt [n], acc [n][3], gyr [n][3] */
+int  isv_estimator_process_imu_n(isv_estimator_t *e, int32_t seq, int32_t n, const double *dt, const double *acc, const double *gyr);
 
 /* The image argument of Estimator::processImage (feature id -> normalised point (x, y, z = 1)); staged until
  * isv_estimator_step.  Ids may come in any order (the reference iterates a std::map, i.e. ascending id). */
@@ -75,6 +80,11 @@ int  isv_estimator_set_bootstrap(isv_estimator_t *e, int32_t seq, const double *
  * ONE batched backendOptimization, slideWindow, removeFailures.  Returns the number of sequences solved (>= 0) or a
  * negative isv_status_t. */
 int  isv_estimator_step(isv_estimator_t *e);
+
+/* wall-clock milliseconds of the last isv_estimator_step: [0] whole step, [1] addFeatureAndCheckParallax + window
+ * packing, [2] triangulate (backend call), [3] initFactorGraph calls, [4] backendOptimization (backend call),
+ * [5] read-back + slideWindow + removeFailures */
+int  isv_estimator_last_step_ms(const isv_estimator_t *e, double out[6]);
 
 /* out[0] solver_flag (0 INITIAL, 1 NON_LINEAR), [1] frame_count, [2] marginalization_flag of the last image
  * (1 MARGIN_OLD, 0 MARGIN_SECOND_NEW), [3] tracks in the feature manager, [4] landmarks in the last solve,

@@ -592,6 +592,22 @@ extern "C" int isv_backend_triangulate(isv_backend_t *h, int32_t n, isv_window_t
     return ISV_OK;
 }
 
+// Estimator::solveOdometry (src/estimator.cpp:461-472) for n windows with ONE hand-over: upload, triangulate on the
+// device, make the triangulated depths the solve's starting point, backendOptimization, download.  The depths a caller
+// would read between the two steps are overwritten by double2vector for every landmark of the window anyway.
+extern "C" int isv_backend_solve_odometry_batch(isv_backend_t *h, int32_t n, isv_window_t *const *ws, isv_summary_t *summary,
+                                                isv_marg_result_t *marg) {
+    TRY(isv_batch_upload(h, n, ws));
+    DevBatch &d = h->d; hipStream_t st = h->stream;
+    if (d.Ltot) {
+        hipLaunchKernelGGL(k_triangulate, dim3((d.Ltot + 63) / 64), dim3(64), 0, st, d);
+        HIPCHK(h, hipGetLastError());
+        D2D(h->depth0, d.depth, (size_t)d.Ltot);        // isv_batch_optimize restores the state from the *0 copies
+    }
+    TRY(isv_batch_optimize(h, 1));
+    return isv_batch_download(h, n, ws, summary, marg);
+}
+
 extern "C" int isv_backend_linearize(isv_backend_t *h, const isv_window_t *w, double *proj_strips, double *imu_strips,
                                      double *cost) {
     if (!h || !w) return ISV_ERR_INVALID_ARG;

@@ -3,10 +3,13 @@
 // isv_estimator_create binds to the HIP backend (isv_backend_triangulate / _init_factor_graph / _optimize_batch).
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <memory>
+#include <cstdlib>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 #include "../../include/isvins_estimator.h"
@@ -232,6 +235,7 @@ struct isv_estimator {
     isv_backend_t *backend = nullptr;          // owned when created by isv_estimator_create
     std::vector<Sequence> seq;
     std::string err;
+    double step_ms[6] = {0, 0, 0, 0, 0, 0};
 };
 
 namespace {
@@ -274,15 +278,15 @@ bool add_features(Sequence &s, double min_parallax) {
 }
 
 // the Estimator members backendOptimization() touches, as an isv_window_t over this sequence's buffers
-int build_window(isv_estimator *e, Sequence &s) {
+int build_window(const isv_estimator *e, Sequence &s, std::string &err) {
     const int N = s.N, Nvo = s.Nvo;
     s.good.clear();
     size_t n_obs = 0;
     for (size_t i = 0; i < s.tracks.size(); i++)            // goodFeature(): used_num >= 2 && start_frame < Vo_SIZE
         if (s.tracks[i].points.size() >= 2 && s.tracks[i].start_frame < Nvo) { s.good.push_back((int)i); n_obs += s.tracks[i].points.size(); }
     const size_t L = s.good.size();
-    if ((int)L > e->p.cfg.max_landmarks || (int)n_obs > e->p.cfg.max_obs) { e->err = "window exceeds the landmark / observation capacity"; return ISV_ERR_CAPACITY; }
-    if ((int)s.rollpitch.size() > e->p.cfg.max_rollpitch) { e->err = "more roll/pitch factors than max_rollpitch"; return ISV_ERR_CAPACITY; }
+    if ((int)L > e->p.cfg.max_landmarks || (int)n_obs > e->p.cfg.max_obs) { err = "window exceeds the landmark / observation capacity"; return ISV_ERR_CAPACITY; }
+    if ((int)s.rollpitch.size() > e->p.cfg.max_rollpitch) { err = "more roll/pitch factors than max_rollpitch"; return ISV_ERR_CAPACITY; }
     s.wPs.resize(N * 3); s.wRs.resize(N * 9); s.wVs.resize(N * 3); s.wBas.resize(N * 3); s.wBgs.resize(N * 3);
     for (int i = 0; i < N; i++) {
         std::memcpy(&s.wPs[i * 3], s.Ps[i].data(), 24); std::memcpy(&s.wRs[i * 9], s.Rs[i].data(), 72); std::memcpy(&s.wVs[i * 3], s.Vs[i].data(), 24);
@@ -300,7 +304,7 @@ int build_window(isv_estimator *e, Sequence &s) {
     }
     s.wimu.resize(N - 1);
     for (int j = 1; j < N; j++) {
-        if (!s.pre[j]) { e->err = "a window frame has no pre-integration (no IMU samples were fed)"; return ISV_ERR_INVALID_ARG; }
+        if (!s.pre[j]) { err = "a window frame has no pre-integration (no IMU samples were fed)"; return ISV_ERR_INVALID_ARG; }
         s.wimu[j - 1] = s.pre[j]->pod;
     }
     s.wpp = s.pose_prior; s.wvb = s.vb_prior;
@@ -429,10 +433,39 @@ void after_solve(const isv_estimator *e, Sequence &s, double header) {
     s.pose_rows.push_back({s.Headers[0], s.Ps[0][0], s.Ps[0][1], s.Ps[0][2], q.w, q.x, q.y, q.z});
 }
 
+// run body(i) for i in [0, n) on min(8, cores) host threads (ISV_HOST_THREADS overrides), one per >= 8 items; the
+// sequences are independent of each other.  Returns the first non-zero status.
+template <class Body>
+int parallel_for(int n, std::vector<std::string> &errs, Body body) {
+    int K = 0;
+    if (const char *ev = getenv("ISV_HOST_THREADS")) K = atoi(ev);
+    if (K <= 0) { K = (int)std::thread::hardware_concurrency(); if (K > 8) K = 8; if (K > n / 8) K = n / 8; }
+    if (K > n) K = n;
+    if (K < 1) K = 1;
+    std::vector<int> rcs(K, ISV_OK);
+    errs.assign(K, std::string());
+    auto work = [&](int k) {
+        for (int i = (int)((int64_t)n * k / K), end = (int)((int64_t)n * (k + 1) / K); i < end; i++) {
+            const int rc = body(i, errs[k]);
+            if (rc != ISV_OK) { rcs[k] = rc; return; }
+        }
+    };
+    std::vector<std::thread> th;
+    for (int k = 1; k < K; k++) th.emplace_back(work, k);
+    work(0);
+    for (auto &t : th) t.join();
+    for (int k = 0; k < K; k++) if (rcs[k] != ISV_OK) { if (k) errs[0] = errs[k]; return rcs[k]; }
+    return ISV_OK;
+}
+
 int hip_triangulate(void *ctx, int32_t n, isv_window_t *const *w) { return isv_backend_triangulate((isv_backend_t *)ctx, n, w); }
 int hip_init(void *ctx, isv_window_t *w, isv_summary_t *s, double *kld) { return isv_backend_init_factor_graph((isv_backend_t *)ctx, w, s, kld); }
 int hip_optimize(void *ctx, int32_t n, isv_window_t *const *w, isv_summary_t *s, isv_marg_result_t *m) {
     return isv_backend_optimize_batch((isv_backend_t *)ctx, n, w, s, m);
+}
+
+int hip_solve_odometry(void *ctx, int32_t n, isv_window_t *const *w, isv_summary_t *s, isv_marg_result_t *m) {
+    return isv_backend_solve_odometry_batch((isv_backend_t *)ctx, n, w, s, m);
 }
 
 int create_common(const isv_estimator_params_t *p, int32_t n_sequences, isv_estimator **out) {
@@ -464,7 +497,7 @@ extern "C" int isv_estimator_create(const isv_estimator_params_t *p, int32_t n_s
     if (rc != ISV_OK) return rc;
     rc = isv_backend_create(&e->p.cfg, &e->backend);           // fails loudly without a GPU: there is no other solver
     if (rc != ISV_OK) { delete e; return rc; }
-    e->solver = isv_solver_vtbl_t{e->backend, hip_triangulate, hip_init, hip_optimize};
+    e->solver = isv_solver_vtbl_t{e->backend, hip_triangulate, hip_init, hip_optimize, hip_solve_odometry};
     *out = e;
     return ISV_OK;
 }
@@ -519,6 +552,22 @@ extern "C" int isv_estimator_process_imu(isv_estimator_t *e, int32_t seq, double
     return ISV_OK;
 }
 
+extern "C" int isv_estimator_process_imu_n(isv_estimator_t *e, int32_t seq, int32_t n, const double *dt, const double *acc, const double *gyr) {
+    SEQ_OR_FAIL(e, seq);
+    if (n < 0 || (n > 0 && (!dt || !acc || !gyr))) return ISV_ERR_INVALID_ARG;
+    for (int i = 0; i < n; i++) {
+        const int rc = isv_estimator_process_imu(e, seq, dt[i], acc + i * 3, gyr + i * 3);
+        if (rc != ISV_OK) return rc;
+    }
+    return ISV_OK;
+}
+
+extern "C" int isv_estimator_last_step_ms(const isv_estimator_t *e, double out[6]) {
+    if (!e || !out) return ISV_ERR_INVALID_ARG;
+    std::memcpy(out, e->step_ms, sizeof(e->step_ms));
+    return ISV_OK;
+}
+
 extern "C" int isv_estimator_push_image(isv_estimator_t *e, int32_t seq, double header, int32_t n, const int32_t *feature_id,
                                         const double *point) {
     SEQ_OR_FAIL(e, seq);
@@ -548,11 +597,17 @@ extern "C" int isv_estimator_set_bootstrap(isv_estimator_t *e, int32_t seq, cons
 // Estimator::processImage (src/estimator.cpp:126-215) on every staged sequence, the solves batched
 extern "C" int isv_estimator_step(isv_estimator_t *e) {
     if (!e) return ISV_ERR_INVALID_ARG;
-    std::vector<int> solve;
-    for (size_t si = 0; si < e->seq.size(); si++) {
+    using clk = std::chrono::steady_clock;
+    auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t0 = clk::now();
+    for (double &x : e->step_ms) x = 0;
+    std::vector<std::string> errs;
+    // per sequence: addFeatureAndCheckParallax, Headers, the INITIAL bookkeeping; mark[si] = 1 when the sequence solves
+    std::vector<char> mark(e->seq.size(), 0);
+    int rc = parallel_for((int)e->seq.size(), errs, [&](int si, std::string &err) {
         Sequence &s = e->seq[si];
-        if (!s.staged) continue;
-        if (s.flag == INITIAL && s.frame_count == s.N - 1 && !s.have_boot) { e->err = "the window is full: isv_estimator_set_bootstrap first"; return ISV_ERR_INVALID_ARG; }
+        if (!s.staged) return (int)ISV_OK;
+        if (s.flag == INITIAL && s.frame_count == s.N - 1 && !s.have_boot) { err = "the window is full: isv_estimator_set_bootstrap first"; return (int)ISV_ERR_INVALID_ARG; }
         s.margin_old = add_features(s, e->p.min_parallax);
         s.Headers[s.frame_count] = s.staged_header;
         s.staged = false;
@@ -560,46 +615,57 @@ extern "C" int isv_estimator_step(isv_estimator_t *e) {
             if (s.frame_count == s.N - 1) {
                 s.Ps = s.boot_P; s.Rs = s.boot_R; s.Vs = s.boot_V;       // in place of initialStructure()
                 s.flag = INITIAL_STRUCTURE;
-                solve.push_back((int)si);
+                mark[si] = 1;
             } else s.frame_count++;
-        } else solve.push_back((int)si);
-    }
+        } else mark[si] = 1;
+        return mark[si] ? build_window(e, s, err) : (int)ISV_OK;
+    });
+    if (rc != ISV_OK) { e->err = errs[0]; return rc; }
+    std::vector<int> solve;
+    for (size_t si = 0; si < e->seq.size(); si++) if (mark[si]) solve.push_back((int)si);
     if (solve.empty()) return 0;
     // solveOdometry (:461-472): f_manager.triangulate(Ps, tic, ric); backendOptimization()
     std::vector<isv_window_t *> ws(solve.size());
-    for (size_t k = 0; k < solve.size(); k++) {
-        Sequence &s = e->seq[solve[k]];
-        const int rc = build_window(e, s);
-        if (rc != ISV_OK) return rc;
-        ws[k] = &s.w;
-    }
-    int rc = e->solver.triangulate(e->solver.ctx, (int32_t)ws.size(), ws.data());
-    if (rc != ISV_OK) { e->err = "triangulate failed"; return rc; }
-    for (int si : solve) {
-        Sequence &s = e->seq[si];
-        for (size_t l = 0; l < s.good.size(); l++) s.tracks[s.good[l]].depth = s.wdepth[l];
-    }
-    // backendOptimization(), INITIAL_STRUCTURE branch (:1543-1548): vector2double, initFactorGraph, NON_LINEAR.  The
-    // NON_LINEAR branch below runs in the same call (two `if`s in the reference, not else-if).
-    for (int si : solve) {
-        Sequence &s = e->seq[si];
-        if (s.flag != INITIAL_STRUCTURE) continue;
-        isv_summary_t s0;
-        double kld = 0;
-        rc = e->solver.init_factor_graph(e->solver.ctx, &s.w, &s0, &kld);
-        if (rc != ISV_OK) { e->err = "initFactorGraph failed"; return rc; }
-        s.rollpitch.clear();
-        read_back(s);
-        s.flag = NON_LINEAR;
-        s.have_to_add = false;
-        rc = build_window(e, s);
-        if (rc != ISV_OK) return rc;
-    }
+    for (size_t k = 0; k < solve.size(); k++) ws[k] = &e->seq[solve[k]].w;
+    bool first_solve = false;
+    for (int si : solve) first_solve |= e->seq[si].flag == INITIAL_STRUCTURE;
     std::vector<isv_summary_t> sums(solve.size());
     std::vector<isv_marg_result_t> margs(solve.size());
-    rc = e->solver.optimize_batch(e->solver.ctx, (int32_t)ws.size(), ws.data(), sums.data(), margs.data());
-    if (rc != ISV_OK) { e->err = "backendOptimization failed"; return rc; }
-    for (size_t k = 0; k < solve.size(); k++) {
+    const auto t1 = clk::now();
+    auto t2 = t1, t3 = t1;
+    if (!first_solve && e->solver.solve_odometry_batch) {
+        rc = e->solver.solve_odometry_batch(e->solver.ctx, (int32_t)ws.size(), ws.data(), sums.data(), margs.data());
+        if (rc != ISV_OK) { e->err = "solveOdometry failed"; return rc; }
+    } else {
+        rc = e->solver.triangulate(e->solver.ctx, (int32_t)ws.size(), ws.data());
+        if (rc != ISV_OK) { e->err = "triangulate failed"; return rc; }
+        for (int si : solve) {
+            Sequence &s = e->seq[si];
+            for (size_t l = 0; l < s.good.size(); l++) s.tracks[s.good[l]].depth = s.wdepth[l];
+        }
+        t2 = clk::now();
+        // backendOptimization(), INITIAL_STRUCTURE branch (:1543-1548): vector2double, initFactorGraph, NON_LINEAR.  The
+        // NON_LINEAR branch below runs in the same call (two `if`s in the reference, not else-if).
+        for (int si : solve) {
+            Sequence &s = e->seq[si];
+            if (s.flag != INITIAL_STRUCTURE) continue;
+            isv_summary_t s0;
+            double kld = 0;
+            rc = e->solver.init_factor_graph(e->solver.ctx, &s.w, &s0, &kld);
+            if (rc != ISV_OK) { e->err = "initFactorGraph failed"; return rc; }
+            s.rollpitch.clear();
+            read_back(s);
+            s.flag = NON_LINEAR;
+            s.have_to_add = false;
+            rc = build_window(e, s, e->err);
+            if (rc != ISV_OK) return rc;
+        }
+        t3 = clk::now();
+        rc = e->solver.optimize_batch(e->solver.ctx, (int32_t)ws.size(), ws.data(), sums.data(), margs.data());
+        if (rc != ISV_OK) { e->err = "backendOptimization failed"; return rc; }
+    }
+    const auto t4 = clk::now();
+    (void)parallel_for((int)solve.size(), errs, [&](int k, std::string &) {
         Sequence &s = e->seq[solve[k]];
         read_back(s);
         const isv_marg_result_t &m = margs[k];
@@ -614,7 +680,11 @@ extern "C" int isv_estimator_step(isv_estimator_t *e) {
         s.n_solves++;
         s.n_good_last = (int)s.good.size();
         after_solve(e, s, s.Headers[s.N - 1]);
-    }
+        return (int)ISV_OK;
+    });
+    const auto t5 = clk::now();
+    e->step_ms[0] = ms(t0, t5); e->step_ms[1] = ms(t0, t1); e->step_ms[2] = ms(t1, t2); e->step_ms[3] = ms(t2, t3);
+    e->step_ms[4] = ms(t3, t4); e->step_ms[5] = ms(t4, t5);
     return (int)solve.size();
 }
 

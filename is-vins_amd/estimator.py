@@ -23,11 +23,12 @@ OPTIMIZE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, _wpp, C.POINTER(abi.is
 
 
 class isv_solver_vtbl_t(C.Structure):
-    _fields_ = [("ctx", C.c_void_p), ("triangulate", TRIANGULATE_FN), ("init_factor_graph", INIT_FN), ("optimize_batch", OPTIMIZE_FN)]
+    _fields_ = [("ctx", C.c_void_p), ("triangulate", TRIANGULATE_FN), ("init_factor_graph", INIT_FN), ("optimize_batch", OPTIMIZE_FN),
+                ("solve_odometry_batch", OPTIMIZE_FN)]
 
 
 EXPORTS = ["isv_estimator_create", "isv_estimator_create_with_solver", "isv_estimator_destroy", "isv_estimator_last_error",
-           "isv_estimator_process_imu", "isv_estimator_push_image", "isv_estimator_set_bootstrap", "isv_estimator_step",
+           "isv_estimator_process_imu", "isv_estimator_process_imu_n", "isv_estimator_last_step_ms", "isv_estimator_push_image", "isv_estimator_set_bootstrap", "isv_estimator_step",
            "isv_estimator_status", "isv_estimator_get_window", "isv_estimator_last_summary", "isv_estimator_trajectory"]
 
 _bound = False
@@ -43,6 +44,8 @@ def _bind(lib):
     lib.isv_estimator_destroy.argtypes = [vp]; lib.isv_estimator_destroy.restype = None
     lib.isv_estimator_last_error.argtypes = [vp]; lib.isv_estimator_last_error.restype = C.c_char_p
     lib.isv_estimator_process_imu.argtypes = [vp, C.c_int32, C.c_double, dp, dp]
+    lib.isv_estimator_process_imu_n.argtypes = [vp, C.c_int32, C.c_int32, dp, dp, dp]
+    lib.isv_estimator_last_step_ms.argtypes = [vp, dp]
     lib.isv_estimator_push_image.argtypes = [vp, C.c_int32, C.c_double, C.c_int32, ip, dp]
     lib.isv_estimator_set_bootstrap.argtypes = [vp, C.c_int32, dp, dp, dp]
     lib.isv_estimator_step.argtypes = [vp]
@@ -97,6 +100,15 @@ class SequenceEstimator:
     def process_imu(self, seq, dt, acc, gyr):
         a = np.ascontiguousarray(acc, float); g = np.ascontiguousarray(gyr, float)
         self._check(self.lib.isv_estimator_process_imu(self.h, seq, float(dt), abi._p(a), abi._p(g)), "process_imu")
+
+    def process_imu_n(self, seq, dts, accs, gyrs):
+        d = np.ascontiguousarray(dts, float); a = np.ascontiguousarray(accs, float).reshape(-1, 3); g = np.ascontiguousarray(gyrs, float).reshape(-1, 3)
+        self._check(self.lib.isv_estimator_process_imu_n(self.h, seq, len(d), abi._p(d), abi._p(a), abi._p(g)), "process_imu_n")
+
+    def last_step_ms(self):
+        out = np.zeros(6)
+        self._check(self.lib.isv_estimator_last_step_ms(self.h, abi._p(out)), "last_step_ms")
+        return dict(zip(("step", "features_and_packing", "triangulate", "init_factor_graph", "optimize", "readback_and_slide"), out))
 
     def push_image(self, seq, header, ids, points):
         ids = np.ascontiguousarray(ids, np.int32); pts = np.ascontiguousarray(points, float).reshape(-1, 3)

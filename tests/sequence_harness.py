@@ -433,7 +433,7 @@ def run_sequence(solver, lib, N, Nvo, n_frames, seed=0):
 
 
 # ---- the native window manager (include/isvins_estimator.h) driven by the same simulated streams ------------------
-def oracle_vtbl(oracle, cfg):
+def oracle_vtbl(oracle, cfg, fused=False):
     """isv_solver_vtbl_t whose three entry points are the CPU oracle: the test seam of isv_estimator_create_with_solver,
     so that the C++ host logic can be checked on a machine without a GPU"""
     from isvins_amd import estimator as E
@@ -454,6 +454,10 @@ def oracle_vtbl(oracle, cfg):
             if oracle.isvo_optimize(C.byref(cfg), ws[i], C.byref(sums[i]), C.byref(margs[i])) != 0:
                 return -1
         return 0
+    def solve_odometry(ctx, n, ws, sums, margs):
+        return tri(ctx, n, ws) or opt(ctx, n, ws, sums, margs)
+    if fused:
+        return E.isv_solver_vtbl_t(None, E.TRIANGULATE_FN(tri), E.INIT_FN(init), E.OPTIMIZE_FN(opt), E.OPTIMIZE_FN(solve_odometry))
     return E.isv_solver_vtbl_t(None, E.TRIANGULATE_FN(tri), E.INIT_FN(init), E.OPTIMIZE_FN(opt))
 
 

@@ -85,15 +85,17 @@ def _cmp_native_vs_harness(est, s, eo, tol):
     assert st["iterations"] == eo.summaries[-1].iterations
 
 
-def test_native_window_manager_matches_the_restatement(oracle):
+@pytest.mark.parametrize("fused", [False, True])
+def test_native_window_manager_matches_the_restatement(oracle, monkeypatch, fused):
     """include/isvins_estimator.h (C++: processIMU, pre-integration, addFeatureAndCheckParallax, slideWindow, prior
     rotation, removeBackShiftDepth / removeFront / removeFailures) against tests/sequence_harness.py on the same
     simulated streams, both with the CPU oracle as the solver (injected through isv_estimator_create_with_solver);
     two sequences in lock step.  Tolerance 1e-9: the two pre-integrations round differently in the last bits."""
     from isvins_amd import estimator as E
+    monkeypatch.setenv("ISV_HOST_THREADS", "2")            # the per-sequence host work on two threads
     N, Nvo, n_frames, seeds = 11, 5, 19, (0, 3)
     cfg = abi.make_config(N, Nvo, max_landmarks=600, max_obs=6600, max_batch=len(seeds))
-    vt = sh.oracle_vtbl(oracle, cfg)
+    vt = sh.oracle_vtbl(oracle, cfg, fused=fused)      # fused: the one-hand-over solveOdometry entry in steady state
     est = E.SequenceEstimator(sh.estimator_params(cfg), len(seeds), solver=vt)
     sh.run_sequences_native(est, N, n_frames, seeds)
     margin_flags = set()

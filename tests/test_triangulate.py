@@ -77,3 +77,28 @@ def test_gpu_triangulate_matches_oracle(oracle, n_frames, n_vo):
             assert np.abs(a / e - 1).max() < 1e-7, np.abs(a / e - 1).max()
     finally:
         b.close()
+
+
+@pytest.mark.gpu
+def test_gpu_solve_odometry_is_triangulate_then_optimize(oracle):
+    """isv_backend_solve_odometry_batch (one hand-over) against isv_backend_triangulate followed by
+    isv_backend_optimize_batch: the same bits; and against the oracle doing the two steps (src/estimator.cpp:461-472)"""
+    from isvins_amd import backend
+    backend.build()
+    ws = synth.make_windows(range(60, 66), n_landmarks=200)
+    for w in ws:
+        w.lm_depth[: w.L : 3] = -1.0                            # a third of the landmarks has no depth yet
+    be = backend.Backend(11, 5, max_landmarks=200, max_obs=max(w.n_obs for w in ws), max_batch=len(ws))
+    a = [w.clone() for w in ws]; b = [w.clone() for w in ws]
+    sa, ma = be.solve_odometry_batch(a)
+    be.triangulate(b); sb, mb = be.optimize_batch(b)
+    for x, y, s1, s2 in zip(a, b, sa, sb):
+        assert np.array_equal(x.state_vector(), y.state_vector()) and s1.final_cost == s2.final_cost and s1.iterations == s2.iterations
+        assert np.array_equal(x.lm_solve_flag[: x.L], y.lm_solve_flag[: y.L])
+    for i in (0, 5):
+        o = ws[i].clone(); s = abi.isv_summary_t(); mg = abi.isv_marg_result_t()
+        assert oracle.isvo_triangulate(C.byref(be.cfg), C.byref(o.c())) == 0
+        assert oracle.isvo_optimize(C.byref(be.cfg), C.byref(o.c()), C.byref(s), C.byref(mg)) == 0
+        assert sa[i].iterations == s.iterations and abs(sa[i].final_cost - s.final_cost) < 1e-8 * s.final_cost
+        assert np.abs(a[i].Ps - o.Ps).max() < 1e-7 and np.abs(a[i].Rs - o.Rs).max() < 1e-7
+    be.close()
