@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--vo", type=int, default=5)
     ap.add_argument("--landmarks", type=int, default=300)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-legs", action="store_true", help="skip the untimed host-buffer (PCIe-inclusive) legs; used for the rocprofv3 passes so that their kernel statistics hold the benchmark's own launches only")
     args = ap.parse_args()
 
     import numpy as np
@@ -118,7 +119,7 @@ def main():
     # PCIe-inclusive rate (never `value`): what a caller handing over HOST buffers sees, isv_batch_upload (host packing +
     # H2D) -> isv_batch_optimize -> isv_batch_download (D2H + unpack into the Estimator arrays)
     t_incl = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_host_legs:
         w2 = [w.clone() for w in windows]               # download() writes into the windows: use a second copy
         ptrs = be.marshal(w2)                           # ctypes marshalling is the Python harness's cost, not the C ABI's
         t1 = time.perf_counter()

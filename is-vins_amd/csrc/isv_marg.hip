@@ -82,27 +82,32 @@ DEV void w_chol_upper(const double *M, int n, double *U, double *L, int t) {
 // Jacobi eigen-decomposition with a round-robin (tournament) ordering: the floor(n/2) rotations of a
 // round touch disjoint index pairs, so they are computed and applied together (3 barriers per round
 // instead of 3 per rotation).  A (destroyed) = V diag(w) V^T.  rot: scratch [3 * 16] doubles + pairs.
-DEV void w_jacobi(double *A, int n, double *wv, double *V, double *tmp, int t) {
+template <int NC>                               // NC > 0: compile-time size (the round loops unroll, their LDS reads batch); NC = 0: runtime n
+DEV void w_jacobi_t(double *A, int n_rt, double *wv, double *V, double *tmp, int t) {
+    const int n = NC > 0 ? NC : n_rt;
     __shared__ double rc[32], rs[32];
     __shared__ int rp[32], rq[32];                 // floor(n / 2) concurrent rotations, n <= 64
     for (int e = t; e < n * n; e += MT) V[e] = (e / n == e % n) ? 1.0 : 0.0;
     SYNC();
     const int m = n + (n & 1), half = m / 2;
+    // lane t walks items t, t + 64, ...: the (row, column) split of an item index advances by a fixed step, so the
+    // runtime divisions are done once here and not in every round
+    const int bq = MT / half, br = MT % half, b_pa0 = t / half, b_pb0 = t % half;      // 2x2 blocks: e = pa * half + pb
+    const int vq = MT / n, vr = MT % n, v_pr0 = t / n, v_k0 = t % n;                   // eigenvector items: e = pr * n + k
     for (int sweep = 0; sweep < 30; sweep++) {
         double off = 0, dg = 0;
         for (int e = t; e < n * n; e += MT) { const int i = e / n, j = e % n; if (j > i) off += A[e] * A[e]; else if (i == j) dg += A[e] * A[e]; }
-        tmp[t] = off; tmp[64 + t] = dg;
-        SYNC();
-        for (int o = 32; o > 0; o >>= 1) { if (t < o) { tmp[t] += tmp[t + o]; tmp[64 + t] += tmp[64 + t + o]; } SYNC(); }
-        const double offs = tmp[0], dgs = tmp[64];
-        SYNC();
+        for (int o = 32; o > 0; o >>= 1) { off += __shfl_xor(off, o); dg += __shfl_xor(dg, o); }      // one wavefront: butterfly sums, every lane ends with the totals
+        const double offs = off, dgs = dg;
         // off-diagonal mass below 1e-14 relative (squared: 1e-28): eigenvalues converged to ~1e-28 relative, far
         // inside the 1e-6 parity tolerance; a tighter test never fires with Newton-refined rotations
         if (offs <= 1e-60 || offs <= 1e-28 * dgs) break;
         for (int r = 0; r < m - 1; r++) {
             if (t < half) {
-                int a = (t == 0) ? m - 1 : (r + t) % (m - 1);
-                int b = (t == 0) ? r : (r + m - 1 - t) % (m - 1);
+                int a = r + t, b = r + m - 1 - t;          // both < 2 (m - 1): one conditional subtraction is the modulo
+                if (a >= m - 1) a -= m - 1;
+                if (b >= m - 1) b -= m - 1;
+                if (t == 0) { a = m - 1; b = r; }
                 int p = a < b ? a : b, q = a < b ? b : a;
                 double c = 1.0, sn = 0.0;
                 if (q < n) {
@@ -115,29 +120,54 @@ DEV void w_jacobi(double *A, int n, double *wv, double *V, double *tmp, int t) {
                         const double tt = (theta >= 0 ? 1.0 : -1.0) * m_rcp(fabs(theta) + th2 * m_rsqrt(th2));
                         c = m_rsqrt(tt * tt + 1.0); sn = tt * c;
                     }
-                } else { p = 0; q = 0; }           // dummy pairing: identity rotation on (0,0) is skipped below
+                } else q = p;                      // odd n: this index sits out the round (identity), but its row and column still see the other rotations
                 rp[t] = p; rq[t] = q; rc[t] = c; rs[t] = sn;
             }
             SYNC();
-            for (int e = t; e < half * n; e += MT) {     // columns
-                const int pr = e / n, k = e % n, p = rp[pr], q = rq[pr];
-                if (p != q) { const double c = rc[pr], sn = rs[pr], akp = A[k * n + p], akq = A[k * n + q]; A[k * n + p] = c * akp - sn * akq; A[k * n + q] = sn * akp + c * akq; }
-            }
-            SYNC();
-            for (int e = t; e < half * n; e += MT) {     // rows, and the eigenvector columns
-                const int pr = e / n, k = e % n, p = rp[pr], q = rq[pr];
+            // A <- J^T A J in ONE pass: the 2x2 block (rows of pair a) x (columns of pair b) only sees the two
+            // rotations a and b, and the blocks of a round are disjoint.  V <- V J in the same pass.
+            auto block = [&](int pa, int pb) {
+                const int p1 = rp[pa], q1 = rq[pa], p2 = rp[pb], q2 = rq[pb];
+                const bool ra = p1 != q1, rb = p2 != q2;       // a dummy pair (odd n) holds one real index, identity rotation
+                if (!ra && !rb) return;
+                const double ca = rc[pa], sa = rs[pa], cb = rc[pb], sb = rs[pb];
+                const double b00 = A[p1 * n + p2], b01 = rb ? A[p1 * n + q2] : 0.0;
+                const double b10 = ra ? A[q1 * n + p2] : 0.0, b11 = (ra && rb) ? A[q1 * n + q2] : 0.0;
+                // columns first (as the two-pass form did), then rows
+                const double c00 = cb * b00 - sb * b01, c01 = sb * b00 + cb * b01;
+                const double c10 = cb * b10 - sb * b11, c11 = sb * b10 + cb * b11;
+                A[p1 * n + p2] = ca * c00 - sa * c10;
+                if (rb) A[p1 * n + q2] = ca * c01 - sa * c11;
+                if (ra) A[q1 * n + p2] = sa * c00 + ca * c10;
+                if (ra && rb) A[q1 * n + q2] = sa * c01 + ca * c11;
+            };
+            auto evec = [&](int pr, int k) {             // eigenvector columns
+                const int p = rp[pr], q = rq[pr];
                 if (p != q) {
-                    const double c = rc[pr], sn = rs[pr], apk = A[p * n + k], aqk = A[q * n + k];
-                    A[p * n + k] = c * apk - sn * aqk; A[q * n + k] = sn * apk + c * aqk;
+                    const double c = rc[pr], sn = rs[pr];
                     const double vkp = V[k * n + p], vkq = V[k * n + q];
                     V[k * n + p] = c * vkp - sn * vkq; V[k * n + q] = sn * vkp + c * vkq;
                 }
+            };
+            if constexpr (NC > 0) {                      // constant trip counts: unrolled, the LDS reads of all items issue together
+#pragma unroll
+                for (int e = t, pa = b_pa0, pb = b_pb0; e < half * half; e += MT, pa += bq, pb += br) { if (pb >= half) { pb -= half; pa++; } block(pa, pb); }
+#pragma unroll
+                for (int e = t, pr = v_pr0, k = v_k0; e < half * n; e += MT, pr += vq, k += vr) { if (k >= n) { k -= n; pr++; } evec(pr, k); }
+            } else {
+                for (int e = t, pa = b_pa0, pb = b_pb0; e < half * half; e += MT, pa += bq, pb += br) { if (pb >= half) { pb -= half; pa++; } block(pa, pb); }
+                for (int e = t, pr = v_pr0, k = v_k0; e < half * n; e += MT, pr += vq, k += vr) { if (k >= n) { k -= n; pr++; } evec(pr, k); }
             }
             SYNC();
         }
     }
     for (int i = t; i < n; i += MT) wv[i] = A[i * n + i];
     SYNC();
+}
+DEV void w_jacobi(double *A, int n, double *wv, double *V, double *tmp, int t) {
+    if (n == 21) w_jacobi_t<21>(A, n, wv, V, tmp, t);
+    else if (n == 6) w_jacobi_t<6>(A, n, wv, V, tmp, t);
+    else w_jacobi_t<0>(A, n, wv, V, tmp, t);
 }
 // log(det(A)) of a symmetric positive-definite matrix by unpivoted elimination (lane-parallel)
 DEV double w_logdet_spd(const double *A, int n, double *W, int t) {
@@ -626,9 +656,14 @@ __global__ __launch_bounds__(MT) void k_marg_bwd(DevBatch d) {
         SYNC();
         // restrict A to kept indices (rank x rank) in Wk+1000.. and evaluate trace / determinants
         double *Ak = Vv;                                  // (Vv was consumed by JUa above)
-        if (t == 0) {
-            int ia = 0;
-            for (int a = 0; a < 21; a++) if (keep[a]) { int ib = 0; for (int b = 0; b < 21; b++) if (keep[b]) { Ak[ia * rank + ib] = A[a * 21 + b]; ib++; } ia++; }
+        for (int e = t; e < 441; e += MT) {               // position of a kept index among the kept ones = kept indices before it
+            const int a = e / 21, b = e % 21;
+            if (keep[a] && keep[b]) {
+                int ia = 0, ib = 0;
+                for (int k = 0; k < a; k++) ia += keep[k];
+                for (int k = 0; k < b; k++) ib += keep[k];
+                Ak[ia * rank + ib] = A[e];
+            }
         }
         SYNC();
         const double ldA = w_logdet_spd(Ak, rank, JU, t);
