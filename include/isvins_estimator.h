@@ -60,6 +60,9 @@ int  isv_estimator_create_with_solver(const isv_estimator_params_t *p, int32_t n
 void isv_estimator_destroy(isv_estimator_t *e);
 const char *isv_estimator_last_error(const isv_estimator_t *e);
 
+/* Threading: a handle is driven by one thread, except that isv_estimator_process_imu(_n), _push_image and
+ * _set_bootstrap touch only their own sequence's state and may be called concurrently for DIFFERENT sequences
+ * (tools/isv_replay feeds the sequences of a group from several host threads).  Distinct handles are independent. */
 /* Estimator::processIMU(dt, linear_acceleration, angular_velocity)  src/estimator.cpp:91-124 */
 int  isv_estimator_process_imu(isv_estimator_t *e, int32_t seq, double dt, const double acc[3], const double gyr[3]);
 

@@ -94,7 +94,8 @@ struct PreIntegration {
         n2[0] = p.acc_n * p.acc_n; n2[1] = p.gyr_n * p.gyr_n; n2[2] = p.acc_w * p.acc_w; n2[3] = p.gyr_w * p.gyr_w;
     }
     // push_back -> propagate -> midPointIntegration (integration_base.h:31-158)
-    void push_back(double dt, const V3 &acc_1, const V3 &gyr_1) {
+    // (AVX2 clone picked at load time where the CPU has it; no FMA contraction, so both clones round identically)
+    __attribute__((target_clones("avx2", "default"))) void push_back(double dt, const V3 &acc_1, const V3 &gyr_1) {
         const V3 ba = {pod.linearized_ba[0], pod.linearized_ba[1], pod.linearized_ba[2]};
         const V3 bg = {pod.linearized_bg[0], pod.linearized_bg[1], pod.linearized_bg[2]};
         const Quat dq = {pod.delta_q[3], pod.delta_q[0], pod.delta_q[1], pod.delta_q[2]};
@@ -115,7 +116,7 @@ struct PreIntegration {
         for (int k = 0; k < 9; k++) ImW[k] = -Wx[k] * dt;
         ImW[0] += 1; ImW[4] += 1; ImW[8] += 1;
         const M3 RdA0 = mm(Rd, hat(a0)), RrA1 = mm(Rr, hat(a1)), RrA1W = mm(RrA1, ImW);
-        std::vector<double> F(225, 0.0), V(15 * 18, 0.0);
+        double F[225] = {0.0}, V[15 * 18] = {0.0};
         auto f = [&](int r, int c, int a, int b) -> double & { return F[(r + a) * 15 + c + b]; };
         auto v = [&](int r, int c, int a, int b) -> double & { return V[(r + a) * 18 + c + b]; };
         for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) {
@@ -147,19 +148,39 @@ struct PreIntegration {
             v(9, 12, a, b) = I * dt;
             v(12, 15, a, b) = I * dt;
         }
-        // jacobian = F jacobian;  covariance = F covariance F^T + V noise V^T
-        double Jn[225], FC[225], Cn[225];
-        for (int i = 0; i < 15; i++) for (int j = 0; j < 15; j++) {
-            double s = 0, c = 0;
-            for (int k = 0; k < 15; k++) { s += F[i * 15 + k] * pod.jacobian[k * 15 + j]; c += F[i * 15 + k] * pod.covariance[k * 15 + j]; }
-            Jn[i * 15 + j] = s; FC[i * 15 + j] = c;
-        }
+        // jacobian = F jacobian;  covariance = F covariance F^T + V noise V^T.  F and V are block-sparse: only the 3x3
+        // blocks listed per block row are non-zero (the others are exact zeros, which add nothing to a dense sum), so
+        // the sums run over those columns only, in ascending order like the dense products
+        static const int FN[5] = {5, 2, 4, 1, 1}, FC0[5][5] = {{0, 3, 6, 9, 12}, {3, 12, 0, 0, 0}, {3, 6, 9, 12, 0}, {9, 0, 0, 0, 0}, {12, 0, 0, 0, 0}};
+        static const int VN[5] = {4, 2, 4, 1, 1}, VC0[5][4] = {{0, 3, 6, 9}, {3, 9, 0, 0}, {0, 3, 6, 9}, {12, 0, 0, 0}, {15, 0, 0, 0}};
+        // (row-times-matrix "axpy" form: the inner loops run over a contiguous row and vectorise; every entry still
+        // accumulates its terms in ascending k)
+        double Jn[225] = {0.0}, FC[225] = {0.0}, Cn[225] = {0.0}, Ft[225], Vt[18 * 15];
+        for (int i = 0; i < 15; i++) for (int k = 0; k < 15; k++) Ft[k * 15 + i] = F[i * 15 + k];
+        for (int i = 0; i < 15; i++) for (int k = 0; k < 18; k++) Vt[k * 15 + i] = V[i * 18 + k];
         const double nd[6] = {n2[0], n2[1], n2[0], n2[1], n2[2], n2[3]};
-        for (int i = 0; i < 15; i++) for (int j = 0; j < 15; j++) {
-            double c = 0, q = 0;
-            for (int k = 0; k < 15; k++) c += FC[i * 15 + k] * F[j * 15 + k];
-            for (int k = 0; k < 18; k++) q += V[i * 18 + k] * nd[k / 3] * V[j * 18 + k];
-            Cn[i * 15 + j] = c + q;
+        for (int i = 0; i < 15; i++) {
+            const int rb = i / 3;
+            double *jn = &Jn[i * 15], *fc = &FC[i * 15], *cn = &Cn[i * 15];
+            for (int b = 0; b < FN[rb]; b++)
+                for (int k = FC0[rb][b]; k < FC0[rb][b] + 3; k++) {
+                    const double f = F[i * 15 + k];
+                    const double *jr = &pod.jacobian[k * 15], *cr = &pod.covariance[k * 15];
+                    for (int j = 0; j < 15; j++) { jn[j] += f * jr[j]; fc[j] += f * cr[j]; }
+                }
+            for (int k = 0; k < 15; k++) {
+                const double f = fc[k];
+                const double *fr = &Ft[k * 15];
+                for (int j = 0; j < 15; j++) cn[j] += f * fr[j];
+            }
+            double q[15] = {0.0};
+            for (int b = 0; b < VN[rb]; b++)
+                for (int k = VC0[rb][b]; k < VC0[rb][b] + 3; k++) {
+                    const double vn = V[i * 18 + k] * nd[k / 3];
+                    const double *vr = &Vt[k * 15];
+                    for (int j = 0; j < 15; j++) q[j] += vn * vr[j];
+                }
+            for (int j = 0; j < 15; j++) cn[j] += q[j];
         }
         std::memcpy(pod.jacobian, Jn, sizeof(Jn)); std::memcpy(pod.covariance, Cn, sizeof(Cn));
         const double nq = std::sqrt(rq.w * rq.w + rq.x * rq.x + rq.y * rq.y + rq.z * rq.z);      // delta_q.normalize()

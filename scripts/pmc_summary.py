@@ -23,7 +23,7 @@ with open(f"{out}/r01_pmc_summary.csv", "w") as f:
         f.write(f"{n},{max(len(fv), len(wv))},{sum(fv)/len(fv):.3f},{sum(wv)/len(wv):.3f},{max(fv):.3f},{max(wv):.3f}\n")
 traffic = {"windows_per_gpu": W,
            "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes of `python3 bench.py --steps 2 --warmup 1 "
-                   "--no-cpu-baseline`; counter unit KB; MEAN over the launches (later iterations run fewer windows, like the "
+                   "--no-cpu-baseline --no-host-legs`; counter unit KB; MEAN over the launches (later iterations run fewer windows, like the "
                    "bench's achieved figure); hbm_bytes_per_launch = (FETCH_SIZE + WRITE_SIZE) * 1024.  MI355X_MICROARCH.md: "
                    "FETCH_SIZE is exact-by-half only for 16-B/lane streaming reads; these kernels read 8 B/lane (f64 elements), "
                    "a width the guide calls uncalibrated, so no factor is applied; WRITE_SIZE is taken as is"}

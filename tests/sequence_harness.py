@@ -488,3 +488,32 @@ def run_sequences_native(est, N, n_frames, seeds):
             est.push_image(s, t, ids, pts)
         est.step()
     return sims
+
+
+def write_stream(path, N, Nvo, n_frames, seed=0, max_landmarks=800, num_iterations=10):
+    """the simulated stream of run_sequence(seed=...) in the text form tools/isv_replay reads (floats with 17
+    significant digits, so the replayed values are the simulator's bit for bit)"""
+    sim = Simulator(seed)
+    r = lambda v: " ".join(repr(float(x)) for x in np.asarray(v, float).ravel())
+    with open(path, "w") as f:
+        f.write("# isv-stream 1: simulated camera-IMU rig (tests/sequence_harness.Simulator), seed %d\n" % seed)
+        f.write("config %d %d %d %d %r %r %r %r %r %r %r %r %r\n" % (N, Nvo, max_landmarks, num_iterations, 460.0, 9.81007, 0.1, 5.0,
+                                                               ACC_N, GYR_N, ACC_W, GYR_W, MIN_PARALLAX))
+        f.write("ric %s\ntic %s\n" % (r(synth.RIC), r(synth.TIC)))
+        for i in range(n_frames):
+            if i > 0:
+                for (dt, a, g) in sim.imu_between(i):
+                    f.write("imu %r %s %s\n" % (float(dt), r(a), r(g)))
+            else:
+                f.write("imu %r %s %s\n" % (sim.frame_dt / sim.k, r(sim.traj.R(0).T @ (sim.traj.acc(0) + np.array([0, 0, 9.81007])) + sim.ba), r(sim.traj.gyro(0) + sim.bg)))
+            t, image = sim.frame(i)
+            if i == N - 1:
+                P, R, V = sim.truth_window(i, N)
+                nrng = np.random.default_rng(1000 + seed)
+                P = P + nrng.normal(0, 0.01, P.shape); V = V + nrng.normal(0, 0.02, V.shape)
+                f.write("boot\n")
+                for k in range(N):
+                    f.write("%s %s %s\n" % (r(P[k]), r(R[k]), r(V[k])))
+            f.write("frame %r %d\n" % (float(t), len(image)))
+            for fid in image:
+                f.write("%d %s\n" % (fid, r(image[fid])))

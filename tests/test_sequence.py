@@ -128,3 +128,33 @@ def test_native_sequences_on_gpu_vs_oracle(oracle, N, Nvo, n_frames, n_seq):
         assert ate < 1e-6 and rot < 1e-6
         assert est.status(s)["n_tracks"] == len(eo.tracks)
     est.close()
+
+
+@pytest.mark.gpu
+def test_replay_tool_writes_the_reference_trajectory_file(oracle, tmp_path):
+    """tools/isv_replay (native executable: stream file -> window manager -> MI355X -> pose_output_<s>.txt) on a
+    recorded simulated stream, 6 copies in 2 groups (two estimators on two host threads), against the Python
+    restatement with the oracle: the rows of pose_output.txt (6 decimals, src/System.cpp:408-409) agree to the last
+    printed digit (+-1e-6) and all copies are identical"""
+    import json, os, subprocess
+    from isvins_amd import backend
+    backend.build()
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "isv_replay")
+    N, Nvo, n_frames = 11, 5, 28
+    stream = tmp_path / "stream.txt"
+    sh.write_stream(stream, N, Nvo, n_frames, seed=2)
+    out = subprocess.run([tool, str(stream), "--sequences", "6", "--groups", "2", "--out", str(tmp_path), "--write", "6"],
+                         check=True, capture_output=True, text=True, timeout=300)
+    rep = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rep["sequences"] == 6 and rep["groups"] == 2 and rep["frames_in_stream"] == n_frames and rep["frames_per_second"] > 0
+    cfg = abi.make_config(N, Nvo, max_landmarks=800, max_obs=800 * N, max_batch=1)
+    eo, _ = sh.run_sequence(sh.OracleSolver(oracle, cfg), oracle, N, Nvo, n_frames, seed=2)
+    ref_path = tmp_path / "pose_output_oracle.txt"
+    eo.write_pose_output(ref_path)
+    ref = np.loadtxt(ref_path)
+    first = np.loadtxt(tmp_path / "pose_output_0.txt")
+    assert first.shape == ref.shape == (n_frames - (N - 1), 8)
+    assert np.abs(first - ref).max() <= 1.000001e-6
+    for s in range(1, 6):
+        assert np.array_equal(np.loadtxt(tmp_path / f"pose_output_{s}.txt"), first)
+    print("isv_replay:", rep)
