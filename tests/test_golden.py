@@ -56,3 +56,55 @@ def test_gpu_matches_golden(case):
         U = np.array(getattr(mg, name).sqrt_info).reshape(nn, nn); G = g[key]
         assert np.abs(U.T @ U - G.T @ G).max() < 1e-6 * np.abs(G.T @ G).max(), name
     be.close()
+
+
+# ---- whole-sequence fixture (tests/golden/make_sequence_golden.py) ------------------------------------------------
+import make_sequence_golden  # noqa: E402
+import sequence_harness as sh  # noqa: E402
+
+SEQ_CASES = list(make_sequence_golden.CASES)
+
+
+@pytest.mark.parametrize("case", SEQ_CASES)
+def test_restatement_reproduces_sequence_golden(case):
+    g = np.load(os.path.join(HERE, "golden", case + ".npz"))
+    _, d = make_sequence_golden.run(case)
+    assert np.array_equal(d["in_fingerprint"], g["in_fingerprint"]), "the simulator is not deterministic"
+    assert np.array_equal(d["margin_history"], g["margin_history"]) and np.array_equal(d["iterations"], g["iterations"])
+    assert np.array_equal(d["counters"], g["counters"])
+    for k in ("pose_output", "newest", "Ps", "Rs", "Vs", "Bas", "Bgs", "Headers"):
+        assert np.allclose(d[k], g[k], rtol=0, atol=1e-10), k
+
+
+def _native_vs_sequence_golden(case, solver, tol):
+    from isvins_amd import estimator as E
+    g = np.load(os.path.join(HERE, "golden", case + ".npz"))
+    kw = make_sequence_golden.CASES[case]
+    cfg = abi.make_config(kw["N"], kw["Nvo"], max_landmarks=800, max_obs=800 * kw["N"], max_batch=1)
+    est = E.SequenceEstimator(sh.estimator_params(cfg), 1, solver=solver(cfg) if solver else None)
+    sh.run_sequences_native(est, kw["N"], kw["n_frames"], (kw["seed"],))
+    assert np.abs(est.trajectory(0, 0) - g["pose_output"]).max() < tol
+    assert np.abs(est.trajectory(0, 1) - g["newest"]).max() < tol
+    w = est.window(0)
+    for k in ("Ps", "Rs", "Vs", "Bas", "Bgs"):
+        assert np.abs(w[k] - g[k]).max() < tol, k
+    assert np.array_equal(w["Headers"], g["Headers"])
+    st = est.status(0)
+    assert [st["frame_count"], st["n_tracks"], st["n_rollpitch"], st["margin_old"], st["iterations"]] == list(g["counters"])
+    est.close()
+
+
+@pytest.mark.parametrize("case", SEQ_CASES)
+def test_native_window_manager_matches_sequence_golden(case):
+    """include/isvins_estimator.h (C++) with the oracle injected as the solver, on the CPU"""
+    import oracle_lib
+    lib = oracle_lib.load()
+    _native_vs_sequence_golden(case, lambda cfg: sh.oracle_vtbl(lib, cfg), 1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", SEQ_CASES)
+def test_gpu_sequence_matches_golden(case):
+    """the native window manager with every solve on the MI355X: north_star's 1e-6 m on the trajectory"""
+    backend.build()
+    _native_vs_sequence_golden(case, None, 1e-6)
