@@ -25,7 +25,7 @@ __host__ __device__ inline int tvis_col(int a, int N) { return 36 * (a * N - a *
 // Jacobi diagonal and the gradient are folded in a fixed order (bitwise reproducible, no atomics).
 // Every strip is read exactly once.
 typedef double double4s __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(64 * ISV_SWEEP_WAVES) void k_sweep_mfma(DevBatch d) {
+__global__ __launch_bounds__(64 * ISV_SWEEP_WAVES, 8) void k_sweep_mfma(DevBatch d) {
     extern __shared__ __align__(16) double lds[];
     const int w = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const SolveState &st = d.st[w];
