@@ -23,7 +23,7 @@ __global__ void k_init_priors(DevBatch d, double *scratch, size_t per_window, do
 __global__ void k_imu_raw(DevBatch d, const double *pose_src, const double *sb_src, int gate);
 __global__ void k_imu_weight(DevBatch d, double *cost_out, int gate);
 __global__ void k_sweep_mfma(DevBatch d);
-template <int NT, int TPW> __global__ void k_rank1_mfma(DevBatch d);
+template <int NT, int TPW, int R1_CHUNK, int MINW> __global__ void k_rank1_mfma(DevBatch d);
 __global__ void k_marg_clear(DevBatch d);
 __global__ void k_marg_fwd(DevBatch d);
 __global__ void k_marg_bwd(DevBatch d);
@@ -488,9 +488,9 @@ int isv_solver_alloc(DevBatch &d, size_t B, size_t L, size_t F, std::vector<void
     TRYA(dal(&d.marg_scratch, L * 26, allocs, err));
     if (d.lds_T) {
 #define SETLDS(K, BYTES) HCHK(hipFuncSetAttribute((const void *)K, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES)))
-        SETLDS((k_rank1_mfma<1, 1>), lds_r1); SETLDS((k_rank1_mfma<2, 1>), lds_r1); SETLDS((k_rank1_mfma<3, 1>), lds_r1);
-        SETLDS((k_rank1_mfma<4, 1>), lds_r1); SETLDS((k_rank1_mfma<5, 1>), lds_r1); SETLDS((k_rank1_mfma<6, 2>), lds_r1);
-        SETLDS((k_rank1_mfma<7, 2>), lds_r1); SETLDS((k_rank1_mfma<8, 3>), lds_r1);
+        SETLDS((k_rank1_mfma<1, 1, 64, 1>), lds_r1); SETLDS((k_rank1_mfma<2, 1, 64, 1>), lds_r1); SETLDS((k_rank1_mfma<3, 1, 64, 1>), lds_r1);
+        SETLDS((k_rank1_mfma<4, 1, 64, 1>), lds_r1); SETLDS((k_rank1_mfma<5, 1, 64, 1>), lds_r1); SETLDS((k_rank1_mfma<6, 2, 64, 1>), lds_r1);
+        SETLDS((k_rank1_mfma<7, 2, 64, 1>), lds_r1); SETLDS((k_rank1_mfma<8, 3, 64, 1>), lds_r1);
         SETLDS(k_sweep_mfma, lds_sw);
         if (d.N <= 11) SETLDS(k_build_solve_sb<false>, lds_sb); else SETLDS(k_build_solve_sb<true>, lds_sb);
 #undef SETLDS
@@ -533,14 +533,14 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
             const size_t lds_r1 = (64 * (d.wd_ld + 4) + (size_t)d.max_lm * 3 + 2) * sizeof(double);
             PROF(slot, 2, 0);
             switch (nt) {
-            case 1: hipLaunchKernelGGL((k_rank1_mfma<1, 1>), dim3(d.B), dim3(64 * 1), lds_r1, st, d); break;
-            case 2: hipLaunchKernelGGL((k_rank1_mfma<2, 1>), dim3(d.B), dim3(64 * 3), lds_r1, st, d); break;
-            case 3: hipLaunchKernelGGL((k_rank1_mfma<3, 1>), dim3(d.B), dim3(64 * 6), lds_r1, st, d); break;
-            case 4: hipLaunchKernelGGL((k_rank1_mfma<4, 1>), dim3(d.B), dim3(64 * 10), lds_r1, st, d); break;
-            case 5: hipLaunchKernelGGL((k_rank1_mfma<5, 1>), dim3(d.B), dim3(64 * 15), lds_r1, st, d); break;
-            case 6: hipLaunchKernelGGL((k_rank1_mfma<6, 2>), dim3(d.B), dim3(64 * 11), lds_r1, st, d); break;
-            case 7: hipLaunchKernelGGL((k_rank1_mfma<7, 2>), dim3(d.B), dim3(64 * 14), lds_r1, st, d); break;
-            default: hipLaunchKernelGGL((k_rank1_mfma<8, 3>), dim3(d.B), dim3(64 * 12), lds_r1, st, d); break;
+            case 1: hipLaunchKernelGGL((k_rank1_mfma<1, 1, 64, 1>), dim3(d.B), dim3(64 * 1), lds_r1, st, d); break;
+            case 2: hipLaunchKernelGGL((k_rank1_mfma<2, 1, 64, 1>), dim3(d.B), dim3(64 * 3), lds_r1, st, d); break;
+            case 3: hipLaunchKernelGGL((k_rank1_mfma<3, 1, 64, 1>), dim3(d.B), dim3(64 * 6), lds_r1, st, d); break;
+            case 4: hipLaunchKernelGGL((k_rank1_mfma<4, 1, 64, 1>), dim3(d.B), dim3(64 * 10), lds_r1, st, d); break;
+            case 5: hipLaunchKernelGGL((k_rank1_mfma<5, 1, 64, 1>), dim3(d.B), dim3(64 * 15), lds_r1, st, d); break;
+            case 6: hipLaunchKernelGGL((k_rank1_mfma<6, 2, 64, 1>), dim3(d.B), dim3(64 * 11), lds_r1, st, d); break;
+            case 7: hipLaunchKernelGGL((k_rank1_mfma<7, 2, 64, 1>), dim3(d.B), dim3(64 * 14), lds_r1, st, d); break;
+            default: hipLaunchKernelGGL((k_rank1_mfma<8, 3, 64, 1>), dim3(d.B), dim3(64 * 12), lds_r1, st, d); break;
             }
             PROF(slot, 2, 1);
         }

@@ -127,11 +127,14 @@ __global__ __launch_bounds__(64 * ISV_SWEEP_WAVES, 8) void k_sweep_mfma(DevBatch
 // the reduced right-hand side.  The packed w vectors (HBM) are expanded to panel rows in LDS, 64 landmarks
 // per pass; the loads of the next pass are in flight while the current one is multiplied.
 typedef double double4v __attribute__((ext_vector_type(4)));
-#define R1_CHUNK 64                       // landmarks staged per pass (64 x wd_ld doubles of LDS)
+// R1_CHUNK = landmarks staged per pass (R1_CHUNK x wd_ld doubles of LDS)
 // NT = panel width / 16, TPW = output tiles per wavefront (compile time: cheap index arithmetic, right-sized
 // prefetch registers; TPW > 1 keeps the workgroup within 1024 threads for long windows)
-template <int NT, int TPW>
-__global__ __launch_bounds__(64 * ((NT * (NT + 1) / 2 + TPW - 1) / TPW)) void k_rank1_mfma(DevBatch d) {
+// R1_CHUNK / MINW: pass size and minimum waves per SIMD.  Variants with fewer, fatter wavefronts and four workgroups per
+// CU (<5, 4, 32, 4>, <5, 2, 32, 8>: a 1024-window launch in one round) measured 138 / 143 us against 96-100 us for one
+// wavefront per tile: the per-workgroup MFMA chain gets longer than the round it saves.
+template <int NT, int TPW, int R1_CHUNK, int MINW>
+__global__ __launch_bounds__(64 * ((NT * (NT + 1) / 2 + TPW - 1) / TPW), MINW) void k_rank1_mfma(DevBatch d) {
     constexpr int ntiles = NT * (NT + 1) / 2, nwaves = (ntiles + TPW - 1) / TPW;
     constexpr int ld = 16 * NT, nthr = 64 * nwaves;
     constexpr int R1_PF = (R1_CHUNK * ld + nthr - 1) / nthr;   // panel elements per thread and pass
@@ -216,12 +219,12 @@ __global__ __launch_bounds__(64 * ((NT * (NT + 1) / 2 + TPW - 1) / TPW)) void k_
         }
     }
 }
-template __global__ void k_rank1_mfma<1, 1>(DevBatch);
-template __global__ void k_rank1_mfma<2, 1>(DevBatch);
-template __global__ void k_rank1_mfma<3, 1>(DevBatch);
-template __global__ void k_rank1_mfma<4, 1>(DevBatch);
-template __global__ void k_rank1_mfma<5, 1>(DevBatch);
-template __global__ void k_rank1_mfma<6, 2>(DevBatch);
-template __global__ void k_rank1_mfma<7, 2>(DevBatch);
-template __global__ void k_rank1_mfma<8, 3>(DevBatch);
+template __global__ void k_rank1_mfma<1, 1, 64, 1>(DevBatch);
+template __global__ void k_rank1_mfma<2, 1, 64, 1>(DevBatch);
+template __global__ void k_rank1_mfma<3, 1, 64, 1>(DevBatch);
+template __global__ void k_rank1_mfma<4, 1, 64, 1>(DevBatch);
+template __global__ void k_rank1_mfma<5, 1, 64, 1>(DevBatch);
+template __global__ void k_rank1_mfma<6, 2, 64, 1>(DevBatch);
+template __global__ void k_rank1_mfma<7, 2, 64, 1>(DevBatch);
+template __global__ void k_rank1_mfma<8, 3, 64, 1>(DevBatch);
 
