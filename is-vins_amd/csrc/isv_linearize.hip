@@ -639,7 +639,12 @@ __global__ __launch_bounds__(256) void k_imu_raw(DevBatch d, const double *pose_
 
 typedef double double4i __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(64) void k_imu_weight(DevBatch d, double *cost_out, int gate) {
-    __shared__ __align__(16) double sS[16 * 17], sRaw[16 * 32], sJw[16 * 32], sH[ISV_IMU_H + 1];
+    // 6.3 KB of LDS (it was 14.3): S (16x17) and one 16x32 buffer that holds raw, then Jw = S raw; the packed J^T J
+    // overlays both once Jw has been consumed.  The launch is one single-wavefront workgroup per IMU factor, so the
+    // LDS footprint sets how many of them share a CU, i.e. how many rounds the 10 (N-1) x B workgroups take.
+    static_assert(ISV_IMU_H + 1 <= 16 * 17 + 16 * 32, "the packed J^T J must fit the staging buffers it overlays");
+    __shared__ __align__(16) double sA[16 * 17 + 16 * 32];
+    double *sS = sA, *sRaw = sA + 16 * 17, *sJw = sRaw, *sH = sA;
     const int f = blockIdx.x, t = threadIdx.x;
     const int N = d.N, w = f / (N - 1);
     if (gate) {
@@ -660,6 +665,7 @@ __global__ __launch_bounds__(64) void k_imu_weight(DevBatch d, double *cost_out,
         a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b0, a0, 0, 0, 0);
         a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b1, a1, 0, 0, 0);
     }
+    __syncthreads();                                        // raw has been read by every lane: Jw takes its place
 #pragma unroll
     for (int reg = 0; reg < 4; reg++) {                     // C/D layout: col = lane & 15, row = (lane >> 4) + 4 reg
         const int row = kq + 4 * reg;
@@ -675,20 +681,9 @@ __global__ __launch_bounds__(64) void k_imu_weight(DevBatch d, double *cost_out,
         h10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x0, h10, 0, 0, 0);
         h11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, h11, 0, 0, 0);
     }
-    // packed J^T J (pairs a >= b at a(a+1)/2 + b, a, b < 30) then J^T r (row 30 of H)
-#pragma unroll
-    for (int reg = 0; reg < 4; reg++) {
-        const int row = kq + 4 * reg;
-        { const int a = row, b = i; if (b <= a) sH[a * (a + 1) / 2 + b] = h00[reg]; }
-        { const int a = 16 + row, b = i; if (a < 30) sH[a * (a + 1) / 2 + b] = h10[reg]; else if (a == 30) sH[465 + b] = h10[reg]; }
-        { const int a = 16 + row, b = 16 + i; if (a < 30) { if (b <= a) sH[a * (a + 1) / 2 + b] = h11[reg]; } else if (a == 30 && b < 30) sH[465 + b] = h11[reg]; }
-    }
-    __syncthreads();
-    double *H = d.imu_H + (size_t)f * ISV_IMU_H;
-    for (int e = t; e < ISV_IMU_H; e += 64) H[e] = sH[e];
     // strip layout: [r15 | 15x6 | 15x9 | 15x6 | 15x9] row-major blocks.  The LDS solver path works from the J^T J
     // blocks alone (k_build_solve_sb, k_dogleg), so the strips are only written for the linearise API (gate 0)
-    // and for the generic path
+    // and for the generic path.  (Jw is read here, before J^T J overwrites it.)
     double *out = d.imu_strip + (size_t)f * ISV_IMU_STRIP;
     const bool want_strip = gate == 0 || !d.lds_T;
     if (want_strip && t < 15) out[t] = sJw[t * 32 + 30];
@@ -705,6 +700,18 @@ __global__ __launch_bounds__(64) void k_imu_weight(DevBatch d, double *cost_out,
         for (int k = 0; k < 15; k++) s += sJw[k * 32 + 30] * sJw[k * 32 + 30];
         cost_out[f] = 0.5 * s;                              // no loss function on IMU factors (:1050)
     }
+    __syncthreads();
+    // packed J^T J (pairs a >= b at a(a+1)/2 + b, a, b < 30) then J^T r (row 30 of H)
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) {
+        const int row = kq + 4 * reg;
+        { const int a = row, b = i; if (b <= a) sH[a * (a + 1) / 2 + b] = h00[reg]; }
+        { const int a = 16 + row, b = i; if (a < 30) sH[a * (a + 1) / 2 + b] = h10[reg]; else if (a == 30) sH[465 + b] = h10[reg]; }
+        { const int a = 16 + row, b = 16 + i; if (a < 30) { if (b <= a) sH[a * (a + 1) / 2 + b] = h11[reg]; } else if (a == 30 && b < 30) sH[465 + b] = h11[reg]; }
+    }
+    __syncthreads();
+    double *H = d.imu_H + (size_t)f * ISV_IMU_H;
+    for (int e = t; e < ISV_IMU_H; e += 64) H[e] = sH[e];
 }
 
 
