@@ -216,3 +216,19 @@ def test_ragged_batch_with_edge_cases_matches_oracle(oracle, be):
     flags = np.concatenate([g.lm_solve_flag[: g.L] for g in gs])
     assert set(np.unique(flags)) <= {1, 2}
     print("solve_flag==2 landmarks per window:", [int((g.lm_solve_flag[: g.L] == 2).sum()) for g in gs])
+
+
+@pytest.mark.parametrize("n_frames,n_vo,n_lm", [(3, 2, 25), (5, 2, 60), (11, 10, 200), (11, 5, 1000)])
+def test_extreme_shapes_match_oracle(oracle, n_frames, n_vo, n_lm):
+    """the smallest window the ABI accepts (3 frames, Vo = 2), Vo at both ends of its range, and the reference's
+    landmark capacity NUM_OF_F = 1000 (include/parameters.h:40) in one window"""
+    w = synth.make_window(70 + n_frames + n_lm, n_frames=n_frames, n_vo=n_vo, n_landmarks=n_lm)
+    backend.build()
+    b = backend.Backend(n_frames, n_vo, max_landmarks=n_lm, max_obs=w.n_obs, max_batch=1)
+    try:
+        o, so, mo = oracle_run(oracle, b.cfg, w)
+        g = w.clone(); sg, mg = b.optimize(g)
+        check_window(o, so, g, sg)
+        assert mg.valid == mo.valid and mg.n_marg_landmarks == mo.n_marg_landmarks
+    finally:
+        b.close()
