@@ -10,7 +10,7 @@
 #include <cstdlib>
 #include <string>
 #include <thread>
-#include <unordered_map>
+#include <cstdint>
 #include <vector>
 #include "../../include/isvins_estimator.h"
 
@@ -191,13 +191,16 @@ struct PreIntegration {
     }
 };
 
-// IDFeatures (include/feature_tracker/feature_manager.h:44-63)
+// IDFeatures (include/feature_tracker/feature_manager.h:44-63).  The per-frame points (Feature::point of frames
+// start_frame, start_frame + 1, ...) live in the sequence's pool: slot `slot` is a ring of POINT_RING entries that
+// starts at `off` -- dropping the oldest observation is off++, and a track record stays 32 bytes, cheap to compact.
+constexpr int POINT_RING = 32;             // >= the longest window (ISV_MAX_FRAMES)
 struct Track {
     int id, start_frame;
-    std::vector<V3> points;        // Feature::point of frames start_frame, start_frame + 1, ...
-    double depth = -1.0;           // estimated_depth
+    int slot, off, n;              // ring slot in Sequence::pool, first element, number of observations
     int solve_flag = 0;
-    int end_frame() const { return start_frame + (int)points.size() - 1; }
+    double depth = -1.0;           // estimated_depth
+    int end_frame() const { return start_frame + n - 1; }
 };
 
 enum Flag { INITIAL = 0, NON_LINEAR = 1, INITIAL_STRUCTURE = 2 };
@@ -214,6 +217,29 @@ struct Sequence {
     V3 acc_0{}, gyr_0{};
     Flag flag = INITIAL;
     std::vector<Track> tracks;                 // f_manager.IDsfeatures, insertion order
+    std::vector<V3> pool;                      // POINT_RING points per slot
+    std::vector<int> free_slots;
+    std::vector<int> hkey, hval;               // scratch: open-addressing id -> track index of addFeatureAndCheckParallax
+    const V3 &pt(const Track &t, int i) const { return pool[(size_t)t.slot * POINT_RING + ((t.off + i) & (POINT_RING - 1))]; }
+    V3 &pt(const Track &t, int i) { return pool[(size_t)t.slot * POINT_RING + ((t.off + i) & (POINT_RING - 1))]; }
+    int new_slot() {
+        if (!free_slots.empty()) { const int k = free_slots.back(); free_slots.pop_back(); return k; }
+        const int k = (int)(pool.size() / POINT_RING);
+        pool.resize(pool.size() + POINT_RING);
+        return k;
+    }
+    void push_point(Track &t, const V3 &v) { pt(t, t.n) = v; t.n++; }
+    void pop_front(Track &t) { t.off = (t.off + 1) & (POINT_RING - 1); t.n--; }
+    void erase_point(Track &t, int i) { for (int k = i; k + 1 < t.n; k++) pt(t, k) = pt(t, k + 1); t.n--; }
+    // keep the tracks for which keep(t) is true, in order; the others give their slot back
+    template <class Pred> void compact(Pred keep) {
+        size_t o = 0;
+        for (size_t i = 0; i < tracks.size(); i++) {
+            if (keep(tracks[i])) { if (o != i) tracks[o] = tracks[i]; o++; }
+            else free_slots.push_back(tracks[i].slot);
+        }
+        tracks.resize(o);
+    }
     isv_se3_prior_t pose_prior{};
     isv_linear9_t vb_prior{};
     std::vector<isv_relpose_t> relpose;        // edge (i, i + 1) = vioRelativePoseEdges[i + 1]
@@ -267,19 +293,24 @@ M3 delta_q_matrix(const V3 &theta) { return qmat(Quat{1.0, theta[0] / 2, theta[1
 // FeatureManager::addFeatureAndCheckParallax (feature_manager.cpp:52-101) + compensatedParallax2 (:356-390)
 bool add_features(Sequence &s, double min_parallax) {
     const int fc = s.frame_count;
-    std::unordered_map<int, size_t> by_id;
-    by_id.reserve(s.tracks.size() * 2 + s.staged_image.size());
-    for (size_t i = 0; i < s.tracks.size(); i++) by_id.emplace(s.tracks[i].id, i);
+    // id -> track index: a flat open-addressing table rebuilt per frame (the reference does a linear find_if per feature)
+    size_t cap = 64;
+    while (cap < 2 * (s.tracks.size() + s.staged_image.size()) + 8) cap <<= 1;
+    s.hkey.assign(cap, 0); s.hval.assign(cap, -1);
+    auto slot_of = [&](int id) { size_t h = ((uint32_t)id * 2654435761u) & (cap - 1); while (s.hval[h] >= 0 && s.hkey[h] != id) h = (h + 1) & (cap - 1); return h; };
+    for (size_t i = 0; i < s.tracks.size(); i++) { const size_t h = slot_of(s.tracks[i].id); s.hkey[h] = s.tracks[i].id; s.hval[h] = (int)i; }
     std::sort(s.staged_image.begin(), s.staged_image.end(), [](const std::pair<int, V3> &a, const std::pair<int, V3> &b) { return a.first < b.first; });
     int last_track_num = 0;
     for (const auto &ob : s.staged_image) {
-        auto it = by_id.find(ob.first);
-        if (it == by_id.end()) {
-            Track t; t.id = ob.first; t.start_frame = fc; t.points.push_back(ob.second);
-            by_id.emplace(ob.first, s.tracks.size());
-            s.tracks.push_back(std::move(t));
+        const size_t h = slot_of(ob.first);
+        if (s.hval[h] < 0) {
+            Track t; t.id = ob.first; t.start_frame = fc; t.slot = s.new_slot(); t.off = 0; t.n = 0;
+            s.push_point(t, ob.second);
+            s.hkey[h] = ob.first; s.hval[h] = (int)s.tracks.size();
+            s.tracks.push_back(t);
         } else {
-            s.tracks[it->second].points.push_back(ob.second);
+            Track &t = s.tracks[s.hval[h]];
+            if (t.n < POINT_RING) s.push_point(t, ob.second);      // (a second observation of an id in one image would overflow a window-long track)
             last_track_num++;
         }
     }
@@ -288,7 +319,7 @@ bool add_features(Sequence &s, double min_parallax) {
     int parallax_num = 0;
     for (const Track &t : s.tracks) {
         if (t.start_frame <= fc - 2 && t.end_frame() >= fc - 1) {
-            const V3 &pi = t.points[fc - 2 - t.start_frame], &pj = t.points[fc - 1 - t.start_frame];
+            const V3 &pi = s.pt(t, fc - 2 - t.start_frame), &pj = s.pt(t, fc - 1 - t.start_frame);
             const double du = pi[0] / pi[2] - pj[0], dv = pi[1] / pi[2] - pj[1];
             parallax_sum += std::max(0.0, std::sqrt(du * du + dv * dv));
             parallax_num++;
@@ -304,7 +335,7 @@ int build_window(const isv_estimator *e, Sequence &s, std::string &err) {
     s.good.clear();
     size_t n_obs = 0;
     for (size_t i = 0; i < s.tracks.size(); i++)            // goodFeature(): used_num >= 2 && start_frame < Vo_SIZE
-        if (s.tracks[i].points.size() >= 2 && s.tracks[i].start_frame < Nvo) { s.good.push_back((int)i); n_obs += s.tracks[i].points.size(); }
+        if (s.tracks[i].n >= 2 && s.tracks[i].start_frame < Nvo) { s.good.push_back((int)i); n_obs += (size_t)s.tracks[i].n; }
     const size_t L = s.good.size();
     if ((int)L > e->p.cfg.max_landmarks || (int)n_obs > e->p.cfg.max_obs) { err = "window exceeds the landmark / observation capacity"; return ISV_ERR_CAPACITY; }
     if ((int)s.rollpitch.size() > e->p.cfg.max_rollpitch) { err = "more roll/pitch factors than max_rollpitch"; return ISV_ERR_CAPACITY; }
@@ -314,13 +345,14 @@ int build_window(const isv_estimator *e, Sequence &s, std::string &err) {
         std::memcpy(&s.wBas[i * 3], s.Bas[i].data(), 24); std::memcpy(&s.wBgs[i * 3], s.Bgs[i].data(), 24);
     }
     std::memcpy(s.wtic, e->p.tic, 24); std::memcpy(s.wric, e->p.ric, 72);
-    s.wstart.assign(std::max<size_t>(L, 1), 0); s.wptr.assign(L + 1, 0); s.wflag.assign(std::max<size_t>(L, 1), 0);
-    s.wobs.assign(std::max<size_t>(n_obs, 1) * 3, 0.0); s.wdepth.assign(std::max<size_t>(L, 1), 0.0); s.wfeat.assign(std::max<size_t>(L, 1), 0.0);
+    s.wstart.resize(std::max<size_t>(L, 1)); s.wptr.resize(L + 1); s.wflag.assign(std::max<size_t>(L, 1), 0);
+    s.wobs.resize(std::max<size_t>(n_obs, 1) * 3); s.wdepth.resize(std::max<size_t>(L, 1)); s.wfeat.resize(std::max<size_t>(L, 1));
+    s.wptr[0] = 0;
     size_t o = 0;
     for (size_t l = 0; l < L; l++) {
         const Track &t = s.tracks[s.good[l]];
         s.wstart[l] = t.start_frame; s.wdepth[l] = t.depth;
-        for (const V3 &pt : t.points) { std::memcpy(&s.wobs[o * 3], pt.data(), 24); o++; }
+        for (int k = 0; k < t.n; k++) { std::memcpy(&s.wobs[o * 3], s.pt(t, k).data(), 24); o++; }
         s.wptr[l + 1] = (int32_t)o;
     }
     s.wimu.resize(N - 1);
@@ -394,31 +426,28 @@ void slide_window(const isv_estimator *e, Sequence &s) {
             s.add_vb.index = Nvo - 1; s.vb_prior = s.add_vb;
             s.have_to_add = false;
         }
-        std::vector<Track> keep;
-        keep.reserve(s.tracks.size());
         if (shift_depth) {                             // slideWindowOld -> removeBackShiftDepth  feature_manager.cpp:275-313
             const M3 ric = {e->p.ric[0], e->p.ric[1], e->p.ric[2], e->p.ric[3], e->p.ric[4], e->p.ric[5], e->p.ric[6], e->p.ric[7], e->p.ric[8]};
             const V3 tic = {e->p.tic[0], e->p.tic[1], e->p.tic[2]};
             const M3 R0 = mm(back_R0, ric), R1 = mm(s.Rs[0], ric);
             const V3 P0 = add(back_P0, mv(back_R0, tic)), P1 = add(s.Ps[0], mv(s.Rs[0], tic));
-            for (Track &t : s.tracks) {
-                if (t.start_frame != 0) { t.start_frame--; keep.push_back(std::move(t)); continue; }
-                const V3 uv = t.points.front();
-                t.points.erase(t.points.begin());
-                if (t.points.size() < 2) continue;
+            s.compact([&](Track &t) {
+                if (t.start_frame != 0) { t.start_frame--; return true; }
+                const V3 uv = s.pt(t, 0);
+                s.pop_front(t);
+                if (t.n < 2) return false;
                 const V3 w_pt = add(mv(R0, mul(uv, t.depth)), P0);
                 const V3 pj = mtv(R1, sub(w_pt, P1));
                 t.depth = pj[2] > 0 ? pj[2] : e->p.cfg.init_depth;
-                keep.push_back(std::move(t));
-            }
+                return true;
+            });
         } else {                                       // removeBack  :315-332
-            for (Track &t : s.tracks) {
-                if (t.start_frame != 0) { t.start_frame--; keep.push_back(std::move(t)); continue; }
-                t.points.erase(t.points.begin());
-                if (!t.points.empty()) keep.push_back(std::move(t));
-            }
+            s.compact([&](Track &t) {
+                if (t.start_frame != 0) { t.start_frame--; return true; }
+                s.pop_front(t);
+                return t.n > 0;
+            });
         }
-        s.tracks.swap(keep);
     } else {
         const int fc = s.frame_count;
         if (fc != N - 1) return;
@@ -430,21 +459,18 @@ void slide_window(const isv_estimator *e, Sequence &s) {
         s.Ps[fc - 1] = s.Ps[fc]; s.Rs[fc - 1] = s.Rs[fc]; s.Vs[fc - 1] = s.Vs[fc]; s.Bas[fc - 1] = s.Bas[fc]; s.Bgs[fc - 1] = s.Bgs[fc];
         new_preintegration(e, s, N - 1);
         s.bufs[N - 1].clear();
-        std::vector<Track> keep;                       // slideWindowNew -> removeFront  :335-354
-        keep.reserve(s.tracks.size());
-        for (Track &t : s.tracks) {
-            if (t.start_frame == fc) { t.start_frame--; keep.push_back(std::move(t)); continue; }
-            if (t.end_frame() < fc - 1) { keep.push_back(std::move(t)); continue; }
-            t.points.erase(t.points.begin() + (N - 1 - 1 - t.start_frame));
-            if (!t.points.empty()) keep.push_back(std::move(t));
-        }
-        s.tracks.swap(keep);
+        s.compact([&](Track &t) {                      // slideWindowNew -> removeFront  :335-354
+            if (t.start_frame == fc) { t.start_frame--; return true; }
+            if (t.end_frame() < fc - 1) return true;
+            s.erase_point(t, N - 1 - 1 - t.start_frame);
+            return t.n > 0;
+        });
     }
 }
 
 void after_solve(const isv_estimator *e, Sequence &s, double header) {
     slide_window(e, s);
-    s.tracks.erase(std::remove_if(s.tracks.begin(), s.tracks.end(), [](const Track &t) { return t.solve_flag == 2; }), s.tracks.end());      // removeFailures
+    s.compact([](Track &t) { return t.solve_flag != 2; });      // removeFailures
     const int N = s.N;
     std::array<double, 13> nr;
     nr[0] = header;
@@ -492,7 +518,7 @@ int hip_solve_odometry(void *ctx, int32_t n, isv_window_t *const *w, isv_summary
 int create_common(const isv_estimator_params_t *p, int32_t n_sequences, isv_estimator **out) {
     if (!p || !out || n_sequences < 1) return ISV_ERR_INVALID_ARG;
     const int N = p->cfg.n_frames, Nvo = p->cfg.n_vo;
-    if (N < 3 || Nvo < 2 || Nvo > N - 1) return ISV_ERR_INVALID_ARG;
+    if (N < 3 || N > POINT_RING || Nvo < 2 || Nvo > N - 1) return ISV_ERR_INVALID_ARG;
     isv_estimator *e = new isv_estimator();
     e->p = *p;
     e->p.cfg.max_batch = n_sequences;
