@@ -12,6 +12,7 @@
 #include <cstdio>
 #include "isv_kernels.h"
 #include "isv_device_math.h"
+#include "isv_proj_factor.h"
 #include "isv_prior_factor.h"
 #include "isv_imu_factor.h"
 
@@ -269,7 +270,13 @@ __global__ __launch_bounds__(256, 4) void k_dogleg(DevBatch d) {
 // ------------------------------------------------------------------------------------------
 // Candidate cost + model cost change (fixed-shape reductions), then TrustRegionMinimizer's step
 // validity / tolerances / acceptance and DoglegStrategy's radius / mu update.  One workgroup per window.
+// FUSED (LDS solver path): the reprojection factors' candidate cost and model cost change are evaluated HERE, one
+// factor per thread in the same thread -> factor order the separate k_proj_linearize<1> pass summed them in, instead
+// of being written to fcost_c / fmodel by a tile-grid kernel and read back: one launch and one round trip less per
+// iteration.  Dynamic LDS: candidate poses [N][12] | extrinsic [12] | poses at x [N][12] | tangent step [N][6].
+template <bool FUSED>
 __global__ __launch_bounds__(256) void k_step_control(DevBatch d) {
+    extern __shared__ __align__(16) double cl[];
     __shared__ double red[256];
     __shared__ int s_accept;
     const int w = blockIdx.x, t = threadIdx.x;
@@ -279,7 +286,63 @@ __global__ __launch_bounds__(256) void k_step_control(DevBatch d) {
     double S = 0, M = 0;
     if (st.step_valid) {
         double s = 0, m = 0;
-        for (int f = d.f_off[w] + t; f < d.f_off[w + 1]; f += 256) { s += d.fcost_c[f]; m += d.fmodel[f]; }
+        if (FUSED) {
+            double *sC = cl, *sEx = cl + N * 12, *sX = sEx + 12, *sD = sX + N * 12;
+            if (t < N) {
+                const double *p = d.cpose + ((size_t)w * N + t) * 7;
+                double R[9]; q_to_R(q_from_pose(p), R);
+#pragma unroll
+                for (int k = 0; k < 9; k++) sC[t * 12 + k] = R[k];
+                sC[t * 12 + 9] = p[0]; sC[t * 12 + 10] = p[1]; sC[t * 12 + 11] = p[2];
+            } else if (t >= 64 && t < 64 + N) {
+                const int fr = t - 64;
+                const double *p = d.pose + ((size_t)w * N + fr) * 7;
+                double R[9]; q_to_R(q_from_pose(p), R);
+#pragma unroll
+                for (int k = 0; k < 9; k++) sX[fr * 12 + k] = R[k];
+                sX[fr * 12 + 9] = p[0]; sX[fr * 12 + 10] = p[1]; sX[fr * 12 + 11] = p[2];
+                const double *dp = d.delta_p + (size_t)w * d.np + 15 * fr;
+#pragma unroll
+                for (int k = 0; k < 6; k++) sD[fr * 6 + k] = dp[k];
+            } else if (t == 128) {
+                const double *e = d.ex + (size_t)w * 7;
+                double R[9]; q_to_R(q_from_pose(e), R);
+#pragma unroll
+                for (int k = 0; k < 9; k++) sEx[k] = R[k];
+                sEx[9] = e[0]; sEx[10] = e[1]; sEx[11] = e[2];
+            }
+            __syncthreads();
+            double ric[9], tic[3];
+#pragma unroll
+            for (int k = 0; k < 9; k++) ric[k] = sEx[k];
+#pragma unroll
+            for (int k = 0; k < 3; k++) tic[k] = sEx[9 + k];
+            for (int f = d.f_off[w] + t; f < d.f_off[w + 1]; f += 256) {
+                const FactorRec rec = d.f_rec[f];
+                const int fi = rec.ij & 255, fj = (rec.ij >> 8) & 255;
+                const double *pi3 = d.lm_pts_i + (size_t)rec.lm * 3;
+                const double2 pj = *reinterpret_cast<const double2 *>(d.f_pts_j + (size_t)f * 2);
+                double Ri[9], Rj[9], Pi[3], Pj[3], r0, r1, Ji[12], Jj[12], Jl[2];
+#pragma unroll
+                for (int k = 0; k < 9; k++) { Ri[k] = sC[fi * 12 + k]; Rj[k] = sC[fj * 12 + k]; }
+#pragma unroll
+                for (int k = 0; k < 3; k++) { Pi[k] = sC[fi * 12 + 9 + k]; Pj[k] = sC[fj * 12 + 9 + k]; }
+                proj_factor<false>(Ri, Pi, Rj, Pj, ric, tic, d.proj_sqrt_info, d.clam[rec.lm], pi3[0], pi3[1], pi3[2], pj.x, pj.y, r0, r1, Ji, Jj, Jl);
+                s += 0.5 * log(1.0 + (r0 * r0 + r1 * r1));          // CauchyLoss(1.0): rho = log(1 + s)
+                // model cost change piece (J delta)^T (r + J delta / 2) at x by the directional derivative
+                double rx0, rx1, m0, m1;
+#pragma unroll
+                for (int k = 0; k < 9; k++) { Ri[k] = sX[fi * 12 + k]; Rj[k] = sX[fj * 12 + k]; }
+#pragma unroll
+                for (int k = 0; k < 3; k++) { Pi[k] = sX[fi * 12 + 9 + k]; Pj[k] = sX[fj * 12 + 9 + k]; }
+                proj_residual_dir(Ri, Pi, Rj, Pj, ric, tic, d.proj_sqrt_info, d.lam[rec.lm], pi3[0], pi3[1], pi3[2], pj.x, pj.y,
+                                  sD + fi * 6, sD + fj * 6, d.delta_l[rec.lm], rx0, rx1, m0, m1);
+                const double rp = 1.0 / (1.0 + (rx0 * rx0 + rx1 * rx1));       // corrector: r, J scaled by sqrt(rho')
+                m += rp * (m0 * (rx0 + m0 / 2.0) + m1 * (rx1 + m1 / 2.0));
+            }
+        } else {
+            for (int f = d.f_off[w] + t; f < d.f_off[w + 1]; f += 256) { s += d.fcost_c[f]; m += d.fmodel[f]; }
+        }
         for (int i = t; i < N - 1; i += 256) { s += d.imu_cost_c[(size_t)w * (N - 1) + i]; m += d.imu_model[(size_t)w * (N - 1) + i]; }
         for (int i = t; i < d.n_prior_slots; i += 256) { s += d.prior_cost_c[(size_t)w * d.n_prior_slots + i]; m += d.prior_model[(size_t)w * d.n_prior_slots + i]; }
         S = block_sum<256>(s, red, t); M = block_sum<256>(m, red, t);
@@ -560,9 +623,12 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
             hipLaunchKernelGGL(k_model_imu_prior, dim3(d.B * d.N), dim3(64), 0, st2, d);
             HCHK(hipEventRecord(fj[3], st2));
         }
-        if (d.n_tiles > 0) hipLaunchKernelGGL(k_proj_linearize<1>, dim3((d.n_tiles + 3) / 4), dim3(256), lds_proj1, st, d, d.cpose, d.clam, d.fcost_c, 2);
-        if (!d.lds_T) HCHK(hipStreamWaitEvent(st, fj[3], 0));
-        hipLaunchKernelGGL(k_step_control, dim3(d.B), dim3(256), 0, st, d);
+        if (d.lds_T) hipLaunchKernelGGL(k_step_control<true>, dim3(d.B), dim3(256), ((size_t)30 * d.N + 12) * sizeof(double), st, d);
+        else {
+            if (d.n_tiles > 0) hipLaunchKernelGGL(k_proj_linearize<1>, dim3((d.n_tiles + 3) / 4), dim3(256), lds_proj1, st, d, d.cpose, d.clam, d.fcost_c, 2);
+            HCHK(hipStreamWaitEvent(st, fj[3], 0));
+            hipLaunchKernelGGL(k_step_control<false>, dim3(d.B), dim3(256), 0, st, d);
+        }
     }
     if (d.init_mode) {                     // Estimator::initFactorGraph: first priors from the solved estimate, then double2vector
         hipLaunchKernelGGL(k_init_priors, dim3(d.B), dim3(64), 0, st, d, d.init_scratch, d.init_per_window, d.init_kld);
