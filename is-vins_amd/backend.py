@@ -32,9 +32,15 @@ class BackendError(RuntimeError):
 
 def build(force=False):
     """compile every HIP source for gfx950 into csrc/libisvins_hip.so (hipcc cross-compiles)"""
-    if force:
-        subprocess.check_call(["make", "-s", "-C", CSRC, "clean"])
-    subprocess.check_call(["make", "-s", "-C", CSRC])
+    import fcntl
+    with open(os.path.join(CSRC, ".build.lock"), "w") as lock:      # ranks of one node may call this at the same time
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if force:
+                subprocess.check_call(["make", "-s", "-C", CSRC, "clean"])
+            subprocess.check_call(["make", "-s", "-C", CSRC])
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     return LIB_PATH
 
 
