@@ -517,3 +517,49 @@ def write_stream(path, N, Nvo, n_frames, seed=0, max_landmarks=800, num_iteratio
             f.write("frame %r %d\n" % (float(t), len(image)))
             for fid in image:
                 f.write("%d %s\n" % (fid, r(image[fid])))
+
+
+def write_euroc_like(root, N, Nvo, n_frames, seed=0, max_landmarks=800, num_iterations=10, t0_ns=1_000_000_000):
+    """the same simulated stream as write_stream(seed=...), in the files the reference's test/run_euroc.cpp reads
+    plus a feature-track table in place of the images:
+      root/mav0/imu0/data.csv   `#timestamp [ns],w_x,w_y,w_z,a_x,a_y,a_z`  (200 Hz, one sample before the first frame)
+      root/tracks.csv           `#timestamp [ns],id,x,y,z`  one row per observation, frames in time order
+      root/config.txt           the `config` / `ric` / `tic` lines of the stream format + the `boot` rows
+    Timestamps are integer nanoseconds; frames fall on IMU sample times.  (With a real EuRoC epoch, ~1.4e18 ns, the
+    reference's `stamp / 1e9` in double precision quantises the sample spacing to 2.4e-7 s; t0_ns = 1 s keeps the
+    spacing exact so that this stream reproduces write_stream's.)"""
+    import os
+    sim = Simulator(seed)
+    r = lambda v: ",".join(repr(float(x)) for x in np.asarray(v, float).ravel())
+    rs = lambda v: " ".join(repr(float(x)) for x in np.asarray(v, float).ravel())
+    os.makedirs(os.path.join(root, "mav0", "imu0"), exist_ok=True)
+    G = np.array([0, 0, 9.81007])
+    dt_ns = int(round(sim.frame_dt / sim.k * 1e9)); frame_ns = dt_ns * sim.k
+    a0 = sim.traj.R(0).T @ (sim.traj.acc(0) + G) + sim.ba; g0 = sim.traj.gyro(0) + sim.bg
+    imu_rows = ["%d,%s,%s" % (t0_ns - dt_ns, r(g0), r(a0)),            # a sample before the first image (else the image is thrown)
+                "%d,%s,%s" % (t0_ns, r(g0), r(a0))]
+    track_rows, boot_rows = [], []
+    for i in range(n_frames + 1):                                       # same generator order as write_stream: IMU of frame i, then frame i
+        if i > 0:                                                       # (+ one more frame of IMU than of images: "wait for imu")
+            for s_, (dt, a, g) in enumerate(sim.imu_between(i), 1):
+                imu_rows.append("%d,%s,%s" % (t0_ns + (i - 1) * frame_ns + s_ * dt_ns, r(g), r(a)))
+        if i == n_frames:
+            break
+        t, image = sim.frame(i)
+        if i == N - 1:
+            P, R, V = sim.truth_window(i, N)
+            nrng = np.random.default_rng(1000 + seed)
+            P = P + nrng.normal(0, 0.01, P.shape); V = V + nrng.normal(0, 0.02, V.shape)
+            boot_rows = ["%s %s %s" % (rs(P[k]), rs(R[k]), rs(V[k])) for k in range(N)]
+        for fid in image:
+            track_rows.append("%d,%d,%s" % (t0_ns + i * frame_ns, fid, r(image[fid])))
+    with open(os.path.join(root, "mav0", "imu0", "data.csv"), "w") as f:
+        f.write("#timestamp [ns],w_RS_S_x [rad s^-1],w_RS_S_y [rad s^-1],w_RS_S_z [rad s^-1],a_RS_S_x [m s^-2],a_RS_S_y [m s^-2],a_RS_S_z [m s^-2]\n")
+        f.write("\n".join(imu_rows) + "\n")
+    with open(os.path.join(root, "tracks.csv"), "w") as f:
+        f.write("#timestamp [ns],id,x,y,z\n" + "\n".join(track_rows) + "\n")
+    with open(os.path.join(root, "config.txt"), "w") as c:
+        c.write("config %d %d %d %d %r %r %r %r %r %r %r %r %r\n" % (N, Nvo, max_landmarks, num_iterations, 460.0, 9.81007, 0.1, 5.0,
+                                                               ACC_N, GYR_N, ACC_W, GYR_W, MIN_PARALLAX))
+        c.write("ric %s\ntic %s\n" % (rs(synth.RIC), rs(synth.TIC)))
+        c.write("boot\n" + "\n".join(boot_rows) + "\n")

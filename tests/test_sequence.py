@@ -158,3 +158,29 @@ def test_replay_tool_writes_the_reference_trajectory_file(oracle, tmp_path):
     for s in range(1, 6):
         assert np.array_equal(np.loadtxt(tmp_path / f"pose_output_{s}.txt"), first)
     print("isv_replay:", rep)
+
+
+@pytest.mark.gpu
+def test_replay_tool_reads_euroc_format_files(tmp_path):
+    """tools/isv_replay --euroc: the reference's imu0/data.csv format (test/run_euroc.cpp:26-50) + a feature-track
+    table, paired the way System::getMeasurements / ProcessBackEnd pair them (src/System.cpp:160-202, 262-296),
+    against the same simulated stream replayed from the pre-digested stream file: the same trajectory (the only
+    difference is the reference's repeated boundary sample with dt = 0, which changes nothing but roundings)"""
+    import json, os, subprocess
+    from isvins_amd import backend
+    backend.build()
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "isv_replay")
+    N, Nvo, n_frames = 11, 5, 26
+    (tmp_path / "a").mkdir(); (tmp_path / "b").mkdir()
+    sh.write_stream(tmp_path / "stream.txt", N, Nvo, n_frames, seed=5)
+    sh.write_euroc_like(str(tmp_path / "ds"), N, Nvo, n_frames, seed=5)
+    subprocess.run([tool, str(tmp_path / "stream.txt"), "--out", str(tmp_path / "a")], check=True, capture_output=True, text=True, timeout=300)
+    out = subprocess.run([tool, "--euroc", str(tmp_path / "ds" / "mav0"), "--tracks", str(tmp_path / "ds" / "tracks.csv"),
+                          "--config", str(tmp_path / "ds" / "config.txt"), "--out", str(tmp_path / "b")],
+                         check=True, capture_output=True, text=True, timeout=300)
+    rep = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rep["frames_in_stream"] == n_frames
+    a = np.loadtxt(tmp_path / "a" / "pose_output_0.txt"); b = np.loadtxt(tmp_path / "b" / "pose_output_0.txt")
+    assert a.shape == b.shape == (n_frames - (N - 1), 8)
+    assert np.abs((b[:, 0] - 1.0) - a[:, 0]).max() < 2e-6                # stamps: offset by the 1 s epoch of the CSV files
+    assert np.abs(a[:, 1:] - b[:, 1:]).max() <= 1.000001e-6              # positions / quaternions to the last printed digit

@@ -3,6 +3,16 @@
 // feeding Estimator::processIMU / processImage, src/System.cpp:246-413), without OpenCV / Pangolin, for many sequences.
 //
 //   isv_replay STREAM [--sequences S] [--groups K] [--out DIR] [--write W]
+//   isv_replay --euroc MAV0_DIR --tracks TRACKS.csv --config CONFIG.txt [--sequences S] ...
+//   ... --dump-events FILE   write the processIMU / processImage calls the input turns into and stop (no GPU needed)
+//
+// --euroc reads the dataset files the reference's test/run_euroc.cpp reads, in its formats: MAV0_DIR/imu0/data.csv
+// (`timestamp[ns],w_x,w_y,w_z,a_x,a_y,a_z`, test/run_euroc.cpp:26-50) and, in place of cam0 images + the feature
+// tracker (OpenCV, out of scope), a feature-track table TRACKS.csv (`timestamp[ns],id,x,y,z` per observation, frames in
+// time order).  IMU samples and frames are paired the way System::getMeasurements / ProcessBackEnd do
+// (src/System.cpp:160-202, 262-296): every sample before the image time, the first one at or after it re-used by the next
+// frame, and a linear interpolation at the image time when a sample falls behind it.  CONFIG.txt holds the `config` /
+// `ric` / `tic` lines below and, optionally, the `boot` rows for the frame that fills the window.
 //
 // STREAM is a text file (tests/sequence_harness.py::write_stream writes one from the simulator; a feature tracker's
 // output can be dumped in the same form):
@@ -90,6 +100,79 @@ bool read_stream(const char *path, Stream &s, std::string &err) {
     fclose(f);
     if (!have_cfg) { err = "no config line"; return false; }
     return true;
+}
+
+// ---- EuRoC-format input (test/run_euroc.cpp readers + the measurement pairing of System) -------------------------
+struct ImuSample { double t; double gyr[3], acc[3]; };
+struct Frame { double t; std::vector<int32_t> ids; std::vector<double> pts; };
+
+bool read_imu_csv(const std::string &path, std::vector<ImuSample> &out, std::string &err) {
+    FILE *f = fopen(path.c_str(), "r");
+    if (!f) { err = "cannot open " + path; return false; }
+    char line[512];
+    while (fgets(line, sizeof(line), f)) {
+        if (line[0] == '#' || line[0] == '\n' || line[0] == '\r') continue;
+        ImuSample s; double ns;
+        if (sscanf(line, "%lf,%lf,%lf,%lf,%lf,%lf,%lf", &ns, &s.gyr[0], &s.gyr[1], &s.gyr[2], &s.acc[0], &s.acc[1], &s.acc[2]) != 7) { err = "bad line in " + path; fclose(f); return false; }
+        s.t = ns / 1e9;                                    // dStampNSec / 1e9  (test/run_euroc.cpp:47)
+        out.push_back(s);
+    }
+    fclose(f);
+    return true;
+}
+
+bool read_tracks_csv(const std::string &path, std::vector<Frame> &out, std::string &err) {
+    FILE *f = fopen(path.c_str(), "r");
+    if (!f) { err = "cannot open " + path; return false; }
+    char line[512];
+    double last_ns = -1;
+    while (fgets(line, sizeof(line), f)) {
+        if (line[0] == '#' || line[0] == '\n' || line[0] == '\r') continue;
+        double ns, x, y, z; int id;
+        if (sscanf(line, "%lf,%d,%lf,%lf,%lf", &ns, &id, &x, &y, &z) != 5) { err = "bad line in " + path; fclose(f); return false; }
+        if (out.empty() || ns != last_ns) { Frame fr; fr.t = ns / 1e9; out.push_back(fr); last_ns = ns; }
+        out.back().ids.push_back(id);
+        out.back().pts.push_back(x); out.back().pts.push_back(y); out.back().pts.push_back(z);
+    }
+    fclose(f);
+    return true;
+}
+
+// System::getMeasurements + the IMU loop of System::ProcessBackEnd (td = 0), offline: the events Estimator::processIMU /
+// processImage receive for these IMU samples and frames
+void assemble_events(const std::vector<ImuSample> &imu, const std::vector<Frame> &frames, const Event *boot, int N, Stream &st) {
+    size_t q = 0;                                  // imu_buf.front()
+    double current_time = -1, last[6] = {0, 0, 0, 0, 0, 0};
+    int frames_out = 0;
+    for (const Frame &fr : frames) {
+        if (q >= imu.size() || !(imu.back().t > fr.t)) break;          // "wait for imu": offline, the end of the data
+        if (!(imu[q].t < fr.t)) continue;                                // "throw img, only should happen at the beginning"
+        std::vector<size_t> take;
+        while (imu[q].t < fr.t) take.push_back(q++);
+        take.push_back(q);                                               // the first sample at or after the image stays queued
+        for (size_t k : take) {
+            const ImuSample &m = imu[k];
+            Event e; e.kind = 0;
+            if (m.t <= fr.t) {
+                if (current_time < 0) current_time = m.t;
+                e.dt = m.t - current_time;
+                current_time = m.t;
+                for (int a = 0; a < 3; a++) { last[a] = m.acc[a]; last[3 + a] = m.gyr[a]; }
+            } else {                                                     // interpolate at the image time
+                const double dt_1 = fr.t - current_time, dt_2 = m.t - fr.t;
+                current_time = fr.t;
+                const double w1 = dt_2 / (dt_1 + dt_2), w2 = dt_1 / (dt_1 + dt_2);
+                for (int a = 0; a < 3; a++) { last[a] = w1 * last[a] + w2 * m.acc[a]; last[3 + a] = w1 * last[3 + a] + w2 * m.gyr[a]; }
+                e.dt = dt_1;
+            }
+            for (int a = 0; a < 3; a++) { e.acc[a] = last[a]; e.gyr[a] = last[3 + a]; }
+            st.events.push_back(e);
+        }
+        if (boot && frames_out == N - 1) st.events.push_back(*boot);
+        Event e; e.kind = 2; e.stamp = fr.t; e.ids = fr.ids; e.pts = fr.pts;
+        st.events.push_back(std::move(e));
+        st.n_frames++; frames_out++;
+    }
 }
 
 struct GroupResult {
@@ -180,11 +263,16 @@ void run_group(const Stream &st, int first_seq, int n_seq, const std::string &ou
 }  // namespace
 
 int main(int argc, char **argv) {
-    if (argc < 2) { fprintf(stderr, "usage: isv_replay STREAM [--sequences S] [--groups K] [--out DIR] [--write W]\n"); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: isv_replay STREAM | --euroc MAV0_DIR --tracks CSV --config TXT  [--sequences S] [--groups K] [--out DIR] [--write W]\n"); return 2; }
     int S = 1, K = 1, W = 1;
-    std::string out_dir;
-    for (int i = 2; i < argc; i++) {
-        if (!strcmp(argv[i], "--sequences") && i + 1 < argc) S = atoi(argv[++i]);
+    std::string out_dir, euroc_dir, tracks_path, config_path, stream_path, dump_path;
+    for (int i = 1; i < argc; i++) {
+        if (!strcmp(argv[i], "--dump-events") && i + 1 < argc) { dump_path = argv[++i]; continue; }
+        if (!strcmp(argv[i], "--euroc") && i + 1 < argc) euroc_dir = argv[++i];
+        else if (!strcmp(argv[i], "--tracks") && i + 1 < argc) tracks_path = argv[++i];
+        else if (!strcmp(argv[i], "--config") && i + 1 < argc) config_path = argv[++i];
+        else if (argv[i][0] != '-' && stream_path.empty()) stream_path = argv[i];
+        else if (!strcmp(argv[i], "--sequences") && i + 1 < argc) S = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--groups") && i + 1 < argc) K = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--out") && i + 1 < argc) out_dir = argv[++i];
         else if (!strcmp(argv[i], "--write") && i + 1 < argc) W = atoi(argv[++i]);
@@ -193,7 +281,27 @@ int main(int argc, char **argv) {
     if (S < 1 || K < 1 || K > S) { fprintf(stderr, "need 1 <= groups <= sequences\n"); return 2; }
     Stream st;
     std::string err;
-    if (!read_stream(argv[1], st, err)) { fprintf(stderr, "isv_replay: %s\n", err.c_str()); return 1; }
+    if (!euroc_dir.empty()) {
+        if (tracks_path.empty() || config_path.empty()) { fprintf(stderr, "--euroc needs --tracks and --config\n"); return 2; }
+        std::vector<ImuSample> imu;
+        std::vector<Frame> frames;
+        if (!read_stream(config_path.c_str(), st, err) || !read_imu_csv(euroc_dir + "/imu0/data.csv", imu, err) || !read_tracks_csv(tracks_path, frames, err)) { fprintf(stderr, "isv_replay: %s\n", err.c_str()); return 1; }
+        Event boot_ev; const Event *boot = nullptr;      // CONFIG.txt may carry the `boot` rows behind its config line
+        for (const Event &e : st.events) if (e.kind == 1) { boot_ev = e; boot = &boot_ev; }
+        st.events.clear(); st.n_frames = 0;
+        assemble_events(imu, frames, boot, st.params.cfg.n_frames, st);
+    } else if (stream_path.empty() || !read_stream(stream_path.c_str(), st, err)) { fprintf(stderr, "isv_replay: %s\n", stream_path.empty() ? "no stream file" : err.c_str()); return 1; }
+    if (!dump_path.empty()) {          // the processIMU / processImage calls this input turns into; no GPU needed
+        FILE *f = fopen(dump_path.c_str(), "w");
+        if (!f) { fprintf(stderr, "isv_replay: cannot write %s\n", dump_path.c_str()); return 1; }
+        for (const Event &e : st.events) {
+            if (e.kind == 0) fprintf(f, "imu %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", e.dt, e.acc[0], e.acc[1], e.acc[2], e.gyr[0], e.gyr[1], e.gyr[2]);
+            else if (e.kind == 1) fprintf(f, "boot\n");
+            else fprintf(f, "frame %.17g %zu\n", e.stamp, e.ids.size());
+        }
+        fclose(f);
+        return 0;
+    }
     int feed_threads = (int)std::thread::hardware_concurrency() / K;      // per group, for the per-sequence feed
     if (feed_threads > 8) feed_threads = 8;
     if (feed_threads < 1) feed_threads = 1;
