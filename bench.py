@@ -72,7 +72,6 @@ def main():
         dist.init_process_group("nccl")
     else:
         torch.cuda.set_device(0)
-    os.environ["HIP_VISIBLE_DEVICES"] = os.environ.get("HIP_VISIBLE_DEVICES", "")
     isvins_loader.load()
     from isvins_amd import backend, synth
     backend.build()
