@@ -114,6 +114,8 @@ struct DevBatch {
     size_t init_per_window;
     int32_t *act;                       // [ISV_MAX_TRACE] windows that linearised / solved in iteration i (bench bookkeeping)
     double2 *lm_cg;                     // [Ltot]  {c_l = s_l^2 / (s_l^2 E_l + mu D_l^2), g_l}
+    int32_t sw_global;                  // this launch keeps the pair partials in sw_part (set per launch: only batches that need the occupancy)
+    double *sw_part;                    // [B][NP * 84] pair partials of k_sweep_mfma when they do not share a CU's LDS four ways (long windows); else null
     double *Tvis;                       // [B][tvis_sz] reprojection part of the reduced system (6x6 pose corners), hd, g, bs
     int32_t force_retry, init_mode;       // init_mode: this enqueue is Estimator::initFactorGraph (no update(), no marginalisation)            // test hook (env ISV_DEBUG_FORCE_RETRY): treat the first n factorisations of an iteration as failed
     int32_t prior_H_sz, tvis_sz, wd_ld, max_lm;   // wd_ld: panel width of k_rank1_mfma (6N + 1 rounded up to 16); max_lm: landmarks per window cap

@@ -541,12 +541,16 @@ int isv_solver_alloc(DevBatch &d, size_t B, size_t L, size_t F, std::vector<void
     // LDS-resident fast path: the structure-aware solve (two windows per CU up to N = 11, one beyond), the pair
     // partials of k_sweep_mfma and the panel + landmark tables of k_rank1_mfma must fit the 160 KB of a CU
     const size_t lds_r1 = (64 * (size_t)(d.wd_ld + 4) + (size_t)d.max_lm * 3 + 2) * sizeof(double);
-    const size_t lds_sw = ((size_t)(d.N * (d.N - 1) / 2) * 84 + (size_t)(d.N * (d.N - 1) / 2 + 2) / 2 + 1) * sizeof(double);
+    const size_t n_pairs = (size_t)d.N * (d.N - 1) / 2;
+    const bool sw_global = n_pairs * 84 * sizeof(double) > 40 * 1024;      // partials too big to share a CU's LDS four ways
+    const size_t lds_sw = (n_pairs * 84 + (n_pairs + 2) / 2 + 1) * sizeof(double);       // (the LDS variant's size; the global one needs less)
     const size_t lds_sb = build_solve_sb_bytes(d.N, d.prior_H_sz);
     d.lds_T = (d.N <= 20 && d.wd_ld <= 128 && d.prior_H_sz <= 1024 && lds_sb <= (d.N <= 11 ? 80u : 160u) * 1024 &&
                lds_r1 <= 160 * 1024 && lds_sw <= 160 * 1024) ? 1 : 0;
     if (getenv("ISV_DEBUG_PATH")) fprintf(stderr, "isv: N=%d wd_ld=%d prior_H_sz=%d lds_sb=%zu lds_r1=%zu lds_sw=%zu -> lds_T=%d\n", d.N, d.wd_ld, d.prior_H_sz, lds_sb, lds_r1, lds_sw, d.lds_T);
     TRYA(dal(&d.Tglob, d.lds_T ? 1 : B * nblkT, allocs, err));
+    d.sw_part = nullptr; d.sw_global = 0;
+    if (d.lds_T && sw_global) TRYA(dal(&d.sw_part, B * n_pairs * 84, allocs, err));
     d.marg_scratch_sz = 26;
     TRYA(dal(&d.marg_scratch, L * 26, allocs, err));
     if (d.lds_T) {
@@ -588,7 +592,11 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
         if (d.lds_T) {
             // landmark elimination: Gram products of the pose Jacobians, then the rank-1 downdates (both FP64 MFMA)
             PROF(slot, 1, 0);
-            hipLaunchKernelGGL(k_sweep_mfma, dim3(d.B), dim3(64 * ISV_SWEEP_WAVES), ((size_t)(d.N * (d.N - 1) / 2) * 84 + (size_t)(d.N * (d.N - 1) / 2 + 2) / 2 + 1) * sizeof(double), st, d);
+            {
+                const size_t n_pairs = (size_t)d.N * (d.N - 1) / 2;
+                d.sw_global = (d.sw_part && d.B > 256) ? 1 : 0;     // more than one workgroup per CU: trade LDS for occupancy
+                hipLaunchKernelGGL(k_sweep_mfma, dim3(d.B), dim3(64 * ISV_SWEEP_WAVES), ((d.sw_global ? 0 : n_pairs * 84) + (n_pairs + 2) / 2 + 1) * sizeof(double), st, d);
+            }
             counts[2]++;
             PROF(slot, 1, 1);
             const int nt = d.wd_ld / 16;
@@ -623,10 +631,12 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
             hipLaunchKernelGGL(k_model_imu_prior, dim3(d.B * d.N), dim3(64), 0, st2, d);
             HCHK(hipEventRecord(fj[3], st2));
         }
-        if (d.lds_T) hipLaunchKernelGGL(k_step_control<true>, dim3(d.B), dim3(256), ((size_t)30 * d.N + 12) * sizeof(double), st, d);
+        // candidate evaluation of the reprojection factors: inside the per-window control kernel, unless the windows are
+        // so large that one workgroup per window would serialise it (config 5: 30 000 factors in one window)
+        if (d.lds_T && (size_t)d.Ftot <= (size_t)4096 * d.B) hipLaunchKernelGGL(k_step_control<true>, dim3(d.B), dim3(256), ((size_t)30 * d.N + 12) * sizeof(double), st, d);
         else {
             if (d.n_tiles > 0) hipLaunchKernelGGL(k_proj_linearize<1>, dim3((d.n_tiles + 3) / 4), dim3(256), lds_proj1, st, d, d.cpose, d.clam, d.fcost_c, 2);
-            HCHK(hipStreamWaitEvent(st, fj[3], 0));
+            if (!d.lds_T) HCHK(hipStreamWaitEvent(st, fj[3], 0));
             hipLaunchKernelGGL(k_step_control<false>, dim3(d.B), dim3(256), 0, st, d);
         }
     }

@@ -31,11 +31,14 @@ __global__ __launch_bounds__(64 * ISV_SWEEP_WAVES, 8) void k_sweep_mfma(DevBatch
     const SolveState &st = d.st[w];
     if (st.termination != ISV_TERM_RUNNING || !st.need_linearize) return;
     const int N = d.N, NP = N * (N - 1) / 2;
-    double *Pjj = lds;                     // [NP][36]  sum J_j^T J_j of pair p
+    // pair partials: in LDS while four workgroups still share a CU that way (NP * 84 doubles <= 40 KB), else in a global
+    // scratch slice of this window (written and read back by this workgroup only: L2 traffic, one launch round kept;
+    // chosen per launch for batches of more than one workgroup per CU -- a lone window is faster out of LDS)
+    double *Pjj = d.sw_global ? d.sw_part + (size_t)w * NP * 84 : lds;      // [NP][36]  sum J_j^T J_j of pair p
     double *Phh = Pjj + NP * 36;           // [NP][36]  sum J_i^T J_i of pair p
     double *Pgj = Phh + NP * 36;           // [NP][6]   sum J_j^T r
     double *Pgh = Pgj + NP * 6;            // [NP][6]   sum J_i^T r
-    int *offL = (int *)(Pgh + NP * 6);     // [NP + 1] group starts, staged once
+    int *offL = d.sw_global ? (int *)lds : (int *)(Pgh + NP * 6);     // [NP + 1] group starts, staged once
     const int *perm = d.pg_perm + d.f_off[w];
     const int *sched = d.pg_sched + (size_t)w * NP, *soff = d.pg_sched_off + (size_t)w * (ISV_SWEEP_WAVES + 1);
     const double *strip = d.strip + (size_t)d.f_off[w] * ISV_PROJ_STRIP;
