@@ -18,7 +18,8 @@ __global__ void k_cost_reduce(DevBatch d, const double *fcost, const double *imu
 // solver stage (isv_solver.hip)
 int isv_solver_alloc(DevBatch &d, size_t B, size_t L, size_t F, std::vector<void *> &allocs, std::string &err);
 int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t *fj, int64_t *counts, hipEvent_t *prof_ev, std::string &err);
-static inline size_t prior_lds_bytes(int slots) { return (size_t)slots * (82 + 90 + 82) * sizeof(double); }
+// (jac = false: the residual-only evaluation, see prior_linearize_body)
+static inline size_t prior_lds_bytes(int slots, bool jac = true) { return (size_t)slots * (jac ? 82 + 90 + 82 : 10 + 10 + 82) * sizeof(double); }
 __global__ void k_triangulate(DevBatch d);
 __global__ void k_imu_raw(DevBatch d, const double *pose_src, const double *sb_src, int gate);
 __global__ void k_imu_weight(DevBatch d, double *cost_out, int gate);

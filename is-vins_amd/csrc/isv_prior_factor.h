@@ -107,7 +107,9 @@ DEV void prior_linearize_body(const DevBatch &d, const double *pose_src, const d
         if (!(ss.termination == ISV_TERM_RUNNING && (gate == 1 ? ss.need_linearize != 0 : ss.step_valid != 0))) return;
     }
     const int n_rp = d.n_rp[w];
-    double *sRaw = lds, *sW = lds + (size_t)slots * PRL_RAW, *sS = sW + (size_t)slots * PRL_W;
+    // residual-only evaluation (JAC = false, the candidate point in k_dogleg): no Jacobian blocks, 10-double slots
+    constexpr int RAWS = JAC ? PRL_RAW : 10, WS = JAC ? PRL_W : 10;
+    double *sRaw = lds, *sW = lds + (size_t)slots * RAWS, *sS = sW + (size_t)slots * WS;
     double *strip = d.prior_strip + (size_t)w * d.prior_strip_sz;
     double *PH = d.prior_H + (size_t)w * d.prior_H_sz;
     const double *poseW = pose_src + (size_t)w * N * 7;
@@ -119,7 +121,7 @@ DEV void prior_linearize_body(const DevBatch &d, const double *pose_src, const d
     }
     // ---- phase 1: raw residual / raw Jacobian blocks, one lane per prior ----
     for (int s = t; s < slots; s += 64) {
-        double *raw = sRaw + s * PRL_RAW, *rawJ = raw + 9;
+        double *raw = sRaw + s * RAWS, *rawJ = raw + 9;
         const int kind = s == 0 ? 0 : (s == 1 ? 1 : (s < 1 + d.Nvo ? 2 : 3));
         Quat rr = Quat{1, 0, 0, 0};
         double Ri[9], Rj[9], qd[3], lg[3], Jr[9];
@@ -212,8 +214,8 @@ DEV void prior_linearize_body(const DevBatch &d, const double *pose_src, const d
     for (int s = 0; s < slots; s++) {
         const PriorDesc p = prior_desc(d, w, s, n_rp);
         if (!p.valid) continue;
-        const double *raw = sRaw + s * PRL_RAW, *rawJ = raw + 9, *S = sS + s * PRL_S;
-        double *wr = sW + s * PRL_W;
+        const double *raw = sRaw + s * RAWS, *rawJ = raw + 9, *S = sS + s * PRL_S;
+        double *wr = sW + s * WS;
         if (p.kind == 0) prior_weight<6, 1, 6, false, JAC>(S, raw, rawJ, wr, t);
         else if (p.kind == 1) prior_weight<9, 1, 9, true, JAC>(S, raw, rawJ, wr, t);
         else if (p.kind == 2) prior_weight<6, 2, 6, false, JAC>(S, raw, rawJ, wr, t);
@@ -223,7 +225,7 @@ DEV void prior_linearize_body(const DevBatch &d, const double *pose_src, const d
     // ---- phase 3: CauchyLoss corrector (scale r and J by sqrt(rho')), cost, strips ----
     for (int s = 0; s < slots; s++) {
         const PriorDesc p = prior_desc(d, w, s, n_rp);
-        double *wr = sW + s * PRL_W, *so = strip + p.strip_off;
+        double *wr = sW + s * WS, *so = strip + p.strip_off;
         double cost = 0.0;
         if (!p.valid) { if (JAC) for (int e = t; e < PR_RP_SZ; e += 64) so[e] = 0.0; }
         else if (p.kind == 0) cost = prior_correct<6, 1, 6, JAC, WAVE>(wr, so, t);
@@ -238,7 +240,7 @@ DEV void prior_linearize_body(const DevBatch &d, const double *pose_src, const d
     for (int s = 0; s < slots; s++) {
         const PriorDesc p = prior_desc(d, w, s, n_rp);
         if (!p.valid) continue;
-        const double *wr = sW + s * PRL_W;
+        const double *wr = sW + s * WS;
         if (p.kind == 0) prior_H<6, 1, 6>(wr, PH + p.H_off, t);
         else if (p.kind == 1) prior_H<9, 1, 9>(wr, PH + p.H_off, t);
         else if (p.kind == 2) prior_H<6, 2, 6>(wr, PH + p.H_off, t);

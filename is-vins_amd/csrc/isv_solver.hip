@@ -623,11 +623,11 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
         else hipLaunchKernelGGL(k_build_solve<false>, dim3(d.B), dim3(512), lds_bs, st, d);
         counts[1]++;
         PROF(slot, 3, 1);
-        hipLaunchKernelGGL(k_dogleg, dim3(d.B), dim3(256), (d.lds_T ? ((size_t)(d.N - 1) * 48 + (size_t)d.n_prior_slots * 16) * sizeof(double) + prior_lds_bytes(d.n_prior_slots) : 0) + 2 * (size_t)d.np * sizeof(double), st, d);
+        hipLaunchKernelGGL(k_dogleg, dim3(d.B), dim3(256), (d.lds_T ? ((size_t)(d.N - 1) * 48 + (size_t)d.n_prior_slots * 16) * sizeof(double) + prior_lds_bytes(d.n_prior_slots, false) : 0) + 2 * (size_t)d.np * sizeof(double), st, d);
         if (!d.lds_T) {                    // (the LDS path evaluates these inside k_dogleg)
             HCHK(hipEventRecord(fj[2], st)); HCHK(hipStreamWaitEvent(st2, fj[2], 0));
             if (NI) hipLaunchKernelGGL(k_imu_linearize<false>, dim3((unsigned)NI), dim3(64), 0, st2, d, d.cpose, d.csb, d.imu_cost_c, 2);
-            hipLaunchKernelGGL(k_prior_linearize<false>, dim3(d.B), dim3(64), prior_lds_bytes(d.n_prior_slots), st2, d, d.cpose, d.csb, d.prior_cost_c, 2);
+            hipLaunchKernelGGL(k_prior_linearize<false>, dim3(d.B), dim3(64), prior_lds_bytes(d.n_prior_slots, false), st2, d, d.cpose, d.csb, d.prior_cost_c, 2);
             hipLaunchKernelGGL(k_model_imu_prior, dim3(d.B * d.N), dim3(64), 0, st2, d);
             HCHK(hipEventRecord(fj[3], st2));
         }
