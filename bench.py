@@ -117,6 +117,18 @@ def main():
     fam = be.last_timing(); cnt = be.last_counts()
     # PCIe-inclusive rate (never `value`): what a caller handing over HOST buffers sees, isv_batch_upload (host packing +
     # H2D) -> isv_batch_optimize -> isv_batch_download (D2H + unpack into the Estimator arrays)
+    # ms / optimize() of ONE window (BASELINE's second figure: the reference calls backendOptimization() once per frame):
+    # a handle of its own with one resident window, median of 7 solves
+    ms_single = None
+    if rank == 0 and world == 1 and not args.no_host_legs:
+        be1 = backend.Backend(args.frames, args.vo, max_landmarks=args.landmarks, max_obs=max_obs, max_batch=1)
+        be1.upload(windows[:1])
+        ts1 = []
+        for _ in range(9):                        # HIP events on the handle's stream (a host clock would add this process's
+            be1.run_optimize(sync=True)           # stream-synchronise wake-up latency, which depends on the runtime's wait mode)
+            ts1.append(float(be1.last_timing()[0]))
+        ms_single = float(np.median(ts1[2:]))
+        be1.close()
     t_incl = None
     if rank == 0 and world == 1 and not args.no_host_legs:
         w2 = [w.clone() for w in windows]               # download() writes into the windows: use a second copy
@@ -210,6 +222,7 @@ def main():
             "metric": "sliding-window solves/sec (11 KF, ~300 landmarks)", "value": value, "unit": "windows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "ms_per_optimize_batched": ms_step / W,
+            "ms_per_optimize_single_window": ms_single,      # one resident window, HIP events, inside this PyTorch process (2.6 ms standalone: scripts/quick_cfg.py 1 11 5 300)
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{W} independent synthetic sliding windows per GPU (N={N} KF, Nvo={args.vo}, L={L} landmarks, F~{Fw:.0f} reprojection factors each; BASELINE config 4 batch of config-2 windows), full backendOptimization(): NUM_ITERATIONS=10 dogleg iterations + update() + double2vector + MargForward/MargBackward on every window",
                        "windows_per_gpu": W, "frames": N, "landmarks": L, "factors_total": Ftot, "iterations_cap": 10,
