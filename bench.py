@@ -61,6 +61,9 @@ def main():
     ap.add_argument("--no-host-legs", action="store_true", help="skip the untimed host-buffer (PCIe-inclusive) legs; used for the rocprofv3 passes so that their kernel statistics hold the benchmark's own launches only")
     args = ap.parse_args()
 
+    # more than two handles' worth of HIP streams in one process (the untimed two-handle leg below): the runtime maps
+    # streams onto 4 hardware queues by default; must be set before the runtime initialises.  One handle is unaffected.
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import numpy as np
     import torch
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -222,7 +225,7 @@ def main():
             "metric": "sliding-window solves/sec (11 KF, ~300 landmarks)", "value": value, "unit": "windows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "ms_per_optimize_batched": ms_step / W,
-            "ms_per_optimize_single_window": ms_single,      # one resident window on a second handle, HIP events (2.6 ms when that handle is the only one of the process: scripts/quick_cfg.py 1 11 5 300)
+            "ms_per_optimize_single_window": ms_single,      # one resident window on a second handle, HIP events
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{W} independent synthetic sliding windows per GPU (N={N} KF, Nvo={args.vo}, L={L} landmarks, F~{Fw:.0f} reprojection factors each; BASELINE config 4 batch of config-2 windows), full backendOptimization(): NUM_ITERATIONS=10 dogleg iterations + update() + double2vector + MargForward/MargBackward on every window",
                        "windows_per_gpu": W, "frames": N, "landmarks": L, "factors_total": Ftot, "iterations_cap": 10,
