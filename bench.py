@@ -68,11 +68,19 @@ def main():
     import torch
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # ISV_BENCH_REHEARSAL=1: rehearse the multi-rank path on ONE GPU (every rank on cuda:0, gloo instead of RCCL, which
+    # refuses two ranks on one device); the driver's real runs have one GPU per rank
+    rehearsal = os.environ.get("ISV_BENCH_REHEARSAL") == "1"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl")
+        if rehearsal:
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl")
     else:
         torch.cuda.set_device(0)
     isvins_loader.load()
@@ -114,7 +122,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        dt = sharding.max_over_ranks(dt, dist, device="cuda")
+        dt = sharding.max_over_ranks(dt, dist, device="cpu" if rehearsal else "cuda")
     # per-kernel-family HIP-event timing of one more (untimed, profiled) step, on the handle's own stream
     be.run_optimize(sync=True, profile=True)
     fam = be.last_timing(); cnt = be.last_counts()
