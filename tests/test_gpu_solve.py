@@ -232,3 +232,27 @@ def test_extreme_shapes_match_oracle(oracle, n_frames, n_vo, n_lm):
         assert mg.valid == mo.valid and mg.n_marg_landmarks == mo.n_marg_landmarks
     finally:
         b.close()
+
+
+@pytest.mark.parametrize("n_frames,n_vo,count", [(11, 5, 48), (18, 8, 16)])
+def test_parity_sweep_over_many_windows(oracle, n_frames, n_vo, count):
+    """many windows of mixed sizes in one batch, every one compared with the oracle: iteration counts, accept / reject
+    patterns, terminations, cost traces, solved states, depth flags and prior updates (a wider net than the named
+    cases above for rounding-induced accept / reject flips)"""
+    rng = np.random.default_rng(11)
+    sizes = [int(x) for x in rng.integers(12, 320, count)]
+    ws = [synth.make_window(500 + i, n_frames=n_frames, n_vo=n_vo, n_landmarks=n) for i, n in enumerate(sizes)]
+    backend.build()
+    b = backend.Backend(n_frames, n_vo, max_landmarks=320, max_obs=max(w.n_obs for w in ws), max_batch=len(ws))
+    try:
+        gs = [w.clone() for w in ws]
+        sums, margs = b.optimize_batch(gs)
+        n_rejected = 0
+        for w, g, sg, mg in zip(ws, gs, sums, margs):
+            o, so, mo = oracle_run(oracle, b.cfg, w)
+            check_window(o, so, g, sg)
+            assert mg.valid == mo.valid and mg.n_marg_landmarks == mo.n_marg_landmarks
+            n_rejected += sum(1 for k in range(1, so.iterations + 1) if so.trace_accepted[k] == 0)
+        print("rejected steps across the sweep:", n_rejected)
+    finally:
+        b.close()
