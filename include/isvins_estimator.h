@@ -96,6 +96,8 @@ int  isv_estimator_status(const isv_estimator_t *e, int32_t seq, int32_t out[8])
 /* the window states; any pointer may be NULL */
 int  isv_estimator_get_window(const isv_estimator_t *e, int32_t seq, double *Ps, double *Rs, double *Vs, double *Bas,
                               double *Bgs, double *Headers);
+/* pre_integrations[frame] of the sequence (IntegrationBase members the IMU factor reads), 1 <= frame <= frame_count */
+int  isv_estimator_get_preintegration(const isv_estimator_t *e, int32_t seq, int32_t frame, isv_imu_t *out);
 int  isv_estimator_last_summary(const isv_estimator_t *e, int32_t seq, isv_summary_t *out);
 /* which = 0: the rows the reference appends to pose_output.txt after every solve, 8 doubles per row
  *            (Headers[0], Ps[0], Quaterniond(Rs[0]) as w x y z)            src/System.cpp:401-410

@@ -759,6 +759,14 @@ extern "C" int isv_estimator_get_window(const isv_estimator_t *e, int32_t seq, d
     return ISV_OK;
 }
 
+extern "C" int isv_estimator_get_preintegration(const isv_estimator_t *e, int32_t seq, int32_t frame, isv_imu_t *out) {
+    SEQ_OR_FAIL(e, seq);
+    const Sequence &s = e->seq[seq];
+    if (!out || frame < 0 || frame >= s.N || !s.pre[frame]) return ISV_ERR_INVALID_ARG;
+    *out = s.pre[frame]->pod;
+    return ISV_OK;
+}
+
 extern "C" int isv_estimator_last_summary(const isv_estimator_t *e, int32_t seq, isv_summary_t *out) {
     SEQ_OR_FAIL(e, seq);
     if (!out) return ISV_ERR_INVALID_ARG;

@@ -184,3 +184,27 @@ def test_replay_tool_reads_euroc_format_files(tmp_path):
     assert a.shape == b.shape == (n_frames - (N - 1), 8)
     assert np.abs((b[:, 0] - 1.0) - a[:, 0]).max() < 2e-6                # stamps: offset by the 1 s epoch of the CSV files
     assert np.abs(a[:, 1:] - b[:, 1:]).max() <= 1.000001e-6              # positions / quaternions to the last printed digit
+
+
+def test_native_preintegration_matches_the_oracle(oracle):
+    """IntegrationBase::push_back (include/factor/integration_base.h:31-158) in the window manager (block-sparse
+    products, AVX2 clone) against the oracle's dense restatement over 400 random samples: delta_p / q / v, the 15x15
+    Jacobian and the covariance"""
+    from isvins_amd import estimator as E
+    cfg = abi.make_config(11, 5, max_landmarks=100, max_obs=1100, max_batch=1)
+    est = E.SequenceEstimator(sh.estimator_params(cfg), 1, solver=sh.oracle_vtbl(oracle, cfg))
+    rng = np.random.default_rng(5)
+    # frame 0 takes no IMU (frame_count == 0); one image moves on to frame 1, whose pre-integration is then fed
+    est.process_imu(0, 0.005, [0.1, -0.2, 9.7], [0.01, 0.02, -0.01])
+    est.push_image(0, 0.0, np.arange(30, dtype=np.int32), np.tile([0.1, 0.2, 1.0], (30, 1))); est.step()
+    acc0, gyr0 = np.array([0.1, -0.2, 9.7]), np.array([0.01, 0.02, -0.01])
+    ref = sh.PreInt(oracle, acc0, gyr0, np.zeros(3), np.zeros(3))
+    for _ in range(400):
+        dt = float(rng.uniform(0.002, 0.01)); a = rng.normal(0, 2.0, 3) + [0, 0, 9.8]; g = rng.normal(0, 0.5, 3)
+        est.process_imu(0, dt, a, g); ref.push_back(dt, a, g)
+    got = est.preintegration(0, 1)
+    for name in ("delta_p", "delta_q", "delta_v", "linearized_ba", "linearized_bg", "jacobian", "covariance"):
+        a, b = abi.arr(getattr(got, name)), abi.arr(getattr(ref.pod, name))
+        assert np.abs(a - b).max() <= 1e-12 * max(1.0, np.abs(b).max()), name
+    assert abs(got.sum_dt - ref.pod.sum_dt) < 1e-12
+    est.close()
