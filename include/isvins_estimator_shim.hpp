@@ -97,14 +97,16 @@ inline void Estimator_backendOptimization_isv(Estimator &e) {
     w.margin_old = (e.marginalization_flag == Estimator::MARGIN_OLD); w.header0 = e.Headers[0];
     w.para_Pose = &e.para_Pose[0][0]; w.para_SpeedBias = &e.para_SpeedBias[0][0]; w.para_Ex_Pose = &e.para_Ex_Pose[0][0]; w.para_Feature = &e.para_Feature[0][0];
 
+    isv_summary_t sum; isv_marg_result_t mg;
 #ifdef ISVINS_DEVICE_TRIANGULATE
     // FeatureManager::triangulate on the device as well (feature_manager.cpp:206-258): landmarks without a depth get the
-    // DLT depth over their views.  Define this and drop the f_manager.triangulate(Ps, tic, ric) call in
-    // Estimator::solveOdometry() (src/estimator.cpp:466); setDepth() below writes the results back like the solve's.
-    { isv_window_t *wp = &w; if (isv_backend_triangulate(e.isv_handle, 1, &wp) != ISV_OK) { std::cerr << "isv_backend_triangulate: " << isv_backend_last_error(e.isv_handle) << std::endl; return; } }
-#endif
-    isv_summary_t sum; isv_marg_result_t mg;
+    // DLT depth over their views, then the solve, with ONE hand-over (isv_backend_solve_odometry_batch).  Define this and
+    // drop the f_manager.triangulate(Ps, tic, ric) call in Estimator::solveOdometry() (src/estimator.cpp:466); setDepth()
+    // below writes the depths back like the solve's.
+    { isv_window_t *wp = &w; if (isv_backend_solve_odometry_batch(e.isv_handle, 1, &wp, &sum, &mg) != ISV_OK) { std::cerr << "isv_backend_solve_odometry_batch: " << isv_backend_last_error(e.isv_handle) << std::endl; return; } }
+#else
     if (isv_backend_optimize(e.isv_handle, &w, &sum, &mg) != ISV_OK) { std::cerr << "isv_backend_optimize: " << isv_backend_last_error(e.isv_handle) << std::endl; return; }
+#endif
 
     // write back (double2vector's outputs and the shifted / rotated priors)
     for (int i = 0; i < N; i++) {
