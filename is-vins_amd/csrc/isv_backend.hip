@@ -3,6 +3,7 @@
 // No torch types, no allocation across the ABI.  There is NO CPU fallback: every entry point
 // fails with ISV_ERR_DEVICE when HIP is unavailable.
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -294,6 +295,7 @@ static int host_threads(int n) {
 // tracks and fixes every window's landmark / factor / tile offsets; pass 2 packs the windows on host threads.
 extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const *ws) {
     if (!h || !ws || n < 1) return ISV_ERR_INVALID_ARG;
+    const auto t_up0 = std::chrono::steady_clock::now();
     if ((size_t)n > h->capB) { h->err = "batch larger than max_batch"; return ISV_ERR_CAPACITY; }
     const isv_config_t &c = h->cfg;
     const int N = c.n_frames;
@@ -341,6 +343,7 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
         for (int k = 0; k < K; k++) if (rcs[k] != ISV_OK) { if (!errs[k].empty()) h->err = errs[k]; return rcs[k]; }
     }
     s.lm_off[n] = (int32_t)L; s.f_off[n] = (int32_t)F;
+    const auto t_packed = std::chrono::steady_clock::now();
     DevBatch &d = h->d;
     d.B = n; d.Ltot = (int32_t)L; d.Ftot = (int32_t)F; d.n_tiles = (int32_t)T;
     hipStream_t st = h->stream;
@@ -367,7 +370,12 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
     // IMU sqrt_info once per upload (the covariances do not change during a solve)
     if (NI) hipLaunchKernelGGL(k_imu_prep, dim3((unsigned)NI), dim3(64), 0, st, d);
     HIPCHK(h, hipGetLastError());
+    const auto t_enq = std::chrono::steady_clock::now();
     HIPCHK(h, hipStreamSynchronize(st));
+    if (getenv("ISV_TRACE_HANDOVER")) {
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "isv upload: n=%d pack %.2f ms, enqueue copies %.2f ms, wait %.2f ms\n", n, ms(t_up0, t_packed), ms(t_packed, t_enq), ms(t_enq, std::chrono::steady_clock::now()));
+    }
     h->resident = n;
     return ISV_OK;
 }
@@ -597,7 +605,10 @@ extern "C" int isv_backend_triangulate(isv_backend_t *h, int32_t n, isv_window_t
 // would read between the two steps are overwritten by double2vector for every landmark of the window anyway.
 extern "C" int isv_backend_solve_odometry_batch(isv_backend_t *h, int32_t n, isv_window_t *const *ws, isv_summary_t *summary,
                                                 isv_marg_result_t *marg) {
+    static const bool trace = getenv("ISV_TRACE_HANDOVER") != nullptr;       // stderr: ms of upload / triangulate + solve / download
+    const auto t0 = std::chrono::steady_clock::now();
     TRY(isv_batch_upload(h, n, ws));
+    const auto t1 = std::chrono::steady_clock::now();
     DevBatch &d = h->d; hipStream_t st = h->stream;
     if (d.Ltot) {
         hipLaunchKernelGGL(k_triangulate, dim3((d.Ltot + 63) / 64), dim3(64), 0, st, d);
@@ -605,7 +616,14 @@ extern "C" int isv_backend_solve_odometry_batch(isv_backend_t *h, int32_t n, isv
         D2D(h->depth0, d.depth, (size_t)d.Ltot);        // isv_batch_optimize restores the state from the *0 copies
     }
     TRY(isv_batch_optimize(h, 1));
-    return isv_batch_download(h, n, ws, summary, marg);
+    const auto t2 = std::chrono::steady_clock::now();
+    const int rc = isv_batch_download(h, n, ws, summary, marg);
+    if (trace) {
+        const auto t3 = std::chrono::steady_clock::now();
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "isv hand-over: n=%d L=%d F=%d upload %.2f ms, triangulate + solve %.2f ms, download %.2f ms\n", n, d.Ltot, d.Ftot, ms(t0, t1), ms(t1, t2), ms(t2, t3));
+    }
+    return rc;
 }
 
 extern "C" int isv_backend_linearize(isv_backend_t *h, const isv_window_t *w, double *proj_strips, double *imu_strips,
