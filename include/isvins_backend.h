@@ -231,6 +231,8 @@ int  isv_backend_optimize_batch(isv_backend_t *h, int32_t n, isv_window_t *const
  * w->pose_prior, w->vb_prior, w->relpose[n_vo - 1] are OUTPUTS; w->n_rollpitch becomes 0.  *kld (may be NULL) receives
  * the Kullback-Leibler divergence of the recovered factors against the truncated marginal (:976-989).          */
 int  isv_backend_init_factor_graph(isv_backend_t *h, isv_window_t *w, isv_summary_t *summary, double *kld);
+/* the same for n windows at once (n sequences reaching their first solve together); summary [n], kld [n] or NULL */
+int  isv_backend_init_factor_graph_batch(isv_backend_t *h, int32_t n, isv_window_t *const *w, isv_summary_t *summary, double *kld);
 /* FeatureManager::triangulate (src/feature_tracker/feature_manager.cpp:206-258), the step solveOdometry() runs right
  * before backendOptimization(): every landmark of the n windows whose lm_depth is not positive gets the DLT depth over
  * all its views (smallest right singular vector, host-camera frame), replaced by INIT_DEPTH outside [0.1, 8].

@@ -47,6 +47,8 @@ typedef struct isv_solver_vtbl {
     int (*triangulate)(void *ctx, int32_t n, isv_window_t *const *w);
     int (*init_factor_graph)(void *ctx, isv_window_t *w, isv_summary_t *summary, double *kld);
     int (*optimize_batch)(void *ctx, int32_t n, isv_window_t *const *w, isv_summary_t *summary, isv_marg_result_t *marg);
+    /* optional (may be NULL): init_factor_graph for n windows at once */
+    int (*init_factor_graph_batch)(void *ctx, int32_t n, isv_window_t *const *w, isv_summary_t *summary, double *kld);
     /* optional (may be NULL): triangulate + optimize_batch in one hand-over; used when no sequence is at its first solve */
     int (*solve_odometry_batch)(void *ctx, int32_t n, isv_window_t *const *w, isv_summary_t *summary, isv_marg_result_t *marg);
 } isv_solver_vtbl_t;

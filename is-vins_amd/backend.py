@@ -21,7 +21,7 @@ _lib = None
 STATUS = {0: "ISV_OK", -1: "ISV_ERR_INVALID_ARG", -2: "ISV_ERR_CAPACITY", -3: "ISV_ERR_NONFINITE",
           -4: "ISV_ERR_DEVICE", -5: "ISV_ERR_UNSUPPORTED"}
 EXPORTS = ["isv_abi_version", "isv_backend_create", "isv_backend_destroy", "isv_backend_last_error",
-           "isv_backend_optimize", "isv_backend_optimize_batch", "isv_backend_init_factor_graph", "isv_backend_triangulate", "isv_backend_solve_odometry_batch", "isv_backend_linearize",
+           "isv_backend_optimize", "isv_backend_optimize_batch", "isv_backend_init_factor_graph", "isv_backend_init_factor_graph_batch", "isv_backend_triangulate", "isv_backend_solve_odometry_batch", "isv_backend_linearize",
            "isv_batch_upload", "isv_batch_optimize", "isv_batch_linearize", "isv_batch_download",
            "isv_batch_sync", "isv_batch_last_timing", "isv_batch_last_counts"]
 
@@ -68,6 +68,7 @@ def load_library():
     lib.isv_backend_optimize.argtypes = [vp, C.POINTER(abi.isv_window_t), C.POINTER(abi.isv_summary_t), C.POINTER(abi.isv_marg_result_t)]
     lib.isv_backend_optimize_batch.argtypes = [vp, C.c_int32, wpp, C.POINTER(abi.isv_summary_t), C.POINTER(abi.isv_marg_result_t)]
     lib.isv_backend_init_factor_graph.argtypes = [vp, C.POINTER(abi.isv_window_t), C.POINTER(abi.isv_summary_t), dp]
+    lib.isv_backend_init_factor_graph_batch.argtypes = [vp, C.c_int32, wpp, C.POINTER(abi.isv_summary_t), dp]
     lib.isv_backend_triangulate.argtypes = [vp, C.c_int32, wpp]
     lib.isv_backend_solve_odometry_batch.argtypes = [vp, C.c_int32, wpp, C.POINTER(abi.isv_summary_t), C.POINTER(abi.isv_marg_result_t)]
     lib.isv_backend_linearize.argtypes = [vp, C.POINTER(abi.isv_window_t), dp, dp, dp]
@@ -148,6 +149,15 @@ class Backend:
         sums = (abi.isv_summary_t * n)(); margs = (abi.isv_marg_result_t * n)()
         self._check(self.lib.isv_backend_solve_odometry_batch(self.h, n, self._ptrs(windows), sums, margs), "solve_odometry_batch")
         return list(sums), list(margs)
+
+    def init_factor_graph_batch(self, windows):
+        """Estimator::initFactorGraph for several windows at once. -> (summaries, klds)"""
+        n = len(windows)
+        sums = (abi.isv_summary_t * n)(); kld = np.zeros(n)
+        self._check(self.lib.isv_backend_init_factor_graph_batch(self.h, n, self._ptrs(windows), sums, abi._p(kld)), "init_factor_graph_batch")
+        for w in windows:
+            w.n_rollpitch = 0; w.margin_old = 0              # (the C side reset them in its view of the windows)
+        return list(sums), kld
 
     def triangulate(self, windows):
         """FeatureManager::triangulate for the landmarks without a positive depth (lm_depth updated in place)"""

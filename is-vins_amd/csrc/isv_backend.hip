@@ -543,22 +543,25 @@ extern "C" int isv_backend_optimize(isv_backend_t *h, isv_window_t *w, isv_summa
 // dogleg iterations), derive the first prior factors from the solved estimate, double2vector.  The window's prior
 // structs are outputs.
 extern size_t init_priors_scratch_doubles(int Vo);
-extern "C" int isv_backend_init_factor_graph(isv_backend_t *h, isv_window_t *w, isv_summary_t *summary, double *kld) {
-    if (!h || !w || !w->pose_prior || !w->vb_prior || !w->relpose) return ISV_ERR_INVALID_ARG;
+extern "C" int isv_backend_init_factor_graph_batch(isv_backend_t *h, int32_t n, isv_window_t *const *ws, isv_summary_t *summary, double *kld) {
+    if (!h || !ws || n < 1) return ISV_ERR_INVALID_ARG;
     const isv_config_t &c = h->cfg;
     if (6 * c.n_vo + 9 > 64) { h->err = "initFactorGraph: 6 Vo + 9 > 64 is not built"; return ISV_ERR_UNSUPPORTED; }
     // the initial graph has no prior factors: zero information, identity rotations so that the residuals stay finite
     static const double I3[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
-    memset(w->pose_prior, 0, sizeof(*w->pose_prior)); memcpy(w->pose_prior->R, I3, sizeof(I3));
-    memset(w->vb_prior, 0, sizeof(*w->vb_prior)); w->vb_prior->index = c.n_vo - 1;
-    for (int i = 0; i < c.n_vo - 1; i++) { memset(&w->relpose[i], 0, sizeof(isv_relpose_t)); memcpy(w->relpose[i].delta_R, I3, sizeof(I3)); w->relpose[i].imu_i = i; w->relpose[i].imu_j = i + 1; }
-    w->n_rollpitch = 0; w->margin_old = 0;
-    isv_window_t *ws[1] = {w};
-    TRY(isv_batch_upload(h, 1, ws));
+    for (int b = 0; b < n; b++) {
+        isv_window_t *w = ws[b];
+        if (!w || !w->pose_prior || !w->vb_prior || !w->relpose) return ISV_ERR_INVALID_ARG;
+        memset(w->pose_prior, 0, sizeof(*w->pose_prior)); memcpy(w->pose_prior->R, I3, sizeof(I3));
+        memset(w->vb_prior, 0, sizeof(*w->vb_prior)); w->vb_prior->index = c.n_vo - 1;
+        for (int i = 0; i < c.n_vo - 1; i++) { memset(&w->relpose[i], 0, sizeof(isv_relpose_t)); memcpy(w->relpose[i].delta_R, I3, sizeof(I3)); w->relpose[i].imu_i = i; w->relpose[i].imu_j = i + 1; }
+        w->n_rollpitch = 0; w->margin_old = 0;
+    }
+    TRY(isv_batch_upload(h, n, ws));
     DevBatch &d = h->d; hipStream_t st = h->stream;
     const size_t per = init_priors_scratch_doubles(c.n_vo);
     double *scratch = nullptr, *kld_dev = nullptr;
-    if (hipMalloc(&scratch, per * sizeof(double)) != hipSuccess || hipMalloc(&kld_dev, sizeof(double)) != hipSuccess) {
+    if (hipMalloc(&scratch, (size_t)n * per * sizeof(double)) != hipSuccess || hipMalloc(&kld_dev, (size_t)n * sizeof(double)) != hipSuccess) {
         if (scratch) (void)hipFree(scratch);
         h->err = "initFactorGraph: scratch allocation failed"; return ISV_ERR_DEVICE;
     }
@@ -574,13 +577,16 @@ extern "C" int isv_backend_init_factor_graph(isv_backend_t *h, isv_window_t *w, 
     }
     h->prof_valid = 0;
     d.max_iter = saved_iter; d.init_mode = 0; d.init_scratch = nullptr; d.init_kld = nullptr;
-    double kv = 0;
-    if (rc == ISV_OK) rc = isv_batch_download(h, 1, ws, summary, nullptr);
-    if (rc == ISV_OK && hipMemcpy(&kv, kld_dev, sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = ISV_ERR_DEVICE;
+    if (rc == ISV_OK) rc = isv_batch_download(h, n, ws, summary, nullptr);
+    if (rc == ISV_OK && kld && hipMemcpy(kld, kld_dev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = ISV_ERR_DEVICE;
     (void)hipFree(scratch); (void)hipFree(kld_dev);
-    if (kld) *kld = kv;
     h->resident = 0;
     return rc;
+}
+
+extern "C" int isv_backend_init_factor_graph(isv_backend_t *h, isv_window_t *w, isv_summary_t *summary, double *kld) {
+    isv_window_t *ws[1] = {w};
+    return isv_backend_init_factor_graph_batch(h, 1, ws, summary, kld);
 }
 
 // FeatureManager::triangulate (src/feature_tracker/feature_manager.cpp:206-258) for every landmark of the n windows whose

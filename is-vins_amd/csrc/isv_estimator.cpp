@@ -511,6 +511,9 @@ int hip_optimize(void *ctx, int32_t n, isv_window_t *const *w, isv_summary_t *s,
     return isv_backend_optimize_batch((isv_backend_t *)ctx, n, w, s, m);
 }
 
+int hip_init_batch(void *ctx, int32_t n, isv_window_t *const *w, isv_summary_t *s, double *kld) {
+    return isv_backend_init_factor_graph_batch((isv_backend_t *)ctx, n, w, s, kld);
+}
 int hip_solve_odometry(void *ctx, int32_t n, isv_window_t *const *w, isv_summary_t *s, isv_marg_result_t *m) {
     return isv_backend_solve_odometry_batch((isv_backend_t *)ctx, n, w, s, m);
 }
@@ -544,7 +547,7 @@ extern "C" int isv_estimator_create(const isv_estimator_params_t *p, int32_t n_s
     if (rc != ISV_OK) return rc;
     rc = isv_backend_create(&e->p.cfg, &e->backend);           // fails loudly without a GPU: there is no other solver
     if (rc != ISV_OK) { delete e; return rc; }
-    e->solver = isv_solver_vtbl_t{e->backend, hip_triangulate, hip_init, hip_optimize, hip_solve_odometry};
+    e->solver = isv_solver_vtbl_t{e->backend, hip_triangulate, hip_init, hip_optimize, hip_init_batch, hip_solve_odometry};
     *out = e;
     return ISV_OK;
 }
@@ -693,13 +696,24 @@ extern "C" int isv_estimator_step(isv_estimator_t *e) {
         t2 = clk::now();
         // backendOptimization(), INITIAL_STRUCTURE branch (:1543-1548): vector2double, initFactorGraph, NON_LINEAR.  The
         // NON_LINEAR branch below runs in the same call (two `if`s in the reference, not else-if).
-        for (int si : solve) {
-            Sequence &s = e->seq[si];
-            if (s.flag != INITIAL_STRUCTURE) continue;
-            isv_summary_t s0;
-            double kld = 0;
-            rc = e->solver.init_factor_graph(e->solver.ctx, &s.w, &s0, &kld);
+        std::vector<int> first;
+        for (int si : solve) if (e->seq[si].flag == INITIAL_STRUCTURE) first.push_back(si);
+        if (!first.empty() && e->solver.init_factor_graph_batch) {       // all first solves of this frame in one batch
+            std::vector<isv_window_t *> wf(first.size());
+            for (size_t k = 0; k < first.size(); k++) wf[k] = &e->seq[first[k]].w;
+            std::vector<isv_summary_t> s0(first.size());
+            rc = e->solver.init_factor_graph_batch(e->solver.ctx, (int32_t)wf.size(), wf.data(), s0.data(), nullptr);
             if (rc != ISV_OK) { e->err = "initFactorGraph failed"; return rc; }
+        } else {
+            for (int si : first) {
+                isv_summary_t s0;
+                double kld = 0;
+                rc = e->solver.init_factor_graph(e->solver.ctx, &e->seq[si].w, &s0, &kld);
+                if (rc != ISV_OK) { e->err = "initFactorGraph failed"; return rc; }
+            }
+        }
+        for (int si : first) {
+            Sequence &s = e->seq[si];
             s.rollpitch.clear();
             read_back(s);
             s.flag = NON_LINEAR;

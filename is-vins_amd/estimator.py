@@ -19,12 +19,13 @@ class isv_estimator_params_t(C.Structure):
 _wpp = C.POINTER(C.POINTER(abi.isv_window_t))
 TRIANGULATE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, _wpp)
 INIT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(abi.isv_window_t), C.POINTER(abi.isv_summary_t), C.POINTER(C.c_double))
+INIT_BATCH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, _wpp, C.POINTER(abi.isv_summary_t), C.POINTER(C.c_double))
 OPTIMIZE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, _wpp, C.POINTER(abi.isv_summary_t), C.POINTER(abi.isv_marg_result_t))
 
 
 class isv_solver_vtbl_t(C.Structure):
     _fields_ = [("ctx", C.c_void_p), ("triangulate", TRIANGULATE_FN), ("init_factor_graph", INIT_FN), ("optimize_batch", OPTIMIZE_FN),
-                ("solve_odometry_batch", OPTIMIZE_FN)]
+                ("init_factor_graph_batch", INIT_BATCH_FN), ("solve_odometry_batch", OPTIMIZE_FN)]
 
 
 EXPORTS = ["isv_estimator_create", "isv_estimator_create_with_solver", "isv_estimator_destroy", "isv_estimator_last_error",

@@ -17,6 +17,7 @@ extern "C" void isv_backend_destroy(isv_backend_t *) {}
 extern "C" int isv_backend_triangulate(isv_backend_t *, int32_t, isv_window_t *const *) { return ISV_ERR_DEVICE; }
 extern "C" int isv_backend_init_factor_graph(isv_backend_t *, isv_window_t *, isv_summary_t *, double *) { return ISV_ERR_DEVICE; }
 extern "C" int isv_backend_optimize_batch(isv_backend_t *, int32_t, isv_window_t *const *, isv_summary_t *, isv_marg_result_t *) { return ISV_ERR_DEVICE; }
+extern "C" int isv_backend_init_factor_graph_batch(isv_backend_t *, int32_t, isv_window_t *const *, isv_summary_t *, double *) { return ISV_ERR_DEVICE; }
 extern "C" int isv_backend_solve_odometry_batch(isv_backend_t *, int32_t, isv_window_t *const *, isv_summary_t *, isv_marg_result_t *) { return ISV_ERR_DEVICE; }
 
 static int g_calls = 0;
@@ -59,7 +60,7 @@ int main() {
     p.cfg.proj_sqrt_info[0] = p.cfg.proj_sqrt_info[3] = 460.0;
     p.ric[0] = p.ric[4] = p.ric[8] = 1.0;
     p.acc_n = 0.2; p.gyr_n = 0.004; p.acc_w = 0.001; p.gyr_w = 0.0001; p.min_parallax = 10.0 / 460.0;
-    isv_solver_vtbl_t vt = {nullptr, st_triangulate, st_init, st_optimize, st_solve_odometry};
+    isv_solver_vtbl_t vt = {nullptr, st_triangulate, st_init, st_optimize, nullptr, st_solve_odometry};
     isv_estimator_t *e = nullptr;
     if (isv_estimator_create(&p, S, &e) == ISV_OK) { fprintf(stderr, "create without a backend must fail\n"); return 1; }
     if (isv_estimator_create_with_solver(&p, S, &vt, &e) != ISV_OK) { fprintf(stderr, "create_with_solver failed\n"); return 1; }

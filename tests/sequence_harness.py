@@ -457,7 +457,13 @@ def oracle_vtbl(oracle, cfg, fused=False):
     def solve_odometry(ctx, n, ws, sums, margs):
         return tri(ctx, n, ws) or opt(ctx, n, ws, sums, margs)
     if fused:
-        return E.isv_solver_vtbl_t(None, E.TRIANGULATE_FN(tri), E.INIT_FN(init), E.OPTIMIZE_FN(opt), E.OPTIMIZE_FN(solve_odometry))
+        def init_batch(ctx, n, ws, sums, klds):
+            for i in range(n):
+                if oracle.isvo_init_factor_graph(C.byref(cfg), ws[i], C.byref(sums[i]), None) != 0:
+                    return -1
+                ws[i].contents.n_rollpitch = 0
+            return 0
+        return E.isv_solver_vtbl_t(None, E.TRIANGULATE_FN(tri), E.INIT_FN(init), E.OPTIMIZE_FN(opt), E.INIT_BATCH_FN(init_batch), E.OPTIMIZE_FN(solve_odometry))
     return E.isv_solver_vtbl_t(None, E.TRIANGULATE_FN(tri), E.INIT_FN(init), E.OPTIMIZE_FN(opt))
 
 

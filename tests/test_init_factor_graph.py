@@ -73,3 +73,25 @@ def test_gpu_init_factor_graph_matches_oracle(oracle, n_frames, n_vo, n_lm):
         assert abs(kld_g - kld_o) < 1e-4 * max(1.0, abs(kld_o))
     finally:
         b.close()
+
+
+@pytest.mark.gpu
+def test_gpu_init_factor_graph_batch_equals_single():
+    """isv_backend_init_factor_graph_batch (many sequences reaching their first solve in the same frame) gives every
+    window the bits of the single-window call"""
+    from isvins_amd import backend
+    backend.build()
+    ws = [synth.make_window(90 + i, n_landmarks=60 + 25 * i) for i in range(5)]
+    be = backend.Backend(11, 5, max_landmarks=200, max_obs=max(w.n_obs for w in ws), max_batch=len(ws))
+    try:
+        a = [w.clone() for w in ws]
+        sums, klds = be.init_factor_graph_batch(a)
+        for i, w in enumerate(ws):
+            b = w.clone()
+            s1, k1 = be.init_factor_graph(b)
+            assert np.array_equal(a[i].state_vector(), b.state_vector()) and np.array_equal(a[i].priors_vector(), b.priors_vector())
+            assert np.array_equal(abi.arr(a[i].pose_prior.sqrt_info), abi.arr(b.pose_prior.sqrt_info))
+            assert np.array_equal(abi.arr(a[i].vb_prior.sqrt_info), abi.arr(b.vb_prior.sqrt_info))
+            assert sums[i].iterations == s1.iterations and sums[i].final_cost == s1.final_cost and klds[i] == k1
+    finally:
+        be.close()
