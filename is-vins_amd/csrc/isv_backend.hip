@@ -45,6 +45,7 @@ struct isv_backend {
         SolveState *st;
         double *pose, *sb, *ex, *lam;
     } h{};
+    SolverStage stage{};          // pinned staging of the result records
     std::vector<void *> hallocs;
     // pristine copies for isv_batch_optimize restore
     double *Ps0 = nullptr, *Rs0 = nullptr, *Vs0 = nullptr, *Bas0 = nullptr, *Bgs0 = nullptr, *depth0 = nullptr, *tic0 = nullptr, *ric0 = nullptr;
@@ -155,6 +156,8 @@ static int create_impl(isv_backend *h) {
     TRY(halloc(h, &s.se3, B)); TRY(halloc(h, &s.lin9, B)); TRY(halloc(h, &s.relpose, B * (c.n_vo - 1))); TRY(halloc(h, &s.rollpitch, B * (size_t)c.max_rollpitch));
     TRY(halloc(h, &s.st, B));
     TRY(halloc(h, &s.pose, B * N * 7)); TRY(halloc(h, &s.sb, B * N * 9)); TRY(halloc(h, &s.ex, B * 7)); TRY(halloc(h, &s.lam, L));
+    TRY(halloc(h, &h->stage.st, B)); TRY(halloc(h, &h->stage.tc, B * ISV_MAX_TRACE)); TRY(halloc(h, &h->stage.tr, B * ISV_MAX_TRACE));
+    TRY(halloc(h, &h->stage.ts, B * ISV_MAX_TRACE)); TRY(halloc(h, &h->stage.ta, B * ISV_MAX_TRACE)); TRY(halloc(h, &h->stage.marg, B));
     TRY(isv_solver_alloc(h->d, B, L, F, h->allocs, h->err));
     return ISV_OK;
 }
@@ -495,7 +498,7 @@ extern "C" int isv_batch_download(isv_backend_t *h, int32_t n, isv_window_t *con
     D2H(s.pose, d.pose, n * N * 7); D2H(s.sb, d.sb, n * N * 9); D2H(s.ex, d.ex, (size_t)n * 7); D2H(s.lam, d.lam, L);
     D2H(s.st, d.st, n);
     HIPCHK(h, hipStreamSynchronize(st));
-    int rcs = isv_solver_download(h->d, st, n, summary, marg, h->err);
+    int rcs = isv_solver_download(h->d, st, n, h->stage, summary, marg, h->err);
     if (rcs != ISV_OK) return rcs;
     auto unpack = [&](int b) {
         isv_window_t *w = ws[b];

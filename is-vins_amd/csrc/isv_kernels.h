@@ -24,5 +24,9 @@ __global__ void k_triangulate(DevBatch d);
 __global__ void k_imu_raw(DevBatch d, const double *pose_src, const double *sb_src, int gate);
 __global__ void k_imu_weight(DevBatch d, double *cost_out, int gate);
 #define ISV_PROF_FAMILIES 4      // 0 = k_proj_linearize<0>, 1 = k_sweep_mfma, 2 = k_rank1_mfma, 3 = k_build_solve*
-int isv_solver_download(DevBatch &d, hipStream_t st, int n, isv_summary_t *summary, isv_marg_result_t *marg, std::string &err);
+// pinned staging for the result records (capacity max_batch): asynchronous device-to-host copies into pageable
+// memory go through the runtime's own staging and may complete lazily, which stalled the NEXT upload by 13-30 ms for
+// batches above ~1 MB of records
+struct SolverStage { SolveState *st; double *tc, *tr, *ts; int32_t *ta; isv_marg_result_t *marg; };
+int isv_solver_download(DevBatch &d, hipStream_t st, int n, const SolverStage &stage, isv_summary_t *summary, isv_marg_result_t *marg, std::string &err);
 int isv_solver_debug_read(DevBatch &d, hipStream_t st, int what, double *out, int64_t count, std::string &err);

@@ -658,28 +658,29 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
     return ISV_OK;
 }
 
-int isv_solver_download(DevBatch &d, hipStream_t st, int n, isv_summary_t *summary, isv_marg_result_t *marg, std::string &err) {
+int isv_solver_download(DevBatch &d, hipStream_t st, int n, const SolverStage &g, isv_summary_t *summary, isv_marg_result_t *marg, std::string &err) {
     if (!summary && !marg) return ISV_OK;
-    std::vector<SolveState> hs(n);
-    std::vector<double> tc((size_t)n * ISV_MAX_TRACE), tr((size_t)n * ISV_MAX_TRACE), ts((size_t)n * ISV_MAX_TRACE);
-    std::vector<int32_t> ta((size_t)n * ISV_MAX_TRACE);
-    HCHK(hipMemcpyAsync(hs.data(), d.st, sizeof(SolveState) * n, hipMemcpyDeviceToHost, st));
-    HCHK(hipMemcpyAsync(tc.data(), d.trace_cost, sizeof(double) * tc.size(), hipMemcpyDeviceToHost, st));
-    HCHK(hipMemcpyAsync(tr.data(), d.trace_radius, sizeof(double) * tr.size(), hipMemcpyDeviceToHost, st));
-    HCHK(hipMemcpyAsync(ts.data(), d.trace_step, sizeof(double) * ts.size(), hipMemcpyDeviceToHost, st));
-    HCHK(hipMemcpyAsync(ta.data(), d.trace_acc, sizeof(int32_t) * ta.size(), hipMemcpyDeviceToHost, st));
-    if (marg) HCHK(hipMemcpyAsync(marg, d.marg, sizeof(isv_marg_result_t) * n, hipMemcpyDeviceToHost, st));
+    const size_t nt = (size_t)n * ISV_MAX_TRACE;
+    if (summary) {
+        HCHK(hipMemcpyAsync(g.st, d.st, sizeof(SolveState) * n, hipMemcpyDeviceToHost, st));
+        HCHK(hipMemcpyAsync(g.tc, d.trace_cost, sizeof(double) * nt, hipMemcpyDeviceToHost, st));
+        HCHK(hipMemcpyAsync(g.tr, d.trace_radius, sizeof(double) * nt, hipMemcpyDeviceToHost, st));
+        HCHK(hipMemcpyAsync(g.ts, d.trace_step, sizeof(double) * nt, hipMemcpyDeviceToHost, st));
+        HCHK(hipMemcpyAsync(g.ta, d.trace_acc, sizeof(int32_t) * nt, hipMemcpyDeviceToHost, st));
+    }
+    if (marg) HCHK(hipMemcpyAsync(g.marg, d.marg, sizeof(isv_marg_result_t) * n, hipMemcpyDeviceToHost, st));
     HCHK(hipStreamSynchronize(st));
+    if (marg) memcpy(marg, g.marg, sizeof(isv_marg_result_t) * n);
     if (summary) {
         for (int b = 0; b < n; b++) {
             isv_summary_t &s = summary[b];
             memset(&s, 0, sizeof(s));
-            s.status = ISV_OK; s.termination = hs[b].termination; s.iterations = hs[b].iteration; s.num_successful = hs[b].num_successful;
-            s.initial_cost = hs[b].initial_cost; s.final_cost = hs[b].x_cost;
-            memcpy(s.trace_cost, &tc[(size_t)b * ISV_MAX_TRACE], sizeof(s.trace_cost));
-            memcpy(s.trace_radius, &tr[(size_t)b * ISV_MAX_TRACE], sizeof(s.trace_radius));
-            memcpy(s.trace_step_norm, &ts[(size_t)b * ISV_MAX_TRACE], sizeof(s.trace_step_norm));
-            memcpy(s.trace_accepted, &ta[(size_t)b * ISV_MAX_TRACE], sizeof(s.trace_accepted));
+            s.status = ISV_OK; s.termination = g.st[b].termination; s.iterations = g.st[b].iteration; s.num_successful = g.st[b].num_successful;
+            s.initial_cost = g.st[b].initial_cost; s.final_cost = g.st[b].x_cost;
+            memcpy(s.trace_cost, &g.tc[(size_t)b * ISV_MAX_TRACE], sizeof(s.trace_cost));
+            memcpy(s.trace_radius, &g.tr[(size_t)b * ISV_MAX_TRACE], sizeof(s.trace_radius));
+            memcpy(s.trace_step_norm, &g.ts[(size_t)b * ISV_MAX_TRACE], sizeof(s.trace_step_norm));
+            memcpy(s.trace_accepted, &g.ta[(size_t)b * ISV_MAX_TRACE], sizeof(s.trace_accepted));
             if (!(s.final_cost - s.final_cost == 0.0)) s.status = ISV_ERR_NONFINITE;
         }
     }
