@@ -641,11 +641,12 @@ extern "C" int isv_backend_linearize(isv_backend_t *h, const isv_window_t *w, do
     isv_window_t *ws[1] = {const_cast<isv_window_t *>(w)};
     TRY(isv_batch_upload(h, 1, ws));
     TRY(isv_batch_linearize(h, 1));
-    DevBatch &d = h->d; hipStream_t st = h->stream;
-    if (proj_strips && d.Ftot) D2H(proj_strips, d.strip, (size_t)d.Ftot * ISV_PROJ_STRIP);
-    if (imu_strips) D2H(imu_strips, d.imu_strip, (size_t)(d.N - 1) * ISV_IMU_STRIP);
-    if (cost) D2H(cost, d.cost, 1);
-    HIPCHK(h, hipStreamSynchronize(st));
+    DevBatch &d = h->d;
+    // (blocking copies: the caller's buffers are pageable, and an asynchronous copy into pageable memory may still be
+    // completing inside the runtime after the stream has drained)
+    if (proj_strips && d.Ftot) HIPCHK(h, hipMemcpy(proj_strips, d.strip, sizeof(double) * (size_t)d.Ftot * ISV_PROJ_STRIP, hipMemcpyDeviceToHost));
+    if (imu_strips) HIPCHK(h, hipMemcpy(imu_strips, d.imu_strip, sizeof(double) * (size_t)(d.N - 1) * ISV_IMU_STRIP, hipMemcpyDeviceToHost));
+    if (cost) HIPCHK(h, hipMemcpy(cost, d.cost, sizeof(double), hipMemcpyDeviceToHost));
     return ISV_OK;
 }
 
