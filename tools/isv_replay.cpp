@@ -268,7 +268,7 @@ int main(int argc, char **argv) {
     // with 4 queues, 27.8 k with 16).  Ask for more before the runtime initialises, unless the caller has chosen.
     setenv("GPU_MAX_HW_QUEUES", "16", 0);
     if (argc < 2) { fprintf(stderr, "usage: isv_replay STREAM | --euroc MAV0_DIR --tracks CSV --config TXT  [--sequences S] [--groups K] [--out DIR] [--write W]\n"); return 2; }
-    int S = 1, K = 1, W = 1;
+    int S = 1, K = 0, W = 1;                        // K = 0: choose the groups from the sequence count
     std::string out_dir, euroc_dir, tracks_path, config_path, stream_path, dump_path;
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--dump-events") && i + 1 < argc) { dump_path = argv[++i]; continue; }
@@ -282,6 +282,7 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--write") && i + 1 < argc) W = atoi(argv[++i]);
         else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
     }
+    if (K == 0) { K = S / 512; if (K > 8) K = 8; if (K < 1) K = 1; }      // ~512 sequences per group, at most 8 groups
     if (S < 1 || K < 1 || K > S) { fprintf(stderr, "need 1 <= groups <= sequences\n"); return 2; }
     Stream st;
     std::string err;
