@@ -3,20 +3,27 @@
 
 Metric (BASELINE.json): sliding-window solves/sec on synthetic 11-KF / ~300-landmark windows, plus
 ms per optimize().  One STEP = one pass of the hot path (Estimator::backendOptimization():
-vector2double + problemSolve [<= 10 dogleg iterations] + update() + double2vector [+ marginalisation
-where built]) over the rank's device-resident batch of windows.  Inputs are resident in HBM before the
+vector2double + problemSolve [<= 10 dogleg iterations] + update() + double2vector + MargForward /
+MargBackward) over the rank's device-resident batch of windows.  Inputs are resident in HBM before the
 timed region (the step restores the pristine uploaded state on device first).
 
   python bench.py --gpus N --steps K --warmup W
-For N > 1 the driver launches one process per GPU with torch.distributed.run (RCCL over xGMI);
-windows are independent, so ranks shard them with no data-path collective ("weak" scaling:
---windows per rank) and only the timing is max-reduced.
+With N > 1 and no RANK in the environment the script starts the N ranks itself (a torch.distributed.run
+CHILD process, before anything in this process touches the GPU); under torch.distributed.run it is one
+rank of the job.  Windows are independent, so ranks shard them with no collective inside the solve;
+the ONE exchange step of the multi-sequence configuration -- an RCCL all-gather of the
+per-window result records, device buffers, no host copy -- runs inside every timed step when N > 1.
+  --scaling weak   (default) --windows per GPU (1024: BASELINE config 4's batch on every GPU)
+  --scaling strong --windows in total, block-partitioned over the ranks (config 4 as written: 1024 / 8 = 128 per GPU)
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -27,83 +34,181 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 FP64_PEAK_TFLOPS = 78.6        # MI355X FP64 vector = matrix peak
 
 
-def cpu_baseline(windows, cfg, budget_s=12.0):
-    """the CPU oracle (oracle/, a 1-thread C port of the reference algorithm) timed on a bounded sample"""
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (a C port of the reference algorithm), built on THIS host with -O3 -march=native into a
+# temporary directory (never in-tree: a native build must not travel to another machine), 1 thread and all cores
+def _native_oracle():
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
+    src = os.path.join(ROOT, "oracle", "isv_oracle.c")
+    so = os.path.join(tempfile.gettempdir(), f"libisv_oracle_native_{os.getuid()}_{os.getpid()}.so")
+    flags = ["-O3", "-march=native", "-fPIC", "-std=gnu11", "-shared"]
+    try:
+        subprocess.check_call(["gcc", *flags, "-o", so, src, "-lm"], stderr=subprocess.DEVNULL)
+        lib = C.CDLL(so)
+        os.unlink(so)
+        how = "gcc -O3 -march=native"
+    except Exception:
+        lib = oracle_lib.load(); how = "gcc -O2 (native build failed)"
+        return lib, how
     from isvins_amd import abi
-    lib = oracle_lib.load()
-    n = 0
-    t0 = time.perf_counter()
-    for w in windows:
-        o = w.clone()
+    dp = C.POINTER(C.c_double)
+    lib.isvo_optimize.argtypes = [C.POINTER(abi.isv_config_t), C.POINTER(abi.isv_window_t), C.POINTER(abi.isv_summary_t), C.POINTER(abi.isv_marg_result_t)]
+    lib.isvo_optimize.restype = C.c_int
+    lib.isvo_linearize.argtypes = [C.POINTER(abi.isv_config_t), C.POINTER(abi.isv_window_t), dp, dp, dp, dp]
+    lib.isvo_linearize.restype = C.c_int
+    return lib, how
+
+
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(windows, cfg, budget_s=10.0):
+    """full backendOptimization() per window on the host: 1 thread, then threads over windows on every core"""
+    from concurrent.futures import ThreadPoolExecutor
+    from isvins_amd import abi
+    lib, how = _native_oracle()
+    nproc = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+
+    def solve(w):
         s = abi.isv_summary_t(); mg = abi.isv_marg_result_t()
-        lib.isvo_optimize(C.byref(cfg), C.byref(o.c()), C.byref(s), C.byref(mg))
-        n += 1
+        lib.isvo_optimize(C.byref(cfg), C.byref(w.c()), C.byref(s), C.byref(mg))
+        return s.iterations
+
+    # 1 thread
+    n1 = 0; t0 = time.perf_counter()
+    for w in windows:
+        solve(w.clone()); n1 += 1
         if time.perf_counter() - t0 > budget_s:
             break
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "windows/s", "cores": 1, "kind": "port",
-            "sample": f"{n} of the benchmark's own 11-KF/300-landmark windows, full backendOptimization(), oracle/libisv_oracle.so (gcc -O2), 1 thread",
-            "ms_per_optimize": 1e3 * dt / n}
+    dt1 = time.perf_counter() - t0
+    # all cores: ctypes releases the GIL inside the C call (7 ms each), clones made before the clock starts
+    est = max(nproc, int(n1 / dt1 * budget_s * nproc * 0.8))
+    sample = [windows[i % len(windows)].clone() for i in range(min(est, 4 * len(windows)))]
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=nproc) as ex:
+        list(ex.map(solve, sample))
+    dtn = time.perf_counter() - t0
+    return {"value": n1 / dt1, "unit": "windows/s", "cores": 1, "kind": "port",
+            "sample": f"{n1} of the benchmark's own 11-KF/300-landmark windows, full backendOptimization() each, oracle/isv_oracle.c built on this host ({how}), 1 thread",
+            "ms_per_optimize": 1e3 * dt1 / n1,
+            "all_cores": {"value": len(sample) / dtn, "unit": "windows/s", "cores": nproc,
+                          "sample": f"{len(sample)} windows, {nproc} threads over windows (the reference's problemSolve is single-threaded, src/estimator.cpp:1122: more cores only help across windows)"},
+            "nproc": nproc, "cpu_model": _cpu_model()}, lib
+
+
+def free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def bs_flops(N):
+    """algorithmic flops of the structure-aware reduced-system solve of one window"""
+    M = N // 2
+    lo = lambda i: i - 1 if i > M else 0
+    hi = lambda i: i + 1 if i < M else N - 1
+    par = lambda i: i + 1 if i < M else (i - 1 if i > M else -1)
+    fl = 0.0
+    for i in range(N):
+        nr = hi(i) - lo(i) + 1
+        fl += 2 * 9 ** 3 / 6.0 * 2                                   # Cholesky + inverse of the 9x9 block
+        fl += ((9 if par(i) >= 0 else 0) + 6 * nr + 1) * 45 * 2      # [C; Y; y^T] L^-T
+        if par(i) >= 0:
+            fl += (45 + 54 * nr + 9) * 9 * 2                         # parent downdates
+    for I in range(N):
+        for J in range(I + 1):
+            cover = sum(1 for i in range(N) if lo(i) <= J and I <= hi(i))
+            fl += cover * (21 if I == J else 36) * 9 * 2             # Spp -= Y Y^T
+    for J in range(N):
+        m = N - J - 1
+        fl += 2 * 6 ** 3 / 6.0 * 2 + (6 * m + 1) * 21 * 2 + (m * (m + 1) / 2 * 36 + 6 * m) * 6 * 2
+    fl += 2 * (6 * N) ** 2 + 4 * N * 81 * 2 + 4 * sum((hi(i) - lo(i) + 1) * 54 for i in range(N)) * 2   # triangular solves + gathers
+    fl += 6.0 * (N * (N + 1) / 2 * 36 + 162 * N + sum((hi(i) - lo(i) + 1) * 54 for i in range(N)))     # scaling, u^T T u, LM diagonal
+    return fl
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--windows", type=int, default=1024, help="windows per GPU (BASELINE config 4 batch)")
+    ap.add_argument("--steps", type=int, default=300, help="timed steps (default: ~2 s of GPU time)")
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--windows", type=int, default=1024, help="windows per GPU (weak) or in total (strong); BASELINE config 4 batch")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--frames", type=int, default=11)
     ap.add_argument("--vo", type=int, default=5)
     ap.add_argument("--landmarks", type=int, default=300)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-host-legs", action="store_true", help="skip the untimed host-buffer (PCIe-inclusive) legs; used for the rocprofv3 passes so that their kernel statistics hold the benchmark's own launches only")
+    ap.add_argument("--no-host-legs", action="store_true", help="skip the untimed secondary legs (host-buffer rates, single window, config 2, N = 18, B = 128); used for the rocprofv3 passes so that their kernel statistics hold the benchmark's own launches only")
     args = ap.parse_args()
+
+    # ---- N > 1 without a launcher: start the ranks as a CHILD job.  This process has not imported torch or touched the
+    # GPU and never will (a process that initialised the GPU must not exec / spawn rank processes on this pool).
+    if args.gpus > 1 and "RANK" not in os.environ:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.run(cmd, env=env).returncode)
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
 
     # more than two handles' worth of HIP streams in one process (the untimed two-handle leg below): the runtime maps
     # streams onto 4 hardware queues by default; must be set before the runtime initialises.  One handle is unaffected.
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     import numpy as np
     import torch
-    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # ISV_BENCH_REHEARSAL=1: rehearse the multi-rank path on ONE GPU (every rank on cuda:0, gloo instead of RCCL, which
     # refuses two ranks on one device); the driver's real runs have one GPU per rank
     rehearsal = os.environ.get("ISV_BENCH_REHEARSAL") == "1"
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if rehearsal:
-            local_rank = 0
-            torch.cuda.set_device(0)
-            dist.init_process_group("gloo")
-        else:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl")
-    else:
-        torch.cuda.set_device(0)
+    dev = 0 if (world == 1 or rehearsal) else local_rank
+    torch.cuda.set_device(dev)
     isvins_loader.load()
-    from isvins_amd import backend, synth
+    from isvins_amd import backend, sharding, synth
     backend.build()
 
-    # The C-ABI library allocates on the calling thread's current HIP device.  backend.load_library() maps torch's
-    # HIP runtime first, so the library and torch share ONE runtime and torch.cuda.set_device() above selects the
-    # device for both; the free-memory check below verifies that the batch really landed on this rank's GPU.
-    dev = local_rank if world > 1 else 0
-    free_before = torch.cuda.mem_get_info(dev)[0]
-
-    W = args.windows
-    from isvins_amd import sharding
-    ids = sharding.shard_window_ids(rank, world, W)
+    W = args.windows if args.scaling == "weak" else None
+    ids = list(sharding.shard_window_ids(rank, world, args.windows, None if args.scaling == "weak" else args.windows))
+    W = len(ids)
     windows = synth.make_windows(ids, n_frames=args.frames, n_vo=args.vo, n_landmarks=args.landmarks)
     Ftot = sum(w.n_factors for w in windows)
     max_obs = max(w.n_obs for w in windows)
+    cfg0 = backend.abi.make_config(args.frames, args.vo, max_landmarks=args.landmarks, max_obs=max_obs, max_batch=W)
+    # CPU baseline on rank 0 BEFORE the process group exists: the other ranks sleep in the rendezvous meanwhile
+    cpu = None; cpu_lib = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu, cpu_lib = cpu_baseline(windows, cfg0, budget_s=10.0 if world == 1 else 5.0)
+
+    dist = None
+    if world > 1:
+        import datetime
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo" if rehearsal else "nccl", timeout=datetime.timedelta(minutes=20))
+
+    # The C-ABI library allocates on the calling thread's current HIP device (and every later entry point re-selects the
+    # device the handle was created on).  backend.load_library() maps torch's HIP runtime first, so the library and torch
+    # share ONE runtime; the free-memory check below verifies that the batch really landed on this rank's GPU.
+    free_before = torch.cuda.mem_get_info(dev)[0]
     be = backend.Backend(args.frames, args.vo, max_landmarks=args.landmarks, max_obs=max_obs, max_batch=W)
     be.upload(windows)
     free_after = torch.cuda.mem_get_info(dev)[0]
     if W >= 64 and free_before - free_after < (64 << 20):
         raise RuntimeError(f"rank {rank}: the backend did not allocate on cuda:{dev} (free memory moved by {free_before - free_after} B)")
+
+    rec = be.record_doubles()
+    records = gathered = None
+    if world > 1:
+        gdev = "cpu" if rehearsal else f"cuda:{dev}"
+        records = torch.zeros((W, rec), dtype=torch.float64, device=f"cuda:{dev}")
+        gathered = torch.zeros((world * W, rec), dtype=torch.float64, device=gdev)
 
     def barrier():
         torch.cuda.synchronize()
@@ -111,37 +216,119 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def step():
+        be.run_optimize(sync=False)
+        if world > 1:      # the exchange step: result records -> all ranks (ordered on torch's stream after the handle's)
+            be.pack_results(records.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            sharding.gather_records(records.cpu() if rehearsal else records, gathered, dist)
+
     for _ in range(args.warmup):
-        be.run_optimize(sync=True)
+        step()
+    be.sync()
     barrier()
     t0 = time.perf_counter()
-    fam = np.zeros(8); cnt = np.zeros(8)
     for _ in range(args.steps):
-        be.run_optimize(sync=False)
+        step()
     be.sync()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        dt = sharding.max_over_ranks(dt, dist, device="cpu" if rehearsal else "cuda")
+        dt = sharding.max_over_ranks(dt, dist, device="cpu" if rehearsal else f"cuda:{dev}")
+    # what the collective really connected: every rank's (rank, device index), gathered over the same process group
+    ranks_seen = None
+    if world > 1:
+        me = torch.tensor([[float(rank), float(dev)]], dtype=torch.float64, device="cpu" if rehearsal else f"cuda:{dev}")
+        allr = torch.zeros((world, 2), dtype=torch.float64, device=me.device)
+        sharding.gather_records(me, allr, dist)
+        ranks_seen = [[int(a), int(b)] for a, b in allr.cpu().tolist()]
+        g = gathered.cpu()
+        ok = bool(torch.isfinite(g[:, -8]).all()) and sorted(int(x) for x in g[:, -2].tolist()) == sorted(
+            i for r in range(world) for i in sharding.shard_window_ids(r, world, args.windows, None if args.scaling == "weak" else args.windows))
+        if not ok:
+            raise RuntimeError("the all-gathered result records do not cover every rank's windows")
     # per-kernel-family HIP-event timing of one more (untimed, profiled) step, on the handle's own stream
     be.run_optimize(sync=True, profile=True)
     fam = be.last_timing(); cnt = be.last_counts()
-    # PCIe-inclusive rate (never `value`): what a caller handing over HOST buffers sees, isv_batch_upload (host packing +
-    # H2D) -> isv_batch_optimize -> isv_batch_download (D2H + unpack into the Estimator arrays)
-    # ms / optimize() of ONE window (BASELINE's second figure: the reference calls backendOptimization() once per frame):
-    # a handle of its own with one resident window, median of 7 solves
-    ms_single = None
-    if rank == 0 and world == 1 and not args.no_host_legs:
-        be1 = backend.Backend(args.frames, args.vo, max_landmarks=args.landmarks, max_obs=max_obs, max_batch=1)
-        be1.upload(windows[:1])
-        ts1 = []
-        for _ in range(9):                        # HIP events on the handle's stream (a host clock would add this process's
-            be1.run_optimize(sync=True)           # stream-synchronise wake-up latency, which depends on the runtime's wait mode)
-            ts1.append(float(be1.last_timing()[0]))
-        ms_single = float(np.median(ts1[2:]))
-        be1.close()
+
+    extra = {}
     t_incl = None
     if rank == 0 and world == 1 and not args.no_host_legs:
+        def single_window_ms(N, Nvo, wins, mo):
+            b1 = backend.Backend(N, Nvo, max_landmarks=args.landmarks, max_obs=mo, max_batch=1)
+            b1.upload(wins[:1])
+            ts1 = []
+            for _ in range(9):                        # HIP events on the handle's stream (a host clock would add this process's
+                b1.run_optimize(sync=True)            # stream-synchronise wake-up latency, which depends on the runtime's wait mode)
+                ts1.append(float(b1.last_timing()[0]))
+            b1.close()
+            return float(np.median(ts1[2:]))
+        # ms / optimize() of ONE window (BASELINE's second figure: the reference calls backendOptimization() once per frame)
+        extra["ms_per_optimize_single_window"] = single_window_ms(args.frames, args.vo, windows, max_obs)
+
+        # ---- BASELINE config 2: ONE 11-KF / 300-landmark window, residual + Jacobian kernels only, vs the CPU -----------
+        b1 = backend.Backend(args.frames, args.vo, max_landmarks=args.landmarks, max_obs=max_obs, max_batch=1)
+        b1.upload(windows[:1])
+        tl = []
+        for _ in range(25):
+            b1.run_linearize(sync=True); tl.append(b1.last_timing()[:3].copy())
+        tl = np.median(np.array(tl[5:]), axis=0)
+        b1.close()
+        F0, N = windows[0].n_factors, args.frames
+        bytes_cfg2 = 284.0 * F0 + 6016.0 * (N - 1)              # algorithmic bytes of one window-linearisation
+        cfg2 = {"workload": f"one synthetic window, N={N} KF, L={windows[0].L} landmarks, F={F0} reprojection + {N - 1} IMU factors + priors: every residual block evaluated once (ceres::Problem::Evaluate equivalent), isv_batch_linearize",
+                "gpu_us": 1e3 * float(tl[0]), "gpu_us_proj_kernel": 1e3 * float(tl[1]), "gpu_us_imu_prior_kernels": 1e3 * float(tl[2]),
+                "algorithmic_bytes": bytes_cfg2, "gpu_GBps": bytes_cfg2 / (float(tl[0]) * 1e-3) / 1e9,
+                "note": "a single window moves 0.4 MB: launch-latency bound, far from the HBM roofline (SURVEY 8d); the batched figure is roofline_by_kernel[k_proj_linearize<0>]"}
+        if cpu_lib is not None:
+            dp = C.POINTER(C.c_double)
+            ps = np.zeros((F0, 28)); im = np.zeros((N - 1, 465)); pr = np.zeros(256); co = np.zeros(1)
+            cw = windows[0].c()
+            tc = []
+            for _ in range(60):
+                t1 = time.perf_counter()
+                cpu_lib.isvo_linearize(C.byref(cfg0), C.byref(cw), ps.ctypes.data_as(dp), im.ctypes.data_as(dp), pr.ctypes.data_as(dp), co.ctypes.data_as(dp))
+                tc.append(time.perf_counter() - t1)
+            cfg2["cpu_us"] = 1e6 * float(np.median(tc[10:])); cfg2["cpu_GBps"] = bytes_cfg2 / float(np.median(tc[10:])) / 1e9
+            cfg2["cpu"] = "oracle isvo_linearize, 1 thread, same host"
+        extra["config2_single_window_linearize"] = cfg2
+
+        # ---- config 4 as written: 1024 windows over 8 GPUs = 128 per GPU; the 1-GPU figure at B = 128 ---------------------
+        nb = min(128, W)
+        b128 = backend.Backend(args.frames, args.vo, max_landmarks=args.landmarks, max_obs=max_obs, max_batch=nb)
+        b128.upload(windows[:nb])
+        for _ in range(3):
+            b128.run_optimize(sync=True)
+        t1 = time.perf_counter()
+        for _ in range(40):
+            b128.run_optimize(sync=False)
+        b128.sync()
+        t128 = (time.perf_counter() - t1) / 40
+        b128.close()
+        extra["strong_scaling_shard"] = {"workload": f"{nb} windows on one GPU (BASELINE config 4 as written: 1024 windows / 8 GPUs)", "ms_per_step": 1e3 * t128,
+                                         "value": nb / t128, "unit": "windows/s"}
+
+        # ---- the reference's compile-time shape: ALL_BUF_SIZE = 18, Vo_SIZE = 8 (include/parameters.h:35-40) ------------
+        n18 = min(W, 1024)
+        w18 = synth.make_windows(range(n18), n_frames=18, n_vo=8, n_landmarks=args.landmarks)
+        mo18 = max(w.n_obs for w in w18)
+        b18 = backend.Backend(18, 8, max_landmarks=args.landmarks, max_obs=mo18, max_batch=n18)
+        b18.upload(w18)
+        for _ in range(2):
+            b18.run_optimize(sync=True)
+        t1 = time.perf_counter()
+        for _ in range(20):
+            b18.run_optimize(sync=False)
+        b18.sync()
+        t18 = (time.perf_counter() - t1) / 20
+        b18.run_optimize(sync=True, profile=True)
+        fam18 = b18.last_timing(); cnt18 = b18.last_counts()
+        b18.close()
+        extra["reference_shape_n18_vo8"] = {"workload": f"{n18} windows, N=18 KF, Nvo=8, L={args.landmarks}, full backendOptimization()", "ms_per_step": 1e3 * t18,
+                                            "value": n18 / t18, "unit": "windows/s",
+                                            "build_solve_avg_launch_us": 1e3 * float(fam18[4]) / max(int(cnt18[1]), 1),
+                                            "ms_per_optimize_single_window": single_window_ms(18, 8, w18, mo18)}
+
+        # ---- PCIe-inclusive rate (never `value`): what a caller handing over HOST buffers sees --------------------------
         w2 = [w.clone() for w in windows]               # download() writes into the windows: use a second copy
         ptrs = be.marshal(w2)                           # ctypes marshalling is the Python harness's cost, not the C ABI's
         t1 = time.perf_counter()
@@ -178,82 +365,81 @@ def main():
         Lw = sum(w.L for w in windows) / W
         n_lin, n_bs, n_sw = max(int(cnt[0]), 1), max(int(cnt[1]), 1), max(int(cnt[2]), 1)
         win_iters = max(int(cnt[3]), 1)                 # window-iterations that were linearised + solved (gated windows excluded)
-        lin_ms, sw_ms, r1_ms, bs_ms = float(fam[1]), float(fam[2]), float(fam[3]), float(fam[4])
+        lin_ms, sw_ms, r1_ms, bs_ms, dg_ms, sc_ms = (float(fam[i]) for i in range(1, 7))
         # ALGORITHMIC work of one window-iteration
         tvis = (36 * N * (N + 1) // 2 + 18 * N) * 8.0
         bytes_lin = Fw * (24.0 + 280.0) + Lw * (32.0 + 104.0)      # in: factor record, observation (+ landmark depth / host point); out: 224 B strip, cost, 48 B w (+ landmark scalars, host w)
         bytes_sweep = Fw * (26 * 8.0 + 4.0) + tvis                 # [J_i | J_j | r] of every factor once + the permutation; out: packed pose blocks, gradient, diagonal
         bytes_rank1 = (Fw + Lw) * 48.0 + Lw * 20.0 + 2.0 * tvis    # packed w vectors, {c_l, g_l}, metadata; read-modify-write of the packed blocks
-
-        def bs_flops(N):
-            M = N // 2
-            lo = lambda i: i - 1 if i > M else 0
-            hi = lambda i: i + 1 if i < M else N - 1
-            par = lambda i: i + 1 if i < M else (i - 1 if i > M else -1)
-            fl = 0.0
-            for i in range(N):
-                nr = hi(i) - lo(i) + 1
-                fl += 2 * 9 ** 3 / 6.0 * 2                                   # Cholesky + inverse of the 9x9 block
-                fl += ((9 if par(i) >= 0 else 0) + 6 * nr + 1) * 45 * 2      # [C; Y; y^T] L^-T
-                if par(i) >= 0:
-                    fl += (45 + 54 * nr + 9) * 9 * 2                         # parent downdates
-            for I in range(N):
-                for J in range(I + 1):
-                    cover = sum(1 for i in range(N) if lo(i) <= J and I <= hi(i))
-                    fl += cover * (21 if I == J else 36) * 9 * 2             # Spp -= Y Y^T
-            for J in range(N):
-                m = N - J - 1
-                fl += 2 * 6 ** 3 / 6.0 * 2 + (6 * m + 1) * 21 * 2 + (m * (m + 1) / 2 * 36 + 6 * m) * 6 * 2
-            fl += 2 * (6 * N) ** 2 + 4 * N * 81 * 2 + 4 * sum((hi(i) - lo(i) + 1) * 54 for i in range(N)) * 2   # triangular solves + gathers
-            fl += 6.0 * (N * (N + 1) / 2 * 36 + 162 * N + sum((hi(i) - lo(i) + 1) * 54 for i in range(N)))     # scaling, u^T T u, LM diagonal
-            return fl
+        # k_dogleg: back-substitution from the packed w vectors (48 B / observation) + landmark scalars in (5) / out (4)
+        # + tangent vectors + candidate states + IMU / prior J^T J blocks for the model cost
+        bytes_dogleg = (Fw + Lw) * 48.0 + Lw * 72.0 + 15 * N * 8.0 * 8 + 2 * 16 * N * 8.0 + (N - 1) * (495 + 64 + 225) * 8.0
+        # k_step_control: factor record + observation + landmark depth (x and candidate) per factor, states
+        bytes_control = Fw * 24.0 + Lw * (24.0 + 24.0) + 3 * 16 * N * 8.0
         flops_bs = bs_flops(N)
         pmc = {}
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-        except Exception:
-            pmc = {}
+        for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
+                break
+            except Exception:
+                pmc = {}
 
-        def roof(kernel, bound, work_per_winiter, ms_sum, launches, peak, unit, scale):
+        def roof(kernel, bound, work_per_winiter, ms_sum, launches, peak, unit, scale, note=None):
             # achieved = algorithmic work of all launches / their total duration (gated windows do no work)
             ach = work_per_winiter * win_iters / (ms_sum * 1e-3) / scale if ms_sum > 0 else None
             t = pmc.get(kernel, {}).get("hbm_bytes_per_launch") if pmc.get("windows_per_gpu") == W else None
-            return {"kernel": kernel, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
-                    "frac": (ach / peak) if ach else None, "traffic": t,
-                    "avg_launch_us": ms_sum / launches * 1e3 if ms_sum > 0 else None, "launches_per_step": launches,
-                    "algorithmic_work_per_window_iteration": work_per_winiter}
+            r = {"kernel": kernel, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
+                 "frac": (ach / peak) if ach else None, "traffic": t,
+                 "avg_launch_us": ms_sum / launches * 1e3 if ms_sum > 0 else None, "launches_per_step": launches,
+                 "algorithmic_work_per_window_iteration": work_per_winiter}
+            if note:
+                r["note"] = note
+            return r
 
-        roofs = [roof("k_build_solve_sb", "mfma", flops_bs, bs_ms, n_bs, FP64_PEAK_TFLOPS, "TFLOP/s", 1e12),
+        roofs = [roof("k_build_solve_sb", "fp64-valu-latency", flops_bs, bs_ms, n_bs, FP64_PEAK_TFLOPS, "TFLOP/s", 1e12,
+                      "issues NO MFMA: chains of dependent 6x6 / 9x9 FP64 pivots (v_readlane -> rsq -> Newton) in LDS; priced against the FP64 vector peak, which equals the FP64 matrix peak on MI355X"),
                  roof("k_proj_linearize<0>", "hbm", bytes_lin, lin_ms, n_lin, HBM_PEAK_GBS, "GB/s", 1e9),
                  roof("k_sweep_mfma", "hbm", bytes_sweep, sw_ms, n_sw, HBM_PEAK_GBS, "GB/s", 1e9),
-                 roof("k_rank1_mfma", "hbm", bytes_rank1, r1_ms, n_sw, HBM_PEAK_GBS, "GB/s", 1e9)]
-        sums = {"k_build_solve_sb": bs_ms, "k_proj_linearize<0>": lin_ms, "k_sweep_mfma": sw_ms, "k_rank1_mfma": r1_ms}
+                 roof("k_rank1_mfma", "hbm", bytes_rank1, r1_ms, n_sw, HBM_PEAK_GBS, "GB/s", 1e9),
+                 roof("k_dogleg", "hbm", bytes_dogleg, dg_ms, args_iters(be), HBM_PEAK_GBS, "GB/s", 1e9),
+                 roof("k_step_control", "hbm", bytes_control, sc_ms, args_iters(be), HBM_PEAK_GBS, "GB/s", 1e9)]
+        sums = {"k_build_solve_sb": bs_ms, "k_proj_linearize<0>": lin_ms, "k_sweep_mfma": sw_ms, "k_rank1_mfma": r1_ms, "k_dogleg": dg_ms, "k_step_control": sc_ms}
         dominant = max(roofs, key=lambda r: sums[r["kernel"]])
+        total_w = world * W
         out = {
             "metric": "sliding-window solves/sec (11 KF, ~300 landmarks)", "value": value, "unit": "windows/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "ms_per_optimize_batched": ms_step / W,
-            "ms_per_optimize_single_window": ms_single,      # one resident window on a second handle, HIP events
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{W} independent synthetic sliding windows per GPU (N={N} KF, Nvo={args.vo}, L={L} landmarks, F~{Fw:.0f} reprojection factors each; BASELINE config 4 batch of config-2 windows), full backendOptimization(): NUM_ITERATIONS=10 dogleg iterations + update() + double2vector + MargForward/MargBackward on every window",
-                       "windows_per_gpu": W, "frames": N, "landmarks": L, "factors_total": Ftot, "iterations_cap": 10,
-                       "parallelism": f"independent windows sharded over {world} rank(s), no data-path collective"},
+            "ms_per_optimize_single_window": extra.get("ms_per_optimize_single_window"),      # one resident window on a second handle, HIP events
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{W} independent synthetic sliding windows per GPU (N={N} KF, Nvo={args.vo}, L={L} landmarks, F~{Fw:.0f} reprojection factors each; BASELINE config 4 batch of config-2 windows), full backendOptimization(): NUM_ITERATIONS=10 dogleg iterations + update() + double2vector + MargForward/MargBackward on every window"
+                                   + ("" if world == 1 else f"; + one RCCL all-gather of the {total_w} per-window result records ({rec * 8} B each) per step"),
+                       "windows_per_gpu": W, "windows_total": total_w, "frames": N, "landmarks": L, "factors_total": Ftot, "iterations_cap": 10,
+                       "parallelism": f"independent windows block-partitioned over {world} rank(s) ({args.scaling} scaling), no collective inside the solve"
+                                      + ("" if world == 1 else "; exchange step = ncclAllGather of the result records on device buffers"),
+                       "ranks_seen_by_the_collective": ranks_seen, "collective_backend": None if world == 1 else ("gloo (one-GPU rehearsal)" if rehearsal else "nccl (RCCL)")},
             "roofline": dominant, "roofline_by_kernel": roofs,
             "host_buffers_inclusive": None if t_incl is None else {
                 "value": W / t_incl, "unit": "windows/s", "ms_per_batch": 1e3 * t_incl,
                 "pipelined_two_handles": {"value": W / t_pipe, "unit": "windows/s", "ms_per_batch": 1e3 * t_pipe},
                 "ms_upload": 1e3 * t_up, "ms_optimize": 1e3 * t_opt, "ms_download": 1e3 * (t_incl - t_up - t_opt),
                 "what": "one isv_batch_upload (host packing + H2D) + isv_batch_optimize + isv_batch_download (D2H) of the same batch, pageable host buffers; packing on min(8, cores) host threads"},
-            "kernel_ms": {"profiled_step_total_events": float(fam[0]), "proj_linearize_sum": lin_ms, "sweep_mfma_sum": sw_ms, "rank1_mfma_sum": r1_ms, "build_solve_sum": bs_ms, "window_iterations": win_iters},
+            "kernel_ms": {"profiled_step_total_events": float(fam[0]), "proj_linearize_sum": lin_ms, "sweep_mfma_sum": sw_ms, "rank1_mfma_sum": r1_ms, "build_solve_sum": bs_ms,
+                          "dogleg_sum": dg_ms, "step_control_sum": sc_ms, "window_iterations": win_iters},
+            "cpu_baseline": cpu,
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(windows, be.cfg)
-        else:
-            out["cpu_baseline"] = None
+        for k in ("config2_single_window_linearize", "strong_scaling_shard", "reference_shape_n18_vo8"):
+            if k in extra:
+                out[k] = extra[k]
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def args_iters(be):
+    return max(int(be.cfg.num_iterations), 1)
 
 
 if __name__ == "__main__":

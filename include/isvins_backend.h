@@ -260,9 +260,18 @@ int  isv_batch_sync(isv_backend_t *h);
 /* HIP-event timing of the last isv_batch_* launch sequence, milliseconds, per kernel family:
  * after isv_batch_linearize: out[0]=total, [1]=k_proj_linearize, [2]=imu+prior+reduce;
  * after isv_batch_optimize:  out[0]=total; after a profiling pass (sync bit 1) also the sums over the
- * iterations of [1]=k_proj_linearize<0>, [2]=k_sweep_mfma, [3]=k_rank1_mfma, [4]=k_build_solve*.
+ * iterations of [1]=k_proj_linearize<0>, [2]=k_sweep_mfma, [3]=k_rank1_mfma, [4]=k_build_solve*, [5]=k_dogleg,
+ * [6]=k_step_control.
  * Events are recorded on the handle's own stream.                                          */
 int  isv_batch_last_timing(isv_backend_t *h, double out_ms[8]);
+/* Multi-GPU exchange step (the reference has no counterpart: it is one process): per-window RESULT RECORDS
+ * of the resident batch, written into a caller-owned DEVICE buffer [n][isv_result_record_doubles()] so that the caller
+ * can all-gather them over RCCL without a host copy.  record = [para_Pose 7N | para_SpeedBias 9N | inverse depths zero
+ * padded to max_landmarks | final_cost initial_cost iterations termination num_successful radius header0 n_landmarks].
+ * `stream` (a hipStream_t, may be NULL = the handle's stream): the pack kernel is ordered after everything enqueued on
+ * the handle's stream and runs on `stream`, so a collective enqueued on `stream` afterwards needs no host sync.       */
+int64_t isv_result_record_doubles(const isv_backend_t *h);
+int  isv_batch_pack_results(isv_backend_t *h, void *device_dst, void *stream);
 /* last optimize: [0] k_proj_linearize<0> launches, [1] k_build_solve* launches, [2] k_sweep_mfma / k_rank1_mfma launches,
  * [3] window-iterations that were linearised and solved (windows gated out of an iteration do no work) */
 int  isv_batch_last_counts(isv_backend_t *h, int64_t out[8]);

@@ -23,7 +23,8 @@ STATUS = {0: "ISV_OK", -1: "ISV_ERR_INVALID_ARG", -2: "ISV_ERR_CAPACITY", -3: "I
 EXPORTS = ["isv_abi_version", "isv_backend_create", "isv_backend_destroy", "isv_backend_last_error",
            "isv_backend_optimize", "isv_backend_optimize_batch", "isv_backend_init_factor_graph", "isv_backend_init_factor_graph_batch", "isv_backend_triangulate", "isv_backend_solve_odometry_batch", "isv_backend_linearize",
            "isv_batch_upload", "isv_batch_optimize", "isv_batch_linearize", "isv_batch_download",
-           "isv_batch_sync", "isv_batch_last_timing", "isv_batch_last_counts"]
+           "isv_batch_sync", "isv_batch_last_timing", "isv_batch_last_counts",
+           "isv_result_record_doubles", "isv_batch_pack_results"]
 
 
 class BackendError(RuntimeError):
@@ -80,6 +81,8 @@ def load_library():
     lib.isv_batch_last_timing.argtypes = [vp, dp]
     lib.isv_batch_last_counts.argtypes = [vp, C.POINTER(C.c_int64)]
     lib.isv_debug_read.argtypes = [vp, C.c_int32, dp, C.c_int64]
+    lib.isv_result_record_doubles.argtypes = [vp]; lib.isv_result_record_doubles.restype = C.c_int64
+    lib.isv_batch_pack_results.argtypes = [vp, vp, vp]
     _lib = lib
     return lib
 
@@ -188,6 +191,14 @@ class Backend:
         sums = (abi.isv_summary_t * n)(); margs = (abi.isv_marg_result_t * n)()
         self._check(self.lib.isv_batch_download(self.h, n, ptrs if ptrs is not None else self._ptrs(windows), sums, margs), "download")
         return (list(sums), list(margs)) if as_list else (sums, margs)
+
+    def record_doubles(self):
+        return int(self.lib.isv_result_record_doubles(self.h))
+
+    def pack_results(self, device_ptr, stream=None):
+        """per-window result records of the resident batch into a caller-owned DEVICE buffer [n][record_doubles()],
+        ordered after the handle's stream and enqueued on `stream` (a hipStream_t value; None = the handle's own)"""
+        self._check(self.lib.isv_batch_pack_results(self.h, C.c_void_p(device_ptr), C.c_void_p(stream or 0)), "pack_results")
 
     def last_timing(self):
         out = np.zeros(8)

@@ -28,6 +28,7 @@ struct isv_backend {
     std::string err;
     hipStream_t stream = nullptr, stream2 = nullptr;
     hipEvent_t fj[4] = {};
+    hipEvent_t pk[2] = {};        // isv_batch_pack_results: handle stream -> caller stream -> handle stream
     hipEvent_t ev[8] = {};
     std::vector<hipEvent_t> prof_ev;      // [max_iter][ISV_PROF_FAMILIES][2]
     int prof_valid = 0;
@@ -51,6 +52,9 @@ struct isv_backend {
     double *Ps0 = nullptr, *Rs0 = nullptr, *Vs0 = nullptr, *Bas0 = nullptr, *Bgs0 = nullptr, *depth0 = nullptr, *tic0 = nullptr, *ric0 = nullptr;
     isv_se3_prior_t *se30 = nullptr; isv_linear9_t *lin90 = nullptr; isv_relpose_t *relpose0 = nullptr; isv_rollpitch_t *rollpitch0 = nullptr;
     int resident = 0;
+    int device = 0;               // the HIP device the handle was created on; every entry point re-selects it
+    double *init_scratch = nullptr, *init_kld = nullptr;   // initFactorGraph scratch, allocated on first use and kept
+    size_t init_cap = 0;
     double last_ms[8] = {};
     int64_t last_counts[8] = {};
 };
@@ -72,6 +76,9 @@ static int halloc(isv_backend *h, T **p, size_t n) {
     return ISV_OK;
 }
 #define TRY(x) do { int rc_ = (x); if (rc_ != ISV_OK) return rc_; } while (0)
+// a handle's buffers and streams live on the device it was created on; a caller may drive it from any thread
+// (fresh threads start on device 0), so every entry point selects that device first
+#define ENTER(h) HIPCHK(h, hipSetDevice((h)->device))
 
 extern "C" int isv_abi_version(void) { return ISV_ABI_VERSION; }
 
@@ -79,11 +86,15 @@ extern "C" const char *isv_backend_last_error(const isv_backend_t *h) { return h
 
 extern "C" void isv_backend_destroy(isv_backend_t *h) {
     if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->init_scratch) (void)hipFree(h->init_scratch);
+    if (h->init_kld) (void)hipFree(h->init_kld);
     for (void *p : h->allocs) (void)hipFree(p);
     for (void *p : h->hallocs) (void)hipHostFree(p);
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : h->prof_ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : h->fj) if (e) (void)hipEventDestroy(e);
+    for (auto &e : h->pk) if (e) (void)hipEventDestroy(e);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -94,9 +105,11 @@ static int create_impl(isv_backend *h) {
     int ndev = 0;
     HIPCHK(h, hipGetDeviceCount(&ndev));
     if (ndev <= 0) { h->err = "no HIP device"; return ISV_ERR_DEVICE; }
+    HIPCHK(h, hipGetDevice(&h->device));
     HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIPCHK(h, hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     for (auto &e : h->fj) HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto &e : h->pk) HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto &e : h->ev) HIPCHK(h, hipEventCreate(&e));
     h->prof_ev.assign((size_t)c.num_iterations * ISV_PROF_FAMILIES * 2, nullptr);
     for (auto &e : h->prof_ev) HIPCHK(h, hipEventCreate(&e));
@@ -108,6 +121,9 @@ static int create_impl(isv_backend *h) {
     d.n_prior_slots = 2 + (c.n_vo - 1) + c.max_rollpitch;
     d.max_lm = c.max_landmarks > 1 ? c.max_landmarks : 1;
     d.force_retry = getenv("ISV_DEBUG_FORCE_RETRY") ? atoi(getenv("ISV_DEBUG_FORCE_RETRY")) : 0;
+    d.force_invalid = getenv("ISV_DEBUG_FORCE_INVALID") ? atoi(getenv("ISV_DEBUG_FORCE_INVALID")) : 0;
+    d.min_radius = getenv("ISV_DEBUG_MIN_RADIUS") ? atof(getenv("ISV_DEBUG_MIN_RADIUS")) : 1e-32;
+    if (!(d.min_radius > 0)) d.min_radius = 1e-32;
     d.prior_strip_sz = PR_REL0 + PR_REL_SZ * (c.n_vo - 1) + PR_RP_SZ * c.max_rollpitch;
     memcpy(d.proj_sqrt_info, c.proj_sqrt_info, sizeof(d.proj_sqrt_info));
     memcpy(d.G, c.gravity, sizeof(d.G));
@@ -197,7 +213,15 @@ static int pack_window(isv_backend *h, int b, const isv_window_t *w, size_t L, s
     memcpy(s.Vs + (size_t)b * N * 3, w->Vs, sizeof(double) * N * 3); memcpy(s.Bas + (size_t)b * N * 3, w->Bas, sizeof(double) * N * 3);
     memcpy(s.Bgs + (size_t)b * N * 3, w->Bgs, sizeof(double) * N * 3);
     memcpy(s.tic + (size_t)b * 3, w->tic, 24); memcpy(s.ric + (size_t)b * 9, w->ric, 72);
-    if (!finite_all(w->Ps, N * 3) || !finite_all(w->Rs, N * 9) || !finite_all(w->Vs, N * 3)) return ISV_ERR_NONFINITE;
+    // every real the device will read is checked here: a NaN / Inf that reached the solve would only surface as a
+    // non-finite cost many kernels later (the reference has no such check: it asserts or silently diverges)
+    if (!finite_all(w->Ps, N * 3) || !finite_all(w->Rs, N * 9) || !finite_all(w->Vs, N * 3) || !finite_all(w->Bas, N * 3) ||
+        !finite_all(w->Bgs, N * 3) || !finite_all(w->tic, 3) || !finite_all(w->ric, 9) ||
+        (w->n_landmarks > 0 && (!finite_all(w->lm_depth, w->n_landmarks) || !finite_all(w->obs_point, (size_t)w->n_obs * 3))) ||
+        !finite_all((const double *)w->imu, (size_t)(N - 1) * (sizeof(isv_imu_t) / sizeof(double))) ||
+        !finite_all(w->pose_prior->t, 3 + 9 + 36) || !finite_all(w->vb_prior->VB, 9 + 81)) { err = "non-finite input"; return ISV_ERR_NONFINITE; }
+    for (int i = 0; i < c.n_vo - 1; i++) if (!finite_all(w->relpose[i].delta_t, 3 + 9 + 36)) { err = "non-finite relative-pose prior"; return ISV_ERR_NONFINITE; }
+    for (int i = 0; i < w->n_rollpitch; i++) if (!finite_all(w->rollpitch[i].R, 9 + 4)) { err = "non-finite roll/pitch prior"; return ISV_ERR_NONFINITE; }
     for (int l = 0; l < w->n_landmarks; l++) {
         const int hst = w->lm_start_frame[l], o0 = w->lm_obs_ptr[l], k = w->lm_obs_ptr[l + 1] - o0;
         s.lm_host[L] = hst; s.lm_k[L] = k; s.lm_f0[L] = (int32_t)F;
@@ -298,6 +322,7 @@ static int host_threads(int n) {
 // tracks and fixes every window's landmark / factor / tile offsets; pass 2 packs the windows on host threads.
 extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const *ws) {
     if (!h || !ws || n < 1) return ISV_ERR_INVALID_ARG;
+    ENTER(h);
     const auto t_up0 = std::chrono::steady_clock::now();
     if ((size_t)n > h->capB) { h->err = "batch larger than max_batch"; return ISV_ERR_CAPACITY; }
     const isv_config_t &c = h->cfg;
@@ -419,12 +444,14 @@ static int enqueue_linearize(isv_backend *h, bool timed) {
 
 extern "C" int isv_batch_sync(isv_backend_t *h) {
     if (!h) return ISV_ERR_INVALID_ARG;
+    ENTER(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     return ISV_OK;
 }
 
 extern "C" int isv_batch_linearize(isv_backend_t *h, int32_t sync) {
     if (!h || !h->resident) return ISV_ERR_INVALID_ARG;
+    ENTER(h);
     DevBatch &d = h->d; hipStream_t st = h->stream;
     memset(h->last_counts, 0, sizeof(h->last_counts));
     HIPCHK(h, hipEventRecord(h->ev[0], st));
@@ -439,14 +466,15 @@ extern "C" int isv_batch_linearize(isv_backend_t *h, int32_t sync) {
 
 extern "C" int isv_batch_last_timing(isv_backend_t *h, double out_ms[8]) {
     if (!h || !out_ms) return ISV_ERR_INVALID_ARG;
+    ENTER(h);
     HIPCHK(h, hipStreamSynchronize(h->stream));
     float ms = 0;
     for (int i = 0; i < 8; i++) out_ms[i] = 0;
     if (hipEventElapsedTime(&ms, h->ev[0], h->ev[4]) == hipSuccess) out_ms[0] = ms;
     if (hipEventElapsedTime(&ms, h->ev[1], h->ev[2]) == hipSuccess) out_ms[1] = ms;
     if (hipEventElapsedTime(&ms, h->ev[2], h->ev[3]) == hipSuccess) out_ms[2] = ms;
-    if (h->prof_valid) {     // profiled optimize: [1] = sum k_proj_linearize<0>, [2] = sum k_sweep_mfma, [3] = sum k_rank1_mfma, [4] = sum k_build_solve*
-        out_ms[1] = out_ms[2] = out_ms[3] = out_ms[4] = 0;
+    if (h->prof_valid) {     // profiled optimize: [1] = sum k_proj_linearize<0>, [2] = sum k_sweep_mfma, [3] = sum k_rank1_mfma, [4] = sum k_build_solve*, [5] = sum k_dogleg, [6] = sum k_step_control
+        for (int i = 1; i <= ISV_PROF_FAMILIES; i++) out_ms[i] = 0;
         for (int slot = 0; slot < h->cfg.num_iterations; slot++)
             for (int fam = 0; fam < ISV_PROF_FAMILIES; fam++) {
                 const size_t b = ((size_t)slot * ISV_PROF_FAMILIES + fam) * 2;
@@ -459,6 +487,7 @@ extern "C" int isv_batch_last_timing(isv_backend_t *h, double out_ms[8]) {
 
 extern "C" int isv_batch_last_counts(isv_backend_t *h, int64_t out[8]) {
     if (!h || !out) return ISV_ERR_INVALID_ARG;
+    ENTER(h);
     memcpy(out, h->last_counts, sizeof(h->last_counts));
     if (h->d.lds_T && h->d.act) {          // [3] = window-iterations that were linearised and solved in the last optimize
         int32_t act[ISV_MAX_TRACE];
@@ -471,6 +500,7 @@ extern "C" int isv_batch_last_counts(isv_backend_t *h, int64_t out[8]) {
 
 extern "C" int isv_batch_optimize(isv_backend_t *h, int32_t sync) {
     if (!h || !h->resident) return ISV_ERR_INVALID_ARG;
+    ENTER(h);
     DevBatch &d = h->d; hipStream_t st = h->stream;
     memset(h->last_counts, 0, sizeof(h->last_counts));
     HIPCHK(h, hipMemsetAsync(d.act, 0, sizeof(int32_t) * ISV_MAX_TRACE, st));
@@ -489,6 +519,7 @@ extern "C" int isv_batch_optimize(isv_backend_t *h, int32_t sync) {
 extern "C" int isv_batch_download(isv_backend_t *h, int32_t n, isv_window_t *const *ws, isv_summary_t *summary,
                                   isv_marg_result_t *marg) {
     if (!h || !ws || n != h->resident) return ISV_ERR_INVALID_ARG;
+    ENTER(h);
     DevBatch &d = h->d; hipStream_t st = h->stream; auto &s = h->h; const isv_config_t &c = h->cfg;
     const size_t N = d.N, L = d.Ltot;
 #define D2H(dst, src, cnt) HIPCHK(h, hipMemcpyAsync(dst, src, sizeof(*(src)) * (size_t)(cnt), hipMemcpyDeviceToHost, st))
@@ -563,11 +594,18 @@ extern "C" int isv_backend_init_factor_graph_batch(isv_backend_t *h, int32_t n, 
     TRY(isv_batch_upload(h, n, ws));
     DevBatch &d = h->d; hipStream_t st = h->stream;
     const size_t per = init_priors_scratch_doubles(c.n_vo);
-    double *scratch = nullptr, *kld_dev = nullptr;
-    if (hipMalloc(&scratch, (size_t)n * per * sizeof(double)) != hipSuccess || hipMalloc(&kld_dev, (size_t)n * sizeof(double)) != hipSuccess) {
-        if (scratch) (void)hipFree(scratch);
-        h->err = "initFactorGraph: scratch allocation failed"; return ISV_ERR_DEVICE;
+    if ((size_t)n > h->init_cap) {          // scratch of the one-time step: allocated on first use, kept with the handle
+        if (h->init_scratch) (void)hipFree(h->init_scratch);
+        if (h->init_kld) (void)hipFree(h->init_kld);
+        h->init_scratch = h->init_kld = nullptr; h->init_cap = 0;
+        if (hipMalloc(&h->init_scratch, (size_t)n * per * sizeof(double)) != hipSuccess || hipMalloc(&h->init_kld, (size_t)n * sizeof(double)) != hipSuccess) {
+            if (h->init_scratch) (void)hipFree(h->init_scratch);
+            h->init_scratch = nullptr;
+            h->err = "initFactorGraph: scratch allocation failed"; return ISV_ERR_DEVICE;
+        }
+        h->init_cap = (size_t)n;
     }
+    double *scratch = h->init_scratch, *kld_dev = h->init_kld;
     const int saved_iter = d.max_iter;
     d.max_iter = 3 * c.num_iterations < ISV_MAX_TRACE - 1 ? 3 * c.num_iterations : ISV_MAX_TRACE - 1;
     d.init_mode = 1; d.init_scratch = scratch; d.init_per_window = per; d.init_kld = kld_dev;
@@ -582,7 +620,6 @@ extern "C" int isv_backend_init_factor_graph_batch(isv_backend_t *h, int32_t n, 
     d.max_iter = saved_iter; d.init_mode = 0; d.init_scratch = nullptr; d.init_kld = nullptr;
     if (rc == ISV_OK) rc = isv_batch_download(h, n, ws, summary, nullptr);
     if (rc == ISV_OK && kld && hipMemcpy(kld, kld_dev, (size_t)n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) rc = ISV_ERR_DEVICE;
-    (void)hipFree(scratch); (void)hipFree(kld_dev);
     h->resident = 0;
     return rc;
 }
@@ -638,6 +675,7 @@ extern "C" int isv_backend_solve_odometry_batch(isv_backend_t *h, int32_t n, isv
 extern "C" int isv_backend_linearize(isv_backend_t *h, const isv_window_t *w, double *proj_strips, double *imu_strips,
                                      double *cost) {
     if (!h || !w) return ISV_ERR_INVALID_ARG;
+    ENTER(h);
     isv_window_t *ws[1] = {const_cast<isv_window_t *>(w)};
     TRY(isv_batch_upload(h, 1, ws));
     TRY(isv_batch_linearize(h, 1));
@@ -650,9 +688,51 @@ extern "C" int isv_backend_linearize(isv_backend_t *h, const isv_window_t *w, do
     return ISV_OK;
 }
 
+// ---- per-window result records in DEVICE memory (the one exchange step of the multi-GPU configuration is an
+// all-gather of these records; the caller owns the buffer, e.g. a torch tensor handed to RCCL) ------------------------
+// record = [para_Pose 7N | para_SpeedBias 9N | inverse depths, zero padded to max_landmarks |
+//           final_cost, initial_cost, iterations, termination, num_successful, radius, header0, n_landmarks]
+__global__ void k_pack_results(DevBatch d, double *dst, int64_t rec, int maxL) {
+    const int w = blockIdx.x, t = threadIdx.x, N = d.N;
+    double *o = dst + (size_t)w * rec;
+    for (int i = t; i < 7 * N; i += blockDim.x) o[i] = d.pose[(size_t)w * N * 7 + i];
+    for (int i = t; i < 9 * N; i += blockDim.x) o[7 * N + i] = d.sb[(size_t)w * N * 9 + i];
+    const int l0 = d.lm_off[w], Lw = d.lm_off[w + 1] - l0;
+    for (int i = t; i < maxL; i += blockDim.x) o[16 * N + i] = i < Lw ? d.lam[l0 + i] : 0.0;
+    if (t == 0) {
+        const SolveState &st = d.st[w];
+        double *q = o + 16 * N + maxL;
+        q[0] = st.x_cost; q[1] = st.initial_cost; q[2] = st.iteration; q[3] = st.termination; q[4] = st.num_successful;
+        q[5] = st.radius; q[6] = d.header0[w]; q[7] = Lw;
+    }
+}
+
+extern "C" int64_t isv_result_record_doubles(const isv_backend_t *h) {
+    return h ? 16 * (int64_t)h->cfg.n_frames + h->cfg.max_landmarks + 8 : 0;
+}
+
+extern "C" int isv_batch_pack_results(isv_backend_t *h, void *device_dst, void *stream) {
+    if (!h || !device_dst || !h->resident) return ISV_ERR_INVALID_ARG;
+    ENTER(h);
+    DevBatch &d = h->d;
+    hipStream_t dst_stream = stream ? (hipStream_t)stream : h->stream;
+    if (dst_stream != h->stream) {           // order the pack after everything enqueued on the handle's stream, without a host sync
+        HIPCHK(h, hipEventRecord(h->pk[0], h->stream));
+        HIPCHK(h, hipStreamWaitEvent(dst_stream, h->pk[0], 0));
+    }
+    hipLaunchKernelGGL(k_pack_results, dim3(d.B), dim3(256), 0, dst_stream, d, (double *)device_dst, isv_result_record_doubles(h), h->cfg.max_landmarks);
+    HIPCHK(h, hipGetLastError());
+    if (dst_stream != h->stream) {           // ... and the handle's next launch (which overwrites the states) after the pack
+        HIPCHK(h, hipEventRecord(h->pk[1], dst_stream));
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->pk[1], 0));
+    }
+    return ISV_OK;
+}
+
 // test hook: prior strips / per-block costs of window 0 after isv_backend_linearize
 extern "C" int isv_debug_read(isv_backend_t *h, int32_t what, double *out, int64_t count) {
     if (!h || !out) return ISV_ERR_INVALID_ARG;
+    ENTER(h);
     DevBatch &d = h->d; hipStream_t st = h->stream;
     const double *src = nullptr;
     switch (what) {

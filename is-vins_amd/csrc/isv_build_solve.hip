@@ -94,7 +94,7 @@ __global__ __launch_bounds__(BS_THREADS) void k_build_solve(DevBatch d) {
     const int l0 = d.lm_off[w], l1 = d.lm_off[w + 1];
     const int iteration = st.iteration;
     double mu = st.mu;
-    int ls_fail = 0;
+    int ls_fail = 0, assembled = 0;
     double gmax_l = 0.0;
 
 #ifdef ISV_STAMP
@@ -102,6 +102,7 @@ __global__ __launch_bounds__(BS_THREADS) void k_build_solve(DevBatch d) {
 #endif
     for (;;) {
         if (!(mu < 1.0)) { ls_fail = 1; break; }      // while (mu_ < max_mu_) of ComputeGaussNewtonStep
+        assembled = 1;
         for (int e = t; e < nblkT; e += BS_THREADS) T[e] = 0.0;
         for (int e = t; e < n; e += BS_THREADS) { g[e] = 0.0; bs[e] = 0.0; hdiag[e] = 0.0; }
         if (t == 0) flag[0] = 0;
@@ -461,7 +462,8 @@ __global__ __launch_bounds__(BS_THREADS) void k_build_solve(DevBatch d) {
         for (int off = BS_THREADS / 2; off > 0; off >>= 1) { if (t < off) red[t] = fmax(red[t], red[t + off]); __syncthreads(); }
     }
     if (t == 0) {
-        st.gmax = red[0];
+        // (mu already at max_mu on entry: nothing was assembled, x has not moved, the gradient is the previous one)
+        if (assembled) st.gmax = red[0];
         st.mu = mu;
         st.ls_fail = ls_fail;
         st.need_linearize = 0;

@@ -147,7 +147,7 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
 #endif
     const int iteration = st.iteration;
     double mu = st.mu;
-    int ls_fail = 0, attempt = 0;
+    int ls_fail = 0, attempt = 0, assembled = 0;
     double gmax_l = 0.0;
     const int l0 = d.lm_off[w], l1 = d.lm_off[w + 1];
     const double *V = d.Tvis + (size_t)w * d.tvis_sz;
@@ -164,6 +164,7 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
     const int t_outer = t;
     for (;;) {
         if (!(mu < 1.0)) { ls_fail = 1; break; }
+        assembled = 1;
         // the retry loop almost never iterates: keep the compiler from hoisting per-thread index math out of
         // it (the hoisted values stay live across the whole body and spill)
         int t = t_outer;
@@ -766,7 +767,8 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
     }
     if (t == 0) {
         atomicAdd(&d.act[iteration], 1);
-        st.gmax = red[0];
+        // (mu already at max_mu on entry: nothing was assembled, x has not moved, the gradient is the previous one)
+        if (assembled) st.gmax = red[0];
         st.mu = mu;
         st.ls_fail = ls_fail;
         st.need_linearize = 0;

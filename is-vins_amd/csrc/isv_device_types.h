@@ -120,4 +120,8 @@ struct DevBatch {
     int32_t force_retry, init_mode;       // init_mode: this enqueue is Estimator::initFactorGraph (no update(), no marginalisation)            // test hook (env ISV_DEBUG_FORCE_RETRY): treat the first n factorisations of an iteration as failed
     int32_t prior_H_sz, tvis_sz, wd_ld, max_lm;   // wd_ld: panel width of k_rank1_mfma (6N + 1 rounded up to 16); max_lm: landmarks per window cap
     int32_t marg_scratch_sz, lds_T;     // lds_T: reduced system lives in LDS (15N <= 165)
+    // test hooks (env, read at create; the oracle has the same two): ISV_DEBUG_FORCE_INVALID = treat the first n
+    // trust-region steps as invalid; ISV_DEBUG_MIN_RADIUS overrides min_trust_region_radius (1e-32)
+    int32_t force_invalid, _pad2;
+    double min_radius;
 };

@@ -23,7 +23,7 @@ static inline size_t prior_lds_bytes(int slots, bool jac = true) { return (size_
 __global__ void k_triangulate(DevBatch d);
 __global__ void k_imu_raw(DevBatch d, const double *pose_src, const double *sb_src, int gate);
 __global__ void k_imu_weight(DevBatch d, double *cost_out, int gate);
-#define ISV_PROF_FAMILIES 4      // 0 = k_proj_linearize<0>, 1 = k_sweep_mfma, 2 = k_rank1_mfma, 3 = k_build_solve*
+#define ISV_PROF_FAMILIES 6      // 0 = k_proj_linearize<0>, 1 = k_sweep_mfma, 2 = k_rank1_mfma, 3 = k_build_solve*, 4 = k_dogleg, 5 = k_step_control
 // pinned staging for the result records (capacity max_batch): asynchronous device-to-host copies into pageable
 // memory go through the runtime's own staging and may complete lazily, which stalled the NEXT upload by 13-30 ms for
 // batches above ~1 MB of records

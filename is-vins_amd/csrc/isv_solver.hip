@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <cstdio>
+#include <cstdlib>
+#include <mutex>
 #include "isv_kernels.h"
 #include "isv_device_math.h"
 #include "isv_proj_factor.h"
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(256) void k_step_control(DevBatch d) {
         double *tc = d.trace_cost + (size_t)w * ISV_MAX_TRACE, *tr = d.trace_radius + (size_t)w * ISV_MAX_TRACE;
         double *ts = d.trace_step + (size_t)w * ISV_MAX_TRACE; int32_t *ta = d.trace_acc + (size_t)w * ISV_MAX_TRACE;
         const double model_cost_change = -M;
-        const bool valid = st.step_valid && (model_cost_change > 0.0);
+        const bool valid = st.step_valid && (model_cost_change > 0.0) && !(it <= d.force_invalid);
         d.cost_c[w] = S; d.model[w] = M;
         if (!valid) {                                       // HandleInvalidStep
             st.invalid += 1;
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(256) void k_step_control(DevBatch d) {
                 }
                 // FinalizeIterationAndCheckIfMinimizerCanContinue (gradient tolerance: k_build_solve)
                 if (it >= d.max_iter) st.termination = ISV_TERM_MAX_ITERATIONS;
-                else if (st.radius <= 1e-32) st.termination = ISV_TERM_MIN_RADIUS;
+                else if (st.radius <= d.min_radius) st.termination = ISV_TERM_MIN_RADIUS;
             }
         }
     }
@@ -519,6 +521,7 @@ static int dal(T **p, size_t n, std::vector<void *> &allocs, std::string &err) {
     return ISV_OK;
 }
 #define TRYA(x) do { int rc_ = (x); if (rc_ != ISV_OK) return rc_; } while (0)
+static std::mutex g_lds_attr_mutex;
 
 int isv_solver_alloc(DevBatch &d, size_t B, size_t L, size_t F, std::vector<void *> &allocs, std::string &err) {
     const size_t n = d.np, NI = B * (d.N - 1);
@@ -550,11 +553,16 @@ int isv_solver_alloc(DevBatch &d, size_t B, size_t L, size_t F, std::vector<void
     if (getenv("ISV_DEBUG_PATH")) fprintf(stderr, "isv: N=%d wd_ld=%d prior_H_sz=%d lds_sb=%zu lds_r1=%zu lds_sw=%zu -> lds_T=%d\n", d.N, d.wd_ld, d.prior_H_sz, lds_sb, lds_r1, lds_sw, d.lds_T);
     TRYA(dal(&d.Tglob, d.lds_T ? 1 : B * nblkT, allocs, err));
     d.sw_part = nullptr; d.sw_global = 0;
-    if (d.lds_T && sw_global) TRYA(dal(&d.sw_part, B * n_pairs * 84, allocs, err));
+    // ISV_DEBUG_SW_GLOBAL=1 (test hook): give every LDS-path handle the global pair-partial scratch and use it for
+    // every launch, so that small batches exercise the variant large N >= 12 batches run
+    if (d.lds_T && (sw_global || getenv("ISV_DEBUG_SW_GLOBAL"))) TRYA(dal(&d.sw_part, B * n_pairs * 84, allocs, err));
     d.marg_scratch_sz = 26;
     TRYA(dal(&d.marg_scratch, L * 26, allocs, err));
+    int dev_ = 0;
+    HCHK(hipGetDevice(&dev_));
     if (d.lds_T) {
-#define SETLDS(K, BYTES) HCHK(hipFuncSetAttribute((const void *)K, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES)))
+        // the attribute is per kernel (and device) and process-wide: handles of different shapes must not lower each other's value
+#define SETLDS(K, BYTES) do { static size_t cur_[64] = {}; std::lock_guard<std::mutex> lk_(g_lds_attr_mutex); if ((size_t)(BYTES) > cur_[dev_ & 63]) { HCHK(hipFuncSetAttribute((const void *)K, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES))); cur_[dev_ & 63] = (size_t)(BYTES); } } while (0)
         SETLDS((k_rank1_mfma<1, 1, 64, 1>), lds_r1); SETLDS((k_rank1_mfma<2, 1, 64, 1>), lds_r1); SETLDS((k_rank1_mfma<3, 1, 64, 1>), lds_r1);
         SETLDS((k_rank1_mfma<4, 1, 64, 1>), lds_r1); SETLDS((k_rank1_mfma<5, 1, 64, 1>), lds_r1); SETLDS((k_rank1_mfma<6, 2, 64, 1>), lds_r1);
         SETLDS((k_rank1_mfma<7, 2, 64, 1>), lds_r1); SETLDS((k_rank1_mfma<8, 3, 64, 1>), lds_r1);
@@ -562,7 +570,12 @@ int isv_solver_alloc(DevBatch &d, size_t B, size_t L, size_t F, std::vector<void
         if (d.N <= 11) SETLDS(k_build_solve_sb<false>, lds_sb); else SETLDS(k_build_solve_sb<true>, lds_sb);
 #undef SETLDS
     }
-    else HCHK(hipFuncSetAttribute((const void *)k_build_solve<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)build_solve_lds_bytes(d.N, false)));
+    else {
+        static size_t cur_bs[64] = {};
+        std::lock_guard<std::mutex> lk(g_lds_attr_mutex);
+        const size_t want = build_solve_lds_bytes(d.N, false);
+        if (want > cur_bs[dev_ & 63]) { HCHK(hipFuncSetAttribute((const void *)k_build_solve<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want)); cur_bs[dev_ & 63] = want; }
+    }
     return ISV_OK;
 }
 
@@ -594,7 +607,7 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
             PROF(slot, 1, 0);
             {
                 const size_t n_pairs = (size_t)d.N * (d.N - 1) / 2;
-                d.sw_global = (d.sw_part && d.B > 256) ? 1 : 0;     // more than one workgroup per CU: trade LDS for occupancy
+                d.sw_global = (d.sw_part && (d.B > 256 || getenv("ISV_DEBUG_SW_GLOBAL"))) ? 1 : 0;     // more than one workgroup per CU: trade LDS for occupancy
                 hipLaunchKernelGGL(k_sweep_mfma, dim3(d.B), dim3(64 * ISV_SWEEP_WAVES), ((d.sw_global ? 0 : n_pairs * 84) + (n_pairs + 2) / 2 + 1) * sizeof(double), st, d);
             }
             counts[2]++;
@@ -623,7 +636,9 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
         else hipLaunchKernelGGL(k_build_solve<false>, dim3(d.B), dim3(512), lds_bs, st, d);
         counts[1]++;
         PROF(slot, 3, 1);
+        PROF(slot, 4, 0);
         hipLaunchKernelGGL(k_dogleg, dim3(d.B), dim3(256), (d.lds_T ? ((size_t)(d.N - 1) * 48 + (size_t)d.n_prior_slots * 16) * sizeof(double) + prior_lds_bytes(d.n_prior_slots, false) : 0) + 2 * (size_t)d.np * sizeof(double), st, d);
+        PROF(slot, 4, 1);
         if (!d.lds_T) {                    // (the LDS path evaluates these inside k_dogleg)
             HCHK(hipEventRecord(fj[2], st)); HCHK(hipStreamWaitEvent(st2, fj[2], 0));
             if (NI) hipLaunchKernelGGL(k_imu_linearize<false>, dim3((unsigned)NI), dim3(64), 0, st2, d, d.cpose, d.csb, d.imu_cost_c, 2);
@@ -633,12 +648,14 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
         }
         // candidate evaluation of the reprojection factors: inside the per-window control kernel, unless the windows are
         // so large that one workgroup per window would serialise it (config 5: 30 000 factors in one window)
+        PROF(slot, 5, 0);
         if (d.lds_T && (size_t)d.Ftot <= (size_t)4096 * d.B) hipLaunchKernelGGL(k_step_control<true>, dim3(d.B), dim3(256), ((size_t)30 * d.N + 12) * sizeof(double), st, d);
         else {
             if (d.n_tiles > 0) hipLaunchKernelGGL(k_proj_linearize<1>, dim3((d.n_tiles + 3) / 4), dim3(256), lds_proj1, st, d, d.cpose, d.clam, d.fcost_c, 2);
             if (!d.lds_T) HCHK(hipStreamWaitEvent(st, fj[3], 0));
             hipLaunchKernelGGL(k_step_control<false>, dim3(d.B), dim3(256), 0, st, d);
         }
+        PROF(slot, 5, 1);
     }
     if (d.init_mode) {                     // Estimator::initFactorGraph: first priors from the solved estimate, then double2vector
         hipLaunchKernelGGL(k_init_priors, dim3(d.B), dim3(64), 0, st, d, d.init_scratch, d.init_per_window, d.init_kld);

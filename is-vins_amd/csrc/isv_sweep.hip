@@ -53,7 +53,10 @@ __global__ __launch_bounds__(64 * ISV_SWEEP_WAVES, 8) void k_sweep_mfma(DevBatch
 #define SWSTAMP(k) do {} while (0)
 #endif
     const int q0 = soff[wv], q1 = soff[wv + 1];
-    const int myrec = (q0 + lane < q1) ? sched[q0 + lane] : 0;         // this wavefront's groups (<= 64)
+    // this wavefront's group records, 64 at a time (one per lane, broadcast by __shfl); a wavefront can own MORE than
+    // 64 groups (N = 18: 153 pairs, most of them empty when the landmarks share few host frames), so the records are
+    // reloaded at every 64-group boundary
+    int myrec = (q0 + lane < q1) ? sched[q0 + lane] : 0;
     for (int e = t; e <= NP; e += blockDim.x) offL[e] = d.pg_off[(size_t)w * (NP + 1) + e];
     __syncthreads();
     SWSTAMP(40);
@@ -61,10 +64,12 @@ __global__ __launch_bounds__(64 * ISV_SWEEP_WAVES, 8) void k_sweep_mfma(DevBatch
     int nxt = 0;
     if (q0 < q1) { const int p = __shfl(myrec, 0) >> 16; const int b0 = offL[p], c0 = offL[p + 1] - b0; nxt = lane < c0 ? perm[b0 + lane] : 0; }
     for (int q = q0; q < q1; q++) {
-        const int rec = __shfl(myrec, q - q0), h = rec & 255, j = (rec >> 8) & 255, p = rec >> 16;
+        const int rel = (q - q0) & 63;
+        const int rec = __shfl(myrec, rel), h = rec & 255, j = (rec >> 8) & 255, p = rec >> 16;
         const int b0 = offL[p], b1 = offL[p + 1];
         int myf = nxt;
-        if (q + 1 < q1) { const int p2 = __shfl(myrec, q + 1 - q0) >> 16; const int b2 = offL[p2], c2 = offL[p2 + 1] - b2; nxt = lane < c2 ? perm[b2 + lane] : 0; }
+        if (rel == 63) myrec = (q + 1 + lane < q1) ? sched[q + 1 + lane] : 0;       // next 64 records (rec is already out)
+        if (q + 1 < q1) { const int p2 = __shfl(myrec, (rel + 1) & 63) >> 16; const int b2 = offL[p2], c2 = offL[p2 + 1] - b2; nxt = lane < c2 ? perm[b2 + lane] : 0; }
         double4s acc = {0, 0, 0, 0};
         for (int base = b0; base < b1; base += 64) {
             const int cnt = (b1 - base) < 64 ? (b1 - base) : 64;

@@ -1,10 +1,14 @@
-"""Multi-GPU sharding of independent sliding windows: static block partition, no
-data-path collective; ranks only agree on the slowest rank's step time."""
+"""Multi-GPU sharding of independent sliding windows: static block partition over the ranks, no
+collective inside the solve; ONE exchange step at the end -- an all-gather of the per-window result records (RCCL over
+xGMI on GPUs, gloo on CPU) -- and a max-reduction of the step time."""
 
 
-def shard_window_ids(rank, world, per_rank):
-    """weak scaling: rank r owns window ids [r * per_rank, (r + 1) * per_rank)"""
-    return range(rank * per_rank, (rank + 1) * per_rank)
+def shard_window_ids(rank, world, per_rank, total=None):
+    """weak scaling (total=None): rank r owns window ids [r * per_rank, (r + 1) * per_rank).
+    strong scaling (total given): the `total` windows are block-partitioned, rank r owns [r * total // world, (r + 1) * total // world)"""
+    if total is None:
+        return range(rank * per_rank, (rank + 1) * per_rank)
+    return range(rank * total // world, (rank + 1) * total // world)
 
 
 def max_over_ranks(value, dist=None, device="cpu"):
@@ -15,3 +19,17 @@ def max_over_ranks(value, dist=None, device="cpu"):
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def gather_records(records, out, dist=None):
+    """the exchange step: all-gather every rank's [n_local, rec] result records into out [world * n_local, rec]
+    (ncclAllGather on device tensors; ranks hold equally many windows -- pad the last shard if they do not).
+    Enqueued on the current stream; returns `out`."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        out.copy_(records)
+        return out
+    try:
+        dist.all_gather_into_tensor(out, records)
+    except (RuntimeError, NotImplementedError):           # a backend without the flat form: gather into views of `out`
+        dist.all_gather(list(out.chunk(dist.get_world_size(), dim=0)), records)
+    return out

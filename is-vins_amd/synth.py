@@ -66,20 +66,24 @@ def _exp_so3(w):
 class Trajectory:
     """body on a circle r=3 m at 0.5 m/s, yaw tangent, roll/pitch +-5 deg sinusoids"""
 
-    def __init__(self, phase):
+    def __init__(self, phase, pitch0=0.0, pitch_amp=None):
         self.r, self.v = 3.0, 0.5
         self.w = self.v / self.r
         self.ph = phase
         self.amp = np.deg2rad(5.0)
+        # (test windows only: a constant pitch offset / another pitch amplitude, e.g. a body that looks straight up,
+        # the double2vector branch of src/estimator.cpp:537-547)
+        self.p0 = pitch0
+        self.pamp = self.amp if pitch_amp is None else pitch_amp
 
     def ypr(self, t):
         y = self.w * t + self.ph + np.pi / 2
-        p = self.amp * np.sin(2 * np.pi * 0.5 * t)
+        p = self.p0 + self.pamp * np.sin(2 * np.pi * 0.5 * t)
         r = self.amp * np.sin(2 * np.pi * 0.3 * t + 1.0)
         return y, p, r
 
     def ypr_dot(self, t):
-        return (self.w, self.amp * 2 * np.pi * 0.5 * np.cos(2 * np.pi * 0.5 * t),
+        return (self.w, self.pamp * 2 * np.pi * 0.5 * np.cos(2 * np.pi * 0.5 * t),
                 self.amp * 2 * np.pi * 0.3 * np.cos(2 * np.pi * 0.3 * t + 1.0))
 
     def R(self, t):
@@ -200,16 +204,20 @@ def _track_lengths(rng, L, N, Nvo, target_F=None):
     return host.astype(np.int32), k.astype(np.int32)
 
 
-def make_windows(window_ids, n_frames=11, n_vo=5, n_landmarks=300, target_factors=None, margin_old=1):
+def make_windows(window_ids, n_frames=11, n_vo=5, n_landmarks=300, target_factors=None, margin_old=1,
+                 host_frames=None, max_track=None, pitch0_deg=0.0, pitch_amp_deg=None):
     """Build `abi.Window`s for the given ids (config 2: ids=[0]; config 4: range(1024);
-    config 5: n_frames=20, n_vo=8, n_landmarks=2000, target_factors=30000)."""
+    config 5: n_frames=20, n_vo=8, n_landmarks=2000, target_factors=30000).
+    Test-only shaping (defaults leave the SURVEY 8d generator untouched): host_frames = (lo, hi) confines the
+    landmarks' host frames to [lo, hi); max_track caps the track length; pitch0_deg / pitch_amp_deg shape the pitch."""
     N, Nvo, L = n_frames, n_vo, n_landmarks
     kf_dt, S, imu_dt = 0.1, 20, 0.005
     specs = []
     acc_all, gyr_all, ba_lin, bg_lin = [], [], [], []
     for wid in window_ids:
         rng = SplitMix64(SEED0 + int(wid))
-        traj = Trajectory(phase=2 * np.pi * rng.uniform(1)[0])
+        traj = Trajectory(phase=2 * np.pi * rng.uniform(1)[0], pitch0=np.deg2rad(pitch0_deg),
+                          pitch_amp=None if pitch_amp_deg is None else np.deg2rad(pitch_amp_deg))
         t0 = 10.0 * rng.uniform(1)[0]
         tk = t0 + kf_dt * np.arange(N)
         P = np.stack([traj.p(t) for t in tk]); R = np.stack([traj.R(t) for t in tk]); Vv = np.stack([traj.vel(t) for t in tk])
@@ -229,6 +237,12 @@ def make_windows(window_ids, n_frames=11, n_vo=5, n_landmarks=300, target_factor
                 gyr[i, s] = traj.gyro(t) + Bg[i] + GYR_N * nG[i, s]
         # landmarks
         host, k = _track_lengths(rng, L, N, Nvo, target_factors)
+        if host_frames is not None:
+            lo, hi = host_frames
+            host = (lo + host % max(hi - lo, 1)).astype(np.int32)
+            k = np.minimum(k, N - host).astype(np.int32)
+        if max_track is not None:
+            k = np.minimum(k, max_track).astype(np.int32)
         xyz = rng.uniform(3 * L).reshape(L, 3)
         pc = np.stack([-3 + 6 * xyz[:, 0], -3 + 6 * xyz[:, 1], 2 + 6 * xyz[:, 2]], -1)   # host camera frame
         n_obs = int(k.sum())

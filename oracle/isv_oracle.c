@@ -241,6 +241,14 @@ static void jac_left_mul(const problem_t *P, const double *r_in, double *g /* nc
  * DoglegStrategy::ComputeGaussNewtonStep, which well-posed windows never reach) */
 static int g_force_retry = 0;
 void isvo_debug_force_retry(int n) { g_force_retry = n; }
+/* test hooks for the terminations well-posed windows never reach (the device has the same hooks:
+ * ISV_DEBUG_FORCE_INVALID / ISV_DEBUG_MIN_RADIUS): treat the first n trust-region steps as invalid
+ * (model_cost_change <= 0, TrustRegionMinimizer::HandleInvalidStep), and override
+ * Solver::Options::min_trust_region_radius (1e-32 by default) */
+static int g_force_invalid = 0;
+static double g_min_radius = 1e-32;
+void isvo_debug_force_invalid(int n) { g_force_invalid = n; }
+void isvo_debug_min_radius(double r) { g_min_radius = r > 0 ? r : 1e-32; }
 
 static int dense_schur_solve(const problem_t *P, const double *D, double *y) {
     int np = P->np, L = P->L, N = P->N;
@@ -360,7 +368,7 @@ static void minimize(problem_t *P, int max_iter, isv_summary_t *sum) {
         /* FinalizeIterationAndCheckIfMinimizerCanContinue */
         if (it >= max_iter) { term = ISV_TERM_MAX_ITERATIONS; break; }
         if (gmax <= 1e-10) { term = ISV_TERM_GRADIENT_TOL; break; }
-        if (radius <= 1e-32) { term = ISV_TERM_MIN_RADIUS; break; }
+        if (radius <= g_min_radius) { term = ISV_TERM_MIN_RADIUS; break; }
         it++;
         /* ---- DoglegStrategy::ComputeStep ---- */
         int ls_fail = 0;
@@ -416,6 +424,7 @@ static void minimize(problem_t *P, int max_iter, isv_summary_t *sum) {
             for (int i = 0; i < P->nres; i++) mc += mres[i] * (P->res[i] + mres[i] / 2.0);
             model_cost_change = -mc;
             valid = model_cost_change > 0.0;
+            if (it <= g_force_invalid) valid = 0;
         }
         if (!valid) {                                /* HandleInvalidStep */
             if (++invalid >= 5) { term = ls_fail ? ISV_TERM_LINEAR_SOLVER : ISV_TERM_INVALID_STEPS; break; }

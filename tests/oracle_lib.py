@@ -41,6 +41,10 @@ def load():
     lib.isvo_triangulate.restype = C.c_int
     lib.isvo_debug_force_retry.argtypes = [C.c_int]
     lib.isvo_debug_force_retry.restype = None
+    lib.isvo_debug_force_invalid.argtypes = [C.c_int]
+    lib.isvo_debug_force_invalid.restype = None
+    lib.isvo_debug_min_radius.argtypes = [C.c_double]
+    lib.isvo_debug_min_radius.restype = None
     for name in dir(abi):
         pass
     _lib = lib

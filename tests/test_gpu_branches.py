@@ -1,0 +1,292 @@
+"""GPU parity (HIP path vs the CPU oracle, through the C ABI) of the reference branches and kernel variants
+that ordinary synthetic windows never reach:
+
+  - double2vector near pitch +-90 deg (src/estimator.cpp:537-547: rot_diff = Rs[0] R0^T instead of a pure yaw)
+  - MargForward with a rank-deficient Lamda_prior (src/estimator.cpp:1304-1331)
+  - the LINEAR_SOLVER / INVALID_STEPS / MIN_RADIUS terminations of ceres' TrustRegionMinimizer, with the SAME
+    fault injected on both sides (the hooks are ceres Solver::Options / failure points, not changes of the algorithm)
+  - k_build_solve<false>, the generic kernel windows of N = 21..32 frames run on
+  - k_sweep_mfma with more than 64 (host, observer) pair groups on one wavefront, and its global-scratch variant
+  - the prior factors' JACOBIANS, compared block by block (not only through the solve trace)
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from isvins_amd import abi, backend, synth
+from test_gpu_solve import check_marg, check_window, oracle_run
+
+pytestmark = pytest.mark.gpu
+dp = C.POINTER(C.c_double)
+
+
+def P(a):
+    return a.ctypes.data_as(dp)
+
+
+def _solve_pair(oracle, b, ws, marg=True):
+    gs = [w.clone() for w in ws]
+    sums, margs = b.optimize_batch(gs)
+    for w, g, s, m in zip(ws, gs, sums, margs):
+        o, so, mo = oracle_run(oracle, b.cfg, w)
+        check_window(o, so, g, s)
+        if marg:
+            check_marg(mo, m, w.Nvo)
+    return gs, sums, margs
+
+
+# ---- k_sweep_mfma: more than 64 pair groups on one wavefront -------------------------------------
+@pytest.mark.parametrize("n_frames,n_vo,n_lm", [(18, 8, 150), (18, 8, 300), (20, 8, 200)])
+def test_sweep_with_more_than_64_groups_per_wavefront(oracle, n_frames, n_vo, n_lm):
+    """every landmark hosted in frame 0 and tracked for at most 7 frames: 6 heavy (host, observer) pairs and ~150 empty
+    ones, so the longest-first schedule piles > 64 groups onto single wavefronts (85 at N = 18 with 150 landmarks)"""
+    ws = synth.make_windows([60, 61], n_frames=n_frames, n_vo=n_vo, n_landmarks=n_lm, host_frames=(0, 1), max_track=7)
+    assert all((w.lm_start_frame[: w.L] == 0).all() for w in ws)
+    b = backend.Backend(n_frames, n_vo, max_landmarks=n_lm, max_obs=max(w.n_obs for w in ws), max_batch=2)
+    try:
+        _solve_pair(oracle, b, ws)
+    finally:
+        b.close()
+
+
+def test_sweep_global_scratch_variant_is_bitwise_the_lds_one(oracle, monkeypatch):
+    """the variant of k_sweep_mfma that keeps its pair partials in a global scratch slice (N >= 12 and more than 256
+    windows) against the LDS variant on the same windows: bitwise; and against the oracle.  ISV_DEBUG_SW_GLOBAL forces
+    the variant on a small batch; the next test reaches it the natural way."""
+    ws = synth.make_windows([70, 71, 72], n_frames=18, n_vo=8, n_landmarks=120)
+    cap = dict(max_landmarks=120, max_obs=max(w.n_obs for w in ws), max_batch=3)
+    monkeypatch.setenv("ISV_DEBUG_SW_GLOBAL", "1")
+    bg = backend.Backend(18, 8, **cap)
+    monkeypatch.delenv("ISV_DEBUG_SW_GLOBAL")
+    bl = backend.Backend(18, 8, **cap)
+    try:
+        monkeypatch.setenv("ISV_DEBUG_SW_GLOBAL", "1")
+        g_glob, _, _ = _solve_pair(oracle, bg, ws)
+        monkeypatch.delenv("ISV_DEBUG_SW_GLOBAL")
+        g_lds = [w.clone() for w in ws]
+        bl.optimize_batch(g_lds)
+        for a, c in zip(g_glob, g_lds):
+            assert np.array_equal(a.state_vector(), c.state_vector())
+    finally:
+        bg.close(); bl.close()
+
+
+def test_batch_of_more_than_256_long_windows(oracle):
+    """260 windows of the reference's own shape (N = 18, Vo = 8) in one batch: the launch configuration large N >= 12
+    batches get (sw_global, several workgroups per CU).  A sample is compared with the oracle, and every window is
+    bitwise the same window solved in a batch of four."""
+    ids = list(range(800, 1060))
+    ws = synth.make_windows(ids, n_frames=18, n_vo=8, n_landmarks=24)
+    cap = dict(max_landmarks=24, max_obs=max(w.n_obs for w in ws))
+    big = backend.Backend(18, 8, max_batch=len(ws), **cap)
+    small = backend.Backend(18, 8, max_batch=4, **cap)
+    try:
+        gs = [w.clone() for w in ws]
+        sums, margs = big.optimize_batch(gs)
+        for k in (0, 1, 130, 259):
+            o, so, mo = oracle_run(oracle, big.cfg, ws[k])
+            check_window(o, so, gs[k], sums[k])
+            check_marg(mo, margs[k], 8)
+        for k0 in (0, 128, 256):
+            ref = [w.clone() for w in ws[k0: k0 + 4]]
+            small.optimize_batch(ref)
+            for a, c in zip(gs[k0: k0 + 4], ref):
+                assert np.array_equal(a.state_vector(), c.state_vector())
+    finally:
+        big.close(); small.close()
+
+
+# ---- double2vector near pitch +-90 deg ------------------------------------------------------------------------------
+def _pitch_deg(R):
+    """Utility::R2ypr (include/utility/utility.h:66-81), pitch in degrees"""
+    n, o, a = R[:, 0], R[:, 1], R[:, 2]
+    y = np.arctan2(n[1], n[0])
+    return np.degrees(np.arctan2(-n[2], n[0] * np.cos(y) + n[1] * np.sin(y)))
+
+
+@pytest.mark.parametrize("pitch0,n_frames,n_vo", [(89.7, 11, 5), (-89.6, 11, 5), (89.8, 18, 8)])
+def test_double2vector_near_pitch_90(oracle, pitch0, n_frames, n_vo):
+    """a body that looks straight up / down: |pitch(Rs[0])| within 1 deg of 90, where double2vector re-anchors with the
+    full rotation Rs[0] R0^T instead of the yaw difference (src/estimator.cpp:537-547)"""
+    ws = synth.make_windows([90, 91, 92, 93], n_frames=n_frames, n_vo=n_vo, n_landmarks=100, pitch0_deg=pitch0, pitch_amp_deg=0.0)
+    # (the generator perturbs the initial attitude by ~0.5 deg: keep the windows whose Rs[0] is inside the 1 deg band)
+    ws = [w for w in ws if abs(abs(_pitch_deg(w.Rs[0])) - 90.0) < 0.9][:2]
+    assert len(ws) >= 1
+    b = backend.Backend(n_frames, n_vo, max_landmarks=100, max_obs=max(w.n_obs for w in ws), max_batch=2)
+    try:
+        gs, _, _ = _solve_pair(oracle, b, ws)
+        # the branch really is a different rotation: a pure-yaw re-anchoring would leave another Rs[0]
+        for w, g in zip(ws, gs):
+            assert np.abs(g.Rs[0] - w.Rs[0]).max() < 1e-9          # full re-anchoring restores Rs[0] exactly
+    finally:
+        b.close()
+
+
+# ---- MargForward, rank-deficient Lamda_prior ------------------------------------------------------------------------
+def test_marg_forward_rank_deficient_prior(oracle):
+    """No landmark is hosted in frame 0 and the relative-pose edge (0, 1) carries no rotation information, so the
+    marginal on pose 1 has rank 3 and both sides take the eigen-truncation branch (src/estimator.cpp:1311-1331).
+    In that branch Sigma = (J U) D^-1 (J U)^T is singular BY CONSTRUCTION and the reference's own next line inverts it
+    (`covi.inverse()`, :1332): its sqrt_info is not finite there.  Parity is therefore: the same branch (the
+    zero-test / KLD is only computed on the full-rank branch), the same non-finite pattern in the recovered prior,
+    and every other output of the marginalisation equal as usual."""
+    ws = synth.make_windows([95, 96], n_frames=11, n_vo=5, n_landmarks=80, host_frames=(1, 5))
+    for w in ws:
+        s = abi.arr(w.relpose[0].sqrt_info, (6, 6)); s[3:, :] = 0.0; s[:, 3:] = 0.0
+        w.relpose[0].sqrt_info[:] = s.ravel()
+    b = backend.Backend(11, 5, max_landmarks=80, max_obs=max(w.n_obs for w in ws), max_batch=2)
+    try:
+        gs = [w.clone() for w in ws]
+        sums, margs = b.optimize_batch(gs)
+        for w, g, s, mg in zip(ws, gs, sums, margs):
+            o, so, mo = oracle_run(oracle, b.cfg, w)
+            check_window(o, so, g, s)
+            assert mg.valid == 1 and mo.valid == 1 and mg.n_marg_landmarks == mo.n_marg_landmarks == 0
+            assert mg.forward_kld == 0.0 and mo.forward_kld == 0.0          # the rank < 6 branch on both sides
+            fo, fg = abi.arr(mo.forward_pose_prior.sqrt_info), abi.arr(mg.forward_pose_prior.sqrt_info)
+            assert not np.isfinite(fo).all() and not np.isfinite(fg).all()
+            assert np.allclose(abi.arr(mg.forward_pose_prior.t), abi.arr(mo.forward_pose_prior.t), atol=1e-7)
+            assert np.allclose(abi.arr(mg.forward_pose_prior.R), abi.arr(mo.forward_pose_prior.R), atol=1e-7)
+            # MargBackward does not depend on it
+            for name, n in (("backward_relpose", 6), ("backward_vb", 9), ("backward_rollpitch", 2)):
+                A = abi.arr(getattr(mg, name).sqrt_info, (n, n)); Bm = abi.arr(getattr(mo, name).sqrt_info, (n, n))
+                assert np.abs(A.T @ A - Bm.T @ Bm).max() < 1e-6 * np.abs(Bm.T @ Bm).max()
+    finally:
+        b.close()
+
+
+# ---- terminations ---------------------------------------------------------------------------------------------------
+def _hooked_backend(monkeypatch, env, **kw):
+    for k, v in env.items():
+        monkeypatch.setenv(k, str(v))
+    b = backend.Backend(11, 5, max_landmarks=80, max_obs=880, max_batch=2, **kw)      # the hooks are read at create
+    for k in env:
+        monkeypatch.delenv(k)
+    return b
+
+
+def test_termination_linear_solver_failure(oracle, monkeypatch):
+    """every factorisation fails (fault injected on both sides): mu climbs to max_mu = 1, the step is invalid, and the
+    fifth consecutive invalid step ends the solve with FAILURE (trust_region_minimizer.cc HandleInvalidStep)"""
+    b = _hooked_backend(monkeypatch, {"ISV_DEBUG_FORCE_RETRY": 20})
+    oracle.isvo_debug_force_retry(20)
+    try:
+        w = synth.make_window(7, n_landmarks=80)
+        o, so, _ = oracle_run(oracle, b.cfg, w)
+        g = w.clone(); sg, _ = b.optimize(g)
+        assert so.termination == 7 and sg.termination == 7 and sg.iterations == so.iterations == 5
+        assert sg.num_successful == 0
+        check_window(o, so, g, sg)
+        assert np.abs(g.Ps - w.Ps).max() < 1e-12                    # nothing was accepted: the state is the input
+    finally:
+        oracle.isvo_debug_force_retry(0); b.close()
+
+
+@pytest.mark.parametrize("n_forced,term", [(5, 6), (2, None)])
+def test_termination_invalid_steps(oracle, monkeypatch, n_forced, term):
+    """the first n trust-region steps count as invalid (model_cost_change <= 0): five in a row end the solve
+    (INVALID_STEPS); two make DoglegStrategy::StepIsInvalid raise mu twice, then the solve goes on as usual"""
+    b = _hooked_backend(monkeypatch, {"ISV_DEBUG_FORCE_INVALID": n_forced})
+    oracle.isvo_debug_force_invalid(n_forced)
+    try:
+        w = synth.make_window(9, n_landmarks=80)
+        o, so, _ = oracle_run(oracle, b.cfg, w)
+        g = w.clone(); sg, _ = b.optimize(g)
+        if term is not None:
+            assert so.termination == term and sg.termination == term and sg.iterations == 5
+        else:
+            assert so.num_successful > 0 and list(so.trace_accepted[1:3]) == [0, 0]
+        check_window(o, so, g, sg)
+    finally:
+        oracle.isvo_debug_force_invalid(0); b.close()
+
+
+def test_termination_min_radius(oracle, monkeypatch):
+    """min_trust_region_radius raised from 1e-32 to 8000 on both sides: window 5 rejects its steps 3 and 4
+    (radius 30000 -> 15000 -> 7500) and stops with 'trust region radius too small' after the fourth iteration"""
+    b = _hooked_backend(monkeypatch, {"ISV_DEBUG_MIN_RADIUS": 8000.0})
+    oracle.isvo_debug_min_radius(8000.0)
+    try:
+        w = synth.make_window(5, n_landmarks=80)
+        o, so, _ = oracle_run(oracle, b.cfg, w)
+        g = w.clone(); sg, _ = b.optimize(g)
+        assert so.termination == 5 and sg.termination == 5 and so.iterations == sg.iterations == 4
+        check_window(o, so, g, sg)
+    finally:
+        oracle.isvo_debug_min_radius(0.0); b.close()
+
+
+# ---- the generic kernel ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n_frames,n_vo,n_lm", [(24, 8, 120), (21, 10, 60), (32, 8, 40)])
+def test_generic_kernel_for_windows_longer_than_20_frames(oracle, n_frames, n_vo, n_lm):
+    """N = 21..32 (ISV_MAX_FRAMES): k_build_solve<false> with the reduced system in a global scratch"""
+    ws = synth.make_windows([110, 111], n_frames=n_frames, n_vo=n_vo, n_landmarks=n_lm)
+    b = backend.Backend(n_frames, n_vo, max_landmarks=n_lm, max_obs=max(w.n_obs for w in ws), max_batch=2)
+    try:
+        _solve_pair(oracle, b, ws)
+    finally:
+        b.close()
+
+
+# ---- prior Jacobians, block by block --------------------------------------------------------------------------------
+def _corrected(r, Js):
+    """ceres Corrector for CauchyLoss(1.0): residual and Jacobians scaled by sqrt(rho') = 1 / sqrt(1 + |r|^2)"""
+    sc = 1.0 / np.sqrt(1.0 + float(r @ r))
+    return r * sc, [J * sc for J in Js]
+
+
+@pytest.mark.parametrize("n_frames,n_vo,perturb", [(11, 5, False), (11, 5, True), (18, 8, True)])
+def test_prior_jacobians_match_oracle(oracle, n_frames, n_vo, perturb):
+    """prior_strip = [se3: r6 J 6x6][lin9: r9 J 9x9][relpose k: r6 Ji 6x6 Jj 6x6]...[rollpitch m: r2 J 2x6] against
+    SE3PriorFactor / Linear9Factor / RelativePoseFactor / RollPitchFactor::Evaluate of the oracle (weighted by sqrt_info,
+    local parameterisation = first 6 of the 7 pose columns, Cauchy corrector)"""
+    w = synth.make_window(120, n_frames=n_frames, n_vo=n_vo, n_landmarks=40)
+    if perturb:                      # away from the prior measurements: non-zero residuals, J_r^-1 != I
+        rng = np.random.default_rng(3)
+        from scipy.spatial.transform import Rotation as Rot
+        w.Ps += 0.03 * rng.normal(size=w.Ps.shape); w.Vs += 0.03 * rng.normal(size=w.Vs.shape)
+        w.Bas += 0.01 * rng.normal(size=w.Bas.shape)
+        for i in range(w.N):
+            w.Rs[i] = w.Rs[i] @ Rot.from_rotvec(0.02 * rng.normal(size=3)).as_matrix()
+    b = backend.Backend(n_frames, n_vo, max_landmarks=40, max_obs=w.n_obs, max_batch=1)
+    try:
+        b.linearize(w)
+        strip = b.debug_read(0, 132 + 78 * (n_vo - 1) + 14 * b.cfg.max_rollpitch)
+        pose = np.zeros((w.N, 7)); sb = np.zeros((w.N, 9))
+        for i in range(w.N):
+            q = np.zeros(4); oracle.isvo_x_R2q(P(np.ascontiguousarray(w.Rs[i])), P(q))
+            pose[i, :3] = w.Ps[i]; pose[i, 3:] = q
+            sb[i] = np.concatenate([w.Vs[i], w.Bas[i], w.Bgs[i]])
+
+        def close(got, want, what):
+            sc = max(1.0, np.abs(want).max())
+            assert np.abs(got - want).max() < 1e-9 * sc, (what, np.abs(got - want).max() / sc)
+
+        r = np.zeros(6); J = np.zeros((6, 7))
+        oracle.isvo_x_se3prior(C.byref(w.pose_prior), 1, P(pose[0]), P(r), P(J))
+        r, (J,) = _corrected(r, [J[:, :6]])
+        close(strip[0:6], r, "se3 r"); close(strip[6:42].reshape(6, 6), J, "se3 J")
+        r = np.zeros(9); J = np.zeros((9, 9))
+        oracle.isvo_x_linear9(C.byref(w.vb_prior), 1, P(sb[n_vo - 1]), P(r), P(J))
+        r, (J,) = _corrected(r, [J])
+        close(strip[42:51], r, "lin9 r"); close(strip[51:132].reshape(9, 9), J, "lin9 J")
+        for k in range(n_vo - 1):
+            r = np.zeros(6); Ji = np.zeros((6, 7)); Jj = np.zeros((6, 7))
+            oracle.isvo_x_relpose(C.byref(w.relpose[k]), 1, P(pose[k]), P(pose[k + 1]), P(r), P(Ji), P(Jj))
+            r, (Ji, Jj) = _corrected(r, [Ji[:, :6], Jj[:, :6]])
+            o0 = 132 + 78 * k
+            close(strip[o0: o0 + 6], r, f"relpose {k} r")
+            close(strip[o0 + 6: o0 + 42].reshape(6, 6), Ji, f"relpose {k} Ji")
+            close(strip[o0 + 42: o0 + 78].reshape(6, 6), Jj, f"relpose {k} Jj")
+        base = 132 + 78 * (n_vo - 1)
+        for m in range(w.n_rollpitch):
+            r = np.zeros(2); J = np.zeros((2, 7))
+            oracle.isvo_x_rollpitch(C.byref(w.rollpitch[m]), 1, P(pose[w.rollpitch[m].index]), P(r), P(J))
+            r, (J,) = _corrected(r, [J[:, :6]])
+            close(strip[base + 14 * m: base + 14 * m + 2], r, f"rollpitch {m} r")
+            close(strip[base + 14 * m + 2: base + 14 * m + 14].reshape(2, 6), J, f"rollpitch {m} J")
+        if perturb:
+            assert np.abs(strip[0:6]).max() > 1e-3
+    finally:
+        b.close()

@@ -95,3 +95,28 @@ def test_timing_queries_leave_the_handle_usable():
     be.upload(out); be.run_optimize(); sums, _ = be.download(out)
     assert all(s.status == 0 and s.final_cost < s.initial_cost for s in sums)
     be.close()
+
+
+def test_result_records_on_the_device_match_the_download(oracle):
+    """isv_batch_pack_results (the records the multi-GPU configuration all-gathers over RCCL) against the
+    ordinary download of the same solve: bitwise the para_* arrays and the summary scalars, zero padding beyond L"""
+    import torch
+    ws = synth.make_windows([300, 301, 302], n_landmarks=50) + [synth.make_window(303, n_landmarks=7)]
+    b = backend.Backend(11, 5, max_landmarks=50, max_obs=max(w.n_obs for w in ws), max_batch=4)
+    try:
+        gs = [w.clone() for w in ws]
+        b.upload(gs); b.run_optimize(sync=False)
+        rec = b.record_doubles()
+        assert rec == 16 * 11 + 50 + 8
+        dst = torch.full((len(gs), rec), float("nan"), dtype=torch.float64, device="cuda:0")
+        b.pack_results(dst.data_ptr(), torch.cuda.current_stream().cuda_stream)      # ordered after the solve, no host sync
+        torch.cuda.synchronize()
+        sums, _ = b.download(gs)
+        out = dst.cpu().numpy()
+        for k, (g, s) in enumerate(zip(gs, sums)):
+            assert np.array_equal(out[k, :77], g.para_Pose.ravel()) and np.array_equal(out[k, 77:176], g.para_SpeedBias.ravel())
+            assert np.array_equal(out[k, 176:176 + g.L], g.para_Feature[: g.L]) and not out[k, 176 + g.L:226].any()
+            assert out[k, 226] == s.final_cost and out[k, 227] == s.initial_cost and out[k, 228] == s.iterations
+            assert out[k, 229] == s.termination and out[k, 230] == s.num_successful and out[k, 232] == g.header0 and out[k, 233] == g.L
+    finally:
+        b.close()

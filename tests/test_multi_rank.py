@@ -1,7 +1,8 @@
-"""N > 1 path on CPU: two gloo ranks shard window ids exactly as bench.py does, solve their own
-windows (with the CPU oracle standing in for the device), and agree on the max step time.  Checks
-that the shards are disjoint, cover the batch, and that a window's result does not depend on the
-rank count (windows are independent: no data-path collective)."""
+"""N > 1 path on CPU: two gloo ranks shard window ids exactly as bench.py does (weak and strong partition), solve their
+own windows (with the CPU oracle standing in for the device), exchange the per-window result records with the SAME
+all-gather bench.py issues over RCCL (sharding.gather_records), and agree on the max step time.  Checks that the shards
+are disjoint and cover the batch, that every rank ends up with every window's record, and that a window's result does
+not depend on the rank count (windows are independent: no collective inside the solve)."""
 import ctypes as C
 import os
 import sys
@@ -11,34 +12,51 @@ import pytest
 import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N_LM = 30
+
+
+def _record(w, s):
+    """the layout isv_batch_pack_results writes on the device (include/isvins_backend.h)"""
+    lam = np.zeros(N_LM); lam[: w.L] = w.para_Feature[: w.L]
+    return np.concatenate([w.para_Pose.ravel(), w.para_SpeedBias.ravel(), lam,
+                           [s.final_cost, s.initial_cost, s.iterations, s.termination, s.num_successful, 0.0, w.header0, w.L]])
+
+
+def _solve(lib, cfg, ids):
+    from isvins_amd import abi, synth
+    recs = []
+    for w in synth.make_windows(ids, n_landmarks=N_LM):
+        s = abi.isv_summary_t(); mg = abi.isv_marg_result_t()
+        lib.isvo_optimize(C.byref(cfg), C.byref(w.c()), C.byref(s), C.byref(mg))
+        recs.append(_record(w, s))
+    return np.stack(recs)
 
 
 def _worker(rank, world, per_rank, port, q):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     import isvins_loader; isvins_loader.load()
+    import torch
     import torch.distributed as dist
-    from isvins_amd import abi, sharding, synth
+    from isvins_amd import abi, sharding
     import oracle_lib
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    ids = list(sharding.shard_window_ids(rank, world, per_rank))
     lib = oracle_lib.load()
     cfg = abi.make_config(11, 5)
-    costs = []
-    for w in synth.make_windows(ids, n_landmarks=30):
-        s = abi.isv_summary_t(); mg = abi.isv_marg_result_t()
-        lib.isvo_optimize(C.byref(cfg), C.byref(w.c()), C.byref(s), C.byref(mg))
-        costs.append(s.final_cost)
+    out = {}
+    for mode, total in (("weak", None), ("strong", world * per_rank)):
+        ids = list(sharding.shard_window_ids(rank, world, per_rank, total))
+        recs = torch.from_numpy(_solve(lib, cfg, ids))
+        gathered = torch.empty((world * len(ids), recs.shape[1]), dtype=torch.float64)
+        sharding.gather_records(recs, gathered, dist)
+        out[mode] = (ids, gathered.numpy().copy())
     dt = sharding.max_over_ranks(0.5 + rank, dist)      # pretend rank r took 0.5 + r seconds
-    gathered = [None] * world
-    dist.all_gather_object(gathered, (ids, costs))
-    if rank == 0:
-        q.put((dt, gathered))
+    q.put((rank, dt, out))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_sharding_and_timing():
+def test_two_rank_sharding_gather_and_timing():
     world, per_rank = 2, 3
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -46,22 +64,23 @@ def test_two_rank_sharding_and_timing():
     procs = [ctx.Process(target=_worker, args=(r, world, per_rank, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    dt, gathered = q.get(timeout=120)
+    got = dict()
+    for _ in range(world):
+        rank, dt, out = q.get(timeout=180)
+        got[rank] = (dt, out)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert dt == 1.5                                    # max over ranks
-    ids = [i for g in gathered for i in g[0]]
-    assert sorted(ids) == list(range(world * per_rank)) and len(set(ids)) == len(ids)
-    # same windows solved in a single process give the same costs (independence)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
-    from isvins_amd import abi, synth
-    lib = oracle_lib.load(); cfg = abi.make_config(11, 5)
-    ref = []
-    for w in synth.make_windows(range(world * per_rank), n_landmarks=30):
-        s = abi.isv_summary_t(); mg = abi.isv_marg_result_t()
-        lib.isvo_optimize(C.byref(cfg), C.byref(w.c()), C.byref(s), C.byref(mg))
-        ref.append(s.final_cost)
-    got = dict(zip(ids, [c for g in gathered for c in g[1]]))
-    assert [got[i] for i in range(world * per_rank)] == ref
+    from isvins_amd import abi
+    ref = _solve(oracle_lib.load(), abi.make_config(11, 5), range(world * per_rank))      # the same windows in ONE process
+    for mode in ("weak", "strong"):
+        ids = [i for r in range(world) for i in got[r][1][mode][0]]
+        assert sorted(ids) == list(range(world * per_rank)) and len(set(ids)) == len(ids)       # disjoint cover
+        for r in range(world):
+            dt, out = got[r]
+            assert dt == 1.5                                                                     # max over ranks
+            # every rank holds every window's record, in rank order = window-id order, bitwise the single-process result
+            assert np.array_equal(out[mode][1], ref)
+            assert np.array_equal(out[mode][1][:, -2], np.arange(world * per_rank, dtype=float))  # header0 = window id
