@@ -269,7 +269,7 @@ struct Sequence {
     std::vector<int> good;                     // indices into tracks of the landmarks in `w`
     // outputs
     isv_summary_t last_summary{};
-    int n_solves = 0, n_good_last = 0;
+    int n_solves = 0, n_good_last = 0, n_failed = 0;   // n_failed: solves whose result was not finite (state kept as it was)
     std::vector<std::array<double, 8>> pose_rows;
     std::vector<std::array<double, 13>> newest_rows;
 };
@@ -728,9 +728,13 @@ extern "C" int isv_estimator_step(isv_estimator_t *e) {
     const auto t4 = clk::now();
     (void)parallel_for((int)solve.size(), errs, [&](int k, std::string &) {
         Sequence &s = e->seq[solve[k]];
-        read_back(s);
+        // A solve that produced a non-finite cost must not be copied into the window (the reference has no such guard:
+        // its NaNs would spread through every later frame): the sequence keeps its pre-solve states, priors and depths,
+        // drops this frame's marginalisation outputs, and the failure is counted (isv_estimator_failed_solves).
+        const bool ok = sums[k].status == ISV_OK;
+        if (ok) read_back(s); else s.n_failed++;
         const isv_marg_result_t &m = margs[k];
-        if (s.margin_old && m.valid) {
+        if (ok && s.margin_old && m.valid) {
             s.add_pose_prior = m.forward_pose_prior; s.add_relpose = m.backward_relpose; s.add_vb = m.backward_vb;
             s.have_to_add = true;
             isv_rollpitch_t brp = m.backward_rollpitch;
@@ -756,6 +760,11 @@ extern "C" int isv_estimator_status(const isv_estimator_t *e, int32_t seq, int32
     out[0] = s.flag == NON_LINEAR ? 1 : 0; out[1] = s.frame_count; out[2] = s.margin_old ? 1 : 0; out[3] = (int32_t)s.tracks.size();
     out[4] = s.n_good_last; out[5] = (int32_t)s.rollpitch.size(); out[6] = s.n_solves; out[7] = s.last_summary.iterations;
     return ISV_OK;
+}
+
+extern "C" int isv_estimator_failed_solves(const isv_estimator_t *e, int32_t seq) {
+    SEQ_OR_FAIL(e, seq);
+    return e->seq[seq].n_failed;
 }
 
 extern "C" int isv_estimator_get_window(const isv_estimator_t *e, int32_t seq, double *Ps, double *Rs, double *Vs, double *Bas,

@@ -30,7 +30,7 @@ class isv_solver_vtbl_t(C.Structure):
 
 EXPORTS = ["isv_estimator_create", "isv_estimator_create_with_solver", "isv_estimator_destroy", "isv_estimator_last_error",
            "isv_estimator_process_imu", "isv_estimator_process_imu_n", "isv_estimator_last_step_ms", "isv_estimator_push_image", "isv_estimator_set_bootstrap", "isv_estimator_step",
-           "isv_estimator_status", "isv_estimator_get_window", "isv_estimator_get_preintegration", "isv_estimator_last_summary", "isv_estimator_trajectory"]
+           "isv_estimator_status", "isv_estimator_get_window", "isv_estimator_get_preintegration", "isv_estimator_last_summary", "isv_estimator_trajectory", "isv_estimator_failed_solves"]
 
 _bound = False
 
@@ -55,6 +55,7 @@ def _bind(lib):
     lib.isv_estimator_get_preintegration.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(abi.isv_imu_t)]
     lib.isv_estimator_last_summary.argtypes = [vp, C.c_int32, C.POINTER(abi.isv_summary_t)]
     lib.isv_estimator_trajectory.argtypes = [vp, C.c_int32, C.c_int32, dp, C.c_int32]
+    lib.isv_estimator_failed_solves.argtypes = [vp, C.c_int32]
     _bound = True
 
 
@@ -143,6 +144,9 @@ class SequenceEstimator:
         s = abi.isv_summary_t()
         self._check(self.lib.isv_estimator_last_summary(self.h, seq, C.byref(s)), "last_summary")
         return s
+
+    def failed_solves(self, seq):
+        return self._check(self.lib.isv_estimator_failed_solves(self.h, seq), "failed_solves")
 
     def trajectory(self, seq, which=0):
         """which=0: pose_output.txt rows [n][8] (stamp p qw qx qy qz of the oldest frame); 1: newest frame [n][13]"""

@@ -833,6 +833,30 @@ int isvo_optimize(const isv_config_t *cfg, isv_window_t *w, isv_summary_t *sum, 
     return ISV_OK;
 }
 
+/* isvo_optimize over n independent windows on `nthreads` host threads (static block partition over windows): the
+ * all-cores leg of bench.py's cpu_baseline.  The reference's problemSolve is single-threaded (src/estimator.cpp:1122),
+ * so more cores only help across windows. */
+#include <pthread.h>
+typedef struct { const isv_config_t *cfg; isv_window_t *const *w; isv_summary_t *sum; isv_marg_result_t *marg; int b0, b1; } mt_job_t;
+static void *mt_worker(void *arg) {
+    mt_job_t *j = (mt_job_t *)arg;
+    for (int b = j->b0; b < j->b1; b++) isvo_optimize(j->cfg, j->w[b], &j->sum[b], j->marg ? &j->marg[b] : NULL);
+    return NULL;
+}
+int isvo_optimize_batch_mt(const isv_config_t *cfg, isv_window_t *const *w, int n, int nthreads, isv_summary_t *sum, isv_marg_result_t *marg) {
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > n) nthreads = n;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * nthreads);
+    mt_job_t *jobs = (mt_job_t *)malloc(sizeof(mt_job_t) * nthreads);
+    for (int k = 0; k < nthreads; k++) {
+        jobs[k] = (mt_job_t){cfg, w, sum, marg, (int)((long long)n * k / nthreads), (int)((long long)n * (k + 1) / nthreads)};
+        pthread_create(&th[k], NULL, mt_worker, &jobs[k]);
+    }
+    for (int k = 0; k < nthreads; k++) pthread_join(th[k], NULL);
+    free(th); free(jobs);
+    return ISV_OK;
+}
+
 /* Estimator::initFactorGraph  src/estimator.cpp:667-1001 (one-time, INITIAL_STRUCTURE -> NON_LINEAR).
  *  1. solve the window WITHOUT prior factors: IMU + reprojection factors only, max_num_iterations = 3 NUM_ITERATIONS
  *     (:677-742; the 1 s wall-clock cap and num_threads = 2 of the reference are not restated);

@@ -371,14 +371,59 @@ class Estimator:
                 f.write("%.6f %.6f %.6f %.6f %.6f %.6f %.6f %.6f\n" % (t, p[0], p[1], p[2], q[0], q[1], q[2], q[3]))
 
 
-class Simulator:
-    """a camera-IMU rig on synth.Trajectory: feature observations at 10 Hz with pixel noise 1/460, IMU at 200 Hz"""
+class FigureEight:
+    """6-DoF stand-in for a EuRoC machine-hall flight: a figure-eight position path
+    (lemniscate of Gerono, 8 m x 4 m, 12 s per lap: up to 2.1 m/s and 1.1 m/s^2, enough excitation for the monocular
+    scale to be observable) with a 0.5 m vertical wave, sinusoidal yaw (+-1 rad), roll and pitch (+-8 deg); analytic
+    velocity / acceleration / body rates, same interface as synth.Trajectory"""
 
-    def __init__(self, seed=0, n_points=1500, frame_dt=0.1, imu_per_frame=20):
+    def __init__(self, A=4.0, B=2.0, Cz=0.5, period=12.0):
+        self.A, self.B, self.Cz = A, B, Cz
+        self.w = 2 * np.pi / period
+        self.wz = 1.7 * self.w
+        self.ya, self.wy = 1.0, 0.6 * self.w * 3
+        self.amp = np.deg2rad(8.0)
+
+    def p(self, t):
+        return np.array([self.A * np.sin(self.w * t), 0.5 * self.B * np.sin(2 * self.w * t), self.Cz * np.sin(self.wz * t)])
+
+    def vel(self, t):
+        return np.array([self.A * self.w * np.cos(self.w * t), self.B * self.w * np.cos(2 * self.w * t), self.Cz * self.wz * np.cos(self.wz * t)])
+
+    def acc(self, t):
+        return np.array([-self.A * self.w ** 2 * np.sin(self.w * t), -2 * self.B * self.w ** 2 * np.sin(2 * self.w * t), -self.Cz * self.wz ** 2 * np.sin(self.wz * t)])
+
+    def ypr(self, t):
+        return (self.ya * np.sin(self.wy * t), self.amp * np.sin(2 * np.pi * 0.5 * t), self.amp * np.sin(2 * np.pi * 0.3 * t + 1.0))
+
+    def ypr_dot(self, t):
+        return (self.ya * self.wy * np.cos(self.wy * t), self.amp * 2 * np.pi * 0.5 * np.cos(2 * np.pi * 0.5 * t),
+                self.amp * 2 * np.pi * 0.3 * np.cos(2 * np.pi * 0.3 * t + 1.0))
+
+    def R(self, t):
+        return synth._rot_zyx(*self.ypr(t))
+
+    def gyro(self, t):
+        y, p, r = self.ypr(t)
+        yd, pd, rd = self.ypr_dot(t)
+        return np.array([rd - yd * np.sin(p), pd * np.cos(r) + yd * np.sin(r) * np.cos(p), -pd * np.sin(r) + yd * np.cos(r) * np.cos(p)])
+
+
+class Simulator:
+    """a camera-IMU rig on synth.Trajectory: feature observations at 10 Hz with pixel noise 1/460, IMU at 200 Hz.
+    `euroc_like=True`: the SURVEY 8d stand-in for the EuRoC runs instead -- FigureEight, 20 Hz frames, 200 Hz IMU,
+    ~150 features per frame (max_cnt of config/euroc_config.yaml:40)."""
+
+    def __init__(self, seed=0, n_points=1500, frame_dt=0.1, imu_per_frame=20, euroc_like=False):
         self.rng = np.random.default_rng(seed)
         self.traj = synth.Trajectory(0.3)
         # the yaml extrinsic points the camera's optical axis along the body z axis: the landmarks form a ceiling
-        self.points = np.stack([self.rng.uniform(-8.0, 8.0, n_points), self.rng.uniform(-8.0, 8.0, n_points), self.rng.uniform(3.0, 8.0, n_points)], 1)
+        if euroc_like:
+            self.traj = FigureEight()
+            n_points, frame_dt, imu_per_frame = 1900, 0.05, 10
+            self.points = np.stack([self.rng.uniform(-13.0, 13.0, n_points), self.rng.uniform(-10.0, 10.0, n_points), self.rng.uniform(3.5, 8.0, n_points)], 1)
+        else:
+            self.points = np.stack([self.rng.uniform(-8.0, 8.0, n_points), self.rng.uniform(-8.0, 8.0, n_points), self.rng.uniform(3.0, 8.0, n_points)], 1)
         self.frame_dt, self.k = frame_dt, imu_per_frame
         self.ba, self.bg = self.rng.normal(0, 0.02, 3), self.rng.normal(0, 0.002, 3)
 
@@ -412,8 +457,8 @@ class Simulator:
         return P, R, V
 
 
-def run_sequence(solver, lib, N, Nvo, n_frames, seed=0):
-    sim = Simulator(seed)
+def run_sequence(solver, lib, N, Nvo, n_frames, seed=0, euroc_like=False, progress=None):
+    sim = Simulator(seed, euroc_like=euroc_like)
     est = Estimator(solver, lib, N, Nvo)
     for i in range(n_frames):
         if i > 0:
@@ -429,6 +474,8 @@ def run_sequence(solver, lib, N, Nvo, n_frames, seed=0):
             P = P + nrng.normal(0, 0.01, P.shape); V = V + nrng.normal(0, 0.02, V.shape)
             boot = (P, R, V)
         est.process_image(image, t, bootstrap=boot)
+        if progress and i % 200 == 0:
+            progress(i)
     return est, sim
 
 
@@ -472,9 +519,9 @@ def estimator_params(cfg):
     return E.make_params(cfg, synth.RIC, synth.TIC, ACC_N, GYR_N, ACC_W, GYR_W, MIN_PARALLAX)
 
 
-def run_sequences_native(est, N, n_frames, seeds):
+def run_sequences_native(est, N, n_frames, seeds, euroc_like=False):
     """push len(seeds) simulated streams (Simulator(seed)) through a SequenceEstimator in lock step"""
-    sims = [Simulator(sd) for sd in seeds]
+    sims = [Simulator(sd, euroc_like=euroc_like) for sd in seeds]
     for i in range(n_frames):
         for s, (sim, sd) in enumerate(zip(sims, seeds)):
             if i > 0:
