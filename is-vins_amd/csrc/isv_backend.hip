@@ -41,6 +41,7 @@ struct isv_backend {
         double *Ps, *Rs, *Vs, *Bas, *Bgs, *tic, *ric, *depth, *lm_pts_i, *f_pts_j, *f_pts_z, *imu_in, *imu_cov;
         int32_t *lm_off, *f_off, *lm_host, *lm_k, *lm_f0, *tile_win, *tile_f0, *tile_n, *imu_skip, *n_rp, *solve_flag, *pg_perm, *pg_off, *pg_sched, *pg_sched_off;
         FactorRec *f_rec;
+        int32_t *pg_rec, *pg_wstart; double *pg_pts;
         uint32_t *lm_meta; int32_t *margin_old; double *header0;
         isv_se3_prior_t *se3; isv_linear9_t *lin9; isv_relpose_t *relpose; isv_rollpitch_t *rollpitch;
         SolveState *st;
@@ -141,6 +142,8 @@ static int create_impl(isv_backend *h) {
     TRY(dalloc(h, &d.tile_win, T)); TRY(dalloc(h, &d.tile_f0, T)); TRY(dalloc(h, &d.tile_n, T));
     TRY(dalloc(h, &d.pg_perm, F)); TRY(dalloc(h, &d.pg_off, B * ((size_t)c.n_frames * (c.n_frames - 1) / 2 + 1)));
     TRY(dalloc(h, &d.pg_sched, B * ((size_t)c.n_frames * (c.n_frames - 1) / 2))); TRY(dalloc(h, &d.pg_sched_off, B * (ISV_SWEEP_WAVES + 1)));
+    TRY(dalloc(h, &d.pg_rec, F * 2)); TRY(dalloc(h, &d.pg_pts, F * 2)); TRY(dalloc(h, &d.flm, F * 8)); TRY(dalloc(h, &d.pg_wstart, B * (ISV_SWEEP_WAVES + 1)));
+    d.fused_visual = getenv("ISV_LEGACY_VISUAL") ? 0 : 1;      // (test hook: the unfused k_proj_linearize<0> + k_sweep_mfma pair)
     TRY(dalloc(h, &d.imu_in, NI * ISV_IMU_IN)); TRY(dalloc(h, &d.imu_cov, NI * 225)); TRY(dalloc(h, &d.imu_sqrt, NI * 225));
     TRY(dalloc(h, &d.imu_skip, NI));
     TRY(dalloc(h, &d.se3, B)); TRY(dalloc(h, &d.lin9, B)); TRY(dalloc(h, &d.relpose, B * (c.n_vo - 1))); TRY(dalloc(h, &d.rollpitch, B * (size_t)c.max_rollpitch));
@@ -166,7 +169,7 @@ static int create_impl(isv_backend *h) {
     TRY(halloc(h, &s.tile_win, T)); TRY(halloc(h, &s.tile_f0, T)); TRY(halloc(h, &s.tile_n, T));
     TRY(halloc(h, &s.pg_perm, F)); TRY(halloc(h, &s.pg_off, B * ((size_t)c.n_frames * (c.n_frames - 1) / 2 + 1)));
     TRY(halloc(h, &s.pg_sched, B * ((size_t)c.n_frames * (c.n_frames - 1) / 2))); TRY(halloc(h, &s.pg_sched_off, B * (ISV_SWEEP_WAVES + 1))); TRY(halloc(h, &s.imu_skip, NI)); TRY(halloc(h, &s.n_rp, B));
-    TRY(halloc(h, &s.f_rec, F));
+    TRY(halloc(h, &s.f_rec, F)); TRY(halloc(h, &s.pg_rec, F * 2)); TRY(halloc(h, &s.pg_pts, F * 2)); TRY(halloc(h, &s.pg_wstart, B * (ISV_SWEEP_WAVES + 1)));
     TRY(halloc(h, &s.margin_old, B)); TRY(halloc(h, &s.header0, B));
     TRY(halloc(h, &s.lm_meta, L));
     TRY(halloc(h, &s.se3, B)); TRY(halloc(h, &s.lin9, B)); TRY(halloc(h, &s.relpose, B * (c.n_vo - 1))); TRY(halloc(h, &s.rollpitch, B * (size_t)c.max_rollpitch));
@@ -281,6 +284,22 @@ static int pack_window(isv_backend *h, int b, const isv_window_t *w, size_t L, s
         int fill[ISV_SWEEP_WAVES] = {0};
         for (int hh = 0, p = 0; hh < N - 1; hh++)
             for (int jj = hh + 1; jj < N; jj++, p++) { const int v = wave_of[p]; sched[soff[v] + fill[v]++] = hh | (jj << 8) | (p << 16); }
+        // the factor stream of the fused kernel: the groups back to back in schedule order, so that a wavefront walks
+        // its groups in full 64-lane chunks
+        int32_t *wst = s.pg_wstart + (size_t)b * (ISV_SWEEP_WAVES + 1);
+        size_t q = f_off;
+        for (int v = 0; v < ISV_SWEEP_WAVES; v++) {
+            wst[v] = (int32_t)(q - f_off);
+            for (int e = soff[v]; e < soff[v + 1]; e++) {
+                const int rec = sched[e], hh = rec & 255, jj = (rec >> 8) & 255, pp = rec >> 16;
+                for (int k2 = off[pp]; k2 < off[pp + 1]; k2++, q++) {
+                    const size_t f = f_off + (size_t)s.pg_perm[f_off + k2];
+                    s.pg_rec[2 * q] = s.f_rec[f].lm; s.pg_rec[2 * q + 1] = (int32_t)((f - f_off) | ((size_t)hh << 16) | ((size_t)jj << 24));
+                    s.pg_pts[2 * q] = s.f_pts_j[2 * f]; s.pg_pts[2 * q + 1] = s.f_pts_j[2 * f + 1];
+                }
+            }
+        }
+        wst[ISV_SWEEP_WAVES] = (int32_t)(q - f_off);
     }
     for (int i = 0; i < N - 1; i++) {
         const isv_imu_t &im = w->imu[i];
@@ -384,6 +403,7 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
     H2D(d.f_rec, s.f_rec, F); H2D(d.f_pts_j, s.f_pts_j, F * 2); H2D(d.f_pts_z, s.f_pts_z, F);
     H2D(d.lm_meta, s.lm_meta, L);
     H2D(d.tile_win, s.tile_win, T); H2D(d.tile_f0, s.tile_f0, T); H2D(d.tile_n, s.tile_n, T);
+    H2D(d.pg_rec, s.pg_rec, F * 2); H2D(d.pg_pts, s.pg_pts, F * 2); H2D(d.pg_wstart, s.pg_wstart, (size_t)n * (ISV_SWEEP_WAVES + 1));
     H2D(d.pg_perm, s.pg_perm, F); H2D(d.pg_off, s.pg_off, (size_t)n * ((size_t)N * (N - 1) / 2 + 1));
     H2D(d.pg_sched, s.pg_sched, (size_t)n * ((size_t)N * (N - 1) / 2)); H2D(d.pg_sched_off, s.pg_sched_off, (size_t)n * (ISV_SWEEP_WAVES + 1));
     H2D(d.imu_in, s.imu_in, NI * ISV_IMU_IN); H2D(d.imu_cov, s.imu_cov, NI * 225); H2D(d.imu_skip, s.imu_skip, NI);

@@ -124,4 +124,11 @@ struct DevBatch {
     // trust-region steps as invalid; ISV_DEBUG_MIN_RADIUS overrides min_trust_region_radius (1e-32)
     int32_t force_invalid, _pad2;
     double min_radius;
+    // fused linearise + Gram kernel (isv_visual.hip): factor records in (host, observer) pair order and the per-factor
+    // landmark pieces it leaves for k_rank1_mfma's prologue
+    int32_t *pg_rec;                    // [Ftot][2] the factor STREAM of k_lin_gram: per window the pair groups in schedule order (sweep wavefront, then pair): {global landmark index, CSR factor id within the window | host << 16 | observer << 24}
+    double *pg_pts;                     // [Ftot][2] observing view's point, same order
+    int32_t *pg_wstart;                 // [B][ISV_SWEEP_WAVES + 1] stream offsets (within the window) of the sweep wavefronts' slices
+    double *flm;                        // [Ftot][8] {J_l^T J_l, J_l^T r, J_i^T J_l (6)} per factor, CSR factor order
+    int32_t fused_visual, _pad3;
 };

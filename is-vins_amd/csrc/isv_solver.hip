@@ -567,6 +567,7 @@ int isv_solver_alloc(DevBatch &d, size_t B, size_t L, size_t F, std::vector<void
         SETLDS((k_rank1_mfma<4, 1, 64, 1>), lds_r1); SETLDS((k_rank1_mfma<5, 1, 64, 1>), lds_r1); SETLDS((k_rank1_mfma<6, 2, 64, 1>), lds_r1);
         SETLDS((k_rank1_mfma<7, 2, 64, 1>), lds_r1); SETLDS((k_rank1_mfma<8, 3, 64, 1>), lds_r1);
         SETLDS(k_sweep_mfma, lds_sw);
+        SETLDS(k_lin_gram, lin_gram_lds_bytes(d.N, true));
         if (d.N <= 11) SETLDS(k_build_solve_sb<false>, lds_sb); else SETLDS(k_build_solve_sb<true>, lds_sb);
 #undef SETLDS
     }
@@ -599,15 +600,20 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
         }
         hipLaunchKernelGGL(k_prior_linearize<true>, dim3(d.B), dim3(64), prior_lds_bytes(d.n_prior_slots), st2, d, d.pose, d.sb, d.prior_cost, 1);
         HCHK(hipEventRecord(fj[1], st2));
+        const bool fused = d.lds_T && d.fused_visual;
+        d.sw_global = (d.sw_part && (d.B > 256 || getenv("ISV_DEBUG_SW_GLOBAL"))) ? 1 : 0;     // more than one workgroup per CU: trade LDS for occupancy
         PROF(slot, 0, 0);
-        if (d.n_tiles > 0) { hipLaunchKernelGGL(k_proj_linearize<0>, dim3((d.n_tiles + 3) / 4), dim3(256), lds_proj, st, d, d.pose, d.lam, d.fcost, 1); counts[0]++; }
+        if (fused) {
+            // linearisation fused with the Gram products: no Jacobian strip goes to HBM (isv_visual.hip)
+            hipLaunchKernelGGL(k_lin_gram, dim3(d.B), dim3(64 * LG_WAVES), lin_gram_lds_bytes(d.N, !d.sw_global), st, d);
+            counts[0]++;
+        } else if (d.n_tiles > 0) { hipLaunchKernelGGL(k_proj_linearize<0>, dim3((d.n_tiles + 3) / 4), dim3(256), lds_proj, st, d, d.pose, d.lam, d.fcost, 1); counts[0]++; }
         PROF(slot, 0, 1);
         if (d.lds_T) {
             // landmark elimination: Gram products of the pose Jacobians, then the rank-1 downdates (both FP64 MFMA)
             PROF(slot, 1, 0);
-            {
+            if (!fused) {
                 const size_t n_pairs = (size_t)d.N * (d.N - 1) / 2;
-                d.sw_global = (d.sw_part && (d.B > 256 || getenv("ISV_DEBUG_SW_GLOBAL"))) ? 1 : 0;     // more than one workgroup per CU: trade LDS for occupancy
                 hipLaunchKernelGGL(k_sweep_mfma, dim3(d.B), dim3(64 * ISV_SWEEP_WAVES), ((d.sw_global ? 0 : n_pairs * 84) + (n_pairs + 2) / 2 + 1) * sizeof(double), st, d);
             }
             counts[2]++;

@@ -169,6 +169,31 @@ __global__ __launch_bounds__(64 * ((NT * (NT + 1) / 2 + TPW - 1) / TPW), MINW) v
         TI[j] = I; TJ[j] = q - I * (I + 1) / 2;
     }
     const int i = lane & 15, kq = lane >> 4;
+    if (d.fused_visual) {
+        // Landmark scalars (what SchurEliminator needs per e-block) from the per-factor pieces k_lin_gram left, summed in
+        // the landmark's own factor order: E = J_l^T J_l, g_l = J_l^T r, host-frame w = sum J_i^T J_l.  (The unfused
+        // path does this inside k_proj_linearize<0>, where a landmark's factors are adjacent lanes.)
+        for (int l = t; l < Lw; l += nthr) {
+            const int gl = l0 + l, kf = d.lm_k[gl] - 1;
+            const double2 *fl = (const double2 *)(d.flm + (size_t)d.lm_f0[gl] * 8);
+            double2 eg = fl[0], w01 = fl[1], w23 = fl[2], w45 = fl[3];
+            for (int o = 1; o < kf; o++) {
+                const double2 a = fl[4 * o], b = fl[4 * o + 1], c = fl[4 * o + 2], e = fl[4 * o + 3];
+                eg.x += a.x; eg.y += a.y; w01.x += b.x; w01.y += b.y; w23.x += c.x; w23.y += c.y; w45.x += e.x; w45.y += e.y;
+            }
+            double sl;
+            if (st.iteration == 0) { sl = 1.0 / (1.0 + sqrt(eg.x)); d.scale_l[gl] = sl; }
+            else sl = d.scale_l[gl];
+            const double Es = sl * sl * eg.x;
+            const double Dl2 = fmin(fmax(Es, 1e-6), 1e32);
+            const double Dl = sqrt(Dl2);
+            d.lm_cg[gl] = make_double2(sl * sl / (Es + st.mu * Dl2), eg.y);
+            d.lmE[gl] = eg.x; d.lmG[gl] = eg.y; d.diag_l[gl] = Dl; d.grad_l[gl] = sl * eg.y / Dl;
+            double2 *wd = (double2 *)(d.W + (size_t)(d.lm_f0[gl] + gl) * 6);           // host observation slot
+            wd[0] = w01; wd[1] = w23; wd[2] = w45;
+        }
+        __syncthreads();                                   // the host slots and lm_cg are read below by other threads
+    }
     for (int l = t; l < Lw; l += nthr) { sM[l] = d.lm_meta[l0 + l]; sCG[l] = d.lm_cg[l0 + l]; }
     __syncthreads();
     // panel element e of a pass: row r = e / ld (landmark lb + r), column c = e % ld

@@ -1,0 +1,192 @@
+// isv_visual.hip -- k_lin_gram: ProjectionFactor::Evaluate (+ CauchyLoss corrector) FUSED with the direct part of the
+// landmark elimination (the Gram products k_sweep_mfma forms), for the solver path.
+//
+// k_proj_linearize<0> wrote a 224-byte Jacobian strip per factor to HBM and k_sweep_mfma read it straight back
+// (0.45 GB per iteration of a 1024-window batch: more than half of the step's HBM traffic).  Here the strips never
+// leave the CU: the factors of a window are visited in (host, observer) frame-PAIR order (pg_* arrays, built at
+// upload), one LANE per factor evaluates residual and Jacobians in registers (src/factor/projection_factor.cpp:24-122),
+// 16 factors at a time are laid out in a wave-private LDS tile and fed to v_mfma_f64_16x16x4 exactly as
+// k_sweep_mfma fed them from HBM:   G = X^T X,  X = [J_i | J_j | r]  (2 rows per factor, 13 columns).
+// What still goes to HBM per factor: its cost (8 B), w = J_j^T J_l of the observing frame (48 B, the packed W layout
+// of the rank-1 kernel) and a 64-byte record {J_l^T J_l, J_l^T r, J_i^T J_l} from which k_rank1_mfma's prologue forms
+// the landmark scalars in the landmark's own factor order (fixed order: bitwise reproducible, no atomics).
+//
+// One workgroup (LG_WAVES wavefronts) per window; wavefront v takes the pair groups the upload schedule gave to the
+// sweep wavefronts 2v and 2v + 1, laid out back to back in the factor stream (pg_rec / pg_pts / pg_wstart) so that it
+// walks them in FULL 64-lane chunks.  Outputs: Tvis (pose blocks, gradient, Jacobi diagonal) as k_sweep_mfma.
+#include <hip/hip_runtime.h>
+#include "isv_kernels.h"
+#include "isv_device_math.h"
+#include "isv_proj_factor.h"
+
+__host__ __device__ inline int tvis_col2(int a, int N) { return 36 * (a * N - a * (a - 1) / 2); }
+typedef double double4g __attribute__((ext_vector_type(4)));
+#define LG_XLD 27                    // LDS row of one factor: r(2) J_i(12) J_j(12) + 1 (odd stride)
+#define LGSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
+size_t lin_gram_lds_bytes(int N, bool partials_in_lds) {
+    const size_t NP = (size_t)N * (N - 1) / 2;
+    return ((size_t)N * 12 + 12 + (size_t)LG_WAVES * 16 * LG_XLD + (partials_in_lds ? NP * 84 : 0) + (NP + 2) / 2 + 1) * sizeof(double);
+}
+
+__global__ __launch_bounds__(64 * LG_WAVES, 3) void k_lin_gram(DevBatch d) {
+    extern __shared__ __align__(16) double lds[];
+    const int w = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const SolveState &st = d.st[w];
+    if (st.termination != ISV_TERM_RUNNING || !st.need_linearize) return;
+    const int N = d.N, NP = N * (N - 1) / 2;
+    double *sPose = lds;                               // [N][12] R (row-major) | P
+    double *sEx = sPose + N * 12;                      // [12]
+    double *sX = sEx + 12 + wv * 16 * LG_XLD;          // this wavefront's 16-factor tile
+    double *pbase = sEx + 12 + LG_WAVES * 16 * LG_XLD;
+    double *Pjj = d.sw_global ? d.sw_part + (size_t)w * NP * 84 : pbase;      // pair partials (see k_sweep_mfma)
+    double *Phh = Pjj + NP * 36, *Pgj = Phh + NP * 36, *Pgh = Pgj + NP * 6;
+    int *offL = (int *)(d.sw_global ? pbase : pbase + NP * 84);                // [NP + 1] group starts
+    const int fw0 = d.f_off[w];
+    const int2 *prec = (const int2 *)d.pg_rec + fw0;   // the factor stream: wavefront-major, then pair group (upload order)
+    const double2 *ppts = (const double2 *)d.pg_pts + fw0;
+    const int *sched = d.pg_sched + (size_t)w * NP, *soff = d.pg_sched_off + (size_t)w * (ISV_SWEEP_WAVES + 1);
+    double *out = d.Tvis + (size_t)w * d.tvis_sz;
+    if (t < N) {
+        const double *p = d.pose + ((size_t)w * N + t) * 7;
+        double R[9]; q_to_R(q_from_pose(p), R);
+#pragma unroll
+        for (int k = 0; k < 9; k++) sPose[t * 12 + k] = R[k];
+        sPose[t * 12 + 9] = p[0]; sPose[t * 12 + 10] = p[1]; sPose[t * 12 + 11] = p[2];
+    } else if (t == 64) {
+        const double *e = d.ex + (size_t)w * 7;
+        double R[9]; q_to_R(q_from_pose(e), R);
+#pragma unroll
+        for (int k = 0; k < 9; k++) sEx[k] = R[k];
+        sEx[9] = e[0]; sEx[10] = e[1]; sEx[11] = e[2];
+    }
+    for (int e = t; e <= NP; e += blockDim.x) offL[e] = d.pg_off[(size_t)w * (NP + 1) + e];
+    __syncthreads();
+    const int i = lane & 15, kq = lane >> 4, row2 = kq & 1, fsel = kq >> 1;
+    // element of the LDS factor row that operand column i takes: J_i row row2 | J_j row row2 | r[row2]
+    const int eoff = i < 6 ? 2 + row2 * 6 + i : (i < 12 ? 14 + row2 * 6 + (i - 6) : row2);
+    const bool colok = i < 13;
+    constexpr int SPW = ISV_SWEEP_WAVES / LG_WAVES;     // sweep-schedule wavefronts per wavefront here
+    const int q0 = soff[wv * SPW], q1 = soff[(wv + 1) * SPW];
+    const int *wst = d.pg_wstart + (size_t)w * (ISV_SWEEP_WAVES + 1);
+    const int s0 = wst[wv * SPW], s1 = wst[(wv + 1) * SPW];       // this wavefront's slice of the factor stream
+    auto gsize = [&](int qq) { const int pp = sched[qq] >> 16; return offL[pp + 1] - offL[pp]; };
+    // one group's accumulator tile -> its five pieces.  C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+    auto flush = [&](int qq, const double4g &acc) {
+        const int rec = sched[qq], h = rec & 255, j = (rec >> 8) & 255, p = rec >> 16;
+#pragma unroll
+        for (int reg = 0; reg <= 2; reg++) {
+            const int row = kq + 4 * reg;
+            if (row < 6) {
+                if (i < 6) Phh[p * 36 + row * 6 + i] = acc[reg];
+                else if (i == 12) Pgh[p * 6 + row] = acc[reg];
+            } else if (row < 12) {
+                const int rr = row - 6;
+                if (i < 6) out[tvis_col2(h, N) + (j - h) * 36 + rr * 6 + i] = acc[reg];        // block (j, h)
+                else if (i < 12) Pjj[p * 36 + rr * 6 + (i - 6)] = acc[reg];
+                else if (i == 12) Pgj[p * 6 + rr] = acc[reg];
+            }
+        }
+    };
+    // pairs nobody observes still own a slot of every sum below: zero them
+    for (int q = q0; q < q1; q++) if (gsize(q) == 0) flush(q, double4g{0, 0, 0, 0});
+    // The factor stream of this wavefront is its pair groups back to back (upload order), visited in FULL 64-lane
+    // chunks: a chunk may span several groups, every lane reads its own pair's pose blocks.  The Gram accumulator
+    // follows the group boundaries: rows of the 16-factor LDS tile outside the current group are masked to zero.
+    int q = q0;
+    while (q < q1 && gsize(q) == 0) q++;
+    int gend = s0 + (q < q1 ? gsize(q) : 0);
+    double4g acc = {0, 0, 0, 0};
+    for (int pos = s0; pos < s1; pos += 64) {
+        const int cnt = (s1 - pos) < 64 ? (s1 - pos) : 64;
+        double r0 = 0, r1 = 0, Ji[12], Jj[12], Jl[2];
+        if (lane < cnt) {
+            const int2 rc = prec[pos + lane];              // {global landmark, f_rel | h << 16 | j << 24}
+            const int h = (rc.y >> 16) & 255, j = (rc.y >> 24) & 255;
+            double ric[9], tic[3], Ri[9], Rj[9], Pi[3], Pj[3];
+#pragma unroll
+            for (int k = 0; k < 9; k++) { ric[k] = sEx[k]; Ri[k] = sPose[h * 12 + k]; Rj[k] = sPose[j * 12 + k]; }
+#pragma unroll
+            for (int k = 0; k < 3; k++) { tic[k] = sEx[9 + k]; Pi[k] = sPose[h * 12 + 9 + k]; Pj[k] = sPose[j * 12 + 9 + k]; }
+            const double2 pj = ppts[pos + lane];
+            const double *pi3 = d.lm_pts_i + (size_t)rc.x * 3;
+            proj_factor<true>(Ri, Pi, Rj, Pj, ric, tic, d.proj_sqrt_info, d.lam[rc.x], pi3[0], pi3[1], pi3[2], pj.x, pj.y, r0, r1, Ji, Jj, Jl);
+            // CauchyLoss(1.0): rho = log(1 + s); the Corrector scales r and J by sqrt(rho') = 1 / sqrt(1 + s)
+            const double sum = 1.0 + (r0 * r0 + r1 * r1);
+            const double sc = sqrt(fmax(1.0 / sum, 2.2250738585072014e-308));
+            const size_t f = (size_t)fw0 + (rc.y & 0xffff);
+            d.fcost[f] = 0.5 * log(sum);
+            r0 *= sc; r1 *= sc;
+#pragma unroll
+            for (int k = 0; k < 12; k++) { Ji[k] *= sc; Jj[k] *= sc; }
+            Jl[0] *= sc; Jl[1] *= sc;
+            // observing frame's w = J_j^T J_l into the landmark's packed W slot (observation index f + landmark + 1)
+            double2 *wd = (double2 *)(d.W + (f + rc.x + 1) * 6);
+            wd[0] = make_double2(Jj[0] * Jl[0] + Jj[6] * Jl[1], Jj[1] * Jl[0] + Jj[7] * Jl[1]);
+            wd[1] = make_double2(Jj[2] * Jl[0] + Jj[8] * Jl[1], Jj[3] * Jl[0] + Jj[9] * Jl[1]);
+            wd[2] = make_double2(Jj[4] * Jl[0] + Jj[10] * Jl[1], Jj[5] * Jl[0] + Jj[11] * Jl[1]);
+            // the factor's pieces of the landmark scalars: E, g, host-frame w
+            double2 *fl = (double2 *)(d.flm + f * 8);
+            fl[0] = make_double2(Jl[0] * Jl[0] + Jl[1] * Jl[1], Jl[0] * r0 + Jl[1] * r1);
+            fl[1] = make_double2(Ji[0] * Jl[0] + Ji[6] * Jl[1], Ji[1] * Jl[0] + Ji[7] * Jl[1]);
+            fl[2] = make_double2(Ji[2] * Jl[0] + Ji[8] * Jl[1], Ji[3] * Jl[0] + Ji[9] * Jl[1]);
+            fl[3] = make_double2(Ji[4] * Jl[0] + Ji[10] * Jl[1], Ji[5] * Jl[0] + Ji[11] * Jl[1]);
+        }
+        // Gram: 16 factors per round through the wave-private LDS tile
+        for (int rq = 0; rq * 16 < cnt; rq++) {
+            if ((lane >> 4) == rq) {
+                double *row = sX + (lane & 15) * LG_XLD;
+                row[0] = r0; row[1] = r1;
+#pragma unroll
+                for (int k = 0; k < 12; k++) { row[2 + k] = Ji[k]; row[14 + k] = Jj[k]; }
+            }
+            LGSYNC();
+            double v[8];
+#pragma unroll
+            for (int u2 = 0; u2 < 8; u2++) v[u2] = colok ? sX[(2 * u2 + fsel) * LG_XLD + eoff] : 0.0;
+            const int rs = pos + 16 * rq, re = (rs + 16) < (pos + cnt) ? (rs + 16) : (pos + cnt);
+            int cur = rs;
+            while (cur < re) {                              // the segments of this round, one per group it touches
+                const int se = gend < re ? gend : re;
+                const int a = cur - rs, b = se - rs;        // tile rows [a, b) belong to the current group
+#pragma unroll
+                for (int u2 = 0; u2 < 8; u2++) {
+                    if (2 * u2 + 1 >= a && 2 * u2 < b) {
+                        const int src = 2 * u2 + fsel;
+                        const double x = (src >= a && src < b) ? v[u2] : 0.0;
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, acc, 0, 0, 0);
+                    }
+                }
+                cur = se;
+                if (se == gend) {                           // the group is complete
+                    flush(q, acc);
+                    acc = double4g{0, 0, 0, 0};
+                    q++;
+                    while (q < q1 && gsize(q) == 0) q++;
+                    gend += q < q1 ? gsize(q) : 0;
+                }
+            }
+            LGSYNC();
+        }
+    }
+    __syncthreads();
+    // fold the pair partials into the diagonal blocks, the Jacobi-scaling diagonal and the gradient (fixed order)
+    const int tail = 36 * (N * (N + 1) / 2);
+    auto pidx = [N](int hh, int jj) { return hh * N - hh * (hh + 1) / 2 + (jj - hh - 1); };
+    for (int tq = t; tq < N * 42; tq += blockDim.x) {
+        if (tq < N * 36) {
+            const int a = tq / 36, rc = tq - 36 * a, r = rc / 6, c = rc - 6 * r;
+            double s = 0.0;
+            for (int j2 = a + 1; j2 < N; j2++) s += Phh[pidx(a, j2) * 36 + rc];
+            for (int h2 = 0; h2 < a; h2++) s += Pjj[pidx(h2, a) * 36 + rc];
+            out[tvis_col2(a, N) + rc] = s;
+            if (r == c) out[tail + 6 * a + r] = s;
+        } else {
+            const int q = tq - N * 36, a = q / 6, r = q - 6 * a;
+            double s = 0.0;
+            for (int j2 = a + 1; j2 < N; j2++) s += Pgh[pidx(a, j2) * 6 + r];
+            for (int h2 = 0; h2 < a; h2++) s += Pgj[pidx(h2, a) * 6 + r];
+            out[tail + 6 * N + 6 * a + r] = s;
+        }
+    }
+}
