@@ -1,0 +1,832 @@
+// isv_posegraph.hip -- PoseGraph::optimizeCS on the MI355X (reference src/pose_graph/pose_graph.cpp:234-428), the consumer
+// of the CombinedFactors the sliding-window backend emits (C ABI: include/isvins_posegraph.h).
+//
+// The problem (Ceres 2.0.0 in the reference: SPARSE_NORMAL_CHOLESKY, LEVENBERG_MARQUARDT, <= 10 iterations): the poses
+// of the keyframes first_looped_index .. cur_index; RelativePoseFactor chain + RollPitchFactor per keyframe + loop-closure
+// RelativePoseFactors under HuberLoss(0.1); then ceres::Covariance of every pose block.
+//
+// Device design.  The normal equations are BLOCK SPARSE: a block-tridiagonal chain plus one long row per loop closure.
+// With the keyframes in their natural order a Cholesky factor fills only inside the row ENVELOPE (row r: columns
+// start[r] .. r, start[r] = its earliest neighbour), so the matrices live in skyline storage of 6x6 blocks: K chain
+// blocks + sum over loop edges of (later - earlier).  ONE WAVEFRONT per pose graph runs the whole optimisation -- the
+// factorisation is a recurrence along the chain, there is nothing for a second wavefront to do -- and a batch of graphs
+// (one per sequence) fills the GPU: grid = graphs.  Inside the wavefront: lane per residual block for the
+// linearisation (RelativePoseFactor / RollPitchFactor::Evaluate + Corrector), lane per pose for the assembly (owner
+// computes, fixed adjacency order: bitwise reproducible), 36 lanes per 6x6 block product in the factorisation, the
+// triangular solves and the selected inversion.  Marginal covariances = the diagonal blocks of H^-1 by the Takahashi
+// recurrence on the same envelope (never a dense inverse).
+// This is latency-bound sparse work (dependent 6x6 block recurrences through L2); it is not reshaped into dense GEMMs.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/isvins_posegraph.h"
+#include "isv_device_math.h"
+#include "isv_prior_factor.h"
+
+#define PG_WSYNC() ISV_WSYNC()
+// make this wavefront's global stores visible to its own later loads (other lanes read what a lane wrote)
+#define PG_GSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
+
+struct PgEdge {                  // one residual block
+    int32_t kind;                // 0 roll/pitch (a), 1 relative pose (a -> b), 2 loop closure (a = matched keyframe, b = the one that closed)
+    int32_t a, b;                // local pose indices
+    int32_t fa, fb;              // their free (non-constant) indices, -1 if constant
+    int32_t dim, robust, _pad;
+    double meas_t[3], meas_R[9], sqrt_info[36];
+};
+
+struct PgGraph {                 // offsets of one pose graph into the handle's pools
+    int32_t P1, nf, ne, nblk;    // poses, free poses, residual blocks, skyline blocks
+    int32_t pose0, free0, edge0, blk0, adj0, col0, vec0, _pad;
+    int32_t max_iter, _pad2;
+    double huber;
+};
+
+struct PgDev {
+    PgGraph *graphs;
+    double *pose, *cand;         // [poses][7]
+    int32_t *free_of;            // [poses] free index of a local pose or -1
+    PgEdge *edges;
+    double *eres, *ejac;         // [edges][6], [edges][72]: corrected residual, Jacobians (block a | block b), Jacobi-scaled
+    int32_t *adj_ptr, *adj;      // per free pose: the residual blocks touching it, (edge << 1) | side
+    int32_t *start, *rowptr;     // skyline: first column of row r, block offset of row r   (per free pose; rowptr has nf + 1)
+    int32_t *colptr, *colrows;   // column pattern: rows i > j with start[i] <= j, ascending
+    double *H, *L, *Z;           // [blocks][36]
+    double *scale, *diag, *grad, *step, *ysol;   // [6 nf] each
+    double *cov;                 // [poses][36] tangent-space marginal covariance (zero for constant poses)
+    isv_pgo_result_t *res;
+};
+
+// ---- 6x6 helpers: lane e < 36 owns element (a, b) = (e / 6, e % 6) -------------------------------------------------
+DEV double readlane_d(double v, int lane) {
+    union { double d; int i[2]; } u; u.d = v;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], lane);
+    u.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
+    return u.d;
+}
+// D (6x6 SPD, row-major in LDS tile T, lower part valid) -> T = inverse of its Cholesky factor (lower); returns false if not SPD
+DEV bool pg_chol_inv6(double *T, int lane) {
+    double row[6], dinv[6], x[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) row[k] = lane < 6 ? T[lane * 6 + k] : 0.0;
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        double s = row[j];
+#pragma unroll
+        for (int k = 0; k < j; k++) s -= row[k] * readlane_d(row[k], j);
+        const double sj = readlane_d(s, j);
+        if (!(sj > 0.0)) bad = true;
+        dinv[j] = 1.0 / sqrt(sj);
+        row[j] = (lane == j) ? sj * dinv[j] : s * dinv[j];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) {                      // lane c solves L x = e_c
+        double s = (lane == i) ? 1.0 : 0.0;
+#pragma unroll
+        for (int k = 0; k < i; k++) s -= readlane_d(row[k], i) * x[k];
+        x[i] = s * dinv[i];
+    }
+    PG_WSYNC();
+    if (lane < 6) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) T[k * 6 + lane] = x[k];      // x[k] = Linv[k][lane], zero for k < lane
+    }
+    PG_WSYNC();
+    return !bad;
+}
+// deterministic wave sum (fixed butterfly)
+DEV double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+DEV double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+    return v;
+}
+
+// RelativePoseFactor::Evaluate (include/factor/relative_pose_factor.h:27-70) / RollPitchFactor::Evaluate
+// (rollpitch_factor.h:26-57) of one residual block at `pose`, HuberLoss corrector applied; returns rho(s) / 2
+DEV double pg_edge_eval(const PgEdge &E, const double *pose, double huber, double *r_out, double *Ja, double *Jb, bool jac) {
+    double raw[6], rJa[36], rJb[36];
+    const double *pa = pose + 7 * E.a, *pb = pose + 7 * E.b;
+    if (E.kind == 0) {
+        Quat Rq = q_normalized(q_from_pose(pa)), Rm = q_from_R(E.meas_R);
+        double nZ[3] = {0, 0, -1.0}, v[3];
+        q_rot(so3_mul(Rm, q_conj(Rq)), nZ, v);
+        raw[0] = v[0]; raw[1] = v[1];
+        if (jac) {
+            double S[9], Rmm[9], Bm[9];
+            skew3(v, S); q_to_R(Rm, Rmm); m3_mul(S, Rmm, Bm);
+            for (int k = 0; k < 12; k++) rJa[k] = 0;
+            for (int a = 0; a < 2; a++) for (int b = 0; b < 3; b++) rJa[a * 6 + 3 + b] = Bm[a * 3 + b];
+        }
+    } else {
+        relpose_jac(E.meas_t, E.meas_R, pa, pb, raw, rJa, rJb);
+    }
+    const int dim = E.dim;
+    double r[6];
+    for (int a = 0; a < dim; a++) { double s = 0; for (int k = 0; k < dim; k++) s += E.sqrt_info[a * dim + k] * raw[k]; r[a] = s; }
+    double sq = 0; for (int a = 0; a < dim; a++) sq += r[a] * r[a];
+    double rho = sq, sc = 1.0;
+    if (E.robust) {                                    // HuberLoss(a): rho = s (s <= a^2), 2 a sqrt(s) - a^2 beyond; Corrector scales by sqrt(rho')
+        const double b2 = huber * huber;
+        if (sq > b2) { const double rr = sqrt(sq); rho = 2.0 * huber * rr - b2; sc = sqrt(fmax(2.2250738585072014e-308, huber / rr)); }
+    }
+    if (jac) {
+        for (int a = 0; a < dim; a++) r_out[a] = r[a] * sc;
+        for (int a = 0; a < dim; a++) for (int c = 0; c < 6; c++) {
+            double s = 0; for (int k = 0; k < dim; k++) s += E.sqrt_info[a * dim + k] * rJa[k * 6 + c];
+            Ja[a * 6 + c] = s * sc;
+        }
+        if (E.kind != 0) for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++) {
+            double s = 0; for (int k = 0; k < 6; k++) s += E.sqrt_info[a * 6 + k] * rJb[k * 6 + c];
+            Jb[a * 6 + c] = s * sc;
+        }
+    }
+    return 0.5 * rho;
+}
+
+__global__ __launch_bounds__(64) void k_pgo(PgDev dv) {
+    __shared__ double T0[36], T1[36], T2[36];
+    const PgGraph G = dv.graphs[blockIdx.x];
+    const int lane = threadIdx.x, nf = G.nf, n = 6 * nf;
+    double *pose = dv.pose + (size_t)G.pose0 * 7, *cand = dv.cand + (size_t)G.pose0 * 7;
+    const int32_t *free_of = dv.free_of + G.pose0;
+    PgEdge *edges = dv.edges + G.edge0;
+    double *eres = dv.eres + (size_t)G.edge0 * 6, *ejac = dv.ejac + (size_t)G.edge0 * 72;
+    const int32_t *adj_ptr = dv.adj_ptr + G.free0 + blockIdx.x, *adj = dv.adj + G.adj0;
+    const int32_t *start = dv.start + G.free0, *rowptr = dv.rowptr + G.free0 + blockIdx.x;
+    const int32_t *colptr = dv.colptr + G.free0 + blockIdx.x, *colrows = dv.colrows + G.col0;
+    double *H = dv.H + (size_t)G.blk0 * 36, *L = dv.L + (size_t)G.blk0 * 36, *Z = dv.Z + (size_t)G.blk0 * 36;
+    double *scale = dv.scale + G.vec0, *diag = dv.diag + G.vec0, *grad = dv.grad + G.vec0, *step = dv.step + G.vec0, *ysol = dv.ysol + G.vec0;
+    isv_pgo_result_t &res = dv.res[blockIdx.x];
+    const int e = lane, ea = e / 6, eb = e - 6 * ea;    // my element of a 6x6 block (lanes 0..35)
+    auto BLK = [&](double *M, int r, int c) -> double * { return M + (size_t)(rowptr[r] + (c - start[r])) * 36; };
+
+    // ---- evaluation of every residual block at x (and linearisation) ------------------------------------------------
+    auto evaluate = [&](const double *x, bool jac) -> double {
+        double c = 0;
+        for (int q = lane; q < G.ne; q += 64) c += pg_edge_eval(edges[q], x, G.huber, eres + 6 * q, ejac + 72 * q, ejac + 72 * q + 36, jac);
+        PG_GSYNC();
+        return wave_sum(c);
+    };
+    // squared column norms of the (current) Jacobian, owner computes: lane per free pose
+    auto colnorm2 = [&](double *out) {
+        for (int f = lane; f < nf; f += 64) {
+            double s[6] = {0, 0, 0, 0, 0, 0};
+            for (int q = adj_ptr[f]; q < adj_ptr[f + 1]; q++) {
+                const int ed = adj[q] >> 1, side = adj[q] & 1, dim = edges[ed].dim;
+                const double *J = ejac + 72 * ed + 36 * side;
+                for (int a = 0; a < dim; a++) for (int c = 0; c < 6; c++) s[c] += J[a * 6 + c] * J[a * 6 + c];
+            }
+            for (int c = 0; c < 6; c++) out[6 * f + c] = s[c];
+        }
+        PG_GSYNC();
+    };
+    auto scale_jac = [&]() {                           // J <- J diag(scale), lane per residual block
+        for (int q = lane; q < G.ne; q += 64) {
+            const PgEdge &E = edges[q];
+            for (int side = 0; side < (E.kind == 0 ? 1 : 2); side++) {
+                const int f = side ? E.fb : E.fa;
+                if (f < 0) continue;
+                double *J = ejac + 72 * q + 36 * side;
+                for (int a = 0; a < E.dim; a++) for (int c = 0; c < 6; c++) J[a * 6 + c] *= scale[6 * f + c];
+            }
+        }
+        PG_GSYNC();
+    };
+    // gradient g = J^T r (scaled Jacobian), lane per free pose; returns nothing
+    auto gradient = [&]() {
+        for (int f = lane; f < nf; f += 64) {
+            double s[6] = {0, 0, 0, 0, 0, 0};
+            for (int q = adj_ptr[f]; q < adj_ptr[f + 1]; q++) {
+                const int ed = adj[q] >> 1, side = adj[q] & 1, dim = edges[ed].dim;
+                const double *J = ejac + 72 * ed + 36 * side, *r = eres + 6 * ed;
+                for (int a = 0; a < dim; a++) for (int c = 0; c < 6; c++) s[c] += J[a * 6 + c] * r[a];
+            }
+            for (int c = 0; c < 6; c++) grad[6 * f + c] = s[c];
+        }
+        PG_GSYNC();
+    };
+    // gradient_max_norm = |x - Plus(x, -g_unscaled)|_inf over the free blocks
+    auto gmax_of = [&]() -> double {
+        double m = 0;
+        for (int k = lane; k < G.P1; k += 64) {
+            const int f = free_of[k];
+            if (f < 0) continue;
+            double ng[6], xp[7];
+            for (int c = 0; c < 6; c++) ng[c] = -grad[6 * f + c] / scale[6 * f + c];
+            pose_plus(pose + 7 * k, ng, xp);
+            for (int c = 0; c < 7; c++) m = fmax(m, fabs(pose[7 * k + c] - xp[c]));
+        }
+        return wave_max(m);
+    };
+    auto xnorm_of = [&](const double *x) -> double {
+        double s = 0;
+        for (int k = lane; k < G.P1; k += 64) if (free_of[k] >= 0) for (int c = 0; c < 7; c++) s += x[7 * k + c] * x[7 * k + c];
+        return sqrt(wave_sum(s));
+    };
+    // H = J^T J on the envelope, lane per free pose (row): its diagonal block and the blocks towards EARLIER neighbours
+    auto assemble = [&]() {
+        for (int q = lane; q < G.nblk * 36; q += 64) H[q] = 0.0;
+        PG_GSYNC();
+        for (int f = lane; f < nf; f += 64) {
+            for (int q = adj_ptr[f]; q < adj_ptr[f + 1]; q++) {
+                const int ed = adj[q] >> 1, side = adj[q] & 1;
+                const PgEdge &E = edges[ed];
+                const double *J = ejac + 72 * ed + 36 * side;
+                double *D = BLK(H, f, f);
+                for (int a = 0; a < 6; a++) for (int b = 0; b <= a; b++) {
+                    double s = 0; for (int k = 0; k < E.dim; k++) s += J[k * 6 + a] * J[k * 6 + b];
+                    D[a * 6 + b] += s; if (b != a) D[b * 6 + a] += s;
+                }
+                if (E.kind != 0) {
+                    const int other = side ? E.fa : E.fb;
+                    if (other >= 0 && other < f) {             // the later endpoint owns the off-diagonal block (f, other)
+                        const double *Jo = ejac + 72 * ed + 36 * (1 - side);
+                        double *O = BLK(H, f, other);
+                        for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) {
+                            double s = 0; for (int k = 0; k < 6; k++) s += J[k * 6 + a] * Jo[k * 6 + b];
+                            O[a * 6 + b] += s;
+                        }
+                    }
+                }
+            }
+        }
+        PG_GSYNC();
+    };
+    // L L^T = H + diag(damp) on the envelope; diagonal slots hold L_rr^-1.  Returns false when a pivot is not positive.
+    auto factor = [&](const double *damp) -> bool {
+        for (int q = lane; q < G.nblk * 36; q += 64) L[q] = H[q];
+        PG_GSYNC();
+        bool ok = true;
+        for (int r = 0; r < nf && ok; r++) {
+            const int s0 = start[r];
+            for (int c = s0; c < r; c++) {
+                // S = A(r,c) - sum_{m = max(start[r], start[c])}^{c-1} L(r,m) L(c,m)^T ;  L(r,c) = S L_cc^-T
+                double acc = 0;
+                if (e < 36) {
+                    acc = BLK(L, r, c)[e];
+                    const int m0 = s0 > start[c] ? s0 : start[c];
+                    for (int m = m0; m < c; m++) {
+                        // (the block L(r, c-1) was finished in the previous step of this row: it is also in T1)
+                        const double *X = (m == c - 1) ? T1 : BLK(L, r, m), *Y = BLK(L, c, m);
+                        for (int k = 0; k < 6; k++) acc -= X[ea * 6 + k] * Y[eb * 6 + k];
+                    }
+                }
+                PG_WSYNC();
+                if (e < 36) T0[e] = acc;
+                PG_WSYNC();
+                double x = 0;
+                if (e < 36) { const double *Li = BLK(L, c, c); for (int k = 0; k <= eb; k++) x += T0[ea * 6 + k] * Li[eb * 6 + k]; }
+                PG_WSYNC();
+                if (e < 36) { T1[e] = x; BLK(L, r, c)[e] = x; }
+                PG_GSYNC();
+            }
+            // diagonal: D = A(r,r) + damp - sum_m L(r,m) L(r,m)^T
+            double acc = 0;
+            if (e < 36) {
+                acc = BLK(L, r, r)[e] + (ea == eb ? damp[6 * r + ea] : 0.0);
+                for (int m = s0; m < r; m++) { const double *X = BLK(L, r, m); for (int k = 0; k < 6; k++) acc -= X[ea * 6 + k] * X[eb * 6 + k]; }
+                T2[e] = acc;
+            }
+            PG_WSYNC();
+            ok = pg_chol_inv6(T2, lane);
+            if (e < 36) BLK(L, r, r)[e] = T2[e];
+            PG_GSYNC();
+        }
+        return ok;
+    };
+    // x = (L L^T)^-1 b  -> xs ; lanes 0..5 own the components of a block
+    auto solve = [&](const double *b, double *xs) {
+        for (int r = 0; r < nf; r++) {                 // forward: y_r = L_rr^-1 (b_r - sum_{m<r} L(r,m) y_m)
+            double v = 0;
+            if (lane < 6) {
+                v = b[6 * r + lane];
+                for (int m = start[r]; m < r; m++) { const double *X = BLK(L, r, m); for (int k = 0; k < 6; k++) v -= X[lane * 6 + k] * ysol[6 * m + k]; }
+            }
+            double y = 0;
+            const double *Li = BLK(L, r, r);
+            for (int k = 0; k < 6; k++) { const double vk = readlane_d(v, k); if (lane < 6 && k <= lane) y += Li[lane * 6 + k] * vk; }
+            if (lane < 6) ysol[6 * r + lane] = y;
+            PG_GSYNC();
+        }
+        for (int r = nf - 1; r >= 0; r--) {            // backward: x_r = L_rr^-T (y_r - sum_{i in colpat(r)} L(i,r)^T x_i)
+            double v = 0;
+            if (lane < 6) {
+                v = ysol[6 * r + lane];
+                for (int q = colptr[r]; q < colptr[r + 1]; q++) { const int i = colrows[q]; const double *X = BLK(L, i, r); for (int k = 0; k < 6; k++) v -= X[k * 6 + lane] * xs[6 * i + k]; }
+            }
+            double x = 0;
+            const double *Li = BLK(L, r, r);
+            for (int k = 0; k < 6; k++) { const double vk = readlane_d(v, k); if (lane < 6 && k >= lane) x += Li[k * 6 + lane] * vk; }
+            if (lane < 6) xs[6 * r + lane] = x;
+            PG_GSYNC();
+        }
+    };
+
+    // ================= TrustRegionMinimizer::Minimize + LevenbergMarquardtStrategy (Ceres 2.0.0 defaults) =============
+    if (lane == 0) { res.status = ISV_OK; res.num_successful = 0; for (int k = 0; k < ISV_MAX_TRACE; k++) { res.trace_cost[k] = 0; res.trace_accepted[k] = 0; } }
+    double x_cost = evaluate(pose, true);
+    int it = 0, term = ISV_TERM_RUNNING, nsucc = 0;
+    if (nf > 0) {
+        colnorm2(scale);
+        for (int q = lane; q < n; q += 64) scale[q] = 1.0 / (1.0 + sqrt(scale[q]));
+        PG_GSYNC();
+        scale_jac();
+        gradient();
+        double gmax = gmax_of(), x_norm = xnorm_of(pose);
+        double radius = 1e4, decrease = 2.0;
+        bool reuse_diag = false;
+        int invalid = 0;
+        if (lane == 0) { res.initial_cost = x_cost; res.trace_cost[0] = x_cost; }
+        for (;;) {
+            if (it >= G.max_iter) { term = ISV_TERM_MAX_ITERATIONS; break; }
+            if (gmax <= 1e-10) { term = ISV_TERM_GRADIENT_TOL; break; }
+            if (radius <= 1e-32) { term = ISV_TERM_MIN_RADIUS; break; }
+            it++;
+            if (!reuse_diag) {                         // diagonal_ = clamp(squared column norms)
+                colnorm2(diag);
+                for (int q = lane; q < n; q += 64) diag[q] = fmin(fmax(diag[q], 1e-6), 1e32);
+                PG_GSYNC();
+            }
+            reuse_diag = true;
+            assemble();
+            for (int q = lane; q < n; q += 64) step[q] = diag[q] / radius;        // D^2 = diagonal / radius (step[] as scratch)
+            PG_GSYNC();
+            bool ok = factor(step);
+            if (ok) {
+                solve(grad, step);
+                double bad = 0;
+                for (int q = lane; q < n; q += 64) { const double v = step[q]; if (!(v - v == 0.0)) bad = 1; step[q] = -v; }
+                PG_GSYNC();
+                if (wave_max(bad) > 0) ok = false;
+            }
+            bool valid = false;
+            double model_cost_change = 0;
+            if (ok) {                                  // -(J step)^T (r + J step / 2)
+                double mc = 0;
+                for (int q = lane; q < G.ne; q += 64) {
+                    const PgEdge &E = edges[q];
+                    for (int a = 0; a < E.dim; a++) {
+                        double m = 0;
+                        if (E.fa >= 0) for (int c = 0; c < 6; c++) m += ejac[72 * q + a * 6 + c] * step[6 * E.fa + c];
+                        if (E.kind != 0 && E.fb >= 0) for (int c = 0; c < 6; c++) m += ejac[72 * q + 36 + a * 6 + c] * step[6 * E.fb + c];
+                        mc += m * (eres[6 * q + a] + m / 2.0);
+                    }
+                }
+                model_cost_change = -wave_sum(mc);
+                valid = model_cost_change > 0.0;
+            }
+            if (!valid) {
+                if (++invalid >= 5) { term = ok ? ISV_TERM_INVALID_STEPS : ISV_TERM_LINEAR_SOLVER; break; }
+                radius /= decrease; decrease *= 2.0; reuse_diag = true;        // StepIsInvalid == StepRejected
+                if (lane == 0 && it < ISV_MAX_TRACE) { res.trace_cost[it] = x_cost; res.trace_accepted[it] = 0; }
+                continue;
+            }
+            invalid = 0;
+            double dn = 0;
+            for (int k = lane; k < G.P1; k += 64) {    // candidate = Plus(x, step * scale)
+                const int f = free_of[k];
+                if (f < 0) { for (int c = 0; c < 7; c++) cand[7 * k + c] = pose[7 * k + c]; continue; }
+                double dl[6], xp[7];
+                for (int c = 0; c < 6; c++) dl[c] = step[6 * f + c] * scale[6 * f + c];
+                pose_plus(pose + 7 * k, dl, xp);
+                for (int c = 0; c < 7; c++) { cand[7 * k + c] = xp[c]; const double df = pose[7 * k + c] - xp[c]; dn += df * df; }
+            }
+            PG_GSYNC();
+            const double step_norm = sqrt(wave_sum(dn));
+            const double cand_cost = evaluate(cand, false);
+            bool stop = false, accepted = false;
+            if (step_norm <= 1e-8 * (x_norm + 1e-8)) { term = ISV_TERM_PARAMETER_TOL; stop = true; }
+            else if (fabs(x_cost - cand_cost) <= 1e-6 * x_cost) { term = ISV_TERM_FUNCTION_TOL; stop = true; }
+            if (stop) { if (lane == 0 && it < ISV_MAX_TRACE) { res.trace_cost[it] = x_cost; res.trace_accepted[it] = 0; } break; }
+            const double rel = (x_cost - cand_cost) / model_cost_change;
+            if (rel > 1e-3) {
+                accepted = true;
+                for (int q = lane; q < 7 * G.P1; q += 64) pose[q] = cand[q];
+                PG_GSYNC();
+                x_norm = xnorm_of(pose);
+                x_cost = evaluate(pose, true);
+                scale_jac();
+                gradient();
+                gmax = gmax_of();
+                radius = radius / fmax(1.0 / 3.0, 1.0 - pow(2.0 * rel - 1.0, 3.0));
+                radius = fmin(1e16, radius); decrease = 2.0; reuse_diag = false;
+                nsucc++;
+            } else { radius /= decrease; decrease *= 2.0; reuse_diag = true; }
+            if (lane == 0 && it < ISV_MAX_TRACE) { res.trace_cost[it] = accepted ? x_cost : cand_cost; res.trace_accepted[it] = accepted ? 1 : 0; }
+        }
+    } else {
+        term = ISV_TERM_GRADIENT_TOL;
+        if (lane == 0) res.initial_cost = x_cost;
+    }
+    if (lane == 0) { res.iterations = it; res.termination = term; res.final_cost = x_cost; res.num_successful = nsucc; res.n_poses = G.P1; res.n_free = nf; }
+
+    // ================= ceres::Covariance: diagonal blocks of (J^T J)^-1 at the solution, tangent space ==================
+    double *cov = dv.cov + (size_t)G.pose0 * 36;
+    for (int q = lane; q < G.P1 * 36; q += 64) cov[q] = 0.0;
+    PG_GSYNC();
+    if (nf == 0) return;
+    // the stored Jacobian is the Jacobi-scaled one at x: H_s = S H S, so H^-1 = S H_s^-1 S
+    assemble();
+    for (int q = lane; q < n; q += 64) step[q] = 0.0;
+    PG_GSYNC();
+    if (!factor(step)) { if (lane == 0) res.status = ISV_ERR_NONFINITE; return; }
+    // Takahashi recurrence on the envelope, columns from the last to the first:
+    //   Z(i,j) = [delta_ij L_jj^-T - sum_{k in colpat(j)} Z(i,k) L(k,j)] L_jj^-1      for i in {j} U colpat(j)
+    for (int j = nf - 1; j >= 0; j--) {
+        const double *Li = BLK(L, j, j);
+        const int c0 = colptr[j], c1 = colptr[j + 1];
+        for (int qi = c0; qi <= c1; qi++) {            // the rows below j first: Z(j,j) needs Z(k,j), k in colpat(j)
+            const int i = qi < c1 ? colrows[qi] : j;
+            if (qi == c1) PG_GSYNC();
+            double acc = 0;
+            if (e < 36) {
+                if (i == j) acc = Li[eb * 6 + ea];                                   // L_jj^-T
+                for (int q = c0; q < c1; q++) {
+                    const int k = colrows[q];
+                    const double *Lkj = BLK(L, k, j);
+                    if (i >= k) { const double *Zik = BLK(Z, i, k); for (int m = 0; m < 6; m++) acc -= Zik[ea * 6 + m] * Lkj[m * 6 + eb]; }
+                    else { const double *Zki = BLK(Z, k, i); for (int m = 0; m < 6; m++) acc -= Zki[m * 6 + ea] * Lkj[m * 6 + eb]; }
+                }
+            }
+            PG_WSYNC();
+            if (e < 36) T0[e] = acc;
+            PG_WSYNC();
+            if (e < 36) {
+                double x = 0;
+                for (int m = eb; m < 6; m++) x += T0[ea * 6 + m] * Li[m * 6 + eb];   // times L_jj^-1 (lower)
+                BLK(Z, i, j)[e] = x;
+            }
+        }
+        PG_GSYNC();
+    }
+    for (int k = lane; k < G.P1; k += 64) {
+        const int f = free_of[k];
+        if (f < 0) continue;
+        const double *Zd = BLK(Z, f, f);
+        for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) cov[k * 36 + a * 6 + b] = scale[6 * f + a] * Zd[a * 6 + b] * scale[6 * f + b];
+    }
+}
+
+// =====================================================================================================================
+// host side
+struct isv_pgo {
+    isv_pgo_config_t cfg;
+    std::string err;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    PgDev d{};
+    std::vector<void *> allocs;
+    size_t cap_pose = 0, cap_edge = 0, cap_blk = 0, cap_adj = 0, cap_col = 0;
+};
+
+#define PCHK(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (h)->err = std::string(#call) + ": " + hipGetErrorString(e_); return ISV_ERR_DEVICE; } } while (0)
+template <typename T> static int pal(isv_pgo *h, T **p, size_t n) {
+    void *q = nullptr;
+    PCHK(h, hipMalloc(&q, (n ? n : 1) * sizeof(T)));
+    h->allocs.push_back(q); *p = (T *)q;
+    return ISV_OK;
+}
+#define PTRY(x) do { int rc_ = (x); if (rc_ != ISV_OK) return rc_; } while (0)
+
+extern "C" const char *isv_pgo_last_error(const isv_pgo_t *h) { return h ? h->err.c_str() : "null handle"; }
+
+extern "C" void isv_pgo_destroy(isv_pgo_t *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    for (void *p : h->allocs) (void)hipFree(p);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+static int pgo_create_impl(isv_pgo *h) {
+    int ndev = 0;
+    PCHK(h, hipGetDeviceCount(&ndev));
+    if (ndev <= 0) { h->err = "no HIP device"; return ISV_ERR_DEVICE; }
+    PCHK(h, hipGetDevice(&h->device));
+    PCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    const size_t G = h->cfg.max_graphs, K = h->cfg.max_keyframes;
+    h->cap_pose = G * K; h->cap_edge = G * 3 * K; h->cap_blk = G * (2 * K + (size_t)h->cfg.max_loop_blocks);
+    h->cap_adj = 2 * h->cap_edge; h->cap_col = h->cap_blk;
+    PgDev &d = h->d;
+    PTRY(pal(h, &d.graphs, G)); PTRY(pal(h, &d.pose, h->cap_pose * 7)); PTRY(pal(h, &d.cand, h->cap_pose * 7)); PTRY(pal(h, &d.free_of, h->cap_pose));
+    PTRY(pal(h, &d.edges, h->cap_edge)); PTRY(pal(h, &d.eres, h->cap_edge * 6)); PTRY(pal(h, &d.ejac, h->cap_edge * 72));
+    PTRY(pal(h, &d.adj_ptr, h->cap_pose + G)); PTRY(pal(h, &d.adj, h->cap_adj));
+    PTRY(pal(h, &d.start, h->cap_pose)); PTRY(pal(h, &d.rowptr, h->cap_pose + G)); PTRY(pal(h, &d.colptr, h->cap_pose + G)); PTRY(pal(h, &d.colrows, h->cap_col));
+    PTRY(pal(h, &d.H, h->cap_blk * 36)); PTRY(pal(h, &d.L, h->cap_blk * 36)); PTRY(pal(h, &d.Z, h->cap_blk * 36));
+    PTRY(pal(h, &d.scale, h->cap_pose * 6)); PTRY(pal(h, &d.diag, h->cap_pose * 6)); PTRY(pal(h, &d.grad, h->cap_pose * 6));
+    PTRY(pal(h, &d.step, h->cap_pose * 6)); PTRY(pal(h, &d.ysol, h->cap_pose * 6));
+    PTRY(pal(h, &d.cov, h->cap_pose * 36)); PTRY(pal(h, &d.res, G));
+    return ISV_OK;
+}
+
+extern "C" int isv_pgo_create(const isv_pgo_config_t *cfg, isv_pgo_t **out) {
+    if (!cfg || !out) return ISV_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (cfg->max_keyframes < 2 || cfg->max_graphs < 1 || cfg->max_loop_blocks < 0 || cfg->max_iterations < 0 || cfg->max_iterations >= ISV_MAX_TRACE ||
+        !(cfg->huber_delta > 0)) return ISV_ERR_INVALID_ARG;
+    isv_pgo *h = new isv_pgo();
+    h->cfg = *cfg;
+    const int rc = pgo_create_impl(h);
+    if (rc != ISV_OK) { fprintf(stderr, "isv_pgo_create: %s\n", h->err.c_str()); isv_pgo_destroy(h); return rc; }
+    *out = h;
+    return ISV_OK;
+}
+
+// ---- small host 3x3 / SO(3) arithmetic for the write-back (RelativePoseFactor::update, drift) ----------------------
+namespace {
+struct HQ { double w, x, y, z; };
+void h_q2R(HQ q, double *R) {
+    const double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z, twx = tx * q.w, twy = ty * q.w, twz = tz * q.w;
+    const double txx = tx * q.x, txy = ty * q.x, txz = tz * q.x, tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+    R[0] = 1 - (tyy + tzz); R[1] = txy - twz; R[2] = txz + twy; R[3] = txy + twz; R[4] = 1 - (txx + tzz); R[5] = tyz - twx;
+    R[6] = txz - twy; R[7] = tyz + twx; R[8] = 1 - (txx + tyy);
+}
+HQ h_R2q(const double *m) {      // Eigen matrix -> quaternion
+    HQ q; double t = m[0] + m[4] + m[8];
+    if (t > 0) { t = std::sqrt(t + 1.0); q.w = 0.5 * t; t = 0.5 / t; q.x = (m[7] - m[5]) * t; q.y = (m[2] - m[6]) * t; q.z = (m[3] - m[1]) * t; return q; }
+    int i = 0; if (m[4] > m[0]) i = 1; if (m[8] > m[i * 4]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = std::sqrt(m[i * 4] - m[j * 4] - m[k * 4] + 1.0);
+    double v[3]; v[i] = 0.5 * t; t = 0.5 / t;
+    q.w = (m[k * 3 + j] - m[j * 3 + k]) * t; v[j] = (m[j * 3 + i] + m[i * 3 + j]) * t; v[k] = (m[k * 3 + i] + m[i * 3 + k]) * t;
+    q.x = v[0]; q.y = v[1]; q.z = v[2];
+    return q;
+}
+HQ h_qn(HQ a) { const double n = std::sqrt(a.w * a.w + a.x * a.x + a.y * a.y + a.z * a.z); return HQ{a.w / n, a.x / n, a.y / n, a.z / n}; }
+HQ h_qinv(HQ a) { const double n2 = a.w * a.w + a.x * a.x + a.y * a.y + a.z * a.z; return HQ{a.w / n2, -a.x / n2, -a.y / n2, -a.z / n2}; }
+HQ h_qmul(HQ a, HQ b) { return HQ{a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z, a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y, a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z, a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x}; }
+void h_mm(const double *A, const double *B, double *C) { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double s = 0; for (int k = 0; k < 3; k++) s += A[i * 3 + k] * B[k * 3 + j]; C[i * 3 + j] = s; } }
+void h_mv(const double *A, const double *v, double *o) { for (int i = 0; i < 3; i++) o[i] = A[i * 3] * v[0] + A[i * 3 + 1] * v[1] + A[i * 3 + 2] * v[2]; }
+void h_mtv(const double *A, const double *v, double *o) { for (int i = 0; i < 3; i++) o[i] = A[i] * v[0] + A[3 + i] * v[1] + A[6 + i] * v[2]; }
+void h_log(HQ q, double *om) {   // Sophus SO3::log of a unit quaternion
+    const double n2 = q.x * q.x + q.y * q.y + q.z * q.z, n = std::sqrt(n2);
+    double f;
+    if (n2 < 1e-20) f = 2.0 / q.w - 2.0 / 3.0 * n2 / (q.w * q.w * q.w);
+    else if (std::fabs(q.w) < 1e-10) f = (q.w > 0 ? M_PI : -M_PI) / n;
+    else f = 2.0 * std::atan(n / q.w) / n;
+    om[0] = f * q.x; om[1] = f * q.y; om[2] = f * q.z;
+}
+HQ h_exp(const double *om) {
+    const double t2 = om[0] * om[0] + om[1] * om[1] + om[2] * om[2], t = std::sqrt(t2);
+    double im, re;
+    if (t2 < 1e-20) { const double t4 = t2 * t2; im = 0.5 - t2 / 48.0 + t4 / 3840.0; re = 1.0 - t2 / 8.0 + t4 / 384.0; }
+    else { im = std::sin(0.5 * t) / t; re = std::cos(0.5 * t); }
+    return HQ{re, im * om[0], im * om[1], im * om[2]};
+}
+void h_R2ypr(const double *R, double *ypr) {     // Utility::R2ypr, degrees
+    const double y = std::atan2(R[3], R[0]), p = std::atan2(-R[6], R[0] * std::cos(y) + R[3] * std::sin(y));
+    const double r = std::atan2(R[2] * std::sin(y) - R[5] * std::cos(y), -R[1] * std::sin(y) + R[4] * std::cos(y));
+    ypr[0] = y / M_PI * 180.0; ypr[1] = p / M_PI * 180.0; ypr[2] = r / M_PI * 180.0;
+}
+// RelativePoseFactor::update, solver overload (include/factor/relative_pose_factor.h:103-117)
+void h_relpose_update(isv_relpose_t *f, const double *ti, const double *Ri, const double *tj, const double *Rj, const double *PSi, const double *PSj) {
+    const HQ Qi{PSi[6], PSi[3], PSi[4], PSi[5]}, Qj{PSj[6], PSj[3], PSj[4], PSj[5]};
+    double d_tj[3], d_ti[3], Qm[9], A[9], B[9], lgi[3], lgj[3], v1[3], v2[3];
+    for (int k = 0; k < 3; k++) { d_tj[k] = PSj[k] - tj[k]; d_ti[k] = PSi[k] - ti[k]; }
+    h_q2R(h_qinv(Qj), Qm); h_mm(Qm, Rj, A); h_log(h_qn(h_R2q(A)), lgj);
+    h_q2R(h_qinv(Qi), Qm); h_mm(Qm, Ri, B); h_log(h_qn(h_R2q(B)), lgi);
+    h_mtv(Ri, d_tj, v1); h_mtv(Ri, d_ti, v2);
+    const double *t = f->delta_t;
+    const double v3[3] = {t[1] * lgi[2] - t[2] * lgi[1], t[2] * lgi[0] - t[0] * lgi[2], t[0] * lgi[1] - t[1] * lgi[0]};     // skew(delta_t) * log
+    for (int k = 0; k < 3; k++) f->delta_t[k] += v1[k] - v2[k] + v3[k];
+    double Ji[9], w[3], E[9], T[9];
+    h_q2R(h_qmul(h_qinv(Qj), Qi), Ji);
+    for (int k = 0; k < 9; k++) Ji[k] = -Ji[k];
+    h_mv(Ji, lgi, w);
+    h_q2R(h_exp(w), E); h_mm(f->delta_R, E, T); memcpy(f->delta_R, T, sizeof(T));
+    h_q2R(h_exp(lgj), E); h_mm(f->delta_R, E, T); memcpy(f->delta_R, T, sizeof(T));
+}
+void h_inv6(const double *Ain, double *Inv) {    // PartialPivLU inverse of a 6x6 (Eigen MatrixXd::inverse)
+    double A[36]; memcpy(A, Ain, sizeof(A));
+    int perm[6]; for (int i = 0; i < 6; i++) perm[i] = i;
+    for (int k = 0; k < 6; k++) {
+        int p = k; double best = std::fabs(A[k * 6 + k]);
+        for (int i = k + 1; i < 6; i++) if (std::fabs(A[i * 6 + k]) > best) { best = std::fabs(A[i * 6 + k]); p = i; }
+        if (p != k) { for (int j = 0; j < 6; j++) std::swap(A[k * 6 + j], A[p * 6 + j]); std::swap(perm[k], perm[p]); }
+        for (int i = k + 1; i < 6; i++) { A[i * 6 + k] /= A[k * 6 + k]; for (int j = k + 1; j < 6; j++) A[i * 6 + j] -= A[i * 6 + k] * A[k * 6 + j]; }
+    }
+    for (int c = 0; c < 6; c++) {
+        double x[6];
+        for (int i = 0; i < 6; i++) x[i] = perm[i] == c ? 1.0 : 0.0;
+        for (int i = 0; i < 6; i++) { double s = x[i]; for (int k = 0; k < i; k++) s -= A[i * 6 + k] * x[k]; x[i] = s; }
+        for (int i = 5; i >= 0; i--) { double s = x[i]; for (int k = i + 1; k < 6; k++) s -= A[i * 6 + k] * x[k]; x[i] = s / A[i * 6 + i]; }
+        for (int i = 0; i < 6; i++) Inv[i * 6 + c] = x[i];
+    }
+}
+}  // namespace
+
+// CombinedFactors::operator+ (include/factor/pose_graph_factors.h:27-51); host arithmetic on 6x6 matrices
+extern "C" int isv_combined_factors_add(isv_combined_factors_t *acc, int32_t *acc_length, int64_t *acc_vio_index,
+                                        const isv_combined_factors_t *other, int64_t other_vio_index) {
+    if (!acc || !acc_length || !acc_vio_index || !other) return ISV_ERR_INVALID_ARG;
+    const double *R0 = acc->relative_pose.delta_R, *t0 = acc->relative_pose.delta_t;
+    const double *R1 = other->relative_pose.delta_R, *t1 = other->relative_pose.delta_t, *S = other->relative_pose.sqrt_info;
+    double W[36], cov1[36], Adj[36] = {0}, T[36], info[36];
+    for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) { double s = 0; for (int k = 0; k < 6; k++) s += S[k * 6 + a] * S[k * 6 + b]; W[a * 6 + b] = s; }
+    h_inv6(W, cov1);
+    // Sophus::SE3d::Adj(): [[R, [t]x R], [0, R]]
+    const double Sk[9] = {0, -t0[2], t0[1], t0[2], 0, -t0[0], -t0[1], t0[0], 0};
+    double SR[9]; h_mm(Sk, R0, SR);
+    for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) { Adj[a * 6 + b] = R0[a * 3 + b]; Adj[a * 6 + 3 + b] = SR[a * 3 + b]; Adj[(3 + a) * 6 + 3 + b] = R0[a * 3 + b]; }
+    for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) { double s = 0; for (int k = 0; k < 6; k++) s += Adj[a * 6 + k] * cov1[k * 6 + b]; T[a * 6 + b] = s; }
+    for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) { double s = 0; for (int k = 0; k < 6; k++) s += T[a * 6 + k] * Adj[b * 6 + k]; acc->covRel[a * 6 + b] += s; }
+    acc->has_rollpitch = other->has_rollpitch; acc->rollpitch = other->rollpitch;
+    double Rn[9], tn[3], v[3];
+    h_mm(R0, R1, Rn); h_mv(R0, t1, v);
+    for (int k = 0; k < 3; k++) tn[k] = v[k] + t0[k];
+    memcpy(acc->relative_pose.delta_R, Rn, sizeof(Rn)); memcpy(acc->relative_pose.delta_t, tn, sizeof(tn));
+    h_inv6(acc->covRel, info);
+    double Lm[36]; memcpy(Lm, info, sizeof(Lm));                 // LLT (lower, reads the lower triangle), sqrt_info = L^T
+    for (int j = 0; j < 6; j++) {
+        double dd = Lm[j * 6 + j];
+        for (int k = 0; k < j; k++) dd -= Lm[j * 6 + k] * Lm[j * 6 + k];
+        Lm[j * 6 + j] = std::sqrt(dd);
+        for (int i = j + 1; i < 6; i++) { double s = Lm[i * 6 + j]; for (int k = 0; k < j; k++) s -= Lm[i * 6 + k] * Lm[j * 6 + k]; Lm[i * 6 + j] = s / Lm[j * 6 + j]; }
+    }
+    for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) acc->relative_pose.sqrt_info[i * 6 + j] = j >= i ? Lm[j * 6 + i] : 0.0;
+    acc->distance = std::sqrt(tn[0] * tn[0] + tn[1] * tn[1] + tn[2] * tn[2]);
+    (*acc_length)++;
+    if (*acc_vio_index == -1) { memcpy(acc->ti, other->ti, 24); memcpy(acc->Ri, other->Ri, 72); *acc_vio_index = other_vio_index; acc->ts = other->ts; }
+    return ISV_OK;
+}
+
+extern "C" int isv_pgo_optimize_batch(isv_pgo_t *h, int32_t ng, const int32_t *ns, isv_pg_keyframe_t *const *kfs, const int32_t *firsts,
+                                      const int32_t *curs, isv_pgo_result_t *results) {
+    if (!h || ng < 1 || !ns || !kfs || !firsts || !curs || !results) return ISV_ERR_INVALID_ARG;
+    PCHK(h, hipSetDevice(h->device));
+    if (ng > h->cfg.max_graphs) { h->err = "more graphs than max_graphs"; return ISV_ERR_CAPACITY; }
+    std::vector<PgGraph> graphs(ng);
+    std::vector<double> pose; std::vector<int32_t> free_of, adj_ptr, adj, start, rowptr, colptr, colrows;
+    std::vector<PgEdge> edges;
+    std::vector<std::vector<int>> local(ng);
+    std::vector<int> cur_pos(ng, -1), n_loops(ng, 0);
+    size_t nblk_tot = 0, nfree_tot = 0;
+    for (int g = 0; g < ng; g++) {
+        const int n = ns[g]; isv_pg_keyframe_t *kf = kfs[g];
+        if (n < 1 || !kf) return ISV_ERR_INVALID_ARG;
+        PgGraph &G = graphs[g];
+        memset(&G, 0, sizeof(G));
+        G.pose0 = (int32_t)(pose.size() / 7); G.free0 = (int32_t)nfree_tot; G.edge0 = (int32_t)edges.size(); G.blk0 = (int32_t)nblk_tot;
+        G.adj0 = (int32_t)adj.size(); G.col0 = (int32_t)colrows.size(); G.vec0 = (int32_t)(6 * nfree_tot);
+        G.max_iter = h->cfg.max_iterations; G.huber = h->cfg.huber_delta;
+        // parameter blocks: keyframes first_looped_index .. cur_index in list order (pose_graph.cpp:271-299)
+        std::vector<int> &loc = local[g];
+        loc.assign(n, -1);
+        int pi = 0;
+        for (int k = 0; k < n; k++) {
+            if (kf[k].index < firsts[g] || cur_pos[g] >= 0) continue;
+            loc[k] = pi++;
+            if (kf[k].index == curs[g]) cur_pos[g] = k;
+        }
+        if (cur_pos[g] < 0) { h->err = "cur_index is not in the keyframe list (or lies before first_looped_index)"; return ISV_ERR_INVALID_ARG; }
+        if (pi > h->cfg.max_keyframes) { h->err = "more keyframes than max_keyframes"; return ISV_ERR_CAPACITY; }
+        G.P1 = pi;
+        const int param_index = pi - 1;
+        std::vector<int> fo(pi, -1);
+        int nf = 0;
+        for (int k = 0; k < n; k++) {
+            const int li = loc[k]; if (li < 0) continue;
+            for (int c = 0; c < 9; c++) if (!(kf[k].vio_R_w_i[c] - kf[k].vio_R_w_i[c] == 0.0)) { h->err = "non-finite keyframe pose"; return ISV_ERR_NONFINITE; }
+            const HQ q = h_qn(h_R2q(kf[k].vio_R_w_i));                    // tmp_q = tmp_r; tmp_q.normalize()
+            pose.insert(pose.end(), {kf[k].vio_T_w_i[0], kf[k].vio_T_w_i[1], kf[k].vio_T_w_i[2], q.x, q.y, q.z, q.w});
+            const bool constant = kf[k].index == firsts[g] || kf[k].sequence == 0;
+            fo[li] = constant ? -1 : nf++;
+        }
+        G.nf = nf;
+        free_of.insert(free_of.end(), fo.begin(), fo.end());
+        // residual blocks of the keyframes BEFORE cur (pose_graph.cpp:303-332)
+        std::vector<std::vector<int32_t>> adjl(nf);
+        std::vector<int> st(nf);
+        for (int f = 0; f < nf; f++) st[f] = f;
+        auto add_edge = [&](PgEdge &E) {
+            E.fa = fo[E.a]; E.fb = E.kind == 0 ? -1 : fo[E.b];
+            const int id = (int)edges.size() - G.edge0;
+            if (E.fa >= 0) adjl[E.fa].push_back((id << 1) | 0);
+            if (E.kind != 0 && E.fb >= 0) adjl[E.fb].push_back((id << 1) | 1);
+            if (E.kind != 0 && E.fa >= 0 && E.fb >= 0) { const int lo = std::min(E.fa, E.fb), hi = std::max(E.fa, E.fb); st[hi] = std::min(st[hi], lo); }
+            edges.push_back(E);
+        };
+        for (int k = 0; k < n; k++) {
+            const int li = loc[k]; if (li < 0 || k == cur_pos[g]) continue;
+            if (kf[k].has_rollpitch) {
+                PgEdge E; memset(&E, 0, sizeof(E));
+                E.kind = 0; E.a = E.b = li; E.dim = 2;
+                memcpy(E.meas_R, kf[k].rollpitch.R, 72); memcpy(E.sqrt_info, kf[k].rollpitch.sqrt_info, 32);
+                add_edge(E);
+            }
+            if (li + 1 <= param_index) {
+                PgEdge E; memset(&E, 0, sizeof(E));
+                E.kind = 1; E.a = li; E.b = li + 1; E.dim = 6;
+                memcpy(E.meas_t, kf[k].relative_pose.delta_t, 24); memcpy(E.meas_R, kf[k].relative_pose.delta_R, 72); memcpy(E.sqrt_info, kf[k].relative_pose.sqrt_info, 288);
+                add_edge(E);
+            }
+            if (kf[k].has_loop) {
+                int conn = -1;
+                for (int m = 0; m < n; m++) if (kf[m].index == kf[k].loop_index) conn = loc[m];
+                if (conn < 0) { h->err = "loop_index outside the optimised range (the reference asserts loop_index >= first_looped_index)"; return ISV_ERR_INVALID_ARG; }
+                PgEdge E; memset(&E, 0, sizeof(E));
+                E.kind = 2; E.a = conn; E.b = li; E.dim = 6; E.robust = 1;
+                memcpy(E.meas_t, kf[k].loop_info, 24);
+                h_q2R(HQ{kf[k].loop_info[3], kf[k].loop_info[4], kf[k].loop_info[5], kf[k].loop_info[6]}, E.meas_R);
+                for (int dd = 0; dd < 6; dd++) E.sqrt_info[dd * 6 + dd] = std::sqrt(kf[k].loop_weight);
+                add_edge(E);
+                n_loops[g]++;
+            }
+        }
+        G.ne = (int32_t)edges.size() - G.edge0;
+        // skyline + adjacency + column patterns
+        int nb = 0;
+        for (int f = 0; f < nf; f++) { adj_ptr.push_back((int32_t)adj.size() - G.adj0); adj.insert(adj.end(), adjl[f].begin(), adjl[f].end()); start.push_back(st[f]); rowptr.push_back(nb); nb += f - st[f] + 1; }
+        adj_ptr.push_back((int32_t)adj.size() - G.adj0); rowptr.push_back(nb);
+        G.nblk = nb;
+        if (nb - 2 * nf > h->cfg.max_loop_blocks) { h->err = "loop closures span more blocks than max_loop_blocks"; return ISV_ERR_CAPACITY; }
+        std::vector<std::vector<int32_t>> cp(nf);
+        for (int i = 0; i < nf; i++) for (int j = st[i]; j < i; j++) cp[j].push_back(i);
+        for (int j = 0; j < nf; j++) { colptr.push_back((int32_t)colrows.size() - G.col0); colrows.insert(colrows.end(), cp[j].begin(), cp[j].end()); }
+        colptr.push_back((int32_t)colrows.size() - G.col0);
+        nblk_tot += nb; nfree_tot += nf;
+    }
+    if (pose.size() / 7 > h->cap_pose || edges.size() > h->cap_edge || nblk_tot > h->cap_blk || adj.size() > h->cap_adj || colrows.size() > h->cap_col) {
+        h->err = "pose graphs exceed the handle's capacity"; return ISV_ERR_CAPACITY;
+    }
+    PgDev &d = h->d; hipStream_t st = h->stream;
+#define UP(dst, vec) do { if (!(vec).empty()) PCHK(h, hipMemcpyAsync(dst, (vec).data(), sizeof((vec)[0]) * (vec).size(), hipMemcpyHostToDevice, st)); } while (0)
+    UP(d.graphs, graphs); UP(d.pose, pose); UP(d.free_of, free_of); UP(d.edges, edges); UP(d.adj_ptr, adj_ptr); UP(d.adj, adj);
+    UP(d.start, start); UP(d.rowptr, rowptr); UP(d.colptr, colptr); UP(d.colrows, colrows);
+#undef UP
+    hipLaunchKernelGGL(k_pgo, dim3(ng), dim3(64), 0, st, d);
+    PCHK(h, hipGetLastError());
+    std::vector<double> cov(pose.size() / 7 * 36);
+    PCHK(h, hipMemcpyAsync(pose.data(), d.pose, sizeof(double) * pose.size(), hipMemcpyDeviceToHost, st));
+    PCHK(h, hipMemcpyAsync(cov.data(), d.cov, sizeof(double) * cov.size(), hipMemcpyDeviceToHost, st));
+    PCHK(h, hipMemcpyAsync(results, d.res, sizeof(isv_pgo_result_t) * ng, hipMemcpyDeviceToHost, st));
+    PCHK(h, hipStreamSynchronize(st));
+    // write back (pose_graph.cpp:366-407): updatePose, updateCov, the update() calls, drift, the keyframes after cur
+    for (int g = 0; g < ng; g++) {
+        const int n = ns[g]; isv_pg_keyframe_t *kf = kfs[g];
+        const PgGraph &G = graphs[g];
+        isv_pgo_result_t &R = results[g];
+        R.n_loop_edges = n_loops[g];
+        const int param_index = G.P1 - 1;
+        isv_pg_keyframe_t *last = nullptr; const double *last_pose = nullptr;
+        for (int k = 0; k < n; k++) {
+            const int li = local[g][k]; if (li < 0) continue;
+            const double *p = pose.data() + (size_t)(G.pose0 + li) * 7;
+            memcpy(kf[k].T_w_i, p, 24); h_q2R(HQ{p[6], p[3], p[4], p[5]}, kf[k].R_w_i);
+            if (li < param_index) {
+                // ceres::Covariance::GetCovarianceBlock returns the 7x7 AMBIENT block [Sigma 0; 0 0]; the reference receives it in a
+                // 36-double buffer and maps that as a column-major 6x6 (pose_graph.cpp:356-358): reproduced, stored row-major
+                double c7[49] = {0};
+                const double *S6 = cov.data() + (size_t)(G.pose0 + li) * 36;
+                for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) c7[a * 7 + b] = S6[a * 6 + b];
+                for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) kf[k].cov[a * 6 + b] = c7[a + 6 * b];
+                kf[k].cov_computed = 1;
+            }
+            if (last) h_relpose_update(&last->relative_pose, last->T_w_i, last->R_w_i, kf[k].T_w_i, kf[k].R_w_i, last_pose, p);
+            last = &kf[k]; last_pose = p;
+        }
+        const isv_pg_keyframe_t &c = kf[cur_pos[g]];
+        double yc[3], yv[3], vT[9], t[3];
+        h_R2ypr(c.R_w_i, yc); h_R2ypr(c.vio_R_w_i, yv);
+        R.yaw_drift = yc[0] - yv[0];
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) vT[a * 3 + b] = c.vio_R_w_i[b * 3 + a];
+        h_mm(c.R_w_i, vT, R.r_drift);
+        h_mv(R.r_drift, c.vio_T_w_i, t);
+        for (int k = 0; k < 3; k++) R.t_drift[k] = c.T_w_i[k] - t[k];
+        for (int k = cur_pos[g] + 1; k < n; k++) {
+            double Pn[3], Rn[9];
+            h_mv(R.r_drift, kf[k].vio_T_w_i, Pn); for (int dd = 0; dd < 3; dd++) Pn[dd] += R.t_drift[dd];
+            h_mm(R.r_drift, kf[k].vio_R_w_i, Rn);
+            memcpy(kf[k].T_w_i, Pn, 24); memcpy(kf[k].R_w_i, Rn, 72);
+        }
+    }
+    return ISV_OK;
+}
+
+extern "C" int isv_pgo_optimize(isv_pgo_t *h, int32_t n, isv_pg_keyframe_t *kf, int32_t first_looped_index, int32_t cur_index, isv_pgo_result_t *result) {
+    isv_pg_keyframe_t *kfs[1] = {kf};
+    return isv_pgo_optimize_batch(h, 1, &n, kfs, &first_looped_index, &cur_index, result);
+}
+
+// ./loop_pose_output.txt (pose_graph.cpp:412-423): `fixed` stream formatting (6 decimals)
+extern "C" int isv_pgo_write_loop_pose_output(const char *path, int32_t n, const isv_pg_keyframe_t *kf) {
+    if (!path || n < 0 || (n > 0 && !kf)) return ISV_ERR_INVALID_ARG;
+    FILE *f = fopen(path, "w");
+    if (!f) return ISV_ERR_INVALID_ARG;
+    for (int k = 0; k < n; k++) {
+        const HQ q = h_R2q(kf[k].R_w_i);
+        fprintf(f, "%.6f %.6f %.6f %.6f %.6f %.6f %.6f %.6f\n", kf[k].time_stamp, kf[k].T_w_i[0], kf[k].T_w_i[1], kf[k].T_w_i[2], q.w, q.x, q.y, q.z);
+    }
+    fclose(f);
+    return ISV_OK;
+}

@@ -14,6 +14,27 @@
 #define PRL_RAW 82      // per-slot LDS: raw r (9) | raw J (72)
 #define PRL_W 90        // per-slot LDS: r (9) | J (81)
 #define PRL_S 82        // per-slot LDS: sqrt_info (<= 81)
+// unweighted prior Jacobians at a pose (EvaluateOnlyJacobians of the reference factors), 6-column form
+DEV void relpose_jac(const double *dt, const double *dR, const double *pi, const double *pj, double *res, double *Ji, double *Jj) {
+    Quat Qi = q_from_pose(pi), Qj = q_from_pose(pj);
+    double Ri[9], Rj[9], dd[3], qd[3], M1[9], M2[9], lg[3], Jr[9], S[9], nJ[9], T1[9], T2[9];
+    q_to_R(Qi, Ri); q_to_R(Qj, Rj);
+    for (int k = 0; k < 3; k++) dd[k] = pj[k] - pi[k];
+    q_rot(q_inv(Qi), dd, qd);
+    m3_mul_nt(dR, Rj, M1); m3_mul(M1, Ri, M2);
+    so3_log(q_from_R(M2), lg);
+    for (int k = 0; k < 3; k++) { res[k] = dt[k] - qd[k]; res[3 + k] = lg[k]; }
+    so3_rjac_inv(lg, Jr); skew3(qd, S);
+    for (int k = 0; k < 36; k++) { Ji[k] = 0; Jj[k] = 0; }
+    for (int k = 0; k < 9; k++) nJ[k] = -Jr[k];
+    m3_mul_nt(nJ, Ri, T1); m3_mul(T1, Rj, T2);
+    for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) {
+        Ji[a * 6 + b] = Ri[b * 3 + a]; Ji[a * 6 + 3 + b] = -S[a * 3 + b]; Ji[(3 + a) * 6 + 3 + b] = Jr[a * 3 + b];
+        Jj[a * 6 + b] = -Ri[b * 3 + a]; Jj[(3 + a) * 6 + 3 + b] = T2[a * 3 + b];
+    }
+}
+
+
 struct PriorDesc { int kind, strip_off, H_off, valid; const double *S; };   // kind 0 SE3, 1 Linear9, 2 relpose, 3 rollpitch
 DEV PriorDesc prior_desc(const DevBatch &d, int w, int s, int n_rp) {
     PriorDesc p;

@@ -85,3 +85,26 @@ def test_create_rejects_bad_config(lib):
     cfg = abi.make_config(11, 5); cfg.estimate_extrinsic = 1
     assert lib.isv_backend_create(C.byref(cfg), C.byref(h)) == -5
     assert lib.isv_backend_create(None, C.byref(h)) == -1
+
+
+def test_every_posegraph_symbol_is_exported_and_sized(lib, tmp_path):
+    """include/isvins_posegraph.h: every declared entry point is exported, the ctypes mirror has the header's struct sizes,
+    and the optimiser fails loudly without a GPU (no CPU path)"""
+    from isvins_amd import posegraph as pg
+    header = os.path.join(ROOT, "include", "isvins_posegraph.h")
+    names = [n for n in declared_functions(header) if n.startswith("isv_pgo_") or n.startswith("isv_combined_")]
+    assert set(names) == set(pg.EXPORTS)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/isvins_posegraph.h but not exported"
+    structs = ["isv_pg_keyframe_t", "isv_pgo_config_t", "isv_pgo_result_t"]
+    src = tmp_path / "szp.c"
+    src.write_text('#include <stdio.h>\n#include "isvins_posegraph.h"\nint main(){' +
+                   "".join(f'printf("%zu\\n", sizeof({n}));' for n in structs) + "return 0;}")
+    exe = tmp_path / "szp"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    for n, s in zip(structs, [int(x) for x in subprocess.check_output([str(exe)]).split()]):
+        assert C.sizeof(getattr(pg, n)) == s, n
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(backend.BackendError):
+            pg.PoseGraphOptimizer(64)
