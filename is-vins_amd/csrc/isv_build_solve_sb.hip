@@ -121,6 +121,10 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
     int *yo = (int *)p; p += 16;             // yo[0..N]: offsets of the fill blocks of each chain node (N <= 31)
     int *skipL = (int *)p; p += 16;          // imu_skip flags of this window
     int *flag = (int *)p; p += 2;
+    // (I | J << 8) of packed pose block q: one LDS lookup instead of a search loop per matrix entry
+    unsigned short *blkIJ = (unsigned short *)p; p += (N * (N + 1) / 2 + 3) / 4 + 1;
+    unsigned char *triAB = (unsigned char *)p; p += 20;   // (row, col) of triangular pair index e < 78 (12 x 12 lower): triAB[2e], triAB[2e+1]
+    unsigned char *yNode = (unsigned char *)p; p += 16;   // chain node of fill block b (ytot / 54 <= 96 blocks for N <= 11; BIG windows search)
     double *Spp = p; p += nS;                // pose-pose, packed lower block triangle of 6x6 blocks (Tvis layout)
     double *Dss = p; p += N * 81;            // speed/bias diagonal blocks -> inverse Cholesky factors
     double *Css = p; p += N * 81;            // coupling of node i to its parent: rows parent, cols i
@@ -132,6 +136,14 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
         yo[N] = o; flag[0] = 0;
     }
     if (t < N - 1) skipL[t] = d.imu_skip[(size_t)w * (N - 1) + t];
+    for (int q = t; q < N * (N + 1) / 2; q += LS) {
+        int ca = 0;
+        while (ca + 1 < N && (ca + 1) * N - (ca + 1) * ca / 2 <= q) ca++;
+        blkIJ[q] = (unsigned short)((ca + (q - (ca * N - ca * (ca - 1) / 2))) | (ca << 8));
+    }
+    if (t < 78) { int a = 0; while ((a + 1) * (a + 2) / 2 <= t) a++; triAB[2 * t] = (unsigned char)a; triAB[2 * t + 1] = (unsigned char)(t - a * (a + 1) / 2); }
+    __syncthreads();
+    if (!BIG) for (int b = t; b < yo[N] / 54; b += LS) { int i = 0; while (yo[i + 1] <= 54 * b) i++; yNode[b] = (unsigned char)i; }
     __syncthreads();
     const int ytot = yo[N];
     // cost of the window at x = sum over its residual blocks (fixed-shape strided partials + tree below)
@@ -156,9 +168,8 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
     auto spp_decode = [&](int e, int &I, int &J, int &r, int &c) {
         const int q = e / 36, rc = e - 36 * q;
         r = rc / 6; c = rc - 6 * r;
-        int ca = 0;
-        while (ca + 1 < N && (ca + 1) * N - (ca + 1) * ca / 2 <= q) ca++;
-        J = ca; I = ca + (q - (ca * N - ca * (ca - 1) / 2));
+        const int ij = blkIJ[q];
+        I = ij & 255; J = ij >> 8;
     };
 
     const int t_outer = t;
@@ -188,13 +199,11 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
             const double *HA = H + (size_t)(I - 1) * ISV_IMU_H, *HB = H + (size_t)I * ISV_IMU_H;
             int ia, ib;
             if (q < 21) {
-                int r = 0; while ((r + 1) * (r + 2) / 2 <= q) r++;
-                const int c = q - r * (r + 1) / 2;
+                const int r = triAB[2 * q], c = triAB[2 * q + 1];
                 ia = pairidx2(15 + r, 15 + c); ib = pairidx2(r, c);
             } else if (q < 66) {
                 q -= 21;
-                int r = 0; while ((r + 1) * (r + 2) / 2 <= q) r++;
-                const int c = q - r * (r + 1) / 2;
+                const int r = triAB[2 * q], c = triAB[2 * q + 1];
                 ia = pairidx2(21 + r, 21 + c); ib = pairidx2(6 + r, 6 + c);
             } else {
                 q -= 66;
@@ -210,14 +219,12 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
             const int I = e / 120;
             int q = e - 120 * I;
             if (q < 21) {
-                int r = 0; while ((r + 1) * (r + 2) / 2 <= q) r++;
-                const int c = q - r * (r + 1) / 2;
+                const int r = triAB[2 * q], c = triAB[2 * q + 1];
                 Spp[sblk(I, I, N) + r * 6 + c] += v;
                 if (r == c) hdiag[15 * I + r] += v;
             } else if (q < 66) {
                 q -= 21;
-                int r = 0; while ((r + 1) * (r + 2) / 2 <= q) r++;
-                const int c = q - r * (r + 1) / 2;
+                const int r = triAB[2 * q], c = triAB[2 * q + 1];
                 Dss[I * 81 + r * 9 + c] = v;
                 if (r == c) hdiag[15 * I + 6 + r] = v;
             } else {
@@ -330,35 +337,42 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
         __syncthreads();
         STAMP(1);
         // ---- prior factors (precomputed J^T J, staged in red[]) ---------------------------------------
+        // Three conflict-free phases instead of a barrier per factor: factors of one phase touch disjoint entries
+        //   A: Linear9 + the relative-pose factors (k, k+1) with k even     B: SE3 prior (pose 0) + those with k odd
+        //   C: the roll/pitch factors, entry e of EVERY factor by the same thread (two factors on one pose stay ordered)
         {
-            const int nprior = 2 + (d.Nvo - 1) + d.n_rp[w];
-            for (int q = 0; q < nprior; q++) {
+            auto prior_entry = [&](int q, int e) {
                 int ncol, off, c0, c1 = 0;
                 if (q == 0) { ncol = 6; off = PH_SE3; c0 = 0; }
                 else if (q == 1) { ncol = 9; off = PH_LIN9; c0 = 15 * (d.Nvo - 1) + 6; }
                 else if (q < 1 + d.Nvo) { const int k = q - 2; ncol = 12; off = PH_REL0 + PH_REL_SZ * k; c0 = 15 * k; c1 = 15 * (k + 1); }
                 else { const int m = q - 1 - d.Nvo; ncol = 6; off = PH_REL0 + PH_REL_SZ * (d.Nvo - 1) + PH_RP_SZ * m; c0 = 15 * d.rollpitch[(size_t)w * d.max_rp + m].index; }
                 const int np2 = ncol * (ncol + 1) / 2;
-                for (int e = t; e < np2 + ncol; e += LS) {
-                    const double v = red[off + e];
-                    if (e < np2) {
-                        int aa = 0;
-                        while ((aa + 1) * (aa + 2) / 2 <= e) aa++;
-                        const int bb = e - aa * (aa + 1) / 2;
-                        const int ga = (aa < 6 || ncol != 12) ? c0 + aa : c1 + aa - 6;
-                        const int gb = (bb < 6 || ncol != 12) ? c0 + bb : c1 + bb - 6;
-                        const int Ia = ga / 15, ra = ga - 15 * Ia, Ib = gb / 15, rb = gb - 15 * Ib;
-                        if (ra < 6) Spp[sblk(Ia, Ib, N) + ra * 6 + rb] += v;
-                        else Dss[Ia * 81 + (ra - 6) * 9 + (rb - 6)] += v;
-                        if (aa == bb) hdiag[ga] += v;
-                    } else {
-                        const int aa = e - np2;
-                        const int ga = (aa < 6 || ncol != 12) ? c0 + aa : c1 + aa - 6;
-                        g[ga] += v;
-                    }
+                if (e >= np2 + ncol) return;
+                const double v = red[off + e];
+                if (e < np2) {
+                    const int aa = triAB[2 * e], bb = triAB[2 * e + 1];
+                    const int ga = (aa < 6 || ncol != 12) ? c0 + aa : c1 + aa - 6;
+                    const int gb = (bb < 6 || ncol != 12) ? c0 + bb : c1 + bb - 6;
+                    const int Ia = ga / 15, ra = ga - 15 * Ia, Ib = gb / 15, rb = gb - 15 * Ib;
+                    if (ra < 6) Spp[sblk(Ia, Ib, N) + ra * 6 + rb] += v;
+                    else Dss[Ia * 81 + (ra - 6) * 9 + (rb - 6)] += v;
+                    if (aa == bb) hdiag[ga] += v;
+                } else {
+                    const int aa = e - np2;
+                    const int ga = (aa < 6 || ncol != 12) ? c0 + aa : c1 + aa - 6;
+                    g[ga] += v;
                 }
-                __syncthreads();
-            }
+            };
+            const int nrel = d.Nvo - 1, nrp = d.n_rp[w];
+            // phase A: slot 0 = Linear9 (54 entries), slots 1.. = relative-pose factors 0, 2, 4, .. (90 entries each)
+            for (int e = t; e < 90 * (1 + (nrel + 1) / 2); e += LS) { const int sl = e / 90; prior_entry(sl == 0 ? 1 : 2 + 2 * (sl - 1), e - 90 * sl); }
+            __syncthreads();
+            // phase B: slot 0 = SE3 prior (27 entries), slots 1.. = relative-pose factors 1, 3, ..
+            for (int e = t; e < 90 * (1 + nrel / 2); e += LS) { const int sl = e / 90; prior_entry(sl == 0 ? 0 : 2 + 2 * (sl - 1) + 1, e - 90 * sl); }
+            __syncthreads();
+            if (t < 27) for (int m = 0; m < nrp; m++) prior_entry(1 + d.Nvo + m, t);
+            __syncthreads();
         }
         STAMP(2);
         // ---- Jacobi scaling, LM diagonal, Cauchy data -------------------------------------------------
@@ -408,7 +422,7 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
             }
             for (int e = t; e < ytot; e += LS) {
                 int i = 0;
-                while (yo[i + 1] <= e) i++;
+                if (BIG) { while (yo[i + 1] <= e) i++; } else i = yNode[e / 54];
                 const int q = e - yo[i], ai = q / 54, rc = q - 54 * ai, r = rc / 9, c = rc - 9 * r;
                 const int gi = 15 * (nlo(i, M) + ai) + r, gj = 15 * i + 6 + c;
                 const double v = Ysb[e];
@@ -416,10 +430,12 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
                 Ysb[e] = v * sc[gi] * sc[gj];
             }
             __syncthreads();                               // every thread is done with u (it lives in red)
-            red[t] = accq;
+            // fixed-shape sum: butterfly inside every wavefront, then the eight wavefront sums in order
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) accq += __shfl_xor(accq, off);
+            if (lane == 0) red[wv] = accq;
             __syncthreads();
-            for (int off = LS / 2; off > 0; off >>= 1) { if (t < off) red[t] += red[t + off]; __syncthreads(); }
-            if (t == 0) st.qT = red[0];
+            if (t == 0) st.qT = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
         }
         __syncthreads();
         STAMP(3);
@@ -461,8 +477,7 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
                     for (int k = 0; k < 9; k++) s += C[r * 9 + k] * y[15 * i + 6 + k];
                     y[15 * pp + 6 + r] -= s;
                 } else if (e < 45) {
-                    int r = 0; while ((r + 1) * (r + 2) / 2 <= e) r++;
-                    const int c = e - r * (r + 1) / 2;
+                    const int r = triAB[2 * e], c = triAB[2 * e + 1];
                     double s = 0;
 #pragma unroll
                     for (int k = 0; k < 9; k++) s += C[r * 9 + k] * C[c * 9 + k];
@@ -568,9 +583,9 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
                         continue;
                     }
                     const int q = e / 36, rc = e - 36 * q, r = rc / 6, c = rc - 6 * r;
-                    int ca = 0;                                  // column within the trailing triangle
-                    while (ca + 1 < m && (ca + 1) * m - (ca + 1) * ca / 2 <= q) ca++;
-                    const int ia = ca + (q - (ca * m - ca * (ca - 1) / 2));
+                    // (the trailing triangle is the tail of the packed storage: absolute block = first trailing block + q)
+                    const int ij = blkIJ[e0 / 36 + q];
+                    const int ia = (ij & 255) - (J + 1), ca = (ij >> 8) - (J + 1);
                     if (ia == ca && r < c) continue;
                     const double *XI = X + ia * 36 + r * 6, *XK = X + ca * 36 + c * 6;
                     double s = 0;
@@ -755,20 +770,23 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
             for (int k = 0; k < 9; k++) m = fmax(m, fabs(g[15 * i + 6 + k]));
         }
         __syncthreads();
-        red[t] = cpart;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { cpart += __shfl_xor(cpart, off); m = fmax(m, __shfl_xor(m, off)); }
+        if (lane == 0) { red[wv] = cpart; red[8 + wv] = m; }
         __syncthreads();
-        for (int off = LS / 2; off > 0; off >>= 1) { if (t < off) red[t] += red[t + off]; __syncthreads(); }
-        cost_w = red[0];
+        cost_w = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+        if (t == 0) {
+            double mm = red[8];
+            for (int k = 1; k < 8; k++) mm = fmax(mm, red[8 + k]);
+            d.cost[w] = cost_w;
+            red[16] = mm;
+        }
         __syncthreads();
-        red[t] = m;
-        __syncthreads();
-        for (int off = LS / 2; off > 0; off >>= 1) { if (t < off) red[t] = fmax(red[t], red[t + off]); __syncthreads(); }
-        if (t == 0) d.cost[w] = cost_w;
     }
     if (t == 0) {
         atomicAdd(&d.act[iteration], 1);
         // (mu already at max_mu on entry: nothing was assembled, x has not moved, the gradient is the previous one)
-        if (assembled) st.gmax = red[0];
+        if (assembled) st.gmax = red[16];
         st.mu = mu;
         st.ls_fail = ls_fail;
         st.need_linearize = 0;
@@ -796,5 +814,5 @@ size_t build_solve_sb_bytes(int N, int prior_H_sz) {
     const size_t stage = (size_t)RCH * (6 * (size_t)N + 1);     // retry staging lives in the Dss/Css/Ysb region
     if (tail < stage) tail = stage;
     const size_t nred = (size_t)sb_nred(N, prior_H_sz);
-    return (3 * n + nred + 16 + 16 + 2 + nS + tail + 2) * sizeof(double);
+    return (3 * n + nred + 16 + 16 + 2 + ((size_t)N * (N + 1) / 2 + 3) / 4 + 1 + 20 + 16 + nS + tail + 2) * sizeof(double);
 }

@@ -173,24 +173,24 @@ __global__ __launch_bounds__(64 * ((NT * (NT + 1) / 2 + TPW - 1) / TPW), MINW) v
         // Landmark scalars (what SchurEliminator needs per e-block) from the per-factor pieces k_lin_gram left, summed in
         // the landmark's own factor order: E = J_l^T J_l, g_l = J_l^T r, host-frame w = sum J_i^T J_l.  (The unfused
         // path does this inside k_proj_linearize<0>, where a landmark's factors are adjacent lanes.)
-        for (int l = t; l < Lw; l += nthr) {
-            const int gl = l0 + l, kf = d.lm_k[gl] - 1;
-            const double2 *fl = (const double2 *)(d.flm + (size_t)d.lm_f0[gl] * 8);
-            double2 eg = fl[0], w01 = fl[1], w23 = fl[2], w45 = fl[3];
-            for (int o = 1; o < kf; o++) {
-                const double2 a = fl[4 * o], b = fl[4 * o + 1], c = fl[4 * o + 2], e = fl[4 * o + 3];
-                eg.x += a.x; eg.y += a.y; w01.x += b.x; w01.y += b.y; w23.x += c.x; w23.y += c.y; w45.x += e.x; w45.y += e.y;
+        // four threads per landmark: part 0 sums {E, g} and forms the scalars, parts 1..3 sum one pair of the host w each
+        for (int q = t; q < 4 * Lw; q += nthr) {
+            const int l = q >> 2, part = q & 3, gl = l0 + l, kf = d.lm_k[gl] - 1;
+            const double2 *fl = (const double2 *)(d.flm + (size_t)d.lm_f0[gl] * 8) + part;
+            double2 acc = fl[0];
+            for (int o = 1; o < kf; o++) { const double2 a = fl[4 * o]; acc.x += a.x; acc.y += a.y; }
+            if (part == 0) {
+                double sl;
+                if (st.iteration == 0) { sl = 1.0 / (1.0 + sqrt(acc.x)); d.scale_l[gl] = sl; }
+                else sl = d.scale_l[gl];
+                const double Es = sl * sl * acc.x;
+                const double Dl2 = fmin(fmax(Es, 1e-6), 1e32);
+                const double Dl = sqrt(Dl2);
+                d.lm_cg[gl] = make_double2(sl * sl / (Es + st.mu * Dl2), acc.y);
+                d.lmE[gl] = acc.x; d.lmG[gl] = acc.y; d.diag_l[gl] = Dl; d.grad_l[gl] = sl * acc.y / Dl;
+            } else {
+                ((double2 *)(d.W + (size_t)(d.lm_f0[gl] + gl) * 6))[part - 1] = acc;     // host observation slot
             }
-            double sl;
-            if (st.iteration == 0) { sl = 1.0 / (1.0 + sqrt(eg.x)); d.scale_l[gl] = sl; }
-            else sl = d.scale_l[gl];
-            const double Es = sl * sl * eg.x;
-            const double Dl2 = fmin(fmax(Es, 1e-6), 1e32);
-            const double Dl = sqrt(Dl2);
-            d.lm_cg[gl] = make_double2(sl * sl / (Es + st.mu * Dl2), eg.y);
-            d.lmE[gl] = eg.x; d.lmG[gl] = eg.y; d.diag_l[gl] = Dl; d.grad_l[gl] = sl * eg.y / Dl;
-            double2 *wd = (double2 *)(d.W + (size_t)(d.lm_f0[gl] + gl) * 6);           // host observation slot
-            wd[0] = w01; wd[1] = w23; wd[2] = w45;
         }
         __syncthreads();                                   // the host slots and lm_cg are read below by other threads
     }
