@@ -65,9 +65,7 @@ DEV double block_sum(double v, double *red, int t) {
 #else
 #define DSTAMP(k) do {} while (0)
 #endif
-__global__ __launch_bounds__(256, 4) void k_dogleg(DevBatch d) {
-    __shared__ double red[256];
-    const int w = blockIdx.x, t = threadIdx.x;
+DEV void dogleg_body(DevBatch &d, const int w, const int t, double *red) {
     SolveState &st = d.st[w];
     if (st.termination != ISV_TERM_RUNNING) return;
     const int n = d.np, N = d.N, l0 = d.lm_off[w], l1 = d.lm_off[w + 1];
@@ -267,6 +265,23 @@ __global__ __launch_bounds__(256, 4) void k_dogleg(DevBatch d) {
     }
     DSTAMP(53);
 }
+template <bool FUSED> DEV void step_control_body(DevBatch &d, const int w, const int t, double *cl, double *red, int &s_accept);
+// CONTROL: the candidate evaluation + TrustRegionMinimizer step control of this window follow in the same workgroup
+// (one launch and one round of workgroups less per iteration than k_dogleg -> k_step_control<true>)
+template <bool CONTROL>
+__global__ __launch_bounds__(256, 4) void k_dogleg(DevBatch d) {
+    __shared__ double red[256];
+    __shared__ int s_accept;
+    const int w = blockIdx.x, t = threadIdx.x;
+    dogleg_body(d, w, t, red);
+    if (CONTROL) {
+        extern __shared__ __align__(16) double dync[];
+        __syncthreads();                               // candidate states, per-factor costs and model pieces of this window are written
+        step_control_body<true>(d, w, t, dync, red, s_accept);
+    }
+}
+template __global__ void k_dogleg<false>(DevBatch);
+template __global__ void k_dogleg<true>(DevBatch);
 
 
 // ------------------------------------------------------------------------------------------
@@ -277,11 +292,7 @@ __global__ __launch_bounds__(256, 4) void k_dogleg(DevBatch d) {
 // of being written to fcost_c / fmodel by a tile-grid kernel and read back: one launch and one round trip less per
 // iteration.  Dynamic LDS: candidate poses [N][12] | extrinsic [12] | poses at x [N][12] | tangent step [N][6].
 template <bool FUSED>
-__global__ __launch_bounds__(256) void k_step_control(DevBatch d) {
-    extern __shared__ __align__(16) double cl[];
-    __shared__ double red[256];
-    __shared__ int s_accept;
-    const int w = blockIdx.x, t = threadIdx.x;
+DEV void step_control_body(DevBatch &d, const int w, const int t, double *cl, double *red, int &s_accept) {
     SolveState &st = d.st[w];
     if (st.termination != ISV_TERM_RUNNING) return;
     const int N = d.N;
@@ -399,6 +410,13 @@ __global__ __launch_bounds__(256) void k_step_control(DevBatch d) {
         for (int i = t; i < N * 9; i += 256) d.sb[(size_t)w * N * 9 + i] = d.csb[(size_t)w * N * 9 + i];
         for (int l = l0 + t; l < l1; l += 256) d.lam[l] = d.clam[l];
     }
+}
+template <bool FUSED>
+__global__ __launch_bounds__(256) void k_step_control(DevBatch d) {
+    extern __shared__ __align__(16) double cl[];
+    __shared__ double red[256];
+    __shared__ int s_accept;
+    step_control_body<FUSED>(d, blockIdx.x, threadIdx.x, cl, red, s_accept);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -642,8 +660,12 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
         else hipLaunchKernelGGL(k_build_solve<false>, dim3(d.B), dim3(512), lds_bs, st, d);
         counts[1]++;
         PROF(slot, 3, 1);
+        const bool fuse_control = d.lds_T && (size_t)d.Ftot <= (size_t)4096 * d.B && !getenv("ISV_SPLIT_CONTROL");
+        const size_t lds_dg = (d.lds_T ? ((size_t)(d.N - 1) * 48 + (size_t)d.n_prior_slots * 16) * sizeof(double) + prior_lds_bytes(d.n_prior_slots, false) : 0) + 2 * (size_t)d.np * sizeof(double);
+        const size_t lds_sc = ((size_t)30 * d.N + 12) * sizeof(double);
         PROF(slot, 4, 0);
-        hipLaunchKernelGGL(k_dogleg, dim3(d.B), dim3(256), (d.lds_T ? ((size_t)(d.N - 1) * 48 + (size_t)d.n_prior_slots * 16) * sizeof(double) + prior_lds_bytes(d.n_prior_slots, false) : 0) + 2 * (size_t)d.np * sizeof(double), st, d);
+        if (fuse_control) hipLaunchKernelGGL(k_dogleg<true>, dim3(d.B), dim3(256), lds_dg > lds_sc ? lds_dg : lds_sc, st, d);
+        else hipLaunchKernelGGL(k_dogleg<false>, dim3(d.B), dim3(256), lds_dg, st, d);
         PROF(slot, 4, 1);
         if (!d.lds_T) {                    // (the LDS path evaluates these inside k_dogleg)
             HCHK(hipEventRecord(fj[2], st)); HCHK(hipStreamWaitEvent(st2, fj[2], 0));
@@ -655,7 +677,8 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
         // candidate evaluation of the reprojection factors: inside the per-window control kernel, unless the windows are
         // so large that one workgroup per window would serialise it (config 5: 30 000 factors in one window)
         PROF(slot, 5, 0);
-        if (d.lds_T && (size_t)d.Ftot <= (size_t)4096 * d.B) hipLaunchKernelGGL(k_step_control<true>, dim3(d.B), dim3(256), ((size_t)30 * d.N + 12) * sizeof(double), st, d);
+        if (fuse_control) {
+        } else if (d.lds_T && (size_t)d.Ftot <= (size_t)4096 * d.B) hipLaunchKernelGGL(k_step_control<true>, dim3(d.B), dim3(256), lds_sc, st, d);
         else {
             if (d.n_tiles > 0) hipLaunchKernelGGL(k_proj_linearize<1>, dim3((d.n_tiles + 3) / 4), dim3(256), lds_proj1, st, d, d.cpose, d.clam, d.fcost_c, 2);
             if (!d.lds_T) HCHK(hipStreamWaitEvent(st, fj[3], 0));
