@@ -381,6 +381,14 @@ def main():
         bytes_lin = Fw * (24.0 + 280.0) + Lw * (32.0 + 104.0)      # in: factor record, observation (+ landmark depth / host point); out: 224 B strip, cost, 48 B w (+ landmark scalars, host w)
         bytes_sweep = Fw * (26 * 8.0 + 4.0) + tvis                 # [J_i | J_j | r] of every factor once + the permutation; out: packed pose blocks, gradient, diagonal
         bytes_rank1 = (Fw + Lw) * 48.0 + Lw * 20.0 + 2.0 * tvis    # packed w vectors, {c_l, g_l}, metadata; read-modify-write of the packed blocks
+        # fused path (k_lin_gram + landmark prologue of k_rank1_mfma): no 224-B strips.  k_lin_gram: in = factor stream record (8 B) +
+        # observation (16 B) per factor, depth + host point (32 B) per landmark; out = cost (8 B) + observer w (48 B) + landmark
+        # pieces (64 B) per factor, the packed pose blocks per window.  k_rank1_mfma additionally reads the 64-B pieces and writes
+        # the landmark scalars (56 B) and the host w (48 B).
+        fused = int(cnt[4]) == 1
+        bytes_lingram = Fw * (24.0 + 120.0) + Lw * 32.0 + tvis
+        if fused:
+            bytes_rank1 += Fw * 64.0 + Lw * 104.0
         # k_dogleg: back-substitution from the packed w vectors (48 B / observation) + landmark scalars in (5) / out (4)
         # + tangent vectors + candidate states + IMU / prior J^T J blocks for the model cost
         bytes_dogleg = (Fw + Lw) * 48.0 + Lw * 72.0 + 15 * N * 8.0 * 8 + 2 * 16 * N * 8.0 + (N - 1) * (495 + 64 + 225) * 8.0
@@ -388,7 +396,7 @@ def main():
         bytes_control = Fw * 24.0 + Lw * (24.0 + 24.0) + 3 * 16 * N * 8.0
         flops_bs = bs_flops(N)
         pmc = {}
-        for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for name in ("r02_pmc_traffic.json",):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
                 break
@@ -409,12 +417,21 @@ def main():
 
         roofs = [roof("k_build_solve_sb", "fp64-valu-latency", flops_bs, bs_ms, n_bs, FP64_PEAK_TFLOPS, "TFLOP/s", 1e12,
                       "issues NO MFMA: chains of dependent 6x6 / 9x9 FP64 pivots (v_readlane -> rsq -> Newton) in LDS; priced against the FP64 vector peak, which equals the FP64 matrix peak on MI355X"),
-                 roof("k_proj_linearize<0>", "hbm", bytes_lin, lin_ms, n_lin, HBM_PEAK_GBS, "GB/s", 1e9),
-                 roof("k_sweep_mfma", "hbm", bytes_sweep, sw_ms, n_sw, HBM_PEAK_GBS, "GB/s", 1e9),
-                 roof("k_rank1_mfma", "hbm", bytes_rank1, r1_ms, n_sw, HBM_PEAK_GBS, "GB/s", 1e9),
-                 roof("k_dogleg", "hbm", bytes_dogleg, dg_ms, args_iters(be), HBM_PEAK_GBS, "GB/s", 1e9),
-                 roof("k_step_control", "hbm", bytes_control, sc_ms, args_iters(be), HBM_PEAK_GBS, "GB/s", 1e9)]
-        sums = {"k_build_solve_sb": bs_ms, "k_proj_linearize<0>": lin_ms, "k_sweep_mfma": sw_ms, "k_rank1_mfma": r1_ms, "k_dogleg": dg_ms, "k_step_control": sc_ms}
+                 roof("k_rank1_mfma", "hbm", bytes_rank1, r1_ms, n_sw, HBM_PEAK_GBS, "GB/s", 1e9)]
+        if fused:
+            roofs.insert(1, roof("k_lin_gram", "hbm", bytes_lingram, lin_ms, n_lin, HBM_PEAK_GBS, "GB/s", 1e9,
+                                 "ProjectionFactor::Evaluate fused with the Gram products: the Jacobian strips stay on the CU; lane per factor + FP64 MFMA, latency / issue bound at 3 workgroups per CU"))
+        else:
+            roofs.insert(1, roof("k_proj_linearize<0>", "hbm", bytes_lin, lin_ms, n_lin, HBM_PEAK_GBS, "GB/s", 1e9))
+            roofs.insert(2, roof("k_sweep_mfma", "hbm", bytes_sweep, sw_ms, n_sw, HBM_PEAK_GBS, "GB/s", 1e9))
+        fused_control = int(cnt[5]) == 1
+        if not fused_control:
+            roofs.append(roof("k_dogleg", "hbm", bytes_dogleg, dg_ms, args_iters(be), HBM_PEAK_GBS, "GB/s", 1e9))
+            roofs.append(roof("k_step_control", "hbm", bytes_control, sc_ms, args_iters(be), HBM_PEAK_GBS, "GB/s", 1e9))
+        else:                  # k_dogleg<true>: the candidate evaluation and the step control run in the same kernel
+            roofs.append(roof("k_dogleg", "hbm", bytes_dogleg + bytes_control, dg_ms + sc_ms, args_iters(be), HBM_PEAK_GBS, "GB/s", 1e9,
+                              "k_dogleg<true>: back-substitution, dogleg step, candidate costs and TrustRegionMinimizer step control in one kernel"))
+        sums = {"k_build_solve_sb": bs_ms, "k_proj_linearize<0>": lin_ms, "k_lin_gram": lin_ms, "k_sweep_mfma": sw_ms, "k_rank1_mfma": r1_ms, "k_dogleg": dg_ms + (sc_ms if fused_control else 0), "k_step_control": sc_ms}
         dominant = max(roofs, key=lambda r: sums[r["kernel"]])
         total_w = world * W
         out = {
@@ -435,7 +452,7 @@ def main():
                 "pipelined_two_handles": {"value": W / t_pipe, "unit": "windows/s", "ms_per_batch": 1e3 * t_pipe},
                 "ms_upload": 1e3 * t_up, "ms_optimize": 1e3 * t_opt, "ms_download": 1e3 * (t_incl - t_up - t_opt),
                 "what": "one isv_batch_upload (host packing + H2D) + isv_batch_optimize + isv_batch_download (D2H) of the same batch, pageable host buffers; packing on min(8, cores) host threads"},
-            "kernel_ms": {"profiled_step_total_events": float(fam[0]), "proj_linearize_sum": lin_ms, "sweep_mfma_sum": sw_ms, "rank1_mfma_sum": r1_ms, "build_solve_sum": bs_ms,
+            "kernel_ms": {"profiled_step_total_events": float(fam[0]), "lin_gram_or_proj_linearize_sum": lin_ms, "sweep_mfma_sum": sw_ms, "rank1_mfma_sum": r1_ms, "build_solve_sum": bs_ms,
                           "dogleg_sum": dg_ms, "step_control_sum": sc_ms, "window_iterations": win_iters},
             "cpu_baseline": cpu,
         }

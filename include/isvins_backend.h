@@ -272,8 +272,9 @@ int  isv_batch_last_timing(isv_backend_t *h, double out_ms[8]);
  * the handle's stream and runs on `stream`, so a collective enqueued on `stream` afterwards needs no host sync.       */
 int64_t isv_result_record_doubles(const isv_backend_t *h);
 int  isv_batch_pack_results(isv_backend_t *h, void *device_dst, void *stream);
-/* last optimize: [0] k_proj_linearize<0> launches, [1] k_build_solve* launches, [2] k_sweep_mfma / k_rank1_mfma launches,
- * [3] window-iterations that were linearised and solved (windows gated out of an iteration do no work) */
+/* last optimize: [0] k_lin_gram (or k_proj_linearize<0>) launches, [1] k_build_solve* launches, [2] k_rank1_mfma launches,
+ * [3] window-iterations that were linearised and solved (windows gated out of an iteration do no work),
+ * [4] 1 when the fused k_lin_gram ran (no Jacobian strips), [5] 1 when k_dogleg<true> carried the step control */
 int  isv_batch_last_counts(isv_backend_t *h, int64_t out[8]);
 
 #ifdef __cplusplus

@@ -624,7 +624,7 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
         if (fused) {
             // linearisation fused with the Gram products: no Jacobian strip goes to HBM (isv_visual.hip)
             hipLaunchKernelGGL(k_lin_gram, dim3(d.B), dim3(64 * LG_WAVES), lin_gram_lds_bytes(d.N, !d.sw_global), st, d);
-            counts[0]++;
+            counts[0]++; counts[4] = 1;
         } else if (d.n_tiles > 0) { hipLaunchKernelGGL(k_proj_linearize<0>, dim3((d.n_tiles + 3) / 4), dim3(256), lds_proj, st, d, d.pose, d.lam, d.fcost, 1); counts[0]++; }
         PROF(slot, 0, 1);
         if (d.lds_T) {
@@ -664,7 +664,7 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
         const size_t lds_dg = (d.lds_T ? ((size_t)(d.N - 1) * 48 + (size_t)d.n_prior_slots * 16) * sizeof(double) + prior_lds_bytes(d.n_prior_slots, false) : 0) + 2 * (size_t)d.np * sizeof(double);
         const size_t lds_sc = ((size_t)30 * d.N + 12) * sizeof(double);
         PROF(slot, 4, 0);
-        if (fuse_control) hipLaunchKernelGGL(k_dogleg<true>, dim3(d.B), dim3(256), lds_dg > lds_sc ? lds_dg : lds_sc, st, d);
+        if (fuse_control) { hipLaunchKernelGGL(k_dogleg<true>, dim3(d.B), dim3(256), lds_dg > lds_sc ? lds_dg : lds_sc, st, d); counts[5] = 1; }
         else hipLaunchKernelGGL(k_dogleg<false>, dim3(d.B), dim3(256), lds_dg, st, d);
         PROF(slot, 4, 1);
         if (!d.lds_T) {                    // (the LDS path evaluates these inside k_dogleg)

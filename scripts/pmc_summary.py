@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Post-process the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs) into
-profiles/r01_pmc_summary.csv and profiles/r01_pmc_traffic.json.
-usage: pmc_summary.py <fetch counter_collection.csv> <write counter_collection.csv> <windows_per_gpu> <outdir>"""
+profiles/rNN_pmc_summary.csv and profiles/rNN_pmc_traffic.json.
+usage: pmc_summary.py <fetch counter_collection.csv> <write counter_collection.csv> <windows_per_gpu> <outdir> [round prefix, default r02]"""
 import csv, collections, json, sys, re
 
 def load(path, counter):
@@ -15,8 +15,9 @@ def load(path, counter):
 
 fetch, write = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
 W, out = int(sys.argv[3]), sys.argv[4]
+RN = sys.argv[5] if len(sys.argv) > 5 else "r02"
 names = sorted(set(fetch) | set(write))
-with open(f"{out}/r01_pmc_summary.csv", "w") as f:
+with open(f"{out}/{RN}_pmc_summary.csv", "w") as f:
     f.write("kernel,launches,FETCH_SIZE_KB_mean,WRITE_SIZE_KB_mean,FETCH_SIZE_KB_max,WRITE_SIZE_KB_max\n")
     for n in names:
         fv, wv = fetch.get(n, [0.0]), write.get(n, [0.0])
@@ -29,10 +30,10 @@ traffic = {"windows_per_gpu": W,
                    "a width the guide calls uncalibrated, so no factor is applied; WRITE_SIZE is taken as is"}
 for n in names:
     base = n.split("<")[0] if not n.startswith("k_proj_linearize") else n
-    if base in ("k_build_solve_sb", "k_proj_linearize<0>", "k_sweep_mfma", "k_rank1_mfma", "k_dogleg", "k_proj_linearize<1>"):
+    if base in ("k_build_solve_sb", "k_proj_linearize<0>", "k_sweep_mfma", "k_rank1_mfma", "k_dogleg", "k_proj_linearize<1>", "k_lin_gram", "k_step_control"):
         fv, wv = fetch.get(n, [0.0]), write.get(n, [0.0])
         key = base
         traffic[key] = {"FETCH_SIZE_KB_mean": sum(fv) / len(fv), "WRITE_SIZE_KB_mean": sum(wv) / len(wv),
                         "hbm_bytes_per_launch": (sum(fv) / len(fv) + sum(wv) / len(wv)) * 1024.0}
-json.dump(traffic, open(f"{out}/r01_pmc_traffic.json", "w"), indent=1)
-print(open(f"{out}/r01_pmc_summary.csv").read())
+json.dump(traffic, open(f"{out}/{RN}_pmc_traffic.json", "w"), indent=1)
+print(open(f"{out}/{RN}_pmc_summary.csv").read())
