@@ -94,7 +94,7 @@ def arr(cfield, shape=None):
 
 
 def make_config(n_frames, n_vo, max_landmarks=1000, max_obs=None, max_batch=1, num_iterations=10,
-                pixel_sqrt_info=460.0, g_norm=9.81007, alpha=0.1, init_depth=5.0):
+                pixel_sqrt_info=460.0, g_norm=9.81007, alpha=0.1, init_depth=5.0, estimate_extrinsic=0):
     """isv_config_t with the reference's yaml defaults (config/euroc_config.yaml:50,61,83,86)."""
     cfg = isv_config_t()
     cfg.n_frames, cfg.n_vo = n_frames, n_vo
@@ -103,7 +103,7 @@ def make_config(n_frames, n_vo, max_landmarks=1000, max_obs=None, max_batch=1, n
     cfg.max_rollpitch = n_vo + 1
     cfg.max_batch = max_batch
     cfg.num_iterations = num_iterations
-    cfg.estimate_extrinsic = 0
+    cfg.estimate_extrinsic = estimate_extrinsic
     cfg.proj_sqrt_info[:] = [pixel_sqrt_info, 0.0, 0.0, pixel_sqrt_info]
     cfg.gravity[:] = [0.0, 0.0, g_norm]
     cfg.alpha = alpha

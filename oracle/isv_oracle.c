@@ -48,6 +48,10 @@ typedef struct {
     double *imu_sqrt_info;   /* [N-1][225] */
     /* current point (ambient) */
     double *pose, *sb, *lam, ex[7];
+    /* ESTIMATE_EXTRINSIC (src/estimator.cpp:1028-1036): the extrinsic block is free, tangent columns 15N .. 15N+5 */
+    int est_ex;
+    double cex[7];           /* candidate extrinsic */
+    const double *ex_use;    /* the extrinsic evaluate() reads (x or the candidate) */
     /* evaluation outputs */
     double *res, *res_c, *jac, *grad;   /* res: residuals at x (with jac); res_c: candidate-point scratch */
 } problem_t;
@@ -56,8 +60,10 @@ static void build_problem(problem_t *P, const isv_config_t *cfg, const isv_windo
     memset(P, 0, sizeof(*P));
     P->cfg = cfg; P->w = w;
     int N = cfg->n_frames, L = w->n_landmarks;
-    P->N = N; P->Nvo = cfg->n_vo; P->L = L; P->np = 15 * N; P->ncols = 15 * N + L;
-    P->namb = 16 * N + L;
+    P->est_ex = cfg->estimate_extrinsic != 0;
+    P->ex_use = P->ex;
+    P->N = N; P->Nvo = cfg->n_vo; P->L = L; P->np = 15 * N + (P->est_ex ? 6 : 0); P->ncols = P->np + L;
+    P->namb = 16 * N + L + (P->est_ex ? 7 : 0);
     int F = w->n_obs - L;
     int maxrb = (N - 1) + F + 2 + (cfg->n_vo - 1) + w->n_rollpitch;
     P->rb = (rblock_t *)calloc(maxrb, sizeof(rblock_t));
@@ -78,11 +84,12 @@ static void build_problem(problem_t *P, const isv_config_t *cfg, const isv_windo
         for (int o = o0 + 1; o < o1; o++) {
             rblock_t *r = &P->rb[n++];
             r->kind = 1; r->a = h; r->b = h + (o - o0); r->c = l; r->obs0 = o0; r->obsj = o;
-            r->dim = 2; r->nb = 3; r->robust = 1;
+            r->dim = 2; r->nb = P->est_ex ? 4 : 3; r->robust = 1;
             r->col[0] = 15 * r->a; r->wid[0] = 6; r->col[1] = 15 * r->b; r->wid[1] = 6;
-            r->col[2] = 15 * N + l; r->wid[2] = 1;
+            if (P->est_ex) { r->col[2] = 15 * N; r->wid[2] = 6; r->col[3] = P->np + l; r->wid[3] = 1; }     /* pose_i, pose_j, ex, lambda (:1077) */
+            else { r->col[2] = P->np + l; r->wid[2] = 1; }
             r->roff = roff; roff += 2;
-            for (int k = 0; k < 3; k++) { r->joff[k] = joff; joff += 2 * r->wid[k]; }
+            for (int k = 0; k < r->nb; k++) { r->joff[k] = joff; joff += 2 * r->wid[k]; }
         }
     }
     /* priors (:1102-1117), all with CauchyLoss(1.0) */
@@ -142,10 +149,10 @@ static double evaluate(problem_t *P, const double *pose, const double *sb, const
             if (want_jac) { take6(J0, 15, jb[0]); take6(J2, 15, jb[2]); }
         } break;
         case 1: {
-            isvo_proj_eval(pose + 7 * r->a, pose + 7 * r->b, P->ex, lam[r->c], w->obs_point + 3 * r->obs0,
+            isvo_proj_eval(pose + 7 * r->a, pose + 7 * r->b, P->ex_use, lam[r->c], w->obs_point + 3 * r->obs0,
                            w->obs_point + 3 * r->obsj, cfg->proj_sqrt_info, 1, res,
-                           want_jac ? J0 : NULL, want_jac ? J1 : NULL, NULL, want_jac ? jb[2] : NULL);
-            if (want_jac) { take6(J0, 2, jb[0]); take6(J1, 2, jb[1]); }
+                           want_jac ? J0 : NULL, want_jac ? J1 : NULL, (want_jac && P->est_ex) ? J2 : NULL, want_jac ? jb[r->nb - 1] : NULL);
+            if (want_jac) { take6(J0, 2, jb[0]); take6(J1, 2, jb[1]); if (P->est_ex) take6(J2, 2, jb[2]); }
         } break;
         case 2:
             isvo_se3prior_eval(w->pose_prior, w->pose_prior->sqrt_info, pose + 7 * 0, res, want_jac ? J0 : NULL);
@@ -254,7 +261,8 @@ static int dense_schur_solve(const problem_t *P, const double *D, double *y) {
     int np = P->np, L = P->L, N = P->N;
     double *S = (double *)calloc((size_t)np * np, 8), *g = (double *)calloc(np, 8);
     double *E = (double *)calloc(L > 0 ? L : 1, 8), *gl = (double *)calloc(L > 0 ? L : 1, 8);
-    double *W = (double *)calloc((size_t)(L > 0 ? L : 1) * N * 6, 8);   /* W[l][frame][6] */
+    const int NF = N + 1;               /* pose-like blocks a landmark couples to: frames 0..N-1 and, when estimated, the extrinsic as "frame" N (columns 15N..) */
+    double *W = (double *)calloc((size_t)(L > 0 ? L : 1) * NF * 6, 8);   /* W[l][frame][6] */
     for (int n = 0; n < P->nrb; n++) {
         const rblock_t *r = &P->rb[n];
         const double *res = P->res + r->roff;
@@ -272,7 +280,7 @@ static int dense_schur_solve(const problem_t *P, const double *D, double *y) {
                 int cm = r->col[m], wm = r->wid[m];
                 if (cm >= np) {                      /* pose x landmark -> W */
                     int l = cm - np, f = ck / 15;
-                    for (int c = 0; c < wk; c++) { double s = 0; for (int e = 0; e < r->dim; e++) s += Jk[e * wk + c] * Jm[e]; W[((size_t)l * N + f) * 6 + c] += s; }
+                    for (int c = 0; c < wk; c++) { double s = 0; for (int e = 0; e < r->dim; e++) s += Jk[e * wk + c] * Jm[e]; W[((size_t)l * NF + f) * 6 + c] += s; }
                     continue;
                 }
                 for (int c = 0; c < wk; c++) for (int d = 0; d < wm; d++) {
@@ -287,11 +295,15 @@ static int dense_schur_solve(const problem_t *P, const double *D, double *y) {
         int h = P->w->lm_start_frame[l], k = P->w->lm_obs_ptr[l + 1] - P->w->lm_obs_ptr[l];
         double ete = E[l] + D[np + l] * D[np + l];
         double inv = 1.0 / ete;
-        for (int fa = h; fa < h + k; fa++) for (int a = 0; a < 6; a++) {
-            double wa = W[((size_t)l * N + fa) * 6 + a];
+        const int kk = k + (P->est_ex ? 1 : 0);             /* the landmark's frames, then the extrinsic */
+        for (int ia = 0; ia < kk; ia++) for (int a = 0; a < 6; a++) {
+            const int fa = ia < k ? h + ia : N;
+            double wa = W[((size_t)l * NF + fa) * 6 + a];
             g[15 * fa + a] -= wa * inv * gl[l];
-            for (int fb = h; fb < h + k; fb++) for (int b = 0; b < 6; b++)
-                S[(size_t)(15 * fa + a) * np + 15 * fb + b] -= wa * inv * W[((size_t)l * N + fb) * 6 + b];
+            for (int ib = 0; ib < kk; ib++) for (int b = 0; b < 6; b++) {
+                const int fb = ib < k ? h + ib : N;
+                S[(size_t)(15 * fa + a) * np + 15 * fb + b] -= wa * inv * W[((size_t)l * NF + fb) * 6 + b];
+            }
         }
     }
     int info = chol_lower(S, np);
@@ -301,7 +313,7 @@ static int dense_schur_solve(const problem_t *P, const double *D, double *y) {
         for (int l = 0; l < L; l++) {
             int h = P->w->lm_start_frame[l], k = P->w->lm_obs_ptr[l + 1] - P->w->lm_obs_ptr[l];
             double ete = E[l] + D[np + l] * D[np + l], s = gl[l];
-            for (int fa = h; fa < h + k; fa++) for (int a = 0; a < 6; a++) s -= W[((size_t)l * N + fa) * 6 + a] * y[15 * fa + a];
+            for (int ia = 0; ia < k + (P->est_ex ? 1 : 0); ia++) for (int a = 0; a < 6; a++) { const int fa = ia < k ? h + ia : N; s -= W[((size_t)l * NF + fa) * 6 + a] * y[15 * fa + a]; }
             y[np + l] = s / ete;
         }
         for (int i = 0; i < P->ncols; i++) if (!isfinite(y[i])) info = 1;
@@ -312,7 +324,8 @@ static int dense_schur_solve(const problem_t *P, const double *D, double *y) {
 
 /* Evaluator::Plus over all blocks */
 static void state_plus(const problem_t *P, const double *pose, const double *sb, const double *lam,
-                       const double *delta, double *pose_o, double *sb_o, double *lam_o) {
+                       const double *delta, double *pose_o, double *sb_o, double *lam_o, double *ex_o) {
+    if (P->est_ex && ex_o) isvo_pose_plus(P->ex, delta + 15 * P->N, ex_o);
     for (int i = 0; i < P->N; i++) {
         isvo_pose_plus(pose + 7 * i, delta + 15 * i, pose_o + 7 * i);
         for (int k = 0; k < 9; k++) sb_o[9 * i + k] = sb[9 * i + k] + delta[15 * i + 6 + k];
@@ -320,8 +333,9 @@ static void state_plus(const problem_t *P, const double *pose, const double *sb,
     for (int l = 0; l < P->L; l++) lam_o[l] = lam[l] + delta[P->np + l];
 }
 static double amb_norm2_diff(const problem_t *P, const double *p0, const double *s0, const double *l0,
-                             const double *p1, const double *s1, const double *l1) {
+                             const double *p1, const double *s1, const double *l1, const double *e1 /* candidate extrinsic or NULL */) {
     double s = 0;
+    if (P->est_ex) for (int i = 0; i < 7; i++) { double d = P->ex[i] - ((p1 && e1) ? e1[i] : 0); s += d * d; }
     for (int i = 0; i < 7 * P->N; i++) { double d = p0[i] - (p1 ? p1[i] : 0); s += d * d; }
     for (int i = 0; i < 9 * P->N; i++) { double d = s0[i] - (s1 ? s1[i] : 0); s += d * d; }
     for (int i = 0; i < P->L; i++) { double d = l0[i] - (l1 ? l1[i] : 0); s += d * d; }
@@ -331,8 +345,10 @@ static double amb_norm2_diff(const problem_t *P, const double *p0, const double 
 static double projected_gradient_max(const problem_t *P, double *scratch) {
     double *ng = scratch, *pp = ng + P->ncols, *ss = pp + 7 * P->N, *ll = ss + 9 * P->N;
     for (int i = 0; i < P->ncols; i++) ng[i] = -P->grad[i];
-    state_plus(P, P->pose, P->sb, P->lam, ng, pp, ss, ll);
+    double ee[7];
+    state_plus(P, P->pose, P->sb, P->lam, ng, pp, ss, ll, ee);
     double m = 0;
+    if (P->est_ex) for (int i = 0; i < 7; i++) m = fmax(m, fabs(P->ex[i] - ee[i]));
     for (int i = 0; i < 7 * P->N; i++) m = fmax(m, fabs(P->pose[i] - pp[i]));
     for (int i = 0; i < 9 * P->N; i++) m = fmax(m, fabs(P->sb[i] - ss[i]));
     for (int i = 0; i < P->L; i++) m = fmax(m, fabs(P->lam[i] - ll[i]));
@@ -361,7 +377,7 @@ static void minimize(problem_t *P, int max_iter, isv_summary_t *sum) {
     for (int i = 0; i < n; i++) scale[i] = 1.0 / (1.0 + sqrt(scale[i]));
     jac_scale_cols(P, scale);
     double gmax = projected_gradient_max(P, scratch);
-    double x_norm = sqrt(amb_norm2_diff(P, P->pose, P->sb, P->lam, NULL, NULL, NULL));
+    double x_norm = sqrt(amb_norm2_diff(P, P->pose, P->sb, P->lam, NULL, NULL, NULL, NULL));
     sum->initial_cost = x_cost; sum->trace_cost[0] = x_cost; sum->trace_radius[0] = radius;
     int it = 0, term = ISV_TERM_RUNNING;
     for (;;) {
@@ -434,9 +450,11 @@ static void minimize(problem_t *P, int max_iter, isv_summary_t *sum) {
         }
         invalid = 0;
         for (int i = 0; i < n; i++) delta[i] = step[i] * scale[i];
-        state_plus(P, P->pose, P->sb, P->lam, delta, cp, cs, cl);
+        state_plus(P, P->pose, P->sb, P->lam, delta, cp, cs, cl, P->cex);
+        if (P->est_ex) P->ex_use = P->cex;
         double cand_cost = evaluate(P, cp, cs, cl, 0);
-        double step_norm = sqrt(amb_norm2_diff(P, P->pose, P->sb, P->lam, cp, cs, cl));
+        P->ex_use = P->ex;
+        double step_norm = sqrt(amb_norm2_diff(P, P->pose, P->sb, P->lam, cp, cs, cl, P->cex));
         int accepted = 0, stop = 0;
         if (step_norm <= 1e-8 * (x_norm + 1e-8)) { term = ISV_TERM_PARAMETER_TOL; stop = 1; }
         else if (fabs(x_cost - cand_cost) <= 1e-6 * x_cost) { term = ISV_TERM_FUNCTION_TOL; stop = 1; }
@@ -448,7 +466,8 @@ static void minimize(problem_t *P, int max_iter, isv_summary_t *sum) {
         if (rel > 1e-3) {                            /* HandleSuccessfulStep */
             accepted = 1;
             memcpy(P->pose, cp, 56 * N); memcpy(P->sb, cs, 72 * N); memcpy(P->lam, cl, 8 * L);
-            x_norm = sqrt(amb_norm2_diff(P, P->pose, P->sb, P->lam, NULL, NULL, NULL));
+            if (P->est_ex) memcpy(P->ex, P->cex, 56);
+            x_norm = sqrt(amb_norm2_diff(P, P->pose, P->sb, P->lam, NULL, NULL, NULL, NULL));
             x_cost = evaluate(P, P->pose, P->sb, P->lam, 1);
             jac_scale_cols(P, scale);
             gmax = projected_gradient_max(P, scratch);

@@ -207,3 +207,68 @@ def test_ragged_and_edge_windows(oracle):
     assert s.status == 0 and np.isfinite(s.final_cost) and s.final_cost <= s.initial_cost
     o, s, _ = run(oracle, w, 10)
     assert s.final_cost < s.initial_cost
+
+
+# ---- ESTIMATE_EXTRINSIC = 1: the extrinsic block is free (src/estimator.cpp:1028-1036, projection_factor.cpp:100-113) ----
+def test_extrinsic_gradient_matches_finite_differences(oracle, win):
+    """columns 15N .. 15N+5 of the normal equations (J_ex of every reprojection factor, Cauchy-corrected) against a
+    central finite difference of the robust cost over the extrinsic's tangent (t, then R <- R Exp(dtheta))"""
+    from scipy.spatial.transform import Rotation as Rot
+    cfg = abi.make_config(11, 5, estimate_extrinsic=1)
+    n = 15 * 11 + 6 + win.L
+    H = np.zeros((n, n)); g = np.zeros(n); nn = C.c_int(0)
+    oracle.isvo_normal_equations(C.byref(cfg), C.byref(win.c()), P(H), P(g), C.byref(nn))
+    assert nn.value == n
+    gex = g[165:171]
+    fd = np.zeros(6)
+    for k in range(6):
+        vals = []
+        for sgn in (+1, -1):
+            w = win.clone(); d = np.zeros(6); d[k] = sgn * 1e-6
+            w.tic[:] = win.tic + d[:3]; w.ric[:] = win.ric @ Rot.from_rotvec(d[3:]).as_matrix()
+            vals.append(oracle.isvo_cost(C.byref(cfg), C.byref(w.c())))
+        fd[k] = (vals[0] - vals[1]) / 2e-6
+    # gradient of 1/2 sum rho(|r|^2) = J^T r with the corrected J and r (the Corrector is exact to first order for rho'' terms
+    # dropped: Cauchy's rho'' < 0 branch only rescales), up to the sign convention g = J^T r
+    # (the cost is ~1e7 with third derivatives ~1e11: a 1e-6 central difference is good to ~1e-4 of the largest entry;
+    # J_ex itself is pinned per factor in tests/test_oracle_factors.py)
+    assert np.abs(gex - fd).max() < 5e-4 * np.abs(fd).max(), (gex, fd)
+    assert np.abs(gex).max() > 0
+
+
+def test_schur_equals_dense_with_free_extrinsic(oracle, win):
+    cfg = abi.make_config(11, 5, estimate_extrinsic=1)
+    n = 15 * 11 + 6 + win.L
+    H = np.zeros((n, n)); g = np.zeros(n); nn = C.c_int(0)
+    oracle.isvo_normal_equations(C.byref(cfg), C.byref(win.c()), P(H), P(g), C.byref(nn))
+    assert np.allclose(H, H.T, rtol=1e-13, atol=1e-9)
+    assert np.abs(H[165:171, :165]).max() > 0 and np.abs(H[165:171, 171:]).max() > 0       # the extrinsic couples to poses and landmarks
+    rng = np.random.default_rng(1)
+    D = np.sqrt(np.clip(np.diag(H), 1e-6, 1e32)) * np.sqrt(1e-4) * (1 + rng.random(n))
+    y = np.zeros(n)
+    assert oracle.isvo_schur_solve(C.byref(cfg), C.byref(win.c()), P(D), P(y)) == 0
+    y_ref = np.linalg.solve(H + np.diag(D * D), g)
+    assert np.allclose(y, y_ref, rtol=1e-6, atol=1e-8 * np.abs(y_ref).max())
+
+
+def test_free_extrinsic_solve_moves_the_extrinsic_and_lowers_the_cost(oracle):
+    """a window generated with the true extrinsic, started from a rotated / shifted one: with the block free the solve ends
+    at a lower cost than with the block constant, and the estimate moves back towards the truth"""
+    from scipy.spatial.transform import Rotation as Rot
+    w = synth.make_window(31, n_landmarks=200)
+    true_ric, true_tic = w.ric.copy(), w.tic.copy()
+    w.ric[:] = true_ric @ Rot.from_rotvec([0.01, -0.008, 0.012]).as_matrix(); w.tic[:] = true_tic + [0.01, -0.01, 0.005]
+    outs = {}
+    for est in (0, 1):
+        cfg = abi.make_config(11, 5, num_iterations=40, estimate_extrinsic=est)
+        o = w.clone(); s = abi.isv_summary_t(); mg = abi.isv_marg_result_t()
+        assert oracle.isvo_optimize(C.byref(cfg), C.byref(o.c()), C.byref(s), C.byref(mg)) == 0
+        outs[est] = (o, s)
+    (o0, s0), (o1, s1) = outs[0], outs[1]
+    assert np.abs(o0.ric - w.ric).max() < 1e-12 and np.abs(o0.tic - w.tic).max() == 0     # constant block: unchanged (up to the quaternion round trip)
+    # one window constrains the extrinsic only weakly (the body poses can absorb most of an extrinsic error), so the gain
+    # is small -- but with six more degrees of freedom the optimum cannot be worse, and the block must have moved
+    assert s1.final_cost < s0.final_cost
+    assert np.abs(o1.ric - w.ric).max() > 1e-5 and np.abs(o1.tic - w.tic).max() > 1e-5
+    assert np.abs(o1.para_Ex_Pose[:3] - o1.tic).max() < 1e-15
+    R = o1.ric; assert np.allclose(R @ R.T, np.eye(3), atol=1e-12)
