@@ -39,7 +39,7 @@ typedef enum isv_status {
     ISV_ERR_CAPACITY = -2,      /* more landmarks / observations / windows than created  */
     ISV_ERR_NONFINITE = -3,     /* NaN/Inf in inputs or produced by the solve            */
     ISV_ERR_DEVICE = -4,        /* HIP runtime error (no GPU, OOM, launch failure)       */
-    ISV_ERR_UNSUPPORTED = -5    /* e.g. estimate_extrinsic=1 (not built yet)             */
+    ISV_ERR_UNSUPPORTED = -5    /* e.g. estimate_extrinsic = 2, or = 1 with n_frames > 19 */
 } isv_status_t;
 
 /* ceres::TerminationType + the reason strings of TrustRegionMinimizer (Ceres 2.0.0) */
@@ -63,7 +63,8 @@ typedef struct isv_config {
     int32_t max_rollpitch;       /* capacity of vioRollPitchEdges (<= n_vo + 1)               */
     int32_t max_batch;           /* windows the handle can hold at once                       */
     int32_t num_iterations;      /* NUM_ITERATIONS (yaml:50) -> max_num_iterations            */
-    int32_t estimate_extrinsic;  /* ESTIMATE_EXTRINSIC; only 0 is built (block constant)      */
+    int32_t estimate_extrinsic;  /* ESTIMATE_EXTRINSIC: 0 = block constant, 1 = free (J_ex,
+                                    src/estimator.cpp:1028-1036); 2 (initial calibration) is refused */
     double  proj_sqrt_info[4];   /* ProjectionFactor::sqrt_info = PIXEL_SQRT_INFO * I2        */
     double  gravity[3];          /* G (src/parameters.cpp), enters the IMU residual with '+'  */
     double  alpha;               /* ALPHA eigenvalue cut of the sparsification (yaml:86)      */

@@ -114,11 +114,12 @@ static int create_impl(isv_backend *h) {
     for (auto &e : h->ev) HIPCHK(h, hipEventCreate(&e));
     h->prof_ev.assign((size_t)c.num_iterations * ISV_PROF_FAMILIES * 2, nullptr);
     for (auto &e : h->prof_ev) HIPCHK(h, hipEventCreate(&e));
-    const size_t B = c.max_batch, N = c.n_frames, L = B * (size_t)c.max_landmarks, F = B * (size_t)c.max_obs;
+    // (N: DEVICE frames = ALL_BUF_SIZE, plus the extrinsic's pseudo-frame when it is estimated -- isv_device_types.h)
+    const size_t B = c.max_batch, N = (size_t)c.n_frames + (c.estimate_extrinsic ? 1 : 0), L = B * (size_t)c.max_landmarks, F = B * (size_t)c.max_obs;
     const size_t T = F / (ISV_TILE / 2) + B + 1;      // tiles hold whole landmarks: >= 33 factors each when N <= 32
     h->capB = B; h->capL = L; h->capF = F; h->capTiles = T;
     DevBatch &d = h->d;
-    d.N = c.n_frames; d.Nvo = c.n_vo; d.np = 15 * c.n_frames; d.max_rp = c.max_rollpitch; d.max_iter = c.num_iterations;
+    d.N = (int32_t)N; d.Nr = c.n_frames; d.est_ex = c.estimate_extrinsic ? 1 : 0; d.Nvo = c.n_vo; d.np = 15 * (int32_t)N; d.max_rp = c.max_rollpitch; d.max_iter = c.num_iterations;
     d.n_prior_slots = 2 + (c.n_vo - 1) + c.max_rollpitch;
     d.max_lm = c.max_landmarks > 1 ? c.max_landmarks : 1;
     d.force_retry = getenv("ISV_DEBUG_FORCE_RETRY") ? atoi(getenv("ISV_DEBUG_FORCE_RETRY")) : 0;
@@ -178,6 +179,11 @@ static int create_impl(isv_backend *h) {
     TRY(halloc(h, &h->stage.st, B)); TRY(halloc(h, &h->stage.tc, B * ISV_MAX_TRACE)); TRY(halloc(h, &h->stage.tr, B * ISV_MAX_TRACE));
     TRY(halloc(h, &h->stage.ts, B * ISV_MAX_TRACE)); TRY(halloc(h, &h->stage.ta, B * ISV_MAX_TRACE)); TRY(halloc(h, &h->stage.marg, B));
     TRY(isv_solver_alloc(h->d, B, L, F, h->allocs, h->err));
+    if (d.est_ex) {
+        if (!d.lds_T) { h->err = "estimate_extrinsic = 1 is built for the LDS solver path only (ALL_BUF_SIZE <= 19)"; return ISV_ERR_UNSUPPORTED; }
+        const size_t NPr = (size_t)c.n_frames * (c.n_frames - 1) / 2;
+        TRY(dalloc(h, &d.Wex, L * 6)); TRY(dalloc(h, &d.flmx, F * 6)); TRY(dalloc(h, &d.ex_part, B * NPr * 114)); TRY(dalloc(h, &d.strip_ex, F * 12));
+    }
     return ISV_OK;
 }
 
@@ -188,7 +194,7 @@ extern "C" int isv_backend_create(const isv_config_t *cfg, isv_backend_t **out) 
         cfg->max_landmarks < 0 || cfg->max_obs < 0 || cfg->max_batch < 1 || cfg->max_rollpitch < 0 || cfg->num_iterations < 0 ||
         cfg->num_iterations >= ISV_MAX_TRACE)
         return ISV_ERR_INVALID_ARG;
-    if (cfg->estimate_extrinsic != 0) return ISV_ERR_UNSUPPORTED;
+    if (cfg->estimate_extrinsic != 0 && cfg->estimate_extrinsic != 1) return ISV_ERR_UNSUPPORTED;     // (2 = online calibration of the initial guess: initial/, out of scope)
     isv_backend *h = new isv_backend();
     h->cfg = *cfg;
     int rc = create_impl(h);
@@ -209,12 +215,16 @@ static bool finite_all(const double *p, size_t n) {
 // pack one caller window into its slice of the pinned staging area (offsets fixed by the caller's first pass)
 static int pack_window(isv_backend *h, int b, const isv_window_t *w, size_t L, size_t F, size_t T, std::string &err) {
     const isv_config_t &c = h->cfg;
-    const int N = c.n_frames;
+    const int N = c.n_frames, Nd = h->d.N;        // real frames; device frames (+ the extrinsic's pseudo-frame)
     auto &s = h->h;
     const size_t f_off = F, lm_off = L;
-    memcpy(s.Ps + (size_t)b * N * 3, w->Ps, sizeof(double) * N * 3); memcpy(s.Rs + (size_t)b * N * 9, w->Rs, sizeof(double) * N * 9);
-    memcpy(s.Vs + (size_t)b * N * 3, w->Vs, sizeof(double) * N * 3); memcpy(s.Bas + (size_t)b * N * 3, w->Bas, sizeof(double) * N * 3);
-    memcpy(s.Bgs + (size_t)b * N * 3, w->Bgs, sizeof(double) * N * 3);
+    memcpy(s.Ps + (size_t)b * Nd * 3, w->Ps, sizeof(double) * N * 3); memcpy(s.Rs + (size_t)b * Nd * 9, w->Rs, sizeof(double) * N * 9);
+    memcpy(s.Vs + (size_t)b * Nd * 3, w->Vs, sizeof(double) * N * 3); memcpy(s.Bas + (size_t)b * Nd * 3, w->Bas, sizeof(double) * N * 3);
+    memcpy(s.Bgs + (size_t)b * Nd * 3, w->Bgs, sizeof(double) * N * 3);
+    if (Nd > N) {       // pseudo-frame: "pose" = the extrinsic (k_vector2double turns it into para_Ex_Pose's twin), zero speed / biases
+        memcpy(s.Ps + ((size_t)b * Nd + N) * 3, w->tic, 24); memcpy(s.Rs + ((size_t)b * Nd + N) * 9, w->ric, 72);
+        memset(s.Vs + ((size_t)b * Nd + N) * 3, 0, 24); memset(s.Bas + ((size_t)b * Nd + N) * 3, 0, 24); memset(s.Bgs + ((size_t)b * Nd + N) * 3, 0, 24);
+    }
     memcpy(s.tic + (size_t)b * 3, w->tic, 24); memcpy(s.ric + (size_t)b * 9, w->ric, 72);
     // every real the device will read is checked here: a NaN / Inf that reached the solve would only surface as a
     // non-finite cost many kernels later (the reference has no such check: it asserts or silently diverges)
@@ -301,9 +311,16 @@ static int pack_window(isv_backend *h, int b, const isv_window_t *w, size_t L, s
         }
         wst[ISV_SWEEP_WAVES] = (int32_t)(q - f_off);
     }
+    if (Nd > N) {       // the IMU "factor" towards the pseudo-frame does not exist: flagged skipped (like sum_dt > 10)
+        const size_t fi = (size_t)b * (Nd - 1) + (N - 1);
+        memset(s.imu_in + fi * ISV_IMU_IN, 0, sizeof(double) * ISV_IMU_IN);
+        s.imu_in[fi * ISV_IMU_IN + IMU_DQ + 3] = 1.0;
+        for (int e = 0; e < 225; e++) s.imu_cov[fi * 225 + e] = (e % 16 == 0) ? 1.0 : 0.0;
+        s.imu_skip[fi] = 1;
+    }
     for (int i = 0; i < N - 1; i++) {
         const isv_imu_t &im = w->imu[i];
-        double *r = s.imu_in + ((size_t)b * (N - 1) + i) * ISV_IMU_IN;
+        double *r = s.imu_in + ((size_t)b * (Nd - 1) + i) * ISV_IMU_IN;
         memset(r, 0, sizeof(double) * ISV_IMU_IN);
         memcpy(r + IMU_DP, im.delta_p, 24); memcpy(r + IMU_DQ, im.delta_q, 32); memcpy(r + IMU_DV, im.delta_v, 24);
         memcpy(r + IMU_LBA, im.linearized_ba, 24); memcpy(r + IMU_LBG, im.linearized_bg, 24); r[IMU_DT] = im.sum_dt;
@@ -314,8 +331,8 @@ static int pack_window(isv_backend *h, int b, const isv_window_t *w, size_t L, s
             r[IMU_DV_DBA + a * 3 + bb] = im.jacobian[(6 + a) * 15 + 9 + bb];
             r[IMU_DV_DBG + a * 3 + bb] = im.jacobian[(6 + a) * 15 + 12 + bb];
         }
-        memcpy(s.imu_cov + ((size_t)b * (N - 1) + i) * 225, im.covariance, sizeof(double) * 225);
-        s.imu_skip[(size_t)b * (N - 1) + i] = im.sum_dt > 10.0;
+        memcpy(s.imu_cov + ((size_t)b * (Nd - 1) + i) * 225, im.covariance, sizeof(double) * 225);
+        s.imu_skip[(size_t)b * (Nd - 1) + i] = im.sum_dt > 10.0;
     }
     s.se3[b] = *w->pose_prior; s.lin9[b] = *w->vb_prior;
     for (int i = 0; i < c.n_vo - 1; i++) s.relpose[(size_t)b * (c.n_vo - 1) + i] = w->relpose[i];
@@ -345,7 +362,7 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
     const auto t_up0 = std::chrono::steady_clock::now();
     if ((size_t)n > h->capB) { h->err = "batch larger than max_batch"; return ISV_ERR_CAPACITY; }
     const isv_config_t &c = h->cfg;
-    const int N = c.n_frames;
+    const int N = c.n_frames, Nd = h->d.N;
     auto &s = h->h;
     size_t L = 0, F = 0, T = 0;
     std::vector<size_t> t_off((size_t)n + 1);
@@ -395,9 +412,9 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
     d.B = n; d.Ltot = (int32_t)L; d.Ftot = (int32_t)F; d.n_tiles = (int32_t)T;
     hipStream_t st = h->stream;
 #define H2D(dst, src, cnt) HIPCHK(h, hipMemcpyAsync(dst, src, sizeof(*(src)) * (size_t)(cnt), hipMemcpyHostToDevice, st))
-    const size_t NI = (size_t)n * (N - 1);
-    H2D(d.Ps, s.Ps, (size_t)n * N * 3); H2D(d.Rs, s.Rs, (size_t)n * N * 9); H2D(d.Vs, s.Vs, (size_t)n * N * 3);
-    H2D(d.Bas, s.Bas, (size_t)n * N * 3); H2D(d.Bgs, s.Bgs, (size_t)n * N * 3); H2D(d.tic, s.tic, (size_t)n * 3); H2D(d.ric, s.ric, (size_t)n * 9);
+    const size_t NI = (size_t)n * (Nd - 1);
+    H2D(d.Ps, s.Ps, (size_t)n * Nd * 3); H2D(d.Rs, s.Rs, (size_t)n * Nd * 9); H2D(d.Vs, s.Vs, (size_t)n * Nd * 3);
+    H2D(d.Bas, s.Bas, (size_t)n * Nd * 3); H2D(d.Bgs, s.Bgs, (size_t)n * Nd * 3); H2D(d.tic, s.tic, (size_t)n * 3); H2D(d.ric, s.ric, (size_t)n * 9);
     H2D(d.depth, s.depth, L); H2D(d.lm_off, s.lm_off, n + 1); H2D(d.f_off, s.f_off, n + 1);
     H2D(d.lm_host, s.lm_host, L); H2D(d.lm_k, s.lm_k, L); H2D(d.lm_f0, s.lm_f0, L); H2D(d.lm_pts_i, s.lm_pts_i, L * 3);
     H2D(d.f_rec, s.f_rec, F); H2D(d.f_pts_j, s.f_pts_j, F * 2); H2D(d.f_pts_z, s.f_pts_z, F);
@@ -411,8 +428,8 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
     H2D(d.n_rp, s.n_rp, n); H2D(d.margin_old, s.margin_old, n); H2D(d.header0, s.header0, n);
 #undef H2D
 #define D2D(dst, src, cnt) HIPCHK(h, hipMemcpyAsync(dst, src, sizeof(*(src)) * (size_t)(cnt), hipMemcpyDeviceToDevice, st))
-    D2D(h->Ps0, d.Ps, (size_t)n * N * 3); D2D(h->Rs0, d.Rs, (size_t)n * N * 9); D2D(h->Vs0, d.Vs, (size_t)n * N * 3);
-    D2D(h->Bas0, d.Bas, (size_t)n * N * 3); D2D(h->Bgs0, d.Bgs, (size_t)n * N * 3); D2D(h->depth0, d.depth, L);
+    D2D(h->Ps0, d.Ps, (size_t)n * Nd * 3); D2D(h->Rs0, d.Rs, (size_t)n * Nd * 9); D2D(h->Vs0, d.Vs, (size_t)n * Nd * 3);
+    D2D(h->Bas0, d.Bas, (size_t)n * Nd * 3); D2D(h->Bgs0, d.Bgs, (size_t)n * Nd * 3); D2D(h->depth0, d.depth, L);
     D2D(h->tic0, d.tic, (size_t)n * 3); D2D(h->ric0, d.ric, (size_t)n * 9);
     D2D(h->se30, d.se3, n); D2D(h->lin90, d.lin9, n); D2D(h->relpose0, d.relpose, (size_t)n * (c.n_vo - 1)); D2D(h->rollpitch0, d.rollpitch, (size_t)n * c.max_rollpitch);
     // IMU sqrt_info once per upload (the covariances do not change during a solve)
@@ -541,7 +558,7 @@ extern "C" int isv_batch_download(isv_backend_t *h, int32_t n, isv_window_t *con
     if (!h || !ws || n != h->resident) return ISV_ERR_INVALID_ARG;
     ENTER(h);
     DevBatch &d = h->d; hipStream_t st = h->stream; auto &s = h->h; const isv_config_t &c = h->cfg;
-    const size_t N = d.N, L = d.Ltot;
+    const size_t N = d.N, Nr = d.Nr, L = d.Ltot;          // device stride (incl. the extrinsic's pseudo-frame), real frames
 #define D2H(dst, src, cnt) HIPCHK(h, hipMemcpyAsync(dst, src, sizeof(*(src)) * (size_t)(cnt), hipMemcpyDeviceToHost, st))
     D2H(s.Ps, d.Ps, n * N * 3); D2H(s.Rs, d.Rs, n * N * 9); D2H(s.Vs, d.Vs, n * N * 3); D2H(s.Bas, d.Bas, n * N * 3); D2H(s.Bgs, d.Bgs, n * N * 3);
     D2H(s.tic, d.tic, (size_t)n * 3); D2H(s.ric, d.ric, (size_t)n * 9); D2H(s.depth, d.depth, L); D2H(s.solve_flag, d.solve_flag, L);
@@ -553,9 +570,9 @@ extern "C" int isv_batch_download(isv_backend_t *h, int32_t n, isv_window_t *con
     if (rcs != ISV_OK) return rcs;
     auto unpack = [&](int b) {
         isv_window_t *w = ws[b];
-        memcpy(w->Ps, s.Ps + (size_t)b * N * 3, sizeof(double) * N * 3); memcpy(w->Rs, s.Rs + (size_t)b * N * 9, sizeof(double) * N * 9);
-        memcpy(w->Vs, s.Vs + (size_t)b * N * 3, sizeof(double) * N * 3); memcpy(w->Bas, s.Bas + (size_t)b * N * 3, sizeof(double) * N * 3);
-        memcpy(w->Bgs, s.Bgs + (size_t)b * N * 3, sizeof(double) * N * 3);
+        memcpy(w->Ps, s.Ps + (size_t)b * N * 3, sizeof(double) * Nr * 3); memcpy(w->Rs, s.Rs + (size_t)b * N * 9, sizeof(double) * Nr * 9);
+        memcpy(w->Vs, s.Vs + (size_t)b * N * 3, sizeof(double) * Nr * 3); memcpy(w->Bas, s.Bas + (size_t)b * N * 3, sizeof(double) * Nr * 3);
+        memcpy(w->Bgs, s.Bgs + (size_t)b * N * 3, sizeof(double) * Nr * 3);
         memcpy(w->tic, s.tic + (size_t)b * 3, 24); memcpy(w->ric, s.ric + (size_t)b * 9, 72);
         const int l0 = s.lm_off[b];
         for (int l = 0; l < w->n_landmarks; l++) {
@@ -566,8 +583,8 @@ extern "C" int isv_batch_download(isv_backend_t *h, int32_t n, isv_window_t *con
         *w->pose_prior = s.se3[b]; *w->vb_prior = s.lin9[b];
         for (int i = 0; i < c.n_vo - 1; i++) w->relpose[i] = s.relpose[(size_t)b * (c.n_vo - 1) + i];
         for (int i = 0; i < w->n_rollpitch; i++) w->rollpitch[i] = s.rollpitch[(size_t)b * c.max_rollpitch + i];
-        if (w->para_Pose) memcpy(w->para_Pose, s.pose + (size_t)b * N * 7, sizeof(double) * N * 7);
-        if (w->para_SpeedBias) memcpy(w->para_SpeedBias, s.sb + (size_t)b * N * 9, sizeof(double) * N * 9);
+        if (w->para_Pose) memcpy(w->para_Pose, s.pose + (size_t)b * N * 7, sizeof(double) * Nr * 7);
+        if (w->para_SpeedBias) memcpy(w->para_SpeedBias, s.sb + (size_t)b * N * 9, sizeof(double) * Nr * 9);
         if (w->para_Ex_Pose) memcpy(w->para_Ex_Pose, s.ex + (size_t)b * 7, 56);
     };
     {
@@ -703,7 +720,7 @@ extern "C" int isv_backend_linearize(isv_backend_t *h, const isv_window_t *w, do
     // (blocking copies: the caller's buffers are pageable, and an asynchronous copy into pageable memory may still be
     // completing inside the runtime after the stream has drained)
     if (proj_strips && d.Ftot) HIPCHK(h, hipMemcpy(proj_strips, d.strip, sizeof(double) * (size_t)d.Ftot * ISV_PROJ_STRIP, hipMemcpyDeviceToHost));
-    if (imu_strips) HIPCHK(h, hipMemcpy(imu_strips, d.imu_strip, sizeof(double) * (size_t)(d.N - 1) * ISV_IMU_STRIP, hipMemcpyDeviceToHost));
+    if (imu_strips) HIPCHK(h, hipMemcpy(imu_strips, d.imu_strip, sizeof(double) * (size_t)(d.Nr - 1) * ISV_IMU_STRIP, hipMemcpyDeviceToHost));
     if (cost) HIPCHK(h, hipMemcpy(cost, d.cost, sizeof(double), hipMemcpyDeviceToHost));
     return ISV_OK;
 }
@@ -713,10 +730,10 @@ extern "C" int isv_backend_linearize(isv_backend_t *h, const isv_window_t *w, do
 // record = [para_Pose 7N | para_SpeedBias 9N | inverse depths, zero padded to max_landmarks |
 //           final_cost, initial_cost, iterations, termination, num_successful, radius, header0, n_landmarks]
 __global__ void k_pack_results(DevBatch d, double *dst, int64_t rec, int maxL) {
-    const int w = blockIdx.x, t = threadIdx.x, N = d.N;
+    const int w = blockIdx.x, t = threadIdx.x, N = d.Nr, Nd = d.N;
     double *o = dst + (size_t)w * rec;
-    for (int i = t; i < 7 * N; i += blockDim.x) o[i] = d.pose[(size_t)w * N * 7 + i];
-    for (int i = t; i < 9 * N; i += blockDim.x) o[7 * N + i] = d.sb[(size_t)w * N * 9 + i];
+    for (int i = t; i < 7 * N; i += blockDim.x) o[i] = d.pose[(size_t)w * Nd * 7 + i];
+    for (int i = t; i < 9 * N; i += blockDim.x) o[7 * N + i] = d.sb[(size_t)w * Nd * 9 + i];
     const int l0 = d.lm_off[w], Lw = d.lm_off[w + 1] - l0;
     for (int i = t; i < maxL; i += blockDim.x) o[16 * N + i] = i < Lw ? d.lam[l0 + i] : 0.0;
     if (t == 0) {
@@ -764,6 +781,7 @@ extern "C" int isv_debug_read(isv_backend_t *h, int32_t what, double *out, int64
     case 5: src = d.pose; break;
     case 6: src = d.lam; break;
     case 7: src = d.cost; break;
+    case 22: src = d.strip_ex; if (!src) return ISV_ERR_INVALID_ARG; break;
     default: return isv_solver_debug_read(h->d, st, what, out, count, h->err);
     }
     D2H(out, src, count);

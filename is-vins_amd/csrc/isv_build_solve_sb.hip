@@ -292,7 +292,8 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
                     const int r = e / n6, c = e - r * n6;
                     const unsigned m0 = d.lm_meta[lb + r];
                     const int h6 = 6 * (int)(m0 & 255), k6 = 6 * (int)((m0 >> 8) & 255);
-                    wS[r * wld + c] = (c >= h6 && c < h6 + k6) ? d.W[(size_t)(d.f_off[w] + (int)(m0 >> 16) + lb + r) * 6 + (c - h6)] : 0.0;
+                    wS[r * wld + c] = (c >= h6 && c < h6 + k6) ? d.W[(size_t)(d.f_off[w] + (int)(m0 >> 16) + lb + r) * 6 + (c - h6)]
+                                    : ((d.est_ex && c >= 6 * d.Nr) ? d.Wex[(size_t)(lb + r) * 6 + (c - 6 * d.Nr)] : 0.0);
                 }
                 if (t < cnt) {
                     const int l = lb + t;
@@ -336,6 +337,10 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
         if (t < n) g[t] += vG;
         __syncthreads();
         STAMP(1);
+        if (d.est_ex && t < 9) {                           // the pseudo-frame's speed/bias block is a dummy: unit diagonal, no coupling, zero gradient
+            Dss[(N - 1) * 81 + t * 9 + t] = 1.0;           // (after the barrier: the IMU gather above stores zeros there)
+            hdiag[15 * (N - 1) + 6 + t] = 1.0;
+        }
         // ---- prior factors (precomputed J^T J, staged in red[]) ---------------------------------------
         // Three conflict-free phases instead of a barrier per factor: factors of one phase touch disjoint entries
         //   A: Linear9 + the relative-pose factors (k, k+1) with k even     B: SE3 prior (pose 0) + those with k odd

@@ -131,4 +131,14 @@ struct DevBatch {
     int32_t *pg_wstart;                 // [B][ISV_SWEEP_WAVES + 1] stream offsets (within the window) of the sweep wavefronts' slices
     double *flm;                        // [Ftot][8] {J_l^T J_l, J_l^T r, J_i^T J_l (6)} per factor, CSR factor order
     int32_t fused_visual, _pad3;
+    // ESTIMATE_EXTRINSIC = 1 (src/estimator.cpp:1028-1036): the extrinsic is one more 6-dof block coupled to every
+    // reprojection factor.  On the device it rides as a PSEUDO-FRAME: N = Nr + 1 frames, frame Nr's pose block IS
+    // para_Ex_Pose (same PoseLocalParameterization), its speed/bias block is a dummy (zero state, unit Hessian diagonal,
+    // zero gradient -> zero step) and the IMU factor towards it is flagged skipped, so Plus / candidate / norms / the
+    // reduced-system solve / the dogleg need no special case.  Only the reprojection kernels know about it.
+    int32_t Nr, est_ex;                 // real frames (ALL_BUF_SIZE); N == Nr + est_ex
+    double *Wex;                        // [Ltot][6]  w of the extrinsic block per landmark: sum over its factors of J_ex^T J_l
+    double *flmx;                       // [Ftot][6]  J_ex^T J_l per factor (CSR factor order)
+    double *ex_part;                    // [B][NP][114] per pair group: J_ex^T J_i (36) | J_ex^T J_j (36) | J_ex^T J_ex (36) | J_ex^T r (6)
+    double *strip_ex;                   // [Ftot][12] J_ex of every factor (linearise API only)
 };

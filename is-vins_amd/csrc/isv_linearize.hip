@@ -191,6 +191,12 @@ __global__ __launch_bounds__(256) void k_proj_linearize(DevBatch d, const double
 #pragma unroll
             for (int k = 0; k < 12; k++) { Ji[k] *= sc; Jj[k] *= sc; }
             Jl[0] *= sc; Jl[1] *= sc;
+            if (d.est_ex && gate == 0) {               // linearise API with a free extrinsic: J_ex next to the 28-double strip
+                double Jex[12];
+                proj_jac_ex(Ri, Pi, Rj, Pj, ric, tic, d.proj_sqrt_info, lam, pi3[0], pi3[1], pi3[2], Jex);
+#pragma unroll
+                for (int k = 0; k < 12; k++) d.strip_ex[(size_t)f * 12 + k] = Jex[k] * sc;
+            }
         }
         fcost_out[f] = cost;
         if (MODE == 1) {

@@ -118,3 +118,86 @@ DEV void proj_residual_dir(const double *Ri, const double *Pi, const double *Rj,
     m0 = sq[0] * du0 + sq[1] * du1;
     m1 = sq[2] * du0 + sq[3] * du1;
 }
+
+// J_ex of ProjectionFactor::Evaluate (src/factor/projection_factor.cpp:100-111), the block that is only filled when the
+// extrinsic is estimated: 2x6 = reduce * [ ric^T (Rj^T Ri - I) | -T [pc]x + [T pc]x + [ric^T (Rj^T (Ri tic + Pi - Pj) - tic)]x ],
+// T = ric^T Rj^T Ri ric, pc = pts_camera_i.  Unweighted by the loss (the caller applies the Corrector's scale).
+DEV void proj_jac_ex(const double *Ri, const double *Pi, const double *Rj, const double *Pj, const double *ric, const double *tic,
+                     const double *sq, double lam, double pix, double piy, double piz, double *Jex) {
+    const double inv = 1.0 / lam;
+    const double pc[3] = {pix * inv, piy * inv, piz * inv};
+    double pb[3], pw[3], t[3], pbj[3], pcj[3];
+    m3v(ric, pc, pb); pb[0] += tic[0]; pb[1] += tic[1]; pb[2] += tic[2];
+    m3v(Ri, pb, pw);
+    t[0] = pw[0] + Pi[0] - Pj[0]; t[1] = pw[1] + Pi[1] - Pj[1]; t[2] = pw[2] + Pi[2] - Pj[2];
+    m3tv(Rj, t, pbj);
+    t[0] = pbj[0] - tic[0]; t[1] = pbj[1] - tic[1]; t[2] = pbj[2] - tic[2];
+    m3tv(ric, t, pcj);
+    const double idep = 1.0 / pcj[2];
+    const double a0 = idep, a2 = -pcj[0] * idep * idep, b2 = -pcj[1] * idep * idep;
+    const double red[6] = {sq[0] * a0, sq[1] * a0, sq[0] * a2 + sq[1] * b2, sq[2] * a0, sq[3] * a0, sq[2] * a2 + sq[3] * b2};
+    double M[9], A[9], Tm[9], je[18];
+    m3_mul_tn(Rj, Ri, M);                              // Rj^T Ri
+    m3_mul_tn(ric, M, A);                              // ric^T Rj^T Ri
+    m3_mul(A, ric, Tm);                                // T
+    double Tpc[3], v[3], w2[3], u[3];
+    m3v(Tm, pc, Tpc);
+    m3v(Ri, tic, v); v[0] += Pi[0] - Pj[0]; v[1] += Pi[1] - Pj[1]; v[2] += Pi[2] - Pj[2];
+    m3tv(Rj, v, w2); w2[0] -= tic[0]; w2[1] -= tic[1]; w2[2] -= tic[2];
+    m3tv(ric, w2, u);
+    double Spc[9], S1[9], S2[9], TS[9];
+    skew3(pc, Spc); skew3(Tpc, S1); skew3(u, S2); m3_mul(Tm, Spc, TS);
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            je[r * 6 + c] = A[r * 3 + c] - ric[c * 3 + r];                        // ric^T (Rj^T Ri - I)
+            je[r * 6 + 3 + c] = -TS[r * 3 + c] + S1[r * 3 + c] + S2[r * 3 + c];
+        }
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+        for (int c = 0; c < 6; c++) Jex[r * 6 + c] = red[r * 3] * je[c] + red[r * 3 + 1] * je[6 + c] + red[r * 3 + 2] * je[12 + c];
+}
+
+// proj_residual_dir with the extrinsic moving as well: (dt_ic, dtheta_ic) = dex, ric <- ric Exp(dtheta_ic)
+DEV void proj_residual_dir_ex(const double *Ri, const double *Pi, const double *Rj, const double *Pj,
+                              const double *ric, const double *tic, const double *sq, double lam,
+                              double pix, double piy, double piz, double pjx, double pjy,
+                              const double *di, const double *dj, const double *dex, double dlam,
+                              double &r0, double &r1, double &m0, double &m1) {
+    const double inv = 1.0 / lam;
+    double pc[3] = {pix * inv, piy * inv, piz * inv};
+    double pb[3], pw[3], t[3], pbj[3], pcj[3];
+    m3v(ric, pc, pb); pb[0] += tic[0]; pb[1] += tic[1]; pb[2] += tic[2];
+    m3v(Ri, pb, pw);
+    t[0] = pw[0] + Pi[0] - Pj[0]; t[1] = pw[1] + Pi[1] - Pj[1]; t[2] = pw[2] + Pi[2] - Pj[2];
+    m3tv(Rj, t, pbj);
+    t[0] = pbj[0] - tic[0]; t[1] = pbj[1] - tic[1]; t[2] = pbj[2] - tic[2];
+    m3tv(ric, t, pcj);
+    const double idep = 1.0 / pcj[2];
+    const double u0 = pcj[0] * idep - pjx, u1 = pcj[1] * idep - pjy;
+    r0 = sq[0] * u0 + sq[1] * u1;
+    r1 = sq[2] * u0 + sq[3] * u1;
+    const double sl = -dlam * inv;
+    // d pc = -pc dlam / lam;  d pb = ric (d pc + dtheta_ic x pc) + dt_ic + dtheta_i x pb (body frame);  d pw = Ri d pb + dP_i
+    double dpc[3] = {pc[0] * sl + dex[4] * pc[2] - dex[5] * pc[1], pc[1] * sl + dex[5] * pc[0] - dex[3] * pc[2], pc[2] * sl + dex[3] * pc[1] - dex[4] * pc[0]};
+    double dpb[3], dw[3], dbj[3], dcj[3];
+    m3v(ric, dpc, dpb);
+    dpb[0] += dex[0] + di[4] * pb[2] - di[5] * pb[1];
+    dpb[1] += dex[1] + di[5] * pb[0] - di[3] * pb[2];
+    dpb[2] += dex[2] + di[3] * pb[1] - di[4] * pb[0];
+    m3v(Ri, dpb, dw);
+    dw[0] += di[0] - dj[0]; dw[1] += di[1] - dj[1]; dw[2] += di[2] - dj[2];
+    m3tv(Rj, dw, dbj);
+    dbj[0] += pbj[1] * dj[5] - pbj[2] * dj[4] - dex[0];
+    dbj[1] += pbj[2] * dj[3] - pbj[0] * dj[5] - dex[1];
+    dbj[2] += pbj[0] * dj[4] - pbj[1] * dj[3] - dex[2];
+    m3tv(ric, dbj, dcj);                               // ric^T (d pbj - dt_ic)
+    dcj[0] += pcj[1] * dex[5] - pcj[2] * dex[4];        // - dtheta_ic x pcj
+    dcj[1] += pcj[2] * dex[3] - pcj[0] * dex[5];
+    dcj[2] += pcj[0] * dex[4] - pcj[1] * dex[3];
+    const double du0 = (dcj[0] - pcj[0] * idep * dcj[2]) * idep, du1 = (dcj[1] - pcj[1] * idep * dcj[2]) * idep;
+    m0 = sq[0] * du0 + sq[1] * du1;
+    m1 = sq[2] * du0 + sq[3] * du1;
+}

@@ -100,6 +100,10 @@ DEV void dogleg_body(DevBatch &d, const int w, const int t, double *red) {
                 wz += w01.x * z[0] + w01.y * z[1] + w23.x * z[2] + w23.y * z[3] + w45.x * z[4] + w45.y * z[5];
                 wu += w01.x * u[0] + w01.y * u[1] + w23.x * u[2] + w23.y * u[3] + w45.x * u[4] + w45.y * u[5];
             }
+            if (d.est_ex) {                                   // the extrinsic block (pseudo-frame Nr) couples to every landmark
+                const double *we = d.Wex + (size_t)l * 6, *z = zs + 15 * d.Nr, *u = us + 15 * d.Nr;
+                for (int c6 = 0; c6 < 6; c6++) { wz += we[c6] * z[c6]; wu += we[c6] * u[c6]; }
+            }
             const double sl = d.scale_l[l], E = d.lmE[l], gl = d.lmG[l], Dl = d.diag_l[l];
             const double Es = sl * sl * E, Dl2 = Dl * Dl;
             // scaled-space y_l = (g'_l - w'_l^T y_p) / (E'_l + mu D_l^2),  w'^T y_p = s_l w^T (Sc_p y_p) = s_l wz
@@ -325,11 +329,13 @@ DEV void step_control_body(DevBatch &d, const int w, const int t, double *cl, do
                 sEx[9] = e[0]; sEx[10] = e[1]; sEx[11] = e[2];
             }
             __syncthreads();
+            // the extrinsic: constant (d.ex), or -- when it is estimated -- the pseudo-frame's pose block, candidate and x
+            const double *exC = d.est_ex ? sC + d.Nr * 12 : sEx, *exX = d.est_ex ? sX + d.Nr * 12 : sEx;
             double ric[9], tic[3];
 #pragma unroll
-            for (int k = 0; k < 9; k++) ric[k] = sEx[k];
+            for (int k = 0; k < 9; k++) ric[k] = exC[k];
 #pragma unroll
-            for (int k = 0; k < 3; k++) tic[k] = sEx[9 + k];
+            for (int k = 0; k < 3; k++) tic[k] = exC[9 + k];
             for (int f = d.f_off[w] + t; f < d.f_off[w + 1]; f += 256) {
                 const FactorRec rec = d.f_rec[f];
                 const int fi = rec.ij & 255, fj = (rec.ij >> 8) & 255;
@@ -348,6 +354,15 @@ DEV void step_control_body(DevBatch &d, const int w, const int t, double *cl, do
                 for (int k = 0; k < 9; k++) { Ri[k] = sX[fi * 12 + k]; Rj[k] = sX[fj * 12 + k]; }
 #pragma unroll
                 for (int k = 0; k < 3; k++) { Pi[k] = sX[fi * 12 + 9 + k]; Pj[k] = sX[fj * 12 + 9 + k]; }
+                if (d.est_ex) {
+                    double ricX[9], ticX[3];
+#pragma unroll
+                    for (int k = 0; k < 9; k++) ricX[k] = exX[k];
+#pragma unroll
+                    for (int k = 0; k < 3; k++) ticX[k] = exX[9 + k];
+                    proj_residual_dir_ex(Ri, Pi, Rj, Pj, ricX, ticX, d.proj_sqrt_info, d.lam[rec.lm], pi3[0], pi3[1], pi3[2], pj.x, pj.y,
+                                         sD + fi * 6, sD + fj * 6, sD + d.Nr * 6, d.delta_l[rec.lm], rx0, rx1, m0, m1);
+                } else
                 proj_residual_dir(Ri, Pi, Rj, Pj, ric, tic, d.proj_sqrt_info, d.lam[rec.lm], pi3[0], pi3[1], pi3[2], pj.x, pj.y,
                                   sD + fi * 6, sD + fj * 6, d.delta_l[rec.lm], rx0, rx1, m0, m1);
                 const double rp = 1.0 / (1.0 + (rx0 * rx0 + rx1 * rx1));       // corrector: r, J scaled by sqrt(rho')
@@ -503,12 +518,15 @@ __global__ __launch_bounds__(64) void k_finalize(DevBatch d, int do_update) {
         double Rn[9];
         m3_mul(rot_diff, d.se3[w].R, Rn); for (int k = 0; k < 9; k++) d.se3[w].R[k] = Rn[k];               // :550
     } else if (lane == 2) {
-        const double *ex = d.ex + (size_t)w * 7;
-        for (int k = 0; k < 3; k++) d.tic[(size_t)w * 3 + k] = ex[k];
-        q_to_R(q_from_pose(ex), d.ric + (size_t)w * 9);
+        // tic / ric <- para_Ex_Pose (:577-586); when the extrinsic is estimated the solved block is the pseudo-frame's
+        // pose, which also becomes d.ex (MargForward linearises at it, and the caller reads para_Ex_Pose from it)
+        double *exw = d.ex + (size_t)w * 7;
+        if (d.est_ex) for (int k = 0; k < 7; k++) exw[k] = pose[7 * d.Nr + k];
+        for (int k = 0; k < 3; k++) d.tic[(size_t)w * 3 + k] = exw[k];
+        q_to_R(q_from_pose(exw), d.ric + (size_t)w * 9);
     }
     const double p0[3] = {pose[0], pose[1], pose[2]};
-    for (int i = lane; i < N; i += 64) {
+    for (int i = lane; i < d.Nr; i += 64) {            // (the real frames: the pseudo-frame is not a body pose)
         double Ri[9], dd[3], tt[3], Ro[9];
         q_to_R(q_normalized(q_from_pose(pose + 7 * i)), Ri);
         m3_mul(rot_diff, Ri, Ro);
@@ -585,7 +603,7 @@ int isv_solver_alloc(DevBatch &d, size_t B, size_t L, size_t F, std::vector<void
         SETLDS((k_rank1_mfma<4, 1, 64, 1>), lds_r1); SETLDS((k_rank1_mfma<5, 1, 64, 1>), lds_r1); SETLDS((k_rank1_mfma<6, 2, 64, 1>), lds_r1);
         SETLDS((k_rank1_mfma<7, 2, 64, 1>), lds_r1); SETLDS((k_rank1_mfma<8, 3, 64, 1>), lds_r1);
         SETLDS(k_sweep_mfma, lds_sw);
-        SETLDS(k_lin_gram, lin_gram_lds_bytes(d.N, true));
+        SETLDS(k_lin_gram<false>, lin_gram_lds_bytes(d.Nr, true, false)); SETLDS(k_lin_gram<true>, lin_gram_lds_bytes(d.Nr, true, true));
         if (d.N <= 11) SETLDS(k_build_solve_sb<false>, lds_sb); else SETLDS(k_build_solve_sb<true>, lds_sb);
 #undef SETLDS
     }
@@ -623,7 +641,8 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
         PROF(slot, 0, 0);
         if (fused) {
             // linearisation fused with the Gram products: no Jacobian strip goes to HBM (isv_visual.hip)
-            hipLaunchKernelGGL(k_lin_gram, dim3(d.B), dim3(64 * LG_WAVES), lin_gram_lds_bytes(d.N, !d.sw_global), st, d);
+            if (d.est_ex) hipLaunchKernelGGL(k_lin_gram<true>, dim3(d.B), dim3(64 * LG_WAVES), lin_gram_lds_bytes(d.Nr, !d.sw_global, true), st, d);
+            else hipLaunchKernelGGL(k_lin_gram<false>, dim3(d.B), dim3(64 * LG_WAVES), lin_gram_lds_bytes(d.Nr, !d.sw_global, false), st, d);
             counts[0]++; counts[4] = 1;
         } else if (d.n_tiles > 0) { hipLaunchKernelGGL(k_proj_linearize<0>, dim3((d.n_tiles + 3) / 4), dim3(256), lds_proj, st, d, d.pose, d.lam, d.fcost, 1); counts[0]++; }
         PROF(slot, 0, 1);

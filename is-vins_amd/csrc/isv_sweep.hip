@@ -192,6 +192,15 @@ __global__ __launch_bounds__(64 * ((NT * (NT + 1) / 2 + TPW - 1) / TPW), MINW) v
                 ((double2 *)(d.W + (size_t)(d.lm_f0[gl] + gl) * 6))[part - 1] = acc;     // host observation slot
             }
         }
+        if (d.est_ex) {                                    // the extrinsic's w of every landmark: sum over its factors of J_ex^T J_l
+            for (int q = t; q < 3 * Lw; q += nthr) {
+                const int l = q / 3, part = q - 3 * l, gl = l0 + l, kf = d.lm_k[gl] - 1;
+                const double2 *fx = (const double2 *)(d.flmx + (size_t)d.lm_f0[gl] * 6) + part;
+                double2 acc = fx[0];
+                for (int o = 1; o < kf; o++) { const double2 a = fx[3 * o]; acc.x += a.x; acc.y += a.y; }
+                ((double2 *)(d.Wex + (size_t)gl * 6))[part] = acc;
+            }
+        }
         __syncthreads();                                   // the host slots and lm_cg are read below by other threads
     }
     for (int l = t; l < Lw; l += nthr) { sM[l] = d.lm_meta[l0 + l]; sCG[l] = d.lm_cg[l0 + l]; }
@@ -208,6 +217,7 @@ __global__ __launch_bounds__(64 * ((NT * (NT + 1) / 2 + TPW - 1) / TPW), MINW) v
                 const int h6 = 6 * (int)(m0 & 255), k6 = 6 * (int)((m0 >> 8) & 255);
                 if (c >= h6 && c < h6 + k6) v = d.W[(size_t)(fw0 + (int)(m0 >> 16) + l0 + l) * 6 + (c - h6)];
                 else if (c == n6) v = sCG[l].y;
+                else if (d.est_ex && c >= 6 * d.Nr && c < n6) v = d.Wex[(size_t)(l0 + l) * 6 + (c - 6 * d.Nr)];     // pseudo-frame columns = the extrinsic block
             }
             pf[u2] = v;
         }

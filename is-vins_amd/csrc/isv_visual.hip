@@ -21,20 +21,25 @@
 
 __host__ __device__ inline int tvis_col2(int a, int N) { return 36 * (a * N - a * (a - 1) / 2); }
 typedef double double4g __attribute__((ext_vector_type(4)));
-#define LG_XLD 27                    // LDS row of one factor: r(2) J_i(12) J_j(12) + 1 (odd stride)
+// LDS row of one factor: r(2) J_i(12) J_j(12) [+ J_ex(12) when the extrinsic is estimated] + 1 (odd stride)
+__host__ __device__ constexpr int lg_xld(bool ex) { return ex ? 39 : 27; }
 #define LGSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
-size_t lin_gram_lds_bytes(int N, bool partials_in_lds) {
+size_t lin_gram_lds_bytes(int N /* real frames */, bool partials_in_lds, bool ex) {
     const size_t NP = (size_t)N * (N - 1) / 2;
-    return ((size_t)N * 12 + 12 + (size_t)LG_WAVES * 16 * LG_XLD + (partials_in_lds ? NP * 84 : 0) + (NP + 2) / 2 + 1) * sizeof(double);
+    return ((size_t)N * 12 + 12 + (size_t)LG_WAVES * 16 * lg_xld(ex) + (partials_in_lds ? NP * 84 : 0) + (NP + 2) / 2 + 1) * sizeof(double);
 }
 
-__global__ __launch_bounds__(64 * LG_WAVES, 3) void k_lin_gram(DevBatch d) {
+template <bool EX>
+__global__ __launch_bounds__(64 * LG_WAVES, EX ? 2 : 3) void k_lin_gram(DevBatch d) {
+    constexpr int LG_XLD = lg_xld(EX);
     extern __shared__ __align__(16) double lds[];
     const int w = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const SolveState &st = d.st[w];
     if (st.termination != ISV_TERM_RUNNING || !st.need_linearize) return;
-    const int N = d.N, NP = N * (N - 1) / 2;
+    // N: the REAL frames (pairs, pose blocks of the factors); Nd: pose blocks of the reduced system (+ the extrinsic's
+    // pseudo-frame, index N, when it is estimated)
+    const int N = d.Nr, Nd = d.N, NP = N * (N - 1) / 2;
     double *sPose = lds;                               // [N][12] R (row-major) | P
     double *sEx = sPose + N * 12;                      // [12]
     double *sX = sEx + 12 + wv * 16 * LG_XLD;          // this wavefront's 16-factor tile
@@ -48,13 +53,13 @@ __global__ __launch_bounds__(64 * LG_WAVES, 3) void k_lin_gram(DevBatch d) {
     const int *sched = d.pg_sched + (size_t)w * NP, *soff = d.pg_sched_off + (size_t)w * (ISV_SWEEP_WAVES + 1);
     double *out = d.Tvis + (size_t)w * d.tvis_sz;
     if (t < N) {
-        const double *p = d.pose + ((size_t)w * N + t) * 7;
+        const double *p = d.pose + ((size_t)w * Nd + t) * 7;
         double R[9]; q_to_R(q_from_pose(p), R);
 #pragma unroll
         for (int k = 0; k < 9; k++) sPose[t * 12 + k] = R[k];
         sPose[t * 12 + 9] = p[0]; sPose[t * 12 + 10] = p[1]; sPose[t * 12 + 11] = p[2];
     } else if (t == 64) {
-        const double *e = d.ex + (size_t)w * 7;
+        const double *e = EX ? d.pose + ((size_t)w * Nd + N) * 7 : d.ex + (size_t)w * 7;      // the estimated extrinsic lives in the pseudo-frame's pose block
         double R[9]; q_to_R(q_from_pose(e), R);
 #pragma unroll
         for (int k = 0; k < 9; k++) sEx[k] = R[k];
@@ -72,6 +77,19 @@ __global__ __launch_bounds__(64 * LG_WAVES, 3) void k_lin_gram(DevBatch d) {
     const int s0 = wst[wv * SPW], s1 = wst[(wv + 1) * SPW];       // this wavefront's slice of the factor stream
     auto gsize = [&](int qq) { const int pp = sched[qq] >> 16; return offL[pp + 1] - offL[pp]; };
     // one group's accumulator tile -> its five pieces.  C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+    double *exp_w = EX ? d.ex_part + (size_t)w * NP * 114 : nullptr;
+    auto flush_ex = [&](int qq, const double4g &a2, const double4g &a3) {       // J_ex^T [J_i | J_j | r] and J_ex^T J_ex of one group
+        const int p = sched[qq] >> 16;
+#pragma unroll
+        for (int reg = 0; reg <= 1; reg++) {
+            const int row = kq + 4 * reg;
+            if (row < 6) {
+                if (i < 6) { exp_w[p * 114 + row * 6 + i] = a2[reg]; exp_w[p * 114 + 72 + row * 6 + i] = a3[reg]; }
+                else if (i < 12) exp_w[p * 114 + 36 + row * 6 + (i - 6)] = a2[reg];
+                else if (i == 12) exp_w[p * 114 + 108 + row] = a2[reg];
+            }
+        }
+    };
     auto flush = [&](int qq, const double4g &acc) {
         const int rec = sched[qq], h = rec & 255, j = (rec >> 8) & 255, p = rec >> 16;
 #pragma unroll
@@ -82,24 +100,25 @@ __global__ __launch_bounds__(64 * LG_WAVES, 3) void k_lin_gram(DevBatch d) {
                 else if (i == 12) Pgh[p * 6 + row] = acc[reg];
             } else if (row < 12) {
                 const int rr = row - 6;
-                if (i < 6) out[tvis_col2(h, N) + (j - h) * 36 + rr * 6 + i] = acc[reg];        // block (j, h)
+                if (i < 6) out[tvis_col2(h, Nd) + (j - h) * 36 + rr * 6 + i] = acc[reg];        // block (j, h)
                 else if (i < 12) Pjj[p * 36 + rr * 6 + (i - 6)] = acc[reg];
                 else if (i == 12) Pgj[p * 6 + rr] = acc[reg];
             }
         }
     };
     // pairs nobody observes still own a slot of every sum below: zero them
-    for (int q = q0; q < q1; q++) if (gsize(q) == 0) flush(q, double4g{0, 0, 0, 0});
+    for (int q = q0; q < q1; q++) if (gsize(q) == 0) { flush(q, double4g{0, 0, 0, 0}); if (EX) flush_ex(q, double4g{0, 0, 0, 0}, double4g{0, 0, 0, 0}); }
     // The factor stream of this wavefront is its pair groups back to back (upload order), visited in FULL 64-lane
     // chunks: a chunk may span several groups, every lane reads its own pair's pose blocks.  The Gram accumulator
     // follows the group boundaries: rows of the 16-factor LDS tile outside the current group are masked to zero.
     int q = q0;
     while (q < q1 && gsize(q) == 0) q++;
     int gend = s0 + (q < q1 ? gsize(q) : 0);
-    double4g acc = {0, 0, 0, 0};
+    double4g acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0}, acc3 = {0, 0, 0, 0};
+    const int eoffx = 26 + row2 * 6 + (i < 6 ? i : 0);  // J_ex row row2, column i of the LDS factor row
     for (int pos = s0; pos < s1; pos += 64) {
         const int cnt = (s1 - pos) < 64 ? (s1 - pos) : 64;
-        double r0 = 0, r1 = 0, Ji[12], Jj[12], Jl[2];
+        double r0 = 0, r1 = 0, Ji[12], Jj[12], Jl[2], Jex[12];
         if (lane < cnt) {
             const int2 rc = prec[pos + lane];              // {global landmark, f_rel | h << 16 | j << 24}
             const int h = (rc.y >> 16) & 255, j = (rc.y >> 24) & 255;
@@ -131,6 +150,15 @@ __global__ __launch_bounds__(64 * LG_WAVES, 3) void k_lin_gram(DevBatch d) {
             fl[1] = make_double2(Ji[0] * Jl[0] + Ji[6] * Jl[1], Ji[1] * Jl[0] + Ji[7] * Jl[1]);
             fl[2] = make_double2(Ji[2] * Jl[0] + Ji[8] * Jl[1], Ji[3] * Jl[0] + Ji[9] * Jl[1]);
             fl[3] = make_double2(Ji[4] * Jl[0] + Ji[10] * Jl[1], Ji[5] * Jl[0] + Ji[11] * Jl[1]);
+            if (EX) {                                   // J_ex (projection_factor.cpp:100-111), same corrector scale; its piece of the landmark's w
+                proj_jac_ex(Ri, Pi, Rj, Pj, ric, tic, d.proj_sqrt_info, d.lam[rc.x], pi3[0], pi3[1], pi3[2], Jex);
+#pragma unroll
+                for (int k = 0; k < 12; k++) Jex[k] *= sc;
+                double2 *fx = (double2 *)(d.flmx + f * 6);
+                fx[0] = make_double2(Jex[0] * Jl[0] + Jex[6] * Jl[1], Jex[1] * Jl[0] + Jex[7] * Jl[1]);
+                fx[1] = make_double2(Jex[2] * Jl[0] + Jex[8] * Jl[1], Jex[3] * Jl[0] + Jex[9] * Jl[1]);
+                fx[2] = make_double2(Jex[4] * Jl[0] + Jex[10] * Jl[1], Jex[5] * Jl[0] + Jex[11] * Jl[1]);
+            }
         }
         // Gram: 16 factors per round through the wave-private LDS tile
         for (int rq = 0; rq * 16 < cnt; rq++) {
@@ -139,11 +167,19 @@ __global__ __launch_bounds__(64 * LG_WAVES, 3) void k_lin_gram(DevBatch d) {
                 row[0] = r0; row[1] = r1;
 #pragma unroll
                 for (int k = 0; k < 12; k++) { row[2 + k] = Ji[k]; row[14 + k] = Jj[k]; }
+                if (EX) {
+#pragma unroll
+                    for (int k = 0; k < 12; k++) row[26 + k] = Jex[k];
+                }
             }
             LGSYNC();
-            double v[8];
+            double v[8], vx[8];
 #pragma unroll
             for (int u2 = 0; u2 < 8; u2++) v[u2] = colok ? sX[(2 * u2 + fsel) * LG_XLD + eoff] : 0.0;
+            if (EX) {
+#pragma unroll
+                for (int u2 = 0; u2 < 8; u2++) vx[u2] = i < 6 ? sX[(2 * u2 + fsel) * LG_XLD + eoffx] : 0.0;
+            }
             const int rs = pos + 16 * rq, re = (rs + 16) < (pos + cnt) ? (rs + 16) : (pos + cnt);
             int cur = rs;
             while (cur < re) {                              // the segments of this round, one per group it touches
@@ -155,12 +191,18 @@ __global__ __launch_bounds__(64 * LG_WAVES, 3) void k_lin_gram(DevBatch d) {
                         const int src = 2 * u2 + fsel;
                         const double x = (src >= a && src < b) ? v[u2] : 0.0;
                         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, acc, 0, 0, 0);
+                        if (EX) {                       // D[r][c] = sum_k A[k][r] B[k][c]: rows = J_ex columns
+                            const double xe = (src >= a && src < b) ? vx[u2] : 0.0;
+                            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(xe, x, acc2, 0, 0, 0);
+                            acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(xe, xe, acc3, 0, 0, 0);
+                        }
                     }
                 }
                 cur = se;
                 if (se == gend) {                           // the group is complete
                     flush(q, acc);
                     acc = double4g{0, 0, 0, 0};
+                    if (EX) { flush_ex(q, acc2, acc3); acc2 = double4g{0, 0, 0, 0}; acc3 = double4g{0, 0, 0, 0}; }
                     q++;
                     while (q < q1 && gsize(q) == 0) q++;
                     gend += q < q1 ? gsize(q) : 0;
@@ -171,22 +213,45 @@ __global__ __launch_bounds__(64 * LG_WAVES, 3) void k_lin_gram(DevBatch d) {
     }
     __syncthreads();
     // fold the pair partials into the diagonal blocks, the Jacobi-scaling diagonal and the gradient (fixed order)
-    const int tail = 36 * (N * (N + 1) / 2);
+    const int tail = 36 * (Nd * (Nd + 1) / 2);
     auto pidx = [N](int hh, int jj) { return hh * N - hh * (hh + 1) / 2 + (jj - hh - 1); };
+    if (EX) {
+        // the extrinsic's block row of the pose system: (ex, a) for every real frame a, (ex, ex), its diagonal and gradient
+        for (int tq = t; tq < (N + 1) * 36 + 6; tq += blockDim.x) {
+            double sum = 0.0;
+            if (tq < N * 36) {
+                const int a = tq / 36, rc = tq - 36 * a;
+                for (int j2 = a + 1; j2 < N; j2++) sum += exp_w[pidx(a, j2) * 114 + rc];
+                for (int h2 = 0; h2 < a; h2++) sum += exp_w[pidx(h2, a) * 114 + 36 + rc];
+                out[tvis_col2(a, Nd) + (N - a) * 36 + rc] = sum;
+            } else if (tq < (N + 1) * 36) {
+                const int rc = tq - N * 36;
+                for (int p2 = 0; p2 < NP; p2++) sum += exp_w[p2 * 114 + 72 + rc];
+                out[tvis_col2(N, Nd) + rc] = sum;
+                if (rc / 6 == rc % 6) out[tail + 6 * N + rc / 6] = sum;
+            } else {
+                const int r = tq - (N + 1) * 36;
+                for (int p2 = 0; p2 < NP; p2++) sum += exp_w[p2 * 114 + 108 + r];
+                out[tail + 6 * Nd + 6 * N + r] = sum;
+            }
+        }
+    }
     for (int tq = t; tq < N * 42; tq += blockDim.x) {
         if (tq < N * 36) {
             const int a = tq / 36, rc = tq - 36 * a, r = rc / 6, c = rc - 6 * r;
             double s = 0.0;
             for (int j2 = a + 1; j2 < N; j2++) s += Phh[pidx(a, j2) * 36 + rc];
             for (int h2 = 0; h2 < a; h2++) s += Pjj[pidx(h2, a) * 36 + rc];
-            out[tvis_col2(a, N) + rc] = s;
+            out[tvis_col2(a, Nd) + rc] = s;
             if (r == c) out[tail + 6 * a + r] = s;
         } else {
             const int q = tq - N * 36, a = q / 6, r = q - 6 * a;
             double s = 0.0;
             for (int j2 = a + 1; j2 < N; j2++) s += Pgh[pidx(a, j2) * 6 + r];
             for (int h2 = 0; h2 < a; h2++) s += Pgj[pidx(h2, a) * 6 + r];
-            out[tail + 6 * N + 6 * a + r] = s;
+            out[tail + 6 * Nd + 6 * a + r] = s;
         }
     }
 }
+template __global__ void k_lin_gram<false>(DevBatch);
+template __global__ void k_lin_gram<true>(DevBatch);

@@ -82,7 +82,7 @@ def test_create_rejects_bad_config(lib):
     h = C.c_void_p()
     cfg.n_frames = 2
     assert lib.isv_backend_create(C.byref(cfg), C.byref(h)) == -1
-    cfg = abi.make_config(11, 5); cfg.estimate_extrinsic = 1
+    cfg = abi.make_config(11, 5); cfg.estimate_extrinsic = 2        # (2 = online initial calibration: initial/, out of scope)
     assert lib.isv_backend_create(C.byref(cfg), C.byref(h)) == -5
     assert lib.isv_backend_create(None, C.byref(h)) == -1
 
