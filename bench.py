@@ -288,7 +288,7 @@ def main():
         cfg2 = {"workload": f"one synthetic window, N={N} KF, L={windows[0].L} landmarks, F={F0} reprojection + {N - 1} IMU factors + priors: every residual block evaluated once (ceres::Problem::Evaluate equivalent), isv_batch_linearize",
                 "gpu_us": 1e3 * float(tl[0]), "gpu_us_proj_kernel": 1e3 * float(tl[1]), "gpu_us_imu_prior_kernels": 1e3 * float(tl[2]),
                 "algorithmic_bytes": bytes_cfg2, "gpu_GBps": bytes_cfg2 / (float(tl[0]) * 1e-3) / 1e9,
-                "note": "a single window moves 0.4 MB: launch-latency bound, far from the HBM roofline (SURVEY 8d); the batched figure is roofline_by_kernel[k_proj_linearize<0>]"}
+                "note": "a single window moves 0.4 MB: launch-latency bound, far from the HBM roofline (SURVEY 8d); the batched figure is the k_lin_gram entry of roofline_by_kernel"}
         if cpu_lib is not None:
             dp = C.POINTER(C.c_double)
             ps = np.zeros((F0, 28)); im = np.zeros((N - 1, 465)); pr = np.zeros(256); co = np.zeros(1)
