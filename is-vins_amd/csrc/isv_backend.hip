@@ -144,7 +144,12 @@ static int create_impl(isv_backend *h) {
     TRY(dalloc(h, &d.pg_perm, F)); TRY(dalloc(h, &d.pg_off, B * ((size_t)c.n_frames * (c.n_frames - 1) / 2 + 1)));
     TRY(dalloc(h, &d.pg_sched, B * ((size_t)c.n_frames * (c.n_frames - 1) / 2))); TRY(dalloc(h, &d.pg_sched_off, B * (ISV_SWEEP_WAVES + 1)));
     TRY(dalloc(h, &d.pg_rec, F * 2)); TRY(dalloc(h, &d.pg_pts, F * 2)); TRY(dalloc(h, &d.flm, F * 8)); TRY(dalloc(h, &d.pg_wstart, B * (ISV_SWEEP_WAVES + 1)));
-    d.fused_visual = getenv("ISV_LEGACY_VISUAL") ? 0 : 1;      // (test hook: the unfused k_proj_linearize<0> + k_sweep_mfma pair)
+    // k_lin_gram takes one window per workgroup: right for batches of ordinary windows; a handle sized for very long factor
+    // lists (BASELINE config 5: 30 000 factors in ONE window) keeps the factor-parallel k_proj_linearize<0> + k_sweep_mfma
+    // pair, which spreads a window over the whole GPU (6.2 against 8.3 ms per optimize there).  Decided per HANDLE, from its
+    // capacity, never from the batch: a window gives the same bits alone and inside any batch of the same handle.
+    // (ISV_LEGACY_VISUAL: test / measurement hook for the unfused pair.)
+    d.fused_visual = (getenv("ISV_LEGACY_VISUAL") || (c.max_obs > 8192 && !c.estimate_extrinsic)) ? 0 : 1;
     TRY(dalloc(h, &d.imu_in, NI * ISV_IMU_IN)); TRY(dalloc(h, &d.imu_cov, NI * 225)); TRY(dalloc(h, &d.imu_sqrt, NI * 225));
     TRY(dalloc(h, &d.imu_skip, NI));
     TRY(dalloc(h, &d.se3, B)); TRY(dalloc(h, &d.lin9, B)); TRY(dalloc(h, &d.relpose, B * (c.n_vo - 1))); TRY(dalloc(h, &d.rollpitch, B * (size_t)c.max_rollpitch));

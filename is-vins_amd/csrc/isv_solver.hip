@@ -26,7 +26,7 @@ __global__ void k_init_priors(DevBatch d, double *scratch, size_t per_window, do
 __global__ void k_imu_raw(DevBatch d, const double *pose_src, const double *sb_src, int gate);
 __global__ void k_imu_weight(DevBatch d, double *cost_out, int gate);
 __global__ void k_sweep_mfma(DevBatch d);
-template <int NT, int TPW, int R1_CHUNK, int MINW> __global__ void k_rank1_mfma(DevBatch d);
+template <int NT, int TPW, int R1_CHUNK, int MINW, bool EX> __global__ void k_rank1_mfma(DevBatch d);
 __global__ void k_marg_clear(DevBatch d);
 __global__ void k_marg_fwd(DevBatch d);
 __global__ void k_marg_bwd(DevBatch d);
@@ -65,6 +65,7 @@ DEV double block_sum(double v, double *red, int t) {
 #else
 #define DSTAMP(k) do {} while (0)
 #endif
+template <bool EX>
 DEV void dogleg_body(DevBatch &d, const int w, const int t, double *red) {
     SolveState &st = d.st[w];
     if (st.termination != ISV_TERM_RUNNING) return;
@@ -100,7 +101,7 @@ DEV void dogleg_body(DevBatch &d, const int w, const int t, double *red) {
                 wz += w01.x * z[0] + w01.y * z[1] + w23.x * z[2] + w23.y * z[3] + w45.x * z[4] + w45.y * z[5];
                 wu += w01.x * u[0] + w01.y * u[1] + w23.x * u[2] + w23.y * u[3] + w45.x * u[4] + w45.y * u[5];
             }
-            if (d.est_ex) {                                   // the extrinsic block (pseudo-frame Nr) couples to every landmark
+            if (EX) {                                         // the extrinsic block (pseudo-frame Nr) couples to every landmark
                 const double *we = d.Wex + (size_t)l * 6, *z = zs + 15 * d.Nr, *u = us + 15 * d.Nr;
                 for (int c6 = 0; c6 < 6; c6++) { wz += we[c6] * z[c6]; wu += we[c6] * u[c6]; }
             }
@@ -269,23 +270,26 @@ DEV void dogleg_body(DevBatch &d, const int w, const int t, double *red) {
     }
     DSTAMP(53);
 }
-template <bool FUSED> DEV void step_control_body(DevBatch &d, const int w, const int t, double *cl, double *red, int &s_accept);
+template <bool FUSED, bool EX> DEV void step_control_body(DevBatch &d, const int w, const int t, double *cl, double *red, int &s_accept);
 // CONTROL: the candidate evaluation + TrustRegionMinimizer step control of this window follow in the same workgroup
 // (one launch and one round of workgroups less per iteration than k_dogleg -> k_step_control<true>)
-template <bool CONTROL>
+// EX: estimate_extrinsic = 1 (its own instantiation: the extra code costs the ordinary kernels registers otherwise)
+template <bool CONTROL, bool EX>
 __global__ __launch_bounds__(256, 4) void k_dogleg(DevBatch d) {
     __shared__ double red[256];
     __shared__ int s_accept;
     const int w = blockIdx.x, t = threadIdx.x;
-    dogleg_body(d, w, t, red);
+    dogleg_body<EX>(d, w, t, red);
     if (CONTROL) {
         extern __shared__ __align__(16) double dync[];
         __syncthreads();                               // candidate states, per-factor costs and model pieces of this window are written
-        step_control_body<true>(d, w, t, dync, red, s_accept);
+        step_control_body<true, EX>(d, w, t, dync, red, s_accept);
     }
 }
-template __global__ void k_dogleg<false>(DevBatch);
-template __global__ void k_dogleg<true>(DevBatch);
+template __global__ void k_dogleg<false, false>(DevBatch);
+template __global__ void k_dogleg<true, false>(DevBatch);
+template __global__ void k_dogleg<false, true>(DevBatch);
+template __global__ void k_dogleg<true, true>(DevBatch);
 
 
 // ------------------------------------------------------------------------------------------
@@ -295,7 +299,7 @@ template __global__ void k_dogleg<true>(DevBatch);
 // factor per thread in the same thread -> factor order the separate k_proj_linearize<1> pass summed them in, instead
 // of being written to fcost_c / fmodel by a tile-grid kernel and read back: one launch and one round trip less per
 // iteration.  Dynamic LDS: candidate poses [N][12] | extrinsic [12] | poses at x [N][12] | tangent step [N][6].
-template <bool FUSED>
+template <bool FUSED, bool EX>
 DEV void step_control_body(DevBatch &d, const int w, const int t, double *cl, double *red, int &s_accept) {
     SolveState &st = d.st[w];
     if (st.termination != ISV_TERM_RUNNING) return;
@@ -330,7 +334,7 @@ DEV void step_control_body(DevBatch &d, const int w, const int t, double *cl, do
             }
             __syncthreads();
             // the extrinsic: constant (d.ex), or -- when it is estimated -- the pseudo-frame's pose block, candidate and x
-            const double *exC = d.est_ex ? sC + d.Nr * 12 : sEx, *exX = d.est_ex ? sX + d.Nr * 12 : sEx;
+            const double *exC = EX ? sC + d.Nr * 12 : sEx, *exX = EX ? sX + d.Nr * 12 : sEx;
             double ric[9], tic[3];
 #pragma unroll
             for (int k = 0; k < 9; k++) ric[k] = exC[k];
@@ -354,7 +358,7 @@ DEV void step_control_body(DevBatch &d, const int w, const int t, double *cl, do
                 for (int k = 0; k < 9; k++) { Ri[k] = sX[fi * 12 + k]; Rj[k] = sX[fj * 12 + k]; }
 #pragma unroll
                 for (int k = 0; k < 3; k++) { Pi[k] = sX[fi * 12 + 9 + k]; Pj[k] = sX[fj * 12 + 9 + k]; }
-                if (d.est_ex) {
+                if (EX) {
                     double ricX[9], ticX[3];
 #pragma unroll
                     for (int k = 0; k < 9; k++) ricX[k] = exX[k];
@@ -426,12 +430,12 @@ DEV void step_control_body(DevBatch &d, const int w, const int t, double *cl, do
         for (int l = l0 + t; l < l1; l += 256) d.lam[l] = d.clam[l];
     }
 }
-template <bool FUSED>
+template <bool FUSED, bool EX>
 __global__ __launch_bounds__(256) void k_step_control(DevBatch d) {
     extern __shared__ __align__(16) double cl[];
     __shared__ double red[256];
     __shared__ int s_accept;
-    step_control_body<FUSED>(d, blockIdx.x, threadIdx.x, cl, red, s_accept);
+    step_control_body<FUSED, EX>(d, blockIdx.x, threadIdx.x, cl, red, s_accept);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -559,6 +563,14 @@ static int dal(T **p, size_t n, std::vector<void *> &allocs, std::string &err) {
 #define TRYA(x) do { int rc_ = (x); if (rc_ != ISV_OK) return rc_; } while (0)
 static std::mutex g_lds_attr_mutex;
 
+// workgroups of kernel `fn` (threads per workgroup, dynamic LDS bytes) the current device holds at once
+static size_t resident_workgroups(const void *fn, int threads, size_t lds) {
+    int per_cu = 0, dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, lds) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return (size_t)per_cu * (size_t)cus;
+}
+
 int isv_solver_alloc(DevBatch &d, size_t B, size_t L, size_t F, std::vector<void *> &allocs, std::string &err) {
     const size_t n = d.np, NI = B * (d.N - 1);
     TRYA(dal(&d.scale_p, B * n, allocs, err)); TRYA(dal(&d.diag_p, B * n, allocs, err)); TRYA(dal(&d.grad_p, B * n, allocs, err));
@@ -599,9 +611,9 @@ int isv_solver_alloc(DevBatch &d, size_t B, size_t L, size_t F, std::vector<void
     if (d.lds_T) {
         // the attribute is per kernel (and device) and process-wide: handles of different shapes must not lower each other's value
 #define SETLDS(K, BYTES) do { static size_t cur_[64] = {}; std::lock_guard<std::mutex> lk_(g_lds_attr_mutex); if ((size_t)(BYTES) > cur_[dev_ & 63]) { HCHK(hipFuncSetAttribute((const void *)K, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES))); cur_[dev_ & 63] = (size_t)(BYTES); } } while (0)
-        SETLDS((k_rank1_mfma<1, 1, 64, 1>), lds_r1); SETLDS((k_rank1_mfma<2, 1, 64, 1>), lds_r1); SETLDS((k_rank1_mfma<3, 1, 64, 1>), lds_r1);
-        SETLDS((k_rank1_mfma<4, 1, 64, 1>), lds_r1); SETLDS((k_rank1_mfma<5, 1, 64, 1>), lds_r1); SETLDS((k_rank1_mfma<6, 2, 64, 1>), lds_r1);
-        SETLDS((k_rank1_mfma<7, 2, 64, 1>), lds_r1); SETLDS((k_rank1_mfma<8, 3, 64, 1>), lds_r1);
+        SETLDS((k_rank1_mfma<1, 1, 64, 1, false>), lds_r1); SETLDS((k_rank1_mfma<1, 1, 64, 1, true>), lds_r1); SETLDS((k_rank1_mfma<2, 1, 64, 1, false>), lds_r1); SETLDS((k_rank1_mfma<2, 1, 64, 1, true>), lds_r1); SETLDS((k_rank1_mfma<3, 1, 64, 1, false>), lds_r1); SETLDS((k_rank1_mfma<3, 1, 64, 1, true>), lds_r1);
+        SETLDS((k_rank1_mfma<4, 1, 64, 1, false>), lds_r1); SETLDS((k_rank1_mfma<4, 1, 64, 1, true>), lds_r1); SETLDS((k_rank1_mfma<5, 1, 64, 1, false>), lds_r1); SETLDS((k_rank1_mfma<5, 1, 64, 1, true>), lds_r1); SETLDS((k_rank1_mfma<6, 2, 64, 1, false>), lds_r1); SETLDS((k_rank1_mfma<6, 2, 64, 1, true>), lds_r1);
+        SETLDS((k_rank1_mfma<7, 2, 64, 1, false>), lds_r1); SETLDS((k_rank1_mfma<7, 2, 64, 1, true>), lds_r1); SETLDS((k_rank1_mfma<8, 3, 64, 1, false>), lds_r1); SETLDS((k_rank1_mfma<8, 3, 64, 1, true>), lds_r1);
         SETLDS(k_sweep_mfma, lds_sw);
         SETLDS(k_lin_gram<false>, lin_gram_lds_bytes(d.Nr, true, false)); SETLDS(k_lin_gram<true>, lin_gram_lds_bytes(d.Nr, true, true));
         if (d.N <= 11) SETLDS(k_build_solve_sb<false>, lds_sb); else SETLDS(k_build_solve_sb<true>, lds_sb);
@@ -626,6 +638,15 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
     const size_t lds_proj = 4 * proj_lds_doubles_per_wave(d.N, 0) * sizeof(double), lds_proj1 = 4 * proj_lds_doubles_per_wave(d.N, 1) * sizeof(double);
     if (getenv("ISV_ONE_STREAM")) st2 = st;            // diagnostics: serialise everything on one stream (per-kernel timelines)
     const size_t lds_bs = build_solve_lds_bytes(d.N, false);
+    const size_t lds_dg = (d.lds_T ? ((size_t)(d.N - 1) * 48 + (size_t)d.n_prior_slots * 16) * sizeof(double) + prior_lds_bytes(d.n_prior_slots, false) : 0) + 2 * (size_t)d.np * sizeof(double);
+    const size_t lds_sc = ((size_t)30 * d.N + 12) * sizeof(double);
+    // dogleg + step control in one kernel while the batch fits ONE resident round of it (it holds fewer workgroups per CU
+    // than k_dogleg<false>: at 2048 windows the fused kernel needs a second round and the step is 21 % slower, measured);
+    // same arithmetic either way (bitwise, tests/test_gpu_branches.py)
+    // (a free extrinsic is only evaluated by the per-window kernels: k_proj_linearize<1> reads the constant one)
+    const bool control_in_wg = d.lds_T && ((size_t)d.Ftot <= (size_t)4096 * d.B || d.est_ex);
+    const bool fuse_control = control_in_wg && !getenv("ISV_SPLIT_CONTROL") &&
+                              d.B <= resident_workgroups(d.est_ex ? (const void *)k_dogleg<true, true> : (const void *)k_dogleg<true, false>, 256, lds_dg > lds_sc ? lds_dg : lds_sc);
     hipLaunchKernelGGL(k_init_state, dim3((d.B + 63) / 64), dim3(64), 0, st, d);
     for (int slot = 0; slot < d.max_iter; slot++) {
         // linearise where needed (k_*_linearize skip windows whose need_linearize == 0 via the tile/window flags)
@@ -660,14 +681,14 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
             const size_t lds_r1 = (64 * (d.wd_ld + 4) + (size_t)d.max_lm * 3 + 2) * sizeof(double);
             PROF(slot, 2, 0);
             switch (nt) {
-            case 1: hipLaunchKernelGGL((k_rank1_mfma<1, 1, 64, 1>), dim3(d.B), dim3(64 * 1), lds_r1, st, d); break;
-            case 2: hipLaunchKernelGGL((k_rank1_mfma<2, 1, 64, 1>), dim3(d.B), dim3(64 * 3), lds_r1, st, d); break;
-            case 3: hipLaunchKernelGGL((k_rank1_mfma<3, 1, 64, 1>), dim3(d.B), dim3(64 * 6), lds_r1, st, d); break;
-            case 4: hipLaunchKernelGGL((k_rank1_mfma<4, 1, 64, 1>), dim3(d.B), dim3(64 * 10), lds_r1, st, d); break;
-            case 5: hipLaunchKernelGGL((k_rank1_mfma<5, 1, 64, 1>), dim3(d.B), dim3(64 * 15), lds_r1, st, d); break;
-            case 6: hipLaunchKernelGGL((k_rank1_mfma<6, 2, 64, 1>), dim3(d.B), dim3(64 * 11), lds_r1, st, d); break;
-            case 7: hipLaunchKernelGGL((k_rank1_mfma<7, 2, 64, 1>), dim3(d.B), dim3(64 * 14), lds_r1, st, d); break;
-            default: hipLaunchKernelGGL((k_rank1_mfma<8, 3, 64, 1>), dim3(d.B), dim3(64 * 12), lds_r1, st, d); break;
+            case 1: if (d.est_ex) hipLaunchKernelGGL((k_rank1_mfma<1, 1, 64, 1, true>), dim3(d.B), dim3(64 * 1), lds_r1, st, d); else hipLaunchKernelGGL((k_rank1_mfma<1, 1, 64, 1, false>), dim3(d.B), dim3(64 * 1), lds_r1, st, d); break;
+            case 2: if (d.est_ex) hipLaunchKernelGGL((k_rank1_mfma<2, 1, 64, 1, true>), dim3(d.B), dim3(64 * 3), lds_r1, st, d); else hipLaunchKernelGGL((k_rank1_mfma<2, 1, 64, 1, false>), dim3(d.B), dim3(64 * 3), lds_r1, st, d); break;
+            case 3: if (d.est_ex) hipLaunchKernelGGL((k_rank1_mfma<3, 1, 64, 1, true>), dim3(d.B), dim3(64 * 6), lds_r1, st, d); else hipLaunchKernelGGL((k_rank1_mfma<3, 1, 64, 1, false>), dim3(d.B), dim3(64 * 6), lds_r1, st, d); break;
+            case 4: if (d.est_ex) hipLaunchKernelGGL((k_rank1_mfma<4, 1, 64, 1, true>), dim3(d.B), dim3(64 * 10), lds_r1, st, d); else hipLaunchKernelGGL((k_rank1_mfma<4, 1, 64, 1, false>), dim3(d.B), dim3(64 * 10), lds_r1, st, d); break;
+            case 5: if (d.est_ex) hipLaunchKernelGGL((k_rank1_mfma<5, 1, 64, 1, true>), dim3(d.B), dim3(64 * 15), lds_r1, st, d); else hipLaunchKernelGGL((k_rank1_mfma<5, 1, 64, 1, false>), dim3(d.B), dim3(64 * 15), lds_r1, st, d); break;
+            case 6: if (d.est_ex) hipLaunchKernelGGL((k_rank1_mfma<6, 2, 64, 1, true>), dim3(d.B), dim3(64 * 11), lds_r1, st, d); else hipLaunchKernelGGL((k_rank1_mfma<6, 2, 64, 1, false>), dim3(d.B), dim3(64 * 11), lds_r1, st, d); break;
+            case 7: if (d.est_ex) hipLaunchKernelGGL((k_rank1_mfma<7, 2, 64, 1, true>), dim3(d.B), dim3(64 * 14), lds_r1, st, d); else hipLaunchKernelGGL((k_rank1_mfma<7, 2, 64, 1, false>), dim3(d.B), dim3(64 * 14), lds_r1, st, d); break;
+            default: if (d.est_ex) hipLaunchKernelGGL((k_rank1_mfma<8, 3, 64, 1, true>), dim3(d.B), dim3(64 * 12), lds_r1, st, d); else hipLaunchKernelGGL((k_rank1_mfma<8, 3, 64, 1, false>), dim3(d.B), dim3(64 * 12), lds_r1, st, d); break;
             }
             PROF(slot, 2, 1);
         }
@@ -679,12 +700,13 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
         else hipLaunchKernelGGL(k_build_solve<false>, dim3(d.B), dim3(512), lds_bs, st, d);
         counts[1]++;
         PROF(slot, 3, 1);
-        const bool fuse_control = d.lds_T && (size_t)d.Ftot <= (size_t)4096 * d.B && !getenv("ISV_SPLIT_CONTROL");
-        const size_t lds_dg = (d.lds_T ? ((size_t)(d.N - 1) * 48 + (size_t)d.n_prior_slots * 16) * sizeof(double) + prior_lds_bytes(d.n_prior_slots, false) : 0) + 2 * (size_t)d.np * sizeof(double);
-        const size_t lds_sc = ((size_t)30 * d.N + 12) * sizeof(double);
         PROF(slot, 4, 0);
-        if (fuse_control) { hipLaunchKernelGGL(k_dogleg<true>, dim3(d.B), dim3(256), lds_dg > lds_sc ? lds_dg : lds_sc, st, d); counts[5] = 1; }
-        else hipLaunchKernelGGL(k_dogleg<false>, dim3(d.B), dim3(256), lds_dg, st, d);
+        if (fuse_control) {
+            if (d.est_ex) hipLaunchKernelGGL((k_dogleg<true, true>), dim3(d.B), dim3(256), lds_dg > lds_sc ? lds_dg : lds_sc, st, d);
+            else hipLaunchKernelGGL((k_dogleg<true, false>), dim3(d.B), dim3(256), lds_dg > lds_sc ? lds_dg : lds_sc, st, d);
+            counts[5] = 1;
+        } else if (d.est_ex) hipLaunchKernelGGL((k_dogleg<false, true>), dim3(d.B), dim3(256), lds_dg, st, d);
+        else hipLaunchKernelGGL((k_dogleg<false, false>), dim3(d.B), dim3(256), lds_dg, st, d);
         PROF(slot, 4, 1);
         if (!d.lds_T) {                    // (the LDS path evaluates these inside k_dogleg)
             HCHK(hipEventRecord(fj[2], st)); HCHK(hipStreamWaitEvent(st2, fj[2], 0));
@@ -697,11 +719,14 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
         // so large that one workgroup per window would serialise it (config 5: 30 000 factors in one window)
         PROF(slot, 5, 0);
         if (fuse_control) {
-        } else if (d.lds_T && (size_t)d.Ftot <= (size_t)4096 * d.B) hipLaunchKernelGGL(k_step_control<true>, dim3(d.B), dim3(256), lds_sc, st, d);
+        } else if (control_in_wg) {
+            if (d.est_ex) hipLaunchKernelGGL((k_step_control<true, true>), dim3(d.B), dim3(256), lds_sc, st, d);
+            else hipLaunchKernelGGL((k_step_control<true, false>), dim3(d.B), dim3(256), lds_sc, st, d);
+        }
         else {
             if (d.n_tiles > 0) hipLaunchKernelGGL(k_proj_linearize<1>, dim3((d.n_tiles + 3) / 4), dim3(256), lds_proj1, st, d, d.cpose, d.clam, d.fcost_c, 2);
             if (!d.lds_T) HCHK(hipStreamWaitEvent(st, fj[3], 0));
-            hipLaunchKernelGGL(k_step_control<false>, dim3(d.B), dim3(256), 0, st, d);
+            hipLaunchKernelGGL((k_step_control<false, false>), dim3(d.B), dim3(256), 0, st, d);
         }
         PROF(slot, 5, 1);
     }

@@ -141,7 +141,7 @@ typedef double double4v __attribute__((ext_vector_type(4)));
 // R1_CHUNK / MINW: pass size and minimum waves per SIMD.  Variants with fewer, fatter wavefronts and four workgroups per
 // CU (<5, 4, 32, 4>, <5, 2, 32, 8>: a 1024-window launch in one round) measured 138 / 143 us against 96-100 us for one
 // wavefront per tile: the per-workgroup MFMA chain gets longer than the round it saves.
-template <int NT, int TPW, int R1_CHUNK, int MINW>
+template <int NT, int TPW, int R1_CHUNK, int MINW, bool EX>
 __global__ __launch_bounds__(64 * ((NT * (NT + 1) / 2 + TPW - 1) / TPW), MINW) void k_rank1_mfma(DevBatch d) {
     constexpr int ntiles = NT * (NT + 1) / 2, nwaves = (ntiles + TPW - 1) / TPW;
     constexpr int ld = 16 * NT, nthr = 64 * nwaves;
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(64 * ((NT * (NT + 1) / 2 + TPW - 1) / TPW), MINW) v
                 ((double2 *)(d.W + (size_t)(d.lm_f0[gl] + gl) * 6))[part - 1] = acc;     // host observation slot
             }
         }
-        if (d.est_ex) {                                    // the extrinsic's w of every landmark: sum over its factors of J_ex^T J_l
+        if (EX) {                                    // the extrinsic's w of every landmark: sum over its factors of J_ex^T J_l
             for (int q = t; q < 3 * Lw; q += nthr) {
                 const int l = q / 3, part = q - 3 * l, gl = l0 + l, kf = d.lm_k[gl] - 1;
                 const double2 *fx = (const double2 *)(d.flmx + (size_t)d.lm_f0[gl] * 6) + part;
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(64 * ((NT * (NT + 1) / 2 + TPW - 1) / TPW), MINW) v
                 const int h6 = 6 * (int)(m0 & 255), k6 = 6 * (int)((m0 >> 8) & 255);
                 if (c >= h6 && c < h6 + k6) v = d.W[(size_t)(fw0 + (int)(m0 >> 16) + l0 + l) * 6 + (c - h6)];
                 else if (c == n6) v = sCG[l].y;
-                else if (d.est_ex && c >= 6 * d.Nr && c < n6) v = d.Wex[(size_t)(l0 + l) * 6 + (c - 6 * d.Nr)];     // pseudo-frame columns = the extrinsic block
+                else if (EX && c >= 6 * d.Nr && c < n6) v = d.Wex[(size_t)(l0 + l) * 6 + (c - 6 * d.Nr)];     // pseudo-frame columns = the extrinsic block
             }
             pf[u2] = v;
         }
@@ -262,12 +262,20 @@ __global__ __launch_bounds__(64 * ((NT * (NT + 1) / 2 + TPW - 1) / TPW), MINW) v
         }
     }
 }
-template __global__ void k_rank1_mfma<1, 1, 64, 1>(DevBatch);
-template __global__ void k_rank1_mfma<2, 1, 64, 1>(DevBatch);
-template __global__ void k_rank1_mfma<3, 1, 64, 1>(DevBatch);
-template __global__ void k_rank1_mfma<4, 1, 64, 1>(DevBatch);
-template __global__ void k_rank1_mfma<5, 1, 64, 1>(DevBatch);
-template __global__ void k_rank1_mfma<6, 2, 64, 1>(DevBatch);
-template __global__ void k_rank1_mfma<7, 2, 64, 1>(DevBatch);
-template __global__ void k_rank1_mfma<8, 3, 64, 1>(DevBatch);
+template __global__ void k_rank1_mfma<1, 1, 64, 1, false>(DevBatch);
+template __global__ void k_rank1_mfma<1, 1, 64, 1, true>(DevBatch);
+template __global__ void k_rank1_mfma<2, 1, 64, 1, false>(DevBatch);
+template __global__ void k_rank1_mfma<2, 1, 64, 1, true>(DevBatch);
+template __global__ void k_rank1_mfma<3, 1, 64, 1, false>(DevBatch);
+template __global__ void k_rank1_mfma<3, 1, 64, 1, true>(DevBatch);
+template __global__ void k_rank1_mfma<4, 1, 64, 1, false>(DevBatch);
+template __global__ void k_rank1_mfma<4, 1, 64, 1, true>(DevBatch);
+template __global__ void k_rank1_mfma<5, 1, 64, 1, false>(DevBatch);
+template __global__ void k_rank1_mfma<5, 1, 64, 1, true>(DevBatch);
+template __global__ void k_rank1_mfma<6, 2, 64, 1, false>(DevBatch);
+template __global__ void k_rank1_mfma<6, 2, 64, 1, true>(DevBatch);
+template __global__ void k_rank1_mfma<7, 2, 64, 1, false>(DevBatch);
+template __global__ void k_rank1_mfma<7, 2, 64, 1, true>(DevBatch);
+template __global__ void k_rank1_mfma<8, 3, 64, 1, false>(DevBatch);
+template __global__ void k_rank1_mfma<8, 3, 64, 1, true>(DevBatch);
 

@@ -97,6 +97,42 @@ def test_batch_of_more_than_256_long_windows(oracle):
         big.close(); small.close()
 
 
+@pytest.mark.parametrize("env", [{"ISV_LEGACY_VISUAL": "1"}, {"ISV_SPLIT_CONTROL": "1"},
+                                 {"ISV_LEGACY_VISUAL": "1", "ISV_SPLIT_CONTROL": "1"}])
+def test_unfused_kernel_variants_against_oracle_and_fused(oracle, monkeypatch, env):
+    """the round-1 kernels the library still ships (k_proj_linearize<0> + k_sweep_mfma instead of k_lin_gram, k_dogleg<false> +
+    k_step_control instead of k_dogleg<true>; selected by environment for A/B measurements, and what N > 20 handles use):
+    against the oracle, and against the fused kernels on the same windows (cost trace and states to rounding: the landmark
+    sums are formed in a different association, so not bitwise)."""
+    ws = synth.make_windows([90, 91, 92], n_frames=11, n_vo=5, n_landmarks=150)
+    cap = dict(max_landmarks=150, max_obs=max(w.n_obs for w in ws), max_batch=3)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    bu = backend.Backend(11, 5, **cap)
+    try:
+        g_unf, s_unf, _ = _solve_pair(oracle, bu, ws)
+        cnt = bu.last_counts()
+        assert cnt[4] == (0 if "ISV_LEGACY_VISUAL" in env else 1)
+        assert cnt[5] == (0 if "ISV_SPLIT_CONTROL" in env else 1)
+    finally:
+        bu.close()
+    for k in env:
+        monkeypatch.delenv(k)
+    bf = backend.Backend(11, 5, **cap)
+    try:
+        g_fus = [w.clone() for w in ws]
+        s_fus, _ = bf.optimize_batch(g_fus)
+        assert tuple(bf.last_counts()[4:6]) == (1, 1)
+        for a, c, sa, sc in zip(g_unf, g_fus, s_unf, s_fus):
+            assert sa.iterations == sc.iterations and sa.termination == sc.termination
+            if "ISV_LEGACY_VISUAL" in env:
+                assert np.allclose(a.state_vector(), c.state_vector(), rtol=0, atol=1e-8)
+            else:       # the step control is the same arithmetic in either kernel: the library switches by batch size
+                assert np.array_equal(a.state_vector(), c.state_vector())
+    finally:
+        bf.close()
+
+
 # ---- double2vector near pitch +-90 deg ------------------------------------------------------------------------------
 def _pitch_deg(R):
     """Utility::R2ypr (include/utility/utility.h:66-81), pitch in degrees"""
