@@ -38,6 +38,10 @@ __host__ __device__ inline int sb_nred(int N, int prior_H_sz) {   // doubles in 
     if (30 * N > m) m = 30 * N;
     return (m + 1) & ~1;
 }
+// a fresh, opaque copy of the thread id per phase: index arithmetic is then recomputed where it is used instead of being
+// shared across phases by CSE -- the shared values live through the whole kernel and spill under the 128-VGPR cap, and
+// every reload is a scratch (global memory) round trip on the serial path
+#define PHASE_IDS() int t = t_outer; asm volatile("" : "+v"(t)); const int lane = t & 63; (void)lane
 #define RCH 32                     // landmarks per staged chunk of the retry correction
 
 DEV int sblk(int I, int J, int N) { return (J * N - J * (J - 1) / 2 + (I - J)) * 36; }   // I >= J
@@ -99,13 +103,16 @@ DEV bool chol_inv_block(double *A, int lane) {
 //               substitution with all nodes of a chain in one register;
 // BIG = true:  N <= 20 (one workgroup per CU: the system needs up to ~160 KB of LDS), plain loops instead of the
 //               fixed-size register stages.
-template <bool BIG>
+// NC: the window length as a compile-time constant (0 = read d.N): the LDS layout, every loop bound and the index
+//     divisions fold, which is worth registers and integer work in every phase; instantiated for the benchmark's 11 and the
+//     reference's 18 frames.
+template <bool BIG, int NC>
 __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) {
     extern __shared__ __align__(16) double lds[];
     const int w = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
     SolveState &st = d.st[w];
     if (st.termination != ISV_TERM_RUNNING || !st.need_linearize) return;
-    const int N = d.N, n = 15 * N, M = N / 2, n6 = 6 * N, nS = N * (N + 1) / 2 * 36;
+    const int N = NC ? NC : d.N, n = 15 * N, M = N / 2, n6 = 6 * N, nS = N * (N + 1) / 2 * 36;
     double *p = lds;
     double *g = p; p += n;
     double *bs = p; p += n;
@@ -255,12 +262,6 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
                 if (I < M) Css[I * 81 + r * 9 + c] = v; else Css[(I + 1) * 81 + c * 9 + r] = v;
             }
         };
-        if (!BIG) {
-#pragma unroll
-            for (int k = 0; k < 3; k++) { const int e = t + k * LS; vF[k] = e < N * 120 ? imu_frame_fetch(e) : 0.0; }
-#pragma unroll
-            for (int k = 0; k < 5; k++) { const int e = t + k * LS; vX[k] = e < (N - 1) * 225 ? imu_pair_fetch(e) : 0.0; }
-        }
         if (t < n) {
             const int I = t / 15, r = t - 15 * I;
             if (I >= 1 && !skipL[I - 1]) vG += H[(size_t)(I - 1) * ISV_IMU_H + 465 + 15 + r];
@@ -272,6 +273,12 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
         else {
 #pragma unroll
             for (int k = 0; k < 5; k++) { const int e = t + k * LS; if (e < nS) Spp[e] = vS[k]; }
+            // second register stage (after the first was stored: both at once cost spills under the 128-VGPR cap of two
+            // workgroups per CU): the IMU blocks, in flight across the barrier and the zeroing below
+#pragma unroll
+            for (int k = 0; k < 3; k++) { const int e = t + k * LS; vF[k] = e < N * 120 ? imu_frame_fetch(e) : 0.0; }
+#pragma unroll
+            for (int k = 0; k < 5; k++) { const int e = t + k * LS; vX[k] = e < (N - 1) * 225 ? imu_pair_fetch(e) : 0.0; }
         }
         __syncthreads();
         if (t < n6) {
@@ -381,6 +388,7 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
         }
         STAMP(2);
         // ---- Jacobi scaling, LM diagonal, Cauchy data -------------------------------------------------
+        { PHASE_IDS();
         for (int e = t; e < n; e += LS) {
             double s;
             if (iteration == 0) { s = 1.0 / (1.0 + sqrt(hdiag[e])); d.scale_p[(size_t)w * n + e] = s; }
@@ -394,7 +402,9 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
             y[e] = s * (g[e] + bs[e]);
         }
         __syncthreads();
+        }
         {   // qT = u^T T u on the unscaled blocks, then scale in place and add the LM diagonal
+            PHASE_IDS();
             double accq = 0;
             for (int e = t; e < nS; e += LS) {
                 int I, J, r, c;
@@ -448,6 +458,7 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
         // node i: (1) D_i -> inverse Cholesky factor; (2) rows of [C_i ; Y_i] times L_i^-T;
         //         (3) downdate the parent's diagonal block and pose coupling (not for children of M here:
         //             both chains end in M, those two downdates are applied after the join).
+        { PHASE_IDS();
         auto node_rows = [&](int i, bool has_par) {            // step (2), executed by one wavefront
             // the right-hand side rides along as one more row: z_i^T = y_i^T L_i^-T (forward substitution)
             const int nr = nhi(i, M, N) - nlo(i, M) + 1, nrows = (has_par ? 9 : 0) + 6 * nr + 1;
@@ -517,9 +528,11 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
             }
             __syncthreads();
         }
+        }
         STAMP(4);
         if (!flag[0]) {
             // ---- pose system: Spp -= sum_i Y_i Y_i^T ---------------------------------------------------
+            { PHASE_IDS();
             for (int e = t; e < nS; e += LS) {
                 int I, J, r, c;
                 spp_decode(e, I, J, r, c);
@@ -548,9 +561,11 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
                 }
                 y[15 * a + r] -= s;
             }
+            }
             __syncthreads();
             STAMP(5);
             // ---- blocked Cholesky of the pose system (6x6 blocks; diagonal blocks hold L_JJ^-1 afterwards)
+            { PHASE_IDS();
             for (int J = 0; J < N; J++) {
                 if (wv == 0 && chol_inv_block<6>(Spp + sblk(J, J, N), lane)) { if (lane == 0) flag[0] = 1; }
                 __syncthreads();
@@ -600,6 +615,7 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
                 }
                 __syncthreads();
             }
+            }
         }
         __syncthreads();
         STAMP(6);
@@ -615,6 +631,7 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
         // + r), yp1 frames 10.. ; pivot vectors travel by v_readlane, every lane forms its own row's dot
         // product: the N dependent steps need no LDS round trip and no barrier.
         if (wv == 0) {
+            PHASE_IDS();
             const int q6 = lane / 6, c6 = lane - 6 * q6;
             const int fA = q6, fB = 10 + q6;                    // my frame in yp0 / yp1
             const bool hasPA = q6 < 10 && fA < N, hasPB = q6 < 10 && fB < N;
@@ -647,6 +664,7 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
         }
         __syncthreads();
         // chain rhs -= Y_i^T x_pose: thread = (speed/bias row, quarter of the pose blocks), folded in fixed order
+        { PHASE_IDS();
         for (int tq = t; tq < 36 * N; tq += LS) {
             const int o = tq >> 2, part = tq & 3, i = o / 9, c = o - 9 * i, lo = nlo(i, M), nr = nhi(i, M, N) - lo + 1;
             const double *Yc = Ysb + yo[i] + c;
@@ -662,6 +680,7 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
         if (t < 9 * N) {
             const int i = t / 9, c = t - 9 * i;
             y[15 * i + 6 + c] -= (red[4 * t] + red[4 * t + 1]) + (red[4 * t + 2] + red[4 * t + 3]);
+        }
         }
         __syncthreads();
         // chains, reverse elimination order: x_i = L_i^-T (z_i - C_i^T x_parent); wavefront 0 takes M and the
@@ -688,6 +707,7 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
             else if (wv == 1) { for (int i = M + 1; i <= N - 1; i++) node_bwd_lds(i, i - 1); }
         } else {
         if (wv < 2) {
+            PHASE_IDS();
             const int q9 = lane / 9, c9 = lane - 9 * q9;
             const int mynode = wv == 0 ? q9 : M + 1 + q9;
             const bool has = q9 < 7 && (wv == 0 ? mynode <= M : mynode <= N - 1);
@@ -724,6 +744,7 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
         __syncthreads();
         if (wv < 2) {
             // (re-declared: the block barrier above must be reached by every wavefront)
+            PHASE_IDS();
             const int q9 = lane / 9, c9 = lane - 9 * q9;
             const int mynode = wv == 0 ? q9 : M + 1 + q9;
             const bool has = q9 < 7 && (wv == 0 ? mynode <= M : mynode <= N - 1);
@@ -807,8 +828,10 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
     STAMP(8);
 }
 
-template __global__ void k_build_solve_sb<false>(DevBatch);
-template __global__ void k_build_solve_sb<true>(DevBatch);
+template __global__ void k_build_solve_sb<false, 0>(DevBatch);
+template __global__ void k_build_solve_sb<false, 11>(DevBatch);
+template __global__ void k_build_solve_sb<true, 0>(DevBatch);
+template __global__ void k_build_solve_sb<true, 18>(DevBatch);
 
 size_t build_solve_sb_bytes(int N, int prior_H_sz) {
     const int M = N / 2;
