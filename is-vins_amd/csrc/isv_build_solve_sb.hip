@@ -507,16 +507,101 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
                 }
             }
         };
-        if (wv < 2) {
-            const int cnt = wv == 0 ? M : N - 1 - M;
-            for (int k = 0; k < cnt; k++) {
-                const int i = wv == 0 ? k : N - 1 - k;
-                if (chol_inv_block<9>(Dss + i * 81, lane)) { if (lane == 0) flag[0] = 1; break; }
-                node_rows(i, true);
-                if (npar(i, M) != M) { node_downdate(i, lane, 64); WSYNC(); }
+        // Software pipeline over the chain nodes, one block barrier per node.  What the NEXT node's factorisation waits for is
+        // small -- C_i L_i^-T (9 rows), z_i, the 45 + 9 entries of the parent's diagonal block and right-hand side -- and stays
+        // on wavefronts 0 (forward chain) / 1 (backward chain).  The bulk, Y_i L_i^-T and the parent's pose coupling
+        // Y_p -= Y_i C_i^T, follows one node behind on wavefronts 2 / 3, a lane per row of Y_i (the transformed row stays in
+        // registers for its own downdate).  Entry for entry the same sums as node_rows / node_downdate.
+        auto crit_rows = [&](int i) {                          // C_i and z_i
+            const double *Li = Dss + i * 81;
+            if (lane < 10) {
+                double *ptr = lane < 9 ? Css + i * 81 + lane * 9 : y + 15 * i + 6;
+                double v[9], o[9];
+#pragma unroll
+                for (int k = 0; k < 9; k++) v[k] = ptr[k];
+#pragma unroll
+                for (int c = 0; c < 9; c++) {
+                    double s = 0;
+#pragma unroll
+                    for (int k = 0; k <= c; k++) s += v[k] * Li[c * 9 + k];
+                    o[c] = s;
+                }
+#pragma unroll
+                for (int k = 0; k < 9; k++) ptr[k] = o[k];
+            }
+            WSYNC();
+        };
+        auto crit_downdate = [&](int i) {                      // D_p -= C_i C_i^T, y_p -= C_i z_i
+            const int pp = npar(i, M);
+            const double *C = Css + i * 81;
+            if (lane < 45) {
+                const int r = triAB[2 * lane], c = triAB[2 * lane + 1];
+                double s = 0;
+#pragma unroll
+                for (int k = 0; k < 9; k++) s += C[r * 9 + k] * C[c * 9 + k];
+                Dss[pp * 81 + r * 9 + c] -= s;
+            } else if (lane < 54) {
+                const int r = lane - 45;
+                double s = 0;
+#pragma unroll
+                for (int k = 0; k < 9; k++) s += C[r * 9 + k] * y[15 * i + 6 + k];
+                y[15 * pp + 6 + r] -= s;
+            }
+            WSYNC();
+        };
+        auto y_rows = [&](int i, bool downdate) {              // Y_i L_i^-T, then Y_p -= Y_i C_i^T (C_i already transformed)
+            const int pp = npar(i, M), lo = nlo(i, M), nr = nhi(i, M, N) - lo + 1;
+            const double *Li = Dss + i * 81, *C = Css + i * 81;
+            for (int rho = lane; rho < 6 * nr; rho += 64) {
+                double *ptr = Ysb + yo[i] + rho * 9;
+                double v[9], o[9];
+#pragma unroll
+                for (int k = 0; k < 9; k++) v[k] = ptr[k];
+#pragma unroll
+                for (int c = 0; c < 9; c++) {
+                    double s = 0;
+#pragma unroll
+                    for (int k = 0; k <= c; k++) s += v[k] * Li[c * 9 + k];
+                    o[c] = s;
+                }
+#pragma unroll
+                for (int k = 0; k < 9; k++) ptr[k] = o[k];
+                if (downdate) {
+                    double *Yp = Ysb + yo[pp] + (lo - nlo(pp, M)) * 54 + rho * 9;
+#pragma unroll
+                    for (int c = 0; c < 9; c++) {
+                        double s = 0;
+#pragma unroll
+                        for (int k = 0; k < 9; k++) s += o[k] * C[c * 9 + k];
+                        Yp[c] -= s;
+                    }
+                }
+            }
+        };
+        {
+            const int cntF = M, cntB = N - 1 - M, steps = (cntF > cntB ? cntF : cntB) + 1;
+            for (int k = 0; k < steps; k++) {
+                if (wv < 2) {
+                    const int cnt = wv == 0 ? cntF : cntB;
+                    if (k < cnt) {
+                        const int i = wv == 0 ? k : N - 1 - k;
+                        if (chol_inv_block<9>(Dss + i * 81, lane)) { if (lane == 0) flag[0] = 1; }
+                        else {
+                            crit_rows(i);
+                            if (npar(i, M) != M) crit_downdate(i);
+                        }
+                    }
+                } else if (wv < 4) {
+                    const int cnt = wv == 2 ? cntF : cntB, kk = k - 1;
+                    if (kk >= 0 && kk < cnt) {
+                        const int i = wv == 2 ? kk : N - 1 - kk;
+                        y_rows(i, npar(i, M) != M);
+                    }
+                }
+                __syncthreads();
+                if (flag[0]) break;
             }
         }
-        __syncthreads();
         if (!flag[0]) {
             if (M >= 1) node_downdate(M - 1, t, LS);
             __syncthreads();
@@ -565,10 +650,13 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
             __syncthreads();
             STAMP(5);
             // ---- blocked Cholesky of the pose system (6x6 blocks; diagonal blocks hold L_JJ^-1 afterwards)
+            // Look-ahead: while wavefronts 1..7 apply the trailing update of step J, wavefront 0 updates the NEXT diagonal block
+            // first and factors it, so the factorisation's dependent pivots and one barrier per step leave the critical path.
+            // Entry for entry the same sums as a plain right-looking sweep.
             { PHASE_IDS();
+            if (wv == 0 && chol_inv_block<6>(Spp + sblk(0, 0, N), lane)) { if (lane == 0) flag[0] = 1; }
+            __syncthreads();
             for (int J = 0; J < N; J++) {
-                if (wv == 0 && chol_inv_block<6>(Spp + sblk(J, J, N), lane)) { if (lane == 0) flag[0] = 1; }
-                __syncthreads();
                 if (flag[0]) break;
                 const int m = N - J - 1;
                 const double *Li = Spp + sblk(J, J, N);
@@ -592,7 +680,7 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
                 // trailing update: S[I,K] -= X_I X_K^T for I >= K > J (packed columns J+1.. are contiguous)
                 const int e0 = sblk(J + 1, J + 1, N), cntT = m * (m + 1) / 2 * 36;
                 const double *X = Spp + sblk(J + 1, J, N);       // X_I at (I - J - 1) * 36
-                for (int e = t; e < cntT + m * 6; e += LS) {
+                auto trailing_entry = [&](int e) {
                     if (e >= cntT) {                             // rhs rows: y_I -= X_I z_J
                         const int rr = e - cntT;
                         const double *XI = X + rr * 6;
@@ -600,18 +688,25 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
 #pragma unroll
                         for (int k = 0; k < 6; k++) s += XI[k] * y[15 * J + k];
                         y[15 * (J + 1 + rr / 6) + rr % 6] -= s;
-                        continue;
+                        return;
                     }
                     const int q = e / 36, rc = e - 36 * q, r = rc / 6, c = rc - 6 * r;
                     // (the trailing triangle is the tail of the packed storage: absolute block = first trailing block + q)
                     const int ij = blkIJ[e0 / 36 + q];
                     const int ia = (ij & 255) - (J + 1), ca = (ij >> 8) - (J + 1);
-                    if (ia == ca && r < c) continue;
+                    if (ia == ca && r < c) return;
                     const double *XI = X + ia * 36 + r * 6, *XK = X + ca * 36 + c * 6;
                     double s = 0;
 #pragma unroll
                     for (int k = 0; k < 6; k++) s += XI[k] * XK[k];
                     Spp[e0 + e] -= s;
+                };
+                if (wv == 0) {
+                    if (lane < 36) trailing_entry(lane);         // block (J+1, J+1) is the first of the trailing storage
+                    WSYNC();
+                    if (chol_inv_block<6>(Spp + e0, lane)) { if (lane == 0) flag[0] = 1; }
+                } else {
+                    for (int e = 36 + (t - 64); e < cntT + m * 6; e += LS - 64) trailing_entry(e);
                 }
                 __syncthreads();
             }
@@ -831,7 +926,6 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
 template __global__ void k_build_solve_sb<false, 0>(DevBatch);
 template __global__ void k_build_solve_sb<false, 11>(DevBatch);
 template __global__ void k_build_solve_sb<true, 0>(DevBatch);
-template __global__ void k_build_solve_sb<true, 18>(DevBatch);
 
 size_t build_solve_sb_bytes(int N, int prior_H_sz) {
     const int M = N / 2;

@@ -135,7 +135,7 @@ DEV void prior_linearize_body(const DevBatch &d, const double *pose_src, const d
     double *PH = d.prior_H + (size_t)w * d.prior_H_sz;
     const double *poseW = pose_src + (size_t)w * N * 7;
     // stage every sqrt_info
-    for (int s = 0; s < slots; s++) {
+    if (JAC) for (int s = 0; s < slots; s++) {
         const PriorDesc p = prior_desc(d, w, s, n_rp);
         const int n = p.kind == 1 ? 81 : (p.kind == 3 ? 4 : 36);
         if (p.valid) for (int e = t; e < n; e += 64) sS[s * PRL_S + e] = p.S[e];
@@ -231,6 +231,36 @@ DEV void prior_linearize_body(const DevBatch &d, const double *pose_src, const d
         }
     }
     if (WAVE) ISV_WSYNC(); else __syncthreads();
+    if (!JAC) {
+        // residual-only evaluation (the candidate point): phases 2 and 3 for ALL priors of the window at once instead of slot
+        // after slot -- lane per (prior, row) forms r = sqrt_info raw straight from the factor records, lane per prior the cost.
+        // Same operation order per entry as prior_weight / prior_correct, so the candidate cost is the same function of the
+        // state, bit for bit, as the cost at x the step control compares it with.
+        for (int e = t; e < slots * 9; e += 64) {
+            const int s = e / 9, row = e - 9 * s;
+            const PriorDesc p = prior_desc(d, w, s, n_rp);
+            const int dim = p.kind == 1 ? 9 : (p.kind == 3 ? 2 : 6);
+            if (!p.valid || row >= dim) continue;
+            const double *raw = sRaw + s * RAWS;
+            double v = 0;
+            for (int k = 0; k < dim; k++) v += p.S[row * dim + k] * raw[k];
+            sW[s * WS + row] = v;
+        }
+        if (WAVE) ISV_WSYNC(); else __syncthreads();
+        for (int s = t; s < slots; s += 64) {
+            const PriorDesc p = prior_desc(d, w, s, n_rp);
+            const int dim = p.kind == 1 ? 9 : (p.kind == 3 ? 2 : 6);
+            double cost = 0.0;
+            if (p.valid) {
+                const double *wr = sW + s * WS;
+                double ssum = 0;
+                for (int k = 0; k < dim; k++) ssum += wr[k] * wr[k];
+                cost = 0.5 * log(1.0 + ssum);
+            }
+            cost_out[(size_t)w * slots + s] = cost;
+        }
+        return;
+    }
     // ---- phase 2: sqrt_info * [raw r | raw J] ----
     for (int s = 0; s < slots; s++) {
         const PriorDesc p = prior_desc(d, w, s, n_rp);

@@ -616,8 +616,9 @@ int isv_solver_alloc(DevBatch &d, size_t B, size_t L, size_t F, std::vector<void
         SETLDS((k_rank1_mfma<7, 2, 64, 1, false>), lds_r1); SETLDS((k_rank1_mfma<7, 2, 64, 1, true>), lds_r1); SETLDS((k_rank1_mfma<8, 3, 64, 1, false>), lds_r1); SETLDS((k_rank1_mfma<8, 3, 64, 1, true>), lds_r1);
         SETLDS(k_sweep_mfma, lds_sw);
         SETLDS(k_lin_gram<false>, lin_gram_lds_bytes(d.Nr, true, false)); SETLDS(k_lin_gram<true>, lin_gram_lds_bytes(d.Nr, true, true));
-        if (d.N == 11) SETLDS((k_build_solve_sb<false, 11>), lds_sb); else if (d.N < 11) SETLDS((k_build_solve_sb<false, 0>), lds_sb);
-        else if (d.N == 18) SETLDS((k_build_solve_sb<true, 18>), lds_sb); else SETLDS((k_build_solve_sb<true, 0>), lds_sb);
+        if (d.N == 11) SETLDS((k_build_solve_sb<false, 11>), lds_sb);
+        if (d.N <= 11) SETLDS((k_build_solve_sb<false, 0>), lds_sb);
+        if (d.N > 11) SETLDS((k_build_solve_sb<true, 0>), lds_sb);
 #undef SETLDS
     }
     else {
@@ -696,10 +697,13 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
         HCHK(hipStreamWaitEvent(st, fj[1], 0));
         if (!d.lds_T) hipLaunchKernelGGL(k_cost_reduce, dim3(d.B), dim3(256), 0, st, d, d.fcost, d.imu_cost, d.prior_cost, d.cost, 1);   // (k_build_solve_sb sums the cost itself)
         PROF(slot, 3, 0);
-        // (the window length as a compile-time constant for the benchmark's 11 and the reference's 18 frames: isv_build_solve_sb.hip)
-        if (d.lds_T && d.N == 11) hipLaunchKernelGGL((k_build_solve_sb<false, 11>), dim3(d.B), dim3(512), build_solve_sb_bytes(d.N, d.prior_H_sz), st, d);
+        // (the window length as a compile-time constant for the benchmark's 11 frames: isv_build_solve_sb.hip)
+        const bool generic_n = getenv("ISV_GENERIC_N") != nullptr;             // (A/B / test hook: the run-time-N instantiations for every N)
+        if (d.lds_T && generic_n) {
+            if (d.N <= 11) hipLaunchKernelGGL((k_build_solve_sb<false, 0>), dim3(d.B), dim3(512), build_solve_sb_bytes(d.N, d.prior_H_sz), st, d);
+            else hipLaunchKernelGGL((k_build_solve_sb<true, 0>), dim3(d.B), dim3(512), build_solve_sb_bytes(d.N, d.prior_H_sz), st, d);
+        } else if (d.lds_T && d.N == 11) hipLaunchKernelGGL((k_build_solve_sb<false, 11>), dim3(d.B), dim3(512), build_solve_sb_bytes(d.N, d.prior_H_sz), st, d);
         else if (d.lds_T && d.N < 11) hipLaunchKernelGGL((k_build_solve_sb<false, 0>), dim3(d.B), dim3(512), build_solve_sb_bytes(d.N, d.prior_H_sz), st, d);
-        else if (d.lds_T && d.N == 18) hipLaunchKernelGGL((k_build_solve_sb<true, 18>), dim3(d.B), dim3(512), build_solve_sb_bytes(d.N, d.prior_H_sz), st, d);
         else if (d.lds_T) hipLaunchKernelGGL((k_build_solve_sb<true, 0>), dim3(d.B), dim3(512), build_solve_sb_bytes(d.N, d.prior_H_sz), st, d);
         else hipLaunchKernelGGL(k_build_solve<false>, dim3(d.B), dim3(512), lds_bs, st, d);
         counts[1]++;
