@@ -18,7 +18,11 @@
 // This is latency-bound sparse work (dependent 6x6 block recurrences through L2); it is not reshaped into dense GEMMs.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <cstdlib>
+#include <functional>
+#include <thread>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -28,6 +32,11 @@
 #include "isv_prior_factor.h"
 
 #define PG_WSYNC() ISV_WSYNC()
+// LDS-only ordering inside the wavefront (the 6x6 tiles T0 / T1 / T2): the LDS executes one wavefront's accesses in issue order,
+// so all that is needed is that the compiler neither reorders them nor keeps tile values in registers.  Unlike a release
+// fence this does NOT wait for outstanding global loads and stores (vmcnt): with PG_WSYNC every step of the factorisation
+// paid the latency of its own L-block store and of the next row's prefetch.
+#define PG_LSYNC() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
 // make this wavefront's global stores visible to its own later loads (other lanes read what a lane wrote)
 #define PG_GSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
 
@@ -59,6 +68,7 @@ struct PgDev {
     double *scale, *diag, *grad, *step, *ysol;   // [6 nf] each
     double *cov;                 // [poses][36] tangent-space marginal covariance (zero for constant poses)
     isv_pgo_result_t *res;
+    int32_t idx_lds_rows, idx_lds_cols;   // capacity of the LDS copies of start / rowptr / colptr and of colrows (0: read them from global memory)
 };
 
 // ---- 6x6 helpers: lane e < 36 owns element (a, b) = (e / 6, e % 6) -------------------------------------------------
@@ -67,6 +77,12 @@ DEV double readlane_d(double v, int lane) {
     u.i[0] = __builtin_amdgcn_readlane(u.i[0], lane);
     u.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
     return u.d;
+}
+DEV double pg_rsqrt(double x) {                       // 1/sqrt(x) to ~1 ulp: hardware estimate + two Newton steps (no f64 sqrt / divide sequences on the serial path)
+    double r = __builtin_amdgcn_rsq(x);
+    r = r * (1.5 - 0.5 * x * r * r);
+    r = r * (1.5 - 0.5 * x * r * r);
+    return r;
 }
 // D (6x6 SPD, row-major in LDS tile T, lower part valid) -> T = inverse of its Cholesky factor (lower); returns false if not SPD
 DEV bool pg_chol_inv6(double *T, int lane) {
@@ -81,7 +97,7 @@ DEV bool pg_chol_inv6(double *T, int lane) {
         for (int k = 0; k < j; k++) s -= row[k] * readlane_d(row[k], j);
         const double sj = readlane_d(s, j);
         if (!(sj > 0.0)) bad = true;
-        dinv[j] = 1.0 / sqrt(sj);
+        dinv[j] = pg_rsqrt(sj);
         row[j] = (lane == j) ? sj * dinv[j] : s * dinv[j];
     }
 #pragma unroll
@@ -91,12 +107,12 @@ DEV bool pg_chol_inv6(double *T, int lane) {
         for (int k = 0; k < i; k++) s -= readlane_d(row[k], i) * x[k];
         x[i] = s * dinv[i];
     }
-    PG_WSYNC();
+    PG_LSYNC();
     if (lane < 6) {
 #pragma unroll
         for (int k = 0; k < 6; k++) T[k * 6 + lane] = x[k];      // x[k] = Linv[k][lane], zero for k < lane
     }
-    PG_WSYNC();
+    PG_LSYNC();
     return !bad;
 }
 // deterministic wave sum (fixed butterfly)
@@ -113,10 +129,22 @@ DEV double wave_max(double v) {
 
 // RelativePoseFactor::Evaluate (include/factor/relative_pose_factor.h:27-70) / RollPitchFactor::Evaluate
 // (rollpitch_factor.h:26-57) of one residual block at `pose`, HuberLoss corrector applied; returns rho(s) / 2
-DEV double pg_edge_eval(const PgEdge &E, const double *pose, double huber, double *r_out, double *Ja, double *Jb, bool jac) {
-    double raw[6], rJa[36], rJb[36];
+// Every global input is read into registers before the first store and the outputs are stored at the very end: the
+// compiler must keep loads behind earlier stores that may alias them, and a store -> dependent load round trip per matrix
+// entry is what the first version of this kernel spent most of its time on.
+DEV double pg_edge_eval(const PgEdge &E, const double *pose, double huber, double *__restrict__ r_out, double *__restrict__ Ja, double *__restrict__ Jb, bool jac) {
+    double raw[6], rJa[36], rJb[36], Sq[36];
     const double *pa = pose + 7 * E.a, *pb = pose + 7 * E.b;
-    if (E.kind == 0) {
+    const int dim = E.dim, kind = E.kind, robust = E.robust;
+    // (fixed 6 x 6 shapes, zero-padded for the 2-row roll/pitch factor: constant loop bounds keep the arrays in registers,
+    //  and the padding adds exact zeros to the sums)
+#pragma unroll
+    for (int a = 0; a < 6; a++)
+#pragma unroll
+        for (int k = 0; k < 6; k++) Sq[a * 6 + k] = (a < dim && k < dim) ? E.sqrt_info[a * dim + k] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) raw[k] = 0.0;
+    if (kind == 0) {
         Quat Rq = q_normalized(q_from_pose(pa)), Rm = q_from_R(E.meas_R);
         double nZ[3] = {0, 0, -1.0}, v[3];
         q_rot(so3_mul(Rm, q_conj(Rq)), nZ, v);
@@ -124,30 +152,57 @@ DEV double pg_edge_eval(const PgEdge &E, const double *pose, double huber, doubl
         if (jac) {
             double S[9], Rmm[9], Bm[9];
             skew3(v, S); q_to_R(Rm, Rmm); m3_mul(S, Rmm, Bm);
-            for (int k = 0; k < 12; k++) rJa[k] = 0;
+            for (int k = 0; k < 36; k++) rJa[k] = 0;
             for (int a = 0; a < 2; a++) for (int b = 0; b < 3; b++) rJa[a * 6 + 3 + b] = Bm[a * 3 + b];
         }
     } else {
         relpose_jac(E.meas_t, E.meas_R, pa, pb, raw, rJa, rJb);
     }
-    const int dim = E.dim;
     double r[6];
-    for (int a = 0; a < dim; a++) { double s = 0; for (int k = 0; k < dim; k++) s += E.sqrt_info[a * dim + k] * raw[k]; r[a] = s; }
-    double sq = 0; for (int a = 0; a < dim; a++) sq += r[a] * r[a];
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) s += Sq[a * 6 + k] * raw[k];
+        r[a] = s;
+    }
+    double sq = 0;
+#pragma unroll
+    for (int a = 0; a < 6; a++) sq += r[a] * r[a];
     double rho = sq, sc = 1.0;
-    if (E.robust) {                                    // HuberLoss(a): rho = s (s <= a^2), 2 a sqrt(s) - a^2 beyond; Corrector scales by sqrt(rho')
+    if (robust) {                                    // HuberLoss(a): rho = s (s <= a^2), 2 a sqrt(s) - a^2 beyond; Corrector scales by sqrt(rho')
         const double b2 = huber * huber;
         if (sq > b2) { const double rr = sqrt(sq); rho = 2.0 * huber * rr - b2; sc = sqrt(fmax(2.2250738585072014e-308, huber / rr)); }
     }
     if (jac) {
-        for (int a = 0; a < dim; a++) r_out[a] = r[a] * sc;
-        for (int a = 0; a < dim; a++) for (int c = 0; c < 6; c++) {
-            double s = 0; for (int k = 0; k < dim; k++) s += E.sqrt_info[a * dim + k] * rJa[k * 6 + c];
-            Ja[a * 6 + c] = s * sc;
+        double oa[36], ob[36];
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                double s = 0;
+#pragma unroll
+                for (int k = 0; k < 6; k++) s += Sq[a * 6 + k] * rJa[k * 6 + c];
+                oa[a * 6 + c] = s * sc;
+            }
+        if (kind != 0) {
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+#pragma unroll
+                for (int c = 0; c < 6; c++) {
+                    double s = 0;
+#pragma unroll
+                    for (int k = 0; k < 6; k++) s += Sq[a * 6 + k] * rJb[k * 6 + c];
+                    ob[a * 6 + c] = s * sc;
+                }
         }
-        if (E.kind != 0) for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++) {
-            double s = 0; for (int k = 0; k < 6; k++) s += E.sqrt_info[a * 6 + k] * rJb[k * 6 + c];
-            Jb[a * 6 + c] = s * sc;
+#pragma unroll
+        for (int a = 0; a < 6; a++) if (a < dim) r_out[a] = r[a] * sc;
+#pragma unroll
+        for (int q = 0; q < 36; q++) if (q < dim * 6) Ja[q] = oa[q];
+        if (kind != 0) {
+#pragma unroll
+            for (int q = 0; q < 36; q++) Jb[q] = ob[q];
         }
     }
     return 0.5 * rho;
@@ -168,7 +223,25 @@ __global__ __launch_bounds__(64) void k_pgo(PgDev dv) {
     double *scale = dv.scale + G.vec0, *diag = dv.diag + G.vec0, *grad = dv.grad + G.vec0, *step = dv.step + G.vec0, *ysol = dv.ysol + G.vec0;
     isv_pgo_result_t &res = dv.res[blockIdx.x];
     const int e = lane, ea = e / 6, eb = e - 6 * ea;    // my element of a 6x6 block (lanes 0..35)
-    auto BLK = [&](double *M, int r, int c) -> double * { return M + (size_t)(rowptr[r] + (c - start[r])) * 36; };
+    // the envelope's index arrays in LDS when they fit (every block address of the factorisation / substitution recurrences
+    // starts from them: one LDS read instead of a dependent global load per step)
+    extern __shared__ int32_t dyn_idx[];
+    const bool idx_lds = dv.idx_lds_rows > 0;          // (sized by the host for the largest graph of the batch)
+    const int IR = dv.idx_lds_rows;
+    if (idx_lds) {
+        const int nc = colptr[nf];
+        for (int q = lane; q < nf; q += 64) { dyn_idx[q] = start[q]; dyn_idx[IR + q] = rowptr[q]; }
+        for (int q = lane; q <= nf; q += 64) dyn_idx[2 * IR + q] = colptr[q];
+        for (int q = lane; q < nc; q += 64) dyn_idx[3 * IR + 1 + q] = colrows[q];
+        PG_WSYNC();
+    }
+    // (explicit LDS reads: a pointer that may be LDS or global becomes a FLAT access, which waits for every outstanding
+    //  global load and store as well)
+    auto ST = [&](int r) -> int { return idx_lds ? dyn_idx[r] : start[r]; };
+    auto RP = [&](int r) -> int { return idx_lds ? dyn_idx[IR + r] : rowptr[r]; };
+    auto CP = [&](int r) -> int { return idx_lds ? dyn_idx[2 * IR + r] : colptr[r]; };
+    auto CR = [&](int q) -> int { return idx_lds ? dyn_idx[3 * IR + 1 + q] : colrows[q]; };
+    auto BLK = [&](double *M, int r, int c) -> double * { return M + (size_t)(RP(r) + (c - ST(r))) * 36; };
 
     // ---- evaluation of every residual block at x (and linearisation) ------------------------------------------------
     auto evaluate = [&](const double *x, bool jac) -> double {
@@ -197,7 +270,14 @@ __global__ __launch_bounds__(64) void k_pgo(PgDev dv) {
                 const int f = side ? E.fb : E.fa;
                 if (f < 0) continue;
                 double *J = ejac + 72 * q + 36 * side;
-                for (int a = 0; a < E.dim; a++) for (int c = 0; c < 6; c++) J[a * 6 + c] *= scale[6 * f + c];
+                double sc6[6], Jl[36];
+                const int nq = E.dim * 6;
+#pragma unroll
+                for (int c = 0; c < 6; c++) sc6[c] = scale[6 * f + c];
+#pragma unroll
+                for (int k = 0; k < 36; k++) Jl[k] = k < nq ? J[k] : 0.0;
+#pragma unroll
+                for (int k = 0; k < 36; k++) if (k < nq) J[k] = Jl[k] * sc6[k % 6];
             }
         }
         PG_GSYNC();
@@ -242,94 +322,222 @@ __global__ __launch_bounds__(64) void k_pgo(PgDev dv) {
                 const int ed = adj[q] >> 1, side = adj[q] & 1;
                 const PgEdge &E = edges[ed];
                 const double *J = ejac + 72 * ed + 36 * side;
+                const int dim = E.dim, kind = E.kind, other = kind != 0 ? (side ? E.fa : E.fb) : -1;
+                double Jl[36], blk[36], old[36];
+#pragma unroll
+                for (int k = 0; k < 36; k++) Jl[k] = k < dim * 6 ? J[k] : 0.0;     // (rows beyond dim: exact zeros in the sums)
                 double *D = BLK(H, f, f);
-                for (int a = 0; a < 6; a++) for (int b = 0; b <= a; b++) {
-                    double s = 0; for (int k = 0; k < E.dim; k++) s += J[k * 6 + a] * J[k * 6 + b];
-                    D[a * 6 + b] += s; if (b != a) D[b * 6 + a] += s;
-                }
-                if (E.kind != 0) {
-                    const int other = side ? E.fa : E.fb;
-                    if (other >= 0 && other < f) {             // the later endpoint owns the off-diagonal block (f, other)
-                        const double *Jo = ejac + 72 * ed + 36 * (1 - side);
-                        double *O = BLK(H, f, other);
-                        for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) {
-                            double s = 0; for (int k = 0; k < 6; k++) s += J[k * 6 + a] * Jo[k * 6 + b];
-                            O[a * 6 + b] += s;
-                        }
+#pragma unroll
+                for (int k = 0; k < 36; k++) old[k] = D[k];
+#pragma unroll
+                for (int a = 0; a < 6; a++)
+#pragma unroll
+                    for (int b = 0; b <= a; b++) {
+                        double s = 0;
+#pragma unroll
+                        for (int k = 0; k < 6; k++) s += Jl[k * 6 + a] * Jl[k * 6 + b];
+                        blk[a * 6 + b] = s; blk[b * 6 + a] = s;
                     }
+#pragma unroll
+                for (int k = 0; k < 36; k++) D[k] = old[k] + blk[k];
+                if (other >= 0 && other < f) {                 // the later endpoint owns the off-diagonal block (f, other)
+                    const double *Jo = ejac + 72 * ed + 36 * (1 - side);
+                    double Jol[36];
+#pragma unroll
+                    for (int k = 0; k < 36; k++) Jol[k] = Jo[k];
+                    double *O = BLK(H, f, other);
+#pragma unroll
+                    for (int k = 0; k < 36; k++) old[k] = O[k];
+#pragma unroll
+                    for (int a = 0; a < 6; a++)
+#pragma unroll
+                        for (int b = 0; b < 6; b++) {
+                            double s = 0;
+#pragma unroll
+                            for (int k = 0; k < 6; k++) s += Jl[k * 6 + a] * Jol[k * 6 + b];
+                            blk[a * 6 + b] = s;
+                        }
+#pragma unroll
+                    for (int k = 0; k < 36; k++) O[k] = old[k] + blk[k];
                 }
             }
         }
         PG_GSYNC();
     };
     // L L^T = H + diag(damp) on the envelope; diagonal slots hold L_rr^-1.  Returns false when a pivot is not positive.
+    // The recurrence runs through LDS: a CHAIN row (its envelope starts at r - 1) needs L_{r-1,r-1}^-1 (still in T2 from the
+    // previous row) and its own new block (T1), nothing from global memory that this wavefront wrote since the last fence;
+    // its two blocks of H are loaded one row ahead.  Only a LOOP row (longer envelope) reads earlier rows' blocks of L back
+    // from global memory and pays for a fence: one when it starts, one before its diagonal block, and one per step whose
+    // column is itself a loop row.
     auto factor = [&](const double *damp) -> bool {
-        for (int q = lane; q < G.nblk * 36; q += 64) L[q] = H[q];
-        PG_GSYNC();
-        bool ok = true;
+        bool ok = true;                                // (every block of L is written before it is read: A comes from H)
+        double nx_rc = 0, nx_rr = 0;                   // H(r, r-1)[e], H(r, r)[e] (+ damping) of the NEXT row when it is a chain row
+        bool have_nx = false;
         for (int r = 0; r < nf && ok; r++) {
-            const int s0 = start[r];
+            const int s0 = ST(r);
+            const bool loop_row = s0 < r - 1;
+            const double a_rc = nx_rc, a_rr = nx_rr;
+            const bool pre = have_nx;
+            have_nx = false;
+            if (r + 1 < nf && ST(r + 1) == r) {        // prefetch the next chain row's blocks
+                if (e < 36) { nx_rc = BLK(H, r + 1, r)[e]; nx_rr = BLK(H, r + 1, r + 1)[e] + (ea == eb ? damp[6 * (r + 1) + ea] : 0.0); }
+                have_nx = true;
+            }
+            if (loop_row) PG_GSYNC();                  // blocks of earlier rows written since the last fence
+            // inside a loop row the operands of the NEXT step (H(r,c+1), row eb of L(c+1,c) and of L_{c+1,c+1}^-1) are loaded
+            // one step ahead whenever column c + 1 is a chain row: the step itself then runs from registers and LDS
+            double pA = 0, pY[6] = {0, 0, 0, 0, 0, 0}, pLi[6] = {0, 0, 0, 0, 0, 0};
+            bool pnext = false;
             for (int c = s0; c < r; c++) {
                 // S = A(r,c) - sum_{m = max(start[r], start[c])}^{c-1} L(r,m) L(c,m)^T ;  L(r,c) = S L_cc^-T
+                const int sc = ST(c), m0 = s0 > sc ? s0 : sc;
+                const double cA = pA;
+                double cY[6], cLi[6];
+                for (int k = 0; k < 6; k++) { cY[k] = pY[k]; cLi[k] = pLi[k]; }
+                const bool have = pnext;
+                pnext = false;
+                if (loop_row && c + 1 < r && ST(c + 1) >= c) {
+                    if (e < 36) {
+                        pA = BLK(H, r, c + 1)[e];
+                        const double *Y = BLK(L, c + 1, c), *Li = BLK(L, c + 1, c + 1);
+                        for (int k = 0; k < 6; k++) { pY[k] = Y[eb * 6 + k]; pLi[k] = Li[eb * 6 + k]; }
+                    }
+                    pnext = true;
+                }
+                if (have) {                            // (column c is a chain row: the only earlier block of this row it meets is L(r, c-1) = T1)
+                    double acc = cA;
+                    if (e < 36) { for (int k = 0; k < 6; k++) acc -= T1[ea * 6 + k] * cY[k]; }
+                    PG_LSYNC();
+                    if (e < 36) T0[e] = acc;
+                    PG_LSYNC();
+                    double x = 0;
+                    if (e < 36) { for (int k = 0; k <= eb; k++) x += T0[ea * 6 + k] * cLi[k]; }
+                    PG_LSYNC();
+                    if (e < 36) { T1[e] = x; BLK(L, r, c)[e] = x; }
+                    PG_LSYNC();
+                    continue;
+                }
+                if (m0 < c - 1) PG_GSYNC();            // several blocks of THIS row are read back (column c is a loop row)
                 double acc = 0;
                 if (e < 36) {
-                    acc = BLK(L, r, c)[e];
-                    const int m0 = s0 > start[c] ? s0 : start[c];
-                    for (int m = m0; m < c; m++) {
-                        // (the block L(r, c-1) was finished in the previous step of this row: it is also in T1)
-                        const double *X = (m == c - 1) ? T1 : BLK(L, r, m), *Y = BLK(L, c, m);
+                    acc = (pre && c == r - 1) ? a_rc : BLK(H, r, c)[e];
+                    for (int m = m0; m < c - 1; m++) {
+                        const double *X = BLK(L, r, m), *Y = BLK(L, c, m);
                         for (int k = 0; k < 6; k++) acc -= X[ea * 6 + k] * Y[eb * 6 + k];
                     }
+                    if (m0 < c) {                      // m = c - 1: the block L(r, c-1) of the previous step is in T1 (LDS)
+                        const double *Y = BLK(L, c, c - 1);
+                        for (int k = 0; k < 6; k++) acc -= T1[ea * 6 + k] * Y[eb * 6 + k];
+                    }
                 }
-                PG_WSYNC();
+                PG_LSYNC();
                 if (e < 36) T0[e] = acc;
-                PG_WSYNC();
+                PG_LSYNC();
                 double x = 0;
-                if (e < 36) { const double *Li = BLK(L, c, c); for (int k = 0; k <= eb; k++) x += T0[ea * 6 + k] * Li[eb * 6 + k]; }
-                PG_WSYNC();
+                if (e < 36) {
+                    if (c == r - 1) { for (int k = 0; k <= eb; k++) x += T0[ea * 6 + k] * T2[eb * 6 + k]; }       // L_cc^-1 of the previous row (LDS)
+                    else { const double *Li = BLK(L, c, c); for (int k = 0; k <= eb; k++) x += T0[ea * 6 + k] * Li[eb * 6 + k]; }
+                }
+                PG_LSYNC();
                 if (e < 36) { T1[e] = x; BLK(L, r, c)[e] = x; }
-                PG_GSYNC();
+                PG_LSYNC();
             }
             // diagonal: D = A(r,r) + damp - sum_m L(r,m) L(r,m)^T
+            if (loop_row) PG_GSYNC();
             double acc = 0;
             if (e < 36) {
-                acc = BLK(L, r, r)[e] + (ea == eb ? damp[6 * r + ea] : 0.0);
-                for (int m = s0; m < r; m++) { const double *X = BLK(L, r, m); for (int k = 0; k < 6; k++) acc -= X[ea * 6 + k] * X[eb * 6 + k]; }
-                T2[e] = acc;
+                acc = pre ? a_rr : BLK(H, r, r)[e] + (ea == eb ? damp[6 * r + ea] : 0.0);
+                for (int m = s0; m < r - 1; m++) { const double *X = BLK(L, r, m); for (int k = 0; k < 6; k++) acc -= X[ea * 6 + k] * X[eb * 6 + k]; }
+                if (s0 < r) { for (int k = 0; k < 6; k++) acc -= T1[ea * 6 + k] * T1[eb * 6 + k]; }                // m = r - 1
             }
-            PG_WSYNC();
+            PG_LSYNC();                                // (T2 = L_{r-1,r-1}^-1 has been read by every lane)
+            if (e < 36) T2[e] = acc;
+            PG_LSYNC();
             ok = pg_chol_inv6(T2, lane);
             if (e < 36) BLK(L, r, r)[e] = T2[e];
-            PG_GSYNC();
         }
+        PG_GSYNC();
         return ok;
     };
-    // x = (L L^T)^-1 b  -> xs ; lanes 0..5 own the components of a block
+    // x = (L L^T)^-1 b  -> xs ; lanes 0..5 own the components of a block.  The previous block of the recurrence stays in
+    // registers (v_readlane) and the two blocks of L a chain row needs are loaded one row ahead, so a step is a few dozen
+    // FMAs; only loop rows exchange through global memory (fences as in factor()).
     auto solve = [&](const double *b, double *xs) {
+        const int ln = lane < 6 ? lane : 0;
+        double prev = 0;                               // y_{r-1} (forward) / x_{r+1} (backward), component = lane
+        double nX[6], nLi[6], nb = 0;                  // prefetched: row ln of L(r, r-1), row ln of L_rr^-1, b_r
+        bool have_nx = false;
         for (int r = 0; r < nf; r++) {                 // forward: y_r = L_rr^-1 (b_r - sum_{m<r} L(r,m) y_m)
+            const int s0 = ST(r);
+            double cX[6], cLi[6], cb = nb;
+            const bool pre = have_nx;
+            for (int k = 0; k < 6; k++) { cX[k] = nX[k]; cLi[k] = nLi[k]; }
+            have_nx = false;
+            if (r + 1 < nf && ST(r + 1) == r) {
+                const double *X = BLK(L, r + 1, r), *Li = BLK(L, r + 1, r + 1);
+                for (int k = 0; k < 6; k++) { nX[k] = X[ln * 6 + k]; nLi[k] = Li[ln * 6 + k]; }
+                nb = b[6 * (r + 1) + ln];
+                have_nx = true;
+            }
+            if (s0 < r - 1) PG_GSYNC();
+            double pv[6];
+            for (int k = 0; k < 6; k++) pv[k] = readlane_d(prev, k);
             double v = 0;
-            if (lane < 6) {
-                v = b[6 * r + lane];
-                for (int m = start[r]; m < r; m++) { const double *X = BLK(L, r, m); for (int k = 0; k < 6; k++) v -= X[lane * 6 + k] * ysol[6 * m + k]; }
+            if (pre) {
+                v = cb;
+                for (int k = 0; k < 6; k++) v -= cX[k] * pv[k];
+            } else {
+                const double *Li = BLK(L, r, r);
+                for (int k = 0; k < 6; k++) cLi[k] = Li[ln * 6 + k];
+                v = b[6 * r + ln];
+                for (int m = s0; m < r; m++) {
+                    const double *X = BLK(L, r, m);
+                    if (m == r - 1) { for (int k = 0; k < 6; k++) v -= X[ln * 6 + k] * pv[k]; }
+                    else { for (int k = 0; k < 6; k++) v -= X[ln * 6 + k] * ysol[6 * m + k]; }
+                }
             }
             double y = 0;
-            const double *Li = BLK(L, r, r);
-            for (int k = 0; k < 6; k++) { const double vk = readlane_d(v, k); if (lane < 6 && k <= lane) y += Li[lane * 6 + k] * vk; }
+            for (int k = 0; k < 6; k++) { const double vk = readlane_d(v, k); if (k <= ln) y += cLi[k] * vk; }
             if (lane < 6) ysol[6 * r + lane] = y;
-            PG_GSYNC();
+            prev = y;
         }
-        for (int r = nf - 1; r >= 0; r--) {            // backward: x_r = L_rr^-T (y_r - sum_{i in colpat(r)} L(i,r)^T x_i)
-            double v = 0;
-            if (lane < 6) {
-                v = ysol[6 * r + lane];
-                for (int q = colptr[r]; q < colptr[r + 1]; q++) { const int i = colrows[q]; const double *X = BLK(L, i, r); for (int k = 0; k < 6; k++) v -= X[k * 6 + lane] * xs[6 * i + k]; }
-            }
-            double x = 0;
+        PG_GSYNC();
+        // backward: x_r = L_rr^-T (y_r - sum_{i in colpat(r)} L(i,r)^T x_i).  A loop row i subtracts its L(i,c)^T x_i from y_c of
+        // every column c it covers as soon as x_i is known (lanes over the span); what is left for a row is the term of row
+        // r + 1 when that is a chain row, from registers.
+        prev = 0;
+        bool next_is_chain = false;                    // row r + 1 exists and its envelope starts at r
+        for (int r = nf - 1; r >= 0; r--) {
             const double *Li = BLK(L, r, r);
-            for (int k = 0; k < 6; k++) { const double vk = readlane_d(v, k); if (lane < 6 && k >= lane) x += Li[k * 6 + lane] * vk; }
+            double cLi[6], cX[6];
+            for (int k = 0; k < 6; k++) cLi[k] = Li[k * 6 + ln];
+            if (next_is_chain) { const double *X = BLK(L, r + 1, r); for (int k = 0; k < 6; k++) cX[k] = X[k * 6 + ln]; }
+            double pv[6];
+            for (int k = 0; k < 6; k++) pv[k] = readlane_d(prev, k);
+            double v = ysol[6 * r + ln];
+            if (next_is_chain) { for (int k = 0; k < 6; k++) v -= cX[k] * pv[k]; }
+            double x = 0;
+            for (int k = 0; k < 6; k++) { const double vk = readlane_d(v, k); if (k >= ln) x += cLi[k] * vk; }
             if (lane < 6) xs[6 * r + lane] = x;
-            PG_GSYNC();
+            prev = x;
+            const int s0 = ST(r);
+            next_is_chain = s0 == r - 1;
+            if (s0 < r - 1) {                          // loop row: y_c -= L(r,c)^T x_r for c in [s0, r)
+                double xr[6];
+                for (int k = 0; k < 6; k++) xr[k] = readlane_d(x, k);
+                PG_GSYNC();
+                for (int q = lane; q < (r - s0) * 6; q += 64) {
+                    const int c = s0 + q / 6, comp = q % 6;
+                    const double *X = BLK(L, r, c);
+                    double a = ysol[6 * c + comp];
+                    for (int k = 0; k < 6; k++) a -= X[k * 6 + comp] * xr[k];
+                    ysol[6 * c + comp] = a;
+                }
+                PG_GSYNC();
+            }
         }
+        PG_GSYNC();
     };
 
     // ================= TrustRegionMinimizer::Minimize + LevenbergMarquardtStrategy (Ceres 2.0.0 defaults) =============
@@ -359,13 +567,21 @@ __global__ __launch_bounds__(64) void k_pgo(PgDev dv) {
             }
             reuse_diag = true;
             assemble();
-            for (int q = lane; q < n; q += 64) step[q] = diag[q] / radius;        // D^2 = diagonal / radius (step[] as scratch)
+            for (int q0 = lane; q0 < n; q0 += 256) {   // D^2 = diagonal / radius (step[] as scratch); four loads in flight per lane
+                double v[4];
+                for (int u = 0; u < 4; u++) v[u] = q0 + 64 * u < n ? diag[q0 + 64 * u] : 0.0;
+                for (int u = 0; u < 4; u++) if (q0 + 64 * u < n) step[q0 + 64 * u] = v[u] / radius;
+            }
             PG_GSYNC();
             bool ok = factor(step);
             if (ok) {
                 solve(grad, step);
                 double bad = 0;
-                for (int q = lane; q < n; q += 64) { const double v = step[q]; if (!(v - v == 0.0)) bad = 1; step[q] = -v; }
+                for (int q0 = lane; q0 < n; q0 += 256) {
+                    double v[4];
+                    for (int u = 0; u < 4; u++) v[u] = q0 + 64 * u < n ? step[q0 + 64 * u] : 0.0;
+                    for (int u = 0; u < 4; u++) if (q0 + 64 * u < n) { if (!(v[u] - v[u] == 0.0)) bad = 1; step[q0 + 64 * u] = -v[u]; }
+                }
                 PG_GSYNC();
                 if (wave_max(bad) > 0) ok = false;
             }
@@ -395,11 +611,13 @@ __global__ __launch_bounds__(64) void k_pgo(PgDev dv) {
             double dn = 0;
             for (int k = lane; k < G.P1; k += 64) {    // candidate = Plus(x, step * scale)
                 const int f = free_of[k];
-                if (f < 0) { for (int c = 0; c < 7; c++) cand[7 * k + c] = pose[7 * k + c]; continue; }
-                double dl[6], xp[7];
+                if (f < 0) { double x0[7]; for (int c = 0; c < 7; c++) x0[c] = pose[7 * k + c]; for (int c = 0; c < 7; c++) cand[7 * k + c] = x0[c]; continue; }
+                double dl[6], xp[7], x0[7];
                 for (int c = 0; c < 6; c++) dl[c] = step[6 * f + c] * scale[6 * f + c];
-                pose_plus(pose + 7 * k, dl, xp);
-                for (int c = 0; c < 7; c++) { cand[7 * k + c] = xp[c]; const double df = pose[7 * k + c] - xp[c]; dn += df * df; }
+                for (int c = 0; c < 7; c++) x0[c] = pose[7 * k + c];
+                pose_plus(x0, dl, xp);
+                for (int c = 0; c < 7; c++) { const double df = x0[c] - xp[c]; dn += df * df; }
+                for (int c = 0; c < 7; c++) cand[7 * k + c] = xp[c];
             }
             PG_GSYNC();
             const double step_norm = sqrt(wave_sum(dn));
@@ -411,7 +629,11 @@ __global__ __launch_bounds__(64) void k_pgo(PgDev dv) {
             const double rel = (x_cost - cand_cost) / model_cost_change;
             if (rel > 1e-3) {
                 accepted = true;
-                for (int q = lane; q < 7 * G.P1; q += 64) pose[q] = cand[q];
+                for (int q0 = lane; q0 < 7 * G.P1; q0 += 256) {
+                    double v[4];
+                    for (int u = 0; u < 4; u++) v[u] = q0 + 64 * u < 7 * G.P1 ? cand[q0 + 64 * u] : 0.0;
+                    for (int u = 0; u < 4; u++) if (q0 + 64 * u < 7 * G.P1) pose[q0 + 64 * u] = v[u];
+                }
                 PG_GSYNC();
                 x_norm = xnorm_of(pose);
                 x_cost = evaluate(pose, true);
@@ -444,23 +666,23 @@ __global__ __launch_bounds__(64) void k_pgo(PgDev dv) {
     //   Z(i,j) = [delta_ij L_jj^-T - sum_{k in colpat(j)} Z(i,k) L(k,j)] L_jj^-1      for i in {j} U colpat(j)
     for (int j = nf - 1; j >= 0; j--) {
         const double *Li = BLK(L, j, j);
-        const int c0 = colptr[j], c1 = colptr[j + 1];
+        const int c0 = CP(j), c1 = CP(j + 1);
         for (int qi = c0; qi <= c1; qi++) {            // the rows below j first: Z(j,j) needs Z(k,j), k in colpat(j)
-            const int i = qi < c1 ? colrows[qi] : j;
+            const int i = qi < c1 ? CR(qi) : j;
             if (qi == c1) PG_GSYNC();
             double acc = 0;
             if (e < 36) {
                 if (i == j) acc = Li[eb * 6 + ea];                                   // L_jj^-T
                 for (int q = c0; q < c1; q++) {
-                    const int k = colrows[q];
+                    const int k = CR(q);
                     const double *Lkj = BLK(L, k, j);
                     if (i >= k) { const double *Zik = BLK(Z, i, k); for (int m = 0; m < 6; m++) acc -= Zik[ea * 6 + m] * Lkj[m * 6 + eb]; }
                     else { const double *Zki = BLK(Z, k, i); for (int m = 0; m < 6; m++) acc -= Zki[m * 6 + ea] * Lkj[m * 6 + eb]; }
                 }
             }
-            PG_WSYNC();
+            PG_LSYNC();
             if (e < 36) T0[e] = acc;
-            PG_WSYNC();
+            PG_LSYNC();
             if (e < 36) {
                 double x = 0;
                 for (int m = eb; m < 6; m++) x += T0[ea * 6 + m] * Li[m * 6 + eb];   // times L_jj^-1 (lower)
@@ -665,19 +887,24 @@ extern "C" int isv_pgo_optimize_batch(isv_pgo_t *h, int32_t ng, const int32_t *n
     if (!h || ng < 1 || !ns || !kfs || !firsts || !curs || !results) return ISV_ERR_INVALID_ARG;
     PCHK(h, hipSetDevice(h->device));
     if (ng > h->cfg.max_graphs) { h->err = "more graphs than max_graphs"; return ISV_ERR_CAPACITY; }
+    // host preparation: the graphs are analysed independently (parameter blocks, residual blocks, skyline, column patterns) into
+    // per-graph buffers by min(8, cores, graphs) host threads (ISV_HOST_THREADS overrides), then laid end to end
+    struct GraphBuild {
+        std::vector<double> pose; std::vector<int32_t> free_of, adj_ptr, adj, start, rowptr, colptr, colrows; std::vector<PgEdge> edges;
+        const char *err = nullptr; int rc = ISV_OK;
+    };
     std::vector<PgGraph> graphs(ng);
-    std::vector<double> pose; std::vector<int32_t> free_of, adj_ptr, adj, start, rowptr, colptr, colrows;
-    std::vector<PgEdge> edges;
+    std::vector<GraphBuild> builds(ng);
     std::vector<std::vector<int>> local(ng);
     std::vector<int> cur_pos(ng, -1), n_loops(ng, 0);
-    size_t nblk_tot = 0, nfree_tot = 0;
-    for (int g = 0; g < ng; g++) {
+    auto build_graph = [&](int g) -> int {
         const int n = ns[g]; isv_pg_keyframe_t *kf = kfs[g];
         if (n < 1 || !kf) return ISV_ERR_INVALID_ARG;
         PgGraph &G = graphs[g];
         memset(&G, 0, sizeof(G));
-        G.pose0 = (int32_t)(pose.size() / 7); G.free0 = (int32_t)nfree_tot; G.edge0 = (int32_t)edges.size(); G.blk0 = (int32_t)nblk_tot;
-        G.adj0 = (int32_t)adj.size(); G.col0 = (int32_t)colrows.size(); G.vec0 = (int32_t)(6 * nfree_tot);
+        GraphBuild &B = builds[g];
+        std::vector<double> &pose = B.pose; std::vector<int32_t> &free_of = B.free_of, &adj_ptr = B.adj_ptr, &adj = B.adj, &start = B.start, &rowptr = B.rowptr, &colptr = B.colptr, &colrows = B.colrows;
+        std::vector<PgEdge> &edges = B.edges;
         G.max_iter = h->cfg.max_iterations; G.huber = h->cfg.huber_delta;
         // parameter blocks: keyframes first_looped_index .. cur_index in list order (pose_graph.cpp:271-299)
         std::vector<int> &loc = local[g];
@@ -688,15 +915,15 @@ extern "C" int isv_pgo_optimize_batch(isv_pgo_t *h, int32_t ng, const int32_t *n
             loc[k] = pi++;
             if (kf[k].index == curs[g]) cur_pos[g] = k;
         }
-        if (cur_pos[g] < 0) { h->err = "cur_index is not in the keyframe list (or lies before first_looped_index)"; return ISV_ERR_INVALID_ARG; }
-        if (pi > h->cfg.max_keyframes) { h->err = "more keyframes than max_keyframes"; return ISV_ERR_CAPACITY; }
+        if (cur_pos[g] < 0) { B.err = "cur_index is not in the keyframe list (or lies before first_looped_index)"; return ISV_ERR_INVALID_ARG; }
+        if (pi > h->cfg.max_keyframes) { B.err = "more keyframes than max_keyframes"; return ISV_ERR_CAPACITY; }
         G.P1 = pi;
         const int param_index = pi - 1;
         std::vector<int> fo(pi, -1);
         int nf = 0;
         for (int k = 0; k < n; k++) {
             const int li = loc[k]; if (li < 0) continue;
-            for (int c = 0; c < 9; c++) if (!(kf[k].vio_R_w_i[c] - kf[k].vio_R_w_i[c] == 0.0)) { h->err = "non-finite keyframe pose"; return ISV_ERR_NONFINITE; }
+            for (int c = 0; c < 9; c++) if (!(kf[k].vio_R_w_i[c] - kf[k].vio_R_w_i[c] == 0.0)) { B.err = "non-finite keyframe pose"; return ISV_ERR_NONFINITE; }
             const HQ q = h_qn(h_R2q(kf[k].vio_R_w_i));                    // tmp_q = tmp_r; tmp_q.normalize()
             pose.insert(pose.end(), {kf[k].vio_T_w_i[0], kf[k].vio_T_w_i[1], kf[k].vio_T_w_i[2], q.x, q.y, q.z, q.w});
             const bool constant = kf[k].index == firsts[g] || kf[k].sequence == 0;
@@ -710,7 +937,7 @@ extern "C" int isv_pgo_optimize_batch(isv_pgo_t *h, int32_t ng, const int32_t *n
         for (int f = 0; f < nf; f++) st[f] = f;
         auto add_edge = [&](PgEdge &E) {
             E.fa = fo[E.a]; E.fb = E.kind == 0 ? -1 : fo[E.b];
-            const int id = (int)edges.size() - G.edge0;
+            const int id = (int)edges.size();
             if (E.fa >= 0) adjl[E.fa].push_back((id << 1) | 0);
             if (E.kind != 0 && E.fb >= 0) adjl[E.fb].push_back((id << 1) | 1);
             if (E.kind != 0 && E.fa >= 0 && E.fb >= 0) { const int lo = std::min(E.fa, E.fb), hi = std::max(E.fa, E.fb); st[hi] = std::min(st[hi], lo); }
@@ -733,7 +960,7 @@ extern "C" int isv_pgo_optimize_batch(isv_pgo_t *h, int32_t ng, const int32_t *n
             if (kf[k].has_loop) {
                 int conn = -1;
                 for (int m = 0; m < n; m++) if (kf[m].index == kf[k].loop_index) conn = loc[m];
-                if (conn < 0) { h->err = "loop_index outside the optimised range (the reference asserts loop_index >= first_looped_index)"; return ISV_ERR_INVALID_ARG; }
+                if (conn < 0) { B.err = "loop_index outside the optimised range (the reference asserts loop_index >= first_looped_index)"; return ISV_ERR_INVALID_ARG; }
                 PgEdge E; memset(&E, 0, sizeof(E));
                 E.kind = 2; E.a = conn; E.b = li; E.dim = 6; E.robust = 1;
                 memcpy(E.meas_t, kf[k].loop_info, 24);
@@ -743,18 +970,43 @@ extern "C" int isv_pgo_optimize_batch(isv_pgo_t *h, int32_t ng, const int32_t *n
                 n_loops[g]++;
             }
         }
-        G.ne = (int32_t)edges.size() - G.edge0;
+        G.ne = (int32_t)edges.size();
         // skyline + adjacency + column patterns
         int nb = 0;
-        for (int f = 0; f < nf; f++) { adj_ptr.push_back((int32_t)adj.size() - G.adj0); adj.insert(adj.end(), adjl[f].begin(), adjl[f].end()); start.push_back(st[f]); rowptr.push_back(nb); nb += f - st[f] + 1; }
-        adj_ptr.push_back((int32_t)adj.size() - G.adj0); rowptr.push_back(nb);
+        for (int f = 0; f < nf; f++) { adj_ptr.push_back((int32_t)adj.size()); adj.insert(adj.end(), adjl[f].begin(), adjl[f].end()); start.push_back(st[f]); rowptr.push_back(nb); nb += f - st[f] + 1; }
+        adj_ptr.push_back((int32_t)adj.size()); rowptr.push_back(nb);
         G.nblk = nb;
-        if (nb - 2 * nf > h->cfg.max_loop_blocks) { h->err = "loop closures span more blocks than max_loop_blocks"; return ISV_ERR_CAPACITY; }
+        if (nb - 2 * nf > h->cfg.max_loop_blocks) { B.err = "loop closures span more blocks than max_loop_blocks"; return ISV_ERR_CAPACITY; }
         std::vector<std::vector<int32_t>> cp(nf);
         for (int i = 0; i < nf; i++) for (int j = st[i]; j < i; j++) cp[j].push_back(i);
-        for (int j = 0; j < nf; j++) { colptr.push_back((int32_t)colrows.size() - G.col0); colrows.insert(colrows.end(), cp[j].begin(), cp[j].end()); }
-        colptr.push_back((int32_t)colrows.size() - G.col0);
-        nblk_tot += nb; nfree_tot += nf;
+        for (int j = 0; j < nf; j++) { colptr.push_back((int32_t)colrows.size()); colrows.insert(colrows.end(), cp[j].begin(), cp[j].end()); }
+        colptr.push_back((int32_t)colrows.size());
+        return ISV_OK;
+    };
+    auto parallel_over_graphs = [&](const std::function<void(int)> &fn) {
+        int T = (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+        if (const char *ev = getenv("ISV_HOST_THREADS")) T = atoi(ev);
+        T = std::max(1, std::min(T, ng));
+        if (T == 1) { for (int g = 0; g < ng; g++) fn(g); return; }
+        std::atomic<int> next{0};
+        std::vector<std::thread> th;
+        for (int k = 0; k < T; k++) th.emplace_back([&] { for (int g; (g = next.fetch_add(1)) < ng; ) fn(g); });
+        for (auto &x : th) x.join();
+    };
+    parallel_over_graphs([&](int g) { builds[g].rc = build_graph(g); });
+    for (int g = 0; g < ng; g++) if (builds[g].rc != ISV_OK) { if (builds[g].err) h->err = builds[g].err; return builds[g].rc; }
+    std::vector<double> pose; std::vector<int32_t> free_of, adj_ptr, adj, start, rowptr, colptr, colrows;
+    std::vector<PgEdge> edges;
+    size_t nblk_tot = 0, nfree_tot = 0;
+    for (int g = 0; g < ng; g++) {
+        PgGraph &G = graphs[g]; GraphBuild &B = builds[g];
+        G.pose0 = (int32_t)(pose.size() / 7); G.free0 = (int32_t)nfree_tot; G.edge0 = (int32_t)edges.size(); G.blk0 = (int32_t)nblk_tot;
+        G.adj0 = (int32_t)adj.size(); G.col0 = (int32_t)colrows.size(); G.vec0 = (int32_t)(6 * nfree_tot);
+#define APP(v) v.insert(v.end(), B.v.begin(), B.v.end())
+        APP(pose); APP(free_of); APP(adj_ptr); APP(adj); APP(start); APP(rowptr); APP(colptr); APP(colrows); APP(edges);
+#undef APP
+        nblk_tot += (size_t)G.nblk; nfree_tot += (size_t)G.nf;
+        B = GraphBuild();
     }
     if (pose.size() / 7 > h->cap_pose || edges.size() > h->cap_edge || nblk_tot > h->cap_blk || adj.size() > h->cap_adj || colrows.size() > h->cap_col) {
         h->err = "pose graphs exceed the handle's capacity"; return ISV_ERR_CAPACITY;
@@ -764,7 +1016,16 @@ extern "C" int isv_pgo_optimize_batch(isv_pgo_t *h, int32_t ng, const int32_t *n
     UP(d.graphs, graphs); UP(d.pose, pose); UP(d.free_of, free_of); UP(d.edges, edges); UP(d.adj_ptr, adj_ptr); UP(d.adj, adj);
     UP(d.start, start); UP(d.rowptr, rowptr); UP(d.colptr, colptr); UP(d.colrows, colrows);
 #undef UP
-    hipLaunchKernelGGL(k_pgo, dim3(ng), dim3(64), 0, st, d);
+    // index arrays of the envelope in LDS when the largest graph's fit into 48 KB
+    size_t max_nf = 0, max_cols = 0;
+    for (int g = 0; g < ng; g++) {
+        max_nf = std::max(max_nf, (size_t)graphs[g].nf);
+        max_cols = std::max(max_cols, (size_t)(graphs[g].nblk - graphs[g].nf));
+    }
+    size_t idx_bytes = (3 * max_nf + 1 + max_cols) * sizeof(int32_t);
+    d.idx_lds_rows = d.idx_lds_cols = 0;
+    if (max_nf > 0 && idx_bytes <= 48 * 1024) { d.idx_lds_rows = (int32_t)max_nf; d.idx_lds_cols = (int32_t)max_cols; } else idx_bytes = 0;
+    hipLaunchKernelGGL(k_pgo, dim3(ng), dim3(64), idx_bytes, st, d);
     PCHK(h, hipGetLastError());
     std::vector<double> cov(pose.size() / 7 * 36);
     PCHK(h, hipMemcpyAsync(pose.data(), d.pose, sizeof(double) * pose.size(), hipMemcpyDeviceToHost, st));
@@ -772,7 +1033,7 @@ extern "C" int isv_pgo_optimize_batch(isv_pgo_t *h, int32_t ng, const int32_t *n
     PCHK(h, hipMemcpyAsync(results, d.res, sizeof(isv_pgo_result_t) * ng, hipMemcpyDeviceToHost, st));
     PCHK(h, hipStreamSynchronize(st));
     // write back (pose_graph.cpp:366-407): updatePose, updateCov, the update() calls, drift, the keyframes after cur
-    for (int g = 0; g < ng; g++) {
+    parallel_over_graphs([&](int g) {
         const int n = ns[g]; isv_pg_keyframe_t *kf = kfs[g];
         const PgGraph &G = graphs[g];
         isv_pgo_result_t &R = results[g];
@@ -809,7 +1070,7 @@ extern "C" int isv_pgo_optimize_batch(isv_pgo_t *h, int32_t ng, const int32_t *n
             h_mm(R.r_drift, kf[k].vio_R_w_i, Rn);
             memcpy(kf[k].T_w_i, Pn, 24); memcpy(kf[k].R_w_i, Rn, 72);
         }
-    }
+    });
     return ISV_OK;
 }
 
