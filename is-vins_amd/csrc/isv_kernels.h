@@ -21,7 +21,10 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
 // (jac = false: the residual-only evaluation, see prior_linearize_body)
 static inline size_t prior_lds_bytes(int slots, bool jac = true) { return (size_t)slots * (jac ? 82 + 90 + 82 : 10 + 10 + 82) * sizeof(double); }
 __global__ void k_triangulate(DevBatch d);
-#define LG_WAVES 4               // wavefronts of k_lin_gram (each takes the pair groups of ISV_SWEEP_WAVES / LG_WAVES sweep wavefronts)
+#ifndef LG_WAVES
+#define LG_WAVES 4
+#endif
+                                 // wavefronts of k_lin_gram (each takes the pair groups of ISV_SWEEP_WAVES / LG_WAVES sweep wavefronts)
 template <bool EX> __global__ void k_lin_gram(DevBatch d);     // EX: the extrinsic is estimated (J_ex, one more block row)
 size_t lin_gram_lds_bytes(int N, bool partials_in_lds, bool ex);
 __global__ void k_imu_raw(DevBatch d, const double *pose_src, const double *sb_src, int gate);

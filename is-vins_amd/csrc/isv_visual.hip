@@ -71,10 +71,11 @@ __global__ __launch_bounds__(64 * LG_WAVES, EX ? 2 : 3) void k_lin_gram(DevBatch
     // element of the LDS factor row that operand column i takes: J_i row row2 | J_j row row2 | r[row2]
     const int eoff = i < 6 ? 2 + row2 * 6 + i : (i < 12 ? 14 + row2 * 6 + (i - 6) : row2);
     const bool colok = i < 13;
-    constexpr int SPW = ISV_SWEEP_WAVES / LG_WAVES;     // sweep-schedule wavefronts per wavefront here
-    const int q0 = soff[wv * SPW], q1 = soff[(wv + 1) * SPW];
+    // sweep-schedule slices [sl0, sl1) of this wavefront (an even split when LG_WAVES divides ISV_SWEEP_WAVES, else 2-3-3 ...)
+    const int sl0 = (wv * ISV_SWEEP_WAVES) / LG_WAVES, sl1 = ((wv + 1) * ISV_SWEEP_WAVES) / LG_WAVES;
+    const int q0 = soff[sl0], q1 = soff[sl1];
     const int *wst = d.pg_wstart + (size_t)w * (ISV_SWEEP_WAVES + 1);
-    const int s0 = wst[wv * SPW], s1 = wst[(wv + 1) * SPW];       // this wavefront's slice of the factor stream
+    const int s0 = wst[sl0], s1 = wst[sl1];            // this wavefront's slice of the factor stream
     auto gsize = [&](int qq) { const int pp = sched[qq] >> 16; return offL[pp + 1] - offL[pp]; };
     // one group's accumulator tile -> its five pieces.  C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
     double *exp_w = EX ? d.ex_part + (size_t)w * NP * 114 : nullptr;
