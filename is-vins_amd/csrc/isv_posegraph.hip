@@ -1024,7 +1024,8 @@ extern "C" int isv_pgo_optimize_batch(isv_pgo_t *h, int32_t ng, const int32_t *n
     }
     size_t idx_bytes = (3 * max_nf + 1 + max_cols) * sizeof(int32_t);
     d.idx_lds_rows = d.idx_lds_cols = 0;
-    if (max_nf > 0 && idx_bytes <= 48 * 1024) { d.idx_lds_rows = (int32_t)max_nf; d.idx_lds_cols = (int32_t)max_cols; } else idx_bytes = 0;
+    // (ISV_PGO_IDX_GLOBAL: test hook for the path graphs too large for the LDS copies take)
+    if (max_nf > 0 && idx_bytes <= 48 * 1024 && !getenv("ISV_PGO_IDX_GLOBAL")) { d.idx_lds_rows = (int32_t)max_nf; d.idx_lds_cols = (int32_t)max_cols; } else idx_bytes = 0;
     hipLaunchKernelGGL(k_pgo, dim3(ng), dim3(64), idx_bytes, st, d);
     PCHK(h, hipGetLastError());
     std::vector<double> cov(pose.size() / 7 * 36);

@@ -104,6 +104,23 @@ def test_batch_of_graphs_is_bitwise_the_single_calls(oracle, opt):
     check_graph(o, ro, batch[2], res[2], graphs[2][2], specs[2][1] - 1)
 
 
+def test_global_index_path_is_bitwise_the_lds_one(opt, monkeypatch):
+    """graphs whose envelope index arrays do not fit the kernel's 48 KB of LDS read them from global memory instead: forced on
+    an ordinary graph (ISV_PGO_IDX_GLOBAL), the result has to be the same bits as with the LDS copies"""
+    kf, P, first = pg.make_pose_graph(11, 300, 8)
+    a = pg.clone_keyframes(kf)
+    ra = opt.optimize(a, first, 299)
+    monkeypatch.setenv("ISV_PGO_IDX_GLOBAL", "1")
+    b = pg.clone_keyframes(kf)
+    rb = opt.optimize(b, first, 299)
+    assert ra.status == 0 and rb.status == 0
+    assert (ra.iterations, ra.termination) == (rb.iterations, rb.termination)
+    assert list(ra.trace_cost) == list(rb.trace_cost)
+    for k in range(len(a)):
+        assert np.array_equal(abi.arr(a[k].T_w_i), abi.arr(b[k].T_w_i)) and np.array_equal(abi.arr(a[k].R_w_i), abi.arr(b[k].R_w_i))
+        assert np.array_equal(abi.arr(a[k].cov), abi.arr(b[k].cov))
+
+
 def test_loop_pose_output_file(opt, tmp_path):
     """./loop_pose_output.txt (pose_graph.cpp:412-423): one `fixed` row per keyframe, stamp px py pz qw qx qy qz of getPose()"""
     kf, P, first = pg.make_pose_graph(30, 50, 2)
