@@ -120,3 +120,41 @@ def test_result_records_on_the_device_match_the_download(oracle):
             assert out[k, 229] == s.termination and out[k, 230] == s.num_successful and out[k, 232] == g.header0 and out[k, 233] == g.L
     finally:
         b.close()
+
+
+def test_exchange_step_through_rccl_on_device_buffers(oracle):
+    """the N > 1 exchange step with the backend the multi-GPU bench uses ("nccl" = RCCL), as far as one GPU allows: a process
+    group of ONE rank (RCCL refuses two ranks on one device), the records packed on the device with no host sync, then the
+    same `all_gather_into_tensor` / MAX all-reduce calls bench.py issues.  Checks the RCCL calls accept these buffers and
+    are ordered after the solve on torch's stream; the partition / multi-rank logic itself is tests/test_multi_rank.py (gloo)."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        ws = synth.make_windows(range(400, 416), n_landmarks=40)
+        b = backend.Backend(11, 5, max_landmarks=40, max_obs=max(w.n_obs for w in ws), max_batch=len(ws))
+        try:
+            gs = [w.clone() for w in ws]
+            b.upload(gs); b.run_optimize(sync=False)
+            rec = b.record_doubles()
+            records = torch.zeros((len(gs), rec), dtype=torch.float64, device="cuda:0")
+            gathered = torch.full((len(gs), rec), float("nan"), dtype=torch.float64, device="cuda:0")
+            b.pack_results(records.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            dist.all_gather_into_tensor(gathered, records)
+            t = torch.tensor([1.25], dtype=torch.float64, device="cuda:0")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            torch.cuda.synchronize()
+            sums, _ = b.download(gs)
+            out = gathered.cpu().numpy()
+            assert float(t.item()) == 1.25
+            for k, (g, sm) in enumerate(zip(gs, sums)):
+                assert np.array_equal(out[k, :77], g.para_Pose.ravel()) and np.array_equal(out[k, 77:176], g.para_SpeedBias.ravel())
+                assert out[k, 176 + 40] == sm.final_cost and out[k, 176 + 40 + 2] == sm.iterations
+        finally:
+            b.close()
+    finally:
+        dist.destroy_process_group()
