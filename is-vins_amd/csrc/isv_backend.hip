@@ -149,7 +149,7 @@ static int create_impl(isv_backend *h) {
     // pair, which spreads a window over the whole GPU (6.2 against 8.3 ms per optimize there).  Decided per HANDLE, from its
     // capacity, never from the batch: a window gives the same bits alone and inside any batch of the same handle.
     // (ISV_LEGACY_VISUAL: test / measurement hook for the unfused pair.)
-    d.fused_visual = (getenv("ISV_LEGACY_VISUAL") || (c.max_obs > 8192 && !c.estimate_extrinsic)) ? 0 : 1;
+    d.fused_visual = (c.estimate_extrinsic || !(getenv("ISV_LEGACY_VISUAL") || c.max_obs > 8192)) ? 1 : 0;      // (a free extrinsic only exists in k_lin_gram<true>)
     TRY(dalloc(h, &d.imu_in, NI * ISV_IMU_IN)); TRY(dalloc(h, &d.imu_cov, NI * 225)); TRY(dalloc(h, &d.imu_sqrt, NI * 225));
     TRY(dalloc(h, &d.imu_skip, NI));
     TRY(dalloc(h, &d.se3, B)); TRY(dalloc(h, &d.lin9, B)); TRY(dalloc(h, &d.relpose, B * (c.n_vo - 1))); TRY(dalloc(h, &d.rollpitch, B * (size_t)c.max_rollpitch));
