@@ -450,13 +450,28 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
     return ISV_OK;
 }
 
+// isv_batch_optimize starts from the state that was uploaded: twelve small device-to-device copies, as ONE kernel (a
+// hipMemcpyAsync each costs ~5 us of stream time at these sizes: 60 us of every 1024-window step)
+struct RestoreJobs { uint64_t *dst[12]; const uint64_t *src[12]; size_t n8[12]; };     // 8-byte words: every buffer holds doubles
+__global__ __launch_bounds__(256) void k_restore(RestoreJobs j) {
+    const int job = blockIdx.y;
+    uint64_t *dst = j.dst[job]; const uint64_t *src = j.src[job];
+    const size_t n = j.n8[job];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
 static int restore_initial(isv_backend *h) {
     DevBatch &d = h->d; const isv_config_t &c = h->cfg; hipStream_t st = h->stream;
     const size_t n = d.B, N = d.N, L = d.Ltot;
-    D2D(d.Ps, h->Ps0, n * N * 3); D2D(d.Rs, h->Rs0, n * N * 9); D2D(d.Vs, h->Vs0, n * N * 3);
-    D2D(d.Bas, h->Bas0, n * N * 3); D2D(d.Bgs, h->Bgs0, n * N * 3); D2D(d.depth, h->depth0, L);
-    D2D(d.tic, h->tic0, n * 3); D2D(d.ric, h->ric0, n * 9);
-    D2D(d.se3, h->se30, n); D2D(d.lin9, h->lin90, n); D2D(d.relpose, h->relpose0, n * (c.n_vo - 1)); D2D(d.rollpitch, h->rollpitch0, n * c.max_rollpitch);
+    RestoreJobs j;
+    int k = 0;
+#define RJOB(dstp, srcp, cnt) do { static_assert(sizeof(*(srcp)) % 8 == 0, "8-byte words"); j.dst[k] = (uint64_t *)(dstp); j.src[k] = (const uint64_t *)(srcp); j.n8[k] = sizeof(*(srcp)) / 8 * (size_t)(cnt); k++; } while (0)
+    RJOB(d.Ps, h->Ps0, n * N * 3); RJOB(d.Rs, h->Rs0, n * N * 9); RJOB(d.Vs, h->Vs0, n * N * 3);
+    RJOB(d.Bas, h->Bas0, n * N * 3); RJOB(d.Bgs, h->Bgs0, n * N * 3); RJOB(d.depth, h->depth0, L);
+    RJOB(d.tic, h->tic0, n * 3); RJOB(d.ric, h->ric0, n * 9);
+    RJOB(d.se3, h->se30, n); RJOB(d.lin9, h->lin90, n); RJOB(d.relpose, h->relpose0, n * (c.n_vo - 1)); RJOB(d.rollpitch, h->rollpitch0, n * c.max_rollpitch);
+#undef RJOB
+    hipLaunchKernelGGL(k_restore, dim3(64, 12), dim3(256), 0, st, j);
+    HIPCHK(h, hipGetLastError());
     return ISV_OK;
 }
 
