@@ -21,12 +21,12 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
 // (jac = false: the residual-only evaluation, see prior_linearize_body)
 static inline size_t prior_lds_bytes(int slots, bool jac = true) { return (size_t)slots * (jac ? 82 + 90 + 82 : 10 + 10 + 82) * sizeof(double); }
 __global__ void k_triangulate(DevBatch d);
-#ifndef LG_WAVES
+// wavefronts of k_lin_gram per window: LG_WAVES for batches (three workgroups per CU), LG_WAVES_SMALL while the batch leaves
+// every window a CU of its own (each wavefront takes the pair groups of ISV_SWEEP_WAVES / LGW sweep wavefronts)
 #define LG_WAVES 4
-#endif
-                                 // wavefronts of k_lin_gram (each takes the pair groups of ISV_SWEEP_WAVES / LG_WAVES sweep wavefronts)
-template <bool EX> __global__ void k_lin_gram(DevBatch d);     // EX: the extrinsic is estimated (J_ex, one more block row)
-size_t lin_gram_lds_bytes(int N, bool partials_in_lds, bool ex);
+#define LG_WAVES_SMALL 8
+template <bool EX, int LGW> __global__ void k_lin_gram(DevBatch d);     // EX: the extrinsic is estimated (J_ex, one more block row)
+size_t lin_gram_lds_bytes(int N, bool partials_in_lds, bool ex, int waves);
 __global__ void k_imu_raw(DevBatch d, const double *pose_src, const double *sb_src, int gate);
 __global__ void k_imu_weight(DevBatch d, double *cost_out, int gate);
 #define ISV_PROF_FAMILIES 6      // 0 = k_proj_linearize<0>, 1 = k_sweep_mfma, 2 = k_rank1_mfma, 3 = k_build_solve*, 4 = k_dogleg, 5 = k_step_control

@@ -615,7 +615,12 @@ int isv_solver_alloc(DevBatch &d, size_t B, size_t L, size_t F, std::vector<void
         SETLDS((k_rank1_mfma<4, 1, 64, 1, false>), lds_r1); SETLDS((k_rank1_mfma<4, 1, 64, 1, true>), lds_r1); SETLDS((k_rank1_mfma<5, 1, 64, 1, false>), lds_r1); SETLDS((k_rank1_mfma<5, 1, 64, 1, true>), lds_r1); SETLDS((k_rank1_mfma<6, 2, 64, 1, false>), lds_r1); SETLDS((k_rank1_mfma<6, 2, 64, 1, true>), lds_r1);
         SETLDS((k_rank1_mfma<7, 2, 64, 1, false>), lds_r1); SETLDS((k_rank1_mfma<7, 2, 64, 1, true>), lds_r1); SETLDS((k_rank1_mfma<8, 3, 64, 1, false>), lds_r1); SETLDS((k_rank1_mfma<8, 3, 64, 1, true>), lds_r1);
         SETLDS(k_sweep_mfma, lds_sw);
-        SETLDS(k_lin_gram<false>, lin_gram_lds_bytes(d.Nr, true, false)); SETLDS(k_lin_gram<true>, lin_gram_lds_bytes(d.Nr, true, true));
+        if (d.est_ex) SETLDS((k_lin_gram<true, LG_WAVES>), lin_gram_lds_bytes(d.Nr, true, true, LG_WAVES));
+        else SETLDS((k_lin_gram<false, LG_WAVES>), lin_gram_lds_bytes(d.Nr, true, false, LG_WAVES));
+        if (lin_gram_lds_bytes(d.Nr, true, d.est_ex != 0, LG_WAVES_SMALL) <= (size_t)160 * 1024) {      // (the small-batch variant where its tiles fit)
+            if (d.est_ex) SETLDS((k_lin_gram<true, LG_WAVES_SMALL>), lin_gram_lds_bytes(d.Nr, true, true, LG_WAVES_SMALL));
+            else SETLDS((k_lin_gram<false, LG_WAVES_SMALL>), lin_gram_lds_bytes(d.Nr, true, false, LG_WAVES_SMALL));
+        }
         if (d.N == 11) SETLDS((k_build_solve_sb<false, 11>), lds_sb);
         if (d.N <= 11) SETLDS((k_build_solve_sb<false, 0>), lds_sb);
         if (d.N > 11) SETLDS((k_build_solve_sb<true, 0>), lds_sb);
@@ -649,6 +654,8 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
     const bool control_in_wg = d.lds_T && ((size_t)d.Ftot <= (size_t)4096 * d.B || d.est_ex);
     const bool fuse_control = control_in_wg && !getenv("ISV_SPLIT_CONTROL") &&
                               d.B <= resident_workgroups(d.est_ex ? (const void *)k_dogleg<true, true> : (const void *)k_dogleg<true, false>, 256, lds_dg > lds_sc ? lds_dg : lds_sc);
+    int n_cus = 0;
+    { int dev_id = 0; if (hipGetDevice(&dev_id) != hipSuccess || hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev_id) != hipSuccess) { (void)hipGetLastError(); n_cus = 0; } }
     hipLaunchKernelGGL(k_init_state, dim3((d.B + 63) / 64), dim3(64), 0, st, d);
     for (int slot = 0; slot < d.max_iter; slot++) {
         // linearise where needed (k_*_linearize skip windows whose need_linearize == 0 via the tile/window flags)
@@ -664,8 +671,12 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
         PROF(slot, 0, 0);
         if (fused) {
             // linearisation fused with the Gram products: no Jacobian strip goes to HBM (isv_visual.hip)
-            if (d.est_ex) hipLaunchKernelGGL(k_lin_gram<true>, dim3(d.B), dim3(64 * LG_WAVES), lin_gram_lds_bytes(d.Nr, !d.sw_global, true), st, d);
-            else hipLaunchKernelGGL(k_lin_gram<false>, dim3(d.B), dim3(64 * LG_WAVES), lin_gram_lds_bytes(d.Nr, !d.sw_global, false), st, d);
+            // (eight wavefronts per window while the batch leaves every window a CU of its own: 41 -> 27 us per launch for one window)
+            if (d.B <= n_cus && !getenv("ISV_LG_BATCH_WAVES") && lin_gram_lds_bytes(d.Nr, true, d.est_ex != 0, LG_WAVES_SMALL) <= (size_t)160 * 1024) {
+                if (d.est_ex) hipLaunchKernelGGL((k_lin_gram<true, LG_WAVES_SMALL>), dim3(d.B), dim3(64 * LG_WAVES_SMALL), lin_gram_lds_bytes(d.Nr, !d.sw_global, true, LG_WAVES_SMALL), st, d);
+                else hipLaunchKernelGGL((k_lin_gram<false, LG_WAVES_SMALL>), dim3(d.B), dim3(64 * LG_WAVES_SMALL), lin_gram_lds_bytes(d.Nr, !d.sw_global, false, LG_WAVES_SMALL), st, d);
+            } else if (d.est_ex) hipLaunchKernelGGL((k_lin_gram<true, LG_WAVES>), dim3(d.B), dim3(64 * LG_WAVES), lin_gram_lds_bytes(d.Nr, !d.sw_global, true, LG_WAVES), st, d);
+            else hipLaunchKernelGGL((k_lin_gram<false, LG_WAVES>), dim3(d.B), dim3(64 * LG_WAVES), lin_gram_lds_bytes(d.Nr, !d.sw_global, false, LG_WAVES), st, d);
             counts[0]++; counts[4] = 1;
         } else if (d.n_tiles > 0) { hipLaunchKernelGGL(k_proj_linearize<0>, dim3((d.n_tiles + 3) / 4), dim3(256), lds_proj, st, d, d.pose, d.lam, d.fcost, 1); counts[0]++; }
         PROF(slot, 0, 1);

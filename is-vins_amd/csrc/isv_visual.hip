@@ -11,7 +11,7 @@
 // of the rank-1 kernel) and a 64-byte record {J_l^T J_l, J_l^T r, J_i^T J_l} from which k_rank1_mfma's prologue forms
 // the landmark scalars in the landmark's own factor order (fixed order: bitwise reproducible, no atomics).
 //
-// One workgroup (LG_WAVES wavefronts) per window; wavefront v takes the pair groups the upload schedule gave to the
+// One workgroup (LGW wavefronts) per window; wavefront v takes the pair groups the upload schedule gave to the
 // sweep wavefronts 2v and 2v + 1, laid out back to back in the factor stream (pg_rec / pg_pts / pg_wstart) so that it
 // walks them in FULL 64-lane chunks.  Outputs: Tvis (pose blocks, gradient, Jacobi diagonal) as k_sweep_mfma.
 #include <hip/hip_runtime.h>
@@ -25,13 +25,15 @@ typedef double double4g __attribute__((ext_vector_type(4)));
 __host__ __device__ constexpr int lg_xld(bool ex) { return ex ? 39 : 27; }
 #define LGSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
-size_t lin_gram_lds_bytes(int N /* real frames */, bool partials_in_lds, bool ex) {
+size_t lin_gram_lds_bytes(int N /* real frames */, bool partials_in_lds, bool ex, int waves) {
     const size_t NP = (size_t)N * (N - 1) / 2;
-    return ((size_t)N * 12 + 12 + (size_t)LG_WAVES * 16 * lg_xld(ex) + (partials_in_lds ? NP * 84 : 0) + (NP + 2) / 2 + 1) * sizeof(double);
+    return ((size_t)N * 12 + 12 + (size_t)waves * 16 * lg_xld(ex) + (partials_in_lds ? NP * 84 : 0) + (NP + 2) / 2 + 1) * sizeof(double);
 }
 
-template <bool EX>
-__global__ __launch_bounds__(64 * LG_WAVES, EX ? 2 : 3) void k_lin_gram(DevBatch d) {
+// LGW wavefronts per window: 4 for batches (158 VGPRs -> three workgroups per CU), 8 while every window has a CU of its own
+// (twice the wavefronts on the factor stream; which wavefront sums a pair group does not change the sums)
+template <bool EX, int LGW>
+__global__ __launch_bounds__(64 * LGW, LGW > 4 ? 2 : (EX ? 2 : 3)) void k_lin_gram(DevBatch d) {
     constexpr int LG_XLD = lg_xld(EX);
     extern __shared__ __align__(16) double lds[];
     const int w = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -43,7 +45,7 @@ __global__ __launch_bounds__(64 * LG_WAVES, EX ? 2 : 3) void k_lin_gram(DevBatch
     double *sPose = lds;                               // [N][12] R (row-major) | P
     double *sEx = sPose + N * 12;                      // [12]
     double *sX = sEx + 12 + wv * 16 * LG_XLD;          // this wavefront's 16-factor tile
-    double *pbase = sEx + 12 + LG_WAVES * 16 * LG_XLD;
+    double *pbase = sEx + 12 + LGW * 16 * LG_XLD;
     double *Pjj = d.sw_global ? d.sw_part + (size_t)w * NP * 84 : pbase;      // pair partials (see k_sweep_mfma)
     double *Phh = Pjj + NP * 36, *Pgj = Phh + NP * 36, *Pgh = Pgj + NP * 6;
     int *offL = (int *)(d.sw_global ? pbase : pbase + NP * 84);                // [NP + 1] group starts
@@ -71,8 +73,8 @@ __global__ __launch_bounds__(64 * LG_WAVES, EX ? 2 : 3) void k_lin_gram(DevBatch
     // element of the LDS factor row that operand column i takes: J_i row row2 | J_j row row2 | r[row2]
     const int eoff = i < 6 ? 2 + row2 * 6 + i : (i < 12 ? 14 + row2 * 6 + (i - 6) : row2);
     const bool colok = i < 13;
-    // sweep-schedule slices [sl0, sl1) of this wavefront (an even split when LG_WAVES divides ISV_SWEEP_WAVES, else 2-3-3 ...)
-    const int sl0 = (wv * ISV_SWEEP_WAVES) / LG_WAVES, sl1 = ((wv + 1) * ISV_SWEEP_WAVES) / LG_WAVES;
+    // sweep-schedule slices [sl0, sl1) of this wavefront (an even split when LGW divides ISV_SWEEP_WAVES, else 2-3-3 ...)
+    const int sl0 = (wv * ISV_SWEEP_WAVES) / LGW, sl1 = ((wv + 1) * ISV_SWEEP_WAVES) / LGW;
     const int q0 = soff[sl0], q1 = soff[sl1];
     const int *wst = d.pg_wstart + (size_t)w * (ISV_SWEEP_WAVES + 1);
     const int s0 = wst[sl0], s1 = wst[sl1];            // this wavefront's slice of the factor stream
@@ -254,5 +256,7 @@ __global__ __launch_bounds__(64 * LG_WAVES, EX ? 2 : 3) void k_lin_gram(DevBatch
         }
     }
 }
-template __global__ void k_lin_gram<false>(DevBatch);
-template __global__ void k_lin_gram<true>(DevBatch);
+template __global__ void k_lin_gram<false, LG_WAVES>(DevBatch);
+template __global__ void k_lin_gram<true, LG_WAVES>(DevBatch);
+template __global__ void k_lin_gram<false, LG_WAVES_SMALL>(DevBatch);
+template __global__ void k_lin_gram<true, LG_WAVES_SMALL>(DevBatch);
