@@ -98,11 +98,14 @@ def test_batch_of_more_than_256_long_windows(oracle):
 
 
 @pytest.mark.parametrize("env", [{"ISV_LEGACY_VISUAL": "1"}, {"ISV_SPLIT_CONTROL": "1"},
-                                 {"ISV_LEGACY_VISUAL": "1", "ISV_SPLIT_CONTROL": "1"}, {"ISV_GENERIC_N": "1"}])
+                                 {"ISV_LEGACY_VISUAL": "1", "ISV_SPLIT_CONTROL": "1"}, {"ISV_GENERIC_N": "1"},
+                                 {"ISV_LG_BATCH_WAVES": "1"}])
 def test_unfused_kernel_variants_against_oracle_and_fused(oracle, monkeypatch, env):
     """the round-1 kernels the library still ships (k_proj_linearize<0> + k_sweep_mfma instead of k_lin_gram, k_dogleg<false> +
     k_step_control instead of k_dogleg<true>; selected by environment for A/B measurements, and what N > 20 handles use),
-    and the run-time-N instantiation of k_build_solve_sb in place of the one compiled for 11 frames:
+    the run-time-N instantiation of k_build_solve_sb in place of the one compiled for 11 frames, and the four-wavefront
+    k_lin_gram large batches use in place of the eight-wavefront one of small batches (bitwise: which wavefront sums a pair
+    group does not change the sums):
     against the oracle, and against the fused kernels on the same windows (cost trace and states to rounding: the landmark
     sums are formed in a different association, so not bitwise)."""
     ws = synth.make_windows([90, 91, 92], n_frames=11, n_vo=5, n_landmarks=150)
