@@ -169,6 +169,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.scaling == "strong" and args.windows % world != 0:
+        # equal shards only: all_gather_into_tensor needs the same record count on every rank
+        sys.exit(f"bench.py: --scaling strong needs --windows ({args.windows}) divisible by the number of ranks ({world})")
 
     # more than two handles' worth of HIP streams in one process (the untimed two-handle leg below): the runtime maps
     # streams onto 4 hardware queues by default; must be set before the runtime initialises.  One handle is unaffected.
@@ -333,10 +336,58 @@ def main():
         b18.run_optimize(sync=True, profile=True)
         fam18 = b18.last_timing(); cnt18 = b18.last_counts()
         b18.close()
+        # one window per call on the handle the drop-in shim creates (include/isvins_estimator_shim.hpp: NUM_OF_F = 1000 landmarks,
+        # NUM_OF_F x ALL_BUF_SIZE = 18 000 observations, Vo_SIZE + 1 roll/pitch slots, max_batch = 1): abi.make_config's defaults
+        bshim = backend.Backend(18, 8)
+        assert (bshim.cfg.max_landmarks, bshim.cfg.max_obs, bshim.cfg.max_batch) == (1000, 18000, 1)
+        bshim.upload(w18[:1])
+        ts1 = []
+        for _ in range(9):
+            bshim.run_optimize(sync=True); ts1.append(float(bshim.last_timing()[0]))
+        cshim = bshim.last_counts()
+        bshim.close()
         extra["reference_shape_n18_vo8"] = {"workload": f"{n18} windows, N=18 KF, Nvo=8, L={args.landmarks}, full backendOptimization()", "ms_per_step": 1e3 * t18,
                                             "value": n18 / t18, "unit": "windows/s",
                                             "build_solve_avg_launch_us": 1e3 * float(fam18[4]) / max(int(cnt18[1]), 1),
-                                            "ms_per_optimize_single_window": single_window_ms(18, 8, w18, mo18)}
+                                            "ms_per_optimize_single_window": float(np.median(ts1[2:])),
+                                            "single_window_handle": "as the shim creates it: max_landmarks 1000, max_obs 18000, max_batch 1",
+                                            "single_window_fused_lin_gram": int(cshim[4]) == 1, "single_window_persistent_launch": int(cshim[6]) == 1,
+                                            "ms_per_optimize_single_window_tight_handle": single_window_ms(18, 8, w18, mo18)}
+
+        # ---- BASELINE config 5: ONE stress window, 20 KF / 2000 landmarks / exactly 30 000 reprojection factors --------------
+        w5 = synth.make_window(0, n_frames=20, n_vo=8, n_landmarks=2000, target_factors=30000)
+        b5 = backend.Backend(20, 8, max_landmarks=2000, max_obs=w5.n_obs, max_batch=1)
+        b5.upload([w5])
+        t5 = []
+        for _ in range(12):
+            b5.run_optimize(sync=True); t5.append(float(b5.last_timing()[0]))
+        b5.run_optimize(sync=True, profile=True)
+        fam5 = b5.last_timing(); cnt5 = b5.last_counts()
+        b5.close()
+        ms5 = float(np.median(t5[2:]))
+        wi5 = max(int(cnt5[3]), 1); nl5 = max(int(cnt5[2]), 1)
+        kl = np.diff(w5.lm_obs_ptr[: w5.L + 1]).astype(float)                       # track lengths k_l
+        r1_dense = 2.0 * (6 * 20) ** 2 * w5.L; r1_sparse = float(np.sum(2.0 * (6.0 * kl) ** 2))
+        r1_us = 1e3 * float(fam5[3]) / nl5
+        cfg5 = {"workload": f"one synthetic stress window: N=20 KF, Nvo=8, L={w5.L} landmarks, F={w5.n_factors} reprojection factors, full backendOptimization() (10 dogleg iterations + marginalisation)",
+                "ms_per_optimize": ms5, "value": 1e3 / ms5, "unit": "windows/s", "window_iterations": wi5, "fused_lin_gram": int(cnt5[4]) == 1,
+                "kernel_us_per_launch": {"k_proj_linearize<0>": 1e3 * float(fam5[1]) / max(int(cnt5[0]), 1), "k_sweep_mfma": 1e3 * float(fam5[2]) / nl5,
+                                         "k_rank1_mfma<8,3>": r1_us, "k_build_solve_sb<true,0>": 1e3 * float(fam5[4]) / max(int(cnt5[1]), 1),
+                                         "k_dogleg": 1e3 * float(fam5[5]) / 10.0, "k_proj_linearize<1> + k_step_control": 1e3 * float(fam5[6]) / 10.0},
+                "roofline": {"kernel": "k_rank1_mfma<8,3>", "bound": "mfma", "achieved": r1_dense / (r1_us * 1e-6) / 1e12 if r1_us > 0 else None,
+                             "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": (r1_dense / (r1_us * 1e-6) / 1e12 / FP64_PEAK_TFLOPS) if r1_us > 0 else None,
+                             "traffic": None, "avg_launch_us": r1_us,
+                             "flops_dense_equivalent": r1_dense, "flops_sparse_exact": r1_sparse,
+                             "note": "the Schur panel contraction S -= sum_l c_l w_l w_l^T of ONE window, dense-equivalent 2 (6N)^2 L flops (SURVEY 8d); one workgroup of 12 wavefronts: a single window cannot fill 256 CUs, so this is a latency figure -- MfmaUtil of the same launch is in profiles/r03_config5_pmc_utilisation.csv"}}
+        if cpu_lib is not None:
+            cfg5c = backend.abi.make_config(20, 8, max_landmarks=2000, max_obs=w5.n_obs, max_batch=1)
+            tcs = []
+            for _ in range(3):
+                o5 = w5.clone(); s5 = backend.abi.isv_summary_t(); m5 = backend.abi.isv_marg_result_t()
+                t1 = time.perf_counter(); cpu_lib.isvo_optimize(C.byref(cfg5c), C.byref(o5.c()), C.byref(s5), C.byref(m5)); tcs.append(time.perf_counter() - t1)
+            cfg5["cpu_baseline"] = {"value": 1.0 / min(tcs), "unit": "windows/s", "ms_per_optimize": 1e3 * min(tcs), "cores": 1, "kind": "port",
+                                    "sample": "the same window, oracle isvo_optimize (-O3 -march=native), best of 3"}
+        extra["stress_config5"] = cfg5
 
         # ---- the pose-graph consumer: PoseGraph::optimizeCS passes, one graph and a batch ---------------
         try:
@@ -430,7 +481,7 @@ def main():
         bytes_control = Fw * 24.0 + Lw * (24.0 + 24.0) + 3 * 16 * N * 8.0
         flops_bs = bs_flops(N)
         pmc = {}
-        for name in ("r02_pmc_traffic.json",):
+        for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
                 break
@@ -489,8 +540,12 @@ def main():
             "kernel_ms": {"profiled_step_total_events": float(fam[0]), "lin_gram_or_proj_linearize_sum": lin_ms, "sweep_mfma_sum": sw_ms, "rank1_mfma_sum": r1_ms, "build_solve_sum": bs_ms,
                           "dogleg_sum": dg_ms, "step_control_sum": sc_ms, "window_iterations": win_iters},
             "cpu_baseline": cpu,
+            # SURVEY 8d / BASELINE.md 3 promise a stock-Ceres cross-check "if find_package(Ceres) succeeds on the GPU box": probed in
+            # round 3 (`find / -name ceres.h -o -path '*eigen3/Eigen/Dense' -o -name so3.hpp`: nothing; gpurun_out/r3_probe) -- the
+            # MI355X image has no Eigen, Ceres or Sophus either, so the oracle stays unpinned by the reference
+            "ceres": "unavailable",
         }
-        for k in ("config2_single_window_linearize", "strong_scaling_shard", "reference_shape_n18_vo8", "pose_graph_optimisation"):
+        for k in ("config2_single_window_linearize", "strong_scaling_shard", "reference_shape_n18_vo8", "stress_config5", "pose_graph_optimisation"):
             if k in extra:
                 out[k] = extra[k]
         print(json.dumps(out))

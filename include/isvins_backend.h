@@ -269,8 +269,13 @@ int  isv_batch_last_timing(isv_backend_t *h, double out_ms[8]);
  * of the resident batch, written into a caller-owned DEVICE buffer [n][isv_result_record_doubles()] so that the caller
  * can all-gather them over RCCL without a host copy.  record = [para_Pose 7N | para_SpeedBias 9N | inverse depths zero
  * padded to max_landmarks | final_cost initial_cost iterations termination num_successful radius header0 n_landmarks].
- * `stream` (a hipStream_t, may be NULL = the handle's stream): the pack kernel is ordered after everything enqueued on
- * the handle's stream and runs on `stream`, so a collective enqueued on `stream` afterwards needs no host sync.       */
+ * `stream` is the CALLER's hipStream_t -- NULL is a stream too (the legacy default stream, which is what
+ * torch.cuda.current_stream().cuda_stream is for torch's default stream): the pack kernel waits (event, no host sync)
+ * for everything enqueued on the handle's own non-blocking stream, runs on `stream`, and the handle's next launch waits
+ * for it in turn, so a collective enqueued on `stream` afterwards reads finished records and the next solve does not
+ * overwrite the states under the pack.  ISV_STREAM_OF_HANDLE asks for the handle's own stream instead (then the caller
+ * orders its reads with isv_batch_sync).                                                                              */
+#define ISV_STREAM_OF_HANDLE ((void *)(intptr_t)-1)
 int64_t isv_result_record_doubles(const isv_backend_t *h);
 int  isv_batch_pack_results(isv_backend_t *h, void *device_dst, void *stream);
 /* last optimize: [0] k_lin_gram (or k_proj_linearize<0>) launches, [1] k_build_solve* launches, [2] k_rank1_mfma launches,

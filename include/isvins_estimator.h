@@ -102,8 +102,10 @@ int  isv_estimator_get_window(const isv_estimator_t *e, int32_t seq, double *Ps,
 int  isv_estimator_get_preintegration(const isv_estimator_t *e, int32_t seq, int32_t frame, isv_imu_t *out);
 int  isv_estimator_last_summary(const isv_estimator_t *e, int32_t seq, isv_summary_t *out);
 /* number of solves of this sequence whose result was not finite (isv_summary_t::status == ISV_ERR_NONFINITE): such a
- * result is NOT copied into the window -- the sequence keeps its pre-solve states, prior factors and depths and goes on
- * (the reference has no guard here, src/estimator.cpp:1541-1562: a NaN would spread through every later frame) */
+ * result is NOT copied into the window -- the sequence keeps its pre-solve states and depths, slides, and REBUILDS its
+ * prior factors with initFactorGraph at its next solve (without this frame's marginalisation outputs the old priors
+ * could not follow the slide).  The reference has no guard here, src/estimator.cpp:1541-1562: a NaN would spread
+ * through every later frame. */
 int  isv_estimator_failed_solves(const isv_estimator_t *e, int32_t seq);
 /* which = 0: the rows the reference appends to pose_output.txt after every solve, 8 doubles per row
  *            (Headers[0], Ps[0], Quaterniond(Rs[0]) as w x y z)            src/System.cpp:401-410

@@ -78,7 +78,9 @@ const char *isv_pgo_last_error(const isv_pgo_t *h);
  * the drift correction of the keyframes after cur_index.  Keyframes are updated in place.                        */
 int  isv_pgo_optimize(isv_pgo_t *h, int32_t n, isv_pg_keyframe_t *kf, int32_t first_looped_index, int32_t cur_index,
                       isv_pgo_result_t *result);
-/* the same for n_graphs independent pose graphs (one per sequence) in one launch */
+/* the same for n_graphs independent pose graphs (one per sequence) in one launch.  Every graph is written back; when a
+ * graph's covariance factorisation fails (results[g].status == ISV_ERR_NONFINITE) its poses are written, its keyframes'
+ * cov / cov_computed are left untouched, and the call returns that status (the first failing graph's).            */
 int  isv_pgo_optimize_batch(isv_pgo_t *h, int32_t n_graphs, const int32_t *n, isv_pg_keyframe_t *const *kf,
                             const int32_t *first_looped_index, const int32_t *cur_index, isv_pgo_result_t *results);
 

@@ -197,8 +197,11 @@ class Backend:
 
     def pack_results(self, device_ptr, stream=None):
         """per-window result records of the resident batch into a caller-owned DEVICE buffer [n][record_doubles()],
-        ordered after the handle's stream and enqueued on `stream` (a hipStream_t value; None = the handle's own)"""
-        self._check(self.lib.isv_batch_pack_results(self.h, C.c_void_p(device_ptr), C.c_void_p(stream or 0)), "pack_results")
+        ordered after the handle's stream and enqueued on `stream`: a hipStream_t VALUE of the caller -- 0 is the legacy
+        default stream (torch's default stream), a stream like any other; None = the handle's own stream
+        (ISV_STREAM_OF_HANDLE), after which the caller orders its reads with sync()"""
+        s = C.c_void_p(-1) if stream is None else C.c_void_p(int(stream))
+        self._check(self.lib.isv_batch_pack_results(self.h, C.c_void_p(device_ptr), s), "pack_results")
 
     def last_timing(self):
         out = np.zeros(8)

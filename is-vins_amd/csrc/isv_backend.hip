@@ -33,6 +33,7 @@ struct isv_backend {
     std::vector<hipEvent_t> prof_ev;      // [max_iter][ISV_PROF_FAMILIES][2]
     int prof_valid = 0;
     DevBatch d{};                 // device pointers
+    SolverHost hc;                // device figures + environment hooks, read once at creation
     std::vector<void *> allocs;
     // capacities
     size_t capB = 0, capL = 0, capF = 0, capTiles = 0;
@@ -144,12 +145,9 @@ static int create_impl(isv_backend *h) {
     TRY(dalloc(h, &d.pg_perm, F)); TRY(dalloc(h, &d.pg_off, B * ((size_t)c.n_frames * (c.n_frames - 1) / 2 + 1)));
     TRY(dalloc(h, &d.pg_sched, B * ((size_t)c.n_frames * (c.n_frames - 1) / 2))); TRY(dalloc(h, &d.pg_sched_off, B * (ISV_SWEEP_WAVES + 1)));
     TRY(dalloc(h, &d.pg_rec, F * 2)); TRY(dalloc(h, &d.pg_pts, F * 2)); TRY(dalloc(h, &d.flm, F * 8)); TRY(dalloc(h, &d.pg_wstart, B * (ISV_SWEEP_WAVES + 1)));
-    // k_lin_gram takes one window per workgroup: right for batches of ordinary windows; a handle sized for very long factor
-    // lists (BASELINE config 5: 30 000 factors in ONE window) keeps the factor-parallel k_proj_linearize<0> + k_sweep_mfma
-    // pair, which spreads a window over the whole GPU (6.2 against 8.3 ms per optimize there).  Decided per HANDLE, from its
-    // capacity, never from the batch: a window gives the same bits alone and inside any batch of the same handle.
-    // (ISV_LEGACY_VISUAL: test / measurement hook for the unfused pair.)
-    d.fused_visual = (c.estimate_extrinsic || !(getenv("ISV_LEGACY_VISUAL") || c.max_obs > 8192)) ? 1 : 0;      // (a free extrinsic only exists in k_lin_gram<true>)
+    // d.fused_visual (k_lin_gram, or the unfused k_proj_linearize<0> + k_sweep_mfma pair) is decided per UPLOAD from the
+    // windows that were handed over, not from the handle's capacity: see isv_batch_upload
+    d.fused_visual = 1;
     TRY(dalloc(h, &d.imu_in, NI * ISV_IMU_IN)); TRY(dalloc(h, &d.imu_cov, NI * 225)); TRY(dalloc(h, &d.imu_sqrt, NI * 225));
     TRY(dalloc(h, &d.imu_skip, NI));
     TRY(dalloc(h, &d.se3, B)); TRY(dalloc(h, &d.lin9, B)); TRY(dalloc(h, &d.relpose, B * (c.n_vo - 1))); TRY(dalloc(h, &d.rollpitch, B * (size_t)c.max_rollpitch));
@@ -183,7 +181,7 @@ static int create_impl(isv_backend *h) {
     TRY(halloc(h, &s.pose, B * N * 7)); TRY(halloc(h, &s.sb, B * N * 9)); TRY(halloc(h, &s.ex, B * 7)); TRY(halloc(h, &s.lam, L));
     TRY(halloc(h, &h->stage.st, B)); TRY(halloc(h, &h->stage.tc, B * ISV_MAX_TRACE)); TRY(halloc(h, &h->stage.tr, B * ISV_MAX_TRACE));
     TRY(halloc(h, &h->stage.ts, B * ISV_MAX_TRACE)); TRY(halloc(h, &h->stage.ta, B * ISV_MAX_TRACE)); TRY(halloc(h, &h->stage.marg, B));
-    TRY(isv_solver_alloc(h->d, B, L, F, h->allocs, h->err));
+    TRY(isv_solver_alloc(h->d, h->hc, B, L, F, h->allocs, h->err));
     if (d.est_ex) {
         if (!d.lds_T) { h->err = "estimate_extrinsic = 1 is built for the LDS solver path only (ALL_BUF_SIZE <= 19)"; return ISV_ERR_UNSUPPORTED; }
         const size_t NPr = (size_t)c.n_frames * (c.n_frames - 1) / 2;
@@ -369,7 +367,7 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
     const isv_config_t &c = h->cfg;
     const int N = c.n_frames, Nd = h->d.N;
     auto &s = h->h;
-    size_t L = 0, F = 0, T = 0;
+    size_t L = 0, F = 0, T = 0, Fmax = 0;
     std::vector<size_t> t_off((size_t)n + 1);
     for (int b = 0; b < n; b++) {
         const isv_window_t *w = ws[b];
@@ -390,6 +388,7 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
         }
         if (tn) T++;
         L += (size_t)w->n_landmarks;
+        if (F - (size_t)s.f_off[b] > Fmax) Fmax = F - (size_t)s.f_off[b];
     }
     t_off[n] = T;
     {
@@ -415,6 +414,14 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
     const auto t_packed = std::chrono::steady_clock::now();
     DevBatch &d = h->d;
     d.B = n; d.Ltot = (int32_t)L; d.Ftot = (int32_t)F; d.n_tiles = (int32_t)T;
+    // k_lin_gram takes one window per workgroup: right for windows of ordinary length, whatever the handle's capacity is
+    // (the reference-shaped handle reserves NUM_OF_F x ALL_BUF_SIZE = 18 000 observations and sees ~2 000 factors).  A
+    // batch with a very long window (BASELINE config 5: 30 000 factors in ONE window) takes the factor-parallel
+    // k_proj_linearize<0> + k_sweep_mfma pair, which spreads a window over the whole GPU (6.2 against 8.3 ms per
+    // optimize there).  The rule looks at the LONGEST window of the upload: a window of <= ISV_FUSED_MAX_FACTORS factors
+    // gives the same bits alone and inside any batch of such windows.  (a free extrinsic only exists in k_lin_gram<true>;
+    // ISV_LEGACY_VISUAL: test / measurement hook for the unfused pair)
+    d.fused_visual = (c.estimate_extrinsic || !(h->hc.legacy_visual || Fmax > ISV_FUSED_MAX_FACTORS)) ? 1 : 0;
     hipStream_t st = h->stream;
 #define H2D(dst, src, cnt) HIPCHK(h, hipMemcpyAsync(dst, src, sizeof(*(src)) * (size_t)(cnt), hipMemcpyHostToDevice, st))
     const size_t NI = (size_t)n * (Nd - 1);
@@ -565,7 +572,7 @@ extern "C" int isv_batch_optimize(isv_backend_t *h, int32_t sync) {
     TRY(restore_initial(h));
     hipLaunchKernelGGL(k_vector2double, dim3(d.B), dim3(64), 0, st, d);
     const bool profile = (sync & 2) != 0 && !h->prof_ev.empty();       // per-kernel-family events only on request
-    int rc = isv_solver_enqueue(h->d, st, h->stream2, h->fj, h->last_counts, profile ? h->prof_ev.data() : nullptr, h->err);
+    int rc = isv_solver_enqueue(h->d, h->hc, st, h->stream2, h->fj, h->last_counts, profile ? h->prof_ev.data() : nullptr, h->err);
     h->prof_valid = profile ? 1 : 0;
     if (rc != ISV_OK) return rc;
     HIPCHK(h, hipEventRecord(h->ev[4], st));
@@ -671,7 +678,7 @@ extern "C" int isv_backend_init_factor_graph_batch(isv_backend_t *h, int32_t n, 
     if (hipMemsetAsync(d.act, 0, sizeof(int32_t) * ISV_MAX_TRACE, st) != hipSuccess) rc = ISV_ERR_DEVICE;
     if (rc == ISV_OK) {
         hipLaunchKernelGGL(k_vector2double, dim3(d.B), dim3(64), 0, st, d);
-        rc = isv_solver_enqueue(h->d, st, h->stream2, h->fj, h->last_counts, nullptr, h->err);
+        rc = isv_solver_enqueue(h->d, h->hc, st, h->stream2, h->fj, h->last_counts, nullptr, h->err);
     }
     h->prof_valid = 0;
     d.max_iter = saved_iter; d.init_mode = 0; d.init_scratch = nullptr; d.init_kld = nullptr;
@@ -772,7 +779,8 @@ extern "C" int isv_batch_pack_results(isv_backend_t *h, void *device_dst, void *
     if (!h || !device_dst || !h->resident) return ISV_ERR_INVALID_ARG;
     ENTER(h);
     DevBatch &d = h->d;
-    hipStream_t dst_stream = stream ? (hipStream_t)stream : h->stream;
+    // (NULL is the legacy default stream, a caller stream like any other: only the sentinel selects the handle's own)
+    hipStream_t dst_stream = stream == ISV_STREAM_OF_HANDLE ? h->stream : (hipStream_t)stream;
     if (dst_stream != h->stream) {           // order the pack after everything enqueued on the handle's stream, without a host sync
         HIPCHK(h, hipEventRecord(h->pk[0], h->stream));
         HIPCHK(h, hipStreamWaitEvent(dst_stream, h->pk[0], 0));

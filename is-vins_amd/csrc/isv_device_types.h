@@ -12,6 +12,7 @@
 
 #define ISV_TILE 64            // reprojection factors per wavefront tile
 #define ISV_MAX_FRAMES 32
+#define ISV_FUSED_MAX_FACTORS 8192   // longest window (reprojection factors) the one-workgroup-per-window k_lin_gram takes
 #define ISV_IMU_IN 64          // packed IMU record (doubles)
 // offsets inside the packed IMU record
 #define IMU_DP 0

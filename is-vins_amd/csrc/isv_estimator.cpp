@@ -729,10 +729,14 @@ extern "C" int isv_estimator_step(isv_estimator_t *e) {
     (void)parallel_for((int)solve.size(), errs, [&](int k, std::string &) {
         Sequence &s = e->seq[solve[k]];
         // A solve that produced a non-finite cost must not be copied into the window (the reference has no such guard:
-        // its NaNs would spread through every later frame): the sequence keeps its pre-solve states, priors and depths,
-        // drops this frame's marginalisation outputs, and the failure is counted (isv_estimator_failed_solves).
+        // its NaNs would spread through every later frame): the sequence keeps its pre-solve states and depths, drops
+        // this frame's marginalisation outputs, and the failure is counted (isv_estimator_failed_solves).  The window
+        // still slides (below), but without marginalisation outputs the prior factors cannot follow it -- with MARGIN_OLD
+        // they would sit one frame off for every later solve -- so the sequence goes back to INITIAL_STRUCTURE after the
+        // slide: its next solve rebuilds EVERY prior at the then-current states through initFactorGraph
+        // (backendOptimization's first branch, src/estimator.cpp:1543-1548), exactly as after initialisation.
         const bool ok = sums[k].status == ISV_OK;
-        if (ok) read_back(s); else s.n_failed++;
+        if (ok) read_back(s); else { s.n_failed++; s.have_to_add = false; }
         const isv_marg_result_t &m = margs[k];
         if (ok && s.margin_old && m.valid) {
             s.add_pose_prior = m.forward_pose_prior; s.add_relpose = m.backward_relpose; s.add_vb = m.backward_vb;
@@ -744,7 +748,8 @@ extern "C" int isv_estimator_step(isv_estimator_t *e) {
         s.last_summary = sums[k];
         s.n_solves++;
         s.n_good_last = (int)s.good.size();
-        after_solve(e, s, s.Headers[s.N - 1]);
+        after_solve(e, s, s.Headers[s.N - 1]);        // (slides as NON_LINEAR: removeBackShiftDepth re-hosts the depths)
+        if (!ok) { s.flag = INITIAL_STRUCTURE; s.rollpitch.clear(); }
         return (int)ISV_OK;
     });
     const auto t5 = clk::now();

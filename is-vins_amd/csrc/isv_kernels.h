@@ -16,8 +16,21 @@ template <bool JAC> __global__ void k_prior_linearize(DevBatch d, const double *
 __global__ void k_cost_reduce(DevBatch d, const double *fcost, const double *imu_cost, const double *prior_cost, double *out, int gate);
 
 // solver stage (isv_solver.hip)
-int isv_solver_alloc(DevBatch &d, size_t B, size_t L, size_t F, std::vector<void *> &allocs, std::string &err);
-int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t *fj, int64_t *counts, hipEvent_t *prof_ev, std::string &err);
+// host-side launch parameters of a handle: device figures and environment hooks, read ONCE in isv_solver_alloc (the
+// kernel VARIANT of a launch is then chosen from these and the uploaded batch: see isv_solver_enqueue)
+struct SolverHost {
+    int n_cus = 0;                    // compute units of the handle's device
+    size_t res_dogleg_ctl = 0;        // resident workgroups of k_dogleg<true, EX> at this handle's LDS size
+    bool one_stream = false;          // ISV_ONE_STREAM: diagnostics, everything on one stream
+    bool split_control = false;       // ISV_SPLIT_CONTROL: k_dogleg<false> + k_step_control
+    bool generic_n = false;           // ISV_GENERIC_N: run-time-N instantiation of k_build_solve_sb for every N
+    bool lg_batch_waves = false;      // ISV_LG_BATCH_WAVES: never the eight-wavefront k_lin_gram
+    bool debug_sw_global = false;     // ISV_DEBUG_SW_GLOBAL: pair partials in the global scratch for every launch
+    bool legacy_visual = false;       // ISV_LEGACY_VISUAL: the unfused k_proj_linearize<0> + k_sweep_mfma pair
+    bool no_persistent = false;       // ISV_NO_PERSISTENT: never the one-launch solve of small batches
+};
+int isv_solver_alloc(DevBatch &d, SolverHost &hc, size_t B, size_t L, size_t F, std::vector<void *> &allocs, std::string &err);
+int isv_solver_enqueue(DevBatch &d, const SolverHost &hc, hipStream_t st, hipStream_t st2, hipEvent_t *fj, int64_t *counts, hipEvent_t *prof_ev, std::string &err);
 // (jac = false: the residual-only evaluation, see prior_linearize_body)
 static inline size_t prior_lds_bytes(int slots, bool jac = true) { return (size_t)slots * (jac ? 82 + 90 + 82 : 10 + 10 + 82) * sizeof(double); }
 __global__ void k_triangulate(DevBatch d);

@@ -1029,10 +1029,12 @@ extern "C" int isv_pgo_optimize_batch(isv_pgo_t *h, int32_t ng, const int32_t *n
     hipLaunchKernelGGL(k_pgo, dim3(ng), dim3(64), idx_bytes, st, d);
     PCHK(h, hipGetLastError());
     std::vector<double> cov(pose.size() / 7 * 36);
-    PCHK(h, hipMemcpyAsync(pose.data(), d.pose, sizeof(double) * pose.size(), hipMemcpyDeviceToHost, st));
-    PCHK(h, hipMemcpyAsync(cov.data(), d.cov, sizeof(double) * cov.size(), hipMemcpyDeviceToHost, st));
-    PCHK(h, hipMemcpyAsync(results, d.res, sizeof(isv_pgo_result_t) * ng, hipMemcpyDeviceToHost, st));
+    // (blocking copies after the stream has drained: the destinations are pageable -- `results` is the caller's array --
+    // and an asynchronous copy into pageable memory may still be completing inside the runtime after the stream is idle)
     PCHK(h, hipStreamSynchronize(st));
+    PCHK(h, hipMemcpy(pose.data(), d.pose, sizeof(double) * pose.size(), hipMemcpyDeviceToHost));
+    PCHK(h, hipMemcpy(cov.data(), d.cov, sizeof(double) * cov.size(), hipMemcpyDeviceToHost));
+    PCHK(h, hipMemcpy(results, d.res, sizeof(isv_pgo_result_t) * ng, hipMemcpyDeviceToHost));
     // write back (pose_graph.cpp:366-407): updatePose, updateCov, the update() calls, drift, the keyframes after cur
     parallel_over_graphs([&](int g) {
         const int n = ns[g]; isv_pg_keyframe_t *kf = kfs[g];
@@ -1045,7 +1047,10 @@ extern "C" int isv_pgo_optimize_batch(isv_pgo_t *h, int32_t ng, const int32_t *n
             const int li = local[g][k]; if (li < 0) continue;
             const double *p = pose.data() + (size_t)(G.pose0 + li) * 7;
             memcpy(kf[k].T_w_i, p, 24); h_q2R(HQ{p[6], p[3], p[4], p[5]}, kf[k].R_w_i);
-            if (li < param_index) {
+            // (a graph whose covariance factorisation failed -- status ISV_ERR_NONFINITE -- keeps its keyframes' cov /
+            // cov_computed as they were: the reference does not check ceres::Covariance::Compute's result and would
+            // store whatever GetCovarianceBlock left; zeros marked "computed" are worse than no covariance)
+            if (li < param_index && R.status == ISV_OK) {
                 // ceres::Covariance::GetCovarianceBlock returns the 7x7 AMBIENT block [Sigma 0; 0 0]; the reference receives it in a
                 // 36-double buffer and maps that as a column-major 6x6 (pose_graph.cpp:356-358): reproduced, stored row-major
                 double c7[49] = {0};
@@ -1072,6 +1077,8 @@ extern "C" int isv_pgo_optimize_batch(isv_pgo_t *h, int32_t ng, const int32_t *n
             memcpy(kf[k].T_w_i, Pn, 24); memcpy(kf[k].R_w_i, Rn, 72);
         }
     });
+    // per-graph failures surface in the return value too (every graph has been written back by now; results[g].status says which)
+    for (int g = 0; g < ng; g++) if (results[g].status != ISV_OK) { h->err = "pose graph " + std::to_string(g) + ": the covariance factorisation failed (poses written, covariances left untouched)"; return results[g].status; }
     return ISV_OK;
 }
 

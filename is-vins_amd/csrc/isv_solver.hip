@@ -562,6 +562,11 @@ static int dal(T **p, size_t n, std::vector<void *> &allocs, std::string &err) {
 }
 #define TRYA(x) do { int rc_ = (x); if (rc_ != ISV_OK) return rc_; } while (0)
 static std::mutex g_lds_attr_mutex;
+// dynamic LDS of k_dogleg (candidate-point IMU / prior evaluation on the LDS path + the two tangent vectors) and of the step control
+static size_t dogleg_lds_bytes(const DevBatch &d) {
+    return (d.lds_T ? ((size_t)(d.N - 1) * 48 + (size_t)d.n_prior_slots * 16) * sizeof(double) + prior_lds_bytes(d.n_prior_slots, false) : 0) + 2 * (size_t)d.np * sizeof(double);
+}
+static size_t step_control_lds_bytes(const DevBatch &d) { return ((size_t)30 * d.N + 12) * sizeof(double); }
 
 // workgroups of kernel `fn` (threads per workgroup, dynamic LDS bytes) the current device holds at once
 static size_t resident_workgroups(const void *fn, int threads, size_t lds) {
@@ -571,7 +576,7 @@ static size_t resident_workgroups(const void *fn, int threads, size_t lds) {
     return (size_t)per_cu * (size_t)cus;
 }
 
-int isv_solver_alloc(DevBatch &d, size_t B, size_t L, size_t F, std::vector<void *> &allocs, std::string &err) {
+int isv_solver_alloc(DevBatch &d, SolverHost &hc, size_t B, size_t L, size_t F, std::vector<void *> &allocs, std::string &err) {
     const size_t n = d.np, NI = B * (d.N - 1);
     TRYA(dal(&d.scale_p, B * n, allocs, err)); TRYA(dal(&d.diag_p, B * n, allocs, err)); TRYA(dal(&d.grad_p, B * n, allocs, err));
     TRYA(dal(&d.gn_p, B * n, allocs, err)); TRYA(dal(&d.delta_p, B * n, allocs, err)); TRYA(dal(&d.zp, B * n, allocs, err)); TRYA(dal(&d.up, B * n, allocs, err));
@@ -603,7 +608,11 @@ int isv_solver_alloc(DevBatch &d, size_t B, size_t L, size_t F, std::vector<void
     d.sw_part = nullptr; d.sw_global = 0;
     // ISV_DEBUG_SW_GLOBAL=1 (test hook): give every LDS-path handle the global pair-partial scratch and use it for
     // every launch, so that small batches exercise the variant large N >= 12 batches run
-    if (d.lds_T && (sw_global || getenv("ISV_DEBUG_SW_GLOBAL"))) TRYA(dal(&d.sw_part, B * n_pairs * 84, allocs, err));
+    hc.one_stream = getenv("ISV_ONE_STREAM") != nullptr; hc.split_control = getenv("ISV_SPLIT_CONTROL") != nullptr;
+    hc.generic_n = getenv("ISV_GENERIC_N") != nullptr; hc.lg_batch_waves = getenv("ISV_LG_BATCH_WAVES") != nullptr;
+    hc.debug_sw_global = getenv("ISV_DEBUG_SW_GLOBAL") != nullptr; hc.legacy_visual = getenv("ISV_LEGACY_VISUAL") != nullptr;
+    hc.no_persistent = getenv("ISV_NO_PERSISTENT") != nullptr;
+    if (d.lds_T && (sw_global || hc.debug_sw_global)) TRYA(dal(&d.sw_part, B * n_pairs * 84, allocs, err));
     d.marg_scratch_sz = 26;
     TRYA(dal(&d.marg_scratch, L * 26, allocs, err));
     int dev_ = 0;
@@ -632,30 +641,33 @@ int isv_solver_alloc(DevBatch &d, size_t B, size_t L, size_t F, std::vector<void
         const size_t want = build_solve_lds_bytes(d.N, false);
         if (want > cur_bs[dev_ & 63]) { HCHK(hipFuncSetAttribute((const void *)k_build_solve<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want)); cur_bs[dev_ & 63] = want; }
     }
+    // device figures the per-launch variant choice needs (once per handle, not per isv_batch_optimize)
+    if (hipDeviceGetAttribute(&hc.n_cus, hipDeviceAttributeMultiprocessorCount, dev_) != hipSuccess) { (void)hipGetLastError(); hc.n_cus = 0; }
+    {
+        const size_t lds_dg = dogleg_lds_bytes(d), lds_sc = step_control_lds_bytes(d);
+        hc.res_dogleg_ctl = d.lds_T ? resident_workgroups(d.est_ex ? (const void *)k_dogleg<true, true> : (const void *)k_dogleg<true, false>, 256, lds_dg > lds_sc ? lds_dg : lds_sc) : 0;
+    }
     return ISV_OK;
 }
 
 // prof_ev (optional): [max_iter][ISV_PROF_FAMILIES][2] events recorded around the three dominant
 // kernel families on the solve stream, so bench.py can report per-kernel durations measured live.
-int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t *fj, int64_t *counts, hipEvent_t *prof_ev, std::string &err) {
+int isv_solver_enqueue(DevBatch &d, const SolverHost &hc, hipStream_t st, hipStream_t st2, hipEvent_t *fj, int64_t *counts, hipEvent_t *prof_ev, std::string &err) {
     // st2 / fj[4]: side stream + fork/join events: the IMU and prior factor kernels are latency-bound and
     // independent of the reprojection pipeline, so they run beside it and are joined before their consumers
 #define PROF(slot, fam, which) do { if (prof_ev) (void)hipEventRecord(prof_ev[((slot) * ISV_PROF_FAMILIES + (fam)) * 2 + (which)], st); } while (0)
     const size_t NI = (size_t)d.B * (d.N - 1);
     const size_t lds_proj = 4 * proj_lds_doubles_per_wave(d.N, 0) * sizeof(double), lds_proj1 = 4 * proj_lds_doubles_per_wave(d.N, 1) * sizeof(double);
-    if (getenv("ISV_ONE_STREAM")) st2 = st;            // diagnostics: serialise everything on one stream (per-kernel timelines)
+    if (hc.one_stream) st2 = st;            // diagnostics: serialise everything on one stream (per-kernel timelines)
     const size_t lds_bs = build_solve_lds_bytes(d.N, false);
-    const size_t lds_dg = (d.lds_T ? ((size_t)(d.N - 1) * 48 + (size_t)d.n_prior_slots * 16) * sizeof(double) + prior_lds_bytes(d.n_prior_slots, false) : 0) + 2 * (size_t)d.np * sizeof(double);
-    const size_t lds_sc = ((size_t)30 * d.N + 12) * sizeof(double);
+    const size_t lds_dg = dogleg_lds_bytes(d), lds_sc = step_control_lds_bytes(d);
     // dogleg + step control in one kernel while the batch fits ONE resident round of it (it holds fewer workgroups per CU
     // than k_dogleg<false>: at 2048 windows the fused kernel needs a second round and the step is 21 % slower, measured);
     // same arithmetic either way (bitwise, tests/test_gpu_branches.py)
     // (a free extrinsic is only evaluated by the per-window kernels: k_proj_linearize<1> reads the constant one)
     const bool control_in_wg = d.lds_T && ((size_t)d.Ftot <= (size_t)4096 * d.B || d.est_ex);
-    const bool fuse_control = control_in_wg && !getenv("ISV_SPLIT_CONTROL") &&
-                              d.B <= resident_workgroups(d.est_ex ? (const void *)k_dogleg<true, true> : (const void *)k_dogleg<true, false>, 256, lds_dg > lds_sc ? lds_dg : lds_sc);
-    int n_cus = 0;
-    { int dev_id = 0; if (hipGetDevice(&dev_id) != hipSuccess || hipDeviceGetAttribute(&n_cus, hipDeviceAttributeMultiprocessorCount, dev_id) != hipSuccess) { (void)hipGetLastError(); n_cus = 0; } }
+    const bool fuse_control = control_in_wg && !hc.split_control && (size_t)d.B <= hc.res_dogleg_ctl;
+    const int n_cus = hc.n_cus;
     hipLaunchKernelGGL(k_init_state, dim3((d.B + 63) / 64), dim3(64), 0, st, d);
     for (int slot = 0; slot < d.max_iter; slot++) {
         // linearise where needed (k_*_linearize skip windows whose need_linearize == 0 via the tile/window flags)
@@ -667,12 +679,12 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
         hipLaunchKernelGGL(k_prior_linearize<true>, dim3(d.B), dim3(64), prior_lds_bytes(d.n_prior_slots), st2, d, d.pose, d.sb, d.prior_cost, 1);
         HCHK(hipEventRecord(fj[1], st2));
         const bool fused = d.lds_T && d.fused_visual;
-        d.sw_global = (d.sw_part && (d.B > 256 || getenv("ISV_DEBUG_SW_GLOBAL"))) ? 1 : 0;     // more than one workgroup per CU: trade LDS for occupancy
+        d.sw_global = (d.sw_part && (d.B > 256 || hc.debug_sw_global)) ? 1 : 0;     // more than one workgroup per CU: trade LDS for occupancy
         PROF(slot, 0, 0);
         if (fused) {
             // linearisation fused with the Gram products: no Jacobian strip goes to HBM (isv_visual.hip)
             // (eight wavefronts per window while the batch leaves every window a CU of its own: 41 -> 27 us per launch for one window)
-            if (d.B <= n_cus && !getenv("ISV_LG_BATCH_WAVES") && lin_gram_lds_bytes(d.Nr, true, d.est_ex != 0, LG_WAVES_SMALL) <= (size_t)160 * 1024) {
+            if (d.B <= n_cus && !hc.lg_batch_waves && lin_gram_lds_bytes(d.Nr, true, d.est_ex != 0, LG_WAVES_SMALL) <= (size_t)160 * 1024) {
                 if (d.est_ex) hipLaunchKernelGGL((k_lin_gram<true, LG_WAVES_SMALL>), dim3(d.B), dim3(64 * LG_WAVES_SMALL), lin_gram_lds_bytes(d.Nr, !d.sw_global, true, LG_WAVES_SMALL), st, d);
                 else hipLaunchKernelGGL((k_lin_gram<false, LG_WAVES_SMALL>), dim3(d.B), dim3(64 * LG_WAVES_SMALL), lin_gram_lds_bytes(d.Nr, !d.sw_global, false, LG_WAVES_SMALL), st, d);
             } else if (d.est_ex) hipLaunchKernelGGL((k_lin_gram<true, LG_WAVES>), dim3(d.B), dim3(64 * LG_WAVES), lin_gram_lds_bytes(d.Nr, !d.sw_global, true, LG_WAVES), st, d);
@@ -709,7 +721,7 @@ int isv_solver_enqueue(DevBatch &d, hipStream_t st, hipStream_t st2, hipEvent_t 
         if (!d.lds_T) hipLaunchKernelGGL(k_cost_reduce, dim3(d.B), dim3(256), 0, st, d, d.fcost, d.imu_cost, d.prior_cost, d.cost, 1);   // (k_build_solve_sb sums the cost itself)
         PROF(slot, 3, 0);
         // (the window length as a compile-time constant for the benchmark's 11 frames: isv_build_solve_sb.hip)
-        const bool generic_n = getenv("ISV_GENERIC_N") != nullptr;             // (A/B / test hook: the run-time-N instantiations for every N)
+        const bool generic_n = hc.generic_n;             // (A/B / test hook: the run-time-N instantiations for every N)
         if (d.lds_T && generic_n) {
             if (d.N <= 11) hipLaunchKernelGGL((k_build_solve_sb<false, 0>), dim3(d.B), dim3(512), build_solve_sb_bytes(d.N, d.prior_H_sz), st, d);
             else hipLaunchKernelGGL((k_build_solve_sb<true, 0>), dim3(d.B), dim3(512), build_solve_sb_bytes(d.N, d.prior_H_sz), st, d);

@@ -23,8 +23,12 @@ def max_over_ranks(value, dist=None, device="cpu"):
 
 def gather_records(records, out, dist=None):
     """the exchange step: all-gather every rank's [n_local, rec] result records into out [world * n_local, rec]
-    (ncclAllGather on device tensors; ranks hold equally many windows -- pad the last shard if they do not).
+    (ncclAllGather on device tensors).  Every rank must hold EQUALLY many records: unequal shards are refused here
+    rather than left to hang in the collective (bench.py rejects --scaling strong with windows % ranks != 0).
     Enqueued on the current stream; returns `out`."""
+    world = 1 if dist is None or not dist.is_initialized() else dist.get_world_size()
+    if out.shape[0] != world * records.shape[0] or out.shape[1:] != records.shape[1:]:
+        raise ValueError(f"gather_records: out {tuple(out.shape)} is not world ({world}) x records {tuple(records.shape)}")
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         out.copy_(records)
         return out

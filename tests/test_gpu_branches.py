@@ -97,6 +97,34 @@ def test_batch_of_more_than_256_long_windows(oracle):
         big.close(); small.close()
 
 
+def test_batch_beyond_one_resident_round_of_the_control_kernel(oracle):
+    """the library picks kernel VARIANTS from the batch size -- eight-wavefront k_lin_gram while B <= CUs, the step
+    control inside k_dogleg<true> while B fits one resident round of it (4 per CU), k_dogleg<false> + k_step_control beyond.
+    1100 short windows of the benchmark's shape cross both thresholds: every sampled window is bitwise the same window
+    solved in a batch of four (the small-batch variants), and a sample is compared with the oracle."""
+    ids = list(range(2000, 3100))
+    ws = synth.make_windows(ids, n_frames=11, n_vo=5, n_landmarks=16)
+    cap = dict(max_landmarks=16, max_obs=max(w.n_obs for w in ws))
+    big = backend.Backend(11, 5, max_batch=len(ws), **cap)
+    small = backend.Backend(11, 5, max_batch=4, **cap)
+    try:
+        gs = [w.clone() for w in ws]
+        sums, margs = big.optimize_batch(gs)
+        assert big.last_counts()[5] == 0                  # the split control ran (more than one resident round)
+        for k in (0, 555, 1099):
+            o, so, mo = oracle_run(oracle, big.cfg, ws[k])
+            check_window(o, so, gs[k], sums[k])
+            check_marg(mo, margs[k], 5)
+        for k0 in (0, 300, 1096):
+            ref = [w.clone() for w in ws[k0: k0 + 4]]
+            small.optimize_batch(ref)
+            assert small.last_counts()[5] == 1
+            for a, c in zip(gs[k0: k0 + 4], ref):
+                assert np.array_equal(a.state_vector(), c.state_vector())
+    finally:
+        big.close(); small.close()
+
+
 @pytest.mark.parametrize("env", [{"ISV_LEGACY_VISUAL": "1"}, {"ISV_SPLIT_CONTROL": "1"},
                                  {"ISV_LEGACY_VISUAL": "1", "ISV_SPLIT_CONTROL": "1"}, {"ISV_GENERIC_N": "1"},
                                  {"ISV_LG_BATCH_WAVES": "1"}])

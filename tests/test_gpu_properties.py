@@ -1,11 +1,14 @@
-"""Size-independent properties at BASELINE.json's full sizes (GPU), where running the CPU oracle on
-everything would take too long:
+"""Size-independent properties at BASELINE.json's full sizes (GPU), plus full-size oracle comparisons where the oracle
+is quick enough:
   - config 4 batch (1024 x 11-KF/300-landmark windows): every solve finite and cost-decreasing;
     a random sample equals the same windows solved alone BITWISE (owner-computes sums, no atomics);
     reversing the batch order permutes the results and changes nothing else; a sample matches the oracle
   - re-running the resident batch is idempotent (state restored on device)
-  - config 5 shape (20 KF / 2000 landmarks / 30 000 factors, generic global-scratch kernel): runs, cost
-    decreases; a reduced-size stress window (20 KF / 300 landmarks) matches the oracle"""
+  - config 5 (20 KF / 2000 landmarks / 30 000 factors in ONE window; the LDS solver path with the factor-parallel
+    k_proj_linearize<0> + k_sweep_mfma pair and k_rank1_mfma<8, 3>): the FULL-SIZE window against the oracle (trace, accept
+    pattern, termination, states 1e-7, marginalisation), on a tight handle and on an over-sized one
+  - the reference-shaped handle (NUM_OF_F x ALL_BUF_SIZE = 18 000 observations of capacity, as the shim creates it) runs
+    the fused k_lin_gram on ordinary windows"""
 import ctypes as C
 
 import numpy as np
@@ -58,27 +61,80 @@ def test_config4_batch_properties(oracle):
     be.close(); be1.close()
 
 
-def test_config5_stress_shape(oracle):
+def test_config5_full_size_against_oracle(oracle):
+    """BASELINE config 5 at its stated size -- 20 KF / 2000 landmarks / exactly 30 000 reprojection factors in one window --
+    against the oracle (0.3 s on one host core): iteration count, termination, accept pattern, cost trace 1e-7 relative,
+    every state 1e-7, depths, the marginalisation outputs.  Then the same window through a handle with twice the capacity:
+    bitwise (capacity never changes a result)."""
+    from test_gpu_solve import check_marg, check_window
     backend.build()
     w = synth.make_window(0, n_frames=20, n_vo=8, n_landmarks=2000, target_factors=30000)
-    assert w.n_factors == 30000
+    assert w.n_factors == 30000 and w.L == 2000
     be = backend.Backend(20, 8, max_landmarks=2000, max_obs=w.n_obs, max_batch=1)
-    g = w.clone(); s, mg = be.optimize(g)
-    assert s.status == 0 and np.isfinite(s.final_cost) and s.final_cost < 1e-2 * s.initial_cost
-    tc = np.array(s.trace_cost[: s.iterations + 1]); acc = np.array(s.trace_accepted[: s.iterations + 1])
-    assert np.all(np.diff(tc[np.r_[True, acc[1:] == 1]]) < 0)          # accepted steps decrease the cost
-    be.close()
-    # reduced stress window against the oracle (same N / Nvo, generic kernel path)
+    big = backend.Backend(20, 8, max_landmarks=4000, max_obs=2 * w.n_obs, max_batch=2)
+    try:
+        o, so, mo = oracle_run(oracle, be.cfg, w)
+        g = w.clone(); s, mg = be.optimize(g)
+        cnt = be.last_counts()
+        assert cnt[4] == 0 and cnt[1] == 10            # 30 000 factors in one window: the factor-parallel pair, LDS solve
+        assert s.status == 0 and np.isfinite(s.final_cost) and s.final_cost < 1e-2 * s.initial_cost
+        tc = np.array(s.trace_cost[: s.iterations + 1]); acc = np.array(s.trace_accepted[: s.iterations + 1])
+        assert np.all(np.diff(tc[np.r_[True, acc[1:] == 1]]) < 0)          # accepted steps decrease the cost
+        check_window(o, so, g, s)
+        check_marg(mo, mg, 8)
+        assert np.abs(g.lm_depth[: g.L] - o.lm_depth[: o.L]).max() < 1e-6 * np.abs(o.lm_depth[: o.L]).max()
+        print(f"config 5 full size: {s.iterations} iterations, cost {s.initial_cost:.4e} -> {s.final_cost:.6e} (oracle {so.final_cost:.6e}), "
+              f"max |dP| {np.abs(g.Ps - o.Ps).max():.2e}, max |dR| {np.abs(g.Rs - o.Rs).max():.2e}")
+        g2 = w.clone(); big.optimize(g2)
+        assert np.array_equal(g2.state_vector(), g.state_vector())
+    finally:
+        be.close(); big.close()
+    # a second stress window of the same frame counts with ordinary track statistics
     w = synth.make_window(1, n_frames=20, n_vo=8, n_landmarks=300)
     be = backend.Backend(20, 8, max_landmarks=300, max_obs=w.n_obs, max_batch=1)
     o, so, mo = oracle_run(oracle, be.cfg, w)
     g = w.clone(); sg, mg = be.optimize(g)
-    assert sg.iterations == so.iterations and sg.termination == so.termination
-    assert list(sg.trace_accepted[: so.iterations + 1]) == list(so.trace_accepted[: so.iterations + 1])
-    assert np.allclose(np.array(sg.trace_cost[: so.iterations + 1]), np.array(so.trace_cost[: so.iterations + 1]), rtol=1e-7)
-    for name in ("Ps", "Rs", "Vs", "Bas", "Bgs"):
-        assert np.abs(getattr(g, name) - getattr(o, name)).max() < 1e-7, name
+    assert be.last_counts()[4] == 1
+    check_window(o, so, g, sg)
     be.close()
+
+
+def test_reference_shaped_handle_runs_the_fused_kernel(oracle):
+    """VERDICT r2 task 2: the handle the drop-in shim creates (include/isvins_estimator_shim.hpp: ALL_BUF_SIZE = 18, Vo_SIZE = 8,
+    NUM_OF_F = 1000 landmarks, NUM_OF_F x ALL_BUF_SIZE = 18 000 observations, one window per call) must run the round-2
+    kernels on the ~2 000-factor windows the reference solves: the visual path is chosen from the uploaded windows, not from
+    the handle's capacity.  Same bits as a tightly sized handle, parity with the oracle; and a 30 000-factor window through
+    a handle of the same kind takes the factor-parallel pair."""
+    from test_gpu_solve import check_marg, check_window
+    shim = backend.Backend(18, 8)                       # abi.make_config defaults = the shim's capacities
+    assert (shim.cfg.max_landmarks, shim.cfg.max_obs, shim.cfg.max_rollpitch, shim.cfg.max_batch) == (1000, 18000, 9, 1)
+    try:
+        for seed, L in ((5, 300), (6, 450)):
+            w = synth.make_window(seed, n_frames=18, n_vo=8, n_landmarks=L)
+            tight = backend.Backend(18, 8, max_landmarks=L, max_obs=w.n_obs, max_batch=1)
+            try:
+                o, so, mo = oracle_run(oracle, shim.cfg, w)
+                g = w.clone(); s, mg = shim.optimize(g)
+                cnt = shim.last_counts()
+                assert cnt[4] == 1 and cnt[5] == 1, cnt            # k_lin_gram and k_dogleg<true>
+                check_window(o, so, g, s); check_marg(mo, mg, 8)
+                t = w.clone(); tight.optimize(t)
+                assert tight.last_counts()[4] == 1
+                assert np.array_equal(t.state_vector(), g.state_vector())
+            finally:
+                tight.close()
+    finally:
+        shim.close()
+    w = synth.make_window(0, n_frames=20, n_vo=8, n_landmarks=2000, target_factors=30000)
+    be = backend.Backend(20, 8, max_landmarks=2000, max_obs=2 * w.n_obs, max_batch=2)
+    try:
+        small = synth.make_window(2, n_frames=20, n_vo=8, n_landmarks=200)
+        g = small.clone(); be.optimize(g)
+        assert be.last_counts()[4] == 1                  # an ordinary window on the big handle: fused
+        g = w.clone(); be.optimize(g)
+        assert be.last_counts()[4] == 0                  # the 30 000-factor window: the factor-parallel pair
+    finally:
+        be.close()
 
 
 def test_timing_queries_leave_the_handle_usable():
@@ -135,25 +191,38 @@ def test_exchange_step_through_rccl_on_device_buffers(oracle):
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
     try:
-        ws = synth.make_windows(range(400, 416), n_landmarks=40)
-        b = backend.Backend(11, 5, max_landmarks=40, max_obs=max(w.n_obs for w in ws), max_batch=len(ws))
+        # the communicator exists BEFORE the solve is enqueued (its first-call initialisation would otherwise outlast the
+        # solve and hide a missing ordering), the records start as NaN, and nothing synchronises the device between the
+        # enqueue of the solve, the pack and the collective.  torch's current stream here is the legacy default stream,
+        # whose hipStream_t value is 0: the ABI must treat it as a caller stream, not as "the handle's own".
+        warm = torch.ones(8, dtype=torch.float64, device="cuda:0"); warm_out = torch.empty_like(warm)
+        dist.all_gather_into_tensor(warm_out, warm); torch.cuda.synchronize()
+        assert torch.cuda.current_stream().cuda_stream == 0
+        batches = [synth.make_windows(range(400, 416), n_landmarks=40), synth.make_windows(range(416, 432), n_landmarks=40)]
+        b = backend.Backend(11, 5, max_landmarks=40, max_obs=max(w.n_obs for ws in batches for w in ws), max_batch=16)
         try:
-            gs = [w.clone() for w in ws]
-            b.upload(gs); b.run_optimize(sync=False)
             rec = b.record_doubles()
-            records = torch.zeros((len(gs), rec), dtype=torch.float64, device="cuda:0")
-            gathered = torch.full((len(gs), rec), float("nan"), dtype=torch.float64, device="cuda:0")
-            b.pack_results(records.data_ptr(), torch.cuda.current_stream().cuda_stream)
-            dist.all_gather_into_tensor(gathered, records)
-            t = torch.tensor([1.25], dtype=torch.float64, device="cuda:0")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            torch.cuda.synchronize()
-            sums, _ = b.download(gs)
-            out = gathered.cpu().numpy()
-            assert float(t.item()) == 1.25
-            for k, (g, sm) in enumerate(zip(gs, sums)):
-                assert np.array_equal(out[k, :77], g.para_Pose.ravel()) and np.array_equal(out[k, 77:176], g.para_SpeedBias.ravel())
-                assert out[k, 176 + 40] == sm.final_cost and out[k, 176 + 40 + 2] == sm.iterations
+            records = torch.full((16, rec), float("nan"), dtype=torch.float64, device="cuda:0")
+            for ws in batches:                      # two different batches through the same buffers: stale records would show
+                gs = [w.clone() for w in ws]
+                gathered = torch.full((len(gs), rec), float("nan"), dtype=torch.float64, device="cuda:0")
+                b.upload(gs); b.run_optimize(sync=False)
+                b.pack_results(records.data_ptr(), torch.cuda.current_stream().cuda_stream)
+                dist.all_gather_into_tensor(gathered, records)
+                t = torch.tensor([1.25], dtype=torch.float64, device="cuda:0")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                out = gathered.cpu().numpy()        # (orders after the collective on torch's stream only)
+                sums, _ = b.download(gs)
+                assert float(t.item()) == 1.25
+                assert np.isfinite(out).all()
+                for k, (g, sm) in enumerate(zip(gs, sums)):
+                    assert np.array_equal(out[k, :77], g.para_Pose.ravel()) and np.array_equal(out[k, 77:176], g.para_SpeedBias.ravel())
+                    assert out[k, 176 + 40] == sm.final_cost and out[k, 176 + 40 + 2] == sm.iterations
+            # the handle's own stream on request (None -> ISV_STREAM_OF_HANDLE), ordered by sync()
+            b.run_optimize(sync=False)
+            own = torch.full((16, rec), float("nan"), dtype=torch.float64, device="cuda:0")
+            b.pack_results(own.data_ptr(), None); b.sync()
+            assert np.array_equal(own.cpu().numpy(), out)
         finally:
             b.close()
     finally:

@@ -4,7 +4,7 @@ initFactorGraph / backendOptimization.  north_star: ATE within 1e-6 m between th
 import numpy as np
 import pytest
 
-from isvins_amd import abi
+from isvins_amd import abi, backend
 
 import sequence_harness as sh
 
@@ -208,3 +208,61 @@ def test_native_preintegration_matches_the_oracle(oracle):
         assert np.abs(a - b).max() <= 1e-12 * max(1.0, np.abs(b).max()), name
     assert abs(got.sum_dt - ref.pod.sum_dt) < 1e-12
     est.close()
+
+
+def test_failed_solve_reinitialises_the_priors(oracle):
+    """a solve whose result is not finite is not copied into the window, but the window still slides; with
+    MARGIN_OLD and no marginalisation outputs the prior factors would then sit one frame off for every later solve.  The
+    window manager instead sends the sequence back through initFactorGraph at its next solve.  The failure is injected
+    through the solver seam (status = ISV_ERR_NONFINITE on one MARGIN_OLD solve); afterwards every window handed to the
+    solver carries its priors on the right frames, and the run stays close to the run without the failure."""
+    from isvins_amd import estimator as E
+    N, Nvo, n_frames, seed = 11, 5, 26, 0
+    cfg = abi.make_config(N, Nvo, max_landmarks=600, max_obs=6600, max_batch=1)
+    base = sh.oracle_vtbl(oracle, cfg)
+    log = dict(opt=0, init=0, failed_at=None, init_after_failure=None, windows=[])
+    ERR_NONFINITE = [k for k, v in backend.STATUS.items() if v == "ISV_ERR_NONFINITE"][0]
+
+    def opt(ctx, n, ws, sums, margs):
+        rc = base.optimize_batch(ctx, n, ws, sums, margs)
+        for i in range(n):
+            w = ws[i].contents
+            log["windows"].append(dict(pp=w.pose_prior.contents.index, vb=w.vb_prior.contents.index,
+                                       rel=[(w.relpose[k].imu_i, w.relpose[k].imu_j) for k in range(Nvo - 1)],
+                                       rp=[w.rollpitch[k].index for k in range(w.n_rollpitch)], margin_old=w.margin_old))
+            if log["failed_at"] is None and log["opt"] >= 6 and w.margin_old:
+                sums[i].status = ERR_NONFINITE
+                log["failed_at"] = log["opt"]
+        log["opt"] += 1
+        return rc
+
+    def init(ctx, w, s, kld):
+        if log["failed_at"] is not None and log["init_after_failure"] is None:
+            log["init_after_failure"] = log["opt"]
+        log["init"] += 1
+        return base.init_factor_graph(ctx, w, s, kld)
+
+    vt = E.isv_solver_vtbl_t(None, base.triangulate, E.INIT_FN(init), E.OPTIMIZE_FN(opt))
+    est = E.SequenceEstimator(sh.estimator_params(cfg), 1, solver=vt)
+    sh.run_sequences_native(est, N, n_frames, (seed,))
+    ref = E.SequenceEstimator(sh.estimator_params(cfg), 1, solver=sh.oracle_vtbl(oracle, cfg))
+    sh.run_sequences_native(ref, N, n_frames, (seed,))
+    assert log["failed_at"] is not None and est.failed_solves(0) == 1 and ref.failed_solves(0) == 0
+    assert log["init"] == 2 and log["init_after_failure"] == log["failed_at"] + 1       # the very next solve re-initialises
+    for k, w in enumerate(log["windows"]):
+        assert w["pp"] == 0 and w["vb"] == Nvo - 1 and w["rel"] == [(i, i + 1) for i in range(Nvo - 1)], (k, w)
+        assert all(0 <= i < Nvo for i in w["rp"]) and len(set(w["rp"])) == len(w["rp"]), (k, w)
+    # the window right after the re-initialisation starts without roll/pitch factors, like the first one ever solved
+    assert log["windows"][log["failed_at"] + 1]["rp"] == []
+    a, b = est.trajectory(0, 1), ref.trajectory(0, 1)
+    assert len(a) == len(b) == n_frames - (N - 1) and np.isfinite(a).all()
+    assert np.abs(a[: log["failed_at"], 1:4] - b[: log["failed_at"], 1:4]).max() == 0.0     # identical up to the failure
+    # afterwards: the re-initialised run is a different (gauge re-anchored, scale re-estimated) but equally valid
+    # estimate -- judged against the simulator's ground truth, beside the run that never failed
+    sim = sh.Simulator(seed)
+    truth = np.array([sim.traj.p(h) for h in a[:, 0]])
+    err_a, err_b = np.linalg.norm(a[:, 1:4] - truth, axis=1).max(), np.linalg.norm(b[:, 1:4] - truth, axis=1).max()
+    print(f"max position error against ground truth: {err_a:.3f} m with the injected failure, {err_b:.3f} m without")
+    assert err_a < max(3.0 * err_b, 0.25)
+    assert est.status(0)["solver_flag"] == 1
+    est.close(); ref.close()
