@@ -367,7 +367,7 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
     const isv_config_t &c = h->cfg;
     const int N = c.n_frames, Nd = h->d.N;
     auto &s = h->h;
-    size_t L = 0, F = 0, T = 0, Fmax = 0;
+    size_t L = 0, F = 0, T = 0, Fmax = 0, Lmax = 0;
     std::vector<size_t> t_off((size_t)n + 1);
     for (int b = 0; b < n; b++) {
         const isv_window_t *w = ws[b];
@@ -389,6 +389,7 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
         if (tn) T++;
         L += (size_t)w->n_landmarks;
         if (F - (size_t)s.f_off[b] > Fmax) Fmax = F - (size_t)s.f_off[b];
+        if ((size_t)w->n_landmarks > Lmax) Lmax = (size_t)w->n_landmarks;
     }
     t_off[n] = T;
     {
@@ -421,7 +422,11 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
     // optimize there).  The rule looks at the LONGEST window of the upload: a window of <= ISV_FUSED_MAX_FACTORS factors
     // gives the same bits alone and inside any batch of such windows.  (a free extrinsic only exists in k_lin_gram<true>;
     // ISV_LEGACY_VISUAL: test / measurement hook for the unfused pair)
-    d.fused_visual = (c.estimate_extrinsic || !(h->hc.legacy_visual || Fmax > ISV_FUSED_MAX_FACTORS)) ? 1 : 0;
+    // k_lin_gram also stages the window's inverse depths and host points in LDS (32 B per landmark): the longest window must fit
+    d.lg_lcap = (int32_t)((Lmax + 31) / 32 * 32);
+    const bool lg_fits = lin_gram_lds_bytes(c.n_frames, true, c.estimate_extrinsic != 0, LG_WAVES, d.lg_lcap) <= ISV_LDS_PER_CU;
+    if (c.estimate_extrinsic && !lg_fits) { h->err = "estimate_extrinsic = 1: a window has more landmarks than k_lin_gram<true> can stage in LDS"; return ISV_ERR_CAPACITY; }
+    d.fused_visual = (c.estimate_extrinsic || !(h->hc.legacy_visual || Fmax > ISV_FUSED_MAX_FACTORS || !lg_fits)) ? 1 : 0;
     hipStream_t st = h->stream;
 #define H2D(dst, src, cnt) HIPCHK(h, hipMemcpyAsync(dst, src, sizeof(*(src)) * (size_t)(cnt), hipMemcpyHostToDevice, st))
     const size_t NI = (size_t)n * (Nd - 1);

@@ -39,7 +39,8 @@ __global__ void k_triangulate(DevBatch d);
 #define LG_WAVES 4
 #define LG_WAVES_SMALL 8
 template <bool EX, int LGW> __global__ void k_lin_gram(DevBatch d);     // EX: the extrinsic is estimated (J_ex, one more block row)
-size_t lin_gram_lds_bytes(int N, bool partials_in_lds, bool ex, int waves);
+size_t lin_gram_lds_bytes(int N, bool partials_in_lds, bool ex, int waves, int lcap);
+#define ISV_LDS_PER_CU ((size_t)160 * 1024)
 __global__ void k_imu_raw(DevBatch d, const double *pose_src, const double *sb_src, int gate);
 __global__ void k_imu_weight(DevBatch d, double *cost_out, int gate);
 #define ISV_PROF_FAMILIES 6      // 0 = k_proj_linearize<0>, 1 = k_sweep_mfma, 2 = k_rank1_mfma, 3 = k_build_solve*, 4 = k_dogleg, 5 = k_step_control

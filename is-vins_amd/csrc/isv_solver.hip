@@ -624,11 +624,10 @@ int isv_solver_alloc(DevBatch &d, SolverHost &hc, size_t B, size_t L, size_t F, 
         SETLDS((k_rank1_mfma<4, 1, 64, 1, false>), lds_r1); SETLDS((k_rank1_mfma<4, 1, 64, 1, true>), lds_r1); SETLDS((k_rank1_mfma<5, 1, 64, 1, false>), lds_r1); SETLDS((k_rank1_mfma<5, 1, 64, 1, true>), lds_r1); SETLDS((k_rank1_mfma<6, 2, 64, 1, false>), lds_r1); SETLDS((k_rank1_mfma<6, 2, 64, 1, true>), lds_r1);
         SETLDS((k_rank1_mfma<7, 2, 64, 1, false>), lds_r1); SETLDS((k_rank1_mfma<7, 2, 64, 1, true>), lds_r1); SETLDS((k_rank1_mfma<8, 3, 64, 1, false>), lds_r1); SETLDS((k_rank1_mfma<8, 3, 64, 1, true>), lds_r1);
         SETLDS(k_sweep_mfma, lds_sw);
-        if (d.est_ex) SETLDS((k_lin_gram<true, LG_WAVES>), lin_gram_lds_bytes(d.Nr, true, true, LG_WAVES));
-        else SETLDS((k_lin_gram<false, LG_WAVES>), lin_gram_lds_bytes(d.Nr, true, false, LG_WAVES));
-        if (lin_gram_lds_bytes(d.Nr, true, d.est_ex != 0, LG_WAVES_SMALL) <= (size_t)160 * 1024) {      // (the small-batch variant where its tiles fit)
-            if (d.est_ex) SETLDS((k_lin_gram<true, LG_WAVES_SMALL>), lin_gram_lds_bytes(d.Nr, true, true, LG_WAVES_SMALL));
-            else SETLDS((k_lin_gram<false, LG_WAVES_SMALL>), lin_gram_lds_bytes(d.Nr, true, false, LG_WAVES_SMALL));
+        {   // k_lin_gram: up to the whole CU (the launch sizes its LDS from the uploaded windows: isv_batch_upload)
+            auto cap = [&](int waves) { const size_t b = lin_gram_lds_bytes(d.Nr, true, d.est_ex != 0, waves, d.max_lm); return b < ISV_LDS_PER_CU ? b : ISV_LDS_PER_CU; };
+            if (d.est_ex) { SETLDS((k_lin_gram<true, LG_WAVES>), cap(LG_WAVES)); SETLDS((k_lin_gram<true, LG_WAVES_SMALL>), cap(LG_WAVES_SMALL)); }
+            else { SETLDS((k_lin_gram<false, LG_WAVES>), cap(LG_WAVES)); SETLDS((k_lin_gram<false, LG_WAVES_SMALL>), cap(LG_WAVES_SMALL)); }
         }
         if (d.N == 11) SETLDS((k_build_solve_sb<false, 11>), lds_sb);
         if (d.N <= 11) SETLDS((k_build_solve_sb<false, 0>), lds_sb);
@@ -684,11 +683,14 @@ int isv_solver_enqueue(DevBatch &d, const SolverHost &hc, hipStream_t st, hipStr
         if (fused) {
             // linearisation fused with the Gram products: no Jacobian strip goes to HBM (isv_visual.hip)
             // (eight wavefronts per window while the batch leaves every window a CU of its own: 41 -> 27 us per launch for one window)
-            if (d.B <= n_cus && !hc.lg_batch_waves && lin_gram_lds_bytes(d.Nr, true, d.est_ex != 0, LG_WAVES_SMALL) <= (size_t)160 * 1024) {
-                if (d.est_ex) hipLaunchKernelGGL((k_lin_gram<true, LG_WAVES_SMALL>), dim3(d.B), dim3(64 * LG_WAVES_SMALL), lin_gram_lds_bytes(d.Nr, !d.sw_global, true, LG_WAVES_SMALL), st, d);
-                else hipLaunchKernelGGL((k_lin_gram<false, LG_WAVES_SMALL>), dim3(d.B), dim3(64 * LG_WAVES_SMALL), lin_gram_lds_bytes(d.Nr, !d.sw_global, false, LG_WAVES_SMALL), st, d);
-            } else if (d.est_ex) hipLaunchKernelGGL((k_lin_gram<true, LG_WAVES>), dim3(d.B), dim3(64 * LG_WAVES), lin_gram_lds_bytes(d.Nr, !d.sw_global, true, LG_WAVES), st, d);
-            else hipLaunchKernelGGL((k_lin_gram<false, LG_WAVES>), dim3(d.B), dim3(64 * LG_WAVES), lin_gram_lds_bytes(d.Nr, !d.sw_global, false, LG_WAVES), st, d);
+            const bool ex = d.est_ex != 0;
+            const int lgw = (d.B <= n_cus && !hc.lg_batch_waves && lin_gram_lds_bytes(d.Nr, !d.sw_global, ex, LG_WAVES_SMALL, d.lg_lcap) <= ISV_LDS_PER_CU) ? LG_WAVES_SMALL : LG_WAVES;
+            const size_t lds_lg = lin_gram_lds_bytes(d.Nr, !d.sw_global, ex, lgw, d.lg_lcap);
+            if (lgw == LG_WAVES_SMALL) {
+                if (ex) hipLaunchKernelGGL((k_lin_gram<true, LG_WAVES_SMALL>), dim3(d.B), dim3(64 * LG_WAVES_SMALL), lds_lg, st, d);
+                else hipLaunchKernelGGL((k_lin_gram<false, LG_WAVES_SMALL>), dim3(d.B), dim3(64 * LG_WAVES_SMALL), lds_lg, st, d);
+            } else if (ex) hipLaunchKernelGGL((k_lin_gram<true, LG_WAVES>), dim3(d.B), dim3(64 * LG_WAVES), lds_lg, st, d);
+            else hipLaunchKernelGGL((k_lin_gram<false, LG_WAVES>), dim3(d.B), dim3(64 * LG_WAVES), lds_lg, st, d);
             counts[0]++; counts[4] = 1;
         } else if (d.n_tiles > 0) { hipLaunchKernelGGL(k_proj_linearize<0>, dim3((d.n_tiles + 3) / 4), dim3(256), lds_proj, st, d, d.pose, d.lam, d.fcost, 1); counts[0]++; }
         PROF(slot, 0, 1);

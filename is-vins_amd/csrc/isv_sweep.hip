@@ -142,7 +142,8 @@ typedef double double4v __attribute__((ext_vector_type(4)));
 // CU (<5, 4, 32, 4>, <5, 2, 32, 8>: a 1024-window launch in one round) measured 138 / 143 us against 96-100 us for one
 // wavefront per tile: the per-workgroup MFMA chain gets longer than the round it saves.
 template <int NT, int TPW, int R1_CHUNK, int MINW, bool EX>
-__global__ __launch_bounds__(64 * ((NT * (NT + 1) / 2 + TPW - 1) / TPW), MINW) void k_rank1_mfma(DevBatch d) {
+// (NT = 5, the benchmark's 11 frames: 15 wavefronts per workgroup, and two workgroups share a CU only at <= 64 VGPRs)
+__device__ __forceinline__ void rank1_body(DevBatch &d) {
     constexpr int ntiles = NT * (NT + 1) / 2, nwaves = (ntiles + TPW - 1) / TPW;
     constexpr int ld = 16 * NT, nthr = 64 * nwaves;
     constexpr int R1_PF = (R1_CHUNK * ld + nthr - 1) / nthr;   // panel elements per thread and pass
@@ -169,16 +170,35 @@ __global__ __launch_bounds__(64 * ((NT * (NT + 1) / 2 + TPW - 1) / TPW), MINW) v
         TI[j] = I; TJ[j] = q - I * (I + 1) / 2;
     }
     const int i = lane & 15, kq = lane >> 4;
+#ifdef ISV_STAMP
+    unsigned long long t_last = wall_clock64();
+#define R1STAMP(k) do { if (t == 0) { unsigned long long now_ = wall_clock64(); d.dbg[(size_t)w * 64 + (k)] += (double)(now_ - t_last); t_last = now_; } } while (0)
+#else
+#define R1STAMP(k) do {} while (0)
+#endif
+    // landmark metadata first: host | k << 8 | (first factor - f_off[w]) << 16 -- everything the prologue and the passes index with
+    for (int l = t; l < Lw; l += nthr) sM[l] = d.lm_meta[l0 + l];
+    __syncthreads();
     if (d.fused_visual) {
         // Landmark scalars (what SchurEliminator needs per e-block) from the per-factor pieces k_lin_gram left, summed in
         // the landmark's own factor order: E = J_l^T J_l, g_l = J_l^T r, host-frame w = sum J_i^T J_l.  (The unfused
         // path does this inside k_proj_linearize<0>, where a landmark's factors are adjacent lanes.)
-        // four threads per landmark: part 0 sums {E, g} and forms the scalars, parts 1..3 sum one pair of the host w each
+        // four threads per landmark: part 0 sums {E, g} and forms the scalars, parts 1..3 sum one pair of the host w each.
+        // The pieces of up to four factors are loaded TOGETHER (clamped addresses, masked adds: same order, same bits);
+        // one load per loop trip cost a memory latency per factor of the track.
         for (int q = t; q < 4 * Lw; q += nthr) {
-            const int l = q >> 2, part = q & 3, gl = l0 + l, kf = d.lm_k[gl] - 1;
-            const double2 *fl = (const double2 *)(d.flm + (size_t)d.lm_f0[gl] * 8) + part;
+            const int l = q >> 2, part = q & 3, gl = l0 + l;
+            const unsigned m0 = sM[l];
+            const int kf = (int)((m0 >> 8) & 255) - 1, f0 = fw0 + (int)(m0 >> 16);
+            const double2 *fl = (const double2 *)(d.flm + (size_t)f0 * 8) + part;
             double2 acc = fl[0];
-            for (int o = 1; o < kf; o++) { const double2 a = fl[4 * o]; acc.x += a.x; acc.y += a.y; }
+            for (int o = 1; o < kf; o += 4) {
+                double2 a[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) a[j] = fl[4 * (o + j < kf ? o + j : kf - 1)];
+#pragma unroll
+                for (int j = 0; j < 4; j++) if (o + j < kf) { acc.x += a[j].x; acc.y += a[j].y; }
+            }
             if (part == 0) {
                 double sl;
                 if (st.iteration == 0) { sl = 1.0 / (1.0 + sqrt(acc.x)); d.scale_l[gl] = sl; }
@@ -186,10 +206,11 @@ __global__ __launch_bounds__(64 * ((NT * (NT + 1) / 2 + TPW - 1) / TPW), MINW) v
                 const double Es = sl * sl * acc.x;
                 const double Dl2 = fmin(fmax(Es, 1e-6), 1e32);
                 const double Dl = sqrt(Dl2);
-                d.lm_cg[gl] = make_double2(sl * sl / (Es + st.mu * Dl2), acc.y);
+                const double2 cg = make_double2(sl * sl / (Es + st.mu * Dl2), acc.y);
+                d.lm_cg[gl] = cg; sCG[l] = cg;
                 d.lmE[gl] = acc.x; d.lmG[gl] = acc.y; d.diag_l[gl] = Dl; d.grad_l[gl] = sl * acc.y / Dl;
             } else {
-                ((double2 *)(d.W + (size_t)(d.lm_f0[gl] + gl) * 6))[part - 1] = acc;     // host observation slot
+                ((double2 *)(d.W + (size_t)(f0 + gl) * 6))[part - 1] = acc;     // host observation slot
             }
         }
         if (EX) {                                    // the extrinsic's w of every landmark: sum over its factors of J_ex^T J_l
@@ -201,40 +222,71 @@ __global__ __launch_bounds__(64 * ((NT * (NT + 1) / 2 + TPW - 1) / TPW), MINW) v
                 ((double2 *)(d.Wex + (size_t)gl * 6))[part] = acc;
             }
         }
-        __syncthreads();                                   // the host slots and lm_cg are read below by other threads
+    } else {
+        for (int l = t; l < Lw; l += nthr) sCG[l] = d.lm_cg[l0 + l];
     }
-    for (int l = t; l < Lw; l += nthr) { sM[l] = d.lm_meta[l0 + l]; sCG[l] = d.lm_cg[l0 + l]; }
-    __syncthreads();
-    // panel element e of a pass: row r = e / ld (landmark lb + r), column c = e % ld
+    __syncthreads();                                       // the host slots (global) and sCG are read below by other threads
+    R1STAMP(32);
+    // panel element e of a pass: row r = e / ld (landmark lb + r), column c = e % ld.
+    // BRANCH-FREE (round 3): every element issues its (clamped, always valid) load unconditionally and selects afterwards.  Written
+    // with `if`s the compiler kept each load inside its own branch with an s_waitcnt vmcnt(0) before the next one (the
+    // destination register is cleared on the other path), so the R1_PF gathers of a pass ran one HBM / L2 latency after
+    // the other -- and the "prefetch" of the next pass stalled before the MFMAs it was meant to hide behind.
     double pf[R1_PF];
+    unsigned pfsel = 0;                                            // 2 bits per element: 0 zero, 1 the loaded w entry, 2 g_l (LDS), 3 the extrinsic's w (loaded)
+    const double *Wwin = d.W + (size_t)(fw0 + l0) * 6;             // this window's packed w vectors
+    // (when the workgroup size is a multiple of the panel width -- NT <= 5 -- a thread's elements share ONE column and their
+    // rows step by nthr / ld: two loop-invariant registers instead of a hoisted (row, column) pair per element)
+    constexpr bool r1_aligned = nthr % ld == 0;
+    const int r_first = t / ld, c_first = t - r_first * ld;
     auto fetch = [&](int lb) {
+        pfsel = 0;
 #pragma unroll
         for (int u2 = 0; u2 < R1_PF; u2++) {
-            const int e = t + u2 * nthr, r = e / ld, c = e - r * ld, l = lb - l0 + r;
-            double v = 0.0;
-            if (e < R1_CHUNK * ld && l < Lw) {
-                const unsigned m0 = sM[l];
-                const int h6 = 6 * (int)(m0 & 255), k6 = 6 * (int)((m0 >> 8) & 255);
-                if (c >= h6 && c < h6 + k6) v = d.W[(size_t)(fw0 + (int)(m0 >> 16) + l0 + l) * 6 + (c - h6)];
-                else if (c == n6) v = sCG[l].y;
-                else if (EX && c >= 6 * d.Nr && c < n6) v = d.Wex[(size_t)(l0 + l) * 6 + (c - 6 * d.Nr)];     // pseudo-frame columns = the extrinsic block
+            const int e = t + u2 * nthr;
+            const int r = r1_aligned ? r_first + u2 * (nthr / ld) : e / ld, c = r1_aligned ? c_first : e - r * ld, l = lb - l0 + r;
+            const bool valid = e < R1_CHUNK * ld && l < Lw;
+            const int lc = valid ? l : 0;                          // (Lw >= 1 inside the pass loop)
+            const unsigned m0 = sM[lc];
+            const int h6 = 6 * (int)(m0 & 255), k6 = 6 * (int)((m0 >> 8) & 255);
+            const bool inw = valid && c >= h6 && c < h6 + k6;
+            unsigned sel = inw ? 1u : ((valid && c == n6) ? 2u : 0u);
+            if (EX) {                                              // pseudo-frame columns = the extrinsic block
+                const bool inx = valid && !inw && c >= 6 * d.Nr && c < n6;
+                const double *src = inx ? d.Wex + (size_t)(l0 + lc) * 6 + (c - 6 * d.Nr) : Wwin + (inw ? ((int)(m0 >> 16) + lc) * 6 + (c - h6) : 0);
+                pf[u2] = *src;
+                if (inx) sel = 3u;
+            } else {
+                // (a 32-bit byte offset from the uniform base: one address VGPR per gather instead of two -- the kernel must stay within 64)
+                pf[u2] = *(const double *)((const char *)Wwin + (size_t)(unsigned)(inw ? (((int)(m0 >> 16) + lc) * 6 + (c - h6)) * 8 : 0));
             }
-            pf[u2] = v;
+            pfsel |= sel << (2 * u2);
+        }
+    };
+    // the selection happens when the pass is written to LDS, i.e. AFTER the MFMAs of the previous pass: the loads stay in flight meanwhile
+    auto commit = [&](int lb) {
+#pragma unroll
+        for (int u2 = 0; u2 < R1_PF; u2++) {
+            const int e = t + u2 * nthr;
+            const int r = r1_aligned ? r_first + u2 * (nthr / ld) : e / ld, c = r1_aligned ? c_first : e - r * ld;
+            const unsigned sel = (pfsel >> (2 * u2)) & 3u;
+            double v = (sel & 1u) ? pf[u2] : 0.0;
+            if (sel == 2u) v = sCG[lb - l0 + r].y;
+            if (e < R1_CHUNK * ld) sW[r * lds_ld + c] = v;
         }
     };
     double4v acc[TPW];
 #pragma unroll
     for (int j = 0; j < TPW; j++) acc[j] = double4v{0, 0, 0, 0};
-    fetch(l0);
+    if (Lw > 0) fetch(l0);
     for (int lb = l0; lb < l1; lb += R1_CHUNK) {
         __syncthreads();                                   // the previous pass has been consumed
-#pragma unroll
-        for (int u2 = 0; u2 < R1_PF; u2++) {
-            const int e = t + u2 * nthr, r = e / ld, c = e - r * ld;
-            if (e < R1_CHUNK * ld) sW[r * lds_ld + c] = pf[u2];
-        }
+        R1STAMP(33);
+        commit(lb);
         __syncthreads();
+        R1STAMP(34);
         if (lb + R1_CHUNK < l1) fetch(lb + R1_CHUNK);      // in flight during the MFMAs below
+        R1STAMP(35);
 #pragma unroll 4
         for (int k4 = 0; k4 < R1_CHUNK; k4 += 4) {
             const int l = k4 + kq, lg = lb - l0 + l;
@@ -245,23 +297,39 @@ __global__ __launch_bounds__(64 * ((NT * (NT + 1) / 2 + TPW - 1) / TPW), MINW) v
                 acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[j], 0, 0, 0);
             }
         }
+        R1STAMP(36);
     }
     // C/D layout of v_mfma_f64_16x16x4: col = lane & 15, row = (lane >> 4) + 4 * reg
+    // (the four read-modify-writes of a tile: all loads first -- clamped, always valid -- then the stores)
 #pragma unroll
     for (int j = 0; j < TPW; j++) {
         if (wv * TPW + j >= ntiles) continue;
+        int off[4]; double cur[4];
 #pragma unroll
         for (int reg = 0; reg < 4; reg++) {
             const int R = 16 * TI[j] + kq + 4 * reg, Cc = 16 * TJ[j] + i;
+            off[reg] = -1;
             if (R < n6 && Cc < n6 && R >= Cc) {
                 const int fa = Cc / 6, c = Cc - 6 * fa, fb = R / 6, r = R - 6 * fb, bo = fb - fa;
-                if (bo > 0 || c <= r) out[tvis_col(fa, N) + bo * 36 + r * 6 + c] -= acc[j][reg];
+                if (bo > 0 || c <= r) off[reg] = tvis_col(fa, N) + bo * 36 + r * 6 + c;
             } else if (R == n6 && Cc < n6) {
-                out[tail + 12 * N + Cc] = -acc[j][reg];    // reduced right-hand side bs = -sum c_l g_l w_l
+                off[reg] = -2 - Cc;                        // reduced right-hand side bs = -sum c_l g_l w_l  (plain store)
             }
+            cur[reg] = out[off[reg] >= 0 ? off[reg] : 0];
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            if (off[reg] >= 0) out[off[reg]] = cur[reg] - acc[j][reg];
+            else if (off[reg] <= -2) out[tail + 12 * N + (-2 - off[reg])] = -acc[j][reg];
         }
     }
+    R1STAMP(37);
 }
+template <int NT, int TPW, int R1_CHUNK, int MINW, bool EX>
+__global__ __launch_bounds__(64 * ((NT * (NT + 1) / 2 + TPW - 1) / TPW), MINW) void k_rank1_mfma(DevBatch d) { rank1_body<NT, TPW, R1_CHUNK, MINW, EX>(d); }
+// NT = 5 (the benchmark's 11 frames): 15 wavefronts per workgroup, and two workgroups share a CU only at eight wavefronts
+// per SIMD, i.e. <= 64 VGPRs -- the launch bounds alone let the compiler settle at 66-70 (occupancy 7: ONE workgroup per CU)
+template <> __global__ __launch_bounds__(960) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_rank1_mfma<5, 1, 64, 1, false>(DevBatch d) { rank1_body<5, 1, 64, 1, false>(d); }
 template __global__ void k_rank1_mfma<1, 1, 64, 1, false>(DevBatch);
 template __global__ void k_rank1_mfma<1, 1, 64, 1, true>(DevBatch);
 template __global__ void k_rank1_mfma<2, 1, 64, 1, false>(DevBatch);
@@ -270,7 +338,6 @@ template __global__ void k_rank1_mfma<3, 1, 64, 1, false>(DevBatch);
 template __global__ void k_rank1_mfma<3, 1, 64, 1, true>(DevBatch);
 template __global__ void k_rank1_mfma<4, 1, 64, 1, false>(DevBatch);
 template __global__ void k_rank1_mfma<4, 1, 64, 1, true>(DevBatch);
-template __global__ void k_rank1_mfma<5, 1, 64, 1, false>(DevBatch);
 template __global__ void k_rank1_mfma<5, 1, 64, 1, true>(DevBatch);
 template __global__ void k_rank1_mfma<6, 2, 64, 1, false>(DevBatch);
 template __global__ void k_rank1_mfma<6, 2, 64, 1, true>(DevBatch);

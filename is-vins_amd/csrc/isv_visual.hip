@@ -25,9 +25,10 @@ typedef double double4g __attribute__((ext_vector_type(4)));
 __host__ __device__ constexpr int lg_xld(bool ex) { return ex ? 39 : 27; }
 #define LGSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
 
-size_t lin_gram_lds_bytes(int N /* real frames */, bool partials_in_lds, bool ex, int waves) {
+// lcap: landmarks per window the launch stages (inverse depths + host points: 4 doubles each)
+size_t lin_gram_lds_bytes(int N /* real frames */, bool partials_in_lds, bool ex, int waves, int lcap) {
     const size_t NP = (size_t)N * (N - 1) / 2;
-    return ((size_t)N * 12 + 12 + (size_t)waves * 16 * lg_xld(ex) + (partials_in_lds ? NP * 84 : 0) + (NP + 2) / 2 + 1) * sizeof(double);
+    return ((size_t)N * 12 + 12 + (size_t)waves * 16 * lg_xld(ex) + (partials_in_lds ? NP * 84 : 0) + (NP + 2) / 2 + 1 + (NP + 1) / 2 + 1 + 4 * (size_t)lcap) * sizeof(double);
 }
 
 // LGW wavefronts per window: 4 for batches (158 VGPRs -> three workgroups per CU), 8 while every window has a CU of its own
@@ -39,6 +40,15 @@ __global__ __launch_bounds__(64 * LGW, LGW > 4 ? 2 : (EX ? 2 : 3)) void k_lin_gr
     const int w = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const SolveState &st = d.st[w];
     if (st.termination != ISV_TERM_RUNNING || !st.need_linearize) return;
+#ifdef ISV_STAMP
+    // phase stamps of wavefront 0 (scripts/stamp_bs.py), accumulated in registers and written once at the end: a
+    // read-modify-write of d.dbg per stamp would cost a memory round trip of its own
+    unsigned long long t_last = wall_clock64(), st_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    constexpr int st_slot[12] = {24, 25, 26, 27, 28, 29, 30, 57, 58, 59, 60, 61};
+#define LGSTAMP(k) do { unsigned long long now_ = wall_clock64(); _Pragma("unroll") for (int q_ = 0; q_ < 12; q_++) if (st_slot[q_] == (k)) st_acc[q_] += now_ - t_last; t_last = now_; } while (0)
+#else
+#define LGSTAMP(k) do {} while (0)
+#endif
     // N: the REAL frames (pairs, pose blocks of the factors); Nd: pose blocks of the reduced system (+ the extrinsic's
     // pseudo-frame, index N, when it is estimated)
     const int N = d.Nr, Nd = d.N, NP = N * (N - 1) / 2;
@@ -49,10 +59,14 @@ __global__ __launch_bounds__(64 * LGW, LGW > 4 ? 2 : (EX ? 2 : 3)) void k_lin_gr
     double *Pjj = d.sw_global ? d.sw_part + (size_t)w * NP * 84 : pbase;      // pair partials (see k_sweep_mfma)
     double *Phh = Pjj + NP * 36, *Pgj = Phh + NP * 36, *Pgh = Pgj + NP * 6;
     int *offL = (int *)(d.sw_global ? pbase : pbase + NP * 84);                // [NP + 1] group starts
-    const int fw0 = d.f_off[w];
+    double *after_off = (double *)offL + (NP + 2) / 2 + 1;
+    int *sSched = (int *)after_off;                                            // [NP] the pair -> wavefront schedule (h | j << 8 | p << 16)
+    double *sLam = after_off + (NP + 1) / 2 + 1;                               // [lg_lcap] inverse depths of the window's landmarks at x
+    double *sPts = sLam + d.lg_lcap;                                           // [lg_lcap][3] host-frame points
+    const int fw0 = d.f_off[w], l0 = d.lm_off[w], Lw = d.lm_off[w + 1] - l0;
     const int2 *prec = (const int2 *)d.pg_rec + fw0;   // the factor stream: wavefront-major, then pair group (upload order)
     const double2 *ppts = (const double2 *)d.pg_pts + fw0;
-    const int *sched = d.pg_sched + (size_t)w * NP, *soff = d.pg_sched_off + (size_t)w * (ISV_SWEEP_WAVES + 1);
+    const int *sched = sSched, *soff = d.pg_sched_off + (size_t)w * (ISV_SWEEP_WAVES + 1);
     double *out = d.Tvis + (size_t)w * d.tvis_sz;
     if (t < N) {
         const double *p = d.pose + ((size_t)w * Nd + t) * 7;
@@ -68,7 +82,15 @@ __global__ __launch_bounds__(64 * LGW, LGW > 4 ? 2 : (EX ? 2 : 3)) void k_lin_gr
         sEx[9] = e[0]; sEx[10] = e[1]; sEx[11] = e[2];
     }
     for (int e = t; e <= NP; e += blockDim.x) offL[e] = d.pg_off[(size_t)w * (NP + 1) + e];
+    // (round 3) everything a factor GATHERS by landmark index -- the inverse depth and the host point -- and the schedule
+    // the group bookkeeping reads are staged once, with coalesced loads: inside the factor loop they were dependent
+    // global loads (record -> landmark -> depth / point; one sched[] word per finished group), a memory latency each,
+    // on a kernel whose chunks otherwise compute from registers and LDS
+    for (int e = t; e < NP; e += blockDim.x) sSched[e] = d.pg_sched[(size_t)w * NP + e];
+    for (int e = t; e < Lw; e += blockDim.x) sLam[e] = d.lam[l0 + e];
+    for (int e = t; e < 3 * Lw; e += blockDim.x) sPts[e] = d.lm_pts_i[(size_t)l0 * 3 + e];
     __syncthreads();
+    LGSTAMP(24);
     const int i = lane & 15, kq = lane >> 4, row2 = kq & 1, fsel = kq >> 1;
     // element of the LDS factor row that operand column i takes: J_i row row2 | J_j row row2 | r[row2]
     const int eoff = i < 6 ? 2 + row2 * 6 + i : (i < 12 ? 14 + row2 * 6 + (i - 6) : row2);
@@ -119,20 +141,27 @@ __global__ __launch_bounds__(64 * LGW, LGW > 4 ? 2 : (EX ? 2 : 3)) void k_lin_gr
     int gend = s0 + (q < q1 ? gsize(q) : 0);
     double4g acc = {0, 0, 0, 0}, acc2 = {0, 0, 0, 0}, acc3 = {0, 0, 0, 0};
     const int eoffx = 26 + row2 * 6 + (i < 6 ? i : 0);  // J_ex row row2, column i of the LDS factor row
+    // the factor stream (record + observing view's point) is loaded ONE CHUNK AHEAD: nothing in it depends on the arithmetic
+    int2 rc_n = make_int2(0, 0); double2 pj_n = make_double2(0, 0);
+    auto issue = [&](int pos) { const int p = pos + lane < s1 ? pos + lane : s1 - 1; rc_n = prec[p]; pj_n = ppts[p]; };
+    if (s0 < s1) issue(s0);
+    LGSTAMP(25);
     for (int pos = s0; pos < s1; pos += 64) {
         const int cnt = (s1 - pos) < 64 ? (s1 - pos) : 64;
         double r0 = 0, r1 = 0, Ji[12], Jj[12], Jl[2], Jex[12];
+        const int2 rc = rc_n;                              // {global landmark, f_rel | h << 16 | j << 24}
+        const double2 pj = pj_n;
+        if (pos + 64 < s1) issue(pos + 64);
         if (lane < cnt) {
-            const int2 rc = prec[pos + lane];              // {global landmark, f_rel | h << 16 | j << 24}
             const int h = (rc.y >> 16) & 255, j = (rc.y >> 24) & 255;
             double ric[9], tic[3], Ri[9], Rj[9], Pi[3], Pj[3];
 #pragma unroll
             for (int k = 0; k < 9; k++) { ric[k] = sEx[k]; Ri[k] = sPose[h * 12 + k]; Rj[k] = sPose[j * 12 + k]; }
 #pragma unroll
             for (int k = 0; k < 3; k++) { tic[k] = sEx[9 + k]; Pi[k] = sPose[h * 12 + 9 + k]; Pj[k] = sPose[j * 12 + 9 + k]; }
-            const double2 pj = ppts[pos + lane];
-            const double *pi3 = d.lm_pts_i + (size_t)rc.x * 3;
-            proj_factor<true>(Ri, Pi, Rj, Pj, ric, tic, d.proj_sqrt_info, d.lam[rc.x], pi3[0], pi3[1], pi3[2], pj.x, pj.y, r0, r1, Ji, Jj, Jl);
+            const double *pi3 = sPts + (rc.x - l0) * 3;
+            const double lam_l = sLam[rc.x - l0];
+            proj_factor<true>(Ri, Pi, Rj, Pj, ric, tic, d.proj_sqrt_info, lam_l, pi3[0], pi3[1], pi3[2], pj.x, pj.y, r0, r1, Ji, Jj, Jl);
             // CauchyLoss(1.0): rho = log(1 + s); the Corrector scales r and J by sqrt(rho') = 1 / sqrt(1 + s)
             const double sum = 1.0 + (r0 * r0 + r1 * r1);
             const double sc = sqrt(fmax(1.0 / sum, 2.2250738585072014e-308));
@@ -154,7 +183,7 @@ __global__ __launch_bounds__(64 * LGW, LGW > 4 ? 2 : (EX ? 2 : 3)) void k_lin_gr
             fl[2] = make_double2(Ji[2] * Jl[0] + Ji[8] * Jl[1], Ji[3] * Jl[0] + Ji[9] * Jl[1]);
             fl[3] = make_double2(Ji[4] * Jl[0] + Ji[10] * Jl[1], Ji[5] * Jl[0] + Ji[11] * Jl[1]);
             if (EX) {                                   // J_ex (projection_factor.cpp:100-111), same corrector scale; its piece of the landmark's w
-                proj_jac_ex(Ri, Pi, Rj, Pj, ric, tic, d.proj_sqrt_info, d.lam[rc.x], pi3[0], pi3[1], pi3[2], Jex);
+                proj_jac_ex(Ri, Pi, Rj, Pj, ric, tic, d.proj_sqrt_info, lam_l, pi3[0], pi3[1], pi3[2], Jex);
 #pragma unroll
                 for (int k = 0; k < 12; k++) Jex[k] *= sc;
                 double2 *fx = (double2 *)(d.flmx + f * 6);
@@ -163,6 +192,7 @@ __global__ __launch_bounds__(64 * LGW, LGW > 4 ? 2 : (EX ? 2 : 3)) void k_lin_gr
                 fx[2] = make_double2(Jex[4] * Jl[0] + Jex[10] * Jl[1], Jex[5] * Jl[0] + Jex[11] * Jl[1]);
             }
         }
+        LGSTAMP(26);
         // Gram: 16 factors per round through the wave-private LDS tile
         for (int rq = 0; rq * 16 < cnt; rq++) {
             if ((lane >> 4) == rq) {
@@ -176,6 +206,7 @@ __global__ __launch_bounds__(64 * LGW, LGW > 4 ? 2 : (EX ? 2 : 3)) void k_lin_gr
                 }
             }
             LGSYNC();
+            LGSTAMP(57);
             double v[8], vx[8];
 #pragma unroll
             for (int u2 = 0; u2 < 8; u2++) v[u2] = colok ? sX[(2 * u2 + fsel) * LG_XLD + eoff] : 0.0;
@@ -183,6 +214,7 @@ __global__ __launch_bounds__(64 * LGW, LGW > 4 ? 2 : (EX ? 2 : 3)) void k_lin_gr
 #pragma unroll
                 for (int u2 = 0; u2 < 8; u2++) vx[u2] = i < 6 ? sX[(2 * u2 + fsel) * LG_XLD + eoffx] : 0.0;
             }
+            LGSTAMP(58);
             const int rs = pos + 16 * rq, re = (rs + 16) < (pos + cnt) ? (rs + 16) : (pos + cnt);
             int cur = rs;
             while (cur < re) {                              // the segments of this round, one per group it touches
@@ -211,10 +243,14 @@ __global__ __launch_bounds__(64 * LGW, LGW > 4 ? 2 : (EX ? 2 : 3)) void k_lin_gr
                     gend += q < q1 ? gsize(q) : 0;
                 }
             }
+            LGSTAMP(59);
             LGSYNC();
         }
+        LGSTAMP(27);
     }
+    LGSTAMP(28);
     __syncthreads();
+    LGSTAMP(29);
     // fold the pair partials into the diagonal blocks, the Jacobi-scaling diagonal and the gradient (fixed order)
     const int tail = 36 * (Nd * (Nd + 1) / 2);
     auto pidx = [N](int hh, int jj) { return hh * N - hh * (hh + 1) / 2 + (jj - hh - 1); };
@@ -255,6 +291,10 @@ __global__ __launch_bounds__(64 * LGW, LGW > 4 ? 2 : (EX ? 2 : 3)) void k_lin_gr
             out[tail + 6 * Nd + 6 * a + r] = s;
         }
     }
+    LGSTAMP(30);
+#ifdef ISV_STAMP
+    if (t == 0) for (int q_ = 0; q_ < 12; q_++) d.dbg[(size_t)w * 64 + st_slot[q_]] += (double)st_acc[q_];
+#endif
 }
 template __global__ void k_lin_gram<false, LG_WAVES>(DevBatch);
 template __global__ void k_lin_gram<true, LG_WAVES>(DevBatch);

@@ -506,8 +506,13 @@ static void vector2double(const isv_window_t *w, int N, double *pose, double *sb
 }
 
 /* pseudo-measurement update after the solve  src/estimator.cpp:1133-1144 */
+/* diagnostic hook (tests/test_sequence_long.py, the sensitivity study): skip the update() calls, i.e. keep every prior's
+ * pseudo-measurement where marginalisation put it.  NOT the reference's behaviour. */
+static int g_no_update = 0;
+void isvo_debug_no_update(int on) { g_no_update = on; }
 static void update_priors(const isv_config_t *cfg, isv_window_t *w, const double *pose, const double *sb) {
     int v = cfg->n_vo - 1;
+    if (g_no_update) return;
     isvo_linear9_update(w->vb_prior, w->Vs + 3 * v, w->Bas + 3 * v, w->Bgs + 3 * v, sb + 9 * v);
     isvo_se3prior_update(w->pose_prior, w->Ps, w->Rs, pose);
     for (int i = 0; i < cfg->n_vo - 1; i++)

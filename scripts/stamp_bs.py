@@ -9,6 +9,7 @@ ws = synth.make_windows(range(B))
 be = backend.Backend(11, 5, max_landmarks=300, max_obs=1600, max_batch=B)
 be.upload(ws)
 be.run_optimize()
+print(f"B = {B}")
 dbg = be.debug_read(21, B * 64).reshape(B, 64)
 names = {0: "load Tvis + zero", 1: "imu gather", 2: "priors", 3: "scale+qT", 4: "sb chains", 5: "Y Y^T", 6: "pose cholesky", 7: "solves", 8: "outputs"}
 tot = dbg[:, :9].sum(1)
@@ -18,3 +19,8 @@ for k, nm in names.items():
 print("  total           ", np.median(tot) / 10 / 100)
 for k, nm in {48: "dogleg: backsub + first loops", 49: "dogleg: step, candidate", 50: "dogleg: norms + stage + sync", 51: "dogleg: w0 imu raw residual", 56: "dogleg: w1 priors", 52: "dogleg: wait for slowest wave", 53: "dogleg: weighted + sums", 20: "chol: panel (w0)", 21: "chol: barrier after panel", 22: "chol: w0 diag update + factor", 23: "chol: barrier after trailing", 40: "sweep: prologue (sched/off -> LDS)", 41: "sweep: wave 0 main loop", 42: "sweep: barrier wait", 43: "sweep: stage 2"}.items():
     print(f"  {nm:36s} {np.median(dbg[:, k]) / 10 / 100:8.1f} us")
+for k, nm in {24: "lin_gram: staging (pose, sched, lam, pts) + sync", 25: "lin_gram: soff / wst + first stream load issued", 26: "lin_gram: factor evaluation + stores (wave 0, all chunks)",
+              27: "lin_gram: LDS tile + MFMA rounds (wave 0) [rest: trailing sync]", 57: "lin_gram:   tile write + sync", 58: "lin_gram:   operand reads", 59: "lin_gram:   MFMA segments + group flushes", 28: "lin_gram: (loop exit)", 29: "lin_gram: wait for the slowest wavefront", 30: "lin_gram: fold + Tvis stores",
+              32: "rank1: meta + landmark scalars prologue", 33: "rank1: barrier (pass consumed)", 34: "rank1: commit (wait gathers, LDS write) + barrier", 35: "rank1: issue next gathers",
+              36: "rank1: MFMA loop", 37: "rank1: epilogue (Tvis read-modify-write)"}.items():
+    print(f"  {nm:60s} {np.median(dbg[:, k]) / 10 / 100:8.1f} us")
