@@ -20,7 +20,7 @@ __global__ void k_cost_reduce(DevBatch d, const double *fcost, const double *imu
 // kernel VARIANT of a launch is then chosen from these and the uploaded batch: see isv_solver_enqueue)
 struct SolverHost {
     int n_cus = 0;                    // compute units of the handle's device
-    size_t res_dogleg_ctl = 0;        // resident workgroups of k_dogleg<true, EX> at this handle's LDS size
+    int dogleg_per_cu_regs = 0;       // workgroups of k_dogleg<true, EX> per CU by registers (the LDS bound is applied per enqueue)
     bool one_stream = false;          // ISV_ONE_STREAM: diagnostics, everything on one stream
     bool split_control = false;       // ISV_SPLIT_CONTROL: k_dogleg<false> + k_step_control
     bool generic_n = false;           // ISV_GENERIC_N: run-time-N instantiation of k_build_solve_sb for every N

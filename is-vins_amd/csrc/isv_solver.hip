@@ -47,15 +47,25 @@ __global__ void k_init_state(DevBatch d) {
 }
 
 // ------------------------------------------------------------------------------------------
-// block-wide deterministic sum of per-thread partials
-template <int NT>
-DEV double block_sum(double v, double *red, int t) {
-    red[t] = v;
+// block-wide deterministic sums of per-thread partials, K values at once (256 threads = four wavefronts): a shuffle tree
+// inside every wavefront, then the four wavefront partials in fixed order through LDS -- TWO block barriers per call.
+// (Rounds 1-2 summed one value at a time through an eight-level LDS tree with a block barrier per level: the nine sums
+// of a dogleg + step-control pass cost ~90 barriers, a fifth of k_dogleg<true>'s critical path.)
+template <int K>
+DEV void block_sums(double (&v)[K], double *red /* >= 4 K doubles */, int t) {
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off, 64);
+    }
+    if ((t & 63) == 0) {
+#pragma unroll
+        for (int k = 0; k < K; k++) red[(t >> 6) * K + k] = v[k];
+    }
     __syncthreads();
-    for (int off = NT / 2; off > 0; off >>= 1) { if (t < off) red[t] += red[t + off]; __syncthreads(); }
-    const double r = red[0];
+#pragma unroll
+    for (int k = 0; k < K; k++) v[k] = ((red[k] + red[K + k]) + red[2 * K + k]) + red[3 * K + k];
     __syncthreads();
-    return r;
 }
 
 // DoglegStrategy::ComputeTraditionalDoglegStep + undo of the scalings + Evaluator::Plus.
@@ -90,22 +100,35 @@ DEV void dogleg_body(DevBatch &d, const int w, const int t, double *red) {
         for (int i = t; i < n; i += 256) { zs[i] = d.zp[(size_t)w * n + i]; us[i] = d.up[(size_t)w * n + i]; }
         __syncthreads();
         const double mu = st.mu;
+        const int fw0 = d.f_off[w];
         for (int l = l0 + t; l < l1; l += 256) {
-            const int h = d.lm_host[l], k = d.lm_k[l];
-            const double *wv = d.W + (size_t)(d.lm_f0[l] + l) * 6;     // slots of frames h .. h + k - 1
+            // (round 3: ONE metadata word instead of three dependent index loads; the landmark scalars are requested
+            // before the w loop; two observations' w vectors are in flight per trip -- clamped address, masked add: same
+            // order of additions, same bits)
+            const unsigned m0 = d.lm_meta[l];
+            const int h = (int)(m0 & 255), k = (int)((m0 >> 8) & 255);
+            const double *wv = d.W + (size_t)(fw0 + (int)(m0 >> 16) + l) * 6;     // slots of frames h .. h + k - 1
+            const double sl = d.scale_l[l], E = d.lmE[l], gl = d.lmG[l], Dl = d.diag_l[l];
             double wz = 0, wu = 0;        // w_l^T z_p, w_l^T u_p
-            for (int o = 0; o < k; o++) {
-                const double2 w01 = *reinterpret_cast<const double2 *>(wv + 6 * o), w23 = *reinterpret_cast<const double2 *>(wv + 6 * o + 2),
-                              w45 = *reinterpret_cast<const double2 *>(wv + 6 * o + 4);
+            for (int o = 0; o < k; o += 2) {
+                const int o1 = o + 1 < k ? o + 1 : o;
+                const double2 a01 = *reinterpret_cast<const double2 *>(wv + 6 * o), a23 = *reinterpret_cast<const double2 *>(wv + 6 * o + 2),
+                              a45 = *reinterpret_cast<const double2 *>(wv + 6 * o + 4);
+                const double2 b01 = *reinterpret_cast<const double2 *>(wv + 6 * o1), b23 = *reinterpret_cast<const double2 *>(wv + 6 * o1 + 2),
+                              b45 = *reinterpret_cast<const double2 *>(wv + 6 * o1 + 4);
                 const double *z = zs + 15 * (h + o), *u = us + 15 * (h + o);
-                wz += w01.x * z[0] + w01.y * z[1] + w23.x * z[2] + w23.y * z[3] + w45.x * z[4] + w45.y * z[5];
-                wu += w01.x * u[0] + w01.y * u[1] + w23.x * u[2] + w23.y * u[3] + w45.x * u[4] + w45.y * u[5];
+                wz += a01.x * z[0] + a01.y * z[1] + a23.x * z[2] + a23.y * z[3] + a45.x * z[4] + a45.y * z[5];
+                wu += a01.x * u[0] + a01.y * u[1] + a23.x * u[2] + a23.y * u[3] + a45.x * u[4] + a45.y * u[5];
+                if (o + 1 < k) {
+                    const double *z1 = zs + 15 * (h + o + 1), *u1 = us + 15 * (h + o + 1);
+                    wz += b01.x * z1[0] + b01.y * z1[1] + b23.x * z1[2] + b23.y * z1[3] + b45.x * z1[4] + b45.y * z1[5];
+                    wu += b01.x * u1[0] + b01.y * u1[1] + b23.x * u1[2] + b23.y * u1[3] + b45.x * u1[4] + b45.y * u1[5];
+                }
             }
             if (EX) {                                         // the extrinsic block (pseudo-frame Nr) couples to every landmark
                 const double *we = d.Wex + (size_t)l * 6, *z = zs + 15 * d.Nr, *u = us + 15 * d.Nr;
                 for (int c6 = 0; c6 < 6; c6++) { wz += we[c6] * z[c6]; wu += we[c6] * u[c6]; }
             }
-            const double sl = d.scale_l[l], E = d.lmE[l], gl = d.lmG[l], Dl = d.diag_l[l];
             const double Es = sl * sl * E, Dl2 = Dl * Dl;
             // scaled-space y_l = (g'_l - w'_l^T y_p) / (E'_l + mu D_l^2),  w'^T y_p = s_l w^T (Sc_p y_p) = s_l wz
             const double yl = (sl * gl - sl * wz) / (Es + mu * Dl2);
@@ -119,8 +142,9 @@ DEV void dogleg_body(DevBatch &d, const int w, const int t, double *red) {
         a += gl * gl; b += nl * nl; c += gl * nl; e += d.lm_aterm[l];
     }
     DSTAMP(48);
-    const double g2 = block_sum<256>(a, red, t), gn2 = block_sum<256>(b, red, t), gdotgn = block_sum<256>(c, red, t);
-    const double aterm = block_sum<256>(e, red, t);
+    double sums4[4] = {a, b, c, e};
+    block_sums<4>(sums4, red, t);
+    const double g2 = sums4[0], gn2 = sums4[1], gdotgn = sums4[2], aterm = sums4[3];
     double alpha = st.alpha;
     if (st.fresh) alpha = g2 / (st.qT + aterm);
     const double radius = st.radius, gn_norm = sqrt(gn2), g_norm = sqrt(g2);
@@ -151,7 +175,9 @@ DEV void dogleg_body(DevBatch &d, const int w, const int t, double *red) {
         d.delta_l[l] = dl;
         d.clam[l] = d.lam[l] + dl;
     }
-    const double sn_tot = block_sum<256>(sn, red, t);
+    double sums1[1] = {sn};
+    block_sums<1>(sums1, red, t);
+    const double sn_tot = sums1[0];
     if (need_norm) step_norm_scaled = sqrt(sn_tot);
     __syncthreads();
     // candidate = Plus(x, delta); ambient step norm and |x|
@@ -166,7 +192,9 @@ DEV void dogleg_body(DevBatch &d, const int w, const int t, double *red) {
     }
     for (int l = l0 + t; l < l1; l += 256) { const double df = d.lam[l] - d.clam[l]; dn += df * df; xn += d.lam[l] * d.lam[l]; }
     DSTAMP(49);
-    const double dn_tot = block_sum<256>(dn, red, t), xn_tot = block_sum<256>(xn, red, t);
+    double sums2[2] = {dn, xn};
+    block_sums<2>(sums2, red, t);
+    const double dn_tot = sums2[0], xn_tot = sums2[1];
     if (t == 0) {
         st.alpha = alpha; st.dogleg_step_norm = step_norm_scaled;
         st.step_norm = sqrt(dn_tot); st.x_norm = sqrt(xn_tot);
@@ -308,7 +336,16 @@ DEV void step_control_body(DevBatch &d, const int w, const int t, double *cl, do
     if (st.step_valid) {
         double s = 0, m = 0;
         if (FUSED) {
-            double *sC = cl, *sEx = cl + N * 12, *sX = sEx + 12, *sD = sX + N * 12;
+            double *sC = cl, *sEx = cl + N * 12, *sX = sEx + 12, *sD = sX + N * 12, *sL = sD + N * 6;
+            const int l0w = d.lm_off[w], Lww = d.lm_off[w + 1] - l0w;
+            const bool stage = d.ctl_stage_lm != 0;
+            if (stage) {          // what the factor loop gathers by landmark index: host point | candidate, current inverse depth | step
+                for (int e = t; e < Lww; e += 256) {
+                    const double *pp = d.lm_pts_i + (size_t)(l0w + e) * 3;
+                    sL[6 * e] = pp[0]; sL[6 * e + 1] = pp[1]; sL[6 * e + 2] = pp[2];
+                    sL[6 * e + 3] = d.clam[l0w + e]; sL[6 * e + 4] = d.lam[l0w + e]; sL[6 * e + 5] = d.delta_l[l0w + e];
+                }
+            }
             if (t < N) {
                 const double *p = d.cpose + ((size_t)w * N + t) * 7;
                 double R[9]; q_to_R(q_from_pose(p), R);
@@ -340,17 +377,30 @@ DEV void step_control_body(DevBatch &d, const int w, const int t, double *cl, do
             for (int k = 0; k < 9; k++) ric[k] = exC[k];
 #pragma unroll
             for (int k = 0; k < 3; k++) tic[k] = exC[9 + k];
-            for (int f = d.f_off[w] + t; f < d.f_off[w + 1]; f += 256) {
-                const FactorRec rec = d.f_rec[f];
+            // the factor records and observations are read one trip ahead (nothing in them depends on the arithmetic)
+            const int f_end = d.f_off[w + 1];
+            FactorRec rec_n = {0, 0}; double2 pj_n = make_double2(0, 0);
+            auto issue = [&](int f) { const int fc = f < f_end ? f : f_end - 1; rec_n = d.f_rec[fc]; pj_n = *reinterpret_cast<const double2 *>(d.f_pts_j + (size_t)fc * 2); };
+            if (d.f_off[w] < f_end) issue(d.f_off[w] + t);
+            for (int f = d.f_off[w] + t; f < f_end; f += 256) {
+                const FactorRec rec = rec_n;
+                const double2 pj = pj_n;
+                if (f + 256 < f_end) issue(f + 256);
                 const int fi = rec.ij & 255, fj = (rec.ij >> 8) & 255;
-                const double *pi3 = d.lm_pts_i + (size_t)rec.lm * 3;
-                const double2 pj = *reinterpret_cast<const double2 *>(d.f_pts_j + (size_t)f * 2);
+                double pi3[3], clam_l, lam_l, dl_l;
+                if (stage) {
+                    const double *q6 = sL + 6 * (rec.lm - l0w);
+                    pi3[0] = q6[0]; pi3[1] = q6[1]; pi3[2] = q6[2]; clam_l = q6[3]; lam_l = q6[4]; dl_l = q6[5];
+                } else {
+                    const double *pp = d.lm_pts_i + (size_t)rec.lm * 3;
+                    pi3[0] = pp[0]; pi3[1] = pp[1]; pi3[2] = pp[2]; clam_l = d.clam[rec.lm]; lam_l = d.lam[rec.lm]; dl_l = d.delta_l[rec.lm];
+                }
                 double Ri[9], Rj[9], Pi[3], Pj[3], r0, r1, Ji[12], Jj[12], Jl[2];
 #pragma unroll
                 for (int k = 0; k < 9; k++) { Ri[k] = sC[fi * 12 + k]; Rj[k] = sC[fj * 12 + k]; }
 #pragma unroll
                 for (int k = 0; k < 3; k++) { Pi[k] = sC[fi * 12 + 9 + k]; Pj[k] = sC[fj * 12 + 9 + k]; }
-                proj_factor<false>(Ri, Pi, Rj, Pj, ric, tic, d.proj_sqrt_info, d.clam[rec.lm], pi3[0], pi3[1], pi3[2], pj.x, pj.y, r0, r1, Ji, Jj, Jl);
+                proj_factor<false>(Ri, Pi, Rj, Pj, ric, tic, d.proj_sqrt_info, clam_l, pi3[0], pi3[1], pi3[2], pj.x, pj.y, r0, r1, Ji, Jj, Jl);
                 s += 0.5 * log(1.0 + (r0 * r0 + r1 * r1));          // CauchyLoss(1.0): rho = log(1 + s)
                 // model cost change piece (J delta)^T (r + J delta / 2) at x by the directional derivative
                 double rx0, rx1, m0, m1;
@@ -364,11 +414,11 @@ DEV void step_control_body(DevBatch &d, const int w, const int t, double *cl, do
                     for (int k = 0; k < 9; k++) ricX[k] = exX[k];
 #pragma unroll
                     for (int k = 0; k < 3; k++) ticX[k] = exX[9 + k];
-                    proj_residual_dir_ex(Ri, Pi, Rj, Pj, ricX, ticX, d.proj_sqrt_info, d.lam[rec.lm], pi3[0], pi3[1], pi3[2], pj.x, pj.y,
-                                         sD + fi * 6, sD + fj * 6, sD + d.Nr * 6, d.delta_l[rec.lm], rx0, rx1, m0, m1);
+                    proj_residual_dir_ex(Ri, Pi, Rj, Pj, ricX, ticX, d.proj_sqrt_info, lam_l, pi3[0], pi3[1], pi3[2], pj.x, pj.y,
+                                         sD + fi * 6, sD + fj * 6, sD + d.Nr * 6, dl_l, rx0, rx1, m0, m1);
                 } else
-                proj_residual_dir(Ri, Pi, Rj, Pj, ric, tic, d.proj_sqrt_info, d.lam[rec.lm], pi3[0], pi3[1], pi3[2], pj.x, pj.y,
-                                  sD + fi * 6, sD + fj * 6, d.delta_l[rec.lm], rx0, rx1, m0, m1);
+                proj_residual_dir(Ri, Pi, Rj, Pj, ric, tic, d.proj_sqrt_info, lam_l, pi3[0], pi3[1], pi3[2], pj.x, pj.y,
+                                  sD + fi * 6, sD + fj * 6, dl_l, rx0, rx1, m0, m1);
                 const double rp = 1.0 / (1.0 + (rx0 * rx0 + rx1 * rx1));       // corrector: r, J scaled by sqrt(rho')
                 m += rp * (m0 * (rx0 + m0 / 2.0) + m1 * (rx1 + m1 / 2.0));
             }
@@ -377,7 +427,9 @@ DEV void step_control_body(DevBatch &d, const int w, const int t, double *cl, do
         }
         for (int i = t; i < N - 1; i += 256) { s += d.imu_cost_c[(size_t)w * (N - 1) + i]; m += d.imu_model[(size_t)w * (N - 1) + i]; }
         for (int i = t; i < d.n_prior_slots; i += 256) { s += d.prior_cost_c[(size_t)w * d.n_prior_slots + i]; m += d.prior_model[(size_t)w * d.n_prior_slots + i]; }
-        S = block_sum<256>(s, red, t); M = block_sum<256>(m, red, t);
+        double sm[2] = {s, m};
+        block_sums<2>(sm, red, t);
+        S = sm[0]; M = sm[1];
     }
     if (t == 0) {
         s_accept = 0;
@@ -566,7 +618,10 @@ static std::mutex g_lds_attr_mutex;
 static size_t dogleg_lds_bytes(const DevBatch &d) {
     return (d.lds_T ? ((size_t)(d.N - 1) * 48 + (size_t)d.n_prior_slots * 16) * sizeof(double) + prior_lds_bytes(d.n_prior_slots, false) : 0) + 2 * (size_t)d.np * sizeof(double);
 }
-static size_t step_control_lds_bytes(const DevBatch &d) { return ((size_t)30 * d.N + 12) * sizeof(double); }
+// the step control: candidate / current poses, the tangent step, and (when they fit) the per-landmark data its factor loop gathers
+// -- host point, candidate and current inverse depth, the landmark's step: 6 doubles each (d.ctl_stage_lm, set per enqueue)
+static size_t step_control_lds_bytes(const DevBatch &d) { return ((size_t)30 * d.N + 12 + (d.ctl_stage_lm ? 6 * (size_t)d.lg_lcap : 0)) * sizeof(double); }
+#define ISV_CTL_STAGE_MAX_BYTES ((size_t)36 * 1024)      // staged only while four workgroups still share a CU
 
 // workgroups of kernel `fn` (threads per workgroup, dynamic LDS bytes) the current device holds at once
 static size_t resident_workgroups(const void *fn, int threads, size_t lds) {
@@ -643,8 +698,10 @@ int isv_solver_alloc(DevBatch &d, SolverHost &hc, size_t B, size_t L, size_t F, 
     // device figures the per-launch variant choice needs (once per handle, not per isv_batch_optimize)
     if (hipDeviceGetAttribute(&hc.n_cus, hipDeviceAttributeMultiprocessorCount, dev_) != hipSuccess) { (void)hipGetLastError(); hc.n_cus = 0; }
     {
-        const size_t lds_dg = dogleg_lds_bytes(d), lds_sc = step_control_lds_bytes(d);
-        hc.res_dogleg_ctl = d.lds_T ? resident_workgroups(d.est_ex ? (const void *)k_dogleg<true, true> : (const void *)k_dogleg<true, false>, 256, lds_dg > lds_sc ? lds_dg : lds_sc) : 0;
+        // k_dogleg<true, EX> by registers alone (a small dynamic LDS request); the LDS bound is applied per enqueue
+        int per_cu = 0;
+        if (d.lds_T && hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, d.est_ex ? (const void *)k_dogleg<true, true> : (const void *)k_dogleg<true, false>, 256, 1024) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
+        hc.dogleg_per_cu_regs = per_cu;
     }
     return ISV_OK;
 }
@@ -659,13 +716,18 @@ int isv_solver_enqueue(DevBatch &d, const SolverHost &hc, hipStream_t st, hipStr
     const size_t lds_proj = 4 * proj_lds_doubles_per_wave(d.N, 0) * sizeof(double), lds_proj1 = 4 * proj_lds_doubles_per_wave(d.N, 1) * sizeof(double);
     if (hc.one_stream) st2 = st;            // diagnostics: serialise everything on one stream (per-kernel timelines)
     const size_t lds_bs = build_solve_lds_bytes(d.N, false);
+    d.ctl_stage_lm = (6 * (size_t)d.lg_lcap * sizeof(double) <= ISV_CTL_STAGE_MAX_BYTES) ? 1 : 0;
     const size_t lds_dg = dogleg_lds_bytes(d), lds_sc = step_control_lds_bytes(d);
+    const size_t lds_dgc = lds_dg > lds_sc ? lds_dg : lds_sc;
+    // workgroups of k_dogleg<true> a CU holds: registers (hc) and LDS (dynamic + the 2 KB of static reduction space)
+    const size_t dg_by_lds = ISV_LDS_PER_CU / (lds_dgc + 2304);
+    const size_t res_dogleg_ctl = (size_t)hc.n_cus * ((size_t)hc.dogleg_per_cu_regs < dg_by_lds ? (size_t)hc.dogleg_per_cu_regs : dg_by_lds);
     // dogleg + step control in one kernel while the batch fits ONE resident round of it (it holds fewer workgroups per CU
     // than k_dogleg<false>: at 2048 windows the fused kernel needs a second round and the step is 21 % slower, measured);
     // same arithmetic either way (bitwise, tests/test_gpu_branches.py)
     // (a free extrinsic is only evaluated by the per-window kernels: k_proj_linearize<1> reads the constant one)
     const bool control_in_wg = d.lds_T && ((size_t)d.Ftot <= (size_t)4096 * d.B || d.est_ex);
-    const bool fuse_control = control_in_wg && !hc.split_control && (size_t)d.B <= hc.res_dogleg_ctl;
+    const bool fuse_control = control_in_wg && !hc.split_control && (size_t)d.B <= res_dogleg_ctl;
     const int n_cus = hc.n_cus;
     hipLaunchKernelGGL(k_init_state, dim3((d.B + 63) / 64), dim3(64), 0, st, d);
     for (int slot = 0; slot < d.max_iter; slot++) {
@@ -735,8 +797,8 @@ int isv_solver_enqueue(DevBatch &d, const SolverHost &hc, hipStream_t st, hipStr
         PROF(slot, 3, 1);
         PROF(slot, 4, 0);
         if (fuse_control) {
-            if (d.est_ex) hipLaunchKernelGGL((k_dogleg<true, true>), dim3(d.B), dim3(256), lds_dg > lds_sc ? lds_dg : lds_sc, st, d);
-            else hipLaunchKernelGGL((k_dogleg<true, false>), dim3(d.B), dim3(256), lds_dg > lds_sc ? lds_dg : lds_sc, st, d);
+            if (d.est_ex) hipLaunchKernelGGL((k_dogleg<true, true>), dim3(d.B), dim3(256), lds_dgc, st, d);
+            else hipLaunchKernelGGL((k_dogleg<true, false>), dim3(d.B), dim3(256), lds_dgc, st, d);
             counts[5] = 1;
         } else if (d.est_ex) hipLaunchKernelGGL((k_dogleg<false, true>), dim3(d.B), dim3(256), lds_dg, st, d);
         else hipLaunchKernelGGL((k_dogleg<false, false>), dim3(d.B), dim3(256), lds_dg, st, d);
