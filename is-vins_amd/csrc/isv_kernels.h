@@ -28,6 +28,9 @@ struct SolverHost {
     bool debug_sw_global = false;     // ISV_DEBUG_SW_GLOBAL: pair partials in the global scratch for every launch
     bool legacy_visual = false;       // ISV_LEGACY_VISUAL: the unfused k_proj_linearize<0> + k_sweep_mfma pair
     bool no_persistent = false;       // ISV_NO_PERSISTENT: never the one-launch solve of small batches
+    bool no_update = false;           // ISV_DEBUG_NO_UPDATE (sensitivity study, tests/test_sequence_long.py; the oracle has the same
+                                      // hook): skip the update() of the prior factors' pseudo-measurements after the solve
+                                      // (src/estimator.cpp:1133-1144).  NOT the reference's behaviour.
 };
 int isv_solver_alloc(DevBatch &d, SolverHost &hc, size_t B, size_t L, size_t F, std::vector<void *> &allocs, std::string &err);
 int isv_solver_enqueue(DevBatch &d, const SolverHost &hc, hipStream_t st, hipStream_t st2, hipEvent_t *fj, int64_t *counts, hipEvent_t *prof_ev, std::string &err);

@@ -667,6 +667,7 @@ int isv_solver_alloc(DevBatch &d, SolverHost &hc, size_t B, size_t L, size_t F, 
     hc.generic_n = getenv("ISV_GENERIC_N") != nullptr; hc.lg_batch_waves = getenv("ISV_LG_BATCH_WAVES") != nullptr;
     hc.debug_sw_global = getenv("ISV_DEBUG_SW_GLOBAL") != nullptr; hc.legacy_visual = getenv("ISV_LEGACY_VISUAL") != nullptr;
     hc.no_persistent = getenv("ISV_NO_PERSISTENT") != nullptr;
+    hc.no_update = getenv("ISV_DEBUG_NO_UPDATE") != nullptr;
     if (d.lds_T && (sw_global || hc.debug_sw_global)) TRYA(dal(&d.sw_part, B * n_pairs * 84, allocs, err));
     d.marg_scratch_sz = 26;
     TRYA(dal(&d.marg_scratch, L * 26, allocs, err));
@@ -831,7 +832,7 @@ int isv_solver_enqueue(DevBatch &d, const SolverHost &hc, hipStream_t st, hipStr
         HCHK(hipGetLastError());
         return ISV_OK;
     }
-    hipLaunchKernelGGL(k_finalize, dim3(d.B), dim3(64), 0, st, d, 1);
+    hipLaunchKernelGGL(k_finalize, dim3(d.B), dim3(64), 0, st, d, hc.no_update ? 0 : 1);
     // MargForward and MargBackward are independent: run them side by side
     hipLaunchKernelGGL(k_marg_clear, dim3(d.B), dim3(64), 0, st, d);
     HCHK(hipEventRecord(fj[0], st)); HCHK(hipStreamWaitEvent(st2, fj[0], 0));

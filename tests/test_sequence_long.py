@@ -3,21 +3,29 @@ the dataset, OpenCV and Ceres are absent from the image, so a simulated 6-DoF fi
 frames, 200 Hz IMU, ~190 tracked features per frame -- is pushed through the reference's compile-time shape
 (ALL_BUF_SIZE = 18, Vo_SIZE = 8, NUM_OF_F = 1000): 2383 solved frames, both slideWindow branches hundreds of times.
 
-What can and cannot agree to 1e-6 m.  The estimator as the reference configures it is SENSITIVE to rounding on such a
-stream: ~93 % of the solves stop at NUM_ITERATIONS = 10 with the cost still falling (every prior factor, the linear
-speed/bias prior included, sits under CauchyLoss(1.0), src/estimator.cpp:1102-1117, so the accelerometer-bias valley of
-a 0.9 s window flattens as the estimate moves along it), and a capped, unconverged solve hands its path-dependent
-result to the next frame.  The CPU oracle run twice with bootstrap positions that differ by 1e-12 m drifts apart to
-1e-7 m after ~100 frames and to centimetres after ~300 (the control measured below): two implementations that are not
-bitwise identical -- the reference's Ceres build included -- cannot stay within 1e-6 m of each other over 2000 frames.
-So parity is established the way that IS possible, and the free-running drift is reported beside the control:
+What can and cannot agree to 1e-6 m (round 3: measured, not argued).  The estimator as the reference configures it is
+SENSITIVE to rounding on such a stream: the CPU oracle run twice with bootstrap positions that differ by 1e-12 m
+separates to 1e-7 m after ~100 frames, to centimetres after ~300 and to decimetres by the end.  Round 2 blamed the
+iteration cap (95 % of the solves stop at NUM_ITERATIONS = 10).  That was incomplete: with max_num_iterations = 60 on
+both sides 86 % of the solves end on a tolerance and the oracle separates from itself just as fast (study 2b).  The
+amplifier is the update() of the prior factors' pseudo-measurements after every solve (src/estimator.cpp:1133-1144: each
+prior is re-centred on the new estimate, so it damps the step of one solve but never pulls the window back): with those
+calls switched off on BOTH sides (the oracle's isvo_debug_no_update, the library's ISV_DEBUG_NO_UPDATE; not the
+reference's behaviour) the same 1e-12 control stays at 2e-8 m after 400 frames, and the native window manager + MI355X
+stay within ATE 8.5e-7 m of the restatement + oracle over the whole 2383 solved frames (study 2c) -- north_star's 1e-6 m.
+With the reference's update() in place, two implementations that are not bitwise identical -- its own Ceres build
+included -- cannot stay within 1e-6 m of each other over 2000 frames; what is asserted instead:
   (1) EVERY one of the 2383 solves (+ the initFactorGraph solve and every triangulation), with the windows the
-      restatement + oracle run produces, is ALSO solved on the MI355X from the same inputs: states within 1e-7,
-      cost trace 1e-7 relative, iteration count / termination / accept pattern identical (flips counted, none allowed);
+      restatement + oracle run produces, is ALSO solved on the MI355X from the same inputs, on the handle the drop-in shim
+      creates (18 000 observations of capacity, the fused k_lin_gram path): states within 1e-7, cost trace 1e-7
+      relative, iteration count / termination / accept pattern identical (flips counted, none allowed);
   (2) free-running, native window manager + MI355X against restatement + oracle: ATE <= 1e-6 m while rounding has not
-      been amplified yet (the first 40 solved frames), identical keyframe decisions there; beyond that the divergence is
-      printed next to the oracle-vs-perturbed-oracle control and must stay of the control's order;
+      been amplified yet (the first 40 solved frames), identical keyframe decisions there; beyond that the separation
+      stays within 10 x the oracle's OWN separation from a copy of itself perturbed by 1e-8 m -- the scale of the
+      per-solve GPU / oracle difference (2.4e-8) -- at every mark, full-length ATE within 3 x that control's;
+  (2b) the converged-mode study; (2c) the no-update study (ATE < 1e-5 m asserted, 8.5e-7 measured);
   (3) the drift against the simulator's ground truth (the one anchor outside the restatement) stays below 1 m rmse.
+The controls and the studies' oracle sides run in CPU child processes (tests/sequence_long_worker.py) beside the GPU work.
 tests/golden/euroc_standin_n18_seed0.npz holds the oracle-side trajectory (tests/golden/make_euroc_standin_golden.py);
 the CPU test below keeps it honest on a prefix."""
 import os
@@ -159,17 +167,69 @@ def run_oracle_perturbed(oracle, cfg, sim, stream, n, eps=1e-12):
     return np.array([p for (_, p, _) in est.trajectory])
 
 
+WORKER = os.path.join(os.path.dirname(os.path.abspath(__file__)), "sequence_long_worker.py")
+N_CONVERGED, NIT_CONVERGED = 420, 60        # the converged-mode study: frames, max_num_iterations (the trace holds 63)
+
+
+def _spawn(tmp, name, **kw):
+    """one restatement + oracle run of the stream in a CPU-only child process (started before this process touches the GPU)"""
+    import json
+    import subprocess
+    import sys
+    out = os.path.join(tmp, name + ".npz")
+    env = dict(os.environ, OMP_NUM_THREADS="1", HIP_VISIBLE_DEVICES="")
+    return name, out, subprocess.Popen([sys.executable, WORKER, json.dumps(kw), out], env=env)
+
+
+def _join(jobs):
+    res = {}
+    for name, out, proc in jobs:
+        assert proc.wait() == 0, f"worker {name} failed"
+        res[name] = np.load(out)
+    return res
+
+
+def _native_run(cfg, sim, stream, env=None):
+    from isvins_amd import estimator as E
+    old = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        est = E.SequenceEstimator(sh.estimator_params(cfg), 1)       # (the hooks are read when the handle is created)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    rows, per = run_native_side(est, sim, stream)
+    assert est.failed_solves(0) == 0
+    est.close()
+    return rows, per
+
+
+def _dp(a, b):
+    n = min(len(a), len(b))
+    return np.linalg.norm(a[:n, 1:4] - b[:n, 1:4], axis=1)
+
+
 @pytest.mark.gpu
-def test_euroc_standin_full_length_gpu_vs_oracle(oracle):
-    from isvins_amd import backend, estimator as E
+def test_euroc_standin_full_length_gpu_vs_oracle(oracle, tmp_path):
+    from isvins_amd import backend
     cfg = abi.make_config(N, NVO, max_landmarks=1000, max_obs=1000 * N, max_batch=1)
+    cfg60 = abi.make_config(N, NVO, max_landmarks=1000, max_obs=1000 * N, max_batch=1, num_iterations=NIT_CONVERGED)
     t0 = time.time()
+    # the controls and the studies' oracle sides: independent, host-bound -> child processes beside the GPU work below
+    tmp = str(tmp_path)
+    jobs = [_spawn(tmp, "ctl12", n_frames=N_FRAMES, eps=1e-12), _spawn(tmp, "ctl8", n_frames=N_FRAMES, eps=1e-8),
+            _spawn(tmp, "noupd", n_frames=N_FRAMES, no_update=1), _spawn(tmp, "noupd_ctl12", n_frames=N_FRAMES, no_update=1, eps=1e-12),
+            _spawn(tmp, "conv", n_frames=N_CONVERGED, num_iterations=NIT_CONVERGED), _spawn(tmp, "conv_ctl12", n_frames=N_CONVERGED, num_iterations=NIT_CONVERGED, eps=1e-12)]
     sim, stream = record_stream(N_FRAMES)
     feats = [len(im) for (_, _, im) in stream]
     t1 = time.time()
-    est = E.SequenceEstimator(sh.estimator_params(cfg), 1)
-    rows, per_g = run_native_side(est, sim, stream)
+    rows, per_g = _native_run(cfg, sim, stream)
     t2 = time.time()
+    # the handle a maintainer's drop-in creates (isvins_estimator_shim.hpp: 1000 landmarks / 18 000 observations / one window):
+    # since round 3 the visual path is chosen from the uploaded window, so these 2383 solves run k_lin_gram (counts[4] below)
     be = backend.Backend(N, NVO, max_landmarks=1000, max_obs=1000 * N, max_batch=1)
     tf = TeacherForced(oracle, cfg, be)
     eo = sh.Estimator(tf, oracle, N, NVO)
@@ -181,49 +241,80 @@ def test_euroc_standin_full_length_gpu_vs_oracle(oracle):
         n0 = len(eo.summaries)
         eo.process_image(image, t, bootstrap=boot)
         if len(eo.summaries) > n0:
-            s = eo.summaries[-1]
-            per_o.append((s.iterations, s.termination, tuple(s.trace_accepted[1: s.iterations + 1]), bool(eo.margin_history[-1])))
+            sm = eo.summaries[-1]
+            per_o.append((sm.iterations, sm.termination, tuple(sm.trace_accepted[1: sm.iterations + 1]), bool(eo.margin_history[-1])))
+    fused_path = be.last_counts()[4]
     traj_o = np.array([np.concatenate([[h], p, R.ravel()]) for (h, p, R) in eo.trajectory])
     t3 = time.time()
-    n_ctl = 420
-    ctl = run_oracle_perturbed(oracle, cfg, sim, stream, n_ctl)
+    rows_nu, _ = _native_run(cfg, sim, stream, env={"ISV_DEBUG_NO_UPDATE": "1"})
+    rows_60, per_g60 = _native_run(cfg60, sim, stream[:N_CONVERGED])
     t4 = time.time()
+    ctl = _join(jobs)
+    t5 = time.time()
     n_solved = N_FRAMES - (N - 1)
     assert len(rows) == len(traj_o) == n_solved >= 2000 and tf.n == n_solved
-    assert est.failed_solves(0) == 0
     old = np.array([p[3] for p in per_o])
     truth = np.array([sim.traj.p(h) for h in traj_o[:, 0]])
     drift = np.linalg.norm(traj_o[:, 1:4] - truth, axis=1)
-    dpos = np.linalg.norm(rows[:, 1:4] - traj_o[:, 1:4], axis=1)
-    dctl = np.linalg.norm(ctl - traj_o[: len(ctl), 1:4], axis=1)
-    marks = [m for m in (20, 40, 80, 160, 240, 320, 400) if m < len(ctl)]
+    dpos = _dp(rows, traj_o)
+    d12, d8 = _dp(ctl["ctl12"]["trajectory"], traj_o), _dp(ctl["ctl8"]["trajectory"], traj_o)
+    dnu = _dp(rows_nu, ctl["noupd"]["trajectory"]); dnu12 = _dp(ctl["noupd_ctl12"]["trajectory"], ctl["noupd"]["trajectory"])
+    d60 = _dp(rows_60, ctl["conv"]["trajectory"]); d60c = _dp(ctl["conv_ctl12"]["trajectory"], ctl["conv"]["trajectory"])
+    tol60 = float(np.mean(ctl["conv"]["termination"] != 4))            # solves that did not end on ISV_TERM_MAX_ITERATIONS
+    tol10 = float(np.mean(np.array([p[1] for p in per_o]) != 4))
+    marks = [m for m in (20, 40, 80, 160, 240, 320, 400, 800, 1600, 2382) if m < n_solved]
+    m60 = [m for m in (20, 40, 80, 160, 240, 320, 400) if m < len(d60)]
+    rms = lambda x: float(np.sqrt(np.mean(x ** 2)))
+    fmt = lambda x, mk: [f"{x[m]:.1e}" for m in mk]
     first_kf_flip = next((k for k, (a, b) in enumerate(zip(per_g, per_o)) if a[3] != b[3]), None)
     print(f"\nEuRoC stand-in, N={N} Vo={NVO}: {N_FRAMES} frames (120 s at 20 Hz), {n_solved} solved, features/frame mean {np.mean(feats):.0f} "
           f"[{min(feats)}, {max(feats)}], MARGIN_OLD {old.mean():.2f} / MARGIN_NEW {1 - old.mean():.2f}\n"
-          f"  (1) every solve repeated on the MI355X from the oracle side's inputs ({tf.n} windows, landmarks {min(len(x[2]) for x in per_o)}..): "
-          f"flips {tf.flips}; worst |dstate| {tf.worst['state']:.2e}, cost trace {tf.worst['cost']:.2e} rel, depth {tf.worst['depth']:.2e} rel, "
+          f"  (1) every solve repeated on the MI355X from the oracle side's inputs, on the shim-shaped handle (18 000 observations of capacity; fused k_lin_gram ran: {fused_path == 1}) "
+          f"({tf.n} windows): flips {tf.flips}; worst |dstate| {tf.worst['state']:.2e}, cost trace {tf.worst['cost']:.2e} rel, depth {tf.worst['depth']:.2e} rel, "
           f"priors {tf.worst['prior']:.2e}, marginalisation information {tf.worst['marg']:.2e} rel, triangulation {tf.worst['tri']:.2e} rel\n"
-          f"  (2) free-running native + MI355X vs restatement + oracle, |dP| at solved frame {marks}: {[f'{dpos[m]:.1e}' for m in marks]}; "
-          f"first keyframe-decision flip at solved frame {first_kf_flip}; full-length ATE {np.sqrt(np.mean(dpos ** 2)):.3f} m\n"
-          f"      control, oracle vs oracle with a 1e-12 m bootstrap perturbation,  |dP| at the same frames: {[f'{dctl[m]:.1e}' for m in marks]}\n"
-          f"  (3) drift of the oracle-side run against the simulator's ground truth: rmse {np.sqrt(np.mean(drift ** 2)):.3f} m, max {drift.max():.3f} m over {traj_o[-1, 0] - traj_o[0, 0]:.0f} s\n"
+          f"  (2) free-running native + MI355X vs restatement + oracle, the reference's configuration (NUM_ITERATIONS = 10; {100 * tol10:.0f} % of the solves end on a tolerance):\n"
+          f"      |dP| at solved frame {marks}:\n        GPU vs oracle                  {fmt(dpos, marks)}   full-length ATE {rms(dpos):.3f} m\n"
+          f"        control 1e-12 m (oracle vs oracle) {fmt(d12, marks)}   ATE {rms(d12):.3f} m\n"
+          f"        control 1e-8 m  (oracle vs oracle) {fmt(d8, marks)}   ATE {rms(d8):.3f} m   <- the scale of the per-solve GPU / oracle difference ({tf.worst['state']:.1e})\n"
+          f"      first keyframe-decision flip at solved frame {first_kf_flip}\n"
+          f"  (2b) converged mode, max_num_iterations = {NIT_CONVERGED} on both sides ({100 * tol60:.0f} % of the oracle's solves end on a tolerance), first {N_CONVERGED} frames, |dP| at {m60}:\n"
+          f"        GPU vs oracle                  {fmt(d60, m60)}\n        control 1e-12 m                {fmt(d60c, m60)}\n"
+          f"  (2c) WITHOUT the update() of the prior pseudo-measurements after each solve (src/estimator.cpp:1133-1144 switched off on both sides; not the reference's behaviour), |dP| at {marks}:\n"
+          f"        GPU vs oracle                  {fmt(dnu, marks)}   full-length ATE {rms(dnu):.2e} m\n"
+          f"        control 1e-12 m                {fmt(dnu12, marks)}   ATE {rms(dnu12):.2e} m\n"
+          f"  (3) drift of the oracle-side run against the simulator's ground truth: rmse {rms(drift):.3f} m, max {drift.max():.3f} m over {traj_o[-1, 0] - traj_o[0, 0]:.0f} s\n"
           f"  wall: stream {t1 - t0:.1f} s, native + GPU {t2 - t1:.1f} s ({1e3 * (t2 - t1) / N_FRAMES:.2f} ms / frame incl. the Python feed), "
-          f"restatement + oracle + per-solve GPU repeats {t3 - t2:.1f} s, control {t4 - t3:.1f} s")
-    # (1) per-solve parity over the whole run
+          f"restatement + oracle + per-solve GPU repeats {t3 - t2:.1f} s, no-update and converged native runs {t4 - t3:.1f} s, waiting for the CPU workers {t5 - t4:.1f} s")
+    # (1) per-solve parity over the whole run, on the fused path
+    assert fused_path == 1
     assert all(v == 0 for v in tf.flips.values()), tf.flips
     # (depths are 1 / lambda of far, weakly constrained points and the recovered information matrices go through an
     # eigen-decomposition and small inverses: 1e-4 relative over 2383 real windows; 1e-5 / 1e-6 on the synthetic ones)
     assert tf.worst["state"] < 1e-7 and tf.worst["prior"] < 1e-7 and tf.worst["cost"] < 1e-7 and tf.worst["depth"] < 1e-4
     assert tf.worst["marg"] < 1e-4 and tf.worst["tri"] < 1e-6
-    # (2) free-running: exact while rounding has not been amplified, of the control's order afterwards
-    assert np.sqrt(np.mean(dpos[:40] ** 2)) < 1e-6 and dpos[:40].max() < 1e-6
+    # (2) free-running: exact while rounding has not been amplified ...
+    assert rms(dpos[:40]) < 1e-6 and dpos[:40].max() < 1e-6
     assert all(a == b for a, b in zip(per_g[:40], per_o[:40]))
     assert first_kf_flip is None or first_kf_flip > 150
-    assert dpos.max() < 3.0 and 0.05 < old.mean() < 0.95
+    # ... and afterwards within a stated factor of the oracle's OWN sensitivity at the scale of the injected difference: at
+    # every mark at most 10 x the largest separation the 1e-8 control has reached by then, and a full-length ATE of its order
+    for m in marks:
+        assert dpos[m] <= 10.0 * max(d8[: m + 1].max(), 1e-9), (m, dpos[m], d8[: m + 1].max())
+    assert rms(dpos) <= 3.0 * rms(d8) and dpos.max() < 3.0 and 0.05 < old.mean() < 0.95
+    # (2b) raising the iteration cap does NOT remove the sensitivity (VERDICT r2 asked for this run: the "unconverged solves"
+    # explanation of round 2 was incomplete): most solves now end on a tolerance and the oracle still separates from itself
+    assert tol60 > 0.8
+    assert d60c[m60[-1]] > 100.0 * d60c[40]
+    for m in m60:
+        assert d60[m] <= 10.0 * max(d60c[: m + 1].max() * 1e4, 1e-9)      # (the control starts 1e4 below the GPU's injection)
+    # (2c) the amplifier is the pseudo-measurement update(): with it switched off on both sides, the two implementations stay
+    # together over the whole 2400 frames and the control does not grow
+    assert rms(dnu) < 1e-5 and dnu.max() < 1e-4             # measured: ATE 8.5e-7 m over the 2383 solved frames, max 4.9e-6 m
+    assert rms(dnu12) < 1e-4 and rms(d12) > 1e-2            # measured: 1.5e-6 m against 1.07 m with the update()
     # (3) ground truth
-    assert np.sqrt(np.mean(drift ** 2)) < 1.0
+    assert rms(drift) < 1.0
     # the committed golden is the oracle side's output (prefix: the full length is as chaotic as (2))
     g = np.load(GOLDEN)
     assert g["trajectory"].shape == traj_o.shape
     assert np.abs(traj_o[:40] - g["trajectory"][:40]).max() < 1e-6
-    est.close(); be.close()
+    be.close()
