@@ -278,6 +278,73 @@ int  isv_batch_last_timing(isv_backend_t *h, double out_ms[8]);
 #define ISV_STREAM_OF_HANDLE ((void *)(intptr_t)-1)
 int64_t isv_result_record_doubles(const isv_backend_t *h);
 int  isv_batch_pack_results(isv_backend_t *h, void *device_dst, void *stream);
+/* ---- device-resident sequences ("keeps device-resident window state across frames so only new
+ * observations / IMU deltas cross PCIe each frame") ----------------------------------------------------------------
+ * Slot b of the handle (0 <= b < max_batch) holds ONE sequence's whole window on the device between frames: the states,
+ * the IMU records and their sqrt_info, the prior factors, and the FeatureManager's tracks (every IDFeatures, good or not:
+ * start_frame, observation ring, estimated_depth, solve_flag) in list order.  Per frame the caller hands over what is NEW --
+ * the newest frame's propagated state, its feature observations, one IMU record (two after a MARGIN_SECOND_NEW slide) --
+ * and the device does the rest of Estimator::slideWindow (src/estimator.cpp:1565-1698: state / IMU shift, the rotation of
+ * the prior factors with the marginalisation outputs that never left the device, slideWindowOld ->
+ * FeatureManager::removeBackShiftDepth feature_manager.cpp:275-313 with the depth re-hosting, slideWindowNew -> removeFront
+ * :335-354, removeFailures :165-174), rebuilds the solver's view of the window (goodFeature() landmarks in list order, the
+ * (host, observer) pair groups, their schedule and the factor stream: what isv_batch_upload builds on the host), and runs
+ * solveOdometry (triangulate + backendOptimization).  The caller keeps the INTEGER side of the FeatureManager (ids,
+ * start_frame, track lengths: which feature continues which track) and therefore knows every offset; it never needs the
+ * points, depths or window states back -- only the newest frame's state (for processIMU), the oldest pose (pose_output.txt),
+ * the solve summary and the landmarks' solve_flag (removeFailures).  Results are bitwise those of the re-upload path
+ * (tests/test_gpu_resident.py).  estimate_extrinsic = 0 only.                                                          */
+typedef struct isv_seq_track {       /* one IDFeatures of the seed: feature_manager.h:36-63 */
+    int32_t start_frame, n_obs, solve_flag, slot;      /* slot: the caller's storage slot of the track (< tracks capacity), kept for its lifetime */
+    double  depth;
+} isv_seq_track_t;
+typedef struct isv_seq_obs {         /* one observation of the newest frame */
+    int32_t track;                   /* ordinal of its track in the list AFTER the slide (== n_tracks + k for the k-th new track) */
+    int32_t slot;                    /* storage slot (only read for a new track) */
+    double  point[3];
+} isv_seq_obs_t;
+typedef struct isv_seq_frame {       /* the hand-over of one frame of one sequence */
+    int32_t prev_slide;              /* what Estimator::slideWindow did after the previous solve: 0 = nothing to apply (first frame after the seed), 1 = MARGIN_OLD, 2 = MARGIN_SECOND_NEW */
+    int32_t margin_old;              /* marginalization_flag of THIS solve */
+    int32_t n_tracks;                /* tracks alive after the slide, before this frame's features are added (consistency check) */
+    int32_t n_obs;                   /* observations of the newest frame */
+    const isv_seq_obs_t *obs;        /* [n_obs] in std::map order of the reference's image (feature id ascending) */
+    int32_t n_imu;                   /* 1: imu[0] = pre_integrations[N-1]; 2 (after MARGIN_SECOND_NEW): imu[0] = the merged pre_integrations[N-2], imu[1] = pre_integrations[N-1] */
+    int32_t want_marg;               /* copy the isv_marg_result_t of this solve back (the CombinedFactors for the pose graph) */
+    const isv_imu_t *imu;
+    double Ps[3], Rs[9], Vs[3], Bas[3], Bgs[3];   /* newest frame (N-1) as processIMU propagated it */
+    double header0;                  /* Headers[0] */
+    /* the solver's view, which the caller knows from its integer bookkeeping (capacity checks, launch sizes) */
+    int32_t n_landmarks, n_factors;  /* goodFeature() landmarks and their reprojection factors after this frame's features were added */
+} isv_seq_frame_t;
+typedef struct isv_seq_result {
+    isv_summary_t summary;
+    double Ps_new[3], Rs_new[9], Vs_new[3], Bas_new[3], Bgs_new[3];   /* frame N-1 after the solve */
+    double Ps_old[3], Rs_old[9];                                       /* frame 0 after the solve (pose_output.txt row) */
+    double Ps_second[3], Rs_second[9];                                 /* frame 1 (becomes frame 0 after a MARGIN_OLD slide) */
+    int32_t marg_valid, n_failed_landmarks;
+} isv_seq_result_t;
+/* allocate the track store: tracks_per_window >= every track alive in a window (good or not) */
+int  isv_backend_seq_enable(isv_backend_t *h, int32_t tracks_per_window);
+/* make slots 0 .. n-1 resident from the caller's full state AFTER a slide: windows as for isv_batch_upload (imu[N-2], the
+ * record of the frame still to come, is ignored), tracks[b][n_tracks[b]] in list order with their points
+ * points[b][sum n_obs][3] (track-major, oldest observation first) */
+int  isv_backend_seq_seed(isv_backend_t *h, int32_t n, isv_window_t *const *w, const int32_t *n_tracks,
+                          const isv_seq_track_t *const *tracks, const double *const *points);
+/* one frame of the n resident sequences: slide, append, solveOdometry.  solve_flags[b] (may be NULL) receives the
+ * lm_solve_flag of the n_landmarks goodFeature() landmarks in list order; marg [n] is filled where want_marg is set */
+int  isv_backend_seq_frame(isv_backend_t *h, int32_t n, const isv_seq_frame_t *frames, isv_seq_result_t *results,
+                           int32_t *const *solve_flags, isv_marg_result_t *marg);
+/* the resident state of slot b back into caller buffers (a sequence leaving the resident mode, tests): the window as
+ * isv_batch_download fills it restricted to states and prior factors, and every track's depth / solve_flag in list order */
+int  isv_backend_seq_download(isv_backend_t *h, int32_t slot, isv_window_t *w, int32_t n_tracks, double *track_depth, int32_t *track_flag);
+/* the slide of the previous solve is applied by the NEXT isv_backend_seq_frame; a caller that has slid its own side and
+ * wants the resident state back first lets the device catch up: prev_slide [n] as in isv_seq_frame_t, n_tracks [n] the
+ * caller's track counts after the slide (consistency check) */
+int  isv_backend_seq_flush(isv_backend_t *h, int32_t n, const int32_t *prev_slide, const int32_t *n_tracks);
+/* the marginalisation outputs of slot b's last solve (they stay on the device unless want_marg was set) */
+int  isv_backend_seq_marg(isv_backend_t *h, int32_t slot, isv_marg_result_t *out);
+
 /* last optimize: [0] k_lin_gram (or k_proj_linearize<0>) launches, [1] k_build_solve* launches, [2] k_rank1_mfma launches,
  * [3] window-iterations that were linearised and solved (windows gated out of an iteration do no work),
  * [4] 1 when the fused k_lin_gram ran (no Jacobian strips), [5] 1 when k_dogleg<true> carried the step control */

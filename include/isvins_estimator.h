@@ -112,6 +112,18 @@ int  isv_estimator_failed_solves(const isv_estimator_t *e, int32_t seq);
  * which = 1: the newest frame after every solve, 13 doubles per row (header, P, R row-major)
  * Copies at most max_rows rows into out (may be NULL) and returns the number of rows recorded so far. */
 int  isv_estimator_trajectory(const isv_estimator_t *e, int32_t seq, int32_t which, double *out, int32_t max_rows);
+/* Device-resident windows (include/isvins_backend.h "device-resident sequences"): once every sequence
+ * has made its first solves on the host path, the windows -- states, IMU records, prior factors, every track with its
+ * points and depth -- stay on the MI355X between frames.  Per frame only the newest frame's propagated state, its feature
+ * observations and one (two) IMU record(s) go to the device; the newest / oldest poses, the solve summary and the
+ * landmarks' solve_flag come back.  Estimator::slideWindow (src/estimator.cpp:1565-1698) then runs on the device; the host
+ * keeps the integer side of the FeatureManager (ids, track lengths) and the IMU pre-integration.  Results are bitwise those
+ * of the re-upload path.  Needs the HIP backend, lock-step frames (every sequence gets an image every frame) and
+ * estimate_extrinsic = 0; a non-finite solve brings every window back to the host (isv_estimator_failed_solves).
+ * isv_estimator_get_window is refused while resident; set_resident(e, 0) downloads the windows again (only valid right
+ * after isv_estimator_create or ... a frame boundary is handled internally).                                          */
+int  isv_estimator_set_resident(isv_estimator_t *e, int32_t on);
+int64_t isv_estimator_resident_frames(const isv_estimator_t *e);      /* frames solved through the resident path so far */
 
 #ifdef __cplusplus
 }

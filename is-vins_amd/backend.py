@@ -24,7 +24,8 @@ EXPORTS = ["isv_abi_version", "isv_backend_create", "isv_backend_destroy", "isv_
            "isv_backend_optimize", "isv_backend_optimize_batch", "isv_backend_init_factor_graph", "isv_backend_init_factor_graph_batch", "isv_backend_triangulate", "isv_backend_solve_odometry_batch", "isv_backend_linearize",
            "isv_batch_upload", "isv_batch_optimize", "isv_batch_linearize", "isv_batch_download",
            "isv_batch_sync", "isv_batch_last_timing", "isv_batch_last_counts",
-           "isv_result_record_doubles", "isv_batch_pack_results"]
+           "isv_result_record_doubles", "isv_batch_pack_results",
+           "isv_backend_seq_enable", "isv_backend_seq_seed", "isv_backend_seq_frame", "isv_backend_seq_download", "isv_backend_seq_flush", "isv_backend_seq_marg"]
 
 
 class BackendError(RuntimeError):

@@ -14,73 +14,7 @@
 #include "isv_device_types.h"
 #include "isv_kernels.h"
 
-#define HIPCHK(h, call)                                                                          \
-    do {                                                                                         \
-        hipError_t e_ = (call);                                                                  \
-        if (e_ != hipSuccess) {                                                                  \
-            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                        \
-            return ISV_ERR_DEVICE;                                                               \
-        }                                                                                        \
-    } while (0)
-
-struct isv_backend {
-    isv_config_t cfg;
-    std::string err;
-    hipStream_t stream = nullptr, stream2 = nullptr;
-    hipEvent_t fj[4] = {};
-    hipEvent_t pk[2] = {};        // isv_batch_pack_results: handle stream -> caller stream -> handle stream
-    hipEvent_t ev[8] = {};
-    std::vector<hipEvent_t> prof_ev;      // [max_iter][ISV_PROF_FAMILIES][2]
-    int prof_valid = 0;
-    DevBatch d{};                 // device pointers
-    SolverHost hc;                // device figures + environment hooks, read once at creation
-    std::vector<void *> allocs;
-    // capacities
-    size_t capB = 0, capL = 0, capF = 0, capTiles = 0;
-    // host staging (pinned)
-    struct Host {
-        double *Ps, *Rs, *Vs, *Bas, *Bgs, *tic, *ric, *depth, *lm_pts_i, *f_pts_j, *f_pts_z, *imu_in, *imu_cov;
-        int32_t *lm_off, *f_off, *lm_host, *lm_k, *lm_f0, *tile_win, *tile_f0, *tile_n, *imu_skip, *n_rp, *solve_flag, *pg_perm, *pg_off, *pg_sched, *pg_sched_off;
-        FactorRec *f_rec;
-        int32_t *pg_rec, *pg_wstart; double *pg_pts;
-        uint32_t *lm_meta; int32_t *margin_old; double *header0;
-        isv_se3_prior_t *se3; isv_linear9_t *lin9; isv_relpose_t *relpose; isv_rollpitch_t *rollpitch;
-        SolveState *st;
-        double *pose, *sb, *ex, *lam;
-    } h{};
-    SolverStage stage{};          // pinned staging of the result records
-    std::vector<void *> hallocs;
-    // pristine copies for isv_batch_optimize restore
-    double *Ps0 = nullptr, *Rs0 = nullptr, *Vs0 = nullptr, *Bas0 = nullptr, *Bgs0 = nullptr, *depth0 = nullptr, *tic0 = nullptr, *ric0 = nullptr;
-    isv_se3_prior_t *se30 = nullptr; isv_linear9_t *lin90 = nullptr; isv_relpose_t *relpose0 = nullptr; isv_rollpitch_t *rollpitch0 = nullptr;
-    int resident = 0;
-    int device = 0;               // the HIP device the handle was created on; every entry point re-selects it
-    double *init_scratch = nullptr, *init_kld = nullptr;   // initFactorGraph scratch, allocated on first use and kept
-    size_t init_cap = 0;
-    double last_ms[8] = {};
-    int64_t last_counts[8] = {};
-};
-
-template <typename T>
-static int dalloc(isv_backend *h, T **p, size_t n) {
-    void *q = nullptr;
-    HIPCHK(h, hipMalloc(&q, (n ? n : 1) * sizeof(T)));
-    h->allocs.push_back(q);
-    *p = (T *)q;
-    return ISV_OK;
-}
-template <typename T>
-static int halloc(isv_backend *h, T **p, size_t n) {
-    void *q = nullptr;
-    HIPCHK(h, hipHostMalloc(&q, (n ? n : 1) * sizeof(T), hipHostMallocDefault));
-    h->hallocs.push_back(q);
-    *p = (T *)q;
-    return ISV_OK;
-}
-#define TRY(x) do { int rc_ = (x); if (rc_ != ISV_OK) return rc_; } while (0)
-// a handle's buffers and streams live on the device it was created on; a caller may drive it from any thread
-// (fresh threads start on device 0), so every entry point selects that device first
-#define ENTER(h) HIPCHK(h, hipSetDevice((h)->device))
+#include "isv_backend_impl.h"
 
 extern "C" int isv_abi_version(void) { return ISV_ABI_VERSION; }
 
@@ -89,6 +23,7 @@ extern "C" const char *isv_backend_last_error(const isv_backend_t *h) { return h
 extern "C" void isv_backend_destroy(isv_backend_t *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    if (h->seq && h->seq_free) h->seq_free(h->seq);
     if (h->init_scratch) (void)hipFree(h->init_scratch);
     if (h->init_kld) (void)hipFree(h->init_kld);
     for (void *p : h->allocs) (void)hipFree(p);
@@ -450,7 +385,7 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
     D2D(h->tic0, d.tic, (size_t)n * 3); D2D(h->ric0, d.ric, (size_t)n * 9);
     D2D(h->se30, d.se3, n); D2D(h->lin90, d.lin9, n); D2D(h->relpose0, d.relpose, (size_t)n * (c.n_vo - 1)); D2D(h->rollpitch0, d.rollpitch, (size_t)n * c.max_rollpitch);
     // IMU sqrt_info once per upload (the covariances do not change during a solve)
-    if (NI) hipLaunchKernelGGL(k_imu_prep, dim3((unsigned)NI), dim3(64), 0, st, d);
+    if (NI) hipLaunchKernelGGL(k_imu_prep, dim3((unsigned)NI), dim3(64), 0, st, d, (const int32_t *)nullptr);
     HIPCHK(h, hipGetLastError());
     const auto t_enq = std::chrono::steady_clock::now();
     HIPCHK(h, hipStreamSynchronize(st));

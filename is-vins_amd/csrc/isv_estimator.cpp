@@ -267,6 +267,12 @@ struct Sequence {
     isv_se3_prior_t wpp{};
     isv_linear9_t wvb{};
     std::vector<int> good;                     // indices into tracks of the landmarks in `w`
+    // device-resident mode (isv_estimator_set_resident): the window lives in slot `index of the sequence` of the backend
+    bool resident = false;
+    int last_slide = 0;                        // what slide_window did after the previous solve: 1 MARGIN_OLD, 2 MARGIN_SECOND_NEW (0: already on the device)
+    std::vector<isv_seq_obs_t> frame_obs;      // the newest frame's observations as (track ordinal, slot, point)
+    std::vector<int32_t> frame_flags;          // lm_solve_flag of the good landmarks, from the device
+    isv_imu_t frame_imu[2];
     // outputs
     isv_summary_t last_summary{};
     int n_solves = 0, n_good_last = 0, n_failed = 0;   // n_failed: solves whose result was not finite (state kept as it was)
@@ -283,6 +289,10 @@ struct isv_estimator {
     std::vector<Sequence> seq;
     std::string err;
     double step_ms[6] = {0, 0, 0, 0, 0, 0};
+    bool resident_mode = false;                // asked for by isv_estimator_set_resident
+    bool resident_ready = false;               // every sequence is seeded on the device
+    int tracks_cap = 0;
+    int64_t resident_frames = 0;
 };
 
 namespace {
@@ -291,8 +301,9 @@ namespace {
 M3 delta_q_matrix(const V3 &theta) { return qmat(Quat{1.0, theta[0] / 2, theta[1] / 2, theta[2] / 2}); }
 
 // FeatureManager::addFeatureAndCheckParallax (feature_manager.cpp:52-101) + compensatedParallax2 (:356-390)
-bool add_features(Sequence &s, double min_parallax) {
+bool add_features(Sequence &s, double min_parallax, bool record = false) {
     const int fc = s.frame_count;
+    if (record) s.frame_obs.clear();
     // id -> track index: a flat open-addressing table rebuilt per frame (the reference does a linear find_if per feature)
     size_t cap = 64;
     while (cap < 2 * (s.tracks.size() + s.staged_image.size()) + 8) cap <<= 1;
@@ -307,10 +318,14 @@ bool add_features(Sequence &s, double min_parallax) {
             Track t; t.id = ob.first; t.start_frame = fc; t.slot = s.new_slot(); t.off = 0; t.n = 0;
             s.push_point(t, ob.second);
             s.hkey[h] = ob.first; s.hval[h] = (int)s.tracks.size();
+            if (record) s.frame_obs.push_back(isv_seq_obs_t{(int32_t)s.tracks.size(), t.slot, {ob.second[0], ob.second[1], ob.second[2]}});
             s.tracks.push_back(t);
         } else {
             Track &t = s.tracks[s.hval[h]];
-            if (t.n < POINT_RING) s.push_point(t, ob.second);      // (a second observation of an id in one image would overflow a window-long track)
+            if (t.n < POINT_RING) {      // (a second observation of an id in one image would overflow a window-long track)
+                s.push_point(t, ob.second);
+                if (record) s.frame_obs.push_back(isv_seq_obs_t{(int32_t)s.hval[h], t.slot, {ob.second[0], ob.second[1], ob.second[2]}});
+            }
             last_track_num++;
         }
     }
@@ -436,6 +451,7 @@ void slide_window(const isv_estimator *e, Sequence &s) {
                 const V3 uv = s.pt(t, 0);
                 s.pop_front(t);
                 if (t.n < 2) return false;
+                if (s.resident) return true;        // (the depths and window states live on the device: k_seq_slide re-hosts them)
                 const V3 w_pt = add(mv(R0, mul(uv, t.depth)), P0);
                 const V3 pj = mtv(R1, sub(w_pt, P1));
                 t.depth = pj[2] > 0 ? pj[2] : e->p.cfg.init_depth;
@@ -644,6 +660,179 @@ extern "C" int isv_estimator_set_bootstrap(isv_estimator_t *e, int32_t seq, cons
     return ISV_OK;
 }
 
+namespace {
+
+// every sequence's window -> the backend's resident slots (after a slide, i.e. between two frames)
+int seed_resident(isv_estimator *e) {
+    const int S = (int)e->seq.size();
+    std::vector<isv_window_t *> ws(S);
+    std::vector<int32_t> nt(S);
+    std::vector<std::vector<isv_seq_track_t>> trk(S);
+    std::vector<std::vector<double>> pts(S);
+    std::vector<const isv_seq_track_t *> trk_p(S);
+    std::vector<const double *> pts_p(S);
+    for (int si = 0; si < S; si++) {
+        Sequence &s = e->seq[si];
+        if ((int)s.tracks.size() > e->tracks_cap) return ISV_ERR_CAPACITY;
+        std::string err;
+        const int rc = build_window(e, s, err);
+        if (rc != ISV_OK) { e->err = err; return rc; }
+        ws[si] = &s.w;
+        nt[si] = (int32_t)s.tracks.size();
+        trk[si].resize(s.tracks.size());
+        for (size_t i = 0; i < s.tracks.size(); i++) {
+            const Track &t = s.tracks[i];
+            if (t.slot >= e->tracks_cap) return ISV_ERR_CAPACITY;
+            trk[si][i] = isv_seq_track_t{t.start_frame, t.n, t.solve_flag, t.slot, t.depth};
+            for (int k = 0; k < t.n; k++) { const V3 &p = s.pt(t, k); pts[si].insert(pts[si].end(), p.begin(), p.end()); }
+        }
+        if (pts[si].empty()) pts[si].resize(3);
+        trk_p[si] = trk[si].data(); pts_p[si] = pts[si].data();
+    }
+    const int rc = isv_backend_seq_seed(e->backend, S, ws.data(), nt.data(), trk_p.data(), pts_p.data());
+    if (rc != ISV_OK) { e->err = std::string("seeding the resident windows failed: ") + isv_backend_last_error(e->backend); return rc; }
+    for (Sequence &s : e->seq) { s.resident = true; s.last_slide = 0; }
+    e->resident_ready = true;
+    return ISV_OK;
+}
+
+// the device's state of every sequence back into the host members (a sequence leaves the resident mode BEFORE its slide)
+int leave_resident(isv_estimator *e, bool host_has_slid) {
+    if (host_has_slid) {      // the device applies a slide with the NEXT frame: let it catch up with the host's bookkeeping first
+        std::vector<int32_t> prev(e->seq.size()), nt(e->seq.size());
+        for (size_t si = 0; si < e->seq.size(); si++) { prev[si] = e->seq[si].last_slide; nt[si] = (int32_t)e->seq[si].tracks.size(); }
+        const int rc = isv_backend_seq_flush(e->backend, (int32_t)e->seq.size(), prev.data(), nt.data());
+        if (rc != ISV_OK) { e->err = std::string("leaving the resident mode failed: ") + isv_backend_last_error(e->backend); return rc; }
+        for (Sequence &s : e->seq) s.last_slide = 0;
+    }
+    for (size_t si = 0; si < e->seq.size(); si++) {
+        Sequence &s = e->seq[si];
+        if (!s.resident) continue;
+        const int N = s.N;
+        s.wPs.resize(N * 3); s.wRs.resize(N * 9); s.wVs.resize(N * 3); s.wBas.resize(N * 3); s.wBgs.resize(N * 3);
+        s.wrel.resize(s.Nvo - 1); s.wrp.resize(std::max(1, e->p.cfg.max_rollpitch));
+        isv_window_t w{};
+        w.Ps = s.wPs.data(); w.Rs = s.wRs.data(); w.Vs = s.wVs.data(); w.Bas = s.wBas.data(); w.Bgs = s.wBgs.data();
+        w.pose_prior = &s.wpp; w.vb_prior = &s.wvb; w.relpose = s.wrel.data(); w.rollpitch = s.wrp.data();
+        std::vector<double> dep(std::max<size_t>(s.tracks.size(), 1));
+        std::vector<int32_t> fl(std::max<size_t>(s.tracks.size(), 1));
+        const int rc = isv_backend_seq_download(e->backend, (int32_t)si, &w, (int32_t)s.tracks.size(), dep.data(), fl.data());
+        if (rc != ISV_OK) { e->err = std::string("leaving the resident mode failed: ") + isv_backend_last_error(e->backend); return rc; }
+        // (after a slide the newest frame is the host's: processIMU may already have propagated it with the next frame's samples)
+        for (int i = 0; i < (host_has_slid ? N - 1 : N); i++) {
+            std::memcpy(s.Ps[i].data(), &s.wPs[i * 3], 24); std::memcpy(s.Rs[i].data(), &s.wRs[i * 9], 72); std::memcpy(s.Vs[i].data(), &s.wVs[i * 3], 24);
+            std::memcpy(s.Bas[i].data(), &s.wBas[i * 3], 24); std::memcpy(s.Bgs[i].data(), &s.wBgs[i * 3], 24);
+        }
+        s.pose_prior = s.wpp; s.vb_prior = s.wvb; s.relpose = s.wrel;
+        s.rollpitch.assign(s.wrp.begin(), s.wrp.begin() + w.n_rollpitch);
+        for (size_t i = 0; i < s.tracks.size(); i++) { s.tracks[i].depth = dep[i]; s.tracks[i].solve_flag = fl[i]; }
+        s.resident = false;
+    }
+    e->resident_ready = false;
+    return ISV_OK;
+}
+
+// one lock-step frame of the resident sequences: only what is new crosses PCIe (include/isvins_backend.h)
+int resident_frame(isv_estimator *e, std::vector<std::string> &errs) {
+    const int S = (int)e->seq.size();
+    std::vector<isv_seq_frame_t> fr(S);
+    std::vector<isv_seq_result_t> res(S);
+    std::vector<int32_t *> flags(S);
+    int rc = parallel_for(S, errs, [&](int si, std::string &err) {
+        Sequence &s = e->seq[si];
+        const int N = s.N;
+        isv_seq_frame_t &f = fr[si];
+        std::memset(&f, 0, sizeof(f));
+        f.prev_slide = s.last_slide;
+        f.n_tracks = (int32_t)s.tracks.size();
+        s.margin_old = add_features(s, e->p.min_parallax, true);
+        s.Headers[s.frame_count] = s.staged_header;
+        s.staged = false;
+        if ((int)s.tracks.size() > e->tracks_cap) { err = "more tracks than the resident store holds (isv_estimator_set_resident)"; return (int)ISV_ERR_CAPACITY; }
+        f.margin_old = s.margin_old ? 1 : 0;
+        f.n_obs = (int32_t)s.frame_obs.size(); f.obs = s.frame_obs.data();
+        for (const isv_seq_obs_t &o : s.frame_obs) if (o.slot >= e->tracks_cap) { err = "track storage slot beyond the resident store"; return (int)ISV_ERR_CAPACITY; }
+        if (!s.pre[N - 1] || (s.last_slide == 2 && !s.pre[N - 2])) { err = "a window frame has no pre-integration (no IMU samples were fed)"; return (int)ISV_ERR_INVALID_ARG; }
+        if (s.last_slide == 2) { s.frame_imu[0] = s.pre[N - 2]->pod; s.frame_imu[1] = s.pre[N - 1]->pod; f.n_imu = 2; }
+        else { s.frame_imu[0] = s.pre[N - 1]->pod; f.n_imu = 1; }
+        f.imu = s.frame_imu;
+        std::memcpy(f.Ps, s.Ps[N - 1].data(), 24); std::memcpy(f.Rs, s.Rs[N - 1].data(), 72); std::memcpy(f.Vs, s.Vs[N - 1].data(), 24);
+        std::memcpy(f.Bas, s.Bas[N - 1].data(), 24); std::memcpy(f.Bgs, s.Bgs[N - 1].data(), 24);
+        f.header0 = s.Headers[0];
+        s.good.clear();
+        int64_t n_obs = 0;
+        for (size_t i = 0; i < s.tracks.size(); i++)
+            if (s.tracks[i].n >= 2 && s.tracks[i].start_frame < s.Nvo) { s.good.push_back((int)i); n_obs += s.tracks[i].n; }
+        f.n_landmarks = (int32_t)s.good.size(); f.n_factors = (int32_t)(n_obs - (int64_t)s.good.size());
+        if (f.n_landmarks > e->p.cfg.max_landmarks || n_obs > e->p.cfg.max_obs) { err = "window exceeds the landmark / observation capacity"; return (int)ISV_ERR_CAPACITY; }
+        s.frame_flags.assign(std::max<size_t>(s.good.size(), 1), 0);
+        flags[si] = s.frame_flags.data();
+        return (int)ISV_OK;
+    });
+    if (rc != ISV_OK) { e->err = errs[0]; return rc; }
+    rc = isv_backend_seq_frame(e->backend, S, fr.data(), res.data(), flags.data(), nullptr);
+    if (rc != ISV_OK) { e->err = std::string("resident frame failed: ") + isv_backend_last_error(e->backend); return rc; }
+    e->resident_frames++;
+    bool failed = false;
+    for (int si = 0; si < S; si++) failed |= res[si].summary.status != ISV_OK;
+    if (failed) {
+        // a non-finite solve: everything comes back to the host (the device has not slid yet) and the host path's policy applies
+        rc = leave_resident(e, false);
+        if (rc != ISV_OK) return rc;
+        for (int si = 0; si < S; si++) {          // the sequences that did solve still install their marginalisation outputs
+            Sequence &s = e->seq[si];
+            isv_marg_result_t m;
+            if (res[si].summary.status != ISV_OK || !s.margin_old) continue;
+            rc = isv_backend_seq_marg(e->backend, si, &m);
+            if (rc != ISV_OK) { e->err = isv_backend_last_error(e->backend); return rc; }
+            if (!m.valid) continue;
+            s.add_pose_prior = m.forward_pose_prior; s.add_relpose = m.backward_relpose; s.add_vb = m.backward_vb; s.have_to_add = true;
+            isv_rollpitch_t brp = m.backward_rollpitch; brp.index = s.Nvo - 1;
+            s.rollpitch.push_back(brp);
+        }
+    }
+    (void)parallel_for(S, errs, [&](int si, std::string &) {
+        Sequence &s = e->seq[si];
+        const int N = s.N;
+        const isv_seq_result_t &r = res[si];
+        const bool ok = r.summary.status == ISV_OK;
+        if (!failed) {      // the frames the host reads: newest (processIMU), oldest and second (pose_output.txt rows)
+            std::memcpy(s.Ps[N - 1].data(), r.Ps_new, 24); std::memcpy(s.Rs[N - 1].data(), r.Rs_new, 72); std::memcpy(s.Vs[N - 1].data(), r.Vs_new, 24);
+            std::memcpy(s.Bas[N - 1].data(), r.Bas_new, 24); std::memcpy(s.Bgs[N - 1].data(), r.Bgs_new, 24);
+            std::memcpy(s.Ps[0].data(), r.Ps_old, 24); std::memcpy(s.Rs[0].data(), r.Rs_old, 72);
+            std::memcpy(s.Ps[1].data(), r.Ps_second, 24); std::memcpy(s.Rs[1].data(), r.Rs_second, 72);
+            for (size_t l = 0; l < s.good.size(); l++) s.tracks[s.good[l]].solve_flag = s.frame_flags[l];
+        } else if (!ok) { s.n_failed++; s.have_to_add = false; }
+        s.last_summary = r.summary;
+        s.n_solves++;
+        s.n_good_last = (int)s.good.size();
+        after_solve(e, s, s.Headers[N - 1]);
+        s.last_slide = s.margin_old ? 1 : 2;
+        if (failed && !ok) { s.flag = INITIAL_STRUCTURE; s.rollpitch.clear(); }
+        return (int)ISV_OK;
+    });
+    return S;
+}
+
+}  // namespace
+
+// keep every sequence's window on the device between frames (include/isvins_backend.h, "device-resident sequences")
+extern "C" int isv_estimator_set_resident(isv_estimator_t *e, int32_t on) {
+    if (!e) return ISV_ERR_INVALID_ARG;
+    if (!on) {
+        if (e->resident_ready) { const int rc = leave_resident(e, true); if (rc != ISV_OK) return rc; }
+        e->resident_mode = false;
+        return ISV_OK;
+    }
+    if (!e->backend) { e->err = "the resident mode needs the HIP backend"; return ISV_ERR_UNSUPPORTED; }
+    e->tracks_cap = std::max(64, 2 * e->p.cfg.max_landmarks);
+    const int rc = isv_backend_seq_enable(e->backend, e->tracks_cap);
+    if (rc != ISV_OK) { e->err = std::string("isv_backend_seq_enable: ") + isv_backend_last_error(e->backend); return rc; }
+    e->resident_mode = true;
+    return ISV_OK;
+}
+extern "C" int64_t isv_estimator_resident_frames(const isv_estimator_t *e) { return e ? e->resident_frames : 0; }
+
 // Estimator::processImage (src/estimator.cpp:126-215) on every staged sequence, the solves batched
 extern "C" int isv_estimator_step(isv_estimator_t *e) {
     if (!e) return ISV_ERR_INVALID_ARG;
@@ -652,6 +841,17 @@ extern "C" int isv_estimator_step(isv_estimator_t *e) {
     const auto t0 = clk::now();
     for (double &x : e->step_ms) x = 0;
     std::vector<std::string> errs;
+    if (e->resident_ready) {
+        bool all = true;
+        for (const Sequence &s : e->seq) all &= s.staged && s.resident && s.flag == NON_LINEAR;
+        if (all) {
+            const int rc = resident_frame(e, errs);
+            e->step_ms[0] = ms(t0, clk::now());
+            return rc;
+        }
+        const int rc = leave_resident(e, true);    // lock step broken (a sequence without an image this frame): the host path takes over
+        if (rc != ISV_OK) return rc;               // (and seeds again once every sequence solves in the same frame)
+    }
     // per sequence: addFeatureAndCheckParallax, Headers, the INITIAL bookkeeping; mark[si] = 1 when the sequence solves
     std::vector<char> mark(e->seq.size(), 0);
     int rc = parallel_for((int)e->seq.size(), errs, [&](int si, std::string &err) {
@@ -752,6 +952,12 @@ extern "C" int isv_estimator_step(isv_estimator_t *e) {
         if (!ok) { s.flag = INITIAL_STRUCTURE; s.rollpitch.clear(); }
         return (int)ISV_OK;
     });
+    if (e->resident_mode && !e->resident_ready && solve.size() == e->seq.size()) {
+        // every sequence solved this frame and is in steady state: from the next frame on the windows stay on the device
+        bool all = true;
+        for (const Sequence &s : e->seq) all &= s.flag == NON_LINEAR && s.frame_count == s.N - 1 && !s.have_to_add;
+        if (all) { const int rcs = seed_resident(e); if (rcs != ISV_OK && rcs != ISV_ERR_CAPACITY && rcs != ISV_ERR_UNSUPPORTED) return rcs; }
+    }
     const auto t5 = clk::now();
     e->step_ms[0] = ms(t0, t5); e->step_ms[1] = ms(t0, t1); e->step_ms[2] = ms(t1, t2); e->step_ms[3] = ms(t2, t3);
     e->step_ms[4] = ms(t3, t4); e->step_ms[5] = ms(t4, t5);
@@ -776,6 +982,12 @@ extern "C" int isv_estimator_get_window(const isv_estimator_t *e, int32_t seq, d
                                         double *Bgs, double *Headers) {
     SEQ_OR_FAIL(e, seq);
     const Sequence &s = e->seq[seq];
+    if (s.resident) {
+        // the window lives on the device and has NOT been slid yet there (the slide is applied with the next frame): only the
+        // frames the host tracks itself (0, 1, N-1) are current in the members below
+        ((isv_estimator *)e)->err = "isv_estimator_get_window: the sequence is device-resident; isv_estimator_set_resident(e, 0) first";
+        return ISV_ERR_UNSUPPORTED;
+    }
     for (int i = 0; i < s.N; i++) {
         if (Ps) std::memcpy(Ps + i * 3, s.Ps[i].data(), 24);
         if (Rs) std::memcpy(Rs + i * 9, s.Rs[i].data(), 72);

@@ -9,7 +9,7 @@
 __host__ __device__ inline size_t proj_lds_doubles_per_wave(int N, int mode) { return (size_t)N * 12 + 12 + (mode == 0 ? 64 * 15 : (size_t)N * 18); }
 
 __global__ void k_vector2double(DevBatch d);
-__global__ void k_imu_prep(DevBatch d);
+__global__ void k_imu_prep(DevBatch d, const int32_t *sel);     // sel: factor index per workgroup (null: identity; < 0: skip)
 template <int MODE> __global__ void k_proj_linearize(DevBatch d, const double *pose_src, const double *lam_src, double *fcost_out, int gate);
 template <bool JAC> __global__ void k_imu_linearize(DevBatch d, const double *pose_src, const double *sb_src, double *cost_out, int gate);
 template <bool JAC> __global__ void k_prior_linearize(DevBatch d, const double *pose_src, const double *sb_src, double *cost_out, int gate);

@@ -50,10 +50,11 @@ __global__ void k_vector2double(DevBatch d) {
 // kernel keeps the textbook order (LU with partial pivoting, column-wise solves, Cholesky) and
 // forbids FMA contraction.  One wavefront per factor; the work is 15^3 and runs once per solve.
 #pragma clang fp contract(off)
-__global__ __launch_bounds__(64) void k_imu_prep(DevBatch d) {
+__global__ __launch_bounds__(64) void k_imu_prep(DevBatch d, const int32_t *sel) {
     __shared__ double A[225], Inv[225], L[225];
     __shared__ int perm[15];
-    int f = blockIdx.x, t = threadIdx.x;
+    int f = sel ? sel[blockIdx.x] : (int)blockIdx.x, t = threadIdx.x;
+    if (f < 0) return;                 // (device-resident sequences: only the records of the newest frame are new)
     const double *cov = d.imu_cov + (size_t)f * 225;
     for (int e = t; e < 225; e += 64) A[e] = cov[e];
     if (t < 15) perm[t] = t;

@@ -30,7 +30,8 @@ class isv_solver_vtbl_t(C.Structure):
 
 EXPORTS = ["isv_estimator_create", "isv_estimator_create_with_solver", "isv_estimator_destroy", "isv_estimator_last_error",
            "isv_estimator_process_imu", "isv_estimator_process_imu_n", "isv_estimator_last_step_ms", "isv_estimator_push_image", "isv_estimator_set_bootstrap", "isv_estimator_step",
-           "isv_estimator_status", "isv_estimator_get_window", "isv_estimator_get_preintegration", "isv_estimator_last_summary", "isv_estimator_trajectory", "isv_estimator_failed_solves"]
+           "isv_estimator_status", "isv_estimator_get_window", "isv_estimator_get_preintegration", "isv_estimator_last_summary", "isv_estimator_trajectory", "isv_estimator_failed_solves",
+           "isv_estimator_set_resident", "isv_estimator_resident_frames"]
 
 _bound = False
 
@@ -56,6 +57,8 @@ def _bind(lib):
     lib.isv_estimator_last_summary.argtypes = [vp, C.c_int32, C.POINTER(abi.isv_summary_t)]
     lib.isv_estimator_trajectory.argtypes = [vp, C.c_int32, C.c_int32, dp, C.c_int32]
     lib.isv_estimator_failed_solves.argtypes = [vp, C.c_int32]
+    lib.isv_estimator_set_resident.argtypes = [vp, C.c_int32]
+    lib.isv_estimator_resident_frames.argtypes = [vp]; lib.isv_estimator_resident_frames.restype = C.c_int64
     _bound = True
 
 
@@ -144,6 +147,13 @@ class SequenceEstimator:
         s = abi.isv_summary_t()
         self._check(self.lib.isv_estimator_last_summary(self.h, seq, C.byref(s)), "last_summary")
         return s
+
+    def set_resident(self, on=True):
+        """keep the windows on the device between frames (include/isvins_estimator.h)"""
+        self._check(self.lib.isv_estimator_set_resident(self.h, 1 if on else 0), "set_resident")
+
+    def resident_frames(self):
+        return int(self.lib.isv_estimator_resident_frames(self.h))
 
     def failed_solves(self, seq):
         return self._check(self.lib.isv_estimator_failed_solves(self.h, seq), "failed_solves")
