@@ -735,6 +735,7 @@ int leave_resident(isv_estimator *e, bool host_has_slid) {
 // one lock-step frame of the resident sequences: only what is new crosses PCIe (include/isvins_backend.h)
 int resident_frame(isv_estimator *e, std::vector<std::string> &errs) {
     const int S = (int)e->seq.size();
+    const auto tr0 = std::chrono::steady_clock::now();
     std::vector<isv_seq_frame_t> fr(S);
     std::vector<isv_seq_result_t> res(S);
     std::vector<int32_t *> flags(S);
@@ -770,8 +771,10 @@ int resident_frame(isv_estimator *e, std::vector<std::string> &errs) {
         return (int)ISV_OK;
     });
     if (rc != ISV_OK) { e->err = errs[0]; return rc; }
+    const auto tr1 = std::chrono::steady_clock::now();
     rc = isv_backend_seq_frame(e->backend, S, fr.data(), res.data(), flags.data(), nullptr);
     if (rc != ISV_OK) { e->err = std::string("resident frame failed: ") + isv_backend_last_error(e->backend); return rc; }
+    const auto tr2 = std::chrono::steady_clock::now();
     e->resident_frames++;
     bool failed = false;
     for (int si = 0; si < S; si++) failed |= res[si].summary.status != ISV_OK;
@@ -811,6 +814,8 @@ int resident_frame(isv_estimator *e, std::vector<std::string> &errs) {
         if (failed && !ok) { s.flag = INITIAL_STRUCTURE; s.rollpitch.clear(); }
         return (int)ISV_OK;
     });
+    auto msd = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    e->step_ms[1] = msd(tr0, tr1); e->step_ms[4] = msd(tr1, tr2); e->step_ms[5] = msd(tr2, std::chrono::steady_clock::now());
     return S;
 }
 
@@ -845,7 +850,7 @@ extern "C" int isv_estimator_step(isv_estimator_t *e) {
         bool all = true;
         for (const Sequence &s : e->seq) all &= s.staged && s.resident && s.flag == NON_LINEAR;
         if (all) {
-            const int rc = resident_frame(e, errs);
+            const int rc = resident_frame(e, errs);        // (fills step_ms[1] host preparation, [4] hand-over + device, [5] read-back + slide)
             e->step_ms[0] = ms(t0, clk::now());
             return rc;
         }

@@ -184,10 +184,12 @@ struct GroupResult {
     long steps = 0;
 };
 
-void run_group(const Stream &st, int first_seq, int n_seq, const std::string &out_dir, int write_upto, int feed_threads, GroupResult &res) {
+void run_group(const Stream &st, int first_seq, int n_seq, const std::string &out_dir, int write_upto, int feed_threads, bool resident, GroupResult &res) {
     isv_estimator_t *e = nullptr;
     res.rc = isv_estimator_create(&st.params, n_seq, &e);
     if (res.rc != ISV_OK) { res.err = "isv_estimator_create failed (a GPU is required)"; return; }
+    // the windows stay on the device between frames (include/isvins_estimator.h); --no-resident: pack and upload them every frame
+    if (resident && isv_estimator_set_resident(e, 1) != ISV_OK) { res.rc = ISV_ERR_UNSUPPORTED; res.err = isv_estimator_last_error(e); isv_estimator_destroy(e); return; }
     const int N = st.params.cfg.n_frames;
     int frames_seen = 0;
     using clk = std::chrono::steady_clock;
@@ -267,8 +269,9 @@ int main(int argc, char **argv) {
     // which serialises the groups' fork / join patterns against each other (256 sequences in 4 groups: 15.7 k frames/s
     // with 4 queues, 27.8 k with 16).  Ask for more before the runtime initialises, unless the caller has chosen.
     setenv("GPU_MAX_HW_QUEUES", "16", 0);
-    if (argc < 2) { fprintf(stderr, "usage: isv_replay STREAM | --euroc MAV0_DIR --tracks CSV --config TXT  [--sequences S] [--groups K] [--out DIR] [--write W]\n"); return 2; }
+    if (argc < 2) { fprintf(stderr, "usage: isv_replay STREAM | --euroc MAV0_DIR --tracks CSV --config TXT  [--sequences S] [--groups K] [--out DIR] [--write W] [--no-resident]\n"); return 2; }
     int S = 1, K = 0, W = 1;                        // K = 0: choose the groups from the sequence count
+    bool resident = true;                           // windows kept on the device between frames (--no-resident: re-upload every frame)
     std::string out_dir, euroc_dir, tracks_path, config_path, stream_path, dump_path;
     for (int i = 1; i < argc; i++) {
         if (!strcmp(argv[i], "--dump-events") && i + 1 < argc) { dump_path = argv[++i]; continue; }
@@ -280,6 +283,8 @@ int main(int argc, char **argv) {
         else if (!strcmp(argv[i], "--groups") && i + 1 < argc) K = atoi(argv[++i]);
         else if (!strcmp(argv[i], "--out") && i + 1 < argc) out_dir = argv[++i];
         else if (!strcmp(argv[i], "--write") && i + 1 < argc) W = atoi(argv[++i]);
+        else if (!strcmp(argv[i], "--no-resident")) resident = false;
+        else if (!strcmp(argv[i], "--resident")) resident = true;
         else { fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
     }
     if (K == 0) { K = S / 512; if (K > 8) K = 8; if (K < 1) K = 1; }      // ~512 sequences per group, at most 8 groups
@@ -315,7 +320,7 @@ int main(int argc, char **argv) {
     const auto t0 = std::chrono::steady_clock::now();
     for (int k = 0; k < K; k++) {
         const int a = (int)((long)S * k / K), b = (int)((long)S * (k + 1) / K);
-        th.emplace_back(run_group, std::cref(st), a, b - a, out_dir, W, feed_threads, std::ref(res[k]));
+        th.emplace_back(run_group, std::cref(st), a, b - a, out_dir, W, feed_threads, resident, std::ref(res[k]));
     }
     for (auto &t : th) t.join();
     const double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
@@ -327,10 +332,10 @@ int main(int argc, char **argv) {
         if (r.seconds > secs) secs = r.seconds;
         for (int k = 0; k < 6; k++) ms[k] += r.step_ms_sum[k];
     }
-    printf("{\"sequences\": %d, \"groups\": %d, \"frames_in_stream\": %d, \"n_frames_window\": %d, \"solved_in_steady_state\": %ld, "
+    printf("{\"resident_windows\": %s, \"sequences\": %d, \"groups\": %d, \"frames_in_stream\": %d, \"n_frames_window\": %d, \"solved_in_steady_state\": %ld, "
            "\"steady_state_seconds\": %.6f, \"frames_per_second\": %.1f, \"wall_seconds\": %.3f, "
            "\"mean_step_ms\": {\"step\": %.3f, \"features_and_packing\": %.3f, \"triangulate\": %.3f, \"init_factor_graph\": %.3f, \"solve_odometry\": %.3f, \"readback_and_slide\": %.3f}}\n",
-           S, K, st.n_frames, st.params.cfg.n_frames, solved, secs, secs > 0 ? solved / secs : 0.0, wall,
+           resident ? "true" : "false", S, K, st.n_frames, st.params.cfg.n_frames, solved, secs, secs > 0 ? solved / secs : 0.0, wall,
            steps ? ms[0] / steps : 0.0, steps ? ms[1] / steps : 0.0, steps ? ms[2] / steps : 0.0, steps ? ms[3] / steps : 0.0, steps ? ms[4] / steps : 0.0,
            steps ? ms[5] / steps : 0.0);
     return 0;
