@@ -19,6 +19,14 @@ extern "C" int isv_backend_init_factor_graph(isv_backend_t *, isv_window_t *, is
 extern "C" int isv_backend_optimize_batch(isv_backend_t *, int32_t, isv_window_t *const *, isv_summary_t *, isv_marg_result_t *) { return ISV_ERR_DEVICE; }
 extern "C" int isv_backend_init_factor_graph_batch(isv_backend_t *, int32_t, isv_window_t *const *, isv_summary_t *, double *) { return ISV_ERR_DEVICE; }
 extern "C" int isv_backend_solve_odometry_batch(isv_backend_t *, int32_t, isv_window_t *const *, isv_summary_t *, isv_marg_result_t *) { return ISV_ERR_DEVICE; }
+// (the device-resident mode is only reachable with the HIP backend: its entry points are stubs here, like the rest)
+extern "C" const char *isv_backend_last_error(const isv_backend_t *) { return "no device in the sanitizer harness"; }
+extern "C" int isv_backend_seq_enable(isv_backend_t *, int32_t) { return ISV_ERR_DEVICE; }
+extern "C" int isv_backend_seq_seed(isv_backend_t *, int32_t, isv_window_t *const *, const int32_t *, const isv_seq_track_t *const *, const double *const *) { return ISV_ERR_DEVICE; }
+extern "C" int isv_backend_seq_frame(isv_backend_t *, int32_t, const isv_seq_frame_t *, isv_seq_result_t *, int32_t *const *, isv_marg_result_t *) { return ISV_ERR_DEVICE; }
+extern "C" int isv_backend_seq_download(isv_backend_t *, int32_t, isv_window_t *, int32_t, double *, int32_t *) { return ISV_ERR_DEVICE; }
+extern "C" int isv_backend_seq_flush(isv_backend_t *, int32_t, const int32_t *, const int32_t *) { return ISV_ERR_DEVICE; }
+extern "C" int isv_backend_seq_marg(isv_backend_t *, int32_t, isv_marg_result_t *) { return ISV_ERR_DEVICE; }
 
 static int g_calls = 0;
 static int st_triangulate(void *, int32_t n, isv_window_t *const *ws) {
