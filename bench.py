@@ -397,28 +397,54 @@ def main():
             def pgo_time(n_graphs, reps):
                 opt = pgm.PoseGraphOptimizer(K, max_graphs=n_graphs, max_loop_blocks=8 * K)
                 firsts = [graphs[s_ % 8][2] for s_ in range(n_graphs)]; curs = [K - 1] * n_graphs
-                best, its = None, 0
+                best, its, kms, nblk = None, 0, None, 0
                 for rep in range(reps + 1):
                     batch = [pgm.clone_keyframes(graphs[s_ % 8][0]) for s_ in range(n_graphs)]
                     t1 = time.perf_counter(); res = opt.optimize_batch(batch, firsts, curs); dt = time.perf_counter() - t1
-                    if rep > 0: best = dt if best is None else min(best, dt)
+                    if rep > 0 and (best is None or dt < best):
+                        best = dt; kms, nblk = opt.last_kernel_ms()
                     its = float(np.mean([r.iterations for r in res]))
                 opt.close()
-                return best, its
-            t_one, it_one = pgo_time(1, 3)
-            t_all, it_all = pgo_time(S, 2)
+                return best, its, kms, nblk
+            t_one, it_one, k_one, nb_one = pgo_time(1, 3)
+            t_all, it_all, k_all, nb_all = pgo_time(S, 2)
+            # algorithmic flops of one graph's pass: per LM iteration one factorisation of the 6x6-block skyline (a block row of
+            # w blocks costs ~ w^2 block products of 2 * 6^3 flops, summed as nblk * mean w ~ 2 blocks for a chain + the loop
+            # rows) and two triangular solves; then the selected inverse (~ 2 factorisations).  Priced per skyline BLOCK STEP:
+            # 2 * 6^3 flops, the unit k_pgo's recurrences advance by.
+            blk_steps = lambda nblk, its: nblk * (its + 1.0) * 3.0 + 2.0 * nblk * 3.0
+            flops_one = 432.0 * blk_steps(nb_one, it_one); flops_all = 432.0 * blk_steps(nb_all, it_all)
             pgo = {"workload": f"PoseGraph::optimizeCS pass (LM <= 10 iterations + marginal covariances + write-back) over {K} keyframes with {loops} loop closures, synthetic",
                    "ms_one_graph": 1e3 * t_one, "lm_iterations_one_graph": it_one,
                    "batch_graphs": S, "ms_per_batch_call": 1e3 * t_all, "value": S / t_all, "unit": "graphs/s", "lm_iterations_batch_mean": it_all,
-                   "what": "one isv_pgo_optimize_batch call: host structure analysis + H2D + k_pgo (one wavefront per graph) + D2H + write-back"}
+                   "what": "one isv_pgo_optimize_batch call: host structure analysis + H2D + k_pgo (one wavefront per graph) + D2H + write-back",
+                   "kernel_ms_one_graph": k_one, "kernel_ms_batch": k_all,
+                   "roofline": {"kernel": "k_pgo", "bound": "fp64-valu-latency", "achieved": flops_all / (k_all * 1e-3) / 1e12 if k_all else None, "peak": FP64_PEAK_TFLOPS,
+                                "unit": "TFLOP/s", "frac": (flops_all / (k_all * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if k_all else None, "traffic": None,
+                                "avg_launch_us": 1e3 * k_all if k_all else None, "skyline_blocks_per_graph": nb_all / S,
+                                "block_steps_per_second_batch": blk_steps(nb_all, it_all) / (k_all * 1e-3) if k_all else None,
+                                "us_per_block_step_one_graph": (1e3 * k_one / blk_steps(nb_one, it_one)) if k_one else None,
+                                "note": "one wavefront per graph walks a chain of dependent 6x6 block steps (skyline Cholesky, Takahashi selected inverse): a latency chain, priced against the FP64 vector peak; the batch fills the GPU with graphs"}}
             if cpu_lib is not None and hasattr(cpu_lib, "isvo_pgo_optimize"):
                 kfp = C.POINTER(pgm.isv_pg_keyframe_t)
                 cpu_lib.isvo_pgo_optimize.argtypes = [C.POINTER(pgm.isv_pgo_config_t), C.c_int32, kfp, C.c_int32, C.c_int32, C.POINTER(pgm.isv_pgo_result_t)]
                 cpu_lib.isvo_pgo_optimize.restype = C.c_int
-                cfgp = pgm.make_config(K); o = pgm.clone_keyframes(graphs[0][0]); r = pgm.isv_pgo_result_t()
-                t1 = time.perf_counter(); cpu_lib.isvo_pgo_optimize(C.byref(cfgp), K, o, graphs[0][2], K - 1, C.byref(r)); t_cpu = time.perf_counter() - t1
-                pgo["cpu_baseline"] = {"value": 1.0 / t_cpu, "unit": "graphs/s", "cores": 1, "kind": "port", "ms_one_graph": 1e3 * t_cpu,
-                                       "sample": "one graph; the oracle forms DENSE normal equations (6K x 6K), which a sparse CPU solver such as the reference's SPARSE_NORMAL_CHOLESKY would not: an upper bound on the CPU time, not a like-for-like baseline"}
+                cfgp = pgm.make_config(K)
+                def cpu_pgo(sparse, reps_):
+                    cpu_lib.isvo_pgo_set_sparse(1 if sparse else 0)
+                    best_ = None
+                    try:
+                        for _ in range(reps_):
+                            o = pgm.clone_keyframes(graphs[0][0]); r = pgm.isv_pgo_result_t()
+                            t1 = time.perf_counter(); cpu_lib.isvo_pgo_optimize(C.byref(cfgp), K, o, graphs[0][2], K - 1, C.byref(r)); dt_ = time.perf_counter() - t1
+                            best_ = dt_ if best_ is None else min(best_, dt_)
+                    finally:
+                        cpu_lib.isvo_pgo_set_sparse(0)
+                    return best_
+                t_sky = cpu_pgo(True, 5); t_dense = cpu_pgo(False, 1)
+                pgo["cpu_baseline"] = {"value": 1.0 / t_sky, "unit": "graphs/s", "cores": 1, "kind": "port", "ms_one_graph": 1e3 * t_sky,
+                                       "sample": "one graph, best of 5: the oracle's LM loop on a SKYLINE (envelope) Cholesky with the covariance blocks by envelope solves (isvo_pgo_set_sparse; oracle/isv_pgo_oracle.c) -- the work a sparse direct solver such as the reference's SPARSE_NORMAL_CHOLESKY does on this matrix; -O3 -march=native, 1 thread (the reference runs this step in one background thread)",
+                                       "ms_one_graph_dense_checker": 1e3 * t_dense}
             extra["pose_graph_optimisation"] = pgo
         except Exception as ex:                          # (secondary leg: never take the benchmark line down)
             extra["pose_graph_optimisation"] = {"error": repr(ex)}

@@ -72,6 +72,9 @@ int  isv_combined_factors_add(isv_combined_factors_t *acc, int32_t *acc_length, 
 int  isv_pgo_create(const isv_pgo_config_t *cfg, isv_pgo_t **out);
 void isv_pgo_destroy(isv_pgo_t *h);
 const char *isv_pgo_last_error(const isv_pgo_t *h);
+/* measurement: duration of the pose-graph kernel of the last optimize call (HIP events on the handle's stream) and the
+ * number of 6x6 skyline blocks its graphs held */
+int  isv_pgo_last_kernel_ms(isv_pgo_t *h, double *ms, double *skyline_blocks);
 
 /* One pass of PoseGraph::optimizeCS (src/pose_graph/pose_graph.cpp:246-409) over the keyframe list kf[0..n) (list
  * order, indices increasing): solve, covariances, updatePose / updateCov, the relative-pose update() calls, drift, and

@@ -709,6 +709,8 @@ struct isv_pgo {
     PgDev d{};
     std::vector<void *> allocs;
     size_t cap_pose = 0, cap_edge = 0, cap_blk = 0, cap_adj = 0, cap_col = 0;
+    hipEvent_t ev[2] = {nullptr, nullptr};       // around k_pgo of the last call (isv_pgo_last_kernel_ms)
+    double last_blocks = 0;                       // skyline blocks of the last batch (all graphs)
 };
 
 #define PCHK(h, call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { (h)->err = std::string(#call) + ": " + hipGetErrorString(e_); return ISV_ERR_DEVICE; } } while (0)
@@ -721,11 +723,22 @@ template <typename T> static int pal(isv_pgo *h, T **p, size_t n) {
 #define PTRY(x) do { int rc_ = (x); if (rc_ != ISV_OK) return rc_; } while (0)
 
 extern "C" const char *isv_pgo_last_error(const isv_pgo_t *h) { return h ? h->err.c_str() : "null handle"; }
+// measurement: duration of k_pgo in the last optimize call (HIP events on the handle's stream) and the number of 6x6 skyline
+// blocks its graphs held
+extern "C" int isv_pgo_last_kernel_ms(isv_pgo_t *h, double *ms, double *skyline_blocks) {
+    if (!h || !ms || !h->ev[0]) return ISV_ERR_INVALID_ARG;
+    float f = 0;
+    if (hipEventElapsedTime(&f, h->ev[0], h->ev[1]) != hipSuccess) { (void)hipGetLastError(); return ISV_ERR_DEVICE; }
+    *ms = f;
+    if (skyline_blocks) *skyline_blocks = h->last_blocks;
+    return ISV_OK;
+}
 
 extern "C" void isv_pgo_destroy(isv_pgo_t *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     for (void *p : h->allocs) (void)hipFree(p);
+    for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1026,8 +1039,12 @@ extern "C" int isv_pgo_optimize_batch(isv_pgo_t *h, int32_t ng, const int32_t *n
     d.idx_lds_rows = d.idx_lds_cols = 0;
     // (ISV_PGO_IDX_GLOBAL: test hook for the path graphs too large for the LDS copies take)
     if (max_nf > 0 && idx_bytes <= 48 * 1024 && !getenv("ISV_PGO_IDX_GLOBAL")) { d.idx_lds_rows = (int32_t)max_nf; d.idx_lds_cols = (int32_t)max_cols; } else idx_bytes = 0;
+    if (!h->ev[0]) { PCHK(h, hipEventCreate(&h->ev[0])); PCHK(h, hipEventCreate(&h->ev[1])); }
+    PCHK(h, hipEventRecord(h->ev[0], st));
     hipLaunchKernelGGL(k_pgo, dim3(ng), dim3(64), idx_bytes, st, d);
     PCHK(h, hipGetLastError());
+    PCHK(h, hipEventRecord(h->ev[1], st));
+    h->last_blocks = (double)nblk_tot;
     std::vector<double> cov(pose.size() / 7 * 36);
     // (blocking copies after the stream has drained: the destinations are pageable -- `results` is the caller's array --
     // and an asynchronous copy into pageable memory may still be completing inside the runtime after the stream is idle)

@@ -166,6 +166,75 @@ static void pg_hessian(const pg_problem_t *P, double *H) {
         }
     }
 }
+/* ---- the CPU BASELINE's linear algebra (bench.py, pose_graph_optimisation.cpp_baseline): the same LM loop on a SKYLINE
+ * (envelope) Cholesky.  In the keyframes' order the normal equations are block tridiagonal plus one long row per loop
+ * closure, and a Cholesky factor fills only inside the row envelope -- what a sparse direct solver (the reference's
+ * SPARSE_NORMAL_CHOLESKY, pose_graph.cpp:262) exploits, and what k_pgo stores.  isvo_pgo_set_sparse(1) switches
+ * pg_minimize and the covariance step to it; the dense path stays the CHECKER of the GPU tests (tests/test_oracle_pgo.py
+ * compares the two).  Storage stays the dense n x n array, only envelope entries are touched. */
+static int g_pgo_sparse = 0;
+void isvo_pgo_set_sparse(int on) { g_pgo_sparse = on; }
+/* first[i]: column of the first non-zero of row i of H (lower triangle) */
+static void pg_envelope(const pg_problem_t *P, int *first) {
+    const int n = P->ncols;
+    for (int i = 0; i < n; i++) first[i] = i - i % 6;
+    for (int e = 0; e < P->nedges; e++) {
+        PG_BLOCKS(P, e, E, nb, blk, Jp)
+        (void)Jp;
+        for (int k = 0; k < nb; k++) for (int m = 0; m < nb; m++) {
+            const int ck = P->col[blk[k]], cm = P->col[blk[m]];
+            if (ck < 0 || cm < 0 || cm >= ck) continue;
+            for (int a = 0; a < 6; a++) if (cm < first[ck + a]) first[ck + a] = cm;
+        }
+    }
+}
+static void pg_hessian_env(const pg_problem_t *P, double *H, const int *first) {
+    const int n = P->ncols;
+    for (int i = 0; i < n; i++) memset(H + (size_t)i * n + first[i], 0, sizeof(double) * (size_t)(i - first[i] + 1));
+    for (int e = 0; e < P->nedges; e++) {
+        PG_BLOCKS(P, e, E, nb, blk, Jp)
+        for (int k = 0; k < nb; k++) for (int m = 0; m < nb; m++) {
+            const int ck = P->col[blk[k]], cm = P->col[blk[m]]; if (ck < 0 || cm < 0 || cm > ck) continue;
+            for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) {
+                if (cm + b > ck + a) continue;
+                double s = 0; for (int r = 0; r < E->dim; r++) s += Jp[k][r * 6 + a] * Jp[m][r * 6 + b];
+                H[(size_t)(ck + a) * n + cm + b] += s;
+            }
+        }
+    }
+}
+static int chol_skyline(double *A, int n, const int *first) {
+    for (int i = 0; i < n; i++) {
+        double *Li = A + (size_t)i * n;
+        for (int j = first[i]; j < i; j++) {
+            const double *Lj = A + (size_t)j * n;
+            double s = Li[j];
+            for (int k = first[i] > first[j] ? first[i] : first[j]; k < j; k++) s -= Li[k] * Lj[k];
+            Li[j] = s / Lj[j];
+        }
+        double s = Li[i];
+        for (int k = first[i]; k < i; k++) s -= Li[k] * Li[k];
+        if (!(s > 0.0)) return 1;
+        Li[i] = sqrt(s);
+    }
+    return 0;
+}
+/* L L^T x = b in place; from: first row with a non-zero right-hand side (unit vectors of the covariance step) */
+static void chol_skyline_solve(const double *L, int n, const int *first, double *b, int from) {
+    for (int i = from; i < n; i++) {
+        const double *Li = L + (size_t)i * n;
+        double s = b[i];
+        for (int k = first[i] > from ? first[i] : from; k < i; k++) s -= Li[k] * b[k];
+        b[i] = s / Li[i];
+    }
+    for (int i = n - 1; i >= 0; i--) {
+        const double *Li = L + (size_t)i * n;
+        const double x = b[i] / Li[i];
+        b[i] = x;
+        for (int k = first[i]; k < i; k++) b[k] -= Li[k] * x;
+    }
+}
+
 static void pg_plus(const pg_problem_t *P, const double *pose, const double *delta, double *out) {
     for (int k = 0; k < P->P1; k++) {
         if (P->col[k] < 0) memcpy(out + 7 * k, pose + 7 * k, 56);
@@ -185,6 +254,8 @@ static void pg_minimize(pg_problem_t *P, int max_iter, isv_pgo_result_t *out) {
     const int n = P->ncols;
     double *scale = calloc(n + 1, 8), *diag = calloc(n + 1, 8), *g = calloc(n + 1, 8), *step = calloc(n + 1, 8), *delta = calloc(n + 1, 8);
     double *H = calloc((size_t)n * n + 1, 8), *mres = calloc(P->nres + 1, 8), *neg = calloc(n + 1, 8), *pp = calloc(7 * P->P1, 8);
+    int *first = calloc(n + 1, sizeof(int));
+    if (g_pgo_sparse) pg_envelope(P, first);
     double radius = 1e4, decrease_factor = 2.0;
     int reuse_diag = 0, invalid = 0, it = 0, term = ISV_TERM_RUNNING;
     double x_cost = pg_evaluate(P, P->pose, 1);
@@ -208,12 +279,13 @@ static void pg_minimize(pg_problem_t *P, int max_iter, isv_pgo_result_t *out) {
             for (int i = 0; i < n; i++) diag[i] = fmin(fmax(diag[i], 1e-6), 1e32);
         }
         reuse_diag = 1;
-        pg_hessian(P, H);
+        if (g_pgo_sparse) pg_hessian_env(P, H, first); else pg_hessian(P, H);
         for (int i = 0; i < n; i++) H[(size_t)i * n + i] += diag[i] / radius;          /* D = sqrt(diagonal / radius) */
         memset(g, 0, 8 * n); pg_left_mul(P, P->res, g);
-        int ls_fail = chol_lower(H, n) != 0;
+        int ls_fail = (g_pgo_sparse ? chol_skyline(H, n, first) : chol_lower(H, n)) != 0;
         if (!ls_fail) {
-            memcpy(step, g, 8 * n); chol_solve(H, n, step);
+            memcpy(step, g, 8 * n);
+            if (g_pgo_sparse) chol_skyline_solve(H, n, first, step, 0); else chol_solve(H, n, step);
             for (int i = 0; i < n; i++) { if (!isfinite(step[i])) ls_fail = 1; step[i] = -step[i]; }
         }
         int valid = 0; double model_cost_change = 0;
@@ -252,7 +324,7 @@ static void pg_minimize(pg_problem_t *P, int max_iter, isv_pgo_result_t *out) {
         if (it < ISV_MAX_TRACE) { out->trace_cost[it] = accepted ? x_cost : cand_cost; out->trace_accepted[it] = accepted; }
     }
     out->iterations = it; out->termination = term; out->final_cost = x_cost; out->status = ISV_OK;
-    free(scale); free(diag); free(g); free(step); free(delta); free(H); free(mres); free(neg); free(pp);
+    free(scale); free(diag); free(g); free(step); free(delta); free(H); free(mres); free(neg); free(pp); free(first);
 }
 
 /* PoseGraph::optimizeCS, one pass (pose_graph.cpp:246-409) */
@@ -319,6 +391,21 @@ int isvo_pgo_optimize(const isv_pgo_config_t *cfg, int32_t n, isv_pg_keyframe_t 
     if (P.ncols > 0) {
         double *H = (double *)calloc((size_t)P.ncols * P.ncols + 1, 8);
         pg_evaluate(&P, P.pose, 1);
+        if (g_pgo_sparse) {
+            /* the diagonal blocks of H^-1 only: six envelope solves per pose block */
+            int *first = (int *)calloc(P.ncols + 1, sizeof(int));
+            double *e = (double *)calloc(P.ncols + 1, 8);
+            pg_envelope(&P, first); pg_hessian_env(&P, H, first);
+            if (chol_skyline(H, P.ncols, first) == 0) {
+                for (int c = 0; c < P.ncols; c++) {
+                    const int c0 = c - c % 6;
+                    memset(e, 0, 8 * (size_t)P.ncols); e[c] = 1.0;
+                    chol_skyline_solve(H, P.ncols, first, e, c);
+                    for (int r = c0; r < c0 + 6; r++) Sig[(size_t)r * P.ncols + c] = e[r];
+                }
+            } else out->status = ISV_ERR_NONFINITE;
+            free(first); free(e);
+        } else {
         pg_hessian(&P, H);
         if (chol_lower(H, P.ncols) == 0) {
             for (int c = 0; c < P.ncols; c++) {              /* column c of the inverse */
@@ -327,6 +414,7 @@ int isvo_pgo_optimize(const isv_pgo_config_t *cfg, int32_t n, isv_pg_keyframe_t 
                 free(e);
             }
         } else out->status = ISV_ERR_NONFINITE;
+        }
         free(H);
     }
     /* write back (:366-385): updatePose, updateCov, update() of the previous keyframe's relative-pose factor */

@@ -190,3 +190,27 @@ def test_covariance_is_the_inverse_gauss_newton_hessian_with_the_reference_reado
         ref = Sig[6 * (k - 1): 6 * k, 6 * (k - 1): 6 * k]
         assert np.abs(S6 - ref[:5]).max() < 2e-4 * np.abs(ref).max(), k
     assert out[0].cov_computed == 1 and not np.any(abi.arr(out[0].cov)) and out[K - 1].cov_computed == 0
+
+
+@pytest.mark.parametrize("seed,K,loops", [(3, 80, 3), (9, 200, 5)])
+def test_skyline_cpu_baseline_equals_the_dense_path(oracle, seed, K, loops):
+    """the bench's pose-graph CPU baseline (isvo_pgo_set_sparse(1): LM on a skyline / envelope Cholesky, covariance blocks by
+    envelope solves -- what a sparse direct solver does with this matrix) against the dense path that checks the GPU:
+    same iterations and accept pattern, poses, covariances and drift to rounding"""
+    import time
+    kf, P, first = pg.make_pose_graph(seed, K, loops)
+    t0 = time.perf_counter(); a, ra = oracle_pgo(oracle, kf, first, K - 1); t_dense = time.perf_counter() - t0
+    oracle.isvo_pgo_set_sparse(1)
+    try:
+        t0 = time.perf_counter(); b, rb = oracle_pgo(oracle, kf, first, K - 1); t_sparse = time.perf_counter() - t0
+    finally:
+        oracle.isvo_pgo_set_sparse(0)
+    print(f"K={K}: dense {1e3 * t_dense:.1f} ms, skyline {1e3 * t_sparse:.1f} ms")
+    assert ra.iterations == rb.iterations and ra.termination == rb.termination and ra.status == rb.status == 0
+    assert list(ra.trace_accepted[: ra.iterations + 1]) == list(rb.trace_accepted[: rb.iterations + 1])
+    assert abs(ra.final_cost - rb.final_cost) <= 1e-9 * abs(ra.final_cost)
+    for x, y in zip(a, b):
+        assert np.abs(np.array(x.T_w_i) - np.array(y.T_w_i)).max() < 1e-9 and np.abs(np.array(x.R_w_i) - np.array(y.R_w_i)).max() < 1e-9
+        cx, cy = np.array(x.cov), np.array(y.cov)
+        assert np.abs(cx - cy).max() <= 1e-8 * max(np.abs(cx).max(), 1e-30)
+    assert np.abs(np.array(ra.t_drift) - np.array(rb.t_drift)).max() < 1e-9
