@@ -29,7 +29,7 @@ extern "C" {
 typedef struct isv_pg_keyframe {
     double  time_stamp;
     int32_t index;                 /* global keyframe index                                              */
-    int32_t sequence;              /* keyframes of sequence 0 are held constant (pose_graph.cpp:291)     */
+    int32_t sequence;              /* keyframes of sequence 0 are held constant (pose_graph.cpp:299-301) */
     int32_t has_loop, loop_index;  /* loop closure found by the reference's detector, matched keyframe    */
     double  loop_info[8];          /* relative t (3), relative q as w x y z (4), relative yaw (keyframe.h:110) */
     double  loop_weight;           /* keyframe.cpp:224                                                   */
@@ -46,8 +46,8 @@ typedef struct isv_pgo_config {
     int32_t max_keyframes;         /* capacity per graph                                                 */
     int32_t max_graphs;            /* graphs per batch call                                              */
     int32_t max_loop_blocks;       /* capacity: sum over loop edges of (later - earlier) keyframes, per graph */
-    int32_t max_iterations;        /* options.max_num_iterations = 10 (pose_graph.cpp:264)               */
-    double  huber_delta;           /* HuberLoss(0.1) (pose_graph.cpp:267)                                */
+    int32_t max_iterations;        /* options.max_num_iterations = 10 (pose_graph.cpp:268)               */
+    double  huber_delta;           /* HuberLoss(0.1) (pose_graph.cpp:271)                                */
 } isv_pgo_config_t;
 
 typedef struct isv_pgo_result {
@@ -57,7 +57,7 @@ typedef struct isv_pgo_result {
     int32_t n_poses, n_free;       /* parameter blocks in the problem, non-constant ones                 */
     int32_t n_loop_edges, _pad;
     double  initial_cost, final_cost;
-    double  yaw_drift, r_drift[9], t_drift[3];     /* pose_graph.cpp:389-396                             */
+    double  yaw_drift, r_drift[9], t_drift[3];     /* pose_graph.cpp:387-393                             */
     double  trace_cost[ISV_MAX_TRACE];
     int32_t trace_accepted[ISV_MAX_TRACE];
 } isv_pgo_result_t;

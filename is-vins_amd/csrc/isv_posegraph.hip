@@ -919,7 +919,7 @@ extern "C" int isv_pgo_optimize_batch(isv_pgo_t *h, int32_t ng, const int32_t *n
         std::vector<double> &pose = B.pose; std::vector<int32_t> &free_of = B.free_of, &adj_ptr = B.adj_ptr, &adj = B.adj, &start = B.start, &rowptr = B.rowptr, &colptr = B.colptr, &colrows = B.colrows;
         std::vector<PgEdge> &edges = B.edges;
         G.max_iter = h->cfg.max_iterations; G.huber = h->cfg.huber_delta;
-        // parameter blocks: keyframes first_looped_index .. cur_index in list order (pose_graph.cpp:271-299)
+        // parameter blocks: keyframes first_looped_index .. cur_index in list order (pose_graph.cpp:277-306)
         std::vector<int> &loc = local[g];
         loc.assign(n, -1);
         int pi = 0;
@@ -944,7 +944,7 @@ extern "C" int isv_pgo_optimize_batch(isv_pgo_t *h, int32_t ng, const int32_t *n
         }
         G.nf = nf;
         free_of.insert(free_of.end(), fo.begin(), fo.end());
-        // residual blocks of the keyframes BEFORE cur (pose_graph.cpp:303-332)
+        // residual blocks of the keyframes BEFORE cur (pose_graph.cpp:309-339)
         std::vector<std::vector<int32_t>> adjl(nf);
         std::vector<int> st(nf);
         for (int f = 0; f < nf; f++) st[f] = f;
@@ -1052,7 +1052,7 @@ extern "C" int isv_pgo_optimize_batch(isv_pgo_t *h, int32_t ng, const int32_t *n
     PCHK(h, hipMemcpy(pose.data(), d.pose, sizeof(double) * pose.size(), hipMemcpyDeviceToHost));
     PCHK(h, hipMemcpy(cov.data(), d.cov, sizeof(double) * cov.size(), hipMemcpyDeviceToHost));
     PCHK(h, hipMemcpy(results, d.res, sizeof(isv_pgo_result_t) * ng, hipMemcpyDeviceToHost));
-    // write back (pose_graph.cpp:366-407): updatePose, updateCov, the update() calls, drift, the keyframes after cur
+    // write back (pose_graph.cpp:362-407): updatePose, updateCov, the update() calls, drift, the keyframes after cur
     parallel_over_graphs([&](int g) {
         const int n = ns[g]; isv_pg_keyframe_t *kf = kfs[g];
         const PgGraph &G = graphs[g];
@@ -1069,7 +1069,7 @@ extern "C" int isv_pgo_optimize_batch(isv_pgo_t *h, int32_t ng, const int32_t *n
             // store whatever GetCovarianceBlock left; zeros marked "computed" are worse than no covariance)
             if (li < param_index && R.status == ISV_OK) {
                 // ceres::Covariance::GetCovarianceBlock returns the 7x7 AMBIENT block [Sigma 0; 0 0]; the reference receives it in a
-                // 36-double buffer and maps that as a column-major 6x6 (pose_graph.cpp:356-358): reproduced, stored row-major
+                // 36-double buffer and maps that as a column-major 6x6 (pose_graph.cpp:346-350): reproduced, stored row-major
                 double c7[49] = {0};
                 const double *S6 = cov.data() + (size_t)(G.pose0 + li) * 36;
                 for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) c7[a * 7 + b] = S6[a * 6 + b];

@@ -14,10 +14,10 @@
  * closed-loop known answer, covariance == inverse Hessian, operator+ against the SE(3) composition identities).
  *
  * Reference quirks kept (they change the stored results): the edge loop stops BEFORE cur_index, so the newest loop
- * edge is not part of the solve it triggered (:314); covariance blocks are fetched in the 7-dim AMBIENT space into a
- * 36-double buffer and mapped as a column-major 6x6 (:356-358), i.e. the stored `cov` is the first 36 doubles of the
+ * edge is not part of the solve it triggered (:312-313); covariance blocks are fetched in the 7-dim AMBIENT space into a
+ * 36-double buffer and mapped as a column-major 6x6 (:346-350), i.e. the stored `cov` is the first 36 doubles of the
  * row-major 7x7 [Sigma 0; 0 0] re-read column-major; the update() of every relative-pose factor runs AFTER updatePose
- * and therefore sees old == new (:376-379).  Not reproducible (undefined behaviour in the reference): updateCov of
+ * and therefore sees old == new (:375-378).  Not reproducible (undefined behaviour in the reference): updateCov of
  * cur_index reads poses_cov[param_index] one past the end (:374) -- cur's cov is left untouched here.
  */
 #include <stdio.h>
@@ -169,7 +169,7 @@ static void pg_hessian(const pg_problem_t *P, double *H) {
 /* ---- the CPU BASELINE's linear algebra (bench.py, pose_graph_optimisation.cpp_baseline): the same LM loop on a SKYLINE
  * (envelope) Cholesky.  In the keyframes' order the normal equations are block tridiagonal plus one long row per loop
  * closure, and a Cholesky factor fills only inside the row envelope -- what a sparse direct solver (the reference's
- * SPARSE_NORMAL_CHOLESKY, pose_graph.cpp:262) exploits, and what k_pgo stores.  isvo_pgo_set_sparse(1) switches
+ * SPARSE_NORMAL_CHOLESKY, pose_graph.cpp:266) exploits, and what k_pgo stores.  isvo_pgo_set_sparse(1) switches
  * pg_minimize and the covariance step to it; the dense path stays the CHECKER of the GPU tests (tests/test_oracle_pgo.py
  * compares the two).  Storage stays the dense n x n array, only envelope entries are touched. */
 static int g_pgo_sparse = 0;
@@ -333,7 +333,7 @@ int isvo_pgo_optimize(const isv_pgo_config_t *cfg, int32_t n, isv_pg_keyframe_t 
     memset(out, 0, sizeof(*out));
     pg_problem_t P; memset(&P, 0, sizeof(P));
     P.huber = cfg->huber_delta;
-    /* parameter blocks: keyframes first_looped_index .. cur_index in list order (:271-299) */
+    /* parameter blocks: keyframes first_looped_index .. cur_index in list order (:277-306) */
     int *local = (int *)malloc(sizeof(int) * (n + 1));      /* list position -> local index, -1 if outside */
     P.kf = (const isv_pg_keyframe_t **)calloc(n + 1, sizeof(void *));
     int pi = 0, cur_pos = -1;
@@ -359,7 +359,7 @@ int isvo_pgo_optimize(const isv_pgo_config_t *cfg, int32_t n, isv_pg_keyframe_t 
         if (!constant) P.nfree++;
     }
     P.ncols = 6 * P.nfree;
-    /* residual blocks (:303-332), keyframes BEFORE cur only */
+    /* residual blocks (:309-339), keyframes BEFORE cur only */
     P.edges = (pg_edge_t *)calloc(3 * (size_t)P.P1 + 1, sizeof(pg_edge_t));
     P.loopf = (isv_relpose_t *)calloc(P.P1 + 1, sizeof(isv_relpose_t));
     int ne = 0, roff = 0, nloop = 0;
@@ -386,7 +386,7 @@ int isvo_pgo_optimize(const isv_pgo_config_t *cfg, int32_t n, isv_pg_keyframe_t 
     out->n_poses = P.P1; out->n_free = P.nfree; out->n_loop_edges = nloop;
     if (P.ncols > 0) pg_minimize(&P, cfg->max_iterations, out);
     else { out->initial_cost = out->final_cost = pg_evaluate(&P, P.pose, 0); out->termination = ISV_TERM_GRADIENT_TOL; }
-    /* ceres::Covariance of every block before cur (:352-359): (J^T J)^-1 at the solution, tangent space, lifted by [I6; 0] */
+    /* ceres::Covariance of every block before cur (:345-350): (J^T J)^-1 at the solution, tangent space, lifted by [I6; 0] */
     double *Sig = (double *)calloc((size_t)P.ncols * P.ncols + 1, 8);
     if (P.ncols > 0) {
         double *H = (double *)calloc((size_t)P.ncols * P.ncols + 1, 8);
@@ -417,7 +417,7 @@ int isvo_pgo_optimize(const isv_pgo_config_t *cfg, int32_t n, isv_pg_keyframe_t 
         }
         free(H);
     }
-    /* write back (:366-385): updatePose, updateCov, update() of the previous keyframe's relative-pose factor */
+    /* write back (:362-385): updatePose, updateCov, update() of the previous keyframe's relative-pose factor */
     isv_pg_keyframe_t *last = NULL; const double *last_pose = NULL;
     for (int k = 0; k < n; k++) {
         const int li = local[k]; if (li < 0) continue;
@@ -433,7 +433,7 @@ int isvo_pgo_optimize(const isv_pgo_config_t *cfg, int32_t n, isv_pg_keyframe_t 
         if (last) isvo_relpose_update(&last->relative_pose, last->T_w_i, last->R_w_i, kf[k].T_w_i, kf[k].R_w_i, last_pose, p);
         last = &kf[k]; last_pose = p;
     }
-    /* drift (:387-396) and the keyframes after cur (:400-407) */
+    /* drift (:387-393) and the keyframes after cur (:399-407) */
     {
         const isv_pg_keyframe_t *c = &kf[cur_pos];
         double yc[3], yv[3], vT[9], t[3];
