@@ -23,6 +23,7 @@ extern "C" const char *isv_backend_last_error(const isv_backend_t *h) { return h
 extern "C" void isv_backend_destroy(isv_backend_t *h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
+    if (h->graph_exec) (void)hipGraphExecDestroy(h->graph_exec);
     if (h->seq && h->seq_free) h->seq_free(h->seq);
     if (h->init_scratch) (void)hipFree(h->init_scratch);
     if (h->init_kld) (void)hipFree(h->init_kld);
@@ -502,16 +503,54 @@ extern "C" int isv_batch_last_counts(isv_backend_t *h, int64_t out[8]) {
     return ISV_OK;
 }
 
+// MEASUREMENT HOOK (ISV_GRAPH=1; VERDICT r2 task 5: "measure the hipGraph instead of arguing it away"): the launch chain of one
+// isv_batch_optimize captured into a hipGraph and replayed while the kernel arguments (DevBatch BY VALUE: counts, offsets,
+// launch variants) stay the same, i.e. while the same resident batch is solved again.  A real caller uploads new factor counts
+// every frame, which changes the arguments of every node: the graph would be re-instantiated per frame (measured below in
+// bench.py: the instantiation costs more than the launch gaps it removes), so this is not the default path.
+static uint64_t fnv1a(const void *p, size_t n) { uint64_t x = 1469598103934665603ull; for (size_t i = 0; i < n; i++) { x ^= ((const unsigned char *)p)[i]; x *= 1099511628211ull; } return x; }
+
 extern "C" int isv_batch_optimize(isv_backend_t *h, int32_t sync) {
     if (!h || !h->resident) return ISV_ERR_INVALID_ARG;
     ENTER(h);
     DevBatch &d = h->d; hipStream_t st = h->stream;
     memset(h->last_counts, 0, sizeof(h->last_counts));
+    const bool profile = (sync & 2) != 0 && !h->prof_ev.empty();       // per-kernel-family events only on request
+    static const bool use_graph = getenv("ISV_GRAPH") != nullptr;
+    if (use_graph && !profile) {
+        d.sw_global = 0; d.ctl_stage_lm = 0;                            // (set inside the enqueue: not part of the key)
+        const uint64_t key = fnv1a(&d, sizeof(d));
+        HIPCHK(h, hipEventRecord(h->ev[0], st));
+        if (!h->graph_exec || h->graph_key != key) {
+            if (h->graph_exec) { (void)hipGraphExecDestroy(h->graph_exec); h->graph_exec = nullptr; }
+            hipGraph_t g = nullptr;
+            HIPCHK(h, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            int rcg = ISV_OK;
+            if (hipMemsetAsync(d.act, 0, sizeof(int32_t) * ISV_MAX_TRACE, st) != hipSuccess) rcg = ISV_ERR_DEVICE;
+            if (rcg == ISV_OK) rcg = restore_initial(h);
+            if (rcg == ISV_OK) {
+                hipLaunchKernelGGL(k_vector2double, dim3(d.B), dim3(64), 0, st, d);
+                rcg = isv_solver_enqueue(h->d, h->hc, st, h->stream2, h->fj, h->last_counts, nullptr, h->err);
+            }
+            const hipError_t ec = hipStreamEndCapture(st, &g);
+            if (rcg != ISV_OK || ec != hipSuccess) { if (g) (void)hipGraphDestroy(g); h->err = "hipGraph capture failed"; return rcg != ISV_OK ? rcg : ISV_ERR_DEVICE; }
+            const hipError_t ei = hipGraphInstantiate(&h->graph_exec, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (ei != hipSuccess) { h->graph_exec = nullptr; h->err = "hipGraphInstantiate failed"; return ISV_ERR_DEVICE; }
+            h->graph_key = key;
+            memcpy(h->graph_counts, h->last_counts, sizeof(h->last_counts));
+        }
+        memcpy(h->last_counts, h->graph_counts, sizeof(h->last_counts));
+        HIPCHK(h, hipGraphLaunch(h->graph_exec, st));
+        h->prof_valid = 0;
+        HIPCHK(h, hipEventRecord(h->ev[4], st));
+        if (sync & 1) HIPCHK(h, hipStreamSynchronize(st));
+        return ISV_OK;
+    }
     HIPCHK(h, hipMemsetAsync(d.act, 0, sizeof(int32_t) * ISV_MAX_TRACE, st));
     HIPCHK(h, hipEventRecord(h->ev[0], st));
     TRY(restore_initial(h));
     hipLaunchKernelGGL(k_vector2double, dim3(d.B), dim3(64), 0, st, d);
-    const bool profile = (sync & 2) != 0 && !h->prof_ev.empty();       // per-kernel-family events only on request
     int rc = isv_solver_enqueue(h->d, h->hc, st, h->stream2, h->fj, h->last_counts, profile ? h->prof_ev.data() : nullptr, h->err);
     h->prof_valid = profile ? 1 : 0;
     if (rc != ISV_OK) return rc;

@@ -52,6 +52,9 @@ struct isv_backend {
     size_t init_cap = 0;
     double last_ms[8] = {};
     int64_t last_counts[8] = {};
+    hipGraphExec_t graph_exec = nullptr;    // ISV_GRAPH=1 (measurement hook): the captured launch chain of isv_batch_optimize
+    uint64_t graph_key = 0;
+    int64_t graph_counts[8] = {};
     void *seq = nullptr;          // device-resident sequences (isv_sequence.hip), allocated by isv_backend_seq_enable
     void (*seq_free)(void *) = nullptr;
 };

@@ -472,6 +472,27 @@ __global__ __launch_bounds__(256) void k_seq_writeback(DevBatch d, SeqDev s) {
     if (t == 0) { o[45] = d.marg[w].valid; o[46] = s_fail; o[47] = s.err[w]; }
 }
 
+// the seed's points (track-major, oldest observation first, all windows back to back) into the tracks' rings
+__global__ __launch_bounds__(256) void k_seq_seed_points(SeqDev s, const double *pts, const int64_t *win_off) {
+    const int w = blockIdx.x, t = threadIdx.x;
+    const size_t tb = (size_t)w * s.Tcap;
+    const int T = s.n_tracks[w];
+    __shared__ int sbuf[8];
+    int base = 0;
+    for (int c0 = 0; c0 < T; c0 += 256) {
+        const int i = c0 + t;
+        const int n = i < T ? s.trk_n[tb + i] : 0;
+        int tot;
+        const int off = base + block_excl_scan(n, sbuf, t, tot);
+        if (i < T) {
+            const double *src = pts + ((size_t)win_off[w] + off) * 3;
+            double *ring = s.pts + ((size_t)tb + s.trk_slot[tb + i]) * ISV_SEQ_RING * 3;
+            for (int k = 0; k < n * 3; k++) ring[k] = src[k];
+        }
+        base += tot;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // host side
 struct isv_seq_state {
@@ -521,7 +542,8 @@ extern "C" int isv_backend_seq_seed(isv_backend_t *h, int32_t n, isv_window_t *c
     hipStream_t st = h->stream;
     const size_t T = (size_t)s.Tcap;
     std::vector<int32_t> a_start(n * T, 0), a_n(n * T, 0), a_flag(n * T, 0), a_slot(n * T, 0), a_off(n * T, 0), a_cnt(n);
-    std::vector<double> a_depth(n * T, -1.0);
+    std::vector<double> a_depth(n * T, -1.0), a_pts;
+    std::vector<int64_t> a_woff((size_t)n);
     for (int b = 0; b < n; b++) {
         if (n_tracks[b] < 0 || (size_t)n_tracks[b] > T) { h->err = "seed: more tracks than tracks_per_window"; return ISV_ERR_CAPACITY; }
         a_cnt[b] = n_tracks[b];
@@ -530,15 +552,24 @@ extern "C" int isv_backend_seq_seed(isv_backend_t *h, int32_t n, isv_window_t *c
             const isv_seq_track_t &tr = tracks[b][i];
             if (tr.slot < 0 || (size_t)tr.slot >= T || tr.n_obs < 1 || tr.n_obs > ISV_SEQ_RING) { h->err = "seed: bad track"; return ISV_ERR_INVALID_ARG; }
             a_start[b * T + i] = tr.start_frame; a_n[b * T + i] = tr.n_obs; a_flag[b * T + i] = tr.solve_flag; a_slot[b * T + i] = tr.slot; a_depth[b * T + i] = tr.depth;
-            HIPCHK(h, hipMemcpyAsync(s.pts + ((size_t)b * T + tr.slot) * ISV_SEQ_RING * 3, points[b] + po * 3, sizeof(double) * 3 * tr.n_obs, hipMemcpyHostToDevice, st));
             po += (size_t)tr.n_obs;
         }
+        a_woff[b] = (int64_t)(a_pts.size() / 3);
+        a_pts.insert(a_pts.end(), points[b], points[b] + po * 3);
     }
+    // (one compact upload + a scatter kernel: a copy per track is 2.7 us of stream time each, 0.2 s per 256 sequences)
+    double *d_pts = nullptr; int64_t *d_woff = nullptr;
+    HIPCHK(h, hipMalloc(&d_pts, sizeof(double) * std::max<size_t>(a_pts.size(), 3)));
+    if (hipMalloc(&d_woff, sizeof(int64_t) * (size_t)n) != hipSuccess) { (void)hipFree(d_pts); h->err = "seed: allocation failed"; return ISV_ERR_DEVICE; }
+    auto free_tmp = [&]() { (void)hipFree(d_pts); (void)hipFree(d_woff); };
+    if ((!a_pts.empty() && hipMemcpyAsync(d_pts, a_pts.data(), sizeof(double) * a_pts.size(), hipMemcpyHostToDevice, st) != hipSuccess) ||
+        hipMemcpyAsync(d_woff, a_woff.data(), sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, st) != hipSuccess) { free_tmp(); h->err = "seed: copy failed"; return ISV_ERR_DEVICE; }
 #define UPV(dst, vec) HIPCHK(h, hipMemcpyAsync(dst, (vec).data(), sizeof((vec)[0]) * (vec).size(), hipMemcpyHostToDevice, st))
     UPV(s.trk_start, a_start); UPV(s.trk_n, a_n); UPV(s.trk_flag, a_flag); UPV(s.trk_slot, a_slot); UPV(s.trk_off, a_off); UPV(s.trk_depth, a_depth); UPV(s.n_tracks, a_cnt);
 #undef UPV
-    HIPCHK(h, hipMemsetAsync(s.err, 0, h->capB * sizeof(int32_t), st));
-    HIPCHK(h, hipStreamSynchronize(st));                  // (the vectors above are pageable and go out of scope)
+    hipLaunchKernelGGL(k_seq_seed_points, dim3(n), dim3(256), 0, st, s, d_pts, d_woff);
+    if (hipMemsetAsync(s.err, 0, h->capB * sizeof(int32_t), st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { free_tmp(); h->err = "seed: device error"; return ISV_ERR_DEVICE; }
+    free_tmp();                                           // (the vectors above are pageable and go out of scope)
     q->seeded = n;
     return ISV_OK;
 }

@@ -1,12 +1,49 @@
 #!/bin/bash
-# Run ON THE GPU BOX (via gpurun): kernel-trace stats of the bench command, then the two PMC passes (separate runs,
-# --pmc only with --kernel-trace), everything under gpurun_out/; copy the summaries into profiles/ afterwards.
+# Run ON THE GPU BOX (via gpurun): the rocprofv3 evidence of one round, everything under gpurun_out/prof_rNN/; copy the
+# summaries into profiles/ afterwards (scripts/copy_profiles.sh).  --pmc passes are separate runs with --kernel-trace only.
+# usage: bash scripts/refresh_profiles.sh [round prefix, default r03] [windows, default 1024]
 set -e
+RN=${1:-r03}; W=${2:-1024}
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-rm -rf gpurun_out/prof_bench gpurun_out/pmc_fetch gpurun_out/pmc_write
-W=${1:-1024}
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_bench -o bench --output-format csv -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-host-legs --windows $W > gpurun_out/prof_bench.json 2> gpurun_out/prof_bench.err
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_fetch -o f --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-host-legs --windows $W > gpurun_out/pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_write -o w --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-host-legs --windows $W > gpurun_out/pmc_write.log 2>&1
-python3 scripts/pmc_summary.py gpurun_out/pmc_fetch/f_counter_collection.csv gpurun_out/pmc_write/w_counter_collection.csv $W gpurun_out r02 > gpurun_out/pmc_summary.log
-head -30 gpurun_out/prof_bench/bench_kernel_stats.csv
+O=gpurun_out/prof_$RN
+rm -rf $O; mkdir -p $O
+B="python3 bench.py --no-cpu-baseline --no-host-legs --windows $W"
+# 1. kernel-trace stats of the bench command (the launches of the benchmark only)
+rocprofv3 --kernel-trace --stats -d $O/bench -o bench --output-format csv -- $B --steps 5 --warmup 2 > $O/bench_under_rocprof.json 2> $O/bench.err
+cp $O/bench/bench_kernel_stats.csv $O/${RN}_bench_${W}win_kernel_stats.csv
+# 2. HBM traffic: FETCH_SIZE and WRITE_SIZE in separate passes
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/pmc_fetch -o f --output-format csv -- $B --steps 2 --warmup 1 > $O/pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/pmc_write -o w --output-format csv -- $B --steps 2 --warmup 1 > $O/pmc_write.log 2>&1
+python3 scripts/pmc_summary.py $O/pmc_fetch/f_counter_collection.csv $O/pmc_write/w_counter_collection.csv $W $O $RN > $O/pmc_summary.log
+# 3. utilisation counters, one pass per group
+i=0
+for grp in "VALUBusy MfmaUtil" "LdsUtil LDSBankConflict" "MemUnitStalled OccupancyPercent"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $grp -d $O/pmc_u$i -o u --output-format csv -- $B --steps 1 --warmup 1 > $O/pmc_u$i.log 2>&1
+done
+python3 scripts/pmc_util_summary.py $O/pmc_u*/u_counter_collection.csv > $O/${RN}_pmc_utilisation.csv
+# 4. the reference's shape: 1024 windows of N = 18 / Vo = 8
+REPS=5 rocprofv3 --kernel-trace --stats -d $O/n18 -o n18 --output-format csv -- python3 scripts/quick_cfg.py 1024 18 8 300 > $O/n18.log 2>&1
+cp $O/n18/n18_kernel_stats.csv $O/${RN}_n18_1024win_kernel_stats.csv
+# 5. BASELINE config 5: one window, 20 KF / 2000 landmarks / 30 000 factors
+REPS=10 rocprofv3 --kernel-trace --stats -d $O/cfg5 -o cfg5 --output-format csv -- python3 scripts/quick_cfg.py 1 20 8 2000 30000 > $O/cfg5.log 2>&1
+cp $O/cfg5/cfg5_kernel_stats.csv $O/${RN}_config5_kernel_stats.csv
+REPS=3 rocprofv3 --kernel-trace --pmc VALUBusy MfmaUtil -d $O/cfg5_u -o u --output-format csv -- python3 scripts/quick_cfg.py 1 20 8 2000 30000 > $O/cfg5_u.log 2>&1
+python3 scripts/pmc_util_summary.py $O/cfg5_u/u_counter_collection.csv > $O/${RN}_config5_pmc_utilisation.csv
+# 6. the pose-graph kernel: one graph and 1024 graphs of 200 keyframes
+PGO_CFGS=200:5:1,200:5:1024 PGO_NO_ORACLE=1 rocprofv3 --kernel-trace --stats -d $O/pgo -o pgo --output-format csv -- python3 scripts/pgo_bench.py > $O/pgo.log 2>&1
+cp $O/pgo/pgo_kernel_stats.csv $O/${RN}_pgo_kernel_stats.csv
+# 7. the resident replay's kernels (slide / append / build beside the solve): 256 sequences
+python3 -c "
+import sys
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+import isvins_loader; isvins_loader.load()
+import sequence_harness as sh
+sh.write_stream('$O/stream_11.txt', 11, 5, 40, seed=1)"
+rocprofv3 --kernel-trace --stats -d $O/replay -o replay --output-format csv -- ./tools/isv_replay $O/stream_11.txt --sequences 256 --groups 1 --write 0 > $O/replay.log 2>&1
+cp $O/replay/replay_kernel_stats.csv $O/${RN}_resident_replay_256seq_kernel_stats.csv
+# 8. the bench line itself and the two-rank rehearsal of the multi-GPU path on this one GPU (gloo stands in for RCCL)
+python3 bench.py > $O/${RN}_bench_1gpu.json 2> $O/bench_plain.err
+ISV_BENCH_REHEARSAL=1 python3 bench.py --gpus 2 --windows 512 --no-host-legs --no-cpu-baseline --steps 50 > $O/${RN}_2rank_rehearsal.json 2> $O/rehearsal.err
+ls $O/*.csv $O/*.json
+head -12 $O/${RN}_bench_${W}win_kernel_stats.csv
