@@ -35,20 +35,40 @@ DEV void relpose_jac(const double *dt, const double *dR, const double *pi, const
 }
 
 
+// The window's prior factor records are STAGED IN LDS once per call (round 3): one coalesced pass instead of field-by-field
+// global loads on the serial path of a lane per prior -- every `f.R`, `f.delta_t`, `sqrt_info[row * dim + k]`, `index` used to
+// be a memory round trip of its own (the candidate evaluation of 13 priors took 20 us inside k_dogleg, on ONE wavefront the
+// other three waited for).  Layout (8-byte words): SE3 | Linear9 | relative pose x (Nvo - 1) | roll/pitch x max_rp.
+struct PriorRecs {
+    const isv_se3_prior_t *se3; const isv_linear9_t *lin9; const isv_relpose_t *relpose; const isv_rollpitch_t *rollpitch;
+};
+DEV PriorRecs prior_stage_records(const DevBatch &d, int w, double *dst, int t, int nthr) {
+    constexpr int SW = sizeof(isv_se3_prior_t) / 8, LW = sizeof(isv_linear9_t) / 8, RW = sizeof(isv_relpose_t) / 8, PW = sizeof(isv_rollpitch_t) / 8;
+    const int nrel = d.Nvo - 1;
+    uint64_t *o = (uint64_t *)dst;
+    const uint64_t *a = (const uint64_t *)(d.se3 + w), *b = (const uint64_t *)(d.lin9 + w);
+    const uint64_t *c = (const uint64_t *)(d.relpose + (size_t)w * nrel), *e = (const uint64_t *)(d.rollpitch + (size_t)w * d.max_rp);
+    const int n0 = SW, n1 = n0 + LW, n2 = n1 + RW * nrel, n3 = n2 + PW * d.max_rp;
+    for (int k = t; k < n3; k += nthr) o[k] = k < n0 ? a[k] : (k < n1 ? b[k - n0] : (k < n2 ? c[k - n1] : e[k - n2]));
+    PriorRecs r;
+    r.se3 = (const isv_se3_prior_t *)o; r.lin9 = (const isv_linear9_t *)(o + n0);
+    r.relpose = (const isv_relpose_t *)(o + n1); r.rollpitch = (const isv_rollpitch_t *)(o + n2);
+    return r;
+}
 struct PriorDesc { int kind, strip_off, H_off, valid; const double *S; };   // kind 0 SE3, 1 Linear9, 2 relpose, 3 rollpitch
-DEV PriorDesc prior_desc(const DevBatch &d, int w, int s, int n_rp) {
+DEV PriorDesc prior_desc(const DevBatch &d, const PriorRecs &R, int s, int n_rp) {
     PriorDesc p;
-    if (s == 0) { p.kind = 0; p.strip_off = PR_SE3; p.H_off = PH_SE3; p.valid = 1; p.S = d.se3[w].sqrt_info; }
-    else if (s == 1) { p.kind = 1; p.strip_off = PR_LIN9; p.H_off = PH_LIN9; p.valid = 1; p.S = d.lin9[w].sqrt_info; }
+    if (s == 0) { p.kind = 0; p.strip_off = PR_SE3; p.H_off = PH_SE3; p.valid = 1; p.S = R.se3->sqrt_info; }
+    else if (s == 1) { p.kind = 1; p.strip_off = PR_LIN9; p.H_off = PH_LIN9; p.valid = 1; p.S = R.lin9->sqrt_info; }
     else if (s < 1 + d.Nvo) {
         const int i = s - 2;
         p.kind = 2; p.strip_off = PR_REL0 + PR_REL_SZ * i; p.H_off = PH_REL0 + PH_REL_SZ * i; p.valid = 1;
-        p.S = d.relpose[(size_t)w * (d.Nvo - 1) + i].sqrt_info;
+        p.S = R.relpose[i].sqrt_info;
     } else {
         const int m = s - 1 - d.Nvo;
         p.kind = 3; p.strip_off = PR_REL0 + PR_REL_SZ * (d.Nvo - 1) + PR_RP_SZ * m;
         p.H_off = PH_REL0 + PH_REL_SZ * (d.Nvo - 1) + PH_RP_SZ * m; p.valid = m < n_rp;
-        p.S = d.rollpitch[(size_t)w * d.max_rp + (p.valid ? m : 0)].sqrt_info;
+        p.S = R.rollpitch[p.valid ? m : 0].sqrt_info;
     }
     return p;
 }
@@ -130,16 +150,12 @@ DEV void prior_linearize_body(const DevBatch &d, const double *pose_src, const d
     const int n_rp = d.n_rp[w];
     // residual-only evaluation (JAC = false, the candidate point in k_dogleg): no Jacobian blocks, 10-double slots
     constexpr int RAWS = JAC ? PRL_RAW : 10, WS = JAC ? PRL_W : 10;
-    double *sRaw = lds, *sW = lds + (size_t)slots * RAWS, *sS = sW + (size_t)slots * WS;
+    double *sRaw = lds, *sW = lds + (size_t)slots * RAWS, *sRec = sW + (size_t)slots * WS;
     double *strip = d.prior_strip + (size_t)w * d.prior_strip_sz;
     double *PH = d.prior_H + (size_t)w * d.prior_H_sz;
     const double *poseW = pose_src + (size_t)w * N * 7;
-    // stage every sqrt_info
-    if (JAC) for (int s = 0; s < slots; s++) {
-        const PriorDesc p = prior_desc(d, w, s, n_rp);
-        const int n = p.kind == 1 ? 81 : (p.kind == 3 ? 4 : 36);
-        if (p.valid) for (int e = t; e < n; e += 64) sS[s * PRL_S + e] = p.S[e];
-    }
+    const PriorRecs R = prior_stage_records(d, w, sRec, t, 64);
+    if (WAVE) ISV_WSYNC(); else __syncthreads();
     // ---- phase 1: raw residual / raw Jacobian blocks, one lane per prior ----
     for (int s = t; s < slots; s += 64) {
         double *raw = sRaw + s * RAWS, *rawJ = raw + 9;
@@ -149,11 +165,11 @@ DEV void prior_linearize_body(const DevBatch &d, const double *pose_src, const d
         const double *pi = poseW;
         if (kind == 0) {
             // SE3PriorFactor::Evaluate  se3_prior_factor.h:21-53
-            Quat ri = q_normalized(q_from_pose(poseW)), rp = q_from_R(d.se3[w].R);
+            Quat ri = q_normalized(q_from_pose(poseW)), rp = q_from_R(R.se3->R);
             rr = so3_mul(q_conj(rp), ri);
         } else if (kind == 2) {
             // RelativePoseFactor::Evaluate  relative_pose_factor.h:27-70
-            const isv_relpose_t &f = d.relpose[(size_t)w * (d.Nvo - 1) + (s - 2)];
+            const isv_relpose_t &f = R.relpose[s - 2];
             pi = poseW + (s - 2) * 7;
             const double *pj = pi + 7;
             Quat Qi = q_from_pose(pi), Qj = q_from_pose(pj);
@@ -168,7 +184,7 @@ DEV void prior_linearize_body(const DevBatch &d, const double *pose_src, const d
         so3_log(rr, lg);
         if (JAC) so3_rjac_inv(lg, Jr);
         if (kind == 0) {
-            const isv_se3_prior_t &f = d.se3[w];
+            const isv_se3_prior_t &f = *R.se3;
 #pragma unroll
             for (int k = 0; k < 3; k++) { raw[k] = poseW[k] - f.t[k]; raw[3 + k] = lg[k]; }
             if (JAC) {
@@ -182,12 +198,12 @@ DEV void prior_linearize_body(const DevBatch &d, const double *pose_src, const d
             }
         } else if (kind == 1) {
             // Linear9Factor::Evaluate  linear9_factor.h:20-44 (Jacobian = sqrt_info)
-            const isv_linear9_t &f = d.lin9[w];
+            const isv_linear9_t &f = *R.lin9;
             const double *sb = sb_src + ((size_t)w * N + (d.Nvo - 1)) * 9;
 #pragma unroll
             for (int k = 0; k < 9; k++) raw[k] = sb[k] - f.VB[k];
         } else if (kind == 2) {
-            const isv_relpose_t &f = d.relpose[(size_t)w * (d.Nvo - 1) + (s - 2)];
+            const isv_relpose_t &f = R.relpose[s - 2];
 #pragma unroll
             for (int k = 0; k < 3; k++) { raw[k] = f.delta_t[k] - qd[k]; raw[3 + k] = lg[k]; }
             if (JAC) {
@@ -212,7 +228,7 @@ DEV void prior_linearize_body(const DevBatch &d, const double *pose_src, const d
             }
         } else if (s - 1 - d.Nvo < n_rp) {
             // RollPitchFactor::Evaluate  rollpitch_factor.h:26-57
-            const isv_rollpitch_t &f = d.rollpitch[(size_t)w * d.max_rp + (s - 1 - d.Nvo)];
+            const isv_rollpitch_t &f = R.rollpitch[s - 1 - d.Nvo];
             const double *p = poseW + f.index * 7;
             Quat Rq = q_normalized(q_from_pose(p)), Rm = q_from_R(f.R);
             double nZ[3] = {0, 0, -1.0}, v[3];
@@ -238,7 +254,7 @@ DEV void prior_linearize_body(const DevBatch &d, const double *pose_src, const d
         // state, bit for bit, as the cost at x the step control compares it with.
         for (int e = t; e < slots * 9; e += 64) {
             const int s = e / 9, row = e - 9 * s;
-            const PriorDesc p = prior_desc(d, w, s, n_rp);
+            const PriorDesc p = prior_desc(d, R, s, n_rp);
             const int dim = p.kind == 1 ? 9 : (p.kind == 3 ? 2 : 6);
             if (!p.valid || row >= dim) continue;
             const double *raw = sRaw + s * RAWS;
@@ -248,7 +264,7 @@ DEV void prior_linearize_body(const DevBatch &d, const double *pose_src, const d
         }
         if (WAVE) ISV_WSYNC(); else __syncthreads();
         for (int s = t; s < slots; s += 64) {
-            const PriorDesc p = prior_desc(d, w, s, n_rp);
+            const PriorDesc p = prior_desc(d, R, s, n_rp);
             const int dim = p.kind == 1 ? 9 : (p.kind == 3 ? 2 : 6);
             double cost = 0.0;
             if (p.valid) {
@@ -263,9 +279,9 @@ DEV void prior_linearize_body(const DevBatch &d, const double *pose_src, const d
     }
     // ---- phase 2: sqrt_info * [raw r | raw J] ----
     for (int s = 0; s < slots; s++) {
-        const PriorDesc p = prior_desc(d, w, s, n_rp);
+        const PriorDesc p = prior_desc(d, R, s, n_rp);
         if (!p.valid) continue;
-        const double *raw = sRaw + s * RAWS, *rawJ = raw + 9, *S = sS + s * PRL_S;
+        const double *raw = sRaw + s * RAWS, *rawJ = raw + 9, *S = p.S;
         double *wr = sW + s * WS;
         if (p.kind == 0) prior_weight<6, 1, 6, false, JAC>(S, raw, rawJ, wr, t);
         else if (p.kind == 1) prior_weight<9, 1, 9, true, JAC>(S, raw, rawJ, wr, t);
@@ -275,7 +291,7 @@ DEV void prior_linearize_body(const DevBatch &d, const double *pose_src, const d
     if (WAVE) ISV_WSYNC(); else __syncthreads();
     // ---- phase 3: CauchyLoss corrector (scale r and J by sqrt(rho')), cost, strips ----
     for (int s = 0; s < slots; s++) {
-        const PriorDesc p = prior_desc(d, w, s, n_rp);
+        const PriorDesc p = prior_desc(d, R, s, n_rp);
         double *wr = sW + s * WS, *so = strip + p.strip_off;
         double cost = 0.0;
         if (!p.valid) { if (JAC) for (int e = t; e < PR_RP_SZ; e += 64) so[e] = 0.0; }
@@ -289,7 +305,7 @@ DEV void prior_linearize_body(const DevBatch &d, const double *pose_src, const d
     if (WAVE) ISV_WSYNC(); else __syncthreads();
     // ---- phase 4: J^T J and J^T r ----
     for (int s = 0; s < slots; s++) {
-        const PriorDesc p = prior_desc(d, w, s, n_rp);
+        const PriorDesc p = prior_desc(d, R, s, n_rp);
         if (!p.valid) continue;
         const double *wr = sW + s * WS;
         if (p.kind == 0) prior_H<6, 1, 6>(wr, PH + p.H_off, t);
