@@ -333,8 +333,21 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
         __syncthreads();
         STAMP(0);
         if (BIG) {
-            for (int e = t; e < N * 120; e += LS) imu_frame_apply(e, imu_frame_fetch(e));
-            for (int e = t; e < (N - 1) * 225; e += LS) if (!skipL[e / 225]) imu_pair_apply(e, imu_pair_fetch(e));
+            // (round 3: four loads in flight per trip instead of a load -> LDS store chain per entry)
+            for (int e0 = t; e0 < N * 120; e0 += 4 * LS) {
+                double v4[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) { const int e = e0 + k * LS; v4[k] = e < N * 120 ? imu_frame_fetch(e) : 0.0; }
+#pragma unroll
+                for (int k = 0; k < 4; k++) { const int e = e0 + k * LS; if (e < N * 120) imu_frame_apply(e, v4[k]); }
+            }
+            for (int e0 = t; e0 < (N - 1) * 225; e0 += 4 * LS) {
+                double v4[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) { const int e = e0 + k * LS; v4[k] = e < (N - 1) * 225 ? imu_pair_fetch(e) : 0.0; }
+#pragma unroll
+                for (int k = 0; k < 4; k++) { const int e = e0 + k * LS; if (e < (N - 1) * 225 && !skipL[e / 225]) imu_pair_apply(e, v4[k]); }
+            }
         } else {
 #pragma unroll
             for (int k = 0; k < 3; k++) { const int e = t + k * LS; if (e < N * 120) imu_frame_apply(e, vF[k]); }
@@ -618,20 +631,35 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
         if (!flag[0]) {
             // ---- pose system: Spp -= sum_i Y_i Y_i^T ---------------------------------------------------
             { PHASE_IDS();
-            for (int e = t; e < nS; e += LS) {
-                int I, J, r, c;
-                spp_decode(e, I, J, r, c);
-                if (I == J && r < c) continue;
-                double s = 0;
+            // (round 3) a thread owns a 2 x 3 sub-block of a 6x6 pose block instead of one entry: per k it reads two values of
+            // Y_I and three of Y_J for six products (5 LDS reads per 6 FMAs instead of 12).  The phase was LDS-bandwidth
+            // bound (every entry re-read both nine-vectors from every covering node): 30.6 us at N = 18, 9.2 us at N = 11.
+            // Entry for entry the same sums in the same order (nodes ascending, k ascending).
+            for (int item = t; item < N * (N + 1) / 2 * 6; item += LS) {
+                const int q = item / 6, sbk = item - 6 * q, r0 = 2 * (sbk >> 1), c0 = 3 * (sbk & 1);
+                const int ij = blkIJ[q], I = ij & 255, J = ij >> 8;
+                if (I == J && r0 + 1 < c0) continue;            // rows {0, 1} x columns {3, 4, 5} of a diagonal block: above the diagonal
+                double s00 = 0, s01 = 0, s02 = 0, s10 = 0, s11 = 0, s12 = 0;
                 for (int i = 0; i < N; i++) {
                     const int lo = nlo(i, M), hi = nhi(i, M, N);
                     if (J >= lo && I <= hi) {
-                        const double *YI = Ysb + yo[i] + (I - lo) * 54 + r * 9, *YJ = Ysb + yo[i] + (J - lo) * 54 + c * 9;
+                        const double *YI = Ysb + yo[i] + (I - lo) * 54 + r0 * 9, *YJ = Ysb + yo[i] + (J - lo) * 54 + c0 * 9;
 #pragma unroll
-                        for (int k = 0; k < 9; k++) s += YI[k] * YJ[k];
+                        for (int k = 0; k < 9; k++) {
+                            const double a0 = YI[k], a1 = YI[9 + k], b0 = YJ[k], b1 = YJ[9 + k], b2 = YJ[18 + k];
+                            s00 += a0 * b0; s01 += a0 * b1; s02 += a0 * b2;
+                            s10 += a1 * b0; s11 += a1 * b1; s12 += a1 * b2;
+                        }
                     }
                 }
-                Spp[e] -= s;
+                double *B = Spp + q * 36 + r0 * 6 + c0;
+                const bool dg = I == J;
+                if (!dg || r0 >= c0) B[0] -= s00;
+                if (!dg || r0 >= c0 + 1) B[1] -= s01;
+                if (!dg || r0 >= c0 + 2) B[2] -= s02;
+                if (!dg || r0 + 1 >= c0) B[6] -= s10;
+                if (!dg || r0 + 1 >= c0 + 1) B[7] -= s11;
+                if (!dg || r0 + 1 >= c0 + 2) B[8] -= s12;
             }
             if (t >= LS - n6) {                                 // pose right-hand side -= sum_i Y_i z_i
                 const int rho = t - (LS - n6), a = rho / 6, r = rho - 6 * a;
@@ -706,7 +734,31 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
                     WSYNC();
                     if (chol_inv_block<6>(Spp + e0, lane)) { if (lane == 0) flag[0] = 1; }
                 } else {
-                    for (int e = 36 + (t - 64); e < cntT + m * 6; e += LS - 64) trailing_entry(e);
+                    // (round 3) 2 x 3 sub-blocks per thread, as in the Y Y^T phase: 5 LDS reads per 6 products instead of 12
+                    const int nit = (m * (m + 1) / 2 - 1) * 6;         // sub-blocks of the trailing blocks after the first one
+                    for (int it = t - 64; it < nit + m * 6; it += LS - 64) {
+                        if (it >= nit) { trailing_entry(cntT + (it - nit)); continue; }      // rhs rows
+                        const int q = 1 + it / 6, sbk = it - 6 * (q - 1), r0 = 2 * (sbk >> 1), c0 = 3 * (sbk & 1);
+                        const int ij = blkIJ[e0 / 36 + q];
+                        const int ia = (ij & 255) - (J + 1), ca = (ij >> 8) - (J + 1);
+                        const bool dg = ia == ca;
+                        if (dg && r0 + 1 < c0) continue;
+                        const double *XI = X + ia * 36 + r0 * 6, *XK = X + ca * 36 + c0 * 6;
+                        double s00 = 0, s01 = 0, s02 = 0, s10 = 0, s11 = 0, s12 = 0;
+#pragma unroll
+                        for (int k = 0; k < 6; k++) {
+                            const double a0 = XI[k], a1 = XI[6 + k], b0 = XK[k], b1 = XK[6 + k], b2 = XK[12 + k];
+                            s00 += a0 * b0; s01 += a0 * b1; s02 += a0 * b2;
+                            s10 += a1 * b0; s11 += a1 * b1; s12 += a1 * b2;
+                        }
+                        double *Bq = Spp + e0 + q * 36 + r0 * 6 + c0;
+                        if (!dg || r0 >= c0) Bq[0] -= s00;
+                        if (!dg || r0 >= c0 + 1) Bq[1] -= s01;
+                        if (!dg || r0 >= c0 + 2) Bq[2] -= s02;
+                        if (!dg || r0 + 1 >= c0) Bq[6] -= s10;
+                        if (!dg || r0 + 1 >= c0 + 1) Bq[7] -= s11;
+                        if (!dg || r0 + 1 >= c0 + 2) Bq[8] -= s12;
+                    }
                 }
                 __syncthreads();
             }

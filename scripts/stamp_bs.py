@@ -5,11 +5,13 @@ import isvins_loader; isvins_loader.load()
 from isvins_amd import backend, synth
 import numpy as np
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-ws = synth.make_windows(range(B))
-be = backend.Backend(11, 5, max_landmarks=300, max_obs=1600, max_batch=B)
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 11
+NVO = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+ws = synth.make_windows(range(B), n_frames=N, n_vo=NVO)
+be = backend.Backend(N, NVO, max_landmarks=300, max_obs=max(w.n_obs for w in ws), max_batch=B)
 be.upload(ws)
 be.run_optimize()
-print(f"B = {B}")
+print(f"B = {B} N = {N} Nvo = {NVO}")
 dbg = be.debug_read(21, B * 64).reshape(B, 64)
 names = {0: "load Tvis + zero", 1: "imu gather", 2: "priors", 3: "scale+qT", 4: "sb chains", 5: "Y Y^T", 6: "pose cholesky", 7: "solves", 8: "outputs"}
 tot = dbg[:, :9].sum(1)
