@@ -315,6 +315,9 @@ int main(int argc, char **argv) {
     int feed_threads = (int)std::thread::hardware_concurrency() / K;      // per group, for the per-sequence feed
     if (feed_threads > 8) feed_threads = 8;
     if (feed_threads < 1) feed_threads = 1;
+    // the library's own per-sequence host work (isv_estimator_step, isv_batch_upload) uses min(8, cores) threads PER CALL: with K
+    // groups calling at once that oversubscribes the host (4 groups x 8 threads on 16 cores); give every group its share
+    { char buf[16]; snprintf(buf, sizeof(buf), "%d", feed_threads); setenv("ISV_HOST_THREADS", buf, 0); }
     std::vector<GroupResult> res(K);
     std::vector<std::thread> th;
     const auto t0 = std::chrono::steady_clock::now();
