@@ -431,6 +431,9 @@ __global__ __launch_bounds__(256) void k_seq_build(DevBatch d, SeqDev s, int lca
     }
 }
 
+// test hook (ISV_DEBUG_SEQ_FAIL_FRAME=k): the solve of window 0 in the k-th resident frame "ends non-finite"
+__global__ void k_seq_poison(DevBatch d) { d.st[0].x_cost = __longlong_as_double(0x7ff8000000000000ll); }
+
 // FeatureManager::setDepth's outputs back into the track list, and the frame's small result record
 __global__ __launch_bounds__(256) void k_seq_writeback(DevBatch d, SeqDev s) {
     const int w = blockIdx.x, t = threadIdx.x, N = d.N;
@@ -497,7 +500,7 @@ __global__ __launch_bounds__(256) void k_seq_seed_points(SeqDev s, const double 
 // host side
 struct isv_seq_state {
     SeqDev dv{};
-    int enabled = 0, seeded = 0;
+    int enabled = 0, seeded = 0, frames_done = 0;
     size_t obs_cap = 0;
     // pinned staging of the frame inputs / outputs
     int32_t *h_hdr = nullptr; isv_seq_obs_t *h_obs = nullptr; double *h_state = nullptr, *h_imu_in = nullptr, *h_imu_cov = nullptr, *h_out = nullptr;
@@ -658,6 +661,12 @@ extern "C" int isv_backend_seq_frame(isv_backend_t *h, int32_t n, const isv_seq_
     hipLaunchKernelGGL(k_vector2double, dim3(n), dim3(64), 0, st, d);
     TRY(isv_solver_enqueue(h->d, h->hc, st, h->stream2, h->fj, h->last_counts, nullptr, h->err));
     h->prof_valid = 0;
+    {
+        const char *ff = getenv("ISV_DEBUG_SEQ_FAIL_FRAME");        // (test hook, read per frame: a pointer compare when unset)
+        const int fail_frame = ff ? atoi(ff) : -1;
+        if (fail_frame >= 0 && q->frames_done == fail_frame) hipLaunchKernelGGL(k_seq_poison, dim3(1), dim3(1), 0, st, d);
+        q->frames_done++;
+    }
     hipLaunchKernelGGL(k_seq_writeback, dim3(n), dim3(256), 0, st, d, s);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipEventRecord(h->ev[4], st));

@@ -70,3 +70,40 @@ def test_resident_mode_is_refused_without_lock_step_and_recovers():
         for k in ("Ps", "Rs", "Vs", "Bas", "Bgs"):
             assert np.array_equal(wa[k], wb[k]), k
     ref.close(); est.close()
+
+
+def test_a_failed_solve_in_resident_mode_falls_back_and_recovers(monkeypatch):
+    """a solve that ends non-finite while the windows are resident (injected: ISV_DEBUG_SEQ_FAIL_FRAME poisons window 0's cost
+    in the 15th resident frame): the device rolls that window back to the states and priors that entered the solve, every window
+    comes back to the host BEFORE the slide, the failed sequence re-initialises its priors with initFactorGraph at its next
+    solve (the host path's policy, tests/test_sequence.py::test_failed_solve_reinitialises_the_priors), the other sequence is
+    unaffected bit for bit, and the windows are seeded on the device again"""
+    from isvins_amd import estimator as E
+    N, Nvo, seeds, n_frames = 11, 5, (0, 3), 60
+    cfg = abi.make_config(N, Nvo, max_landmarks=800, max_obs=800 * N, max_batch=2)
+    ref = E.SequenceEstimator(sh.estimator_params(cfg), 2)
+    ref.set_resident(True)
+    sh.run_sequences_native(ref, N, n_frames, seeds)
+    monkeypatch.setenv("ISV_DEBUG_SEQ_FAIL_FRAME", "15")
+    est = E.SequenceEstimator(sh.estimator_params(cfg), 2)
+    est.set_resident(True)
+    sh.run_sequences_native(est, N, n_frames, seeds)
+    monkeypatch.delenv("ISV_DEBUG_SEQ_FAIL_FRAME")
+    assert est.failed_solves(0) == 1 and est.failed_solves(1) == 0 and ref.failed_solves(0) == 0
+    a0, b0 = est.trajectory(0, 1), ref.trajectory(0, 1)
+    a1, b1 = est.trajectory(1, 1), ref.trajectory(1, 1)
+    assert a0.shape == b0.shape and np.isfinite(a0).all()
+    assert np.array_equal(a1, b1)                                 # the sequence that did not fail: identical
+    k_fail = int(np.argmax(np.any(a0 != b0, axis=1)))
+    assert 10 < k_fail < 25 and np.array_equal(a0[:k_fail], b0[:k_fail])
+    # re-initialised, not lost: a different (gauge re-anchored, scale re-estimated) but equally valid estimate, judged against
+    # the simulator's ground truth beside the run that never failed (as tests/test_sequence.py does for the host path)
+    sim = sh.Simulator(seeds[0])
+    truth = np.array([sim.traj.p(h) for h in a0[:, 0]])
+    err_a, err_b = np.linalg.norm(a0[:, 1:4] - truth, axis=1).max(), np.linalg.norm(b0[:, 1:4] - truth, axis=1).max()
+    print(f"max position error against ground truth: {err_a:.3f} m with the injected failure, {err_b:.3f} m without; first differing solved frame {k_fail}")
+    assert err_a < max(3.0 * err_b, 0.25)
+    # resident again after the re-seed: most of the frames after the failure went through the resident path
+    assert est.resident_frames() > n_frames - (N - 1) - 8
+    est.set_resident(False); ref.set_resident(False)
+    est.close(); ref.close()
