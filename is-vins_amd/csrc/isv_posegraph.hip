@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <functional>
@@ -709,6 +710,7 @@ struct isv_pgo {
     PgDev d{};
     std::vector<void *> allocs;
     size_t cap_pose = 0, cap_edge = 0, cap_blk = 0, cap_adj = 0, cap_col = 0;
+    void *pin = nullptr; size_t pin_cap = 0;      // pinned staging of a batch call's arrays (grown on demand, kept)
     hipEvent_t ev[2] = {nullptr, nullptr};       // around k_pgo of the last call (isv_pgo_last_kernel_ms)
     double last_blocks = 0;                       // skyline blocks of the last batch (all graphs)
 };
@@ -739,6 +741,7 @@ extern "C" void isv_pgo_destroy(isv_pgo_t *h) {
     (void)hipSetDevice(h->device);
     for (void *p : h->allocs) (void)hipFree(p);
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
+    if (h->pin) (void)hipHostFree(h->pin);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -1006,24 +1009,63 @@ extern "C" int isv_pgo_optimize_batch(isv_pgo_t *h, int32_t ng, const int32_t *n
         for (int k = 0; k < T; k++) th.emplace_back([&] { for (int g; (g = next.fetch_add(1)) < ng; ) fn(g); });
         for (auto &x : th) x.join();
     };
+    const auto tp0 = std::chrono::steady_clock::now();
     parallel_over_graphs([&](int g) { builds[g].rc = build_graph(g); });
+    const auto tp1 = std::chrono::steady_clock::now();
     for (int g = 0; g < ng; g++) if (builds[g].rc != ISV_OK) { if (builds[g].err) h->err = builds[g].err; return builds[g].rc; }
-    std::vector<double> pose; std::vector<int32_t> free_of, adj_ptr, adj, start, rowptr, colptr, colrows;
-    std::vector<PgEdge> edges;
+    // the batch's arrays live in ONE pinned staging area kept with the handle: no zero-initialised 170 MB vectors per call
+    // (a third of a 1024-graph call in round 2), and the copies to and from the device run at the pinned rate
+    struct SpanD { double *p = nullptr; size_t n = 0; double *data() const { return p; } size_t size() const { return n; } bool empty() const { return n == 0; } double &operator[](size_t i) const { return p[i]; } };
+    struct SpanI { int32_t *p = nullptr; size_t n = 0; int32_t *data() const { return p; } size_t size() const { return n; } bool empty() const { return n == 0; } int32_t &operator[](size_t i) const { return p[i]; } };
+    struct SpanE { PgEdge *p = nullptr; size_t n = 0; PgEdge *data() const { return p; } size_t size() const { return n; } bool empty() const { return n == 0; } PgEdge &operator[](size_t i) const { return p[i]; } };
+    SpanD pose; SpanI free_of, adj_ptr, adj, start, rowptr, colptr, colrows; SpanE edges;
     size_t nblk_tot = 0, nfree_tot = 0;
+    // offsets first (serial, integers only), then the per-graph buffers are copied into place by the host threads: the serial
+    // append of round 2 moved ~240 KB per graph (the edge records) on ONE thread, half of a 1024-graph call
+    struct Off { size_t pose, free_of, adj_ptr, adj, start, rowptr, colptr, colrows, edges; };
+    std::vector<Off> off((size_t)ng + 1);
+    memset(&off[0], 0, sizeof(Off));
     for (int g = 0; g < ng; g++) {
-        PgGraph &G = graphs[g]; GraphBuild &B = builds[g];
-        G.pose0 = (int32_t)(pose.size() / 7); G.free0 = (int32_t)nfree_tot; G.edge0 = (int32_t)edges.size(); G.blk0 = (int32_t)nblk_tot;
-        G.adj0 = (int32_t)adj.size(); G.col0 = (int32_t)colrows.size(); G.vec0 = (int32_t)(6 * nfree_tot);
-#define APP(v) v.insert(v.end(), B.v.begin(), B.v.end())
-        APP(pose); APP(free_of); APP(adj_ptr); APP(adj); APP(start); APP(rowptr); APP(colptr); APP(colrows); APP(edges);
-#undef APP
+        PgGraph &G = graphs[g]; const GraphBuild &B = builds[g]; const Off &o = off[g];
+        G.pose0 = (int32_t)(o.pose / 7); G.free0 = (int32_t)nfree_tot; G.edge0 = (int32_t)o.edges; G.blk0 = (int32_t)nblk_tot;
+        G.adj0 = (int32_t)o.adj; G.col0 = (int32_t)o.colrows; G.vec0 = (int32_t)(6 * nfree_tot);
+        off[g + 1] = Off{o.pose + B.pose.size(), o.free_of + B.free_of.size(), o.adj_ptr + B.adj_ptr.size(), o.adj + B.adj.size(), o.start + B.start.size(),
+                         o.rowptr + B.rowptr.size(), o.colptr + B.colptr.size(), o.colrows + B.colrows.size(), o.edges + B.edges.size()};
         nblk_tot += (size_t)G.nblk; nfree_tot += (size_t)G.nf;
-        B = GraphBuild();
     }
+    SpanD cov;
+    {
+        const Off &e = off[ng];
+        auto al = [](size_t b) { return (b + 63) & ~(size_t)63; };
+        const size_t b_pose = al(e.pose * 8), b_cov = al(e.pose / 7 * 36 * 8), b_edges = al(e.edges * sizeof(PgEdge));
+        const size_t b_i[7] = {al(e.free_of * 4), al(e.adj_ptr * 4), al(e.adj * 4), al(e.start * 4), al(e.rowptr * 4), al(e.colptr * 4), al(e.colrows * 4)};
+        size_t need = b_pose + b_cov + b_edges;
+        for (size_t b : b_i) need += b;
+        if (need > h->pin_cap) {
+            if (h->pin) (void)hipHostFree(h->pin);
+            h->pin = nullptr; h->pin_cap = 0;
+            PCHK(h, hipHostMalloc(&h->pin, need + need / 4, hipHostMallocDefault));
+            h->pin_cap = need + need / 4;
+        }
+        char *q = (char *)h->pin;
+        pose.p = (double *)q; pose.n = e.pose; q += b_pose;
+        cov.p = (double *)q; cov.n = e.pose / 7 * 36; q += b_cov;
+        edges.p = (PgEdge *)q; edges.n = e.edges; q += b_edges;
+        SpanI *si[7] = {&free_of, &adj_ptr, &adj, &start, &rowptr, &colptr, &colrows};
+        const size_t ni[7] = {e.free_of, e.adj_ptr, e.adj, e.start, e.rowptr, e.colptr, e.colrows};
+        for (int k = 0; k < 7; k++) { si[k]->p = (int32_t *)q; si[k]->n = ni[k]; q += b_i[k]; }
+    }
+    parallel_over_graphs([&](int g) {
+        GraphBuild &B = builds[g]; const Off &o = off[g];
+#define PUT(v) do { if (!B.v.empty()) memcpy(v.data() + o.v, B.v.data(), sizeof(B.v[0]) * B.v.size()); } while (0)
+        PUT(pose); PUT(free_of); PUT(adj_ptr); PUT(adj); PUT(start); PUT(rowptr); PUT(colptr); PUT(colrows); PUT(edges);
+#undef PUT
+        B = GraphBuild();
+    });
     if (pose.size() / 7 > h->cap_pose || edges.size() > h->cap_edge || nblk_tot > h->cap_blk || adj.size() > h->cap_adj || colrows.size() > h->cap_col) {
         h->err = "pose graphs exceed the handle's capacity"; return ISV_ERR_CAPACITY;
     }
+    const auto tp2 = std::chrono::steady_clock::now();
     PgDev &d = h->d; hipStream_t st = h->stream;
 #define UP(dst, vec) do { if (!(vec).empty()) PCHK(h, hipMemcpyAsync(dst, (vec).data(), sizeof((vec)[0]) * (vec).size(), hipMemcpyHostToDevice, st)); } while (0)
     UP(d.graphs, graphs); UP(d.pose, pose); UP(d.free_of, free_of); UP(d.edges, edges); UP(d.adj_ptr, adj_ptr); UP(d.adj, adj);
@@ -1045,13 +1087,14 @@ extern "C" int isv_pgo_optimize_batch(isv_pgo_t *h, int32_t ng, const int32_t *n
     PCHK(h, hipGetLastError());
     PCHK(h, hipEventRecord(h->ev[1], st));
     h->last_blocks = (double)nblk_tot;
-    std::vector<double> cov(pose.size() / 7 * 36);
+
     // (blocking copies after the stream has drained: the destinations are pageable -- `results` is the caller's array --
     // and an asynchronous copy into pageable memory may still be completing inside the runtime after the stream is idle)
     PCHK(h, hipStreamSynchronize(st));
     PCHK(h, hipMemcpy(pose.data(), d.pose, sizeof(double) * pose.size(), hipMemcpyDeviceToHost));
     PCHK(h, hipMemcpy(cov.data(), d.cov, sizeof(double) * cov.size(), hipMemcpyDeviceToHost));
     PCHK(h, hipMemcpy(results, d.res, sizeof(isv_pgo_result_t) * ng, hipMemcpyDeviceToHost));
+    const auto tp3 = std::chrono::steady_clock::now();
     // write back (pose_graph.cpp:362-407): updatePose, updateCov, the update() calls, drift, the keyframes after cur
     parallel_over_graphs([&](int g) {
         const int n = ns[g]; isv_pg_keyframe_t *kf = kfs[g];
@@ -1094,6 +1137,11 @@ extern "C" int isv_pgo_optimize_batch(isv_pgo_t *h, int32_t ng, const int32_t *n
             memcpy(kf[k].T_w_i, Pn, 24); memcpy(kf[k].R_w_i, Rn, 72);
         }
     });
+    if (getenv("ISV_TRACE_HANDOVER")) {
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "isv pgo batch: %d graphs: analysis %.2f ms, assembly %.2f ms, H2D + kernel + D2H %.2f ms (%.1f MB up), write-back %.2f ms\n", ng, ms(tp0, tp1), ms(tp1, tp2), ms(tp2, tp3),
+                (pose.size() * 8 + edges.size() * sizeof(PgEdge) + (free_of.size() + adj_ptr.size() + adj.size() + start.size() + rowptr.size() + colptr.size() + colrows.size()) * 4) / 1e6, ms(tp3, std::chrono::steady_clock::now()));
+    }
     // per-graph failures surface in the return value too (every graph has been written back by now; results[g].status says which)
     for (int g = 0; g < ng; g++) if (results[g].status != ISV_OK) { h->err = "pose graph " + std::to_string(g) + ": the covariance factorisation failed (poses written, covariances left untouched)"; return results[g].status; }
     return ISV_OK;
