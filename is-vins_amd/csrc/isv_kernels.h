@@ -36,7 +36,7 @@ int isv_solver_alloc(DevBatch &d, SolverHost &hc, size_t B, size_t L, size_t F, 
 int isv_solver_enqueue(DevBatch &d, const SolverHost &hc, hipStream_t st, hipStream_t st2, hipEvent_t *fj, int64_t *counts, hipEvent_t *prof_ev, std::string &err);
 // (jac = false: the residual-only evaluation, see prior_linearize_body)
 // + the window's prior factor records staged in LDS (round 3): SE3 49 + Linear9 91 + 49 per relative-pose / 14 per roll-pitch words
-static inline size_t prior_lds_bytes(int slots, bool jac = true) { return ((size_t)slots * (jac ? 82 + 90 : 10 + 10) + 140 + (size_t)(slots > 2 ? slots - 2 : 0) * 49) * sizeof(double); }
+__host__ __device__ static inline size_t prior_lds_bytes(int slots, bool jac = true) { return ((size_t)slots * (jac ? 82 + 90 : 10 + 10) + 140 + (size_t)(slots > 2 ? slots - 2 : 0) * 49) * sizeof(double); }
 __global__ void k_triangulate(DevBatch d);
 // wavefronts of k_lin_gram per window: LG_WAVES for batches (three workgroups per CU), LG_WAVES_SMALL while the batch leaves
 // every window a CU of its own (each wavefront takes the pair groups of ISV_SWEEP_WAVES / LGW sweep wavefronts)

@@ -210,6 +210,10 @@ DEV void dogleg_body(DevBatch &d, const int w, const int t, double *red) {
     double *sMod = sImu + NIw * 16;                // [NIw][32] model pieces per tangent row
     double *sPm = sMod + NIw * 32;                 // [slots][16]
     double *sPrior = sPm + (size_t)slots * 16;     // prior_linearize_body scratch
+    {   // the tangent step in LDS for the model pieces (its own region behind the prior scratch; every thread wrote its entries above)
+        double *sDpw = sPrior + prior_lds_bytes(slots, false) / sizeof(double) + 992;
+        for (int i = t; i < n; i += 256) sDpw[i] = dp[i];
+    }
     __syncthreads();                               // candidate states and delta_p are visible to the workgroup
     DSTAMP(50);
 #ifdef ISV_STAMP
@@ -231,13 +235,30 @@ DEV void dogleg_body(DevBatch &d, const int w, const int t, double *red) {
         prior_linearize_body<false, true>(d, d.cpose, d.csb, d.prior_cost_c, 0, w, sPrior);
     } else {
         const int tt = t - 128;
-        // IMU factor q, tangent row a (30 per factor): H row dot delta, packed pairs (max, min)
-        for (int e = tt; e < NIw * 30; e += 128) {
-            const int q = e / 30, a = e - 30 * q;
-            const double *H = d.imu_H + ((size_t)w * NIw + q) * ISV_IMU_H, *dd = dp + 15 * q;
-            double s = 0;
-            for (int b = 0; b < 30; b++) s += H[a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a] * dd[b];
-            sMod[q * 32 + a] = dd[a] * (H[465 + a] + 0.5 * s);
+        // IMU factor q, tangent row a (30 per factor): H row dot delta, packed pairs (max, min).
+        // (round 3) Each of the two wavefronts STAGES its factor's 495-double J^T J record in LDS with coalesced loads and
+        // forms the 30 row products from there; a lane used to walk "its" row of the packed triangle straight from global
+        // memory -- 30 scattered loads per row, three rows per lane: 37 us, the slowest wavefront of the workgroup (the
+        // other three waited 31 us for it).  Same order of additions per row.
+        double *sH = sPrior + prior_lds_bytes(slots, false) / sizeof(double) + (size_t)(wv - 2) * 496;
+        const double *sDp = sPrior + prior_lds_bytes(slots, false) / sizeof(double) + 992;      // delta_p of this window (staged above)
+        for (int q = wv - 2; q < NIw; q += 2) {
+            const double *H = d.imu_H + ((size_t)w * NIw + q) * ISV_IMU_H;
+            double hv[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { const int e = lane + 64 * k; hv[k] = H[e < ISV_IMU_H ? e : ISV_IMU_H - 1]; }
+            ISV_WSYNC();                                   // the previous factor's rows have been read
+#pragma unroll
+            for (int k = 0; k < 8; k++) { const int e = lane + 64 * k; if (e < ISV_IMU_H) sH[e] = hv[k]; }
+            ISV_WSYNC();
+            if (lane < 30) {
+                const int a = lane;
+                const double *dd = sDp + 15 * q;
+                double s = 0;
+#pragma unroll
+                for (int b = 0; b < 30; b++) s += sH[a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a] * dd[b];
+                sMod[q * 32 + a] = dd[a] * (sH[465 + a] + 0.5 * s);
+            }
         }
         const double *PH = d.prior_H + (size_t)w * d.prior_H_sz;
         for (int e = tt; e < slots * 12; e += 128) {
@@ -257,16 +278,19 @@ DEV void dogleg_body(DevBatch &d, const int w, const int t, double *red) {
                 double s = 0;
                 for (int b = 0; b < ncol; b++) {
                     const int gb = (b < 6 || ncol != 12) ? c0 + b : c1 + b - 6;
-                    s += PH[off + (a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a)] * dp[gb];
+                    s += PH[off + (a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a)] * sDp[gb];
                 }
                 const int ga = (a < 6 || ncol != 12) ? c0 + a : c1 + a - 6;
-                v = dp[ga] * (PH[off + np2 + a] + 0.5 * s);
+                v = sDp[ga] * (PH[off + np2 + a] + 0.5 * s);
             }
             sPm[q * 16 + a] = v;
         }
     }
     DSTAMP(51);
     DSTAMP(56);
+#ifdef ISV_STAMP
+    if (t == 128) d.dbg[(size_t)w * 64 + 62] += (double)(wall_clock64() - t1_last);      // wavefront 2: the model pieces
+#endif
     __syncthreads();
     DSTAMP(52);
     // sqrt_info-weighted IMU residuals -> cost; fixed-order sums of the model pieces
@@ -307,12 +331,21 @@ __global__ __launch_bounds__(256, 4) void k_dogleg(DevBatch d) {
     __shared__ double red[256];
     __shared__ int s_accept;
     const int w = blockIdx.x, t = threadIdx.x;
+#ifdef ISV_STAMP
+    const unsigned long long tk0 = wall_clock64();
+#endif
     dogleg_body<EX>(d, w, t, red);
+#ifdef ISV_STAMP
+    const unsigned long long tk1 = wall_clock64();
+#endif
     if (CONTROL) {
         extern __shared__ __align__(16) double dync[];
         __syncthreads();                               // candidate states, per-factor costs and model pieces of this window are written
         step_control_body<true, EX>(d, w, t, dync, red, s_accept);
     }
+#ifdef ISV_STAMP
+    if (t == 0) { d.dbg[(size_t)w * 64 + 54] += (double)(tk1 - tk0); d.dbg[(size_t)w * 64 + 55] += (double)(wall_clock64() - tk1); }
+#endif
 }
 template __global__ void k_dogleg<false, false>(DevBatch);
 template __global__ void k_dogleg<true, false>(DevBatch);
@@ -616,7 +649,8 @@ static int dal(T **p, size_t n, std::vector<void *> &allocs, std::string &err) {
 static std::mutex g_lds_attr_mutex;
 // dynamic LDS of k_dogleg (candidate-point IMU / prior evaluation on the LDS path + the two tangent vectors) and of the step control
 static size_t dogleg_lds_bytes(const DevBatch &d) {
-    return (d.lds_T ? ((size_t)(d.N - 1) * 48 + (size_t)d.n_prior_slots * 16) * sizeof(double) + prior_lds_bytes(d.n_prior_slots, false) : 0) + 2 * (size_t)d.np * sizeof(double);
+    // + two 496-double staging rows for the IMU J^T J records of the model pieces and the tangent step (np)
+    return (d.lds_T ? ((size_t)(d.N - 1) * 48 + (size_t)d.n_prior_slots * 16 + 992 + (size_t)d.np) * sizeof(double) + prior_lds_bytes(d.n_prior_slots, false) : 0) + 2 * (size_t)d.np * sizeof(double);
 }
 // the step control: candidate / current poses, the tangent step, and (when they fit) the per-landmark data its factor loop gathers
 // -- host point, candidate and current inverse depth, the landmark's step: 6 doubles each (d.ctl_stage_lm, set per enqueue)

@@ -19,7 +19,7 @@ print("per k_build_solve_sb call (us), median over windows; 10 calls/solve; wall
 for k, nm in names.items():
     print(f"  {nm:30s} {np.median(dbg[:, k]) / 10 / 100:8.1f} us")
 print("  total           ", np.median(tot) / 10 / 100)
-for k, nm in {48: "dogleg: backsub + first loops", 49: "dogleg: step, candidate", 50: "dogleg: norms + stage + sync", 51: "dogleg: w0 imu raw residual", 56: "dogleg: w1 priors", 52: "dogleg: wait for slowest wave", 53: "dogleg: weighted + sums", 20: "chol: panel (w0)", 21: "chol: barrier after panel", 22: "chol: w0 diag update + factor", 23: "chol: barrier after trailing", 40: "sweep: prologue (sched/off -> LDS)", 41: "sweep: wave 0 main loop", 42: "sweep: barrier wait", 43: "sweep: stage 2"}.items():
+for k, nm in {48: "dogleg: backsub + first loops", 49: "dogleg: step, candidate", 50: "dogleg: norms + stage + sync", 51: "dogleg: w0 imu raw residual", 56: "dogleg: w1 priors", 62: "dogleg: w2 model pieces", 52: "dogleg: wait for slowest wave", 54: "k_dogleg: dogleg body (total)", 55: "k_dogleg: step control (total)", 53: "dogleg: weighted + sums", 20: "chol: panel (w0)", 21: "chol: barrier after panel", 22: "chol: w0 diag update + factor", 23: "chol: barrier after trailing", 40: "sweep: prologue (sched/off -> LDS)", 41: "sweep: wave 0 main loop", 42: "sweep: barrier wait", 43: "sweep: stage 2"}.items():
     print(f"  {nm:36s} {np.median(dbg[:, k]) / 10 / 100:8.1f} us")
 for k, nm in {24: "lin_gram: staging (pose, sched, lam, pts) + sync", 25: "lin_gram: soff / wst + first stream load issued", 26: "lin_gram: factor evaluation + stores (wave 0, all chunks)",
               27: "lin_gram: LDS tile + MFMA rounds (wave 0) [rest: trailing sync]", 57: "lin_gram:   tile write + sync", 58: "lin_gram:   operand reads", 59: "lin_gram:   MFMA segments + group flushes", 28: "lin_gram: (loop exit)", 29: "lin_gram: wait for the slowest wavefront", 30: "lin_gram: fold + Tvis stores",
