@@ -226,7 +226,7 @@ __device__ __forceinline__ void rank1_body(DevBatch &d) {
         for (int l = t; l < Lw; l += nthr) sCG[l] = d.lm_cg[l0 + l];
     }
     __syncthreads();                                       // the host slots (global) and sCG are read below by other threads
-    R1STAMP(32);
+    R1STAMP(10);
     // panel element e of a pass: row r = e / ld (landmark lb + r), column c = e % ld.
     // BRANCH-FREE (round 3): every element issues its (clamped, always valid) load unconditionally and selects afterwards.  Written
     // with `if`s the compiler kept each load inside its own branch with an s_waitcnt vmcnt(0) before the next one (the
@@ -281,12 +281,12 @@ __device__ __forceinline__ void rank1_body(DevBatch &d) {
     if (Lw > 0) fetch(l0);
     for (int lb = l0; lb < l1; lb += R1_CHUNK) {
         __syncthreads();                                   // the previous pass has been consumed
-        R1STAMP(33);
+        R1STAMP(11);
         commit(lb);
         __syncthreads();
-        R1STAMP(34);
+        R1STAMP(12);
         if (lb + R1_CHUNK < l1) fetch(lb + R1_CHUNK);      // in flight during the MFMAs below
-        R1STAMP(35);
+        R1STAMP(13);
 #pragma unroll 4
         for (int k4 = 0; k4 < R1_CHUNK; k4 += 4) {
             const int l = k4 + kq, lg = lb - l0 + l;
@@ -297,7 +297,7 @@ __device__ __forceinline__ void rank1_body(DevBatch &d) {
                 acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[j], 0, 0, 0);
             }
         }
-        R1STAMP(36);
+        R1STAMP(14);
     }
     // C/D layout of v_mfma_f64_16x16x4: col = lane & 15, row = (lane >> 4) + 4 * reg
     // (the four read-modify-writes of a tile: all loads first -- clamped, always valid -- then the stores)
@@ -323,7 +323,7 @@ __device__ __forceinline__ void rank1_body(DevBatch &d) {
             else if (off[reg] <= -2) out[tail + 12 * N + (-2 - off[reg])] = -acc[j][reg];
         }
     }
-    R1STAMP(37);
+    R1STAMP(15);
 }
 template <int NT, int TPW, int R1_CHUNK, int MINW, bool EX>
 __global__ __launch_bounds__(64 * ((NT * (NT + 1) / 2 + TPW - 1) / TPW), MINW) void k_rank1_mfma(DevBatch d) { rank1_body<NT, TPW, R1_CHUNK, MINW, EX>(d); }

@@ -23,6 +23,6 @@ for k, nm in {48: "dogleg: backsub + first loops", 49: "dogleg: step, candidate"
     print(f"  {nm:36s} {np.median(dbg[:, k]) / 10 / 100:8.1f} us")
 for k, nm in {24: "lin_gram: staging (pose, sched, lam, pts) + sync", 25: "lin_gram: soff / wst + first stream load issued", 26: "lin_gram: factor evaluation + stores (wave 0, all chunks)",
               27: "lin_gram: LDS tile + MFMA rounds (wave 0) [rest: trailing sync]", 57: "lin_gram:   tile write + sync", 58: "lin_gram:   operand reads", 59: "lin_gram:   MFMA segments + group flushes", 28: "lin_gram: (loop exit)", 29: "lin_gram: wait for the slowest wavefront", 30: "lin_gram: fold + Tvis stores",
-              32: "rank1: meta + landmark scalars prologue", 33: "rank1: barrier (pass consumed)", 34: "rank1: commit (wait gathers, LDS write) + barrier", 35: "rank1: issue next gathers",
-              36: "rank1: MFMA loop", 37: "rank1: epilogue (Tvis read-modify-write)"}.items():
+              10: "rank1: meta + landmark scalars prologue", 11: "rank1: barrier (pass consumed)", 12: "rank1: commit (wait gathers, LDS write) + barrier", 13: "rank1: issue next gathers",
+              14: "rank1: MFMA loop", 15: "rank1: epilogue (Tvis read-modify-write)"}.items():
     print(f"  {nm:60s} {np.median(dbg[:, k]) / 10 / 100:8.1f} us")
