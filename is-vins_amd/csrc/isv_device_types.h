@@ -12,6 +12,7 @@
 
 #define ISV_TILE 64            // reprojection factors per wavefront tile
 #define ISV_MAX_FRAMES 32
+#define ISV_MARG_WS 1408             // doubles per window: Lp @0 (441), Jr @448 (441), V @896 (441), eigenvalues @1344 (21)
 #define ISV_FUSED_MAX_FACTORS 8192   // longest window (reprojection factors) the one-workgroup-per-window k_lin_gram takes
 #define ISV_IMU_IN 64          // packed IMU record (doubles)
 // offsets inside the packed IMU record
@@ -104,6 +105,7 @@ struct DevBatch {
     int32_t *trace_acc;
     isv_marg_result_t *marg;            // [B]
     double *marg_scratch;               // [B][marg_scratch_sz]
+    double *marg_ws;                    // [B][ISV_MARG_WS] MargBackward between its three kernels: Lp | Jr | V | eigenvalues
     int32_t *margin_old;                // [B]
     double *header0;                    // [B]
     double *dbg;                        // [B][64] diagnostic stamps (ISV_STAMP builds)

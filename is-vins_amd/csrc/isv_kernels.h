@@ -28,6 +28,8 @@ struct SolverHost {
     bool debug_sw_global = false;     // ISV_DEBUG_SW_GLOBAL: pair partials in the global scratch for every launch
     bool legacy_visual = false;       // ISV_LEGACY_VISUAL: the unfused k_proj_linearize<0> + k_sweep_mfma pair
     bool no_persistent = false;       // ISV_NO_PERSISTENT: never the one-launch solve of small batches
+    bool marg_one_kernel = false;     // ISV_MARG_ONE_KERNEL / ISV_MARG_SPLIT force MargBackward as one launch (k_marg_bwd<2>) or as build / k_marg_jacobi /
+    bool marg_split = false;          // project, whatever the batch size (default: split up to n_cus windows); the two are bitwise equal (tested)
     bool no_update = false;           // ISV_DEBUG_NO_UPDATE (sensitivity study, tests/test_sequence_long.py; the oracle has the same
                                       // hook): skip the update() of the prior factors' pseudo-measurements after the solve
                                       // (src/estimator.cpp:1133-1144).  NOT the reference's behaviour.

@@ -28,6 +28,29 @@
 DEV double m_rsqrt(double x) { double r = __builtin_amdgcn_rsq(x); r = r * (1.5 - 0.5 * x * r * r); r = r * (1.5 - 0.5 * x * r * r); return r; }
 DEV double m_rcp(double x) { double r = __builtin_amdgcn_rcp(x); r = r * (2.0 - x * r); r = r * (2.0 - x * r); return r; }
 
+// The arithmetic of one Jacobi rotation, written with explicit fma() so that every instance (the one-wavefront loops, the
+// four-wavefront kernel) rounds the same way whatever the compiler would have contracted: their results are bitwise equal.
+DEV double jr_rsqrt(double x) { double r = __builtin_amdgcn_rsq(x); const double h = 0.5 * x; r = r * fma(-(h * r), r, 1.5); r = r * fma(-(h * r), r, 1.5); return r; }
+DEV double jr_rcp(double x) { double r = __builtin_amdgcn_rcp(x); r = r * fma(-x, r, 2.0); r = r * fma(-x, r, 2.0); return r; }
+// Newton-refined rcp / rsq instead of IEEE div / sqrt: the rotation only has to be orthogonal to rounding, which
+// c = rsqrt(1 + t^2), s = t c guarantees independently of t's accuracy.  rot = false: the identity.
+DEV void jr_params(double app, double aqq, double apq, bool rot, double &c, double &sn) {
+    const double theta = ((aqq - app) * 0.5) * jr_rcp(apq);
+    const double th2 = fma(theta, theta, 1.0);
+    const double tv = (theta >= 0 ? 1.0 : -1.0) * jr_rcp(fma(th2, jr_rsqrt(th2), fabs(theta)));
+    const double cc = jr_rsqrt(fma(tv, tv, 1.0));
+    c = rot ? cc : 1.0; sn = rot ? tv * cc : 0.0;
+}
+// the 2x2 block (rows of pair a) x (columns of pair b) of J^T A J: columns first, then rows
+DEV void jr_block(double ca, double sa, double cb, double sb, double b00, double b01, double b10, double b11,
+                  double &o00, double &o01, double &o10, double &o11) {
+    const double c00 = fma(cb, b00, -(sb * b01)), c01 = fma(sb, b00, cb * b01);
+    const double c10 = fma(cb, b10, -(sb * b11)), c11 = fma(sb, b10, cb * b11);
+    o00 = fma(ca, c00, -(sa * c10)); o01 = fma(ca, c01, -(sa * c11));
+    o10 = fma(sa, c00, ca * c10); o11 = fma(sa, c01, ca * c11);
+}
+DEV void jr_vec(double c, double sn, double vp, double vq, double &op, double &oq) { op = fma(c, vp, -(sn * vq)); oq = fma(sn, vp, c * vq); }
+
 // ---- wave-cooperative dense helpers on LDS matrices (row-major) --------------------------------
 DEV void w_mm(const double *A, const double *B, double *C, int m, int k, int n, int t) {
     for (int e = t; e < m * n; e += MT) { const int i = e / n, j = e % n; double s = 0; for (int p = 0; p < k; p++) s += A[i * k + p] * B[p * n + j]; C[e] = s; }
@@ -113,14 +136,7 @@ DEV void w_jacobi_t(double *A, int n_rt, double *wv, double *V, double *tmp, int
                 double c = 1.0, sn = 0.0;
                 if (q < n) {
                     const double apq = A[p * n + q];
-                    if (apq != 0.0) {
-                        // Newton-refined rcp / rsq instead of IEEE div / sqrt: the rotation only has to be orthogonal
-                        // to rounding, which c = rsqrt(1 + t^2), s = t c guarantees independently of t's accuracy
-                        const double theta = (A[q * n + q] - A[p * n + p]) * 0.5 * m_rcp(apq);
-                        const double th2 = theta * theta + 1.0;
-                        const double tt = (theta >= 0 ? 1.0 : -1.0) * m_rcp(fabs(theta) + th2 * m_rsqrt(th2));
-                        c = m_rsqrt(tt * tt + 1.0); sn = tt * c;
-                    }
+                    if (apq != 0.0) jr_params(A[p * n + p], A[q * n + q], apq, true, c, sn);
                 } else q = p;                      // odd n: this index sits out the round (identity), but its row and column still see the other rotations
                 rp[t] = p; rq[t] = q; rc[t] = c; rs[t] = sn;
             }
@@ -134,20 +150,19 @@ DEV void w_jacobi_t(double *A, int n_rt, double *wv, double *V, double *tmp, int
                 const double ca = rc[pa], sa = rs[pa], cb = rc[pb], sb = rs[pb];
                 const double b00 = A[p1 * n + p2], b01 = rb ? A[p1 * n + q2] : 0.0;
                 const double b10 = ra ? A[q1 * n + p2] : 0.0, b11 = (ra && rb) ? A[q1 * n + q2] : 0.0;
-                // columns first (as the two-pass form did), then rows
-                const double c00 = cb * b00 - sb * b01, c01 = sb * b00 + cb * b01;
-                const double c10 = cb * b10 - sb * b11, c11 = sb * b10 + cb * b11;
-                A[p1 * n + p2] = ca * c00 - sa * c10;
-                if (rb) A[p1 * n + q2] = ca * c01 - sa * c11;
-                if (ra) A[q1 * n + p2] = sa * c00 + ca * c10;
-                if (ra && rb) A[q1 * n + q2] = sa * c01 + ca * c11;
+                double o00, o01, o10, o11;
+                jr_block(ca, sa, cb, sb, b00, b01, b10, b11, o00, o01, o10, o11);
+                A[p1 * n + p2] = o00;
+                if (rb) A[p1 * n + q2] = o01;
+                if (ra) A[q1 * n + p2] = o10;
+                if (ra && rb) A[q1 * n + q2] = o11;
             };
             auto evec = [&](int pr, int k) {             // eigenvector columns
                 const int p = rp[pr], q = rq[pr];
                 if (p != q) {
                     const double c = rc[pr], sn = rs[pr];
                     const double vkp = V[k * n + p], vkq = V[k * n + q];
-                    V[k * n + p] = c * vkp - sn * vkq; V[k * n + q] = sn * vkp + c * vkq;
+                    jr_vec(c, sn, vkp, vkq, V[k * n + p], V[k * n + q]);
                 }
             };
             if constexpr (NC > 0) {                      // constant trip counts: unrolled, the LDS reads of all items issue together
@@ -165,9 +180,80 @@ DEV void w_jacobi_t(double *A, int n_rt, double *wv, double *V, double *tmp, int
     for (int i = t; i < n; i += MT) wv[i] = A[i * n + i];
     SYNC();
 }
+// The same rotations in the same order for a compile-time n, arranged for ONE wavefront's latency: a round is a chain of
+// dependent LDS round trips and FP64 steps (rotation parameters -> 2x2 blocks -> eigenvector columns), so (i) every item
+// is branch-free -- a dummy pair (odd n) is the identity rotation on a doubled index, lanes past the item count work on
+// item 0 and store to a sink -- which leaves each phase one basic block the scheduler can interleave, and (ii) the
+// parameters of round r + 1 (they need A after round r's blocks, nothing of V) are computed between the same two
+// barriers as round r's eigenvector update, double-buffered, so the two chains overlap instead of following each other.
+template <int NC>
+DEV void w_jacobi_pipe(double *A, double *wv, double *V, int t) {
+    constexpr int n = NC, m = n + (n & 1), half = m / 2, NB = half * half, NV = half * n;
+    __shared__ double rc[2][32], rs[2][32], sink[2];
+    __shared__ int rp[2][32], rq[2][32];
+    for (int e = t; e < n * n; e += MT) V[e] = (e / n == e % n) ? 1.0 : 0.0;
+    SYNC();
+    const int tt = t % half;                          // lanes beyond the first `half` recompute (and re-store) the same parameters
+    auto params = [&](int r, int buf) {
+        int a = r + tt, b = r + m - 1 - tt;           // both < 2 (m - 1): one conditional subtraction is the modulo
+        a = a >= m - 1 ? a - (m - 1) : a;
+        b = b >= m - 1 ? b - (m - 1) : b;
+        a = tt == 0 ? m - 1 : a; b = tt == 0 ? r : b;
+        const int p = a < b ? a : b, q0 = a < b ? b : a;
+        const bool real = q0 < n;                     // odd n: the pair holding the phantom index sits out the round
+        const int q = real ? q0 : p;
+        const double apq = A[p * n + q], aqq = A[q * n + q], app = A[p * n + p];
+        double c, sn;
+        jr_params(app, aqq, apq, real && apq != 0.0, c, sn);
+        rp[buf][tt] = p; rq[buf][tt] = q; rc[buf][tt] = c; rs[buf][tt] = sn;
+    };
+    for (int sweep = 0; sweep < 30; sweep++) {
+        double off = 0, dg = 0;
+        for (int e = t; e < n * n; e += MT) { const int i = e / n, j = e % n; if (j > i) off += A[e] * A[e]; else if (i == j) dg += A[e] * A[e]; }
+        for (int o = 32; o > 0; o >>= 1) { off += __shfl_xor(off, o); dg += __shfl_xor(dg, o); }
+        if (off <= 1e-60 || off <= 1e-28 * dg) break;      // as w_jacobi_t
+        params(0, 0);
+        SYNC();
+        for (int r = 0; r < m - 1; r++) {
+            const int buf = r & 1;
+            // A <- J^T A J: the 2x2 block (rows of pair a) x (columns of pair b) only sees the rotations a and b
+#pragma unroll
+            for (int e0 = 0; e0 < NB; e0 += MT) {
+                const int e = e0 + t;
+                const bool valid = e < NB;
+                const int ee = valid ? e : 0, pa = ee / half, pb = ee % half;
+                const int p1 = rp[buf][pa], q1 = rq[buf][pa], p2 = rp[buf][pb], q2 = rq[buf][pb];
+                const double ca = rc[buf][pa], sa = rs[buf][pa], cb = rc[buf][pb], sb = rs[buf][pb];
+                double *const a00 = valid ? A + p1 * n + p2 : sink, *const a01 = valid ? A + p1 * n + q2 : sink;
+                double *const a10 = valid ? A + q1 * n + p2 : sink, *const a11 = valid ? A + q1 * n + q2 : sink;
+                const double b00 = *a00, b01 = *a01, b10 = *a10, b11 = *a11;
+                double o00, o01, o10, o11;
+                jr_block(ca, sa, cb, sb, b00, b01, b10, b11, o00, o01, o10, o11);
+                // a dummy pair doubles its index: its two stores hit one address with one value
+                *a00 = o00; *a01 = o01; *a10 = o10; *a11 = o11;
+            }
+            SYNC();
+            params(r + 1, buf ^ 1);                        // (after the last round: computed and dropped)
+#pragma unroll
+            for (int e0 = 0; e0 < NV; e0 += MT) {          // V <- V J
+                const int e = e0 + t;
+                const bool valid = e < NV;
+                const int ee = valid ? e : 0, pr = ee / n, k = ee % n;
+                const int p = rp[buf][pr], q = rq[buf][pr];
+                const double c = rc[buf][pr], sn = rs[buf][pr];
+                double *const vp = valid ? V + k * n + p : sink + 1, *const vq = valid ? V + k * n + q : sink + 1;
+                const double vkp = *vp, vkq = *vq;
+                jr_vec(c, sn, vkp, vkq, *vp, *vq);
+            }
+            SYNC();
+        }
+    }
+    for (int i = t; i < n; i += MT) wv[i] = A[i * n + i];
+    SYNC();
+}
 DEV void w_jacobi(double *A, int n, double *wv, double *V, double *tmp, int t) {
-    if (n == 21) w_jacobi_t<21>(A, n, wv, V, tmp, t);
-    else if (n == 6) w_jacobi_t<6>(A, n, wv, V, tmp, t);
+    if (n == 21) w_jacobi_pipe<21>(A, wv, V, t);
+    else if (n == 6) w_jacobi_pipe<6>(A, wv, V, t);
     else w_jacobi_t<0>(A, n, wv, V, tmp, t);
 }
 // log(det(A)) of a symmetric positive-definite matrix by unpivoted elimination (lane-parallel)
@@ -225,7 +311,8 @@ __global__ void k_marg_clear(DevBatch d) {
 
 // MargForward (+ the pose-graph edge); the record is cleared by k_marg_clear beforehand
 __global__ __launch_bounds__(MT) void k_marg_fwd(DevBatch d) {
-    __shared__ double Lam[144], M1[144], M2[144], Wk[1700], Vv[36], wv[8], JU[36], tmp[128];
+    // (LDS decides how many windows a CU holds next to k_marg_bwd's: 4 + 4 workgroups need <= 40 KB for the pair)
+    __shared__ double Lam[144], M1[144], M2[144], Wk[936], Vv[36], wv[8], JU[36];
     __shared__ double sJ[3 * 36];
     __shared__ int keep[8], piv[4];
     const int w = blockIdx.x, t = threadIdx.x;
@@ -275,8 +362,8 @@ __global__ __launch_bounds__(MT) void k_marg_fwd(DevBatch d) {
     // raw pose block Hraw (12x12, order [T1, T0]) in Lam[0..143]; Schur-reduced over the landmarks in M1[0..143]
     {
         double hr[3] = {0, 0, 0}, hs[3] = {0, 0, 0};
-        for (int mb = 0; mb < n0; mb += 64) {
-            const int cnt = (n0 - mb) < 64 ? (n0 - mb) : 64;
+        for (int mb = 0; mb < n0; mb += 32) {
+            const int cnt = (n0 - mb) < 32 ? (n0 - mb) : 32;
             for (int e = t; e < cnt * 26; e += MT) Wk[e] = Jw[(size_t)mb * 26 + e];
             SYNC();
             for (int m = 0; m < cnt; m++) {
@@ -344,7 +431,7 @@ __global__ __launch_bounds__(MT) void k_marg_fwd(DevBatch d) {
         w_mm_nt(M2, M2, G, 6, 12, 6, t);
         for (int e = t; e < 36; e += MT) JU[e] = G[e];
         SYNC();
-        w_jacobi(JU, 6, wv, Vv, tmp, t);
+        w_jacobi(JU, 6, wv, Vv, nullptr, t);
         double smax2 = 0; for (int k = 0; k < 6; k++) smax2 = fmax(smax2, wv[k]);
         const double thr = 1e-8 * 12;
         for (int e = t; e < 36; e += MT) {
@@ -430,7 +517,7 @@ __global__ __launch_bounds__(MT) void k_marg_fwd(DevBatch d) {
         } else {
             for (int e = t; e < 36; e += MT) JU[e] = Lp[e];
             SYNC();
-            w_jacobi(JU, 6, wv, Vv, tmp, t);
+            w_jacobi(JU, 6, wv, Vv, nullptr, t);
             if (t < 6) keep[t] = wv[t] > d.alpha_cut;
             SYNC();
             w_project_cov(sJ, 6, 6, Vv, wv, keep, JU, covi, t);
@@ -454,15 +541,107 @@ __global__ __launch_bounds__(MT) void k_marg_fwd(DevBatch d) {
     MSTAMP(4);
 }
 
-// MargBackward
+// ------------------------------------------------------------------------------------------
+// The eigen-decomposition of MargBackward's 21 x 21 marginal as a kernel of its own, FOUR wavefronts per window.  One
+// wavefront issues ~300 instructions per Jacobi round (11 rotation parameters, 121 2x2 blocks in two passes, 231
+// eigenvector items in four); here a round is one item per lane:
+//   * wavefronts 0-1: lane e < half^2 owns the 2x2 block (rows of pair e / half) x (columns of pair e % half);
+//   * wavefronts 2-3: lane e owns the rotation of pair e / half applied to eigenvector rows 2 (e % half), + 1
+//     (the eigenvectors never enter the rotation parameters, so this runs beside the block update);
+//   * then lanes 0..half-1 of wavefront 0 compute the next round's parameters from the updated A (double-buffered
+//     parameter table), the other wavefronts wait at the barrier: two barriers per round, ~210 instructions per window.
+// Rotations, their order and the arithmetic of each item (jr_params / jr_block / jr_vec) are those of w_jacobi_pipe: the
+// result is bitwise the same.  In: Lp at ws[0..n^2).  Out: V at ws[896..), eigenvalues at ws[1344..).
+template <int NC>
+__global__ __launch_bounds__(256) void k_marg_jacobi(DevBatch d) {
+    constexpr int n = NC, m = n + (n & 1), half = m / 2, NI = half * half, NN = n * n;
+    static_assert(NI <= 128 && half <= 32, "one item per lane of two wavefronts");
+    __shared__ double sA[NN + 1], sV[NN + 1], red[8], sink[2], rc[2][32], rs[2][32];
+    __shared__ int rp[2][32], rq[2][32];
+    const int w = blockIdx.x, t = threadIdx.x;
+    if (!d.margin_old[w]) return;
+#ifdef ISV_STAMP
+    unsigned long long t_last = wall_clock64();
+#endif
+    double *const ws = d.marg_ws + (size_t)w * ISV_MARG_WS;
+    for (int e = t; e < NN; e += 256) { sA[e] = ws[e]; sV[e] = (e / n == e % n) ? 1.0 : 0.0; }
+    __syncthreads();
+    const bool is_block = t < 128;                    // wavefront-uniform
+    const int e = is_block ? t : t - 128;
+    const bool valid = e < NI;
+    const int i0 = valid ? e / half : 0, i1 = valid ? e % half : 0;
+    // pair k of round r in the round-robin tournament; the pair holding the phantom index (odd n) doubles its real one
+    auto params = [&](int r, int buf) {
+        if (t < half) {
+            const int k = t;
+            int a = r + k, b = r + m - 1 - k;
+            a = a >= m - 1 ? a - (m - 1) : a;
+            b = b >= m - 1 ? b - (m - 1) : b;
+            a = k == 0 ? m - 1 : a; b = k == 0 ? r : b;
+            const int p = a < b ? a : b, q0 = a < b ? b : a, q = q0 < n ? q0 : p;
+            const double apq = sA[p * n + q], aqq = sA[q * n + q], app = sA[p * n + p];
+            double c, sn;
+            jr_params(app, aqq, apq, p != q && apq != 0.0, c, sn);
+            rp[buf][k] = p; rq[buf][k] = q; rc[buf][k] = c; rs[buf][k] = sn;
+        }
+    };
+    for (int sweep = 0; sweep < 30; sweep++) {
+        double off = 0, dg = 0;
+        for (int x = t; x < NN; x += 256) { const int i = x / n, j = x % n; const double v = sA[x]; if (j > i) off += v * v; else if (i == j) dg += v * v; }
+        for (int o = 32; o > 0; o >>= 1) { off += __shfl_xor(off, o); dg += __shfl_xor(dg, o); }
+        if ((t & 63) == 0) { red[(t >> 6) * 2] = off; red[(t >> 6) * 2 + 1] = dg; }
+        params(0, 0);
+        __syncthreads();
+        // (the sums of the one-wavefront version run over the same lanes in another order: the test below is a
+        // threshold many orders of magnitude wide, not a value that is carried on)
+        off = red[0] + red[2] + red[4] + red[6]; dg = red[1] + red[3] + red[5] + red[7];
+        if (off <= 1e-60 || off <= 1e-28 * dg) break;
+        for (int r = 0; r < m - 1; r++) {
+            const int buf = r & 1;
+            if (is_block) {
+                const int p1 = rp[buf][i0], q1 = rq[buf][i0], p2 = rp[buf][i1], q2 = rq[buf][i1];
+                const double ca = rc[buf][i0], sa = rs[buf][i0], cb = rc[buf][i1], sb = rs[buf][i1];
+                double *const a00 = valid ? sA + p1 * n + p2 : sink, *const a01 = valid ? sA + p1 * n + q2 : sink;
+                double *const a10 = valid ? sA + q1 * n + p2 : sink, *const a11 = valid ? sA + q1 * n + q2 : sink;
+                const double b00 = *a00, b01 = *a01, b10 = *a10, b11 = *a11;
+                double o00, o01, o10, o11;
+                jr_block(ca, sa, cb, sb, b00, b01, b10, b11, o00, o01, o10, o11);
+                *a00 = o00; *a01 = o01; *a10 = o10; *a11 = o11;      // a dummy pair doubles its index: two stores, one address, one value
+            } else {
+                const int p = rp[buf][i0], q = rq[buf][i0];
+                const double c = rc[buf][i0], sn = rs[buf][i0];
+                const int k0 = 2 * i1, k1 = (2 * i1 + 1 < n) ? 2 * i1 + 1 : k0;       // odd n: the last lane's second row repeats its first
+                double *const v0p = valid ? sV + k0 * n + p : sink + 1, *const v0q = valid ? sV + k0 * n + q : sink + 1;
+                double *const v1p = valid ? sV + k1 * n + p : sink + 1, *const v1q = valid ? sV + k1 * n + q : sink + 1;
+                const double a0 = *v0p, b0 = *v0q, a1 = *v1p, b1 = *v1q;
+                double r0p, r0q, r1p, r1q;
+                jr_vec(c, sn, a0, b0, r0p, r0q); jr_vec(c, sn, a1, b1, r1p, r1q);
+                *v0p = r0p; *v0q = r0q; *v1p = r1p; *v1q = r1q;
+            }
+            __syncthreads();
+            if (r + 1 < m - 1) { params(r + 1, buf ^ 1); __syncthreads(); }
+        }
+    }
+    for (int x = t; x < NN; x += 256) ws[896 + x] = sV[x];
+    if (t < n) ws[1344 + t] = sA[t * n + t];
+#ifdef ISV_STAMP
+    if (t == 0) d.dbg[(size_t)w * 64 + 32 + 6] += (double)(wall_clock64() - t_last);
+#endif
+}
+template __global__ void k_marg_jacobi<21>(DevBatch);
+
+// MargBackward.  In three launches: <0> builds the 21 x 21 marginal Lp and the recovered factors' Jacobian Jr (left in
+// d.marg_ws), k_marg_jacobi<21> eigen-decomposes Lp, <1> projects the covariance onto the factors and takes the KLD.
+// In one launch: <2>, the eigen-decomposition by the window's one wavefront (w_jacobi_pipe).
+template <int PART>
 __global__ __launch_bounds__(MT) void k_marg_bwd(DevBatch d) {
     // LDS is what limits residency (one wavefront per window, all windows should be resident at once next to
     // k_marg_fwd's): Lam (30x30) is dead once the 21x21 marginal Lp exists, so the recovered-factor Jacobian Jr
     // and the projection scratch JU live in its space; M1 (Lp) is dead after the eigen-decomposition copy and
     // then holds the block-diagonal information Xall; Vv is dead once (Jr U) is formed and then holds Ak.
-    __shared__ double Lam[900], M1[450], M2[450], Wk[900], Vv[441], wv[32], tmp[128];
+    __shared__ double Lam[900], M1[450], M2[450], Wk[464], Vv[441], wv[32];
     __shared__ double sJ[2 * 36];
-    __shared__ int keep[32], piv[4];
+    __shared__ int keep[32], kpos[32], piv[4];
     double *const Jr = Lam, *const JU = Lam + 441;
     const int w = blockIdx.x, t = threadIdx.x;
     isv_marg_result_t &out = d.marg[w];
@@ -474,6 +653,9 @@ __global__ __launch_bounds__(MT) void k_marg_bwd(DevBatch d) {
     const double *pose = d.pose + (size_t)w * N * 7, *sb = d.sb + (size_t)w * N * 9, *ex = d.ex + (size_t)w * 7;
     const int l0 = d.lm_off[w], l1 = d.lm_off[w + 1];
     (void)sb; (void)ex; (void)l0; (void)l1; (void)v;
+    double *const ws = d.marg_ws + (size_t)w * ISV_MARG_WS;
+    isv_relpose_t &rp = out.backward_relpose; isv_linear9_t &vb = out.backward_vb; isv_rollpitch_t &gp = out.backward_rollpitch;
+    if constexpr (PART != 1) {
     // ================= MargBackward =================
     // order: T1 = frame v (@0), VB1 (@6), T0 = frame v-1 (@15), VB0 (@21)
     for (int e = t; e < 900; e += MT) Lam[e] = 0.0;
@@ -550,7 +732,6 @@ __global__ __launch_bounds__(MT) void k_marg_bwd(DevBatch d) {
         SYNC();
     }
     // recovered factors at the current estimate
-    isv_relpose_t &rp = out.backward_relpose; isv_linear9_t &vb = out.backward_vb; isv_rollpitch_t &gp = out.backward_rollpitch;
     for (int e = t; e < 441; e += MT) Jr[e] = 0.0;
     SYNC();
     if (t == 0) {
@@ -581,20 +762,24 @@ __global__ __launch_bounds__(MT) void k_marg_bwd(DevBatch d) {
         for (int b = 0; b < 3; b++) Jr[20 * 21 + 18 + b] += By[3 + b];
     }
     SYNC();
+    if constexpr (PART == 0) for (int e = t; e < 441; e += MT) { ws[e] = Lp[e]; ws[448 + e] = Jr[e]; }
     MSTAMP(5);
-#if defined(MARG_STOP) && MARG_STOP == 1
-    return;
-#endif
-    // eigen-truncate Lp at ALPHA
-    for (int e = t; e < 441; e += MT) M2[e] = Lp[e];
-    SYNC();
-    w_jacobi(M2, 21, wv, Vv, tmp, t);
-    if (t < 21) keep[t] = wv[t] > d.alpha_cut;
-    SYNC();
-#if defined(MARG_STOP) && MARG_STOP == 2
-    return;
-#endif
-    MSTAMP(6);
+    if constexpr (PART == 2) {                       // one launch: the eigen-decomposition by this wavefront
+        for (int e = t; e < 441; e += MT) M2[e] = Lp[e];
+        SYNC();
+        w_jacobi(M2, 21, wv, Vv, nullptr, t);
+        if (t < 21) keep[t] = wv[t] > d.alpha_cut;
+        SYNC();
+        MSTAMP(6);
+    }
+    }   // PART != 1
+    if constexpr (PART == 1) {
+        // eigen-truncate Lp at ALPHA: k_marg_jacobi<21> left the eigenpairs in the workspace
+        for (int e = t; e < 441; e += MT) { Jr[e] = ws[448 + e]; Vv[e] = ws[896 + e]; }
+        if (t < 21) { const double ev = ws[1344 + t]; wv[t] = ev; keep[t] = ev > d.alpha_cut; }
+        SYNC();
+    }
+    if constexpr (PART != 0) {
     {
         double *Sg = Wk, *Xi = Wk + 100, *Xall = M1;             // Xall: 21x21 block-diagonal information (M1 is free now)
         for (int e = t; e < 441; e += MT) Xall[e] = 0.0;
@@ -625,7 +810,7 @@ __global__ __launch_bounds__(MT) void k_marg_bwd(DevBatch d) {
         MSTAMP(7);
         // zero test / KLD (estimator.cpp:1519-1534): A = (Jr U)^T X (Jr U) over the kept eigenpairs vs D
         int rank = 0; for (int k = 0; k < 21; k++) rank += keep[k];
-        double *JUa = Wk, *XJU = Wk + 450, *A = M2;
+        double *JUa = Wk, *XJU = JU, *A = M2;            // (Jr is dead once JUa exists, the projection scratch JU already is)
         for (int e = t; e < 21 * 21; e += MT) {
             const int a = e / 21, k = e % 21; double s = 0;
             for (int c = 0; c < 21; c++) s += Jr[a * 21 + c] * Vv[c * 21 + k];
@@ -637,14 +822,11 @@ __global__ __launch_bounds__(MT) void k_marg_bwd(DevBatch d) {
         SYNC();
         // restrict A to kept indices (rank x rank) in Wk+1000.. and evaluate trace / determinants
         double *Ak = Vv;                                  // (Vv was consumed by JUa above)
-        for (int e = t; e < 441; e += MT) {               // position of a kept index among the kept ones = kept indices before it
+        if (t < 21) { int c = 0; for (int k = 0; k < t; k++) c += keep[k]; kpos[t] = c; }     // position of a kept index among the kept ones
+        SYNC();
+        for (int e = t; e < 441; e += MT) {
             const int a = e / 21, b = e % 21;
-            if (keep[a] && keep[b]) {
-                int ia = 0, ib = 0;
-                for (int k = 0; k < a; k++) ia += keep[k];
-                for (int k = 0; k < b; k++) ib += keep[k];
-                Ak[ia * rank + ib] = A[e];
-            }
+            if (keep[a] && keep[b]) Ak[kpos[a] * rank + kpos[b]] = A[e];
         }
         SYNC();
         const double ldA = w_logdet_spd(Ak, rank, JU, t);
@@ -655,7 +837,11 @@ __global__ __launch_bounds__(MT) void k_marg_bwd(DevBatch d) {
         }
         MSTAMP(8);
     }
+    }   // PART != 0
 }
+template __global__ void k_marg_bwd<0>(DevBatch);
+template __global__ void k_marg_bwd<1>(DevBatch);
+template __global__ void k_marg_bwd<2>(DevBatch);
 
 // ------------------------------------------------------------------------------------------
 // Estimator::initFactorGraph, the part after its ceres::Solve (src/estimator.cpp:744-999): build the first prior

@@ -29,7 +29,8 @@ __global__ void k_sweep_mfma(DevBatch d);
 template <int NT, int TPW, int R1_CHUNK, int MINW, bool EX> __global__ void k_rank1_mfma(DevBatch d);
 __global__ void k_marg_clear(DevBatch d);
 __global__ void k_marg_fwd(DevBatch d);
-__global__ void k_marg_bwd(DevBatch d);
+template <int PART> __global__ void k_marg_bwd(DevBatch d);
+template <int NC> __global__ void k_marg_jacobi(DevBatch d);
 template <bool LDS_T> __global__ void k_build_solve(DevBatch d);
 
 // ------------------------------------------------------------------------------------------
@@ -702,9 +703,11 @@ int isv_solver_alloc(DevBatch &d, SolverHost &hc, size_t B, size_t L, size_t F, 
     hc.debug_sw_global = getenv("ISV_DEBUG_SW_GLOBAL") != nullptr; hc.legacy_visual = getenv("ISV_LEGACY_VISUAL") != nullptr;
     hc.no_persistent = getenv("ISV_NO_PERSISTENT") != nullptr;
     hc.no_update = getenv("ISV_DEBUG_NO_UPDATE") != nullptr;
+    hc.marg_one_kernel = getenv("ISV_MARG_ONE_KERNEL") != nullptr; hc.marg_split = getenv("ISV_MARG_SPLIT") != nullptr;
     if (d.lds_T && (sw_global || hc.debug_sw_global)) TRYA(dal(&d.sw_part, B * n_pairs * 84, allocs, err));
     d.marg_scratch_sz = 26;
     TRYA(dal(&d.marg_scratch, L * 26, allocs, err));
+    TRYA(dal(&d.marg_ws, B * ISV_MARG_WS, allocs, err));
     int dev_ = 0;
     HCHK(hipGetDevice(&dev_));
     if (d.lds_T) {
@@ -867,12 +870,24 @@ int isv_solver_enqueue(DevBatch &d, const SolverHost &hc, hipStream_t st, hipStr
         return ISV_OK;
     }
     hipLaunchKernelGGL(k_finalize, dim3(d.B), dim3(64), 0, st, d, hc.no_update ? 0 : 1);
-    // MargForward and MargBackward are independent: run them side by side
+    // MargForward and MargBackward are independent: run them side by side.  The longer one (backward, 270 us per window against
+    // 110) goes on the main stream so that it is dispatched FIRST: four workgroups of each per CU do not fit the LDS together
+    // (4 x 27 KB + 4 x 19 KB > 160 KB), and whichever kernel arrives second runs its last workgroups after the first one's.
     hipLaunchKernelGGL(k_marg_clear, dim3(d.B), dim3(64), 0, st, d);
     HCHK(hipEventRecord(fj[0], st)); HCHK(hipStreamWaitEvent(st2, fj[0], 0));
-    hipLaunchKernelGGL(k_marg_bwd, dim3(d.B), dim3(64), 0, st2, d);
+    // a batch that leaves SIMDs idle (one wavefront per window: B < 4 n_cus) is latency bound and takes the four-wavefront
+    // eigen-decomposition (B = 1 / 64 / 256 / 512: 1.95 / 2.27 / 2.47 / 3.16 ms against 1.98 / 2.35 / 2.55 / 3.25); once
+    // every SIMD holds a window the phase is instruction-issue bound and the two forms tie (B = 1024: 5.75 ms either way);
+    // beyond that the one launch is kept
+    const bool marg_one = hc.marg_one_kernel || (!hc.marg_split && d.B > 3 * hc.n_cus);
+    if (marg_one) hipLaunchKernelGGL(k_marg_bwd<2>, dim3(d.B), dim3(64), 0, st, d);
+    else {
+        hipLaunchKernelGGL(k_marg_bwd<0>, dim3(d.B), dim3(64), 0, st, d);
+        hipLaunchKernelGGL(k_marg_jacobi<21>, dim3(d.B), dim3(256), 0, st, d);
+        hipLaunchKernelGGL(k_marg_bwd<1>, dim3(d.B), dim3(64), 0, st, d);
+    }
+    hipLaunchKernelGGL(k_marg_fwd, dim3(d.B), dim3(64), 0, st2, d);
     HCHK(hipEventRecord(fj[1], st2));
-    hipLaunchKernelGGL(k_marg_fwd, dim3(d.B), dim3(64), 0, st, d);
     HCHK(hipStreamWaitEvent(st, fj[1], 0));
     HCHK(hipGetLastError());
     return ISV_OK;

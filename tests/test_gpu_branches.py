@@ -165,6 +165,27 @@ def test_unfused_kernel_variants_against_oracle_and_fused(oracle, monkeypatch, e
         bf.close()
 
 
+def test_marg_backward_one_launch_against_three(oracle, monkeypatch):
+    """MargBackward as one kernel (k_marg_bwd<2>: the window's one wavefront runs the 21 x 21 Jacobi sweeps, what batches
+    beyond n_cus windows take) against build / k_marg_jacobi<21> (four wavefronts, one item per lane) / project (small
+    batches): the same rotations in the same order with the same arithmetic per item, so the records are BYTEWISE equal;
+    and either against the oracle."""
+    import ctypes
+    ws = synth.make_windows([70, 71, 72, 73, 74], n_frames=11, n_vo=5, n_landmarks=120)
+    cap = dict(max_landmarks=120, max_obs=max(w.n_obs for w in ws), max_batch=5)
+    recs = {}
+    for env in ("ISV_MARG_ONE_KERNEL", "ISV_MARG_SPLIT"):
+        monkeypatch.setenv(env, "1")
+        b = backend.Backend(11, 5, **cap)
+        try:
+            _, _, margs = _solve_pair(oracle, b, ws)
+            recs[env] = [bytes(ctypes.string_at(ctypes.addressof(m), ctypes.sizeof(m))) for m in margs]
+        finally:
+            b.close()
+        monkeypatch.delenv(env)
+    assert recs["ISV_MARG_ONE_KERNEL"] == recs["ISV_MARG_SPLIT"]
+
+
 # ---- double2vector near pitch +-90 deg ------------------------------------------------------------------------------
 def _pitch_deg(R):
     """Utility::R2ypr (include/utility/utility.h:66-81), pitch in degrees"""
