@@ -518,7 +518,7 @@ extern "C" int isv_batch_optimize(isv_backend_t *h, int32_t sync) {
     const bool profile = (sync & 2) != 0 && !h->prof_ev.empty();       // per-kernel-family events only on request
     static const bool use_graph = getenv("ISV_GRAPH") != nullptr;
     if (use_graph && !profile) {
-        d.sw_global = 0; d.ctl_stage_lm = 0;                            // (set inside the enqueue: not part of the key)
+        d.sw_global = 0; d.ctl_stage_lm = 0; d.dg_stage_ph = 0;                            // (set inside the enqueue: not part of the key)
         const uint64_t key = fnv1a(&d, sizeof(d));
         HIPCHK(h, hipEventRecord(h->ev[0], st));
         if (!h->graph_exec || h->graph_key != key) {

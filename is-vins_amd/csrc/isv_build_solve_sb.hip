@@ -190,7 +190,9 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
         // ---- issue every global load of the assembly up front (one memory latency instead of five) ----
         const double *H = d.imu_H + (size_t)w * (N - 1) * ISV_IMU_H;
         const double *PH = d.prior_H + (size_t)w * d.prior_H_sz;
-        double vS[5], vT[3] = {0, 0, 0}, vF[3], vX[5], vG = 0, vP[2] = {0, 0};
+        // (BIG: one workgroup per CU = 256 VGPRs per lane, room for the IMU blocks of up to 20 frames: 2400 / 512 and 4275 / 512 entries per thread)
+        constexpr int KF = BIG ? 5 : 3, KX = BIG ? 9 : 5;
+        double vS[5], vT[3] = {0, 0, 0}, vF[KF], vX[KX], vG = 0, vP[2] = {0, 0};
         if (!BIG) {
 #pragma unroll
             for (int k = 0; k < 5; k++) { const int e = t + k * LS; vS[k] = e < nS ? V[e] : 0.0; }
@@ -269,16 +271,25 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
         }
         // ---- reprojection part from k_sweep / k_rank1_mfma (same packed layout) ----------------------
         for (int e = t; e < n; e += LS) { g[e] = 0.0; bs[e] = 0.0; hdiag[e] = 0.0; }
-        if (BIG) { for (int e = t; e < nS; e += LS) Spp[e] = V[e]; }
-        else {
+        if (!BIG) {
 #pragma unroll
             for (int k = 0; k < 5; k++) { const int e = t + k * LS; if (e < nS) Spp[e] = vS[k]; }
-            // second register stage (after the first was stored: both at once cost spills under the 128-VGPR cap of two
-            // workgroups per CU): the IMU blocks, in flight across the barrier and the zeroing below
+        }
+        // second register stage (after the first was stored: both at once cost spills under the 128-VGPR cap of two
+        // workgroups per CU): the IMU blocks, in flight across the barrier and the zeroing below (BIG: across the copy of
+        // the pose blocks as well)
 #pragma unroll
-            for (int k = 0; k < 3; k++) { const int e = t + k * LS; vF[k] = e < N * 120 ? imu_frame_fetch(e) : 0.0; }
+        for (int k = 0; k < KF; k++) { const int e = t + k * LS; vF[k] = e < N * 120 ? imu_frame_fetch(e) : 0.0; }
 #pragma unroll
-            for (int k = 0; k < 5; k++) { const int e = t + k * LS; vX[k] = e < (N - 1) * 225 ? imu_pair_fetch(e) : 0.0; }
+        for (int k = 0; k < KX; k++) { const int e = t + k * LS; vX[k] = e < (N - 1) * 225 ? imu_pair_fetch(e) : 0.0; }
+        if (BIG) {
+            for (int e0 = t; e0 < nS; e0 += 4 * LS) {       // four loads in flight per trip
+                double v4[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) { const int e = e0 + k * LS; v4[k] = e < nS ? V[e] : 0.0; }
+#pragma unroll
+                for (int k = 0; k < 4; k++) { const int e = e0 + k * LS; if (e < nS) Spp[e] = v4[k]; }
+            }
         }
         __syncthreads();
         if (t < n6) {
@@ -332,28 +343,10 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
         if (t + LS < nred) red[t + LS] = vP[1];
         __syncthreads();
         STAMP(0);
-        if (BIG) {
-            // (round 3: four loads in flight per trip instead of a load -> LDS store chain per entry)
-            for (int e0 = t; e0 < N * 120; e0 += 4 * LS) {
-                double v4[4];
 #pragma unroll
-                for (int k = 0; k < 4; k++) { const int e = e0 + k * LS; v4[k] = e < N * 120 ? imu_frame_fetch(e) : 0.0; }
+        for (int k = 0; k < KF; k++) { const int e = t + k * LS; if (e < N * 120) imu_frame_apply(e, vF[k]); }
 #pragma unroll
-                for (int k = 0; k < 4; k++) { const int e = e0 + k * LS; if (e < N * 120) imu_frame_apply(e, v4[k]); }
-            }
-            for (int e0 = t; e0 < (N - 1) * 225; e0 += 4 * LS) {
-                double v4[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) { const int e = e0 + k * LS; v4[k] = e < (N - 1) * 225 ? imu_pair_fetch(e) : 0.0; }
-#pragma unroll
-                for (int k = 0; k < 4; k++) { const int e = e0 + k * LS; if (e < (N - 1) * 225 && !skipL[e / 225]) imu_pair_apply(e, v4[k]); }
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 3; k++) { const int e = t + k * LS; if (e < N * 120) imu_frame_apply(e, vF[k]); }
-#pragma unroll
-            for (int k = 0; k < 5; k++) { const int e = t + k * LS; if (e < (N - 1) * 225 && !skipL[e / 225]) imu_pair_apply(e, vX[k]); }
-        }
+        for (int k = 0; k < KX; k++) { const int e = t + k * LS; if (e < (N - 1) * 225 && !skipL[e / 225]) imu_pair_apply(e, vX[k]); }
         if (t < n) g[t] += vG;
         __syncthreads();
         STAMP(1);

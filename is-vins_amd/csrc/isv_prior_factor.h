@@ -42,6 +42,15 @@ DEV void relpose_jac(const double *dt, const double *dR, const double *pi, const
 struct PriorRecs {
     const isv_se3_prior_t *se3; const isv_linear9_t *lin9; const isv_relpose_t *relpose; const isv_rollpitch_t *rollpitch;
 };
+DEV PriorRecs prior_recs_at(const DevBatch &d, const double *dst) {          // the staged records' addresses (no copy)
+    constexpr int SW = sizeof(isv_se3_prior_t) / 8, LW = sizeof(isv_linear9_t) / 8, RW = sizeof(isv_relpose_t) / 8;
+    const uint64_t *o = (const uint64_t *)dst;
+    const int n0 = SW, n1 = n0 + LW, n2 = n1 + RW * (d.Nvo - 1);
+    PriorRecs r;
+    r.se3 = (const isv_se3_prior_t *)o; r.lin9 = (const isv_linear9_t *)(o + n0);
+    r.relpose = (const isv_relpose_t *)(o + n1); r.rollpitch = (const isv_rollpitch_t *)(o + n2);
+    return r;
+}
 DEV PriorRecs prior_stage_records(const DevBatch &d, int w, double *dst, int t, int nthr) {
     constexpr int SW = sizeof(isv_se3_prior_t) / 8, LW = sizeof(isv_linear9_t) / 8, RW = sizeof(isv_relpose_t) / 8, PW = sizeof(isv_rollpitch_t) / 8;
     const int nrel = d.Nvo - 1;
@@ -49,11 +58,19 @@ DEV PriorRecs prior_stage_records(const DevBatch &d, int w, double *dst, int t, 
     const uint64_t *a = (const uint64_t *)(d.se3 + w), *b = (const uint64_t *)(d.lin9 + w);
     const uint64_t *c = (const uint64_t *)(d.relpose + (size_t)w * nrel), *e = (const uint64_t *)(d.rollpitch + (size_t)w * d.max_rp);
     const int n0 = SW, n1 = n0 + LW, n2 = n1 + RW * nrel, n3 = n2 + PW * d.max_rp;
-    for (int k = t; k < n3; k += nthr) o[k] = k < n0 ? a[k] : (k < n1 ? b[k - n0] : (k < n2 ? c[k - n1] : e[k - n2]));
-    PriorRecs r;
-    r.se3 = (const isv_se3_prior_t *)o; r.lin9 = (const isv_linear9_t *)(o + n0);
-    r.relpose = (const isv_relpose_t *)(o + n1); r.rollpitch = (const isv_rollpitch_t *)(o + n2);
-    return r;
+    // two words per trip, the source chosen by address (one load instruction each, no branch), both loads before the stores
+    for (int k0 = t; k0 < n3; k0 += 2 * nthr) {
+        uint64_t v[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int k = (k0 + u * nthr) < n3 ? k0 + u * nthr : n3 - 1;
+            const uint64_t *src = k < n0 ? a + k : (k < n1 ? b + (k - n0) : (k < n2 ? c + (k - n1) : e + (k - n2)));
+            v[u] = *src;
+        }
+#pragma unroll
+        for (int u = 0; u < 2; u++) { const int k = k0 + u * nthr; if (k < n3) o[k] = v[u]; }
+    }
+    return prior_recs_at(d, dst);
 }
 struct PriorDesc { int kind, strip_off, H_off, valid; const double *S; };   // kind 0 SE3, 1 Linear9, 2 relpose, 3 rollpitch
 DEV PriorDesc prior_desc(const DevBatch &d, const PriorRecs &R, int s, int n_rp) {
@@ -138,28 +155,18 @@ DEV void prior_H(const double *wr, double *H, int t) {
     }
 }
 
-// WAVE: executed by ONE wavefront of a larger workgroup (lane ids, wave-level LDS ordering instead of barriers)
-template <bool JAC, bool WAVE>
-DEV void prior_linearize_body(const DevBatch &d, const double *pose_src, const double *sb_src, double *cost_out, int gate, int w, double *lds) {
-    const int t = WAVE ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
+// ---- phase 1: raw residual / raw Jacobian blocks, one lane per prior; `kinds`: bit k set = evaluate the priors of kind k
+//      (k_dogleg splits the kinds over two wavefronts: the kinds of a wavefront's lanes diverge, i.e. run one after another)
+template <bool JAC>
+DEV void prior_phase1(const DevBatch &d, const PriorRecs &R, const double *pose_src, const double *sb_src, int w, int n_rp,
+                      double *sRaw, int t, unsigned kinds) {
+    constexpr int RAWS = JAC ? PRL_RAW : 10;
     const int slots = d.n_prior_slots, N = d.N;
-    if (gate) {
-        const SolveState &ss = d.st[w];
-        if (!(ss.termination == ISV_TERM_RUNNING && (gate == 1 ? ss.need_linearize != 0 : ss.step_valid != 0))) return;
-    }
-    const int n_rp = d.n_rp[w];
-    // residual-only evaluation (JAC = false, the candidate point in k_dogleg): no Jacobian blocks, 10-double slots
-    constexpr int RAWS = JAC ? PRL_RAW : 10, WS = JAC ? PRL_W : 10;
-    double *sRaw = lds, *sW = lds + (size_t)slots * RAWS, *sRec = sW + (size_t)slots * WS;
-    double *strip = d.prior_strip + (size_t)w * d.prior_strip_sz;
-    double *PH = d.prior_H + (size_t)w * d.prior_H_sz;
     const double *poseW = pose_src + (size_t)w * N * 7;
-    const PriorRecs R = prior_stage_records(d, w, sRec, t, 64);
-    if (WAVE) ISV_WSYNC(); else __syncthreads();
-    // ---- phase 1: raw residual / raw Jacobian blocks, one lane per prior ----
     for (int s = t; s < slots; s += 64) {
         double *raw = sRaw + s * RAWS, *rawJ = raw + 9;
         const int kind = s == 0 ? 0 : (s == 1 ? 1 : (s < 1 + d.Nvo ? 2 : 3));
+        if (!((kinds >> kind) & 1u)) continue;
         Quat rr = Quat{1, 0, 0, 0};
         double Ri[9], Rj[9], qd[3], lg[3], Jr[9];
         const double *pi = poseW;
@@ -246,35 +253,60 @@ DEV void prior_linearize_body(const DevBatch &d, const double *pose_src, const d
             }
         }
     }
+}
+// residual-only evaluation (the candidate point), phases 2 and 3 for ALL priors of the window at once instead of slot after
+// slot -- lane per (prior, row) forms r = sqrt_info raw straight from the factor records, lane per prior the cost.  Same
+// operation order per entry as prior_weight / prior_correct, so the candidate cost is the same function of the state, bit for
+// bit, as the cost at x the step control compares it with.  One wavefront (t = lane).
+DEV void prior_residual_costs(const DevBatch &d, const PriorRecs &R, int w, int n_rp, const double *sRaw, double *sW, double *cost_out, int t) {
+    constexpr int RAWS = 10, WS = 10;
+    const int slots = d.n_prior_slots;
+    for (int e = t; e < slots * 9; e += 64) {
+        const int s = e / 9, row = e - 9 * s;
+        const PriorDesc p = prior_desc(d, R, s, n_rp);
+        const int dim = p.kind == 1 ? 9 : (p.kind == 3 ? 2 : 6);
+        if (!p.valid || row >= dim) continue;
+        const double *raw = sRaw + s * RAWS;
+        double v = 0;
+        for (int k = 0; k < dim; k++) v += p.S[row * dim + k] * raw[k];
+        sW[s * WS + row] = v;
+    }
+    ISV_WSYNC();
+    for (int s = t; s < slots; s += 64) {
+        const PriorDesc p = prior_desc(d, R, s, n_rp);
+        const int dim = p.kind == 1 ? 9 : (p.kind == 3 ? 2 : 6);
+        double cost = 0.0;
+        if (p.valid) {
+            const double *wr = sW + s * WS;
+            double ssum = 0;
+            for (int k = 0; k < dim; k++) ssum += wr[k] * wr[k];
+            cost = 0.5 * log(1.0 + ssum);
+        }
+        cost_out[(size_t)w * slots + s] = cost;
+    }
+}
+
+// WAVE: executed by ONE wavefront of a larger workgroup (lane ids, wave-level LDS ordering instead of barriers)
+template <bool JAC, bool WAVE>
+DEV void prior_linearize_body(const DevBatch &d, const double *pose_src, const double *sb_src, double *cost_out, int gate, int w, double *lds) {
+    const int t = WAVE ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
+    const int slots = d.n_prior_slots;
+    if (gate) {
+        const SolveState &ss = d.st[w];
+        if (!(ss.termination == ISV_TERM_RUNNING && (gate == 1 ? ss.need_linearize != 0 : ss.step_valid != 0))) return;
+    }
+    const int n_rp = d.n_rp[w];
+    // residual-only evaluation (JAC = false, the candidate point in k_dogleg): no Jacobian blocks, 10-double slots
+    constexpr int RAWS = JAC ? PRL_RAW : 10, WS = JAC ? PRL_W : 10;
+    double *sRaw = lds, *sW = lds + (size_t)slots * RAWS, *sRec = sW + (size_t)slots * WS;
+    double *strip = d.prior_strip + (size_t)w * d.prior_strip_sz;
+    double *PH = d.prior_H + (size_t)w * d.prior_H_sz;
+    const PriorRecs R = prior_stage_records(d, w, sRec, t, 64);
+    if (WAVE) ISV_WSYNC(); else __syncthreads();
+    prior_phase1<JAC>(d, R, pose_src, sb_src, w, n_rp, sRaw, t, 0xFu);
     if (WAVE) ISV_WSYNC(); else __syncthreads();
     if (!JAC) {
-        // residual-only evaluation (the candidate point): phases 2 and 3 for ALL priors of the window at once instead of slot
-        // after slot -- lane per (prior, row) forms r = sqrt_info raw straight from the factor records, lane per prior the cost.
-        // Same operation order per entry as prior_weight / prior_correct, so the candidate cost is the same function of the
-        // state, bit for bit, as the cost at x the step control compares it with.
-        for (int e = t; e < slots * 9; e += 64) {
-            const int s = e / 9, row = e - 9 * s;
-            const PriorDesc p = prior_desc(d, R, s, n_rp);
-            const int dim = p.kind == 1 ? 9 : (p.kind == 3 ? 2 : 6);
-            if (!p.valid || row >= dim) continue;
-            const double *raw = sRaw + s * RAWS;
-            double v = 0;
-            for (int k = 0; k < dim; k++) v += p.S[row * dim + k] * raw[k];
-            sW[s * WS + row] = v;
-        }
-        if (WAVE) ISV_WSYNC(); else __syncthreads();
-        for (int s = t; s < slots; s += 64) {
-            const PriorDesc p = prior_desc(d, R, s, n_rp);
-            const int dim = p.kind == 1 ? 9 : (p.kind == 3 ? 2 : 6);
-            double cost = 0.0;
-            if (p.valid) {
-                const double *wr = sW + s * WS;
-                double ssum = 0;
-                for (int k = 0; k < dim; k++) ssum += wr[k] * wr[k];
-                cost = 0.5 * log(1.0 + ssum);
-            }
-            cost_out[(size_t)w * slots + s] = cost;
-        }
+        prior_residual_costs(d, R, w, n_rp, sRaw, sW, cost_out, t);     // (64 threads either way: the wavefront-level ordering is the block's)
         return;
     }
     // ---- phase 2: sqrt_info * [raw r | raw J] ----

@@ -91,6 +91,24 @@ DEV void dogleg_body(DevBatch &d, const int w, const int t, double *red) {
 #ifdef ISV_STAMP
     unsigned long long t_last = wall_clock64(), t1_last = t_last;
 #endif
+    if (d.lds_T) {
+        // the window's prior factor records go to LDS NOW, by every thread: their global loads are in flight behind the
+        // back-substitution instead of opening the candidate evaluation's serial path (5 us of the slowest wavefront there);
+        // the region lies behind everything the phases before the candidate evaluation touch (zs / us: 2 n doubles)
+        extern __shared__ __align__(16) double dynp[];
+        double *const sPr = dynp + (size_t)(N - 1) * 48 + (size_t)d.n_prior_slots * 16;
+        prior_stage_records(d, w, sPr + (size_t)d.n_prior_slots * 20, t, 256);
+        // ... and their J^T J record at x (the priors' model pieces walked it entry by entry from global memory)
+        double *const sPHw = sPr + prior_lds_bytes(d.n_prior_slots, false) / sizeof(double) + 992 + n;
+        const double *PHg = d.prior_H + (size_t)w * d.prior_H_sz;
+        for (int i0 = t; i0 < (d.dg_stage_ph ? d.prior_H_sz : 0); i0 += 4 * 256) {          // (up to 1024 doubles: one trip, four loads in flight)
+            double v4[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int i = i0 + 256 * u; v4[u] = PHg[i < d.prior_H_sz ? i : d.prior_H_sz - 1]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int i = i0 + 256 * u; if (i < d.prior_H_sz) sPHw[i] = v4[u]; }
+        }
+    }
     double a = 0, b = 0, c = 0, e = 0;
     for (int i = t; i < n; i += 256) { a += gp[i] * gp[i]; b += gnp[i] * gnp[i]; c += gp[i] * gnp[i]; }
     if (st.fresh) {
@@ -221,6 +239,13 @@ DEV void dogleg_body(DevBatch &d, const int w, const int t, double *red) {
     t1_last = wall_clock64();
 #endif
     const int lane = t & 63, wv = t >> 6;
+    // the prior factors at the candidate: raw residuals (lane per prior; the kinds of a wavefront's lanes run one after
+    // another) split by kind over wavefronts 0 and 1, the sqrt_info rows and costs by wavefront 3 after the barrier
+    double *const sRaw = sPrior, *const sW = sPrior + (size_t)slots * 10;
+    const PriorRecs PR = prior_recs_at(d, sPrior + (size_t)slots * 20);       // staged at the top of this function
+    const int n_rp = d.n_rp[w];
+    double *const sHb = sPrior + prior_lds_bytes(slots, false) / sizeof(double);      // [2][496] J^T J records, then the weighted IMU residuals
+    const double *sDp = sHb + 992;                         // delta_p of this window (staged above)
     if (wv == 0) {
         if (lane < NIw) {
             const size_t f = (size_t)w * NIw + lane;
@@ -232,37 +257,12 @@ DEV void dogleg_body(DevBatch &d, const int w, const int t, double *red) {
                 for (int k = 0; k < 15; k++) sImu[lane * 16 + k] = r15[k];
             }
         }
+        prior_phase1<false>(d, PR, d.cpose, d.csb, w, n_rp, sRaw, lane, 0x8u);     // roll / pitch
     } else if (wv == 1) {
-        prior_linearize_body<false, true>(d, d.cpose, d.csb, d.prior_cost_c, 0, w, sPrior);
-    } else {
-        const int tt = t - 128;
-        // IMU factor q, tangent row a (30 per factor): H row dot delta, packed pairs (max, min).
-        // (round 3) Each of the two wavefronts STAGES its factor's 495-double J^T J record in LDS with coalesced loads and
-        // forms the 30 row products from there; a lane used to walk "its" row of the packed triangle straight from global
-        // memory -- 30 scattered loads per row, three rows per lane: 37 us, the slowest wavefront of the workgroup (the
-        // other three waited 31 us for it).  Same order of additions per row.
-        double *sH = sPrior + prior_lds_bytes(slots, false) / sizeof(double) + (size_t)(wv - 2) * 496;
-        const double *sDp = sPrior + prior_lds_bytes(slots, false) / sizeof(double) + 992;      // delta_p of this window (staged above)
-        for (int q = wv - 2; q < NIw; q += 2) {
-            const double *H = d.imu_H + ((size_t)w * NIw + q) * ISV_IMU_H;
-            double hv[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) { const int e = lane + 64 * k; hv[k] = H[e < ISV_IMU_H ? e : ISV_IMU_H - 1]; }
-            ISV_WSYNC();                                   // the previous factor's rows have been read
-#pragma unroll
-            for (int k = 0; k < 8; k++) { const int e = lane + 64 * k; if (e < ISV_IMU_H) sH[e] = hv[k]; }
-            ISV_WSYNC();
-            if (lane < 30) {
-                const int a = lane;
-                const double *dd = sDp + 15 * q;
-                double s = 0;
-#pragma unroll
-                for (int b = 0; b < 30; b++) s += sH[a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a] * dd[b];
-                sMod[q * 32 + a] = dd[a] * (sH[465 + a] + 0.5 * s);
-            }
-        }
-        const double *PH = d.prior_H + (size_t)w * d.prior_H_sz;
-        for (int e = tt; e < slots * 12; e += 128) {
+        prior_phase1<false>(d, PR, d.cpose, d.csb, w, n_rp, sRaw, lane, 0x6u);     // Linear9, relative poses
+        // model pieces of the prior factors from their J^T J blocks at x (staged at the top)
+        const double *PH = d.dg_stage_ph ? sDp + n : d.prior_H + (size_t)w * d.prior_H_sz;
+        for (int e = lane; e < slots * 12; e += 64) {
             const int q = e / 12, a = e - 12 * q;
             int ncol, off, c0, c1 = 0;
             bool valid = true;
@@ -271,7 +271,7 @@ DEV void dogleg_body(DevBatch &d, const int w, const int t, double *red) {
             else if (q < 1 + d.Nvo) { const int k = q - 2; ncol = 12; off = PH_REL0 + PH_REL_SZ * k; c0 = 15 * k; c1 = 15 * (k + 1); }
             else {
                 const int m = q - 1 - d.Nvo; ncol = 6; off = PH_REL0 + PH_REL_SZ * (d.Nvo - 1) + PH_RP_SZ * m;
-                valid = m < d.n_rp[w]; c0 = valid ? 15 * d.rollpitch[(size_t)w * d.max_rp + m].index : 0;
+                valid = m < n_rp; c0 = valid ? 15 * PR.rollpitch[m].index : 0;
             }
             double v = 0;
             if (valid && a < ncol) {
@@ -286,6 +286,37 @@ DEV void dogleg_body(DevBatch &d, const int w, const int t, double *red) {
             }
             sPm[q * 16 + a] = v;
         }
+    } else {
+        // IMU factor q, tangent row a (30 per factor): H row dot delta, packed pairs (max, min).
+        // (round 3) Each of the two wavefronts STAGES its factor's 495-double J^T J record in LDS with coalesced loads and
+        // forms the 30 row products from there; a lane used to walk "its" row of the packed triangle straight from global
+        // memory -- 30 scattered loads per row, three rows per lane: 37 us, the slowest wavefront of the workgroup (the
+        // other three waited 31 us for it).  Same order of additions per row.  The NEXT factor's record is requested as soon
+        // as this one's is in LDS: its memory latency runs behind the row products.
+        double *sH = sHb + (size_t)(wv - 2) * 496;
+        double hv[8];
+        auto fetch = [&](int q) {
+            const double *H = d.imu_H + ((size_t)w * NIw + (q < NIw ? q : NIw - 1)) * ISV_IMU_H;
+#pragma unroll
+            for (int k = 0; k < 8; k++) { const int e = lane + 64 * k; hv[k] = H[e < ISV_IMU_H ? e : ISV_IMU_H - 1]; }
+        };
+        if (wv - 2 < NIw) fetch(wv - 2);
+        if (wv == 3) prior_phase1<false>(d, PR, d.cpose, d.csb, w, n_rp, sRaw, lane, 0x1u);      // SE3 prior (behind the first record's latency)
+        for (int q = wv - 2; q < NIw; q += 2) {
+            ISV_WSYNC();                                   // the previous factor's rows have been read
+#pragma unroll
+            for (int k = 0; k < 8; k++) { const int e = lane + 64 * k; if (e < ISV_IMU_H) sH[e] = hv[k]; }
+            ISV_WSYNC();
+            if (q + 2 < NIw) fetch(q + 2);
+            if (lane < 30) {
+                const int a = lane;
+                const double *dd = sDp + 15 * q;
+                double s = 0;
+#pragma unroll
+                for (int b = 0; b < 30; b++) s += sH[a >= b ? a * (a + 1) / 2 + b : b * (b + 1) / 2 + a] * dd[b];
+                sMod[q * 32 + a] = dd[a] * (sH[465 + a] + 0.5 * s);
+            }
+        }
     }
     DSTAMP(51);
     DSTAMP(56);
@@ -294,8 +325,10 @@ DEV void dogleg_body(DevBatch &d, const int w, const int t, double *red) {
 #endif
     __syncthreads();
     DSTAMP(52);
-    // sqrt_info-weighted IMU residuals -> cost; fixed-order sums of the model pieces
-    double *sR2 = sPrior;                          // (the prior scratch is free again)
+    // sqrt_info-weighted IMU residuals -> cost; fixed-order sums of the model pieces; wavefront 3 (idle in the IMU loop for
+    // every window length: 15 (N - 1) <= 192 only fails beyond N = 13, where it simply comes later): the priors' rows and costs
+    double *sR2 = sHb;                             // (the J^T J staging is free again)
+    if (wv == 3) prior_residual_costs(d, PR, w, n_rp, sRaw, sW, d.prior_cost_c, lane);
     for (int tq = t; tq < NIw * 15; tq += 256) {
         const int q = tq / 15, row = tq - 15 * q;
         const size_t f = (size_t)w * NIw + q;
@@ -651,7 +684,8 @@ static std::mutex g_lds_attr_mutex;
 // dynamic LDS of k_dogleg (candidate-point IMU / prior evaluation on the LDS path + the two tangent vectors) and of the step control
 static size_t dogleg_lds_bytes(const DevBatch &d) {
     // + two 496-double staging rows for the IMU J^T J records of the model pieces and the tangent step (np)
-    return (d.lds_T ? ((size_t)(d.N - 1) * 48 + (size_t)d.n_prior_slots * 16 + 992 + (size_t)d.np) * sizeof(double) + prior_lds_bytes(d.n_prior_slots, false) : 0) + 2 * (size_t)d.np * sizeof(double);
+    // + the window's prior J^T J record (prior_H_sz) for the priors' model pieces
+    return (d.lds_T ? ((size_t)(d.N - 1) * 48 + (size_t)d.n_prior_slots * 16 + 992 + (size_t)d.np + (d.dg_stage_ph ? (size_t)d.prior_H_sz : 0)) * sizeof(double) + prior_lds_bytes(d.n_prior_slots, false) : 0) + 2 * (size_t)d.np * sizeof(double);
 }
 // the step control: candidate / current poses, the tangent step, and (when they fit) the per-landmark data its factor loop gathers
 // -- host point, candidate and current inverse depth, the landmark's step: 6 doubles each (d.ctl_stage_lm, set per enqueue)
@@ -755,6 +789,9 @@ int isv_solver_enqueue(DevBatch &d, const SolverHost &hc, hipStream_t st, hipStr
     if (hc.one_stream) st2 = st;            // diagnostics: serialise everything on one stream (per-kernel timelines)
     const size_t lds_bs = build_solve_lds_bytes(d.N, false);
     d.ctl_stage_lm = (6 * (size_t)d.lg_lcap * sizeof(double) <= ISV_CTL_STAGE_MAX_BYTES) ? 1 : 0;
+    // the priors' J^T J record is staged in k_dogleg's LDS while that keeps the batch in one resident round (else: read from global)
+    d.dg_stage_ph = 1;
+    if (ISV_LDS_PER_CU / ((dogleg_lds_bytes(d) > step_control_lds_bytes(d) ? dogleg_lds_bytes(d) : step_control_lds_bytes(d)) + 2304) * (size_t)hc.n_cus < (size_t)d.B) d.dg_stage_ph = 0;
     const size_t lds_dg = dogleg_lds_bytes(d), lds_sc = step_control_lds_bytes(d);
     const size_t lds_dgc = lds_dg > lds_sc ? lds_dg : lds_sc;
     // workgroups of k_dogleg<true> a CU holds: registers (hc) and LDS (dynamic + the 2 KB of static reduction space)
