@@ -588,7 +588,7 @@ def main():
                 "value": W / t_incl, "unit": "windows/s", "ms_per_batch": 1e3 * t_incl,
                 "pipelined_two_handles": {"value": W / t_pipe, "unit": "windows/s", "ms_per_batch": 1e3 * t_pipe},
                 "ms_upload": 1e3 * t_up, "ms_optimize": 1e3 * t_opt, "ms_download": 1e3 * (t_incl - t_up - t_opt),
-                "what": "one isv_batch_upload (host packing + H2D) + isv_batch_optimize + isv_batch_download (D2H) of the same batch, pageable host buffers; packing on min(8, cores) host threads.  This is the STATELESS hand-over (every call carries whole windows); consecutive frames of the same sequences keep their windows on the device instead: device_resident_replay",
+                "what": "one isv_batch_upload (host packing + H2D) + isv_batch_optimize + isv_batch_download (D2H) of the same batch, pageable host buffers; packing on min(16, allowed CPUs) host threads.  This is the STATELESS hand-over (every call carries whole windows); consecutive frames of the same sequences keep their windows on the device instead: device_resident_replay",
                 "resident_path_frames_per_s_2048_sequences": (extra.get("device_resident_replay") or {}).get("resident_2048_seq_4_groups_frames_per_s")},
             "kernel_ms": {"profiled_step_total_events": float(fam[0]), "lin_gram_or_proj_linearize_sum": lin_ms, "sweep_mfma_sum": sw_ms, "rank1_mfma_sum": r1_ms, "build_solve_sum": bs_ms,
                           "dogleg_sum": dg_ms, "step_control_sum": sc_ms, "window_iterations": win_iters},

