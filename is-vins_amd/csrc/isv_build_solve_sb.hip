@@ -131,7 +131,7 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
     // (I | J << 8) of packed pose block q: one LDS lookup instead of a search loop per matrix entry
     unsigned short *blkIJ = (unsigned short *)p; p += (N * (N + 1) / 2 + 3) / 4 + 1;
     unsigned char *triAB = (unsigned char *)p; p += 20;   // (row, col) of triangular pair index e < 78 (12 x 12 lower): triAB[2e], triAB[2e+1]
-    unsigned char *yNode = (unsigned char *)p; p += 16;   // chain node of fill block b (ytot / 54 <= 96 blocks for N <= 11; BIG windows search)
+    unsigned char *yNode = (unsigned char *)p; p += 24;   // chain node of fill block b (ytot / 54 <= 139 blocks for N <= 20)
     double *Spp = p; p += nS;                // pose-pose, packed lower block triangle of 6x6 blocks (Tvis layout)
     double *Dss = p; p += N * 81;            // speed/bias diagonal blocks -> inverse Cholesky factors
     double *Css = p; p += N * 81;            // coupling of node i to its parent: rows parent, cols i
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
     }
     if (t < 78) { int a = 0; while ((a + 1) * (a + 2) / 2 <= t) a++; triAB[2 * t] = (unsigned char)a; triAB[2 * t + 1] = (unsigned char)(t - a * (a + 1) / 2); }
     __syncthreads();
-    if (!BIG) for (int b = t; b < yo[N] / 54; b += LS) { int i = 0; while (yo[i + 1] <= 54 * b) i++; yNode[b] = (unsigned char)i; }
+    for (int b = t; b < yo[N] / 54; b += LS) { int i = 0; while (yo[i + 1] <= 54 * b) i++; yNode[b] = (unsigned char)i; }
     __syncthreads();
     const int ytot = yo[N];
     // cost of the window at x = sum over its residual blocks (fixed-shape strided partials + tree below)
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
             }
             for (int e = t; e < ytot; e += LS) {
                 int i = 0;
-                if (BIG) { while (yo[i + 1] <= e) i++; } else i = yNode[e / 54];
+                i = yNode[e / 54];          // (long windows searched yo[] per ENTRY here: ~9 dependent LDS reads each)
                 const int q = e - yo[i], ai = q / 54, rc = q - 54 * ai, r = rc / 9, c = rc - 9 * r;
                 const int gi = 15 * (nlo(i, M) + ai) + r, gj = 15 * i + 6 + c;
                 const double v = Ysb[e];
@@ -826,7 +826,9 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
         // chains, reverse elimination order: x_i = L_i^-T (z_i - C_i^T x_parent); wavefront 0 takes M and the
         // forward chain (lane = 9 i + c), wavefront 1 the backward chain (lane = 9 (i - M - 1) + c)
         if (BIG) {
-            // long windows: one node at a time on lanes 0..8, the parent's x through LDS
+            // long windows: one node at a time on lanes 0..8, the parent's x through LDS (measured against two chain positions per
+            // lane in registers with the parent by v_readlane, the short-window form: 21.4 us of solves at N = 18 against 17.8 -- the
+            // run-time chain positions cost more integer work than the two wave syncs per node)
             auto node_bwd_lds = [&](int i, int pp) {
                 const int cl = lane < 9 ? lane : 0;
                 double sv = y[15 * i + 6 + cl];
@@ -981,5 +983,5 @@ size_t build_solve_sb_bytes(int N, int prior_H_sz) {
     const size_t stage = (size_t)RCH * (6 * (size_t)N + 1);     // retry staging lives in the Dss/Css/Ysb region
     if (tail < stage) tail = stage;
     const size_t nred = (size_t)sb_nred(N, prior_H_sz);
-    return (3 * n + nred + 16 + 16 + 2 + ((size_t)N * (N + 1) / 2 + 3) / 4 + 1 + 20 + 16 + nS + tail + 2) * sizeof(double);
+    return (3 * n + nred + 16 + 16 + 2 + ((size_t)N * (N + 1) / 2 + 3) / 4 + 1 + 20 + 24 + nS + tail + 2) * sizeof(double);
 }
