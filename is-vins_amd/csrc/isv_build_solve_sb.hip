@@ -624,6 +624,45 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
         if (!flag[0]) {
             // ---- pose system: Spp -= sum_i Y_i Y_i^T ---------------------------------------------------
             { PHASE_IDS();
+            if constexpr (BIG) {
+            // (round 3) a thread owns a 3 x 6 half of a 6x6 pose block: per k it reads three values of Y_I and six of Y_J for
+            // eighteen products (9 LDS reads per 18 FMAs; one entry per thread needed 2 per FMA, the 2 x 3 sub-blocks of the
+            // first rewrite 5 per 6).  The phase is LDS-bandwidth bound (every entry re-reads both nine-vectors from every
+            // covering node): 30.6 -> 15.4 us with 2 x 3 at N = 18 and 10.7 us with 3 x 6.  Long windows only: under the 128-VGPR
+            // cap of the two-per-CU instantiation the eighteen accumulators spill (7.6 against 7.1 us at N = 11, 81 against 79 us
+            // for the kernel).  Entry for entry the same sums in the same order (nodes ascending, k ascending).
+            for (int item = t; item < N * (N + 1); item += LS) {
+                const int q = item >> 1, r0 = 3 * (item & 1);
+                const int ij = blkIJ[q], I = ij & 255, J = ij >> 8;
+                double acc[3][6];
+#pragma unroll
+                for (int r = 0; r < 3; r++)
+#pragma unroll
+                    for (int c = 0; c < 6; c++) acc[r][c] = 0;
+                for (int i = 0; i < N; i++) {
+                    const int lo = nlo(i, M), hi = nhi(i, M, N);
+                    if (J >= lo && I <= hi) {
+                        const double *YI = Ysb + yo[i] + (I - lo) * 54 + r0 * 9, *YJ = Ysb + yo[i] + (J - lo) * 54;
+#pragma unroll
+                        for (int k = 0; k < 9; k++) {
+                            const double a0 = YI[k], a1 = YI[9 + k], a2 = YI[18 + k];
+                            double bb[6];
+#pragma unroll
+                            for (int c = 0; c < 6; c++) bb[c] = YJ[9 * c + k];
+#pragma unroll
+                            for (int c = 0; c < 6; c++) { acc[0][c] += a0 * bb[c]; acc[1][c] += a1 * bb[c]; acc[2][c] += a2 * bb[c]; }
+                        }
+                    }
+                }
+                double *B = Spp + q * 36 + r0 * 6;
+                const bool dg = I == J;
+#pragma unroll
+                for (int r = 0; r < 3; r++)
+#pragma unroll
+                    for (int c = 0; c < 6; c++)
+                        if (!dg || r0 + r >= c) B[r * 6 + c] -= acc[r][c];      // (a diagonal block keeps its lower triangle)
+            }
+            } else {
             // (round 3) a thread owns a 2 x 3 sub-block of a 6x6 pose block instead of one entry: per k it reads two values of
             // Y_I and three of Y_J for six products (5 LDS reads per 6 FMAs instead of 12).  The phase was LDS-bandwidth
             // bound (every entry re-read both nine-vectors from every covering node): 30.6 us at N = 18, 9.2 us at N = 11.
@@ -653,6 +692,7 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
                 if (!dg || r0 + 1 >= c0) B[6] -= s10;
                 if (!dg || r0 + 1 >= c0 + 1) B[7] -= s11;
                 if (!dg || r0 + 1 >= c0 + 2) B[8] -= s12;
+            }
             }
             if (t >= LS - n6) {                                 // pose right-hand side -= sum_i Y_i z_i
                 const int rho = t - (LS - n6), a = rho / 6, r = rho - 6 * a;
