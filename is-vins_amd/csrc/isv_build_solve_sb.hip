@@ -767,6 +767,36 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
                     WSYNC();
                     if (chol_inv_block<6>(Spp + e0, lane)) { if (lane == 0) flag[0] = 1; }
                 } else {
+                    if constexpr (BIG) {
+                    // long windows: 3 x 6 halves (9 LDS reads per 18 products), as in their Y Y^T phase: the first steps of an
+                    // 18-frame window have 900 2 x 3 sub-blocks for 448 threads, i.e. three passes; 300 halves are one
+                    const int nit = (m * (m + 1) / 2 - 1) * 2;
+                    for (int it = t - 64; it < nit + m * 6; it += LS - 64) {
+                        if (it >= nit) { trailing_entry(cntT + (it - nit)); continue; }      // rhs rows
+                        const int q = 1 + (it >> 1), r0 = 3 * (it & 1);
+                        const int ij = blkIJ[e0 / 36 + q];
+                        const int ia = (ij & 255) - (J + 1), ca = (ij >> 8) - (J + 1);
+                        const bool dg = ia == ca;
+                        const double *XI = X + ia * 36 + r0 * 6, *XK = X + ca * 36;
+                        double acc[3][6];
+#pragma unroll
+                        for (int r = 0; r < 3; r++)
+#pragma unroll
+                            for (int c = 0; c < 6; c++) acc[r][c] = 0;
+#pragma unroll
+                        for (int k = 0; k < 6; k++) {
+                            const double a0 = XI[k], a1 = XI[6 + k], a2 = XI[12 + k];
+#pragma unroll
+                            for (int c = 0; c < 6; c++) { const double bk = XK[6 * c + k]; acc[0][c] += a0 * bk; acc[1][c] += a1 * bk; acc[2][c] += a2 * bk; }
+                        }
+                        double *Bq = Spp + e0 + q * 36 + r0 * 6;
+#pragma unroll
+                        for (int r = 0; r < 3; r++)
+#pragma unroll
+                            for (int c = 0; c < 6; c++)
+                                if (!dg || r0 + r >= c) Bq[r * 6 + c] -= acc[r][c];
+                    }
+                    } else {
                     // (round 3) 2 x 3 sub-blocks per thread, as in the Y Y^T phase: 5 LDS reads per 6 products instead of 12
                     const int nit = (m * (m + 1) / 2 - 1) * 6;         // sub-blocks of the trailing blocks after the first one
                     for (int it = t - 64; it < nit + m * 6; it += LS - 64) {
@@ -791,6 +821,7 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
                         if (!dg || r0 + 1 >= c0) Bq[6] -= s10;
                         if (!dg || r0 + 1 >= c0 + 1) Bq[7] -= s11;
                         if (!dg || r0 + 1 >= c0 + 2) Bq[8] -= s12;
+                    }
                     }
                 }
                 __syncthreads();
