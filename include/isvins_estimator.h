@@ -30,7 +30,11 @@ extern "C" {
 #endif
 
 typedef struct isv_estimator_params {
-    isv_config_t cfg;            /* window shape, capacities, solver constants; cfg.max_batch is set to n_sequences */
+    isv_config_t cfg;            /* window shape, capacities, solver constants; cfg.max_batch is set to n_sequences.
+                                  * cfg.estimate_extrinsic = 1 (ESTIMATE_EXTRINSIC, src/estimator.cpp:1033): the extrinsic is a free
+                                  * block of every solve and tic[0] / ric[0] carry over from frame to frame (double2vector :575-583,
+                                  * slideWindowOld :1714-1719); = 0: the configured ric / tic below, every frame.  (2, the online
+                                  * initial calibration of src/initial/, is outside this path.)                                  */
     double ric[9];               /* RIC[0], row-major  (config yaml extrinsicRotation)                            */
     double tic[3];               /* TIC[0]                                                                       */
     double acc_n, gyr_n;         /* ACC_N, GYR_N  (yaml acc_n / gyr_n)  -> IntegrationBase::noise                */

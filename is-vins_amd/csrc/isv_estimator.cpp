@@ -260,6 +260,8 @@ struct Sequence {
     isv_window_t w{};
     std::vector<double> wPs, wRs, wVs, wBas, wBgs, wobs, wdepth, wpose, wsb, wex, wfeat;
     double wtic[3], wric[9];
+    double cur_tic[3] = {0, 0, 0}, cur_ric[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};   // tic[0] / ric[0] as the last solve left them (cfg.estimate_extrinsic = 1 only)
+    bool have_ex = false;
     std::vector<int32_t> wstart, wptr, wflag;
     std::vector<isv_imu_t> wimu;
     std::vector<isv_relpose_t> wrel;
@@ -359,7 +361,11 @@ int build_window(const isv_estimator *e, Sequence &s, std::string &err) {
         std::memcpy(&s.wPs[i * 3], s.Ps[i].data(), 24); std::memcpy(&s.wRs[i * 9], s.Rs[i].data(), 72); std::memcpy(&s.wVs[i * 3], s.Vs[i].data(), 24);
         std::memcpy(&s.wBas[i * 3], s.Bas[i].data(), 24); std::memcpy(&s.wBgs[i * 3], s.Bgs[i].data(), 24);
     }
-    std::memcpy(s.wtic, e->p.tic, 24); std::memcpy(s.wric, e->p.ric, 72);
+    // estimate_extrinsic = 0: the configured extrinsic, every frame (a constant parameter block; the reference's double2vector
+    // round-trips it through a quaternion each frame, a rounding-level drift this port does not reproduce).  = 1: what the
+    // previous solve left in tic[0] / ric[0] (double2vector, src/estimator.cpp:575-583), the configured one before the first solve.
+    if (e->p.cfg.estimate_extrinsic && s.have_ex) { std::memcpy(s.wtic, s.cur_tic, 24); std::memcpy(s.wric, s.cur_ric, 72); }
+    else { std::memcpy(s.wtic, e->p.tic, 24); std::memcpy(s.wric, e->p.ric, 72); }
     s.wstart.resize(std::max<size_t>(L, 1)); s.wptr.resize(L + 1); s.wflag.assign(std::max<size_t>(L, 1), 0);
     s.wobs.resize(std::max<size_t>(n_obs, 1) * 3); s.wdepth.resize(std::max<size_t>(L, 1)); s.wfeat.resize(std::max<size_t>(L, 1));
     s.wptr[0] = 0;
@@ -406,6 +412,7 @@ void read_back(Sequence &s) {
     s.pose_prior = s.wpp; s.vb_prior = s.wvb;
     s.relpose = s.wrel;
     for (size_t i = 0; i < s.rollpitch.size(); i++) s.rollpitch[i] = s.wrp[i];
+    std::memcpy(s.cur_tic, s.wtic, 24); std::memcpy(s.cur_ric, s.wric, 72); s.have_ex = true;      // (double2vector: tic[0], ric[0])
 }
 
 void new_preintegration(const isv_estimator *e, Sequence &s, int j) {
@@ -442,8 +449,11 @@ void slide_window(const isv_estimator *e, Sequence &s) {
             s.have_to_add = false;
         }
         if (shift_depth) {                             // slideWindowOld -> removeBackShiftDepth  feature_manager.cpp:275-313
-            const M3 ric = {e->p.ric[0], e->p.ric[1], e->p.ric[2], e->p.ric[3], e->p.ric[4], e->p.ric[5], e->p.ric[6], e->p.ric[7], e->p.ric[8]};
-            const V3 tic = {e->p.tic[0], e->p.tic[1], e->p.tic[2]};
+            // ric[0] / tic[0] of slideWindowOld (src/estimator.cpp:1714-1719): the configured extrinsic, or the estimated one
+            const bool est = e->p.cfg.estimate_extrinsic && s.have_ex;
+            const double *rr = est ? s.cur_ric : e->p.ric, *tt = est ? s.cur_tic : e->p.tic;
+            const M3 ric = {rr[0], rr[1], rr[2], rr[3], rr[4], rr[5], rr[6], rr[7], rr[8]};
+            const V3 tic = {tt[0], tt[1], tt[2]};
             const M3 R0 = mm(back_R0, ric), R1 = mm(s.Rs[0], ric);
             const V3 P0 = add(back_P0, mv(back_R0, tic)), P1 = add(s.Ps[0], mv(s.Rs[0], tic));
             s.compact([&](Track &t) {

@@ -228,6 +228,10 @@ class Estimator:
             C.memmove(C.byref(self.relpose[i]), C.byref(w.relpose[i]), C.sizeof(abi.isv_relpose_t))
         for i in range(len(self.rollpitch)):
             C.memmove(C.byref(self.rollpitch[i]), C.byref(w.rollpitch[i]), C.sizeof(abi.isv_rollpitch_t))
+        if getattr(self.solver, "cfg", None) is not None and self.solver.cfg.estimate_extrinsic:
+            # double2vector: tic[0] / ric[0] from para_Ex_Pose (src/estimator.cpp:575-583) -- the next window and slideWindowOld use them
+            self.tic = np.asarray(w.tic, dtype=np.float64).reshape(3).copy()
+            self.ric = np.asarray(w.ric, dtype=np.float64).reshape(3, 3).copy()
 
     # ---- solveOdometry  src/estimator.cpp:461-472 + backendOptimization :1541-1562 ------------------
     @staticmethod

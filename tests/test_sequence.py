@@ -4,7 +4,7 @@ initFactorGraph / backendOptimization.  north_star: ATE within 1e-6 m between th
 import numpy as np
 import pytest
 
-from isvins_amd import abi, backend
+from isvins_amd import abi, backend, synth
 
 import sequence_harness as sh
 
@@ -107,14 +107,35 @@ def test_native_window_manager_matches_the_restatement(oracle, monkeypatch, fuse
     est.close()
 
 
+def test_native_window_manager_carries_the_estimated_extrinsic(oracle):
+    """cfg.estimate_extrinsic = 1: every solve moves para_Ex_Pose, double2vector writes it to tic[0] / ric[0]
+    (src/estimator.cpp:575-583), and the NEXT frame's triangulation, window and slideWindowOld (:1714-1719) use those.  The
+    native window manager against the restatement, both on the CPU oracle; and the extrinsic really moved (the same stream
+    with estimate_extrinsic = 0 ends elsewhere)."""
+    from isvins_amd import estimator as E
+    N, Nvo, n_frames, seed = 11, 5, 19, 2
+    cfg1 = abi.make_config(N, Nvo, max_landmarks=600, max_obs=6600, max_batch=1, estimate_extrinsic=1)
+    est = E.SequenceEstimator(sh.estimator_params(cfg1), 1, solver=sh.oracle_vtbl(oracle, cfg1))
+    sh.run_sequences_native(est, N, n_frames, (seed,))
+    eo, _ = sh.run_sequence(sh.OracleSolver(oracle, cfg1), oracle, N, Nvo, n_frames, seed=seed)
+    _cmp_native_vs_harness(est, 0, eo, 1e-9)
+    assert np.abs(eo.tic - synth.TIC).max() > 1e-6 or np.abs(eo.ric - synth.RIC).max() > 1e-6
+    cfg0 = abi.make_config(N, Nvo, max_landmarks=600, max_obs=6600, max_batch=1)
+    e0, _ = sh.run_sequence(sh.OracleSolver(oracle, cfg0), oracle, N, Nvo, n_frames, seed=seed)
+    assert np.array_equal(e0.tic, synth.TIC) and np.abs(e0.Ps - eo.Ps).max() > 1e-9
+    est.close()
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("N,Nvo,n_frames,n_seq", [(11, 5, 31, 4), (18, 8, 30, 2)])
-def test_native_sequences_on_gpu_vs_oracle(oracle, N, Nvo, n_frames, n_seq):
+@pytest.mark.parametrize("N,Nvo,n_frames,n_seq,est_ex", [(11, 5, 31, 4, 0), (18, 8, 30, 2, 0), (11, 5, 27, 2, 1)])
+def test_native_sequences_on_gpu_vs_oracle(oracle, N, Nvo, n_frames, n_seq, est_ex):
     """S sequences in lock step through the native window manager with every solve on the MI355X (one batched
-    triangulate + backendOptimization per frame) against the Python restatement with the CPU oracle: ATE <= 1e-6 m"""
+    triangulate + backendOptimization per frame) against the Python restatement with the CPU oracle: ATE <= 1e-6 m.
+    est_ex = 1: the extrinsic is a free block of every solve (k_lin_gram<true>, k_dogleg<.., true>) and is carried from
+    frame to frame by the window manager."""
     from isvins_amd import estimator as E
     seeds = tuple(range(n_seq))
-    cfg = abi.make_config(N, Nvo, max_landmarks=800, max_obs=800 * N, max_batch=n_seq)
+    cfg = abi.make_config(N, Nvo, max_landmarks=800, max_obs=800 * N, max_batch=n_seq, estimate_extrinsic=est_ex)
     est = E.SequenceEstimator(sh.estimator_params(cfg), n_seq)
     sh.run_sequences_native(est, N, n_frames, seeds)
     for s, sd in enumerate(seeds):
