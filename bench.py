@@ -368,17 +368,31 @@ def main():
         wi5 = max(int(cnt5[3]), 1); nl5 = max(int(cnt5[2]), 1)
         kl = np.diff(w5.lm_obs_ptr[: w5.L + 1]).astype(float)                       # track lengths k_l
         r1_dense = 2.0 * (6 * 20) ** 2 * w5.L; r1_sparse = float(np.sum(2.0 * (6.0 * kl) ** 2))
-        r1_us = 1e3 * float(fam5[3]) / nl5
+        # Only `window_iterations` of the launches of the elimination / solve kernels do work (a rejected step re-runs the dogleg
+        # alone and the gated launches return at once, ~4 us each): per ACTIVE launch = family time / window_iterations (the
+        # no-op launches' few us stay in the numerator: the figure errs on the slow side).  VERDICT r3 weak 4: the r03 line divided
+        # by all launches and overstated frac 2x.
+        split5 = int(cnt5[7])
+        act = lambda fam_ms: 1e3 * float(fam_ms) / wi5
+        if split5 > 0:
+            dom5, r1_us = "k_schur_split<8,3>", act(fam5[2])
+            kern5 = {"k_proj_linearize<0>": act(fam5[1]), "k_schur_split<8,3> (direct part + rank-1 downdates, one launch)": act(fam5[2]), "k_schur_fold": act(fam5[3])}
+        else:
+            dom5, r1_us = "k_rank1_mfma<8,3>", act(fam5[3])
+            kern5 = {"k_proj_linearize<0>": act(fam5[1]), "k_sweep_mfma": act(fam5[2]), "k_rank1_mfma<8,3>": r1_us}
+        kern5.update({"k_build_solve_sb<true,0>": act(fam5[4]), "k_dogleg (all 10 launches, mean)": 1e3 * float(fam5[5]) / 10.0,
+                      "k_proj_linearize<1> + k_step_control (all 10 launches, mean)": 1e3 * float(fam5[6]) / 10.0})
         cfg5 = {"workload": f"one synthetic stress window: N=20 KF, Nvo=8, L={w5.L} landmarks, F={w5.n_factors} reprojection factors, full backendOptimization() (10 dogleg iterations + marginalisation)",
-                "ms_per_optimize": ms5, "value": 1e3 / ms5, "unit": "windows/s", "window_iterations": wi5, "fused_lin_gram": int(cnt5[4]) == 1,
-                "kernel_us_per_launch": {"k_proj_linearize<0>": 1e3 * float(fam5[1]) / max(int(cnt5[0]), 1), "k_sweep_mfma": 1e3 * float(fam5[2]) / nl5,
-                                         "k_rank1_mfma<8,3>": r1_us, "k_build_solve_sb<true,0>": 1e3 * float(fam5[4]) / max(int(cnt5[1]), 1),
-                                         "k_dogleg": 1e3 * float(fam5[5]) / 10.0, "k_proj_linearize<1> + k_step_control": 1e3 * float(fam5[6]) / 10.0},
-                "roofline": {"kernel": "k_rank1_mfma<8,3>", "bound": "mfma", "achieved": r1_dense / (r1_us * 1e-6) / 1e12 if r1_us > 0 else None,
+                "ms_per_optimize": ms5, "value": 1e3 / ms5, "unit": "windows/s", "window_iterations": wi5, "launches_per_family": nl5, "fused_lin_gram": int(cnt5[4]) == 1,
+                "schur_split_groups": split5,
+                "kernel_us_per_active_launch": kern5,
+                "roofline": {"kernel": dom5, "bound": "mfma", "achieved": r1_dense / (r1_us * 1e-6) / 1e12 if r1_us > 0 else None,
                              "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": (r1_dense / (r1_us * 1e-6) / 1e12 / FP64_PEAK_TFLOPS) if r1_us > 0 else None,
-                             "traffic": None, "avg_launch_us": r1_us,
+                             "traffic": None, "active_launch_us": r1_us,
                              "flops_dense_equivalent": r1_dense, "flops_sparse_exact": r1_sparse,
-                             "note": "the Schur panel contraction S -= sum_l c_l w_l w_l^T of ONE window, dense-equivalent 2 (6N)^2 L flops (SURVEY 8d); one workgroup of 12 wavefronts: a single window cannot fill 256 CUs, so this is a latency figure -- MfmaUtil of the same launch is in profiles/r03_config5_pmc_utilisation.csv"}}
+                             "note": "the Schur panel contraction S -= sum_l c_l w_l w_l^T of ONE window, dense-equivalent 2 (6N)^2 L flops (SURVEY 8d), per ACTIVE launch; "
+                                     + ("round 4: the window's landmarks are split over schur_split_groups workgroups (+ up to 16 for the direct part in the same launch) and folded in fixed order by k_schur_fold; MfmaUtil of the same launch: profiles/r04_config5_pmc_utilisation.csv"
+                                        if split5 > 0 else "one workgroup of 12 wavefronts on one CU")}}
         if cpu_lib is not None:
             cfg5c = backend.abi.make_config(20, 8, max_landmarks=2000, max_obs=w5.n_obs, max_batch=1)
             tcs = []

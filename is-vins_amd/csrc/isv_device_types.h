@@ -13,6 +13,8 @@
 #define ISV_TILE 64            // reprojection factors per wavefront tile
 #define ISV_MAX_FRAMES 32
 #define ISV_MARG_WS 1408             // doubles per window: Lp @0 (441), Jr @448 (441), V @896 (441), eigenvalues @1344 (21)
+#define ISV_SPLIT_MAX_GROUPS 32       // workgroups one window's rank-1 downdates are split over (k_schur_split)
+#define ISV_SPLIT_MIN_PASSES 8        // ... when it has at least this many 64-landmark passes (> 448 landmarks)
 #define ISV_FUSED_MAX_FACTORS 8192   // longest window (reprojection factors) the one-workgroup-per-window k_lin_gram takes
 #define ISV_IMU_IN 64          // packed IMU record (doubles)
 // offsets inside the packed IMU record
@@ -119,6 +121,7 @@ struct DevBatch {
     double2 *lm_cg;                     // [Ltot]  {c_l = s_l^2 / (s_l^2 E_l + mu D_l^2), g_l}
     int32_t sw_global;                  // this launch keeps the pair partials in sw_part (set per launch: only batches that need the occupancy)
     double *sw_part;                    // [B][NP * 84] pair partials of k_sweep_mfma when they do not share a CU's LDS four ways (long windows); else null
+    double *r1_part;                    // [split_cap_B][ISV_SPLIT_MAX_GROUPS][tiles * 256] raw accumulator tiles of the split rank-1 downdates (k_schur_split -> k_schur_fold); null: no split on this handle
     double *Tvis;                       // [B][tvis_sz] reprojection part of the reduced system (6x6 pose corners), hd, g, bs
     int32_t force_retry, init_mode;       // init_mode: this enqueue is Estimator::initFactorGraph (no update(), no marginalisation)            // test hook (env ISV_DEBUG_FORCE_RETRY): treat the first n factorisations of an iteration as failed
     int32_t prior_H_sz, tvis_sz, wd_ld, max_lm;   // wd_ld: panel width of k_rank1_mfma (6N + 1 rounded up to 16); max_lm: landmarks per window cap

@@ -28,6 +28,8 @@ struct SolverHost {
     bool debug_sw_global = false;     // ISV_DEBUG_SW_GLOBAL: pair partials in the global scratch for every launch
     bool legacy_visual = false;       // ISV_LEGACY_VISUAL: the unfused k_proj_linearize<0> + k_sweep_mfma pair
     bool no_persistent = false;       // ISV_NO_PERSISTENT: never the one-launch solve of small batches
+    bool sw_global_ok = false;        // the handle's windows are long enough (or ISV_DEBUG_SW_GLOBAL) for the pair partials in global memory
+    bool no_split = false;            // ISV_NO_SPLIT: never spread one window's landmark elimination over several workgroups (k_schur_split)
     bool marg_one_kernel = false;     // ISV_MARG_ONE_KERNEL / ISV_MARG_SPLIT force MargBackward as one launch (k_marg_bwd<2>) or as build / k_marg_jacobi /
     bool marg_split = false;          // project, whatever the batch size (default: split up to n_cus windows); the two are bitwise equal (tested)
     bool no_update = false;           // ISV_DEBUG_NO_UPDATE (sensitivity study, tests/test_sequence_long.py; the oracle has the same
@@ -47,6 +49,8 @@ __global__ void k_triangulate(DevBatch d);
 template <bool EX, int LGW> __global__ void k_lin_gram(DevBatch d);     // EX: the extrinsic is estimated (J_ex, one more block row)
 size_t lin_gram_lds_bytes(int N, bool partials_in_lds, bool ex, int waves, int lcap);
 #define ISV_LDS_PER_CU ((size_t)160 * 1024)
+template <int NT, int TPW> __global__ void k_schur_split(DevBatch d, int Gs, int GrMax);
+__global__ void k_schur_fold(DevBatch d, int GrMax, int NT, int from_partials);
 __global__ void k_imu_raw(DevBatch d, const double *pose_src, const double *sb_src, int gate);
 __global__ void k_imu_weight(DevBatch d, double *cost_out, int gate);
 #define ISV_PROF_FAMILIES 6      // 0 = k_proj_linearize<0>, 1 = k_sweep_mfma, 2 = k_rank1_mfma, 3 = k_build_solve*, 4 = k_dogleg, 5 = k_step_control

@@ -490,7 +490,16 @@ DEV void step_control_body(DevBatch &d, const int w, const int t, double *cl, do
                 m += rp * (m0 * (rx0 + m0 / 2.0) + m1 * (rx1 + m1 / 2.0));
             }
         } else {
-            for (int f = d.f_off[w] + t; f < d.f_off[w + 1]; f += 256) { s += d.fcost_c[f]; m += d.fmodel[f]; }
+            // (round 4: eight trips' loads in flight -- clamped addresses, masked adds in the same order: same bits; one load per
+            // trip made the 30 000-factor window of BASELINE config 5 wait a memory latency 117 times: 36 us per launch)
+            const int f_end = d.f_off[w + 1];
+            for (int f0 = d.f_off[w] + t; f0 < f_end; f0 += 8 * 256) {
+                double cs[8], ms[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { const int f = f0 + 256 * u < f_end ? f0 + 256 * u : f_end - 1; cs[u] = d.fcost_c[f]; ms[u] = d.fmodel[f]; }
+#pragma unroll
+                for (int u = 0; u < 8; u++) if (f0 + 256 * u < f_end) { s += cs[u]; m += ms[u]; }
+            }
         }
         for (int i = t; i < N - 1; i += 256) { s += d.imu_cost_c[(size_t)w * (N - 1) + i]; m += d.imu_model[(size_t)w * (N - 1) + i]; }
         for (int i = t; i < d.n_prior_slots; i += 256) { s += d.prior_cost_c[(size_t)w * d.n_prior_slots + i]; m += d.prior_model[(size_t)w * d.n_prior_slots + i]; }
@@ -735,10 +744,18 @@ int isv_solver_alloc(DevBatch &d, SolverHost &hc, size_t B, size_t L, size_t F, 
     hc.one_stream = getenv("ISV_ONE_STREAM") != nullptr; hc.split_control = getenv("ISV_SPLIT_CONTROL") != nullptr;
     hc.generic_n = getenv("ISV_GENERIC_N") != nullptr; hc.lg_batch_waves = getenv("ISV_LG_BATCH_WAVES") != nullptr;
     hc.debug_sw_global = getenv("ISV_DEBUG_SW_GLOBAL") != nullptr; hc.legacy_visual = getenv("ISV_LEGACY_VISUAL") != nullptr;
-    hc.no_persistent = getenv("ISV_NO_PERSISTENT") != nullptr;
+    hc.no_persistent = getenv("ISV_NO_PERSISTENT") != nullptr; hc.no_split = getenv("ISV_NO_SPLIT") != nullptr;
     hc.no_update = getenv("ISV_DEBUG_NO_UPDATE") != nullptr;
     hc.marg_one_kernel = getenv("ISV_MARG_ONE_KERNEL") != nullptr; hc.marg_split = getenv("ISV_MARG_SPLIT") != nullptr;
-    if (d.lds_T && (sw_global || hc.debug_sw_global)) TRYA(dal(&d.sw_part, B * n_pairs * 84, allocs, err));
+    int dev0_ = 0;
+    HCHK(hipGetDevice(&dev0_));
+    if (hipDeviceGetAttribute(&hc.n_cus, hipDeviceAttributeMultiprocessorCount, dev0_) != hipSuccess) { (void)hipGetLastError(); hc.n_cus = 0; }
+    // one long window over many CUs (k_schur_split): possible on this handle when a window can have ISV_SPLIT_MIN_PASSES passes
+    const bool can_split = d.lds_T && !d.est_ex && !hc.no_split && ((size_t)d.max_lm + 63) / 64 >= ISV_SPLIT_MIN_PASSES && hc.n_cus > ISV_SPLIT_MIN_PASSES;
+    if (d.lds_T && (sw_global || hc.debug_sw_global || can_split)) TRYA(dal(&d.sw_part, B * n_pairs * 84, allocs, err));
+    hc.sw_global_ok = sw_global || hc.debug_sw_global;
+    d.r1_part = nullptr;
+    if (can_split) { const size_t nt_ = d.wd_ld / 16; TRYA(dal(&d.r1_part, (size_t)hc.n_cus * (nt_ * (nt_ + 1) / 2) * 256, allocs, err)); }
     d.marg_scratch_sz = 26;
     TRYA(dal(&d.marg_scratch, L * 26, allocs, err));
     TRYA(dal(&d.marg_ws, B * ISV_MARG_WS, allocs, err));
@@ -751,6 +768,11 @@ int isv_solver_alloc(DevBatch &d, SolverHost &hc, size_t B, size_t L, size_t F, 
         SETLDS((k_rank1_mfma<4, 1, 64, 1, false>), lds_r1); SETLDS((k_rank1_mfma<4, 1, 64, 1, true>), lds_r1); SETLDS((k_rank1_mfma<5, 1, 64, 1, false>), lds_r1); SETLDS((k_rank1_mfma<5, 1, 64, 1, true>), lds_r1); SETLDS((k_rank1_mfma<6, 2, 64, 1, false>), lds_r1); SETLDS((k_rank1_mfma<6, 2, 64, 1, true>), lds_r1);
         SETLDS((k_rank1_mfma<7, 2, 64, 1, false>), lds_r1); SETLDS((k_rank1_mfma<7, 2, 64, 1, true>), lds_r1); SETLDS((k_rank1_mfma<8, 3, 64, 1, false>), lds_r1); SETLDS((k_rank1_mfma<8, 3, 64, 1, true>), lds_r1);
         SETLDS(k_sweep_mfma, lds_sw);
+        if (d.r1_part) {
+            const size_t lds_sp = lds_r1 > (2 * n_pairs + 2) * sizeof(int) ? lds_r1 : (2 * n_pairs + 2) * sizeof(int);
+            SETLDS((k_schur_split<1, 1>), lds_sp); SETLDS((k_schur_split<2, 1>), lds_sp); SETLDS((k_schur_split<3, 1>), lds_sp); SETLDS((k_schur_split<4, 1>), lds_sp);
+            SETLDS((k_schur_split<5, 1>), lds_sp); SETLDS((k_schur_split<6, 2>), lds_sp); SETLDS((k_schur_split<7, 2>), lds_sp); SETLDS((k_schur_split<8, 3>), lds_sp);
+        }
         {   // k_lin_gram: up to the whole CU (the launch sizes its LDS from the uploaded windows: isv_batch_upload)
             auto cap = [&](int waves) { const size_t b = lin_gram_lds_bytes(d.Nr, true, d.est_ex != 0, waves, d.max_lm); return b < ISV_LDS_PER_CU ? b : ISV_LDS_PER_CU; };
             if (d.est_ex) { SETLDS((k_lin_gram<true, LG_WAVES>), cap(LG_WAVES)); SETLDS((k_lin_gram<true, LG_WAVES_SMALL>), cap(LG_WAVES_SMALL)); }
@@ -767,8 +789,7 @@ int isv_solver_alloc(DevBatch &d, SolverHost &hc, size_t B, size_t L, size_t F, 
         const size_t want = build_solve_lds_bytes(d.N, false);
         if (want > cur_bs[dev_ & 63]) { HCHK(hipFuncSetAttribute((const void *)k_build_solve<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)want)); cur_bs[dev_ & 63] = want; }
     }
-    // device figures the per-launch variant choice needs (once per handle, not per isv_batch_optimize)
-    if (hipDeviceGetAttribute(&hc.n_cus, hipDeviceAttributeMultiprocessorCount, dev_) != hipSuccess) { (void)hipGetLastError(); hc.n_cus = 0; }
+    // device figures the per-launch variant choice needs (once per handle, not per isv_batch_optimize): hc.n_cus (above) and
     {
         // k_dogleg<true, EX> by registers alone (a small dynamic LDS request); the LDS bound is applied per enqueue
         int per_cu = 0;
@@ -815,7 +836,7 @@ int isv_solver_enqueue(DevBatch &d, const SolverHost &hc, hipStream_t st, hipStr
         hipLaunchKernelGGL(k_prior_linearize<true>, dim3(d.B), dim3(64), prior_lds_bytes(d.n_prior_slots), st2, d, d.pose, d.sb, d.prior_cost, 1);
         HCHK(hipEventRecord(fj[1], st2));
         const bool fused = d.lds_T && d.fused_visual;
-        d.sw_global = (d.sw_part && (d.B > 256 || hc.debug_sw_global)) ? 1 : 0;     // more than one workgroup per CU: trade LDS for occupancy
+        d.sw_global = (d.sw_part && hc.sw_global_ok && (d.B > 256 || hc.debug_sw_global)) ? 1 : 0;     // more than one workgroup per CU: trade LDS for occupancy
         PROF(slot, 0, 0);
         if (fused) {
             // linearisation fused with the Gram products: no Jacobian strip goes to HBM (isv_visual.hip)
@@ -831,7 +852,34 @@ int isv_solver_enqueue(DevBatch &d, const SolverHost &hc, hipStream_t st, hipStr
             counts[0]++; counts[4] = 1;
         } else if (d.n_tiles > 0) { hipLaunchKernelGGL(k_proj_linearize<0>, dim3((d.n_tiles + 3) / 4), dim3(256), lds_proj, st, d, d.pose, d.lam, d.fcost, 1); counts[0]++; }
         PROF(slot, 0, 1);
-        if (d.lds_T) {
+        // a SMALL batch with LONG windows: one window's elimination over many CUs (k_schur_split + k_schur_fold, isv_sweep.hip)
+        const int Pmax = (d.lg_lcap + 63) / 64, GrMax = Pmax < ISV_SPLIT_MAX_GROUPS ? Pmax : ISV_SPLIT_MAX_GROUPS;
+        const bool split = d.lds_T && d.r1_part && !hc.no_split && Pmax >= ISV_SPLIT_MIN_PASSES && (size_t)d.B * (GrMax + 1) <= (size_t)n_cus;
+        if (split) {
+            int Gs = 0;
+            if (!fused) { Gs = n_cus / d.B - GrMax; if (Gs > 16) Gs = 16; if (Gs < 1) Gs = 1; }
+            const int nt = d.wd_ld / 16;
+            const size_t n_pairs = (size_t)d.N * (d.N - 1) / 2;
+            size_t lds_sp = (64 * (d.wd_ld + 4) + (size_t)d.max_lm * 3 + 2) * sizeof(double);
+            if (lds_sp < (2 * n_pairs + 2) * sizeof(int)) lds_sp = (2 * n_pairs + 2) * sizeof(int);
+            const dim3 grid(d.B, Gs + GrMax);
+            PROF(slot, 1, 0);
+            switch (nt) {
+            case 1: hipLaunchKernelGGL((k_schur_split<1, 1>), grid, dim3(64 * 1), lds_sp, st, d, Gs, GrMax); break;
+            case 2: hipLaunchKernelGGL((k_schur_split<2, 1>), grid, dim3(64 * 3), lds_sp, st, d, Gs, GrMax); break;
+            case 3: hipLaunchKernelGGL((k_schur_split<3, 1>), grid, dim3(64 * 6), lds_sp, st, d, Gs, GrMax); break;
+            case 4: hipLaunchKernelGGL((k_schur_split<4, 1>), grid, dim3(64 * 10), lds_sp, st, d, Gs, GrMax); break;
+            case 5: hipLaunchKernelGGL((k_schur_split<5, 1>), grid, dim3(64 * 15), lds_sp, st, d, Gs, GrMax); break;
+            case 6: hipLaunchKernelGGL((k_schur_split<6, 2>), grid, dim3(64 * 11), lds_sp, st, d, Gs, GrMax); break;
+            case 7: hipLaunchKernelGGL((k_schur_split<7, 2>), grid, dim3(64 * 14), lds_sp, st, d, Gs, GrMax); break;
+            default: hipLaunchKernelGGL((k_schur_split<8, 3>), grid, dim3(64 * 12), lds_sp, st, d, Gs, GrMax); break;
+            }
+            PROF(slot, 1, 1);
+            PROF(slot, 2, 0);
+            hipLaunchKernelGGL(k_schur_fold, dim3(d.B, 8), dim3(256), 0, st, d, GrMax, nt, Gs > 0 ? 1 : 0);
+            PROF(slot, 2, 1);
+            counts[2]++; counts[7] = GrMax;
+        } else if (d.lds_T) {
             // landmark elimination: Gram products of the pose Jacobians, then the rank-1 downdates (both FP64 MFMA)
             PROF(slot, 1, 0);
             if (!fused) {

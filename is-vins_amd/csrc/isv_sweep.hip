@@ -141,9 +141,14 @@ typedef double double4v __attribute__((ext_vector_type(4)));
 // R1_CHUNK / MINW: pass size and minimum waves per SIMD.  Variants with fewer, fatter wavefronts and four workgroups per
 // CU (<5, 4, 32, 4>, <5, 2, 32, 8>: a 1024-window launch in one round) measured 138 / 143 us against 96-100 us for one
 // wavefront per tile: the per-workgroup MFMA chain gets longer than the round it saves.
-template <int NT, int TPW, int R1_CHUNK, int MINW, bool EX>
+// SPLIT (round 4): ONE window's landmarks over Gr workgroups (grid (B, Gs + Gr), this is group blockIdx.y - Gs): the group takes
+// the passes [g P / Gr, (g + 1) P / Gr) of the window's P = ceil(L / R1_CHUNK) passes, forms the landmark scalars of exactly
+// those landmarks, and leaves its raw accumulator tiles in d.r1_part for k_schur_fold (fixed order, no atomics).
+// groups of a window with P passes: a function of the window alone (its bits do not depend on the batch around it)
+__host__ __device__ inline int schur_split_groups(int P) { return P >= ISV_SPLIT_MIN_PASSES ? (P < ISV_SPLIT_MAX_GROUPS ? P : ISV_SPLIT_MAX_GROUPS) : 1; }
+template <int NT, int TPW, int R1_CHUNK, int MINW, bool EX, bool SPLIT = false>
 // (NT = 5, the benchmark's 11 frames: 15 wavefronts per workgroup, and two workgroups share a CU only at <= 64 VGPRs)
-__device__ __forceinline__ void rank1_body(DevBatch &d) {
+__device__ __forceinline__ void rank1_body(DevBatch &d, const int grp = 0, const int GrMax = 1) {
     constexpr int ntiles = NT * (NT + 1) / 2, nwaves = (ntiles + TPW - 1) / TPW;
     constexpr int ld = 16 * NT, nthr = 64 * nwaves;
     constexpr int R1_PF = (R1_CHUNK * ld + nthr - 1) / nthr;   // panel elements per thread and pass
@@ -152,7 +157,16 @@ __device__ __forceinline__ void rank1_body(DevBatch &d) {
     const SolveState &st = d.st[w];
     if (st.termination != ISV_TERM_RUNNING || !st.need_linearize) return;
     const int N = d.N, n6 = 6 * N;
-    const int l0 = d.lm_off[w], l1 = d.lm_off[w + 1], Lw = l1 - l0;
+    int l0 = d.lm_off[w], l1 = d.lm_off[w + 1];
+    if (SPLIT) {                           // this group's passes: everything below indexes relative to ITS first landmark
+        const int P = (l1 - l0 + R1_CHUNK - 1) / R1_CHUNK, Gr = schur_split_groups(P);
+        if (grp >= Gr) return;             // (uniform over the workgroup; a short window of the batch is one group: the unsplit sums)
+        const int pa = (int)((long long)grp * P / Gr), pb = (int)((long long)(grp + 1) * P / Gr);
+        const int e1 = l0 + R1_CHUNK * pb;
+        l0 += R1_CHUNK * pa; l1 = e1 < l1 ? e1 : l1;
+        if (l1 < l0) l1 = l0;
+    }
+    const int Lw = l1 - l0;
     constexpr int lds_ld = ld + 4;         // padded rows: the 4 k-rows of an operand hit distinct banks
     double *sW = lds;                      // [R1_CHUNK][ld + 4]
     double2 *sCG = (double2 *)(lds + R1_CHUNK * lds_ld);       // [max_lm] {c_l, g_l}
@@ -299,6 +313,16 @@ __device__ __forceinline__ void rank1_body(DevBatch &d) {
         }
         R1STAMP(14);
     }
+    if (SPLIT) {                           // raw accumulator tiles of this group: [w][group][tile][reg][lane], coalesced
+        double *part = d.r1_part + ((size_t)w * GrMax + grp) * (size_t)(ntiles * 256);
+#pragma unroll
+        for (int j = 0; j < TPW; j++) {
+            if (wv * TPW + j >= ntiles) continue;
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) part[(wv * TPW + j) * 256 + reg * 64 + lane] = acc[j][reg];
+        }
+        return;
+    }
     // C/D layout of v_mfma_f64_16x16x4: col = lane & 15, row = (lane >> 4) + 4 * reg
     // (the four read-modify-writes of a tile: all loads first -- clamped, always valid -- then the stores)
 #pragma unroll
@@ -346,3 +370,172 @@ template __global__ void k_rank1_mfma<7, 2, 64, 1, true>(DevBatch);
 template __global__ void k_rank1_mfma<8, 3, 64, 1, false>(DevBatch);
 template __global__ void k_rank1_mfma<8, 3, 64, 1, true>(DevBatch);
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// (round 4) ONE window over many compute units: the landmark elimination of a long window in a small batch (BASELINE
+// config 5: one window of 2000 landmarks / 30 000 factors) used ONE workgroup -- one CU of 256 -- for each of its two
+// kernels.  k_schur_split runs both parts side by side on Gs + Gr workgroups per window:
+//   groups [0, Gs)       the DIRECT part (k_sweep_mfma's Gram products): the window's (host, observer) pair groups dealt
+//                        longest-first over the Gs x nwaves wavefronts (rank by size in LDS, snake order); a pair group is
+//                        still summed by ONE wavefront in its stored factor order, so every pair partial has the bits the
+//                        one-workgroup kernel gives; partials -> d.sw_part, blocks (j, h) -> Tvis;
+//   groups [Gs, Gs + Gr) the rank-1 downdates (rank1_body<SPLIT>): Gr landmark ranges, raw accumulator tiles -> d.r1_part.
+// k_schur_fold then folds the pair partials into the diagonal blocks / Jacobi diagonal / gradient (k_sweep_mfma's own
+// order) and subtracts the Gr tile partials in group order: fixed order, no atomics, run-to-run reproducible.  Gr depends
+// on the window's landmark count only (isv_solver.hip: schur_split_groups), so a window has ONE split result whatever
+// the batch around it; it differs from the one-workgroup result in the last bits of the downdate (partial sums).
+DEV void sweep_split_body(DevBatch &d, const int grp, const int Gs, const int nwaves) {
+    extern __shared__ __align__(16) double lds[];
+    const int w = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const SolveState &st = d.st[w];
+    if (st.termination != ISV_TERM_RUNNING || !st.need_linearize) return;
+    const int N = d.N, NP = N * (N - 1) / 2, nthr = 64 * nwaves;
+    int *offL = (int *)lds;                    // [NP + 1] group starts
+    int *order = offL + NP + 1;                // [NP] pairs by descending size (ties: ascending pair index)
+    double *part = d.sw_part + (size_t)w * NP * 84;
+    double *Pjj = part, *Phh = Pjj + NP * 36, *Pgj = Phh + NP * 36, *Pgh = Pgj + NP * 6;
+    const int *perm = d.pg_perm + d.f_off[w];
+    const double *strip = d.strip + (size_t)d.f_off[w] * ISV_PROJ_STRIP;
+    double *out = d.Tvis + (size_t)w * d.tvis_sz;
+    for (int e = t; e <= NP; e += nthr) offL[e] = d.pg_off[(size_t)w * (NP + 1) + e];
+    __syncthreads();
+    for (int p = t; p < NP; p += nthr) {
+        const int c = offL[p + 1] - offL[p];
+        int r = 0;
+        for (int q = 0; q < NP; q++) { const int cq = offL[q + 1] - offL[q]; r += (cq > c || (cq == c && q < p)) ? 1 : 0; }
+        order[r] = p;
+    }
+    __syncthreads();
+    const int TW = Gs * nwaves, gw = grp * nwaves + wv;
+    const int i = lane & 15, kq = lane >> 4, row2 = kq & 1, fsel = kq >> 1;
+    const int eoff = i < 6 ? 2 + row2 * 6 + i : (i < 12 ? 14 + row2 * 6 + (i - 6) : row2);   // strip element of operand column i
+    const bool colok = i < 13;
+    for (int k = 0; k * TW < NP; k++) {
+        const int r = k * TW + ((k & 1) ? TW - 1 - gw : gw);
+        if (r >= NP) continue;                 // (wave-uniform)
+        const int p = order[r];
+        int h = 0;
+        while ((h + 1) * N - (h + 1) * (h + 2) / 2 <= p) h++;
+        const int j = h + 1 + (p - (h * N - h * (h + 1) / 2));
+        const int b0 = offL[p], b1 = offL[p + 1];
+        double4s acc = {0, 0, 0, 0};
+        // 16 factors per round: 8 loads in flight, then 8 MFMAs; the NEXT round's loads are issued before this round's MFMAs
+        int myf = lane < (b1 - b0) ? perm[b0 + lane] : 0;
+        double v[8], vn[8];
+        auto gather = [&](int cnt, int s2, int mf, double (&dst)[8]) {
+#pragma unroll
+            for (int u2 = 0; u2 < 8; u2++) {
+                const int src = s2 + 2 * u2 + fsel;
+                const int f = __shfl(mf, src & 63);
+                const double x = strip[(size_t)f * ISV_PROJ_STRIP + (colok ? eoff : 0)];      // (always a valid address: branch-free gathers)
+                dst[u2] = (colok && src < cnt) ? x : 0.0;
+            }
+        };
+        if (b0 < b1) gather((b1 - b0) < 64 ? (b1 - b0) : 64, 0, myf, v);
+        for (int base = b0; base < b1; base += 64) {
+            const int cnt = (b1 - base) < 64 ? (b1 - base) : 64;
+            const int ncnt = (b1 - base - 64) < 64 ? (b1 - base - 64) : 64;
+            const int nf = (base + 64 < b1 && lane < ncnt) ? perm[base + 64 + lane] : 0;       // next chunk's factor ids
+            for (int s2 = 0; s2 < cnt; s2 += 16) {
+                if (s2 + 16 < cnt) gather(cnt, s2 + 16, myf, vn);
+                else if (base + 64 < b1) gather(ncnt, 0, nf, vn);
+#pragma unroll
+                for (int u2 = 0; u2 < 8; u2++)
+                    if (s2 + 2 * u2 < cnt) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v[u2], v[u2], acc, 0, 0, 0);
+#pragma unroll
+                for (int u2 = 0; u2 < 8; u2++) v[u2] = vn[u2];
+            }
+            myf = nf;
+        }
+        // C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+        for (int reg = 0; reg <= 2; reg++) {
+            const int row = kq + 4 * reg;
+            if (row < 6) {
+                if (i < 6) Phh[p * 36 + row * 6 + i] = acc[reg];
+                else if (i == 12) Pgh[p * 6 + row] = acc[reg];
+            } else if (row < 12) {
+                const int rr = row - 6;
+                if (i < 6) out[tvis_col(h, N) + (j - h) * 36 + rr * 6 + i] = acc[reg];        // block (j, h)
+                else if (i < 12) Pjj[p * 36 + rr * 6 + (i - 6)] = acc[reg];
+                else if (i == 12) Pgj[p * 6 + rr] = acc[reg];
+            }
+        }
+    }
+}
+
+template <int NT, int TPW>
+__global__ __launch_bounds__(64 * ((NT * (NT + 1) / 2 + TPW - 1) / TPW)) void k_schur_split(DevBatch d, int Gs, int GrMax) {
+    constexpr int nwaves = (NT * (NT + 1) / 2 + TPW - 1) / TPW;
+    if ((int)blockIdx.y < Gs) sweep_split_body(d, blockIdx.y, Gs, nwaves);
+    else rank1_body<NT, TPW, 64, 1, false, true>(d, (int)blockIdx.y - Gs, GrMax);
+}
+template __global__ void k_schur_split<1, 1>(DevBatch, int, int);
+template __global__ void k_schur_split<2, 1>(DevBatch, int, int);
+template __global__ void k_schur_split<3, 1>(DevBatch, int, int);
+template __global__ void k_schur_split<4, 1>(DevBatch, int, int);
+template __global__ void k_schur_split<5, 1>(DevBatch, int, int);
+template __global__ void k_schur_split<6, 2>(DevBatch, int, int);
+template __global__ void k_schur_split<7, 2>(DevBatch, int, int);
+template __global__ void k_schur_split<8, 3>(DevBatch, int, int);
+
+// Fold of the split elimination (grid (B, any)): every thread owns whole output entries, so any number of workgroups works.
+//   from_partials != 0 (the direct part was split too): the diagonal pose blocks, the Jacobi-scaling diagonal and the gradient
+//       are the fixed-order sums over the pair partials (exactly k_sweep_mfma's fold);
+//   then, per accumulator-tile entry: Tvis -= sum over the Gr group partials in group order; row 6N = the reduced rhs.
+__global__ __launch_bounds__(256) void k_schur_fold(DevBatch d, int GrMax, int NT, int from_partials) {
+    const int w = blockIdx.x;
+    const SolveState &st = d.st[w];
+    if (st.termination != ISV_TERM_RUNNING || !st.need_linearize) return;
+    const int N = d.N, NP = N * (N - 1) / 2, n6 = 6 * N, ntiles = NT * (NT + 1) / 2;
+    const int tid = blockIdx.y * 256 + threadIdx.x, nthr = gridDim.y * 256;
+    double *out = d.Tvis + (size_t)w * d.tvis_sz;
+    const double *part = d.sw_part ? d.sw_part + (size_t)w * NP * 84 : nullptr;
+    const double *Pjj = part, *Phh = part + NP * 36, *Pgj = part + NP * 72, *Pgh = part + NP * 78;
+    const int tail = 36 * (N * (N + 1) / 2);
+    auto pidx = [N](int hh, int jj) { return hh * N - hh * (hh + 1) / 2 + (jj - hh - 1); };
+    auto diag_entry = [&](int a, int rc) {             // entry rc of diagonal block a: pairs (a, j2) ascending, then (h2, a) ascending
+        double s = 0.0;
+        for (int j2 = a + 1; j2 < N; j2++) s += Phh[pidx(a, j2) * 36 + rc];
+        for (int h2 = 0; h2 < a; h2++) s += Pjj[pidx(h2, a) * 36 + rc];
+        return s;
+    };
+    if (from_partials) {
+        for (int tq = tid; tq < N * 42; tq += nthr) {
+            if (tq < N * 36) {
+                const int a = tq / 36, rc = tq - 36 * a, r = rc / 6, c = rc - 6 * r;
+                if (c < r) continue;                   // (the lower triangle is written below, together with its downdate)
+                const double s = diag_entry(a, rc);
+                if (c > r) out[tvis_col(a, N) + rc] = s;
+                else out[tail + 6 * a + r] = s;        // Jacobi-scaling diagonal: the direct part, before the downdates
+            } else {
+                const int q = tq - N * 36, a = q / 6, r = q - 6 * a;
+                double s = 0.0;
+                for (int j2 = a + 1; j2 < N; j2++) s += Pgh[pidx(a, j2) * 6 + r];
+                for (int h2 = 0; h2 < a; h2++) s += Pgj[pidx(h2, a) * 6 + r];
+                out[tail + 6 * N + 6 * a + r] = s;
+            }
+        }
+    }
+    const int Gr = schur_split_groups((d.lm_off[w + 1] - d.lm_off[w] + 63) / 64);
+    const double *r1 = d.r1_part + (size_t)w * GrMax * (size_t)(ntiles * 256);
+    for (int e = tid; e < ntiles * 256; e += nthr) {
+        const int tile = e >> 8, reg = (e >> 6) & 3, lane = e & 63;
+        int I = 0;
+        while ((I + 1) * (I + 2) / 2 <= tile) I++;
+        const int J = tile - I * (I + 1) / 2;
+        const int R = 16 * I + (lane >> 4) + 4 * reg, Cc = 16 * J + (lane & 15);
+        int off = -1, dgA = -1, dgRC = 0;
+        if (R < n6 && Cc < n6 && R >= Cc) {
+            const int fa = Cc / 6, c = Cc - 6 * fa, fb = R / 6, r = R - 6 * fb, bo = fb - fa;
+            if (bo > 0 || c <= r) { off = tvis_col(fa, N) + bo * 36 + r * 6 + c; if (bo == 0) { dgA = fa; dgRC = r * 6 + c; } }
+        } else if (R == n6 && Cc < n6) off = -2 - Cc;
+        if (off == -1) continue;
+        double s = r1[e];
+        for (int g = 1; g < Gr; g++) s += r1[(size_t)g * (ntiles * 256) + e];
+        if (off >= 0) {
+            const double cur = (from_partials && dgA >= 0) ? diag_entry(dgA, dgRC) : out[off];
+            out[off] = cur - s;
+        } else out[tail + 12 * N + (-2 - off)] = -s;
+    }
+}

@@ -379,3 +379,50 @@ def test_prior_jacobians_match_oracle(oracle, n_frames, n_vo, perturb):
             assert np.abs(strip[0:6]).max() > 1e-3
     finally:
         b.close()
+
+
+# ---- one long window over many compute units (round 4: k_schur_split + k_schur_fold) ----------------------------------
+@pytest.mark.parametrize("shape", ["unfused", "fused", "batch_mixed"])
+def test_split_landmark_elimination_against_oracle_and_one_workgroup(oracle, monkeypatch, shape):
+    """A small batch of LONG windows spreads each window's landmark elimination over Gs + Gr workgroups (src/estimator.cpp:1057-1092
+    + DENSE_SCHUR :1121 for one window): `unfused` = more than ISV_FUSED_MAX_FACTORS factors (the direct part is split over pair
+    groups too, bit for bit the one-workgroup partials), `fused` = k_lin_gram + split rank-1 downdates, `batch_mixed` = a long and
+    a short window in one batch (the short one is ONE group: the unsplit bits).  Against the oracle (trace, accept pattern,
+    states 1e-7) and against the same handle shape with ISV_NO_SPLIT=1 (the one-workgroup kernels: same control flow, states
+    within 1e-9 -- only the downdate's partial sums differ)."""
+    from test_gpu_solve import check_marg, check_window, oracle_run
+    if shape == "unfused":
+        ws = [synth.make_window(21, n_frames=14, n_vo=6, n_landmarks=900, target_factors=9000)]
+        N, Nvo = 14, 6
+    elif shape == "fused":
+        ws = [synth.make_window(22, n_frames=11, n_vo=5, n_landmarks=640)]
+        N, Nvo = 11, 5
+    else:
+        ws = [synth.make_window(23, n_frames=11, n_vo=5, n_landmarks=520), synth.make_window(24, n_frames=11, n_vo=5, n_landmarks=90)]
+        N, Nvo = 11, 5
+    L = max(w.L for w in ws); nobs = max(w.n_obs for w in ws)
+    be = backend.Backend(N, Nvo, max_landmarks=L, max_obs=nobs, max_batch=len(ws))
+    monkeypatch.setenv("ISV_NO_SPLIT", "1")
+    one = backend.Backend(N, Nvo, max_landmarks=L, max_obs=nobs, max_batch=len(ws))
+    monkeypatch.delenv("ISV_NO_SPLIT")
+    try:
+        gs = [w.clone() for w in ws]; sums, margs = be.optimize_batch(gs)
+        cnt = be.last_counts()
+        assert cnt[7] >= 8, cnt                                    # split groups of the longest window
+        assert (cnt[4] == 0) == (shape == "unfused"), cnt
+        g1 = [w.clone() for w in ws]; sums1, _ = one.optimize_batch(g1)
+        assert one.last_counts()[7] == 0
+        for w, g, s, mg, h, s1 in zip(ws, gs, sums, margs, g1, sums1):
+            o, so, mo = oracle_run(oracle, be.cfg, w)
+            check_window(o, so, g, s); check_marg(mo, mg, Nvo)
+            assert s.iterations == s1.iterations and list(s.trace_accepted[: s.iterations + 1]) == list(s1.trace_accepted[: s1.iterations + 1])
+            if w.L < 449:                                          # one group: the one-workgroup sums, bit for bit
+                assert np.array_equal(g.state_vector(), h.state_vector())
+            else:
+                assert np.abs(g.state_vector() - h.state_vector()).max() < 1e-8          # (depths of O(10) included)
+        # run-to-run reproducible (fixed-order fold, no atomics)
+        again = [w.clone() for w in ws]; be.optimize_batch(again)
+        for a, g in zip(again, gs):
+            assert np.array_equal(a.state_vector(), g.state_vector())
+    finally:
+        be.close(); one.close()
