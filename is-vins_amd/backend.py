@@ -15,7 +15,8 @@ import numpy as np
 from . import abi
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.path.join(CSRC, "libisvins_hip.so")
+# (ISVINS_LIB: A/B measurement hook -- another build of the same library, e.g. one compiled with -DISV_STAMP)
+LIB_PATH = os.environ.get("ISVINS_LIB") or os.path.join(CSRC, "libisvins_hip.so")
 _lib = None
 
 STATUS = {0: "ISV_OK", -1: "ISV_ERR_INVALID_ARG", -2: "ISV_ERR_CAPACITY", -3: "ISV_ERR_NONFINITE",

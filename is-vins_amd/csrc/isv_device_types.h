@@ -137,6 +137,7 @@ struct DevBatch {
     int32_t *pg_wstart;                 // [B][ISV_SWEEP_WAVES + 1] stream offsets (within the window) of the sweep wavefronts' slices
     double *flm;                        // [Ftot][8] {J_l^T J_l, J_l^T r, J_i^T J_l (6)} per factor, CSR factor order
     int32_t fused_visual;
+    int32_t bs_split, _pad3;             // set per enqueue: k_backsub_split does the landmark back-substitution (k_dogleg skips it)
     int32_t ctl_stage_lm, dg_stage_ph;  // the step control stages its per-landmark gathers in LDS (set per enqueue from lg_lcap); k_dogleg stages the priors' J^T J record (set per enqueue: while the batch still fits one resident round)
     int32_t lg_lcap;                    // landmarks per window k_lin_gram stages in LDS for this upload (longest window, rounded up to 32)
     // ESTIMATE_EXTRINSIC = 1 (src/estimator.cpp:1028-1036): the extrinsic is one more 6-dof block coupled to every

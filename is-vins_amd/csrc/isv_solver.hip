@@ -22,6 +22,7 @@ extern size_t build_solve_lds_bytes(int N, bool lds_T);
 template <bool BIG, int NC> __global__ void k_build_solve_sb(DevBatch d);
 extern size_t build_solve_sb_bytes(int N, int prior_H_sz);
 __global__ void k_model_imu_prior(DevBatch d);
+__global__ void k_backsub_split(DevBatch d);
 __global__ void k_init_priors(DevBatch d, double *scratch, size_t per_window, double *kld_out);
 __global__ void k_imu_raw(DevBatch d, const double *pose_src, const double *sb_src, int gate);
 __global__ void k_imu_weight(DevBatch d, double *cost_out, int gate);
@@ -76,6 +77,45 @@ DEV void block_sums(double (&v)[K], double *red /* >= 4 K doubles */, int t) {
 #else
 #define DSTAMP(k) do {} while (0)
 #endif
+// back-substitution of ONE eliminated landmark (schur_eliminator BackSubstitute) + its term of the Cauchy-point denominator,
+// from the packed w vectors; zs / us: the window's z_p / u_p in LDS.  Shared by k_dogleg and the multi-workgroup k_backsub_split.
+template <bool EX>
+DEV void backsub_landmark(const DevBatch &d, const int l, const int fw0, const double *zs, const double *us, const double mu) {
+            // (round 3: ONE metadata word instead of three dependent index loads; the landmark scalars are requested
+            // before the w loop; two observations' w vectors are in flight per trip -- clamped address, masked add: same
+            // order of additions, same bits)
+            const unsigned m0 = d.lm_meta[l];
+            const int h = (int)(m0 & 255), k = (int)((m0 >> 8) & 255);
+            const double *wv = d.W + (size_t)(fw0 + (int)(m0 >> 16) + l) * 6;     // slots of frames h .. h + k - 1
+            const double sl = d.scale_l[l], E = d.lmE[l], gl = d.lmG[l], Dl = d.diag_l[l];
+            double wz = 0, wu = 0;        // w_l^T z_p, w_l^T u_p
+            for (int o = 0; o < k; o += 2) {
+                const int o1 = o + 1 < k ? o + 1 : o;
+                const double2 a01 = *reinterpret_cast<const double2 *>(wv + 6 * o), a23 = *reinterpret_cast<const double2 *>(wv + 6 * o + 2),
+                              a45 = *reinterpret_cast<const double2 *>(wv + 6 * o + 4);
+                const double2 b01 = *reinterpret_cast<const double2 *>(wv + 6 * o1), b23 = *reinterpret_cast<const double2 *>(wv + 6 * o1 + 2),
+                              b45 = *reinterpret_cast<const double2 *>(wv + 6 * o1 + 4);
+                const double *z = zs + 15 * (h + o), *u = us + 15 * (h + o);
+                wz += a01.x * z[0] + a01.y * z[1] + a23.x * z[2] + a23.y * z[3] + a45.x * z[4] + a45.y * z[5];
+                wu += a01.x * u[0] + a01.y * u[1] + a23.x * u[2] + a23.y * u[3] + a45.x * u[4] + a45.y * u[5];
+                if (o + 1 < k) {
+                    const double *z1 = zs + 15 * (h + o + 1), *u1 = us + 15 * (h + o + 1);
+                    wz += b01.x * z1[0] + b01.y * z1[1] + b23.x * z1[2] + b23.y * z1[3] + b45.x * z1[4] + b45.y * z1[5];
+                    wu += b01.x * u1[0] + b01.y * u1[1] + b23.x * u1[2] + b23.y * u1[3] + b45.x * u1[4] + b45.y * u1[5];
+                }
+            }
+            if (EX) {                                         // the extrinsic block (pseudo-frame Nr) couples to every landmark
+                const double *we = d.Wex + (size_t)l * 6, *z = zs + 15 * d.Nr, *u = us + 15 * d.Nr;
+                for (int c6 = 0; c6 < 6; c6++) { wz += we[c6] * z[c6]; wu += we[c6] * u[c6]; }
+            }
+            const double Es = sl * sl * E, Dl2 = Dl * Dl;
+            // scaled-space y_l = (g'_l - w'_l^T y_p) / (E'_l + mu D_l^2),  w'^T y_p = s_l w^T (Sc_p y_p) = s_l wz
+            const double yl = (sl * gl - sl * wz) / (Es + mu * Dl2);
+            d.gn_l[l] = -Dl * yl;
+            const double ul = sl * sl * gl / Dl2, cl = sl * sl / (Es + mu * Dl2);
+            d.lm_aterm[l] = cl * wu * wu + 2.0 * ul * wu + E * ul * ul;
+}
+
 template <bool EX>
 DEV void dogleg_body(DevBatch &d, const int w, const int t, double *red) {
     SolveState &st = d.st[w];
@@ -111,7 +151,7 @@ DEV void dogleg_body(DevBatch &d, const int w, const int t, double *red) {
     }
     double a = 0, b = 0, c = 0, e = 0;
     for (int i = t; i < n; i += 256) { a += gp[i] * gp[i]; b += gnp[i] * gnp[i]; c += gp[i] * gnp[i]; }
-    if (st.fresh) {
+    if (st.fresh && !d.bs_split) {          // (bs_split: k_backsub_split has done this on many CUs)
         // back-substitution of the eliminated landmarks (schur_eliminator BackSubstitute) + the landmark
         // terms of the Cauchy-point denominator, from the w vectors (one landmark per thread and pass)
         extern __shared__ __align__(16) double dyn0[];
@@ -120,45 +160,16 @@ DEV void dogleg_body(DevBatch &d, const int w, const int t, double *red) {
         __syncthreads();
         const double mu = st.mu;
         const int fw0 = d.f_off[w];
-        for (int l = l0 + t; l < l1; l += 256) {
-            // (round 3: ONE metadata word instead of three dependent index loads; the landmark scalars are requested
-            // before the w loop; two observations' w vectors are in flight per trip -- clamped address, masked add: same
-            // order of additions, same bits)
-            const unsigned m0 = d.lm_meta[l];
-            const int h = (int)(m0 & 255), k = (int)((m0 >> 8) & 255);
-            const double *wv = d.W + (size_t)(fw0 + (int)(m0 >> 16) + l) * 6;     // slots of frames h .. h + k - 1
-            const double sl = d.scale_l[l], E = d.lmE[l], gl = d.lmG[l], Dl = d.diag_l[l];
-            double wz = 0, wu = 0;        // w_l^T z_p, w_l^T u_p
-            for (int o = 0; o < k; o += 2) {
-                const int o1 = o + 1 < k ? o + 1 : o;
-                const double2 a01 = *reinterpret_cast<const double2 *>(wv + 6 * o), a23 = *reinterpret_cast<const double2 *>(wv + 6 * o + 2),
-                              a45 = *reinterpret_cast<const double2 *>(wv + 6 * o + 4);
-                const double2 b01 = *reinterpret_cast<const double2 *>(wv + 6 * o1), b23 = *reinterpret_cast<const double2 *>(wv + 6 * o1 + 2),
-                              b45 = *reinterpret_cast<const double2 *>(wv + 6 * o1 + 4);
-                const double *z = zs + 15 * (h + o), *u = us + 15 * (h + o);
-                wz += a01.x * z[0] + a01.y * z[1] + a23.x * z[2] + a23.y * z[3] + a45.x * z[4] + a45.y * z[5];
-                wu += a01.x * u[0] + a01.y * u[1] + a23.x * u[2] + a23.y * u[3] + a45.x * u[4] + a45.y * u[5];
-                if (o + 1 < k) {
-                    const double *z1 = zs + 15 * (h + o + 1), *u1 = us + 15 * (h + o + 1);
-                    wz += b01.x * z1[0] + b01.y * z1[1] + b23.x * z1[2] + b23.y * z1[3] + b45.x * z1[4] + b45.y * z1[5];
-                    wu += b01.x * u1[0] + b01.y * u1[1] + b23.x * u1[2] + b23.y * u1[3] + b45.x * u1[4] + b45.y * u1[5];
-                }
-            }
-            if (EX) {                                         // the extrinsic block (pseudo-frame Nr) couples to every landmark
-                const double *we = d.Wex + (size_t)l * 6, *z = zs + 15 * d.Nr, *u = us + 15 * d.Nr;
-                for (int c6 = 0; c6 < 6; c6++) { wz += we[c6] * z[c6]; wu += we[c6] * u[c6]; }
-            }
-            const double Es = sl * sl * E, Dl2 = Dl * Dl;
-            // scaled-space y_l = (g'_l - w'_l^T y_p) / (E'_l + mu D_l^2),  w'^T y_p = s_l w^T (Sc_p y_p) = s_l wz
-            const double yl = (sl * gl - sl * wz) / (Es + mu * Dl2);
-            d.gn_l[l] = -Dl * yl;
-            const double ul = sl * sl * gl / Dl2, cl = sl * sl / (Es + mu * Dl2);
-            d.lm_aterm[l] = cl * wu * wu + 2.0 * ul * wu + E * ul * ul;
-        }
+        for (int l = l0 + t; l < l1; l += 256) backsub_landmark<EX>(d, l, fw0, zs, us, mu);
     }
-    for (int l = l0 + t; l < l1; l += 256) {
-        const double gl = d.grad_l[l], nl = d.gn_l[l];
-        a += gl * gl; b += nl * nl; c += gl * nl; e += d.lm_aterm[l];
+    // (round 4: four trips' loads in flight in the three landmark loops -- clamped addresses, masked updates in the same order:
+    // same bits; a 2000-landmark window waited a memory latency per trip, 8 trips x 3 loops)
+    for (int lq = l0 + t; lq < l1; lq += 4 * 256) {
+        double gl4[4], nl4[4], at4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int l = lq + 256 * u < l1 ? lq + 256 * u : l1 - 1; gl4[u] = d.grad_l[l]; nl4[u] = d.gn_l[l]; at4[u] = d.lm_aterm[l]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (lq + 256 * u < l1) { a += gl4[u] * gl4[u]; b += nl4[u] * nl4[u]; c += gl4[u] * nl4[u]; e += at4[u]; }
     }
     DSTAMP(48);
     double sums4[4] = {a, b, c, e};
@@ -187,12 +198,19 @@ DEV void dogleg_body(DevBatch &d, const int w, const int t, double *red) {
         sn += s * s;
         dp[i] = s / Dp[i] * scp[i];
     }
-    for (int l = l0 + t; l < l1; l += 256) {
-        const double s = cg * d.grad_l[l] + cn * d.gn_l[l];
-        sn += s * s;
-        const double dl = s / d.diag_l[l] * d.scale_l[l];
-        d.delta_l[l] = dl;
-        d.clam[l] = d.lam[l] + dl;
+    for (int lq = l0 + t; lq < l1; lq += 4 * 256) {
+        double gl4[4], nl4[4], dg4[4], sc4[4], lam4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int l = lq + 256 * u < l1 ? lq + 256 * u : l1 - 1; gl4[u] = d.grad_l[l]; nl4[u] = d.gn_l[l]; dg4[u] = d.diag_l[l]; sc4[u] = d.scale_l[l]; lam4[u] = d.lam[l]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (lq + 256 * u < l1) {
+            const int l = lq + 256 * u;
+            const double s = cg * gl4[u] + cn * nl4[u];
+            sn += s * s;
+            const double dl = s / dg4[u] * sc4[u];
+            d.delta_l[l] = dl;
+            d.clam[l] = lam4[u] + dl;
+        }
     }
     double sums1[1] = {sn};
     block_sums<1>(sums1, red, t);
@@ -209,7 +227,13 @@ DEV void dogleg_body(DevBatch &d, const int w, const int t, double *red) {
         for (int k = 0; k < 7; k++) { xc[k] = xp[k]; const double df = x[k] - xp[k]; dn += df * df; xn += x[k] * x[k]; }
         for (int k = 0; k < 9; k++) { const double v = sb[k] + dp[15 * i + 6 + k]; sc[k] = v; const double df = sb[k] - v; dn += df * df; xn += sb[k] * sb[k]; }
     }
-    for (int l = l0 + t; l < l1; l += 256) { const double df = d.lam[l] - d.clam[l]; dn += df * df; xn += d.lam[l] * d.lam[l]; }
+    for (int lq = l0 + t; lq < l1; lq += 4 * 256) {
+        double lam4[4], cl4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int l = lq + 256 * u < l1 ? lq + 256 * u : l1 - 1; lam4[u] = d.lam[l]; cl4[u] = d.clam[l]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (lq + 256 * u < l1) { const double df = lam4[u] - cl4[u]; dn += df * df; xn += lam4[u] * lam4[u]; }
+    }
     DSTAMP(49);
     double sums2[2] = {dn, xn};
     block_sums<2>(sums2, red, t);
@@ -385,6 +409,23 @@ template __global__ void k_dogleg<false, false>(DevBatch);
 template __global__ void k_dogleg<true, false>(DevBatch);
 template __global__ void k_dogleg<false, true>(DevBatch);
 template __global__ void k_dogleg<true, true>(DevBatch);
+
+// (round 4) the landmark back-substitution of a LONG window on many CUs (grid (B, groups of 128 landmarks)): what k_dogleg's
+// first phase does with one workgroup -- per landmark the same function, so the same bits.  Launched between
+// k_build_solve_sb and k_dogleg when the elimination is split (d.bs_split).
+__global__ __launch_bounds__(128) void k_backsub_split(DevBatch d) {
+    extern __shared__ __align__(16) double zsus[];
+    const int w = blockIdx.x, t = threadIdx.x;
+    const SolveState &st = d.st[w];
+    if (st.termination != ISV_TERM_RUNNING || st.ls_fail || !st.fresh) return;
+    const int n = d.np, l0 = d.lm_off[w], l1 = d.lm_off[w + 1];
+    const int l = l0 + (int)blockIdx.y * 128 + t;
+    if (l0 + (int)blockIdx.y * 128 >= l1) return;
+    double *zs = zsus, *us = zsus + n;
+    for (int i = t; i < n; i += 128) { zs[i] = d.zp[(size_t)w * n + i]; us[i] = d.up[(size_t)w * n + i]; }
+    __syncthreads();
+    if (l < l1) backsub_landmark<false>(d, l, d.f_off[w], zs, us, st.mu);
+}
 
 
 // ------------------------------------------------------------------------------------------
@@ -855,6 +896,7 @@ int isv_solver_enqueue(DevBatch &d, const SolverHost &hc, hipStream_t st, hipStr
         // a SMALL batch with LONG windows: one window's elimination over many CUs (k_schur_split + k_schur_fold, isv_sweep.hip)
         const int Pmax = (d.lg_lcap + 63) / 64, GrMax = Pmax < ISV_SPLIT_MAX_GROUPS ? Pmax : ISV_SPLIT_MAX_GROUPS;
         const bool split = d.lds_T && d.r1_part && !hc.no_split && Pmax >= ISV_SPLIT_MIN_PASSES && (size_t)d.B * (GrMax + 1) <= (size_t)n_cus;
+        d.bs_split = split ? 1 : 0;
         if (split) {
             int Gs = 0;
             if (!fused) { Gs = n_cus / d.B - GrMax; if (Gs > 16) Gs = 16; if (Gs < 1) Gs = 1; }
@@ -876,7 +918,7 @@ int isv_solver_enqueue(DevBatch &d, const SolverHost &hc, hipStream_t st, hipStr
             }
             PROF(slot, 1, 1);
             PROF(slot, 2, 0);
-            hipLaunchKernelGGL(k_schur_fold, dim3(d.B, 8), dim3(256), 0, st, d, GrMax, nt, Gs > 0 ? 1 : 0);
+            hipLaunchKernelGGL(k_schur_fold, dim3(d.B, nt * (nt + 1) / 2), dim3(256), 0, st, d, GrMax, nt, Gs > 0 ? 1 : 0);      // one accumulator-tile entry per thread
             PROF(slot, 2, 1);
             counts[2]++; counts[7] = GrMax;
         } else if (d.lds_T) {
@@ -919,6 +961,7 @@ int isv_solver_enqueue(DevBatch &d, const SolverHost &hc, hipStream_t st, hipStr
         counts[1]++;
         PROF(slot, 3, 1);
         PROF(slot, 4, 0);
+        if (split) hipLaunchKernelGGL(k_backsub_split, dim3(d.B, (d.lg_lcap + 127) / 128), dim3(128), 2 * (size_t)d.np * sizeof(double), st, d);
         if (fuse_control) {
             if (d.est_ex) hipLaunchKernelGGL((k_dogleg<true, true>), dim3(d.B), dim3(256), lds_dgc, st, d);
             else hipLaunchKernelGGL((k_dogleg<true, false>), dim3(d.B), dim3(256), lds_dgc, st, d);

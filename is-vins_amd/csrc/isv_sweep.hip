@@ -80,11 +80,17 @@ __global__ __launch_bounds__(64 * ISV_SWEEP_WAVES, 8) void k_sweep_mfma(DevBatch
                 for (int u2 = 0; u2 < 8; u2++) {
                     const int src = s2 + 2 * u2 + fsel;
                     const int f = __shfl(myf, src & 63);
-                    v[u2] = (colok && src < cnt) ? strip[(size_t)f * ISV_PROJ_STRIP + eoff] : 0.0;
+                    // (round 4: unconditional, clamped loads; masked operand entries are multiplied by zero where they are used.
+                    // As `cond ? load : 0.0` the compiler sank every load into a branch of its own behind an s_waitcnt vmcnt(0):
+                    // eight serialised memory latencies per round instead of one)
+                    v[u2] = strip[(size_t)f * ISV_PROJ_STRIP + (colok ? eoff : 0)];
                 }
 #pragma unroll
                 for (int u2 = 0; u2 < 8; u2++)
-                    if (s2 + 2 * u2 < cnt) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v[u2], v[u2], acc, 0, 0, 0);
+                    if (s2 + 2 * u2 < cnt) {
+                        const double x = v[u2] * ((colok && s2 + 2 * u2 + fsel < cnt) ? 1.0 : 0.0);
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, acc, 0, 0, 0);
+                    }
             }
         }
         // C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
@@ -419,33 +425,48 @@ DEV void sweep_split_body(DevBatch &d, const int grp, const int Gs, const int nw
         const int j = h + 1 + (p - (h * N - h * (h + 1) / 2));
         const int b0 = offL[p], b1 = offL[p + 1];
         double4s acc = {0, 0, 0, 0};
-        // 16 factors per round: 8 loads in flight, then 8 MFMAs; the NEXT round's loads are issued before this round's MFMAs
-        int myf = lane < (b1 - b0) ? perm[b0 + lane] : 0;
-        double v[8], vn[8];
-        auto gather = [&](int cnt, int s2, int mf, double (&dst)[8]) {
+        // 16 factors (8 MFMAs) per round, four rounds per 64-factor chunk.  The gathers of chunk c + 1 are issued round by round
+        // behind the MFMAs of chunk c (a register ring of four rounds), and the factor ids of chunk c + 2 (one coalesced load,
+        // broadcast by __shfl) are requested before them: a wavefront keeps 32 strip loads in flight and never waits for an id
+        // load with strip loads queued behind it.  (First version: ids fetched per round -- a dependent load whose s_waitcnt
+        // drained the whole ring: two memory latencies per round, 60 us for the 268-factor pair groups of BASELINE config 5.)
+        // Same MFMA order as k_sweep_mfma: same bits per pair group.
+        const int nrounds = (b1 - b0 + 15) / 16, nch = (b1 - b0 + 63) / 64;
+        auto ids = [&](int c) { const int pos = b0 + 64 * c + lane; return perm[pos < b1 ? pos : (b1 > b0 ? b1 - 1 : 0)]; };
+        int myf0 = ids(0), myf1 = ids(1);
+        double v[4][8];
+        auto gather = [&](int q, int mf, double (&dst)[8]) {         // round q (ids of its chunk in mf); clamped, always valid addresses
 #pragma unroll
             for (int u2 = 0; u2 < 8; u2++) {
-                const int src = s2 + 2 * u2 + fsel;
-                const int f = __shfl(mf, src & 63);
-                const double x = strip[(size_t)f * ISV_PROJ_STRIP + (colok ? eoff : 0)];      // (always a valid address: branch-free gathers)
-                dst[u2] = (colok && src < cnt) ? x : 0.0;
+                const int src = 16 * (q & 3) + 2 * u2 + fsel;
+                const int f = __shfl(mf, src);
+                // (masked operand entries are MULTIPLIED by zero after an unconditional, clamped load: with `cond ? load : 0.0` the
+                // compiler sinks the load into a branch of its own with an s_waitcnt vmcnt(0) behind it -- eight serialised memory
+                // latencies per round, 60 us per launch measured; the strips of valid factors are finite, so x * 0 is a zero)
+                // (the ring keeps the RAW value: the multiplication happens where the operand is used, so the wait for a round's loads
+                // sits in front of its MFMAs, four rounds later)
+                dst[u2] = strip[(size_t)f * ISV_PROJ_STRIP + (colok ? eoff : 0)];
             }
         };
-        if (b0 < b1) gather((b1 - b0) < 64 ? (b1 - b0) : 64, 0, myf, v);
-        for (int base = b0; base < b1; base += 64) {
-            const int cnt = (b1 - base) < 64 ? (b1 - base) : 64;
-            const int ncnt = (b1 - base - 64) < 64 ? (b1 - base - 64) : 64;
-            const int nf = (base + 64 < b1 && lane < ncnt) ? perm[base + 64 + lane] : 0;       // next chunk's factor ids
-            for (int s2 = 0; s2 < cnt; s2 += 16) {
-                if (s2 + 16 < cnt) gather(cnt, s2 + 16, myf, vn);
-                else if (base + 64 < b1) gather(ncnt, 0, nf, vn);
 #pragma unroll
-                for (int u2 = 0; u2 < 8; u2++)
-                    if (s2 + 2 * u2 < cnt) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(v[u2], v[u2], acc, 0, 0, 0);
+        for (int q = 0; q < 4; q++) if (q < nrounds) gather(q, myf0, v[q]);
+        for (int c = 0; c < nch; c++) {
+            const int myf2 = ids(c + 2);
 #pragma unroll
-                for (int u2 = 0; u2 < 8; u2++) v[u2] = vn[u2];
+            for (int qq = 0; qq < 4; qq++) {
+                const int q = 4 * c + qq;
+                if (q < nrounds) {
+                    const int left = b1 - b0 - 16 * q;                  // factors from this round on
+#pragma unroll
+                    for (int u2 = 0; u2 < 8; u2++)
+                        if (2 * u2 < left) {
+                            const double x = v[qq][u2] * ((colok && 2 * u2 + fsel < left) ? 1.0 : 0.0);
+                            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, acc, 0, 0, 0);
+                        }
+                    if (q + 4 < nrounds) gather(q + 4, myf1, v[qq]);
+                }
             }
-            myf = nf;
+            myf0 = myf1; myf1 = myf2;
         }
         // C/D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
@@ -467,6 +488,10 @@ DEV void sweep_split_body(DevBatch &d, const int grp, const int Gs, const int nw
 template <int NT, int TPW>
 __global__ __launch_bounds__(64 * ((NT * (NT + 1) / 2 + TPW - 1) / TPW)) void k_schur_split(DevBatch d, int Gs, int GrMax) {
     constexpr int nwaves = (NT * (NT + 1) / 2 + TPW - 1) / TPW;
+#ifdef ISV_SPLIT_SKIP          /* timing experiment: 1 = no direct part, 2 = no downdates (results are wrong) */
+    if (ISV_SPLIT_SKIP == 1 && (int)blockIdx.y < Gs) return;
+    if (ISV_SPLIT_SKIP == 2 && (int)blockIdx.y >= Gs) return;
+#endif
     if ((int)blockIdx.y < Gs) sweep_split_body(d, blockIdx.y, Gs, nwaves);
     else rank1_body<NT, TPW, 64, 1, false, true>(d, (int)blockIdx.y - Gs, GrMax);
 }
@@ -496,7 +521,9 @@ __global__ __launch_bounds__(256) void k_schur_fold(DevBatch d, int GrMax, int N
     auto pidx = [N](int hh, int jj) { return hh * N - hh * (hh + 1) / 2 + (jj - hh - 1); };
     auto diag_entry = [&](int a, int rc) {             // entry rc of diagonal block a: pairs (a, j2) ascending, then (h2, a) ascending
         double s = 0.0;
+#pragma unroll 4
         for (int j2 = a + 1; j2 < N; j2++) s += Phh[pidx(a, j2) * 36 + rc];
+#pragma unroll 4
         for (int h2 = 0; h2 < a; h2++) s += Pjj[pidx(h2, a) * 36 + rc];
         return s;
     };
@@ -531,8 +558,15 @@ __global__ __launch_bounds__(256) void k_schur_fold(DevBatch d, int GrMax, int N
             if (bo > 0 || c <= r) { off = tvis_col(fa, N) + bo * 36 + r * 6 + c; if (bo == 0) { dgA = fa; dgRC = r * 6 + c; } }
         } else if (R == n6 && Cc < n6) off = -2 - Cc;
         if (off == -1) continue;
-        double s = r1[e];
-        for (int g = 1; g < Gr; g++) s += r1[(size_t)g * (ntiles * 256) + e];
+        // (eight group partials in flight; masked adds in group order)
+        double s = 0.0;
+        for (int g0 = 0; g0 < Gr; g0 += 8) {
+            double p8[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) p8[u] = r1[(size_t)(g0 + u < Gr ? g0 + u : Gr - 1) * (ntiles * 256) + e];
+#pragma unroll
+            for (int u = 0; u < 8; u++) if (g0 + u < Gr) s = (g0 + u == 0) ? p8[u] : s + p8[u];
+        }
         if (off >= 0) {
             const double cur = (from_partials && dgA >= 0) ? diag_entry(dgA, dgRC) : out[off];
             out[off] = cur - s;
