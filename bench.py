@@ -351,7 +351,7 @@ def main():
                                             "build_solve_avg_launch_us": 1e3 * float(fam18[4]) / max(int(cnt18[1]), 1),
                                             "ms_per_optimize_single_window": float(np.median(ts1[2:])),
                                             "single_window_handle": "as the shim creates it: max_landmarks 1000, max_obs 18000, max_batch 1",
-                                            "single_window_fused_lin_gram": int(cshim[4]) == 1, "single_window_persistent_launch": int(cshim[6]) == 1,
+                                            "single_window_fused_lin_gram": int(cshim[4]) == 1, "single_window_solve_kernel": "k_build_solve_st" if int(cshim[6]) == 1 else "k_build_solve_sb",
                                             "ms_per_optimize_single_window_tight_handle": single_window_ms(18, 8, w18, mo18)}
 
         # ---- BASELINE config 5: ONE stress window, 20 KF / 2000 landmarks / exactly 30 000 reprojection factors --------------

@@ -121,6 +121,7 @@ struct DevBatch {
     double2 *lm_cg;                     // [Ltot]  {c_l = s_l^2 / (s_l^2 E_l + mu D_l^2), g_l}
     int32_t sw_global;                  // this launch keeps the pair partials in sw_part (set per launch: only batches that need the occupancy)
     double *sw_part;                    // [B][NP * 84] pair partials of k_sweep_mfma when they do not share a CU's LDS four ways (long windows); else null
+    double *st_ws;                      // [B][162 N + ytot] k_build_solve_st: L_i^-1 | C_i' | Y_i' of the chain nodes between elimination and back-substitution; null: the handle runs k_build_solve_sb
     double *r1_part;                    // [split_cap_B][ISV_SPLIT_MAX_GROUPS][tiles * 256] raw accumulator tiles of the split rank-1 downdates (k_schur_split -> k_schur_fold); null: no split on this handle
     double *Tvis;                       // [B][tvis_sz] reprojection part of the reduced system (6x6 pose corners), hd, g, bs
     int32_t force_retry, init_mode;       // init_mode: this enqueue is Estimator::initFactorGraph (no update(), no marginalisation)            // test hook (env ISV_DEBUG_FORCE_RETRY): treat the first n factorisations of an iteration as failed

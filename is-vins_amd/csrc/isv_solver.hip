@@ -21,6 +21,9 @@
 extern size_t build_solve_lds_bytes(int N, bool lds_T);
 template <bool BIG, int NC> __global__ void k_build_solve_sb(DevBatch d);
 extern size_t build_solve_sb_bytes(int N, int prior_H_sz);
+template <bool BIG, int NC> __global__ void k_build_solve_st(DevBatch d);
+extern size_t build_solve_st_bytes(int N, int prior_H_sz);
+extern size_t build_solve_st_ws_doubles(int N);
 __global__ void k_model_imu_prior(DevBatch d);
 __global__ void k_backsub_split(DevBatch d);
 __global__ void k_init_priors(DevBatch d, double *scratch, size_t per_window, double *kld_out);
@@ -795,6 +798,20 @@ int isv_solver_alloc(DevBatch &d, SolverHost &hc, size_t B, size_t L, size_t F, 
     const bool can_split = d.lds_T && !d.est_ex && !hc.no_split && ((size_t)d.max_lm + 63) / 64 >= ISV_SPLIT_MIN_PASSES && hc.n_cus > ISV_SPLIT_MIN_PASSES;
     if (d.lds_T && (sw_global || hc.debug_sw_global || can_split)) TRYA(dal(&d.sw_part, B * n_pairs * 84, allocs, err));
     hc.sw_global_ok = sw_global || hc.debug_sw_global;
+    // k_build_solve_st (isv_build_solve_st.hip): a quarter (N <= 11) / half of a CU's LDS per window, 256 threads.  It wins when
+    // the batch fills the GPU more than twice over with k_build_solve_sb's two (one) windows per CU; a window alone on a CU is
+    // faster with the 512-thread kernel.  The choice is per HANDLE (its max_batch): a window gives the same bits alone and in any
+    // batch of the same handle.
+    d.st_ws = nullptr;
+    {
+        const size_t lds_st = build_solve_st_bytes(d.N, d.prior_H_sz);
+        const bool fits = d.lds_T && (d.N <= 11 ? lds_st <= 40 * 1024 : lds_st <= 80 * 1024);
+        const char *e = getenv("ISV_SOLVE_ST");
+        const size_t per_cu_sb = d.N <= 11 ? 2 : 1;
+        hc.solve_st = fits && (e ? atoi(e) != 0 : B > per_cu_sb * (size_t)hc.n_cus);
+        if (getenv("ISV_DEBUG_PATH")) fprintf(stderr, "isv: k_build_solve_st lds=%zu fits=%d -> solve_st=%d\n", lds_st, (int)fits, (int)hc.solve_st);
+        if (hc.solve_st) TRYA(dal(&d.st_ws, B * build_solve_st_ws_doubles(d.N), allocs, err));
+    }
     d.r1_part = nullptr;
     if (can_split) { const size_t nt_ = d.wd_ld / 16; TRYA(dal(&d.r1_part, (size_t)hc.n_cus * (nt_ * (nt_ + 1) / 2) * 256, allocs, err)); }
     d.marg_scratch_sz = 26;
@@ -818,6 +835,12 @@ int isv_solver_alloc(DevBatch &d, SolverHost &hc, size_t B, size_t L, size_t F, 
             auto cap = [&](int waves) { const size_t b = lin_gram_lds_bytes(d.Nr, true, d.est_ex != 0, waves, d.max_lm); return b < ISV_LDS_PER_CU ? b : ISV_LDS_PER_CU; };
             if (d.est_ex) { SETLDS((k_lin_gram<true, LG_WAVES>), cap(LG_WAVES)); SETLDS((k_lin_gram<true, LG_WAVES_SMALL>), cap(LG_WAVES_SMALL)); }
             else { SETLDS((k_lin_gram<false, LG_WAVES>), cap(LG_WAVES)); SETLDS((k_lin_gram<false, LG_WAVES_SMALL>), cap(LG_WAVES_SMALL)); }
+        }
+        if (hc.solve_st) {
+            const size_t lds_st = build_solve_st_bytes(d.N, d.prior_H_sz);
+            if (d.N == 11) SETLDS((k_build_solve_st<false, 11>), lds_st);
+            if (d.N <= 11) SETLDS((k_build_solve_st<false, 0>), lds_st);
+            if (d.N > 11) SETLDS((k_build_solve_st<true, 0>), lds_st);
         }
         if (d.N == 11) SETLDS((k_build_solve_sb<false, 11>), lds_sb);
         if (d.N <= 11) SETLDS((k_build_solve_sb<false, 0>), lds_sb);
@@ -951,7 +974,13 @@ int isv_solver_enqueue(DevBatch &d, const SolverHost &hc, hipStream_t st, hipStr
         PROF(slot, 3, 0);
         // (the window length as a compile-time constant for the benchmark's 11 frames: isv_build_solve_sb.hip)
         const bool generic_n = hc.generic_n;             // (A/B / test hook: the run-time-N instantiations for every N)
-        if (d.lds_T && generic_n) {
+        if (d.lds_T && hc.solve_st) {
+            counts[6] = 1;
+            const size_t lds_st = build_solve_st_bytes(d.N, d.prior_H_sz);
+            if (d.N == 11 && !generic_n) hipLaunchKernelGGL((k_build_solve_st<false, 11>), dim3(d.B), dim3(256), lds_st, st, d);
+            else if (d.N <= 11) hipLaunchKernelGGL((k_build_solve_st<false, 0>), dim3(d.B), dim3(256), lds_st, st, d);
+            else hipLaunchKernelGGL((k_build_solve_st<true, 0>), dim3(d.B), dim3(256), lds_st, st, d);
+        } else if (d.lds_T && generic_n) {
             if (d.N <= 11) hipLaunchKernelGGL((k_build_solve_sb<false, 0>), dim3(d.B), dim3(512), build_solve_sb_bytes(d.N, d.prior_H_sz), st, d);
             else hipLaunchKernelGGL((k_build_solve_sb<true, 0>), dim3(d.B), dim3(512), build_solve_sb_bytes(d.N, d.prior_H_sz), st, d);
         } else if (d.lds_T && d.N == 11) hipLaunchKernelGGL((k_build_solve_sb<false, 11>), dim3(d.B), dim3(512), build_solve_sb_bytes(d.N, d.prior_H_sz), st, d);

@@ -426,3 +426,55 @@ def test_split_landmark_elimination_against_oracle_and_one_workgroup(oracle, mon
             assert np.array_equal(a.state_vector(), g.state_vector())
     finally:
         be.close(); one.close()
+
+
+# ---- k_build_solve_st: the four-windows-per-CU linear solve (round 4) -------------------------------------------------
+@pytest.mark.parametrize("N,Nvo,L,ex", [(11, 5, 120, 0), (6, 3, 60, 0), (18, 8, 150, 0), (16, 7, 200, 0), (11, 5, 100, 1), (9, 4, 80, 0)])
+def test_streamed_linear_solve_against_oracle_and_k_build_solve_sb(oracle, monkeypatch, N, Nvo, L, ex):
+    """k_build_solve_st (isv_build_solve_st.hip; DENSE_SCHUR linear solve of src/estimator.cpp:1119-1128) streams the speed/bias
+    chain blocks through small LDS rings and downdates the pose system node by node, so that four windows share a CU.  It is
+    chosen per HANDLE (max_batch > 2 n_cus at N <= 11); here it is forced on a small handle (ISV_SOLVE_ST=1) and compared with the
+    oracle (trace, accept pattern, states 1e-7, marginalisation) and with k_build_solve_sb on the same windows (ISV_SOLVE_ST=0:
+    identical control flow, states within 1e-8 -- the two kernels sum in different orders)."""
+    from test_gpu_solve import check_marg, check_window, oracle_run
+    ws = synth.make_windows([31, 32, 33], n_frames=N, n_vo=Nvo, n_landmarks=L)
+    kw = dict(max_landmarks=L, max_obs=max(w.n_obs for w in ws), max_batch=3, estimate_extrinsic=ex)
+    monkeypatch.setenv("ISV_SOLVE_ST", "1")
+    be = backend.Backend(N, Nvo, **kw)
+    monkeypatch.setenv("ISV_SOLVE_ST", "0")
+    sb = backend.Backend(N, Nvo, **kw)
+    monkeypatch.delenv("ISV_SOLVE_ST")
+    try:
+        gs = [w.clone() for w in ws]; sums, margs = be.optimize_batch(gs)
+        assert be.last_counts()[6] == 1
+        hs = [w.clone() for w in ws]; sums1, _ = sb.optimize_batch(hs)
+        assert sb.last_counts()[6] == 0
+        for w, g, s, mg, h, s1 in zip(ws, gs, sums, margs, hs, sums1):
+            o, so, mo = oracle_run(oracle, be.cfg, w)
+            check_window(o, so, g, s); check_marg(mo, mg, Nvo)
+            assert s.iterations == s1.iterations and list(s.trace_accepted[: s.iterations + 1]) == list(s1.trace_accepted[: s1.iterations + 1])
+            assert np.abs(g.state_vector() - h.state_vector()).max() < 1e-7          # (depths of O(10) included: 1.5e-8 measured)
+        # a window alone on the same handle: the same bits as inside the batch
+        a = ws[1].clone(); be.optimize(a)
+        assert np.array_equal(a.state_vector(), gs[1].state_vector())
+    finally:
+        be.close(); sb.close()
+
+
+def test_streamed_linear_solve_forced_mu_retry(oracle, monkeypatch):
+    """the retry branch of k_build_solve_st (a failed factorisation retries with mu x 10, the landmark part corrected in place)
+    with the same fault injected into the oracle"""
+    from test_gpu_solve import check_window, oracle_run
+    monkeypatch.setenv("ISV_SOLVE_ST", "1"); monkeypatch.setenv("ISV_DEBUG_FORCE_RETRY", "2")
+    be = backend.Backend(11, 5, max_landmarks=100, max_obs=1100, max_batch=2)
+    monkeypatch.delenv("ISV_SOLVE_ST"); monkeypatch.delenv("ISV_DEBUG_FORCE_RETRY")
+    oracle.isvo_debug_force_retry(2)
+    try:
+        for wid in (41, 42):
+            w = synth.make_window(wid, n_landmarks=100)
+            o, so, _ = oracle_run(oracle, be.cfg, w)
+            g = w.clone(); s, _ = be.optimize(g)
+            assert be.last_counts()[6] == 1
+            check_window(o, so, g, s)
+    finally:
+        oracle.isvo_debug_force_retry(0); be.close()
