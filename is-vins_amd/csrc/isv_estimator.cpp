@@ -251,6 +251,8 @@ struct Sequence {
     isv_linear9_t add_vb{};                    // backwardVBEdgeToAdd
     // staged input
     bool staged = false;
+    bool features_added = false;      // the resident path already ran addFeatureAndCheckParallax for the staged image and then fell back to the host path (same frame)
+    int tracks_before = 0;            // tracks before that call: what the device's track list holds
     double staged_header = 0;
     std::vector<std::pair<int, V3>> staged_image;
     bool have_boot = false;
@@ -295,6 +297,7 @@ struct isv_estimator {
     bool resident_ready = false;               // every sequence is seeded on the device
     int tracks_cap = 0;
     int64_t resident_frames = 0;
+    bool dbg_fell_back = false;       // the ISV_DEBUG_SEQ_*_FRAME hooks fire once
 };
 
 namespace {
@@ -653,6 +656,11 @@ extern "C" int isv_estimator_push_image(isv_estimator_t *e, int32_t seq, double 
     s.staged_image.clear();
     s.staged_image.reserve(n);
     for (int i = 0; i < n; i++) s.staged_image.emplace_back(feature_id[i], V3{point[i * 3], point[i * 3 + 1], point[i * 3 + 2]});
+    // a feature id seen twice in one image: the reference's std::map<int, vector<...>> keeps both and processImage reads the FIRST
+    // (id_pts.second[0], src/feature_tracker/feature_manager.cpp:64-66); the resident track store appends one observation per
+    // track and frame (k_seq_append), so duplicates are dropped here, once, for both paths
+    std::stable_sort(s.staged_image.begin(), s.staged_image.end(), [](const std::pair<int, V3> &a, const std::pair<int, V3> &b) { return a.first < b.first; });
+    s.staged_image.erase(std::unique(s.staged_image.begin(), s.staged_image.end(), [](const std::pair<int, V3> &a, const std::pair<int, V3> &b) { return a.first == b.first; }), s.staged_image.end());
     s.staged_header = header;
     s.staged = true;
     return ISV_OK;
@@ -707,10 +715,13 @@ int seed_resident(isv_estimator *e) {
 }
 
 // the device's state of every sequence back into the host members (a sequence leaves the resident mode BEFORE its slide)
-int leave_resident(isv_estimator *e, bool host_has_slid) {
+// (pre_add: the host has ALREADY appended this frame's features to its track lists -- the device holds the first tracks_before
+//  tracks of every sequence; the tracks behind them are this frame's new ones and keep their fresh depth)
+int leave_resident(isv_estimator *e, bool host_has_slid, bool pre_add = false) {
+    auto ntracks = [&](const Sequence &s) { return pre_add ? (size_t)s.tracks_before : s.tracks.size(); };
     if (host_has_slid) {      // the device applies a slide with the NEXT frame: let it catch up with the host's bookkeeping first
         std::vector<int32_t> prev(e->seq.size()), nt(e->seq.size());
-        for (size_t si = 0; si < e->seq.size(); si++) { prev[si] = e->seq[si].last_slide; nt[si] = (int32_t)e->seq[si].tracks.size(); }
+        for (size_t si = 0; si < e->seq.size(); si++) { prev[si] = e->seq[si].last_slide; nt[si] = (int32_t)ntracks(e->seq[si]); }
         const int rc = isv_backend_seq_flush(e->backend, (int32_t)e->seq.size(), prev.data(), nt.data());
         if (rc != ISV_OK) { e->err = std::string("leaving the resident mode failed: ") + isv_backend_last_error(e->backend); return rc; }
         for (Sequence &s : e->seq) s.last_slide = 0;
@@ -724,9 +735,10 @@ int leave_resident(isv_estimator *e, bool host_has_slid) {
         isv_window_t w{};
         w.Ps = s.wPs.data(); w.Rs = s.wRs.data(); w.Vs = s.wVs.data(); w.Bas = s.wBas.data(); w.Bgs = s.wBgs.data();
         w.pose_prior = &s.wpp; w.vb_prior = &s.wvb; w.relpose = s.wrel.data(); w.rollpitch = s.wrp.data();
-        std::vector<double> dep(std::max<size_t>(s.tracks.size(), 1));
-        std::vector<int32_t> fl(std::max<size_t>(s.tracks.size(), 1));
-        const int rc = isv_backend_seq_download(e->backend, (int32_t)si, &w, (int32_t)s.tracks.size(), dep.data(), fl.data());
+        const size_t ntr = ntracks(s);
+        std::vector<double> dep(std::max<size_t>(ntr, 1));
+        std::vector<int32_t> fl(std::max<size_t>(ntr, 1));
+        const int rc = isv_backend_seq_download(e->backend, (int32_t)si, &w, (int32_t)ntr, dep.data(), fl.data());
         if (rc != ISV_OK) { e->err = std::string("leaving the resident mode failed: ") + isv_backend_last_error(e->backend); return rc; }
         // (after a slide the newest frame is the host's: processIMU may already have propagated it with the next frame's samples)
         for (int i = 0; i < (host_has_slid ? N - 1 : N); i++) {
@@ -735,13 +747,14 @@ int leave_resident(isv_estimator *e, bool host_has_slid) {
         }
         s.pose_prior = s.wpp; s.vb_prior = s.wvb; s.relpose = s.wrel;
         s.rollpitch.assign(s.wrp.begin(), s.wrp.begin() + w.n_rollpitch);
-        for (size_t i = 0; i < s.tracks.size(); i++) { s.tracks[i].depth = dep[i]; s.tracks[i].solve_flag = fl[i]; }
+        for (size_t i = 0; i < ntr; i++) { s.tracks[i].depth = dep[i]; s.tracks[i].solve_flag = fl[i]; }
         s.resident = false;
     }
     e->resident_ready = false;
     return ISV_OK;
 }
 
+#define RESIDENT_FELL_BACK (-1000)      // resident_frame: the frame did not fit the resident path; the windows are back on the host
 // one lock-step frame of the resident sequences: only what is new crosses PCIe (include/isvins_backend.h)
 int resident_frame(isv_estimator *e, std::vector<std::string> &errs) {
     const int S = (int)e->seq.size();
@@ -749,6 +762,7 @@ int resident_frame(isv_estimator *e, std::vector<std::string> &errs) {
     std::vector<isv_seq_frame_t> fr(S);
     std::vector<isv_seq_result_t> res(S);
     std::vector<int32_t *> flags(S);
+    std::vector<char> fits(S, 1);
     int rc = parallel_for(S, errs, [&](int si, std::string &err) {
         Sequence &s = e->seq[si];
         const int N = s.N;
@@ -756,14 +770,18 @@ int resident_frame(isv_estimator *e, std::vector<std::string> &errs) {
         std::memset(&f, 0, sizeof(f));
         f.prev_slide = s.last_slide;
         f.n_tracks = (int32_t)s.tracks.size();
+        if (!s.pre[N - 1] || (s.last_slide == 2 && !s.pre[N - 2])) { err = "a window frame has no pre-integration (no IMU samples were fed)"; return (int)ISV_ERR_INVALID_ARG; }
+        // (from here on the host state changes.  A window that does not fit the resident store or the per-window
+        //  kernels is NOT an error -- the re-upload path solves it -- so the limits only mark the frame for the fall-back below;
+        //  the tracks this call appends are remembered so that the device's shorter list can be brought back consistently)
+        s.tracks_before = (int)s.tracks.size();
         s.margin_old = add_features(s, e->p.min_parallax, true);
         s.Headers[s.frame_count] = s.staged_header;
-        s.staged = false;
-        if ((int)s.tracks.size() > e->tracks_cap) { err = "more tracks than the resident store holds (isv_estimator_set_resident)"; return (int)ISV_ERR_CAPACITY; }
+        s.staged = false; s.features_added = true;
+        if ((int)s.tracks.size() > e->tracks_cap) fits[si] = 0;
         f.margin_old = s.margin_old ? 1 : 0;
         f.n_obs = (int32_t)s.frame_obs.size(); f.obs = s.frame_obs.data();
-        for (const isv_seq_obs_t &o : s.frame_obs) if (o.slot >= e->tracks_cap) { err = "track storage slot beyond the resident store"; return (int)ISV_ERR_CAPACITY; }
-        if (!s.pre[N - 1] || (s.last_slide == 2 && !s.pre[N - 2])) { err = "a window frame has no pre-integration (no IMU samples were fed)"; return (int)ISV_ERR_INVALID_ARG; }
+        for (const isv_seq_obs_t &o : s.frame_obs) if (o.slot >= e->tracks_cap) fits[si] = 0;
         if (s.last_slide == 2) { s.frame_imu[0] = s.pre[N - 2]->pod; s.frame_imu[1] = s.pre[N - 1]->pod; f.n_imu = 2; }
         else { s.frame_imu[0] = s.pre[N - 1]->pod; f.n_imu = 1; }
         f.imu = s.frame_imu;
@@ -775,15 +793,29 @@ int resident_frame(isv_estimator *e, std::vector<std::string> &errs) {
         for (size_t i = 0; i < s.tracks.size(); i++)
             if (s.tracks[i].n >= 2 && s.tracks[i].start_frame < s.Nvo) { s.good.push_back((int)i); n_obs += s.tracks[i].n; }
         f.n_landmarks = (int32_t)s.good.size(); f.n_factors = (int32_t)(n_obs - (int64_t)s.good.size());
-        if (f.n_landmarks > e->p.cfg.max_landmarks || n_obs > e->p.cfg.max_obs) { err = "window exceeds the landmark / observation capacity"; return (int)ISV_ERR_CAPACITY; }
+        if (f.n_landmarks > e->p.cfg.max_landmarks || n_obs > e->p.cfg.max_obs) fits[si] = 0;      // (the host path reports it, as it always did)
         s.frame_flags.assign(std::max<size_t>(s.good.size(), 1), 0);
         flags[si] = s.frame_flags.data();
         return (int)ISV_OK;
     });
     if (rc != ISV_OK) { e->err = errs[0]; return rc; }
     const auto tr1 = std::chrono::steady_clock::now();
-    rc = isv_backend_seq_frame(e->backend, S, fr.data(), res.data(), flags.data(), nullptr);
+    bool fit_all = true;
+    for (int si = 0; si < S; si++) fit_all &= fits[si] != 0;
+    {
+        const char *ff = getenv("ISV_DEBUG_SEQ_UNSUPPORTED_FRAME");   // (test hook, read per frame: this resident frame "does not fit")
+        if (ff && !e->dbg_fell_back && e->resident_frames == atoi(ff)) { fit_all = false; e->dbg_fell_back = true; }      // (once)
+    }
+    // isv_backend_seq_frame refuses a frame BEFORE it launches anything (capacity, or windows the per-window kernels do not take):
+    // the device still holds the state of the previous solve
+    rc = fit_all ? isv_backend_seq_frame(e->backend, S, fr.data(), res.data(), flags.data(), nullptr) : (int)ISV_ERR_UNSUPPORTED;
+    if (rc == ISV_ERR_CAPACITY || rc == ISV_ERR_UNSUPPORTED) {
+        const int rcl = leave_resident(e, true, true);
+        if (rcl != ISV_OK) return rcl;
+        return RESIDENT_FELL_BACK;                   // isv_estimator_step goes on with the host path for this frame (the features are in)
+    }
     if (rc != ISV_OK) { e->err = std::string("resident frame failed: ") + isv_backend_last_error(e->backend); return rc; }
+    for (Sequence &s : e->seq) s.features_added = false;
     const auto tr2 = std::chrono::steady_clock::now();
     e->resident_frames++;
     bool failed = false;
@@ -859,23 +891,38 @@ extern "C" int isv_estimator_step(isv_estimator_t *e) {
     if (e->resident_ready) {
         bool all = true;
         for (const Sequence &s : e->seq) all &= s.staged && s.resident && s.flag == NON_LINEAR;
-        if (all) {
+        // the resident store's own limits, checked BEFORE anything is mutated (an upper bound: every staged id taken as a new track)
+        bool fits = true;
+        for (const Sequence &s : e->seq) {
+            const size_t fresh = s.staged_image.size() > s.free_slots.size() ? s.staged_image.size() - s.free_slots.size() : 0;
+            fits &= s.tracks.size() + s.staged_image.size() <= (size_t)e->tracks_cap && s.pool.size() / POINT_RING + fresh <= (size_t)e->tracks_cap;
+        }
+        {
+            const char *ff = getenv("ISV_DEBUG_SEQ_PRECHECK_FAIL_FRAME");     // (test hook, read per frame)
+            if (ff && !e->dbg_fell_back && e->resident_frames == atoi(ff)) { fits = false; e->dbg_fell_back = true; }      // (once)
+        }
+        if (all && fits) {
             const int rc = resident_frame(e, errs);        // (fills step_ms[1] host preparation, [4] hand-over + device, [5] read-back + slide)
             e->step_ms[0] = ms(t0, clk::now());
-            return rc;
+            if (rc != RESIDENT_FELL_BACK) return rc;
+            // the frame did not fit the resident path: the windows are back, this frame's features are already in the track lists
+        } else {
+            const int rc = leave_resident(e, true);    // lock step broken (a sequence without an image this frame) or the store is full:
+            if (rc != ISV_OK) return rc;               // the host path takes over (and seeds again once every sequence solves in one frame)
         }
-        const int rc = leave_resident(e, true);    // lock step broken (a sequence without an image this frame): the host path takes over
-        if (rc != ISV_OK) return rc;               // (and seeds again once every sequence solves in the same frame)
     }
     // per sequence: addFeatureAndCheckParallax, Headers, the INITIAL bookkeeping; mark[si] = 1 when the sequence solves
     std::vector<char> mark(e->seq.size(), 0);
     int rc = parallel_for((int)e->seq.size(), errs, [&](int si, std::string &err) {
         Sequence &s = e->seq[si];
-        if (!s.staged) return (int)ISV_OK;
+        if (!s.staged && !s.features_added) return (int)ISV_OK;
         if (s.flag == INITIAL && s.frame_count == s.N - 1 && !s.have_boot) { err = "the window is full: isv_estimator_set_bootstrap first"; return (int)ISV_ERR_INVALID_ARG; }
-        s.margin_old = add_features(s, e->p.min_parallax);
-        s.Headers[s.frame_count] = s.staged_header;
-        s.staged = false;
+        if (!s.features_added) {                   // (else: the resident path ran addFeatureAndCheckParallax for this image before it fell back)
+            s.margin_old = add_features(s, e->p.min_parallax);
+            s.Headers[s.frame_count] = s.staged_header;
+            s.staged = false;
+        }
+        s.features_added = false;
         if (s.flag == INITIAL) {
             if (s.frame_count == s.N - 1) {
                 s.Ps = s.boot_P; s.Rs = s.boot_R; s.Vs = s.boot_V;       // in place of initialStructure()

@@ -20,6 +20,9 @@ __global__ void k_cost_reduce(DevBatch d, const double *fcost, const double *imu
 // kernel VARIANT of a launch is then chosen from these and the uploaded batch: see isv_solver_enqueue)
 struct SolverHost {
     int n_cus = 0;                    // compute units of the handle's device
+    size_t cap_batch = 0;             // the handle's max_batch: kernel VARIANTS whose results differ in the last bits (k_build_solve_st, the split
+                                      // elimination, the one-launch MargBackward) are chosen from it, never from the uploaded batch size, so a
+                                      // window gives the same bits alone and inside any batch of the same handle
     int dogleg_per_cu_regs = 0;       // workgroups of k_dogleg<true, EX> per CU by registers (the LDS bound is applied per enqueue)
     bool one_stream = false;          // ISV_ONE_STREAM: diagnostics, everything on one stream
     bool split_control = false;       // ISV_SPLIT_CONTROL: k_dogleg<false> + k_step_control

@@ -798,6 +798,7 @@ int isv_solver_alloc(DevBatch &d, SolverHost &hc, size_t B, size_t L, size_t F, 
     const bool can_split = d.lds_T && !d.est_ex && !hc.no_split && ((size_t)d.max_lm + 63) / 64 >= ISV_SPLIT_MIN_PASSES && hc.n_cus > ISV_SPLIT_MIN_PASSES;
     if (d.lds_T && (sw_global || hc.debug_sw_global || can_split)) TRYA(dal(&d.sw_part, B * n_pairs * 84, allocs, err));
     hc.sw_global_ok = sw_global || hc.debug_sw_global;
+    hc.cap_batch = B;
     // k_build_solve_st (isv_build_solve_st.hip): a quarter (N <= 11) / half of a CU's LDS per window, 256 threads.  It wins when
     // the batch fills the GPU more than twice over with k_build_solve_sb's two (one) windows per CU; a window alone on a CU is
     // faster with the 512-thread kernel.  The choice is per HANDLE (its max_batch): a window gives the same bits alone and in any
@@ -921,7 +922,7 @@ int isv_solver_enqueue(DevBatch &d, const SolverHost &hc, hipStream_t st, hipStr
         PROF(slot, 0, 1);
         // a SMALL batch with LONG windows: one window's elimination over many CUs (k_schur_split + k_schur_fold, isv_sweep.hip)
         const int Pmax = (d.lg_lcap + 63) / 64, GrMax = Pmax < ISV_SPLIT_MAX_GROUPS ? Pmax : ISV_SPLIT_MAX_GROUPS;
-        const bool split = d.lds_T && d.r1_part && !hc.no_split && Pmax >= ISV_SPLIT_MIN_PASSES && (size_t)d.B * (GrMax + 1) <= (size_t)n_cus;
+        const bool split = d.lds_T && d.r1_part && !hc.no_split && Pmax >= ISV_SPLIT_MIN_PASSES && hc.cap_batch * (size_t)(GrMax + 1) <= (size_t)n_cus;     // (per handle: its max_batch, not this upload's size)
         d.bs_split = split ? 1 : 0;
         if (split) {
             int Gs = 0;
@@ -1039,7 +1040,7 @@ int isv_solver_enqueue(DevBatch &d, const SolverHost &hc, hipStream_t st, hipStr
     // eigen-decomposition (B = 1 / 64 / 256 / 512: 1.95 / 2.27 / 2.47 / 3.16 ms against 1.98 / 2.35 / 2.55 / 3.25); once
     // every SIMD holds a window the phase is instruction-issue bound and the two forms tie (B = 1024: 5.75 ms either way);
     // beyond that the one launch is kept
-    const bool marg_one = hc.marg_one_kernel || (!hc.marg_split && d.B > 3 * hc.n_cus);
+    const bool marg_one = hc.marg_one_kernel || (!hc.marg_split && hc.cap_batch > 3 * (size_t)hc.n_cus);     // (per handle: the two forms sum their convergence test in different orders)
     if (marg_one) hipLaunchKernelGGL(k_marg_bwd<2>, dim3(d.B), dim3(64), 0, st, d);
     else {
         hipLaunchKernelGGL(k_marg_bwd<0>, dim3(d.B), dim3(64), 0, st, d);

@@ -101,7 +101,7 @@ def test_batch_beyond_one_resident_round_of_the_control_kernel(oracle):
     """the library picks kernel VARIANTS from the batch size -- eight-wavefront k_lin_gram while B <= CUs, the step
     control inside k_dogleg<true> while B fits one resident round of it (4 per CU), k_dogleg<false> + k_step_control beyond.
     1100 short windows of the benchmark's shape cross both thresholds: every sampled window is bitwise the same window
-    solved in a batch of four (the small-batch variants), and a sample is compared with the oracle."""
+    solved in a batch of four ON THE SAME HANDLE (the small-batch variants), and a sample is compared with the oracle."""
     ids = list(range(2000, 3100))
     ws = synth.make_windows(ids, n_frames=11, n_vo=5, n_landmarks=16)
     cap = dict(max_landmarks=16, max_obs=max(w.n_obs for w in ws))
@@ -116,11 +116,21 @@ def test_batch_beyond_one_resident_round_of_the_control_kernel(oracle):
             check_window(o, so, gs[k], sums[k])
             check_marg(mo, margs[k], 5)
         for k0 in (0, 300, 1096):
+            # the same HANDLE, a batch of four: the small-batch launch variants (eight-wavefront k_lin_gram, the step control inside
+            # k_dogleg<true>) -- bitwise.  (Round 4: kernels whose sums differ in the last bits -- k_build_solve_st, the one-launch
+            # MargBackward -- are chosen per handle from its max_batch, never from the uploaded batch size.)
             ref = [w.clone() for w in ws[k0: k0 + 4]]
-            small.optimize_batch(ref)
-            assert small.last_counts()[5] == 1
+            big.optimize_batch(ref)
+            assert big.last_counts()[5] == 1 and big.last_counts()[6] == 1
             for a, c in zip(gs[k0: k0 + 4], ref):
                 assert np.array_equal(a.state_vector(), c.state_vector())
+            # a four-window handle runs k_build_solve_sb: same control flow, states to rounding
+            ref2 = [w.clone() for w in ws[k0: k0 + 4]]
+            s2, _ = small.optimize_batch(ref2)
+            assert small.last_counts()[5] == 1 and small.last_counts()[6] == 0
+            for k, (a, c) in enumerate(zip(gs[k0: k0 + 4], ref2)):
+                assert s2[k].iterations == sums[k0 + k].iterations
+                assert np.abs(a.state_vector() - c.state_vector()).max() < 1e-7
     finally:
         big.close(); small.close()
 

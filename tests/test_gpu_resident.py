@@ -107,3 +107,68 @@ def test_a_failed_solve_in_resident_mode_falls_back_and_recovers(monkeypatch):
     assert est.resident_frames() > n_frames - (N - 1) - 8
     est.set_resident(False); ref.set_resident(False)
     est.close(); ref.close()
+
+
+@pytest.mark.parametrize("hook", ["ISV_DEBUG_SEQ_PRECHECK_FAIL_FRAME", "ISV_DEBUG_SEQ_UNSUPPORTED_FRAME"])
+def test_a_frame_that_does_not_fit_the_resident_path_takes_the_host_path(monkeypatch, hook):
+    """a window that trips a resident-only limit (track store full: checked BEFORE the host state changes; or the
+    backend refuses the frame -- capacity, > 8192 factors -- AFTER addFeatureAndCheckParallax has run) must be solved by the
+    re-upload path, not kill the estimator: the windows come back (the device holds the track list without this frame's new
+    tracks), the host path solves the frame, and the windows are seeded again.  Both injected at the 12th resident frame; the
+    re-upload path is bitwise the resident one, so the trajectories equal an undisturbed resident run's bit for bit."""
+    from isvins_amd import estimator as E
+    N, Nvo, seeds, n_frames = 11, 5, (0, 3), 50
+    cfg = abi.make_config(N, Nvo, max_landmarks=800, max_obs=800 * N, max_batch=2)
+    ref = E.SequenceEstimator(sh.estimator_params(cfg), 2)
+    ref.set_resident(True)
+    sh.run_sequences_native(ref, N, n_frames, seeds)
+    monkeypatch.setenv(hook, "12")
+    est = E.SequenceEstimator(sh.estimator_params(cfg), 2)
+    est.set_resident(True)
+    sh.run_sequences_native(est, N, n_frames, seeds)
+    monkeypatch.delenv(hook)
+    for s in range(2):
+        assert est.failed_solves(s) == 0
+        assert np.array_equal(ref.trajectory(s, 1), est.trajectory(s, 1))
+    assert ref.resident_frames() - 4 <= est.resident_frames() < ref.resident_frames()      # one frame on the host path, then resident again
+    est.set_resident(False); ref.set_resident(False)
+    for s in range(2):
+        wa, wb = ref.window(s), est.window(s)
+        for k in ("Ps", "Rs", "Vs", "Bas", "Bgs"):
+            assert np.array_equal(wa[k], wb[k]), k
+    est.close(); ref.close()
+
+
+def test_duplicate_feature_ids_in_one_image_keep_the_first_observation():
+    """the reference's image map keeps every observation of an id and processImage reads the first (feature_manager.cpp:64-66);
+    a duplicate must not reach the resident track store (one observation per track and frame): resident and re-upload runs with a
+    duplicated id in every image equal the run without duplicates"""
+    from isvins_amd import estimator as E
+    N, Nvo, n_frames = 11, 5, 30
+    cfg = abi.make_config(N, Nvo, max_landmarks=800, max_obs=800 * N, max_batch=1)
+    outs = []
+    for dup, resident in ((False, True), (True, True), (True, False)):
+        sim = sh.Simulator(0)                        # (a fresh one per run: frame() draws the pixel noise)
+        est = E.SequenceEstimator(sh.estimator_params(cfg), 1)
+        est.set_resident(resident)
+        for i in range(n_frames):
+            if i > 0:
+                imu = sim.imu_between(i)
+                est.process_imu_n(0, [x[0] for x in imu], [x[1] for x in imu], [x[2] for x in imu])
+            else:
+                G = np.array([0, 0, 9.81007])
+                est.process_imu_n(0, [sim.frame_dt / sim.k], [sim.traj.R(0).T @ (sim.traj.acc(0) + G) + sim.ba], [sim.traj.gyro(0) + sim.bg])
+            t, image = sim.frame(i)
+            st = est.status(0)
+            if st["solver_flag"] == 0 and st["frame_count"] == N - 1:
+                P, R, V = sim.truth_window(i, N)
+                est.set_bootstrap(0, P, R, V)
+            ids = list(image.keys()); pts = [image[k] for k in ids]
+            if dup and len(ids) > 3:
+                ids = ids + [ids[1], ids[2]]; pts = pts + [np.array(pts[1]) + 0.25, np.array(pts[2]) - 0.25]      # second observations: must be ignored
+            est.push_image(0, t, np.array(ids, np.int32), np.array(pts, float).reshape(-1, 3))
+            est.step()
+        outs.append(est.trajectory(0, 1))
+        est.close()
+    assert len(outs[0]) > 10
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
