@@ -23,7 +23,8 @@
 #include "isv_kernels.h"
 #include "isv_device_math.h"
 
-#define LT 256                     // threads (4 wavefronts)
+// threads per window: 256 (4 wavefronts; four workgroups per CU) for N <= 11, 512 (8 wavefronts; two per CU) for long windows
+#define ST_THREADS(BIG) ((BIG) ? 512 : 256)
 #ifdef ISV_STAMP
 #define STSTAMP(k) do { if (t_outer == 0) { unsigned long long now_ = wall_clock64(); st_acc[k] += now_ - t_last; t_last = now_; } } while (0)
 #else
@@ -49,6 +50,10 @@ DEV double st_rsqrt(double x) {    // 1/sqrt(x) to ~1 ulp: hardware estimate + t
     return r;
 }
 #define ST_WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+// a block barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding GLOBAL store of the wavefront (its
+// release fence covers all address spaces), i.e. for the acknowledgement of the chain pipeline's spills -- a memory round trip per
+// chain node on the critical path.  Used where no wavefront reads global data another one wrote since the last full barrier.
+#define ST_LDS_BARRIER() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local"); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local"); } while (0)
 #define ST_IDS() int t = t_outer; asm volatile("" : "+v"(t)); const int lane = t & 63; (void)lane
 
 // Factor the BS x BS SPD block at A (row-major, lower part valid) in registers and overwrite it with the INVERSE of its
@@ -110,10 +115,12 @@ size_t build_solve_st_bytes(int N, int prior_H_sz) {
     return (4 * n + 32 + 32 + 2 + ((size_t)N * (N + 1) / 2 + 3) / 4 + 1 + 20 + nS + (size_t)st_work_doubles(N, prior_H_sz) + 2) * sizeof(double);
 }
 
-// BIG = false: four workgroups per CU (<= 128 VGPRs); BIG = true: two per CU (long windows, N <= 20).
+// BIG = false: 256 threads, four workgroups per CU; BIG = true: 512 threads, two per CU (long windows, N <= 18): 16 wavefronts per CU
+// and <= 128 VGPRs either way.
 // NC: compile-time window length (0 = d.N).
 template <bool BIG, int NC>
-__global__ __launch_bounds__(LT, BIG ? 2 : 4) void k_build_solve_st(DevBatch d) {
+__global__ __launch_bounds__(ST_THREADS(BIG), 4) void k_build_solve_st(DevBatch d) {
+    constexpr int LT = ST_THREADS(BIG), NW = LT / 64;
     extern __shared__ __align__(16) double lds[];
     const int w = blockIdx.x, t_outer = threadIdx.x;
     SolveState &st = d.st[w];
@@ -418,7 +425,7 @@ __global__ __launch_bounds__(LT, BIG ? 2 : 4) void k_build_solve_st(DevBatch d) 
                             }
                         }
                     }
-                } else {
+                } else if (q < 324) {                           // (512-thread instantiation: the threads beyond the 324 entries idle here)
                     const int b3 = (q - 162) / 54, rc = (q - 162) - 54 * b3, r = rc / 9, c = rc - 9 * r;
                     for (int i0 = 0; i0 < N; i0 += 4) {
                         double raw[4];
@@ -440,7 +447,7 @@ __global__ __launch_bounds__(LT, BIG ? 2 : 4) void k_build_solve_st(DevBatch d) 
                     }
                 }
             }
-            {   // entries 256 .. 323 of every node (the tail of its pose x speed/bias blocks), item-wise over all threads
+            if constexpr (LT < 324) {   // entries 256 .. 323 of every node (the tail of its pose x speed/bias blocks), item-wise over all threads
                 constexpr int TQ = 324 - LT;
                 const int nitems = N * TQ;
                 for (int it0 = t; it0 < nitems; it0 += 4 * LT) {
@@ -471,7 +478,7 @@ __global__ __launch_bounds__(LT, BIG ? 2 : 4) void k_build_solve_st(DevBatch d) 
             for (int off = 32; off > 0; off >>= 1) accq += __shfl_xor(accq, off);
             if ((t & 63) == 0) red[t >> 6] = accq;
             __syncthreads();
-            if (t == 0) st.qT = (red[0] + red[1]) + (red[2] + red[3]);
+            if (t == 0) st.qT = BIG ? ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7])) : (red[0] + red[1]) + (red[2] + red[3]);
         }
         __syncthreads();                                           // u and the staged priors are dead: the work area becomes the chain buffers
         STSTAMP(3);
@@ -609,7 +616,9 @@ __global__ __launch_bounds__(LT, BIG ? 2 : 4) void k_build_solve_st(DevBatch d) 
                         y[15 * (lo + a) + r] -= s;
                     }
                     // Spp -= Y_j' Y_j'^T: this node's rows of Ybuf are the panel (9 columns)
-                    yyt_tiles([&](int row) { return (s0 * 6 + row) * 9; }, Ybuf, 6 * nr, 9, lo, 0, 1, deferM, lane);
+                    // (long windows: wavefronts 4 .. 7 do this two nodes behind, from the spilled Y' -- ten tiles of a 60-row node on this
+                    //  wavefront made IT the chain's critical path: 7 us per node against 3.5 us for the factorisation)
+                    if constexpr (!BIG) yyt_tiles([&](int row) { return (s0 * 6 + row) * 9; }, Ybuf, 6 * nr, 9, lo, 0, 1, deferM, lane);
                 }
                 if (last) return;
                 ST_WSYNC();
@@ -635,7 +644,7 @@ __global__ __launch_bounds__(LT, BIG ? 2 : 4) void k_build_solve_st(DevBatch d) 
                 if (wv < 2) {
                     const int cnt = wv == 0 ? cntF : cntB;
                     if (k < cnt) crit(wv, wv == 0 ? k : N - 1 - k);
-                } else {
+                } else if (wv < 4) {
                     const int ch = wv - 2, cnt = ch == 0 ? cntF : cntB, kk = k - 1;
                     // requests: D two nodes ahead of the critical path (k + 2; the forward ring also carries D_M), the coupling of the next
                     // node (k + 1), and the own blocks of the node whose fill this step forms (the parent of kk)
@@ -674,8 +683,67 @@ __global__ __launch_bounds__(LT, BIG ? 2 : 4) void k_build_solve_st(DevBatch d) 
                         if (e < 81) { if (needD) Dslot(ch, iD)[e] = pD[q]; if (needC) Cslot(ch, iC)[e] = pC[q]; }
                     }
                 }
-                __syncthreads();
+                if constexpr (BIG) {
+                    if (wv >= 4) {
+                        // Spp -= Y_j' Y_j'^T of the node the lag wavefront finished in the PREVIOUS step (its Y' is in the global scratch,
+                        // column-major: an operand is a coalesced read of 16 consecutive rows); two wavefronts per chain split the tiles.
+                        // The children of M are left to the join (both touch pose block (M, M)).
+                        const int ch = (wv - 4) >> 1, half = (wv - 4) & 1, cnt = ch == 0 ? cntF : cntB, kk = k - 2;
+                        if (kk >= 0 && kk < cnt - 1) {
+                            const int j = ch == 0 ? kk : N - 1 - kk;
+                            const int lo = st_nlo(j, M), nr = st_nhi(j, M, N) - lo + 1, R = 6 * nr;
+                            const double *Yg = gY + yo[j];
+                            const int T = (R + 15) >> 4, ntile = T * (T + 1) / 2;
+                            const int i16 = lane & 15, kq = lane >> 4;
+                            for (int tile = half; tile < ntile; tile += 2) {
+                                int TI = 0;
+                                while ((TI + 1) * (TI + 2) / 2 <= tile) TI++;
+                                const int TJ = tile - TI * (TI + 1) / 2;
+                                const int ra = 16 * TI + i16, rb = 16 * TJ + i16;
+                                double av[3], bv[3];
+#pragma unroll
+                                for (int s4 = 0; s4 < 3; s4++) {          // (clamped, unconditional loads; masked by multiplication)
+                                    const int kcol = 4 * s4 + kq, kc = kcol < 9 ? kcol : 8;
+                                    av[s4] = Yg[kc * R + (ra < R ? ra : R - 1)]; bv[s4] = Yg[kc * R + (rb < R ? rb : R - 1)];
+                                }
+                                st_double4 acc = {0, 0, 0, 0};
+#pragma unroll
+                                for (int s4 = 0; s4 < 3; s4++) {
+                                    const double mk = 4 * s4 + kq < 9 ? 1.0 : 0.0;
+                                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s4] * (ra < R ? mk : 0.0), bv[s4] * (rb < R ? mk : 0.0), acc, 0, 0, 0);
+                                }
+#pragma unroll
+                                for (int reg = 0; reg < 4; reg++) {
+                                    const int Rr = 16 * TI + kq + 4 * reg, Cc = 16 * TJ + i16;
+                                    if (Rr < R && Cc <= Rr) {
+                                        const int pI = Rr / 6, r = Rr - 6 * pI, pJ = Cc / 6, c = Cc - 6 * pJ;
+                                        Spp[st_sblk(lo + pI, lo + pJ, N) + r * 6 + c] -= acc[reg];
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+                // (short windows: inside the loop nobody reads global data written inside it -- the spills are read after the loop, the
+                //  prefetched blocks were written before it -- so the per-node barrier orders LDS only; long windows: the tile wavefronts
+                //  read the previous step's spills, a full barrier)
+                if constexpr (BIG) __syncthreads(); else ST_LDS_BARRIER();
                 if (flag[0]) break;
+            }
+            __syncthreads();
+            if constexpr (BIG) {
+                // (every non-child node got its tiles inside the loop: node cnt - 2 in step cnt.)  The children of M: straight from Ybuf,
+                // where their Y' still lie, with all wavefronts; forward child, then the backward one (it leaves block (M, M) to the join)
+                if (!flag[0]) {
+                    for (int ch = 0; ch < 2; ch++) {
+                        const int cnt = ch == 0 ? cntF : cntB;
+                        if (cnt >= 1) {
+                            const int j = ch == 0 ? M - 1 : M + 1, lo = st_nlo(j, M), nr = st_nhi(j, M, N) - lo + 1, s0 = lo + ch;
+                            yyt_tiles([&](int row) { return (s0 * 6 + row) * 9; }, Ybuf, 6 * nr, 9, lo, wv, NW, ch == 1, lane);
+                        }
+                        __syncthreads();
+                    }
+                }
             }
         }
         STSTAMP(4);
@@ -807,7 +875,7 @@ __global__ __launch_bounds__(LT, BIG ? 2 : 4) void k_build_solve_st(DevBatch d) 
                     for (int kk = 0; kk < 9; kk++) s += Yr[kk] * zi[kk];
                     y[15 * a + r] -= s;
                 }
-                yyt_tiles([&](int row) { const int pz = row / 6; return (slotM(pz) * 6 + (row - 6 * pz)) * 9; }, Ybuf, 6 * N, 9, 0, wv, 4, false, lane);
+                yyt_tiles([&](int row) { const int pz = row / 6; return (slotM(pz) * 6 + (row - 6 * pz)) * 9; }, Ybuf, 6 * N, 9, 0, wv, NW, false, lane);
                 __syncthreads();
             }
         }
@@ -965,12 +1033,14 @@ __global__ __launch_bounds__(LT, BIG ? 2 : 4) void k_build_solve_st(DevBatch d) 
         __syncthreads();
         // chains, reverse elimination order: x_i = L_i^-T (z_i - C_i'^T x_parent).  Wavefront 0: M, then the forward chain downwards;
         // wavefront 1 (after M): the backward chain upwards.
-        if constexpr (!BIG) {
-            // short windows: every node's C_i' and L_i^-1 come back from the global scratch into the (dead) chain buffers with ONE
-            // coalesced sweep (162 N doubles fit the work area up to N = 11: st_work_doubles), then the nodes run out of LDS
+        {
+            // every node's C_i' and L_i^-1 come back from the global scratch with ONE coalesced sweep -- into the (dead) chain buffers
+            // (162 N doubles fit them up to N = 11: st_work_doubles), or, for long windows, over the pose blocks: the pose system's
+            // factor is dead once x_pose is known -- then the nodes run out of LDS
             ST_IDS();
-            double *sDi = work, *sC = work + 81 * N;
-            for (int e = t; e < 162 * N; e += LT) work[e] = ws[e];          // gDinv | gC are contiguous in the scratch
+            double *stg = BIG ? Spp : work;
+            double *sDi = stg, *sC = stg + 81 * N;
+            for (int e = t; e < 162 * N; e += LT) stg[e] = ws[e];          // gDinv | gC are contiguous in the scratch
             __syncthreads();
             const int cl = lane < 9 ? lane : 0;
             auto node_bwd = [&](int i, int pp) {
@@ -990,56 +1060,6 @@ __global__ __launch_bounds__(LT, BIG ? 2 : 4) void k_build_solve_st(DevBatch d) 
             __syncthreads();
             if (wv == 0) { for (int i = M - 1; i >= 0; i--) node_bwd(i, i + 1); }
             else if (wv == 1) { for (int i = M + 1; i <= N - 1; i++) node_bwd(i, i - 1); }
-        } else {
-            // long windows: a node's columns of C_i' and L_i^-1 from the global scratch into registers ONE NODE AHEAD
-            ST_IDS();
-            const int cl = lane < 9 ? lane : 0;
-            auto fetch18 = [&](int i, double (&cC)[9], double (&cL)[9]) {
-                const int ic = i < 0 ? 0 : (i > N - 1 ? N - 1 : i);
-#pragma unroll
-                for (int k = 0; k < 9; k++) { cC[k] = gC[ic * 81 + k * 9 + cl]; cL[k] = gDinv[ic * 81 + k * 9 + cl]; }
-            };
-            auto node_bwd = [&](int i, int pp, const double (&cC)[9], const double (&cL)[9]) {
-                double sv = y[15 * i + 6 + cl];
-                if (pp >= 0) {
-#pragma unroll
-                    for (int k = 0; k < 9; k++) sv -= cC[k] * y[15 * pp + 6 + k];
-                }
-                double x = 0;
-#pragma unroll
-                for (int k = 0; k < 9; k++) x += cL[k] * st_readlane(sv, k);
-                ST_WSYNC();
-                if (lane < 9) y[15 * i + 6 + lane] = x;
-                ST_WSYNC();
-            };
-            double cCa[9], cLa[9], cCb[9], cLb[9];
-            if (wv == 0) {
-                fetch18(M, cCa, cLa);
-                if (M >= 1) fetch18(M - 1, cCb, cLb);
-                node_bwd(M, -1, cCa, cLa);
-            } else if (wv == 1) {
-                if (M + 1 <= N - 1) fetch18(M + 1, cCa, cLa);
-            }
-            __syncthreads();
-            if (wv == 0) {
-                for (int i = M - 1; i >= 0; i -= 2) {           // two register sets alternate (b holds M - 1)
-                    if (i - 1 >= 0) fetch18(i - 1, cCa, cLa);
-                    node_bwd(i, i + 1, cCb, cLb);
-                    if (i - 1 >= 0) {
-                        if (i - 2 >= 0) fetch18(i - 2, cCb, cLb);
-                        node_bwd(i - 1, i, cCa, cLa);
-                    }
-                }
-            } else if (wv == 1) {
-                for (int i = M + 1; i <= N - 1; i += 2) {
-                    if (i + 1 <= N - 1) fetch18(i + 1, cCb, cLb);
-                    node_bwd(i, i - 1, cCa, cLa);
-                    if (i + 1 <= N - 1) {
-                        if (i + 2 <= N - 1) fetch18(i + 2, cCa, cLa);
-                        node_bwd(i + 1, i, cCb, cLb);
-                    }
-                }
-            }
         }
         __syncthreads();
         STSTAMP(7);
@@ -1068,10 +1088,10 @@ __global__ __launch_bounds__(LT, BIG ? 2 : 4) void k_build_solve_st(DevBatch d) 
         for (int off = 32; off > 0; off >>= 1) { cpart += __shfl_xor(cpart, off); m = fmax(m, __shfl_xor(m, off)); }
         if (lane == 0) { red[wv] = cpart; red[8 + wv] = m; }
         __syncthreads();
-        cost_w = (red[0] + red[1]) + (red[2] + red[3]);
+        cost_w = BIG ? ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7])) : (red[0] + red[1]) + (red[2] + red[3]);
         if (t == 0) {
             double mm = red[8];
-            for (int k = 1; k < 4; k++) mm = fmax(mm, red[8 + k]);
+            for (int k = 1; k < NW; k++) mm = fmax(mm, red[8 + k]);
             d.cost[w] = cost_w;
             red[16] = mm;
         }

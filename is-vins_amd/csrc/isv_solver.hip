@@ -809,10 +809,10 @@ int isv_solver_alloc(DevBatch &d, SolverHost &hc, size_t B, size_t L, size_t F, 
         const bool fits = d.lds_T && (d.N <= 11 ? lds_st <= 40 * 1024 : lds_st <= 80 * 1024);
         const char *e = getenv("ISV_SOLVE_ST");
         const size_t per_cu_sb = d.N <= 11 ? 2 : 1;
-        // (measured, 1024 windows: N = 11: 180 -> 146 us per launch, 182 -> 190-193 k windows/s; 512 windows: 3.55 against 3.22 ms, so
-        //  only batches beyond two resident rounds take it; N = 18: 10.98 against 11.09 ms per step -- within the noise, its lag
-        //  wavefronts carry two-trip rows and ten tiles per node: long windows stay on k_build_solve_sb unless ISV_SOLVE_ST=1 forces it)
-        hc.solve_st = fits && (e ? atoi(e) != 0 : (d.N <= 11 && B > per_cu_sb * (size_t)hc.n_cus));
+        // (measured: N = 11, 1024 windows: 180 -> 146 us per launch, 182 -> 190-193 k windows/s, 512 windows: 3.55 against 3.22 ms;
+        //  N = 18 (512 threads, two windows per CU), 1024 windows: 11.09 -> 10.33 ms per step, 512: 5.99 -> 5.61, 256: 3.27 -> 3.68:
+        //  only handles whose batches exceed the resident windows of k_build_solve_sb take it)
+        hc.solve_st = fits && (e ? atoi(e) != 0 : B > per_cu_sb * (size_t)hc.n_cus);
         if (getenv("ISV_DEBUG_PATH")) fprintf(stderr, "isv: k_build_solve_st lds=%zu fits=%d -> solve_st=%d\n", lds_st, (int)fits, (int)hc.solve_st);
         if (hc.solve_st) TRYA(dal(&d.st_ws, B * build_solve_st_ws_doubles(d.N), allocs, err));
     }
@@ -983,7 +983,7 @@ int isv_solver_enqueue(DevBatch &d, const SolverHost &hc, hipStream_t st, hipStr
             const size_t lds_st = build_solve_st_bytes(d.N, d.prior_H_sz);
             if (d.N == 11 && !generic_n) hipLaunchKernelGGL((k_build_solve_st<false, 11>), dim3(d.B), dim3(256), lds_st, st, d);
             else if (d.N <= 11) hipLaunchKernelGGL((k_build_solve_st<false, 0>), dim3(d.B), dim3(256), lds_st, st, d);
-            else hipLaunchKernelGGL((k_build_solve_st<true, 0>), dim3(d.B), dim3(256), lds_st, st, d);
+            else hipLaunchKernelGGL((k_build_solve_st<true, 0>), dim3(d.B), dim3(512), lds_st, st, d);       // (long windows: eight wavefronts, two windows per CU)
         } else if (d.lds_T && generic_n) {
             if (d.N <= 11) hipLaunchKernelGGL((k_build_solve_sb<false, 0>), dim3(d.B), dim3(512), build_solve_sb_bytes(d.N, d.prior_H_sz), st, d);
             else hipLaunchKernelGGL((k_build_solve_sb<true, 0>), dim3(d.B), dim3(512), build_solve_sb_bytes(d.N, d.prior_H_sz), st, d);

@@ -189,12 +189,14 @@ def _join(jobs):
     return res
 
 
-def _native_run(cfg, sim, stream, env=None):
+def _native_run(cfg, sim, stream, env=None, resident=False):
     from isvins_amd import estimator as E
     old = {k: os.environ.get(k) for k in (env or {})}
     os.environ.update(env or {})
     try:
         est = E.SequenceEstimator(sh.estimator_params(cfg), 1)       # (the hooks are read when the handle is created)
+        if resident:
+            est.set_resident(True)                                   # the window stays on the MI355X between frames (isv_sequence.hip)
     finally:
         for k, v in old.items():
             if v is None:
@@ -203,6 +205,8 @@ def _native_run(cfg, sim, stream, env=None):
                 os.environ[k] = v
     rows, per = run_native_side(est, sim, stream)
     assert est.failed_solves(0) == 0
+    if resident:
+        assert est.resident_frames() >= len(rows) - 4                # every frame after the seeding went through the resident path
     est.close()
     return rows, per
 
@@ -226,7 +230,7 @@ def test_euroc_standin_full_length_gpu_vs_oracle(oracle, tmp_path):
     sim, stream = record_stream(N_FRAMES)
     feats = [len(im) for (_, _, im) in stream]
     t1 = time.time()
-    rows, per_g = _native_run(cfg, sim, stream)
+    rows, per_g = _native_run(cfg, sim, stream, resident=True)       # (the free-running side runs DEVICE-RESIDENT, all 2383 frames)
     t2 = time.time()
     # the handle a maintainer's drop-in creates (isvins_estimator_shim.hpp: 1000 landmarks / 18 000 observations / one window):
     # since round 3 the visual path is chosen from the uploaded window, so these 2383 solves run k_lin_gram (counts[4] below)
