@@ -547,7 +547,7 @@ def main():
         bytes_control = Fw * 24.0 + Lw * (24.0 + 24.0) + 3 * 16 * N * 8.0
         flops_bs = bs_flops(N)
         pmc = {}
-        for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
                 break
@@ -566,8 +566,10 @@ def main():
                 r["note"] = note
             return r
 
-        roofs = [roof("k_build_solve_sb", "fp64-valu-latency", flops_bs, bs_ms, n_bs, FP64_PEAK_TFLOPS, "TFLOP/s", 1e12,
-                      "issues NO MFMA: chains of dependent 6x6 / 9x9 FP64 pivots (v_readlane -> rsq -> Newton) in LDS; priced against the FP64 vector peak, which equals the FP64 matrix peak on MI355X"),
+        solve_kernel = "k_build_solve_st" if int(cnt[6]) == 1 else "k_build_solve_sb"
+        roofs = [roof(solve_kernel, "fp64-valu-latency", flops_bs, bs_ms, n_bs, FP64_PEAK_TFLOPS, "TFLOP/s", 1e12,
+                      ("k_build_solve_st (round 4): 256 threads and <= 40 KB of LDS per window, four windows per CU; the speed/bias chain blocks stream through small LDS rings, the pose-block downdates are FP64 MFMA tiles. " if int(cnt[6]) == 1 else "")
+                      + "chains of dependent 6x6 / 9x9 FP64 pivots (v_readlane -> rsq -> Newton) in LDS: latency bound; priced against the FP64 vector peak, which equals the FP64 matrix peak on MI355X"),
                  roof("k_rank1_mfma", "hbm", bytes_rank1, r1_ms, n_sw, HBM_PEAK_GBS, "GB/s", 1e9)]
         if fused:
             roofs.insert(1, roof("k_lin_gram", "hbm", bytes_lingram, lin_ms, n_lin, HBM_PEAK_GBS, "GB/s", 1e9,
@@ -582,7 +584,7 @@ def main():
         else:                  # k_dogleg<true>: the candidate evaluation and the step control run in the same kernel
             roofs.append(roof("k_dogleg", "hbm", bytes_dogleg + bytes_control, dg_ms + sc_ms, args_iters(be), HBM_PEAK_GBS, "GB/s", 1e9,
                               "k_dogleg<true>: back-substitution, dogleg step, candidate costs and TrustRegionMinimizer step control in one kernel"))
-        sums = {"k_build_solve_sb": bs_ms, "k_proj_linearize<0>": lin_ms, "k_lin_gram": lin_ms, "k_sweep_mfma": sw_ms, "k_rank1_mfma": r1_ms, "k_dogleg": dg_ms + (sc_ms if fused_control else 0), "k_step_control": sc_ms}
+        sums = {solve_kernel: bs_ms, "k_proj_linearize<0>": lin_ms, "k_lin_gram": lin_ms, "k_sweep_mfma": sw_ms, "k_rank1_mfma": r1_ms, "k_dogleg": dg_ms + (sc_ms if fused_control else 0), "k_step_control": sc_ms}
         dominant = max(roofs, key=lambda r: sums[r["kernel"]])
         total_w = world * W
         out = {

@@ -75,6 +75,10 @@ const char *isv_pgo_last_error(const isv_pgo_t *h);
 /* measurement: duration of the pose-graph kernel of the last optimize call (HIP events on the handle's stream) and the
  * number of 6x6 skyline blocks its graphs held */
 int  isv_pgo_last_kernel_ms(isv_pgo_t *h, double *ms, double *skyline_blocks);
+/* graphs whose STRUCTURE analysis (parameter blocks, adjacency, skyline, column patterns) was reused from the previous call on the same
+   batch slot since the handle was created: a graph that is optimised again with the same keyframe list (same indices, sequences,
+   roll/pitch and loop flags) only refreshes its numbers.  Results are identical either way. */
+int64_t isv_pgo_structure_cache_hits(const isv_pgo_t *h);
 
 /* One pass of PoseGraph::optimizeCS (src/pose_graph/pose_graph.cpp:246-409) over the keyframe list kf[0..n) (list
  * order, indices increasing): solve, covariances, updatePose / updateCov, the relative-pose update() calls, drift, and

@@ -702,7 +702,22 @@ __global__ __launch_bounds__(64) void k_pgo(PgDev dv) {
 
 // =====================================================================================================================
 // host side
+// the STRUCTURE of one graph slot as the last call analysed it (round 4: PoseGraph::optimizeCS re-optimises a graph that grew by
+// at most one keyframe since the last loop closure; a batch that is optimised again -- the benchmark, a replay -- has the same
+// topology slot by slot): parameter-block map, free indices, adjacency, skyline, column patterns and the edges' integer fields.
+// Keyed by a hash of everything the structure depends on; the numbers (poses, measurements, sqrt_info) are refreshed every call.
+struct PgEdgeTpl { int32_t kind, a, b, fa, fb, dim, robust, src; };     // src: the keyframe whose factor this residual block is
+struct PgStructCache {
+    uint64_t key = 0; bool valid = false;
+    std::vector<int> loc;
+    int cur_pos = -1, n_loops = 0;
+    int32_t P1 = 0, nf = 0, nblk = 0;
+    std::vector<int32_t> free_of, adj_ptr, adj, start, rowptr, colptr, colrows;
+    std::vector<PgEdgeTpl> edges;
+};
 struct isv_pgo {
+    std::vector<PgStructCache> cache;             // [max_graphs]
+    int64_t cache_hits = 0;
     isv_pgo_config_t cfg;
     std::string err;
     int device = 0;
@@ -727,6 +742,7 @@ template <typename T> static int pal(isv_pgo *h, T **p, size_t n) {
 extern "C" const char *isv_pgo_last_error(const isv_pgo_t *h) { return h ? h->err.c_str() : "null handle"; }
 // measurement: duration of k_pgo in the last optimize call (HIP events on the handle's stream) and the number of 6x6 skyline
 // blocks its graphs held
+extern "C" int64_t isv_pgo_structure_cache_hits(const isv_pgo_t *h) { return h ? h->cache_hits : 0; }
 extern "C" int isv_pgo_last_kernel_ms(isv_pgo_t *h, double *ms, double *skyline_blocks) {
     if (!h || !ms || !h->ev[0]) return ISV_ERR_INVALID_ARG;
     float f = 0;
@@ -913,12 +929,58 @@ extern "C" int isv_pgo_optimize_batch(isv_pgo_t *h, int32_t ng, const int32_t *n
     std::vector<GraphBuild> builds(ng);
     std::vector<std::vector<int>> local(ng);
     std::vector<int> cur_pos(ng, -1), n_loops(ng, 0);
+    if (h->cache.size() < (size_t)h->cfg.max_graphs) h->cache.resize((size_t)h->cfg.max_graphs);
+    static const bool no_cache = getenv("ISV_PGO_NO_CACHE") != nullptr;       // (A/B and test hook)
+    std::vector<char> hit(ng, 0);
+    auto fill_edge_numbers = [&](PgEdge &E, const isv_pg_keyframe_t &k) {
+        if (E.kind == 0) { memcpy(E.meas_R, k.rollpitch.R, 72); memcpy(E.sqrt_info, k.rollpitch.sqrt_info, 32); }
+        else if (E.kind == 1) { memcpy(E.meas_t, k.relative_pose.delta_t, 24); memcpy(E.meas_R, k.relative_pose.delta_R, 72); memcpy(E.sqrt_info, k.relative_pose.sqrt_info, 288); }
+        else {
+            memcpy(E.meas_t, k.loop_info, 24);
+            h_q2R(HQ{k.loop_info[3], k.loop_info[4], k.loop_info[5], k.loop_info[6]}, E.meas_R);
+            for (int dd = 0; dd < 6; dd++) E.sqrt_info[dd * 6 + dd] = std::sqrt(k.loop_weight);
+        }
+    };
     auto build_graph = [&](int g) -> int {
         const int n = ns[g]; isv_pg_keyframe_t *kf = kfs[g];
         if (n < 1 || !kf) return ISV_ERR_INVALID_ARG;
         PgGraph &G = graphs[g];
         memset(&G, 0, sizeof(G));
         GraphBuild &B = builds[g];
+        // ---- the cached structure of this slot, when nothing it depends on has changed ----
+        PgStructCache &SC = h->cache[g];
+        uint64_t key = 1469598103934665603ull;
+        auto mix = [&](uint64_t v) { key ^= v + 0x9e3779b97f4a7c15ull + (key << 6) + (key >> 2); };
+        mix((uint64_t)n); mix((uint64_t)(uint32_t)firsts[g]); mix((uint64_t)(uint32_t)curs[g]);
+        for (int k = 0; k < n; k++) {
+            mix(((uint64_t)(uint32_t)kf[k].index << 32) | (uint32_t)kf[k].sequence);
+            mix(((uint64_t)(kf[k].has_rollpitch != 0) << 33) | ((uint64_t)(kf[k].has_loop != 0) << 32) | (uint32_t)(kf[k].has_loop ? kf[k].loop_index : 0));
+        }
+        if (!no_cache && SC.valid && SC.key == key && (int)SC.loc.size() == n) {
+            G.max_iter = h->cfg.max_iterations; G.huber = h->cfg.huber_delta;
+            G.P1 = SC.P1; G.nf = SC.nf; G.nblk = SC.nblk; G.ne = (int32_t)SC.edges.size();
+            local[g] = SC.loc; cur_pos[g] = SC.cur_pos; n_loops[g] = SC.n_loops;
+            B.pose.reserve((size_t)SC.P1 * 7);
+            for (int k = 0; k < n; k++) {
+                if (SC.loc[k] < 0) continue;
+                for (int c = 0; c < 9; c++) if (!(kf[k].vio_R_w_i[c] - kf[k].vio_R_w_i[c] == 0.0)) { B.err = "non-finite keyframe pose"; return ISV_ERR_NONFINITE; }
+                const HQ q = h_qn(h_R2q(kf[k].vio_R_w_i));
+                B.pose.insert(B.pose.end(), {kf[k].vio_T_w_i[0], kf[k].vio_T_w_i[1], kf[k].vio_T_w_i[2], q.x, q.y, q.z, q.w});
+            }
+            B.free_of = SC.free_of; B.adj_ptr = SC.adj_ptr; B.adj = SC.adj; B.start = SC.start; B.rowptr = SC.rowptr; B.colptr = SC.colptr; B.colrows = SC.colrows;
+            B.edges.resize(SC.edges.size());
+            for (size_t e = 0; e < SC.edges.size(); e++) {
+                const PgEdgeTpl &T = SC.edges[e];
+                PgEdge &E = B.edges[e];
+                memset(&E, 0, sizeof(E));
+                E.kind = T.kind; E.a = T.a; E.b = T.b; E.fa = T.fa; E.fb = T.fb; E.dim = T.dim; E.robust = T.robust;
+                fill_edge_numbers(E, kf[T.src]);
+            }
+            hit[g] = 1;
+            return ISV_OK;
+        }
+        SC.valid = false;
+        std::vector<int32_t> edge_src;
         std::vector<double> &pose = B.pose; std::vector<int32_t> &free_of = B.free_of, &adj_ptr = B.adj_ptr, &adj = B.adj, &start = B.start, &rowptr = B.rowptr, &colptr = B.colptr, &colrows = B.colrows;
         std::vector<PgEdge> &edges = B.edges;
         G.max_iter = h->cfg.max_iterations; G.huber = h->cfg.huber_delta;
@@ -965,13 +1027,13 @@ extern "C" int isv_pgo_optimize_batch(isv_pgo_t *h, int32_t ng, const int32_t *n
                 PgEdge E; memset(&E, 0, sizeof(E));
                 E.kind = 0; E.a = E.b = li; E.dim = 2;
                 memcpy(E.meas_R, kf[k].rollpitch.R, 72); memcpy(E.sqrt_info, kf[k].rollpitch.sqrt_info, 32);
-                add_edge(E);
+                add_edge(E); edge_src.push_back(k);
             }
             if (li + 1 <= param_index) {
                 PgEdge E; memset(&E, 0, sizeof(E));
                 E.kind = 1; E.a = li; E.b = li + 1; E.dim = 6;
                 memcpy(E.meas_t, kf[k].relative_pose.delta_t, 24); memcpy(E.meas_R, kf[k].relative_pose.delta_R, 72); memcpy(E.sqrt_info, kf[k].relative_pose.sqrt_info, 288);
-                add_edge(E);
+                add_edge(E); edge_src.push_back(k);
             }
             if (kf[k].has_loop) {
                 int conn = -1;
@@ -982,7 +1044,7 @@ extern "C" int isv_pgo_optimize_batch(isv_pgo_t *h, int32_t ng, const int32_t *n
                 memcpy(E.meas_t, kf[k].loop_info, 24);
                 h_q2R(HQ{kf[k].loop_info[3], kf[k].loop_info[4], kf[k].loop_info[5], kf[k].loop_info[6]}, E.meas_R);
                 for (int dd = 0; dd < 6; dd++) E.sqrt_info[dd * 6 + dd] = std::sqrt(kf[k].loop_weight);
-                add_edge(E);
+                add_edge(E); edge_src.push_back(k);
                 n_loops[g]++;
             }
         }
@@ -997,6 +1059,12 @@ extern "C" int isv_pgo_optimize_batch(isv_pgo_t *h, int32_t ng, const int32_t *n
         for (int i = 0; i < nf; i++) for (int j = st[i]; j < i; j++) cp[j].push_back(i);
         for (int j = 0; j < nf; j++) { colptr.push_back((int32_t)colrows.size()); colrows.insert(colrows.end(), cp[j].begin(), cp[j].end()); }
         colptr.push_back((int32_t)colrows.size());
+        // remember the structure for the next call on this slot
+        SC.key = key; SC.loc = loc; SC.cur_pos = cur_pos[g]; SC.n_loops = n_loops[g]; SC.P1 = G.P1; SC.nf = G.nf; SC.nblk = G.nblk;
+        SC.free_of = free_of; SC.adj_ptr = adj_ptr; SC.adj = adj; SC.start = start; SC.rowptr = rowptr; SC.colptr = colptr; SC.colrows = colrows;
+        SC.edges.resize(edges.size());
+        for (size_t e = 0; e < edges.size(); e++) SC.edges[e] = PgEdgeTpl{edges[e].kind, edges[e].a, edges[e].b, edges[e].fa, edges[e].fb, edges[e].dim, edges[e].robust, edge_src[e]};
+        SC.valid = true;
         return ISV_OK;
     };
     auto parallel_over_graphs = [&](const std::function<void(int)> &fn) {
@@ -1013,6 +1081,7 @@ extern "C" int isv_pgo_optimize_batch(isv_pgo_t *h, int32_t ng, const int32_t *n
     parallel_over_graphs([&](int g) { builds[g].rc = build_graph(g); });
     const auto tp1 = std::chrono::steady_clock::now();
     for (int g = 0; g < ng; g++) if (builds[g].rc != ISV_OK) { if (builds[g].err) h->err = builds[g].err; return builds[g].rc; }
+    for (int g = 0; g < ng; g++) h->cache_hits += hit[g];
     // the batch's arrays live in ONE pinned staging area kept with the handle: no zero-initialised 170 MB vectors per call
     // (a third of a 1024-graph call in round 2), and the copies to and from the device run at the pinned rate
     struct SpanD { double *p = nullptr; size_t n = 0; double *data() const { return p; } size_t size() const { return n; } bool empty() const { return n == 0; } double &operator[](size_t i) const { return p[i]; } };

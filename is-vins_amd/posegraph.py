@@ -34,7 +34,7 @@ class isv_pgo_result_t(C.Structure):
                 ("t_drift", C.c_double * 3), ("trace_cost", C.c_double * ISV_MAX_TRACE), ("trace_accepted", C.c_int32 * ISV_MAX_TRACE)]
 
 
-EXPORTS = ["isv_combined_factors_add", "isv_pgo_create", "isv_pgo_destroy", "isv_pgo_last_error", "isv_pgo_last_kernel_ms", "isv_pgo_optimize",
+EXPORTS = ["isv_combined_factors_add", "isv_pgo_create", "isv_pgo_destroy", "isv_pgo_last_error", "isv_pgo_last_kernel_ms", "isv_pgo_structure_cache_hits", "isv_pgo_optimize",
            "isv_pgo_optimize_batch", "isv_pgo_write_loop_pose_output"]
 
 
@@ -107,6 +107,11 @@ class PoseGraphOptimizer:
         self.lib.isv_pgo_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_double)]
         self._check(self.lib.isv_pgo_last_kernel_ms(self.h, C.byref(ms), C.byref(nb)), "pgo_last_kernel_ms")
         return ms.value, nb.value
+
+    def structure_cache_hits(self):
+        """graphs whose structure analysis was reused from the previous call on the same batch slot (since create)"""
+        self.lib.isv_pgo_structure_cache_hits.argtypes = [C.c_void_p]; self.lib.isv_pgo_structure_cache_hits.restype = C.c_int64
+        return int(self.lib.isv_pgo_structure_cache_hits(self.h))
 
     def optimize_batch(self, graphs, firsts, curs):
         n = len(graphs)

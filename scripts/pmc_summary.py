@@ -30,7 +30,7 @@ traffic = {"windows_per_gpu": W,
                    "a width the guide calls uncalibrated, so no factor is applied; WRITE_SIZE is taken as is"}
 for n in names:
     base = n.split("<")[0] if not n.startswith("k_proj_linearize") else n
-    if base in ("k_build_solve_sb", "k_proj_linearize<0>", "k_sweep_mfma", "k_rank1_mfma", "k_dogleg", "k_proj_linearize<1>", "k_lin_gram", "k_step_control"):
+    if base in ("k_build_solve_sb", "k_build_solve_st", "k_schur_split", "k_schur_fold", "k_proj_linearize<0>", "k_sweep_mfma", "k_rank1_mfma", "k_dogleg", "k_proj_linearize<1>", "k_lin_gram", "k_step_control"):
         fv, wv = fetch.get(n, [0.0]), write.get(n, [0.0])
         key = base
         traffic[key] = {"FETCH_SIZE_KB_mean": sum(fv) / len(fv), "WRITE_SIZE_KB_mean": sum(wv) / len(wv),

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Run ON THE GPU BOX (via gpurun): the rocprofv3 evidence of one round, everything under gpurun_out/prof_rNN/; copy the
 # summaries into profiles/ afterwards (scripts/copy_profiles.sh).  --pmc passes are separate runs with --kernel-trace only.
-# usage: bash scripts/refresh_profiles.sh [round prefix, default r03] [windows, default 1024]
+# usage: bash scripts/refresh_profiles.sh [round prefix, default r04] [windows, default 1024]
 set -e
-RN=${1:-r03}; W=${2:-1024}
+RN=${1:-r04}; W=${2:-1024}
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/prof_$RN
 rm -rf $O; mkdir -p $O
@@ -42,8 +42,17 @@ import sequence_harness as sh
 sh.write_stream('$O/stream_11.txt', 11, 5, 40, seed=1)"
 rocprofv3 --kernel-trace --stats -d $O/replay -o replay --output-format csv -- ./tools/isv_replay $O/stream_11.txt --sequences 256 --groups 1 --write 0 > $O/replay.log 2>&1
 cp $O/replay/replay_kernel_stats.csv $O/${RN}_resident_replay_256seq_kernel_stats.csv
-# 8. the bench line itself and the two-rank rehearsal of the multi-GPU path on this one GPU (gloo stands in for RCCL)
-python3 bench.py > $O/${RN}_bench_1gpu.json 2> $O/bench_plain.err
-ISV_BENCH_REHEARSAL=1 python3 bench.py --gpus 2 --windows 512 --no-host-legs --no-cpu-baseline --steps 50 > $O/${RN}_2rank_rehearsal.json 2> $O/rehearsal.err
+# 8. the bench line itself and the two-rank rehearsal of the multi-GPU path on this one GPU (gloo stands in for RCCL);
+#    only the JSON line goes into the artefact (gloo's connection messages used to land in the .json)
+python3 bench.py > $O/bench_plain.out 2> $O/bench_plain.err
+grep '^{' $O/bench_plain.out | tail -1 > $O/${RN}_bench_1gpu.json
+ISV_BENCH_REHEARSAL=1 python3 bench.py --gpus 2 --windows 512 --no-host-legs --no-cpu-baseline --steps 50 > $O/rehearsal.out 2> $O/rehearsal.err
+grep '^{' $O/rehearsal.out | tail -1 > $O/${RN}_2rank_rehearsal.json
+# 9. kernel boundary against grid barrier (what a persistent single-window kernel would have to beat) and the launch chain of one window
+hipcc -O3 --offload-arch=gfx950 -o /tmp/launch_vs_barrier scripts/launch_vs_barrier.hip && timeout -k 10 120 /tmp/launch_vs_barrier > $O/${RN}_launch_vs_barrier.json
+REPS=6 rocprofv3 --kernel-trace --stats -d $O/one11 -o one --output-format csv -- python3 scripts/quick_cfg.py 1 11 5 300 > $O/one11.log 2>&1
+cp $O/one11/one_kernel_stats.csv $O/${RN}_single_window_n11_kernel_stats.csv
+REPS=6 rocprofv3 --kernel-trace --stats -d $O/one18 -o one --output-format csv -- python3 scripts/quick_cfg.py 1 18 8 300 > $O/one18.log 2>&1
+cp $O/one18/one_kernel_stats.csv $O/${RN}_single_window_n18_kernel_stats.csv
 ls $O/*.csv $O/*.json
 head -12 $O/${RN}_bench_${W}win_kernel_stats.csv

@@ -152,3 +152,41 @@ def test_invalid_inputs_are_refused(opt):
     bad2 = pg.clone_keyframes(kf); bad2[3].vio_R_w_i[0] = float("nan")
     with pytest.raises(backend.BackendError):
         opt.optimize(bad2, 0, 19)
+
+
+def test_structure_cache_reuses_the_analysis_and_changes_nothing(oracle):
+    """round 4: the structure analysis of a graph slot (parameter blocks, adjacency, skyline, column patterns) is kept with the handle
+    and reused while the keyframe list's structure is unchanged -- PoseGraph::optimizeCS (src/pose_graph/pose_graph.cpp:234-428)
+    re-optimises the same list with new numbers.  A second call on the same batch hits the cache for every graph and gives the
+    bytes of the first; changed measurements on the same structure are picked up (against a fresh handle); a graph that grew by one
+    keyframe misses and is analysed again (checked against the oracle)."""
+    specs = [(40, 90, 3), (41, 64, 2), (42, 120, 4)]
+    graphs = [pg.make_pose_graph(*s) for s in specs]
+    firsts = [f for (_, _, f) in graphs]; curs = [s[1] - 1 for s in specs]
+    opt = pg.PoseGraphOptimizer(200, max_graphs=4, max_loop_blocks=8 * 200)
+    fresh = pg.PoseGraphOptimizer(200, max_graphs=4, max_loop_blocks=8 * 200)
+    try:
+        a = [pg.clone_keyframes(kf) for (kf, _, _) in graphs]; ra = opt.optimize_batch(a, firsts, curs)
+        assert opt.structure_cache_hits() == 0
+        b = [pg.clone_keyframes(kf) for (kf, _, _) in graphs]; rb = opt.optimize_batch(b, firsts, curs)
+        assert opt.structure_cache_hits() == 3
+        for x, y, r1, r2 in zip(a, b, ra, rb):
+            assert bytes(x) == bytes(y) and (r1.iterations, r1.final_cost) == (r2.iterations, r2.final_cost)
+        # same structure, other numbers: the cache must not serve stale measurements
+        c = [pg.clone_keyframes(kf) for (kf, _, _) in graphs]
+        for g in c:
+            for k in range(5, 15):
+                g[k].relative_pose.delta_t[0] += 0.01; g[k].vio_T_w_i[1] += 0.02
+        c2 = [pg.clone_keyframes(g) for g in c]
+        rc = opt.optimize_batch(c, firsts, curs); rf = fresh.optimize_batch(c2, firsts, curs)
+        assert opt.structure_cache_hits() == 6 and fresh.structure_cache_hits() == 0
+        for x, y, r1, r2 in zip(c, c2, rc, rf):
+            assert bytes(x) == bytes(y) and (r1.iterations, r1.final_cost) == (r2.iterations, r2.final_cost)
+        # the graph grows by one keyframe: a miss, analysed again, against the oracle
+        kf, P, first = pg.make_pose_graph(40, 91, 3)
+        g = pg.clone_keyframes(kf); r = opt.optimize(g, first, 90)
+        assert opt.structure_cache_hits() == 6
+        o, ro = oracle_pgo(oracle, kf, first, 90)
+        check_graph(o, ro, g, r, first, 90)
+    finally:
+        opt.close(); fresh.close()
