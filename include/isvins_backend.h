@@ -31,7 +31,10 @@
 extern "C" {
 #endif
 
-#define ISV_ABI_VERSION 1
+/* 2 (round 4): isv_batch_pack_results' `stream` is ALWAYS the caller's hipStream_t since round 3 (NULL = the legacy default stream;
+   ISV_STREAM_OF_HANDLE = the handle's own) -- version 1 callers passed NULL for the handle's stream --, the isv_backend_seq_* entry
+   points and structs exist, and the launch variants whose sums differ in the last bits are chosen per HANDLE (max_batch). */
+#define ISV_ABI_VERSION 2
 
 typedef enum isv_status {
     ISV_OK = 0,

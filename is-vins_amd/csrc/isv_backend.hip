@@ -96,6 +96,7 @@ static int create_impl(isv_backend *h) {
     TRY(dalloc(h, &d.cost, B)); TRY(dalloc(h, &d.st, B));
     d.prior_H_sz = PH_REL0 + PH_REL_SZ * (c.n_vo - 1) + PH_RP_SZ * c.max_rollpitch;
     TRY(dalloc(h, &d.imu_H, NI * ISV_IMU_H)); TRY(dalloc(h, &d.prior_H, B * (size_t)d.prior_H_sz));
+    HIPCHK(h, hipMemset(d.imu_H, 0, NI * ISV_IMU_H * sizeof(double)));      // (the solve kernels read EVERY record and mask the skipped factors' by multiplication: a record that is never written must be finite)
     TRY(dalloc(h, &d.lm_meta, L));
     TRY(dalloc(h, &h->Ps0, B * N * 3)); TRY(dalloc(h, &h->Rs0, B * N * 9)); TRY(dalloc(h, &h->Vs0, B * N * 3));
     TRY(dalloc(h, &h->Bas0, B * N * 3)); TRY(dalloc(h, &h->Bgs0, B * N * 3)); TRY(dalloc(h, &h->depth0, L));

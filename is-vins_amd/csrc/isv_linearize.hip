@@ -561,6 +561,9 @@ __global__ __launch_bounds__(256) void k_imu_raw(DevBatch d, const double *pose_
         if (!(ss.termination == ISV_TERM_RUNNING && (gate == 1 ? ss.need_linearize != 0 : ss.step_valid != 0))) return;
     }
     if (d.imu_skip[f]) return;
+    // (round 4, measured and dropped: the 64 records and states staged through 50 KB of LDS with coalesced loads -- the lane's 25
+    //  dependent load -> wait pairs disappear, but the kernel went from 49 to 75 us per launch beside k_lin_gram: its workgroups
+    //  then compete with k_lin_gram's for LDS)
     const double *rec = d.imu_in + (size_t)f * ISV_IMU_IN;
     const double *pi = pose_src + ((size_t)w * N + i) * 7, *pj = pi + 7;
     const double *si = sb_src + ((size_t)w * N + i) * 9, *sj = si + 9;
@@ -660,8 +663,20 @@ __global__ __launch_bounds__(64) void k_imu_weight(DevBatch d, double *cost_out,
     }
     if (d.imu_skip[f]) { if (t == 0) cost_out[f] = 0.0; return; }
     const double *Sg = d.imu_sqrt + (size_t)f * 225, *Rg = d.imu_raw + (size_t)f * 480;
-    for (int e = t; e < 16 * 17; e += 64) { const int r = e / 17, c = e - 17 * r; sS[e] = (r < 15 && c < 15) ? Sg[r * 15 + c] : 0.0; }
-    for (int e = t; e < 512; e += 64) sRaw[e] = e < 480 ? Rg[e] : 0.0;
+    {
+        // (round 4) all thirteen loads of a lane in flight together: clamped addresses, the padding zeros applied when the values
+        // go to LDS.  Written as `cond ? load : 0.0` per loop trip the compiler put every load in a branch of its own behind an
+        // s_waitcnt vmcnt(0): thirteen serialised memory latencies at the top of each of the 10 240 single-wavefront workgroups.
+        double vs[5], vr[8];
+#pragma unroll
+        for (int k = 0; k < 5; k++) { const int e = t + 64 * k, r = e / 17, c = e - 17 * r; vs[k] = Sg[(r < 15 && c < 15) ? r * 15 + c : 0]; }
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const int e = t + 64 * k; vr[k] = Rg[e < 480 ? e : 479]; }
+#pragma unroll
+        for (int k = 0; k < 5; k++) { const int e = t + 64 * k, r = e / 17, c = e - 17 * r; if (e < 16 * 17) sS[e] = (r < 15 && c < 15) ? vs[k] : 0.0; }
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const int e = t + 64 * k; sRaw[e] = e < 480 ? vr[k] : 0.0; }
+    }
     __syncthreads();
     const int i = t & 15, kq = t >> 4;
     double4i a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};

@@ -33,7 +33,7 @@ def test_every_declared_symbol_is_exported(lib):
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/isvins_backend.h but not exported"
     assert set(names) == set(backend.EXPORTS)
-    assert lib.isv_abi_version() == 1
+    assert lib.isv_abi_version() == 2
 
 
 def test_every_estimator_symbol_is_exported(lib):

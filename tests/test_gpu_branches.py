@@ -75,7 +75,7 @@ def test_sweep_global_scratch_variant_is_bitwise_the_lds_one(oracle, monkeypatch
 def test_batch_of_more_than_256_long_windows(oracle):
     """260 windows of the reference's own shape (N = 18, Vo = 8) in one batch: the launch configuration large N >= 12
     batches get (sw_global, several workgroups per CU).  A sample is compared with the oracle, and every window is
-    bitwise the same window solved in a batch of four."""
+    bitwise the same window solved in a batch of four on the same handle."""
     ids = list(range(800, 1060))
     ws = synth.make_windows(ids, n_frames=18, n_vo=8, n_landmarks=24)
     cap = dict(max_landmarks=24, max_obs=max(w.n_obs for w in ws))
@@ -89,10 +89,19 @@ def test_batch_of_more_than_256_long_windows(oracle):
             check_window(o, so, gs[k], sums[k])
             check_marg(mo, margs[k], 8)
         for k0 in (0, 128, 256):
+            # bitwise on the SAME handle (round 4: a handle of more than 256 long windows runs k_build_solve_st -- chosen per handle);
+            # a four-window handle (k_build_solve_sb) agrees to rounding with identical control flow
             ref = [w.clone() for w in ws[k0: k0 + 4]]
-            small.optimize_batch(ref)
+            big.optimize_batch(ref)
+            assert big.last_counts()[6] == 1
             for a, c in zip(gs[k0: k0 + 4], ref):
                 assert np.array_equal(a.state_vector(), c.state_vector())
+            ref2 = [w.clone() for w in ws[k0: k0 + 4]]
+            s2, _ = small.optimize_batch(ref2)
+            assert small.last_counts()[6] == 0
+            for k, (a, c) in enumerate(zip(gs[k0: k0 + 4], ref2)):
+                assert s2[k].iterations == sums[k0 + k].iterations
+                assert np.abs(a.state_vector() - c.state_vector()).max() < 1e-7
     finally:
         big.close(); small.close()
 
