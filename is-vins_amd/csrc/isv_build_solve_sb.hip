@@ -195,6 +195,8 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
         int t = t_outer;
         asm volatile("" : "+v"(t));
         // ---- issue every global load of the assembly up front (one memory latency instead of five) ----
+        // (round 4, measured and dropped: the IMU fetches below as unconditional, clamped, mask-multiplied loads -- the form that pays in
+        //  k_build_solve_st and k_imu_weight -- made THIS kernel slower: one 18-frame window 2.64 -> 2.78 ms, 256 of them 3.28 -> 3.38 ms)
         const double *H = d.imu_H + (size_t)w * (N - 1) * ISV_IMU_H;
         const double *PH = d.prior_H + (size_t)w * d.prior_H_sz;
         // (BIG: one workgroup per CU = 256 VGPRs per lane, room for the IMU blocks of up to 20 frames: 2400 / 512 and 4275 / 512 entries per thread)
@@ -202,19 +204,17 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
         double vS[5], vT[3] = {0, 0, 0}, vF[KF], vX[KX], vG = 0, vP[2] = {0, 0};
         if (!BIG) {
 #pragma unroll
-            for (int k = 0; k < 5; k++) { const int e = t + k * LS; vS[k] = V[e < nS ? e : nS - 1]; }      // (clamped; stored under e < nS)
+            for (int k = 0; k < 5; k++) { const int e = t + k * LS; vS[k] = e < nS ? V[e] : 0.0; }
         }
         if (t < n6) { vT[0] = V[nS + t]; vT[1] = V[nS + n6 + t]; vT[2] = V[nS + 2 * n6 + t]; }
-        vP[0] = PH[t < d.prior_H_sz ? t : d.prior_H_sz - 1];      // (clamped: entries beyond the record are staged but never read)
-        vP[1] = PH[t + LS < d.prior_H_sz ? t + LS : d.prior_H_sz - 1];
+        if (t < d.prior_H_sz) vP[0] = PH[t];
+        if (t + LS < d.prior_H_sz) vP[1] = PH[t + LS];
         // IMU factors (precomputed J^T J, local order pose_i sb_i pose_j sb_j)
         auto imu_frame_fetch = [&](int e) -> double {       // per frame: pose diag (21), sb diag (45), pose x sb (54)
             const int I = e / 120;
             int q = e - 120 * I;
-            // (round 4: both loads unconditional -- clamped record, 0 / 1 mask; as `if (has) v += H[i]` each load sat in a branch of
-            //  its own behind an s_waitcnt vmcnt(0).  imu_H is zeroed at create, so a record that was never written is finite)
-            const double mA = (I >= 1 && !skipL[I >= 1 ? I - 1 : 0]) ? 1.0 : 0.0, mB = (I <= N - 2 && !skipL[I <= N - 2 ? I : N - 2]) ? 1.0 : 0.0;
-            const double *HA = H + (size_t)(I >= 1 ? I - 1 : 0) * ISV_IMU_H, *HB = H + (size_t)(I <= N - 2 ? I : N - 2) * ISV_IMU_H;
+            const bool hasA = I >= 1 && !skipL[I - 1], hasB = I <= N - 2 && !skipL[I];
+            const double *HA = H + (size_t)(I - 1) * ISV_IMU_H, *HB = H + (size_t)I * ISV_IMU_H;
             int ia, ib;
             if (q < 21) {
                 const int r = triAB[2 * q], c = triAB[2 * q + 1];
@@ -228,8 +228,10 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
                 const int r = q / 9, c = q - 9 * r;         // pose row r, speed/bias column c of frame I
                 ia = pairidx2(21 + c, 15 + r); ib = pairidx2(6 + c, r);
             }
-            const double va = HA[ia], vb = HB[ib];
-            return va * mA + vb * mB;
+            double v = 0;
+            if (hasA) v += HA[ia];
+            if (hasB) v += HB[ib];
+            return v;
         };
         auto imu_frame_apply = [&](int e, double v) {
             const int I = e / 120;
@@ -250,14 +252,14 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
         auto imu_pair_fetch = [&](int e) -> double {        // per factor: the blocks between frames I and I + 1
             const int I = e / 225;
             int q = e - 225 * I;
-            const double mI = skipL[I] ? 0.0 : 1.0;
+            if (skipL[I]) return 0.0;
             const double *HB = H + (size_t)I * ISV_IMU_H;
             int ib;
             if (q < 36) { const int r = q / 6, c = q - 6 * r; ib = pairidx2(15 + r, c); }
             else if (q < 90) { q -= 36; const int r = q / 9, c = q - 9 * r; ib = pairidx2(15 + r, 6 + c); }      // pose_{I+1} x sb_I
             else if (q < 144) { q -= 90; const int r = q / 9, c = q - 9 * r; ib = pairidx2(21 + c, r); }          // pose_I x sb_{I+1}
             else { q -= 144; const int r = q / 9, c = q - 9 * r; ib = pairidx2(21 + r, 6 + c); }                  // sb_{I+1} (r) x sb_I (c)
-            return HB[ib] * mI;
+            return HB[ib];
         };
         auto imu_pair_apply = [&](int e, double v) {
             const int I = e / 225;
@@ -271,10 +273,10 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
                 if (I < M) Css[I * 81 + r * 9 + c] = v; else Css[(I + 1) * 81 + c * 9 + r] = v;
             }
         };
-        {
-            const int tc = t < n ? t : 0, I = tc / 15, r = tc - 15 * I;
-            const double ga = H[(size_t)(I >= 1 ? I - 1 : 0) * ISV_IMU_H + 465 + 15 + r], gb = H[(size_t)(I <= N - 2 ? I : N - 2) * ISV_IMU_H + 465 + r];
-            if (t < n) vG = ga * ((I >= 1 && !skipL[I >= 1 ? I - 1 : 0]) ? 1.0 : 0.0) + gb * ((I <= N - 2 && !skipL[I <= N - 2 ? I : N - 2]) ? 1.0 : 0.0);
+        if (t < n) {
+            const int I = t / 15, r = t - 15 * I;
+            if (I >= 1 && !skipL[I - 1]) vG += H[(size_t)(I - 1) * ISV_IMU_H + 465 + 15 + r];
+            if (I <= N - 2 && !skipL[I]) vG += H[(size_t)I * ISV_IMU_H + 465 + r];
         }
         // ---- reprojection part from k_sweep / k_rank1_mfma (same packed layout) ----------------------
         for (int e = t; e < n; e += LS) { g[e] = 0.0; bs[e] = 0.0; hdiag[e] = 0.0; }
@@ -286,9 +288,9 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
         // workgroups per CU): the IMU blocks, in flight across the barrier and the zeroing below (BIG: across the copy of
         // the pose blocks as well)
 #pragma unroll
-        for (int k = 0; k < KF; k++) { const int e = t + k * LS; vF[k] = imu_frame_fetch(e < N * 120 ? e : N * 120 - 1); }      // (clamped: the applies are range-checked)
+        for (int k = 0; k < KF; k++) { const int e = t + k * LS; vF[k] = e < N * 120 ? imu_frame_fetch(e) : 0.0; }
 #pragma unroll
-        for (int k = 0; k < KX; k++) { const int e = t + k * LS; vX[k] = imu_pair_fetch(e < (N - 1) * 225 ? e : (N - 1) * 225 - 1); }
+        for (int k = 0; k < KX; k++) { const int e = t + k * LS; vX[k] = e < (N - 1) * 225 ? imu_pair_fetch(e) : 0.0; }
         if (BIG) {
             for (int e0 = t; e0 < nS; e0 += 4 * LS) {       // four loads in flight per trip
                 double v4[4];
