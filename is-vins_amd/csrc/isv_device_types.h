@@ -14,7 +14,10 @@
 #define ISV_MAX_FRAMES 32
 #define ISV_MARG_WS 1408             // doubles per window: Lp @0 (441), Jr @448 (441), V @896 (441), eigenvalues @1344 (21)
 #define ISV_SPLIT_MAX_GROUPS 32       // workgroups one window's rank-1 downdates are split over (k_schur_split)
-#define ISV_SPLIT_MIN_PASSES 8        // ... when it has at least this many 64-landmark passes (> 448 landmarks)
+#ifndef ISV_SPLIT_MIN_PASSES
+#define ISV_SPLIT_MIN_PASSES 4        // ... when it has at least this many 64-landmark passes (> 192 landmarks; measured on ONE 18-frame
+                                      // window of 300 landmarks: 2.66 ms with 8, 2.52 ms with 4; 11 frames: 1.94 either way)
+#endif
 #define ISV_FUSED_MAX_FACTORS 8192   // longest window (reprojection factors) the one-workgroup-per-window k_lin_gram takes
 #define ISV_IMU_IN 64          // packed IMU record (doubles)
 // offsets inside the packed IMU record

@@ -427,7 +427,7 @@ def test_split_landmark_elimination_against_oracle_and_one_workgroup(oracle, mon
     try:
         gs = [w.clone() for w in ws]; sums, margs = be.optimize_batch(gs)
         cnt = be.last_counts()
-        assert cnt[7] >= 8, cnt                                    # split groups of the longest window
+        assert cnt[7] >= 8, cnt                                    # split groups of the longest window (>= 512 landmarks here)
         assert (cnt[4] == 0) == (shape == "unfused"), cnt
         g1 = [w.clone() for w in ws]; sums1, _ = one.optimize_batch(g1)
         assert one.last_counts()[7] == 0
@@ -435,7 +435,7 @@ def test_split_landmark_elimination_against_oracle_and_one_workgroup(oracle, mon
             o, so, mo = oracle_run(oracle, be.cfg, w)
             check_window(o, so, g, s); check_marg(mo, mg, Nvo)
             assert s.iterations == s1.iterations and list(s.trace_accepted[: s.iterations + 1]) == list(s1.trace_accepted[: s1.iterations + 1])
-            if w.L < 449:                                          # one group: the one-workgroup sums, bit for bit
+            if w.L <= 192:                                         # fewer than four 64-landmark passes: one group, the one-workgroup sums bit for bit
                 assert np.array_equal(g.state_vector(), h.state_vector())
             else:
                 assert np.abs(g.state_vector() - h.state_vector()).max() < 1e-8          # (depths of O(10) included)
