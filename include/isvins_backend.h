@@ -296,7 +296,9 @@ int  isv_batch_pack_results(isv_backend_t *h, void *device_dst, void *stream);
  * start_frame, track lengths: which feature continues which track) and therefore knows every offset; it never needs the
  * points, depths or window states back -- only the newest frame's state (for processIMU), the oldest pose (pose_output.txt),
  * the solve summary and the landmarks' solve_flag (removeFailures).  Results are bitwise those of the re-upload path
- * (tests/test_gpu_resident.py).  estimate_extrinsic = 0 only.                                                          */
+ * (tests/test_gpu_resident.py).  estimate_extrinsic = 0 only (the pseudo-frame of a free extrinsic is not threaded through the
+ * slide / build kernels); windows the per-window kernels do not take (> 8192 factors) are refused with ISV_ERR_UNSUPPORTED
+ * BEFORE anything is launched, and the caller (isv_estimator_step does) solves that frame through the upload path.        */
 typedef struct isv_seq_track {       /* one IDFeatures of the seed: feature_manager.h:36-63 */
     int32_t start_frame, n_obs, solve_flag, slot;      /* slot: the caller's storage slot of the track (< tracks capacity), kept for its lifetime */
     double  depth;
@@ -307,7 +309,10 @@ typedef struct isv_seq_obs {         /* one observation of the newest frame */
     double  point[3];
 } isv_seq_obs_t;
 typedef struct isv_seq_frame {       /* the hand-over of one frame of one sequence */
-    int32_t prev_slide;              /* what Estimator::slideWindow did after the previous solve: 0 = nothing to apply (first frame after the seed), 1 = MARGIN_OLD, 2 = MARGIN_SECOND_NEW */
+    int32_t prev_slide;              /* what Estimator::slideWindow did after the previous solve: 0 = nothing to apply (first frame after the seed), 1 = MARGIN_OLD, 2 = MARGIN_SECOND_NEW;
+                                        -1 (round 4) = this sequence has NO image this step (System::getMeasurements pairs IMU and images per sequence,
+                                        src/System.cpp:160-202): only n_tracks is read, nothing is slid, appended, solved or written back for it -- a pending
+                                        slide stays pending -- and its isv_seq_result_t comes back zeroed */
     int32_t margin_old;              /* marginalization_flag of THIS solve */
     int32_t n_tracks;                /* tracks alive after the slide, before this frame's features are added (consistency check) */
     int32_t n_obs;                   /* observations of the newest frame */

@@ -359,6 +359,7 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
     const auto t_packed = std::chrono::steady_clock::now();
     DevBatch &d = h->d;
     d.B = n; d.Ltot = (int32_t)L; d.Ftot = (int32_t)F; d.n_tiles = (int32_t)T;
+    d.seq_hdr = nullptr;                       // (the upload path: every window of the batch is solved)
     // k_lin_gram takes one window per workgroup: right for windows of ordinary length, whatever the handle's capacity is
     // (the reference-shaped handle reserves NUM_OF_F x ALL_BUF_SIZE = 18 000 observations and sees ~2 000 factors).  A
     // batch with a very long window (BASELINE config 5: 30 000 factors in ONE window) takes the factor-parallel

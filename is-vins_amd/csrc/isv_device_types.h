@@ -48,6 +48,7 @@
 #define PH_REL_SZ 90
 #define PH_RP_SZ 27            // 21 + 6 each
 
+#define ISV_SEQ_IDLE(d, w) ((d).seq_hdr != nullptr && (d).seq_hdr[(size_t)(w) * 8] < 0)
 struct FactorRec { int32_t lm; int32_t ij; };   // global landmark index; frame_i | frame_j << 8
 
 // solver scalars of one window (DoglegStrategy + TrustRegionMinimizer state, Ceres 2.0.0)
@@ -124,6 +125,8 @@ struct DevBatch {
     double2 *lm_cg;                     // [Ltot]  {c_l = s_l^2 / (s_l^2 E_l + mu D_l^2), g_l}
     int32_t sw_global;                  // this launch keeps the pair partials in sw_part (set per launch: only batches that need the occupancy)
     double *sw_part;                    // [B][NP * 84] pair partials of k_sweep_mfma when they do not share a CU's LDS four ways (long windows); else null
+    const int32_t *seq_hdr;             // device-resident sequences: the frame headers [B][8]; header word 0 < 0 = this window has NO FRAME this step (ISV_SEQ_IDLE):
+                                        // nothing is slid, appended, solved or written back for it.  null on the upload path
     double *st_ws;                      // [B][162 N + ytot] k_build_solve_st: L_i^-1 | C_i' | Y_i' of the chain nodes between elimination and back-substitution; null: the handle runs k_build_solve_sb
     double *r1_part;                    // [split_cap_B][ISV_SPLIT_MAX_GROUPS][tiles * 256] raw accumulator tiles of the split rank-1 downdates (k_schur_split -> k_schur_fold); null: no split on this handle
     double *Tvis;                       // [B][tvis_sz] reprojection part of the reduced system (6x6 pose corners), hd, g, bs

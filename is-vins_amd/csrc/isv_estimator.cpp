@@ -717,14 +717,19 @@ int seed_resident(isv_estimator *e) {
 // the device's state of every sequence back into the host members (a sequence leaves the resident mode BEFORE its slide)
 // (pre_add: the host has ALREADY appended this frame's features to its track lists -- the device holds the first tracks_before
 //  tracks of every sequence; the tracks behind them are this frame's new ones and keep their fresh depth)
-int leave_resident(isv_estimator *e, bool host_has_slid, bool pre_add = false) {
+// (slid: per sequence, overrides host_has_slid -- a frame in which only SOME sequences had an image: the idle ones' slide of their
+//  last solve is still pending on the device while the active ones have not slid yet)
+int leave_resident(isv_estimator *e, bool host_has_slid, bool pre_add = false, const std::vector<char> *slid = nullptr) {
     auto ntracks = [&](const Sequence &s) { return pre_add ? (size_t)s.tracks_before : s.tracks.size(); };
-    if (host_has_slid) {      // the device applies a slide with the NEXT frame: let it catch up with the host's bookkeeping first
+    auto has_slid = [&](size_t si) { return slid ? (*slid)[si] != 0 : host_has_slid; };
+    bool any_slid = false;
+    for (size_t si = 0; si < e->seq.size(); si++) any_slid |= has_slid(si);
+    if (any_slid) {           // the device applies a slide with the NEXT frame: let it catch up with the host's bookkeeping first
         std::vector<int32_t> prev(e->seq.size()), nt(e->seq.size());
-        for (size_t si = 0; si < e->seq.size(); si++) { prev[si] = e->seq[si].last_slide; nt[si] = (int32_t)ntracks(e->seq[si]); }
+        for (size_t si = 0; si < e->seq.size(); si++) { prev[si] = has_slid(si) ? e->seq[si].last_slide : 0; nt[si] = (int32_t)ntracks(e->seq[si]); }
         const int rc = isv_backend_seq_flush(e->backend, (int32_t)e->seq.size(), prev.data(), nt.data());
         if (rc != ISV_OK) { e->err = std::string("leaving the resident mode failed: ") + isv_backend_last_error(e->backend); return rc; }
-        for (Sequence &s : e->seq) s.last_slide = 0;
+        for (size_t si = 0; si < e->seq.size(); si++) if (has_slid(si)) e->seq[si].last_slide = 0;
     }
     for (size_t si = 0; si < e->seq.size(); si++) {
         Sequence &s = e->seq[si];
@@ -741,7 +746,7 @@ int leave_resident(isv_estimator *e, bool host_has_slid, bool pre_add = false) {
         const int rc = isv_backend_seq_download(e->backend, (int32_t)si, &w, (int32_t)ntr, dep.data(), fl.data());
         if (rc != ISV_OK) { e->err = std::string("leaving the resident mode failed: ") + isv_backend_last_error(e->backend); return rc; }
         // (after a slide the newest frame is the host's: processIMU may already have propagated it with the next frame's samples)
-        for (int i = 0; i < (host_has_slid ? N - 1 : N); i++) {
+        for (int i = 0; i < (has_slid(si) ? N - 1 : N); i++) {
             std::memcpy(s.Ps[i].data(), &s.wPs[i * 3], 24); std::memcpy(s.Rs[i].data(), &s.wRs[i * 9], 72); std::memcpy(s.Vs[i].data(), &s.wVs[i * 3], 24);
             std::memcpy(s.Bas[i].data(), &s.wBas[i * 3], 24); std::memcpy(s.Bgs[i].data(), &s.wBgs[i * 3], 24);
         }
@@ -762,12 +767,18 @@ int resident_frame(isv_estimator *e, std::vector<std::string> &errs) {
     std::vector<isv_seq_frame_t> fr(S);
     std::vector<isv_seq_result_t> res(S);
     std::vector<int32_t *> flags(S);
-    std::vector<char> fits(S, 1);
+    std::vector<char> fits(S, 1), idle(S, 0);
     int rc = parallel_for(S, errs, [&](int si, std::string &err) {
         Sequence &s = e->seq[si];
         const int N = s.N;
         isv_seq_frame_t &f = fr[si];
         std::memset(&f, 0, sizeof(f));
+        if (!s.staged) {                           // no image for this sequence this step (round 4): it idles on the device, its slide stays pending
+            f.prev_slide = -1; f.n_tracks = (int32_t)s.tracks.size();
+            s.tracks_before = (int)s.tracks.size();
+            idle[si] = 1; flags[si] = nullptr;
+            return (int)ISV_OK;
+        }
         f.prev_slide = s.last_slide;
         f.n_tracks = (int32_t)s.tracks.size();
         if (!s.pre[N - 1] || (s.last_slide == 2 && !s.pre[N - 2])) { err = "a window frame has no pre-integration (no IMU samples were fed)"; return (int)ISV_ERR_INVALID_ARG; }
@@ -816,18 +827,21 @@ int resident_frame(isv_estimator *e, std::vector<std::string> &errs) {
     }
     if (rc != ISV_OK) { e->err = std::string("resident frame failed: ") + isv_backend_last_error(e->backend); return rc; }
     for (Sequence &s : e->seq) s.features_added = false;
+    int n_active = 0;
+    for (int si = 0; si < S; si++) n_active += !idle[si];
     const auto tr2 = std::chrono::steady_clock::now();
     e->resident_frames++;
     bool failed = false;
-    for (int si = 0; si < S; si++) failed |= res[si].summary.status != ISV_OK;
+    for (int si = 0; si < S; si++) failed |= !idle[si] && res[si].summary.status != ISV_OK;
     if (failed) {
-        // a non-finite solve: everything comes back to the host (the device has not slid yet) and the host path's policy applies
-        rc = leave_resident(e, false);
+        // a non-finite solve: everything comes back to the host (the device has not slid the sequences of this frame yet; an idle one's
+        // slide of its last solve is still pending and is applied first) and the host path's policy applies
+        rc = leave_resident(e, false, false, &idle);
         if (rc != ISV_OK) return rc;
         for (int si = 0; si < S; si++) {          // the sequences that did solve still install their marginalisation outputs
             Sequence &s = e->seq[si];
             isv_marg_result_t m;
-            if (res[si].summary.status != ISV_OK || !s.margin_old) continue;
+            if (idle[si] || res[si].summary.status != ISV_OK || !s.margin_old) continue;
             rc = isv_backend_seq_marg(e->backend, si, &m);
             if (rc != ISV_OK) { e->err = isv_backend_last_error(e->backend); return rc; }
             if (!m.valid) continue;
@@ -838,6 +852,7 @@ int resident_frame(isv_estimator *e, std::vector<std::string> &errs) {
     }
     (void)parallel_for(S, errs, [&](int si, std::string &) {
         Sequence &s = e->seq[si];
+        if (idle[si]) return (int)ISV_OK;          // (nothing was solved for it: no slide, no row, its counters stand)
         const int N = s.N;
         const isv_seq_result_t &r = res[si];
         const bool ok = r.summary.status == ISV_OK;
@@ -858,7 +873,7 @@ int resident_frame(isv_estimator *e, std::vector<std::string> &errs) {
     });
     auto msd = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     e->step_ms[1] = msd(tr0, tr1); e->step_ms[4] = msd(tr1, tr2); e->step_ms[5] = msd(tr2, std::chrono::steady_clock::now());
-    return S;
+    return n_active;
 }
 
 }  // namespace
@@ -889,11 +904,15 @@ extern "C" int isv_estimator_step(isv_estimator_t *e) {
     for (double &x : e->step_ms) x = 0;
     std::vector<std::string> errs;
     if (e->resident_ready) {
-        bool all = true;
-        for (const Sequence &s : e->seq) all &= s.staged && s.resident && s.flag == NON_LINEAR;
+        // (round 4: a sequence WITHOUT an image this step no longer evicts the group -- it idles on the device, src/System.cpp:160-202
+        //  pairs IMU and images per sequence -- but every sequence must be resident and in steady state)
+        bool all = true, any = false;
+        for (const Sequence &s : e->seq) { all &= s.resident && s.flag == NON_LINEAR; any |= s.staged; }
+        if (!any) return 0;
         // the resident store's own limits, checked BEFORE anything is mutated (an upper bound: every staged id taken as a new track)
         bool fits = true;
         for (const Sequence &s : e->seq) {
+            if (!s.staged) continue;
             const size_t fresh = s.staged_image.size() > s.free_slots.size() ? s.staged_image.size() - s.free_slots.size() : 0;
             fits &= s.tracks.size() + s.staged_image.size() <= (size_t)e->tracks_cap && s.pool.size() / POINT_RING + fresh <= (size_t)e->tracks_cap;
         }
@@ -907,7 +926,7 @@ extern "C" int isv_estimator_step(isv_estimator_t *e) {
             if (rc != RESIDENT_FELL_BACK) return rc;
             // the frame did not fit the resident path: the windows are back, this frame's features are already in the track lists
         } else {
-            const int rc = leave_resident(e, true);    // lock step broken (a sequence without an image this frame) or the store is full:
+            const int rc = leave_resident(e, true);    // a sequence left the steady state, or the store is full:
             if (rc != ISV_OK) return rc;               // the host path takes over (and seeds again once every sequence solves in one frame)
         }
     }

@@ -305,6 +305,7 @@ DEV double w_det(const double *A, int n, double *W, int *piv, int t) {     // vi
 // clears the marg records (padding included) so downloads are deterministic; valid = margin_old
 __global__ void k_marg_clear(DevBatch d) {
     const int w = blockIdx.x, t = threadIdx.x;
+    if (ISV_SEQ_IDLE(d, w)) return;        // (a resident sequence without a frame this step keeps the record of its last solve: its slide is still pending)
     double *z = reinterpret_cast<double *>(&d.marg[w]);
     for (int e = t; e < (int)(sizeof(isv_marg_result_t) / sizeof(double)); e += blockDim.x) z[e] = 0.0;
 }
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(MT) void k_marg_fwd(DevBatch d) {
     __shared__ int keep[8], piv[4];
     const int w = blockIdx.x, t = threadIdx.x;
     isv_marg_result_t &out = d.marg[w];
-    if (!d.margin_old[w]) return;
+    if (!d.margin_old[w] || ISV_SEQ_IDLE(d, w)) return;
 #ifdef ISV_STAMP
     unsigned long long t_last = wall_clock64();
 #endif
@@ -559,7 +560,7 @@ __global__ __launch_bounds__(256) void k_marg_jacobi(DevBatch d) {
     __shared__ double sA[NN + 1], sV[NN + 1], red[8], sink[2], rc[2][32], rs[2][32];
     __shared__ int rp[2][32], rq[2][32];
     const int w = blockIdx.x, t = threadIdx.x;
-    if (!d.margin_old[w]) return;
+    if (!d.margin_old[w] || ISV_SEQ_IDLE(d, w)) return;
 #ifdef ISV_STAMP
     unsigned long long t_last = wall_clock64();
 #endif
@@ -645,7 +646,7 @@ __global__ __launch_bounds__(MT) void k_marg_bwd(DevBatch d) {
     double *const Jr = Lam, *const JU = Lam + 441;
     const int w = blockIdx.x, t = threadIdx.x;
     isv_marg_result_t &out = d.marg[w];
-    if (!d.margin_old[w]) return;
+    if (!d.margin_old[w] || ISV_SEQ_IDLE(d, w)) return;
 #ifdef ISV_STAMP
     unsigned long long t_last = wall_clock64();
 #endif

@@ -91,6 +91,10 @@ __global__ __launch_bounds__(256) void k_seq_slide(DevBatch d, SeqDev s) {
     const int w = blockIdx.x, t = threadIdx.x, N = d.N, Nvo = d.Nvo, NI = N - 1;
     const int *hdr = s.f_hdr + (size_t)w * SEQ_HDR;
     const int prev = hdr[FH_PREV];
+    if (prev < 0) {                                // no frame for this sequence this step (round 4): its pending slide stays pending
+        if (t == 0) { s.imu_sel[(size_t)w * 2] = -1; s.imu_sel[(size_t)w * 2 + 1] = -1; }
+        return;
+    }
     __shared__ int sbuf[8];
     __shared__ double sR0[9], sP0[3], sR1[9], sP1[3];
     __shared__ double sStage[2048];                // prior structs in transit
@@ -266,6 +270,7 @@ __global__ __launch_bounds__(256) void k_seq_slide(DevBatch d, SeqDev s) {
 __global__ __launch_bounds__(256) void k_seq_append(DevBatch d, SeqDev s) {
     const int w = blockIdx.x, t = threadIdx.x;
     const int *hdr = s.f_hdr + (size_t)w * SEQ_HDR;
+    if (hdr[FH_PREV] < 0) return;
     const int T0 = s.n_tracks[w], nobs = hdr[FH_NOBS];
     const isv_seq_obs_t *obs = s.f_obs + hdr[FH_OBSOFF];
     const size_t tb = (size_t)w * s.Tcap;
@@ -304,6 +309,7 @@ __global__ __launch_bounds__(256) void k_seq_build(DevBatch d, SeqDev s, int lca
     int *sF0 = ldsi + lcap, *sSize = sF0 + lcap, *sOff = sSize + NP + 1, *sOrder = sOff + NP + 1, *sBase = sOrder + NP + 1, *sWave = sBase + NP + 1;
     __shared__ int sbuf[8];
     const int *hdr = s.f_hdr + (size_t)w * SEQ_HDR;
+    if (hdr[FH_PREV] < 0) return;                  // (no frame: the window contributes no landmarks / factors to this step's batch)
     const int T = s.n_tracks[w];
     const size_t tb = (size_t)w * s.Tcap;
     const int L0 = d.lm_off[w], F0 = d.f_off[w];
@@ -437,6 +443,7 @@ __global__ void k_seq_poison(DevBatch d) { d.st[0].x_cost = __longlong_as_double
 // FeatureManager::setDepth's outputs back into the track list, and the frame's small result record
 __global__ __launch_bounds__(256) void k_seq_writeback(DevBatch d, SeqDev s) {
     const int w = blockIdx.x, t = threadIdx.x, N = d.N;
+    if (ISV_SEQ_IDLE(d, w)) return;
     const size_t tb = (size_t)w * s.Tcap;
     __shared__ int s_fail;
     if (t == 0) s_fail = 0;
@@ -607,8 +614,17 @@ extern "C" int isv_backend_seq_frame(isv_backend_t *h, int32_t n, const isv_seq_
     const int N = c.n_frames;
     size_t L = 0, F = 0, O = 0, Fmax = 0, Lmax = 0;
     bool any_marg = false;
+    int n_idle = 0;
     for (int b = 0; b < n; b++) {
         const isv_seq_frame_t &f = fr[b];
+        if (f.prev_slide == -1) {                  // no frame for this sequence this step: an empty slice of the batch, every kernel skips it
+            int32_t *hd0 = q->h_hdr + (size_t)b * SEQ_HDR;
+            memset(hd0, 0, sizeof(int32_t) * SEQ_HDR);
+            hd0[FH_PREV] = -1; hd0[FH_NTRK] = f.n_tracks; hd0[FH_OBSOFF] = (int32_t)O;
+            h->h.lm_off[b] = (int32_t)L; h->h.f_off[b] = (int32_t)F;
+            n_idle++;
+            continue;
+        }
         if (f.n_obs < 0 || (f.n_obs > 0 && !f.obs) || !f.imu || f.n_imu < 1 || f.n_imu > 2 || f.prev_slide < 0 || f.prev_slide > 2 || f.n_landmarks < 0 || f.n_factors < 0) return ISV_ERR_INVALID_ARG;
         if (f.n_landmarks > c.max_landmarks || f.n_factors + f.n_landmarks > c.max_obs) { h->err = "window exceeds capacity"; return ISV_ERR_CAPACITY; }
         if (f.n_factors > 65535) { h->err = "more than 65535 factors in one window"; return ISV_ERR_CAPACITY; }
@@ -629,7 +645,9 @@ extern "C" int isv_backend_seq_frame(isv_backend_t *h, int32_t n, const isv_seq_
     if (L > h->capL || F > h->capF) { h->err = "batch exceeds capacity"; return ISV_ERR_CAPACITY; }
     h->h.lm_off[n] = (int32_t)L; h->h.f_off[n] = (int32_t)F;
     // the resident path runs the per-window kernels only (no factor tiles are built): ordinary windows
+    if (n_idle == n) { h->err = "seq_frame: no sequence has a frame"; return ISV_ERR_INVALID_ARG; }
     d.B = n; d.Ltot = (int32_t)L; d.Ftot = (int32_t)F; d.n_tiles = 0;
+    d.seq_hdr = s.f_hdr;
     d.lg_lcap = (int32_t)((Lmax + 31) / 32 * 32);
     const bool lg_fits = lin_gram_lds_bytes(N, true, false, LG_WAVES, d.lg_lcap) <= ISV_LDS_PER_CU;
     if (!d.lds_T || Fmax > ISV_FUSED_MAX_FACTORS || !lg_fits || h->hc.legacy_visual || F > (size_t)4096 * n) {
@@ -679,6 +697,7 @@ extern "C" int isv_backend_seq_frame(isv_backend_t *h, int32_t n, const isv_seq_
     int rc = ISV_OK;
     for (int b = 0; b < n; b++) {
         isv_seq_result_t &r = res[b];
+        if (fr[b].prev_slide == -1) { memset(&r, 0, sizeof(r)); continue; }      // (no frame: nothing was solved or written back)
         const double *o = q->h_out + (size_t)b * SEQ_OUT;
         r.summary = sums[b];
         memcpy(r.Ps_new, o, 24); memcpy(r.Rs_new, o + 3, 72); memcpy(r.Vs_new, o + 12, 24); memcpy(r.Bas_new, o + 15, 24); memcpy(r.Bgs_new, o + 18, 24);

@@ -44,6 +44,7 @@ __global__ void k_init_state(DevBatch d) {
     SolveState s;
     memset(&s, 0, sizeof(s));
     s.radius = 1e4; s.mu = 1e-8; s.need_linearize = 1; s.termination = ISV_TERM_RUNNING;
+    if (ISV_SEQ_IDLE(d, w)) { s.termination = ISV_TERM_MAX_ITERATIONS; s.need_linearize = 0; }      // (a resident sequence without a frame this step: every solver kernel skips it)
     d.st[w] = s;
     for (int k = 0; k < ISV_MAX_TRACE; k++) {
         d.trace_cost[(size_t)w * ISV_MAX_TRACE + k] = 0; d.trace_radius[(size_t)w * ISV_MAX_TRACE + k] = 0;
@@ -616,6 +617,7 @@ __global__ __launch_bounds__(64) void k_finalize(DevBatch d, int do_update) {
     // one wavefront per window: lane roles for the prior updates, lane per frame for double2vector, lanes over
     // the landmarks for the depths
     const int w = blockIdx.x, lane = threadIdx.x;
+    if (ISV_SEQ_IDLE(d, w)) return;
     const int N = d.N, v = d.Nvo - 1;
     const double *pose = d.pose + (size_t)w * N * 7, *sb = d.sb + (size_t)w * N * 9;
     double *Ps = d.Ps + (size_t)w * N * 3, *Rs = d.Rs + (size_t)w * N * 9, *Vs = d.Vs + (size_t)w * N * 3;
