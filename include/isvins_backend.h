@@ -296,8 +296,8 @@ int  isv_batch_pack_results(isv_backend_t *h, void *device_dst, void *stream);
  * start_frame, track lengths: which feature continues which track) and therefore knows every offset; it never needs the
  * points, depths or window states back -- only the newest frame's state (for processIMU), the oldest pose (pose_output.txt),
  * the solve summary and the landmarks' solve_flag (removeFailures).  Results are bitwise those of the re-upload path
- * (tests/test_gpu_resident.py).  estimate_extrinsic = 0 only (the pseudo-frame of a free extrinsic is not threaded through the
- * slide / build kernels); windows the per-window kernels do not take (> 8192 factors) are refused with ISV_ERR_UNSUPPORTED
+ * (tests/test_gpu_resident.py), estimate_extrinsic = 1 included (round 4: the solved tic[0] / ric[0] stay on the device, k_seq_slide
+ * makes them the next solve's extrinsic block, every result record carries them); windows the per-window kernels do not take (> 8192 factors) are refused with ISV_ERR_UNSUPPORTED
  * BEFORE anything is launched, and the caller (isv_estimator_step does) solves that frame through the upload path.        */
 typedef struct isv_seq_track {       /* one IDFeatures of the seed: feature_manager.h:36-63 */
     int32_t start_frame, n_obs, solve_flag, slot;      /* slot: the caller's storage slot of the track (< tracks capacity), kept for its lifetime */
@@ -331,6 +331,7 @@ typedef struct isv_seq_result {
     double Ps_old[3], Rs_old[9];                                       /* frame 0 after the solve (pose_output.txt row) */
     double Ps_second[3], Rs_second[9];                                 /* frame 1 (becomes frame 0 after a MARGIN_OLD slide) */
     int32_t marg_valid, n_failed_landmarks;
+    double tic[3], ric[9];                                             /* the extrinsic after the solve (estimate_extrinsic = 1: tic[0] / ric[0] of double2vector) */
 } isv_seq_result_t;
 /* allocate the track store: tracks_per_window >= every track alive in a window (good or not) */
 int  isv_backend_seq_enable(isv_backend_t *h, int32_t tracks_per_window);

@@ -102,6 +102,9 @@ int  isv_estimator_status(const isv_estimator_t *e, int32_t seq, int32_t out[8])
 /* the window states; any pointer may be NULL */
 int  isv_estimator_get_window(const isv_estimator_t *e, int32_t seq, double *Ps, double *Rs, double *Vs, double *Bas,
                               double *Bgs, double *Headers);
+/* tic[0] / ric[0] (row-major): the configured extrinsic, or with cfg.estimate_extrinsic = 1 the one the last solve left
+ * (double2vector, src/estimator.cpp:575-583); valid in the resident mode too.  Either pointer may be NULL */
+int  isv_estimator_get_extrinsic(const isv_estimator_t *e, int32_t seq, double *tic, double *ric);
 /* pre_integrations[frame] of the sequence (IntegrationBase members the IMU factor reads), 1 <= frame <= frame_count */
 int  isv_estimator_get_preintegration(const isv_estimator_t *e, int32_t seq, int32_t frame, isv_imu_t *out);
 int  isv_estimator_last_summary(const isv_estimator_t *e, int32_t seq, isv_summary_t *out);
@@ -122,8 +125,9 @@ int  isv_estimator_trajectory(const isv_estimator_t *e, int32_t seq, int32_t whi
  * observations and one (two) IMU record(s) go to the device; the newest / oldest poses, the solve summary and the
  * landmarks' solve_flag come back.  Estimator::slideWindow (src/estimator.cpp:1565-1698) then runs on the device; the host
  * keeps the integer side of the FeatureManager (ids, track lengths) and the IMU pre-integration.  Results are bitwise those
- * of the re-upload path.  Needs the HIP backend, lock-step frames (every sequence gets an image every frame) and
- * estimate_extrinsic = 0; a non-finite solve brings every window back to the host (isv_estimator_failed_solves).
+ * of the re-upload path (estimate_extrinsic = 1 included, round 4: the solved tic[0] / ric[0] stay on the device and are the
+ * next frame's extrinsic block).  Needs the HIP backend; a sequence without an image in a step idles on the device; a
+ * non-finite solve brings every window back to the host (isv_estimator_failed_solves).
  * isv_estimator_get_window is refused while resident; set_resident(e, 0) downloads the windows again (only valid right
  * after isv_estimator_create or ... a frame boundary is handled internally).                                          */
 int  isv_estimator_set_resident(isv_estimator_t *e, int32_t on);

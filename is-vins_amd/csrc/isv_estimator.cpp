@@ -740,6 +740,7 @@ int leave_resident(isv_estimator *e, bool host_has_slid, bool pre_add = false, c
         isv_window_t w{};
         w.Ps = s.wPs.data(); w.Rs = s.wRs.data(); w.Vs = s.wVs.data(); w.Bas = s.wBas.data(); w.Bgs = s.wBgs.data();
         w.pose_prior = &s.wpp; w.vb_prior = &s.wvb; w.relpose = s.wrel.data(); w.rollpitch = s.wrp.data();
+        w.tic = s.wtic; w.ric = s.wric;
         const size_t ntr = ntracks(s);
         std::vector<double> dep(std::max<size_t>(ntr, 1));
         std::vector<int32_t> fl(std::max<size_t>(ntr, 1));
@@ -750,6 +751,7 @@ int leave_resident(isv_estimator *e, bool host_has_slid, bool pre_add = false, c
             std::memcpy(s.Ps[i].data(), &s.wPs[i * 3], 24); std::memcpy(s.Rs[i].data(), &s.wRs[i * 9], 72); std::memcpy(s.Vs[i].data(), &s.wVs[i * 3], 24);
             std::memcpy(s.Bas[i].data(), &s.wBas[i * 3], 24); std::memcpy(s.Bgs[i].data(), &s.wBgs[i * 3], 24);
         }
+        if (e->p.cfg.estimate_extrinsic) { std::memcpy(s.cur_tic, s.wtic, 24); std::memcpy(s.cur_ric, s.wric, 72); s.have_ex = true; }     // (tic[0] / ric[0])
         s.pose_prior = s.wpp; s.vb_prior = s.wvb; s.relpose = s.wrel;
         s.rollpitch.assign(s.wrp.begin(), s.wrp.begin() + w.n_rollpitch);
         for (size_t i = 0; i < ntr; i++) { s.tracks[i].depth = dep[i]; s.tracks[i].solve_flag = fl[i]; }
@@ -862,6 +864,7 @@ int resident_frame(isv_estimator *e, std::vector<std::string> &errs) {
             std::memcpy(s.Ps[0].data(), r.Ps_old, 24); std::memcpy(s.Rs[0].data(), r.Rs_old, 72);
             std::memcpy(s.Ps[1].data(), r.Ps_second, 24); std::memcpy(s.Rs[1].data(), r.Rs_second, 72);
             for (size_t l = 0; l < s.good.size(); l++) s.tracks[s.good[l]].solve_flag = s.frame_flags[l];
+            if (e->p.cfg.estimate_extrinsic) { std::memcpy(s.cur_tic, r.tic, 24); std::memcpy(s.cur_ric, r.ric, 72); s.have_ex = true; }
         } else if (!ok) { s.n_failed++; s.have_to_add = false; }
         s.last_summary = r.summary;
         s.n_solves++;
@@ -1077,6 +1080,17 @@ extern "C" int isv_estimator_get_window(const isv_estimator_t *e, int32_t seq, d
         if (Bgs) std::memcpy(Bgs + i * 3, s.Bgs[i].data(), 24);
         if (Headers) Headers[i] = s.Headers[i];
     }
+    return ISV_OK;
+}
+
+// tic[0] / ric[0] (the configured extrinsic, or with cfg.estimate_extrinsic = 1 what the last solve's double2vector left; current in
+// the resident mode too: every resident frame's result record carries it)
+extern "C" int isv_estimator_get_extrinsic(const isv_estimator_t *e, int32_t seq, double *tic, double *ric) {
+    SEQ_OR_FAIL(e, seq);
+    const Sequence &s = e->seq[seq];
+    const bool est = e->p.cfg.estimate_extrinsic && s.have_ex;
+    if (tic) std::memcpy(tic, est ? s.cur_tic : e->p.tic, 24);
+    if (ric) std::memcpy(ric, est ? s.cur_ric : e->p.ric, 72);
     return ISV_OK;
 }
 

@@ -88,7 +88,9 @@ __device__ inline double rehost_depth(const double *R0, const double *P0, const 
 
 // Estimator::slideWindow for the previous solve, then the newest state and IMU record(s).  One workgroup per window.
 __global__ __launch_bounds__(256) void k_seq_slide(DevBatch d, SeqDev s) {
-    const int w = blockIdx.x, t = threadIdx.x, N = d.N, Nvo = d.Nvo, NI = N - 1;
+    // N: the REAL frames (ALL_BUF_SIZE); with a free extrinsic the device arrays carry one more (pseudo-)frame per window: Nd, and one
+    // more (dummy, skipped) IMU slot: the strides below are Nd / NI, the window logic runs over N / NIr
+    const int w = blockIdx.x, t = threadIdx.x, N = d.Nr, Nd = d.N, Nvo = d.Nvo, NI = Nd - 1, NIr = N - 1;
     const int *hdr = s.f_hdr + (size_t)w * SEQ_HDR;
     const int prev = hdr[FH_PREV];
     if (prev < 0) {                                // no frame for this sequence this step (round 4): its pending slide stays pending
@@ -98,7 +100,7 @@ __global__ __launch_bounds__(256) void k_seq_slide(DevBatch d, SeqDev s) {
     __shared__ int sbuf[8];
     __shared__ double sR0[9], sP0[3], sR1[9], sP1[3];
     __shared__ double sStage[2048];                // prior structs in transit
-    double *Ps = d.Ps + (size_t)w * N * 3, *Rs = d.Rs + (size_t)w * N * 9, *Vs = d.Vs + (size_t)w * N * 3, *Bas = d.Bas + (size_t)w * N * 3, *Bgs = d.Bgs + (size_t)w * N * 3;
+    double *Ps = d.Ps + (size_t)w * Nd * 3, *Rs = d.Rs + (size_t)w * Nd * 9, *Vs = d.Vs + (size_t)w * Nd * 3, *Bas = d.Bas + (size_t)w * Nd * 3, *Bgs = d.Bgs + (size_t)w * Nd * 3;
     if (prev != 0) {
         // ---- back_R0 / back_P0 and the frame that becomes frame 0 (with the extrinsic folded in, as slideWindowOld does) ----
         if (t == 0) {
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(256) void k_seq_slide(DevBatch d, SeqDev s) {
         }
         // ---- IMU factors: MARGIN_OLD drops factor 0 (j <- j + 1); MARGIN_SECOND_NEW keeps 0 .. N-4 (N-3 is re-uploaded merged) ----
         if (prev == 1) {
-            for (int j = 0; j + 1 < NI; j++) {
+            for (int j = 0; j + 1 < NIr; j++) {
                 const size_t fd = (size_t)w * NI + j, fs = fd + 1;
                 double a[3];
                 int sk = 0;
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(256) void k_seq_slide(DevBatch d, SeqDev s) {
     // ---- the new IMU record(s): factor N-2 (and N-3, merged, after MARGIN_SECOND_NEW) ----
     const int nimu = hdr[FH_NIMU];
     for (int r = 0; r < nimu; r++) {
-        const size_t fd = (size_t)w * NI + (NI - nimu + r), fsrc = (size_t)w * 2 + r;
+        const size_t fd = (size_t)w * NI + (NIr - nimu + r), fsrc = (size_t)w * 2 + r;
         for (int e = t; e < ISV_IMU_IN + 225; e += 256) {
             if (e < ISV_IMU_IN) d.imu_in[fd * ISV_IMU_IN + e] = s.f_imu_in[fsrc * ISV_IMU_IN + e];
             else d.imu_cov[fd * 225 + e - ISV_IMU_IN] = s.f_imu_cov[fsrc * 225 + e - ISV_IMU_IN];
@@ -263,6 +265,12 @@ __global__ __launch_bounds__(256) void k_seq_slide(DevBatch d, SeqDev s) {
         if (t == 0) { d.imu_skip[fd] = s.f_imu_skip[fsrc]; s.imu_sel[(size_t)w * 2 + r] = (int32_t)fd; }
     }
     if (t == 0) for (int r = nimu; r < 2; r++) s.imu_sel[(size_t)w * 2 + r] = -1;
+    if (d.est_ex) {
+        // the extrinsic the last solve left in tic / ric (k_finalize, double2vector :577-586) is the pseudo-frame's state of this one
+        // (k_vector2double turns it into para_Ex_Pose's twin); its speed / biases stay zero from the seed
+        if (t < 3) Ps[N * 3 + t] = d.tic[(size_t)w * 3 + t];
+        if (t < 9) Rs[N * 9 + t] = d.ric[(size_t)w * 9 + t];
+    }
 }
 #pragma clang fp contract(fast)
 
@@ -290,7 +298,7 @@ __global__ __launch_bounds__(256) void k_seq_append(DevBatch d, SeqDev s) {
         } else {
             sl = ob.slot; pos = 0;
             if (sl < 0 || sl >= s.Tcap) { atomicOr(&s.err[w], SEQ_ERR_CAP); continue; }
-            s.trk_start[tb + ord] = d.N - 1; s.trk_n[tb + ord] = 1; s.trk_flag[tb + ord] = 0; s.trk_slot[tb + ord] = sl; s.trk_off[tb + ord] = 0; s.trk_depth[tb + ord] = -1.0;
+            s.trk_start[tb + ord] = d.Nr - 1; s.trk_n[tb + ord] = 1; s.trk_flag[tb + ord] = 0; s.trk_slot[tb + ord] = sl; s.trk_off[tb + ord] = 0; s.trk_depth[tb + ord] = -1.0;
             atomicMax(&s_new, ord + 1 - T0);
         }
         double *p = s.pts + (((size_t)tb + sl) * ISV_SEQ_RING + pos) * 3;
@@ -304,7 +312,8 @@ __global__ __launch_bounds__(256) void k_seq_append(DevBatch d, SeqDev s) {
 // Dynamic LDS: sMeta [Lcap] uint32 (host | k << 8) | sF0 [Lcap] int32 | per pair: size, off, order, base [4][NP + 1] int32
 __global__ __launch_bounds__(256) void k_seq_build(DevBatch d, SeqDev s, int lcap) {
     extern __shared__ int ldsi[];
-    const int w = blockIdx.x, t = threadIdx.x, N = d.N, Nvo = d.Nvo, NP = N * (N - 1) / 2;
+    // (Nd: device frames per window = the stride of the state arrays; N: the real frames -- pairs, schedule, factor stream)
+    const int w = blockIdx.x, t = threadIdx.x, Nd = d.N, N = d.Nr, Nvo = d.Nvo, NP = N * (N - 1) / 2;
     unsigned *sMeta = (unsigned *)ldsi;
     int *sF0 = ldsi + lcap, *sSize = sF0 + lcap, *sOff = sSize + NP + 1, *sOrder = sOff + NP + 1, *sBase = sOrder + NP + 1, *sWave = sBase + NP + 1;
     __shared__ int sbuf[8];
@@ -315,9 +324,9 @@ __global__ __launch_bounds__(256) void k_seq_build(DevBatch d, SeqDev s, int lca
     const int L0 = d.lm_off[w], F0 = d.f_off[w];
     // ---- the window as it enters the solve (k_seq_writeback rolls a non-finite solve back to it) ----
     {
-        const size_t o3 = (size_t)w * N * 3, o9 = (size_t)w * N * 9;
-        for (int e = t; e < N * 3; e += 256) { s.Ps0[o3 + e] = d.Ps[o3 + e]; s.Vs0[o3 + e] = d.Vs[o3 + e]; s.Bas0[o3 + e] = d.Bas[o3 + e]; s.Bgs0[o3 + e] = d.Bgs[o3 + e]; }
-        for (int e = t; e < N * 9; e += 256) s.Rs0[o9 + e] = d.Rs[o9 + e];
+        const size_t o3 = (size_t)w * Nd * 3, o9 = (size_t)w * Nd * 9;
+        for (int e = t; e < Nd * 3; e += 256) { s.Ps0[o3 + e] = d.Ps[o3 + e]; s.Vs0[o3 + e] = d.Vs[o3 + e]; s.Bas0[o3 + e] = d.Bas[o3 + e]; s.Bgs0[o3 + e] = d.Bgs[o3 + e]; }
+        for (int e = t; e < Nd * 9; e += 256) s.Rs0[o9 + e] = d.Rs[o9 + e];
         constexpr int SW = sizeof(isv_se3_prior_t) / 8, LW = sizeof(isv_linear9_t) / 8, RW = sizeof(isv_relpose_t) / 8, PW = sizeof(isv_rollpitch_t) / 8;
         const uint64_t *a = (const uint64_t *)(d.se3 + w); uint64_t *b = (uint64_t *)(s.se30 + w);
         for (int e = t; e < SW; e += 256) b[e] = a[e];
@@ -442,7 +451,7 @@ __global__ void k_seq_poison(DevBatch d) { d.st[0].x_cost = __longlong_as_double
 
 // FeatureManager::setDepth's outputs back into the track list, and the frame's small result record
 __global__ __launch_bounds__(256) void k_seq_writeback(DevBatch d, SeqDev s) {
-    const int w = blockIdx.x, t = threadIdx.x, N = d.N;
+    const int w = blockIdx.x, t = threadIdx.x, N = d.N, Nn = d.Nr;      // N: stride (device frames); Nn: the real frames
     if (ISV_SEQ_IDLE(d, w)) return;
     const size_t tb = (size_t)w * s.Tcap;
     __shared__ int s_fail;
@@ -464,6 +473,10 @@ __global__ __launch_bounds__(256) void k_seq_writeback(DevBatch d, SeqDev s) {
         for (int e = t; e < RW * (d.Nvo - 1); e += 256) b[e] = a[e];
         a = (const uint64_t *)(s.rollpitch0 + (size_t)w * d.max_rp); b = (uint64_t *)(d.rollpitch + (size_t)w * d.max_rp);
         for (int e = t; e < PW * d.max_rp; e += 256) b[e] = a[e];
+        if (d.est_ex) {                             // (the extrinsic too: the pseudo-frame's copy is the one that entered the solve)
+            if (t < 3) d.tic[(size_t)w * 3 + t] = s.Ps0[o3 + Nn * 3 + t];
+            if (t < 9) d.ric[(size_t)w * 9 + t] = s.Rs0[o9 + Nn * 9 + t];
+        }
         if (t == 0) d.marg[w].valid = 0;
         __syncthreads();
     }
@@ -477,9 +490,11 @@ __global__ __launch_bounds__(256) void k_seq_writeback(DevBatch d, SeqDev s) {
     __syncthreads();
     double *o = s.out + (size_t)w * SEQ_OUT;
     const double *Ps = d.Ps + (size_t)w * N * 3, *Rs = d.Rs + (size_t)w * N * 9, *Vs = d.Vs + (size_t)w * N * 3, *Bas = d.Bas + (size_t)w * N * 3, *Bgs = d.Bgs + (size_t)w * N * 3;
-    if (t < 3) { o[t] = Ps[(N - 1) * 3 + t]; o[12 + t] = Vs[(N - 1) * 3 + t]; o[15 + t] = Bas[(N - 1) * 3 + t]; o[18 + t] = Bgs[(N - 1) * 3 + t]; o[21 + t] = Ps[t]; o[33 + t] = Ps[3 + t]; }
-    if (t < 9) { o[3 + t] = Rs[(N - 1) * 9 + t]; o[24 + t] = Rs[t]; o[36 + t] = Rs[9 + t]; }
+    if (t < 3) { o[t] = Ps[(Nn - 1) * 3 + t]; o[12 + t] = Vs[(Nn - 1) * 3 + t]; o[15 + t] = Bas[(Nn - 1) * 3 + t]; o[18 + t] = Bgs[(Nn - 1) * 3 + t]; o[21 + t] = Ps[t]; o[33 + t] = Ps[3 + t]; }
+    if (t < 9) { o[3 + t] = Rs[(Nn - 1) * 9 + t]; o[24 + t] = Rs[t]; o[36 + t] = Rs[9 + t]; }
     if (t == 0) { o[45] = d.marg[w].valid; o[46] = s_fail; o[47] = s.err[w]; }
+    if (t < 3) o[48 + t] = d.tic[(size_t)w * 3 + t];
+    if (t < 9) o[51 + t] = d.ric[(size_t)w * 9 + t];
 }
 
 // the seed's points (track-major, oldest observation first, all windows back to back) into the tracks' rings
@@ -519,7 +534,6 @@ static isv_seq_state *seq_of(isv_backend *h) { return (isv_seq_state *)h->seq; }
 extern "C" int isv_backend_seq_enable(isv_backend_t *h, int32_t tracks_per_window) {
     if (!h || tracks_per_window < 1) return ISV_ERR_INVALID_ARG;
     ENTER(h);
-    if (h->cfg.estimate_extrinsic) { h->err = "device-resident sequences: estimate_extrinsic = 0 only"; return ISV_ERR_UNSUPPORTED; }
     if (h->seq) return ((isv_seq_state *)h->seq)->dv.Tcap >= tracks_per_window ? ISV_OK : ISV_ERR_CAPACITY;
     isv_seq_state *q = new isv_seq_state();
     h->seq = q; h->seq_free = [](void *p) { delete (isv_seq_state *)p; };
@@ -649,7 +663,7 @@ extern "C" int isv_backend_seq_frame(isv_backend_t *h, int32_t n, const isv_seq_
     d.B = n; d.Ltot = (int32_t)L; d.Ftot = (int32_t)F; d.n_tiles = 0;
     d.seq_hdr = s.f_hdr;
     d.lg_lcap = (int32_t)((Lmax + 31) / 32 * 32);
-    const bool lg_fits = lin_gram_lds_bytes(N, true, false, LG_WAVES, d.lg_lcap) <= ISV_LDS_PER_CU;
+    const bool lg_fits = lin_gram_lds_bytes(N, true, c.estimate_extrinsic != 0, LG_WAVES, d.lg_lcap) <= ISV_LDS_PER_CU;
     if (!d.lds_T || Fmax > ISV_FUSED_MAX_FACTORS || !lg_fits || h->hc.legacy_visual || F > (size_t)4096 * n) {
         h->err = "device-resident sequences run the per-window kernels only (N <= 20, <= 8192 factors per window): use the upload path";
         return ISV_ERR_UNSUPPORTED;
@@ -663,8 +677,10 @@ extern "C" int isv_backend_seq_frame(isv_backend_t *h, int32_t n, const isv_seq_
 #undef H2D
     // the extrinsic the kernels read is the caller's, every frame: k_finalize leaves R(q(ric)) in d.ric, the re-upload path
     // hands the pristine matrix over again
-    HIPCHK(h, hipMemcpyAsync(d.tic, h->tic0, sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToDevice, st));
-    HIPCHK(h, hipMemcpyAsync(d.ric, h->ric0, sizeof(double) * 9 * (size_t)n, hipMemcpyDeviceToDevice, st));
+    if (!c.estimate_extrinsic) {       // (a free extrinsic is CARRIED from solve to solve: tic[0] / ric[0] of double2vector, round 4)
+        HIPCHK(h, hipMemcpyAsync(d.tic, h->tic0, sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToDevice, st));
+        HIPCHK(h, hipMemcpyAsync(d.ric, h->ric0, sizeof(double) * 9 * (size_t)n, hipMemcpyDeviceToDevice, st));
+    }
     hipLaunchKernelGGL(k_seq_slide, dim3(n), dim3(256), 0, st, d, s);
     hipLaunchKernelGGL(k_seq_append, dim3(n), dim3(256), 0, st, d, s);
     hipLaunchKernelGGL(k_imu_prep, dim3(2 * n), dim3(64), 0, st, d, s.imu_sel);
@@ -703,6 +719,7 @@ extern "C" int isv_backend_seq_frame(isv_backend_t *h, int32_t n, const isv_seq_
         memcpy(r.Ps_new, o, 24); memcpy(r.Rs_new, o + 3, 72); memcpy(r.Vs_new, o + 12, 24); memcpy(r.Bas_new, o + 15, 24); memcpy(r.Bgs_new, o + 18, 24);
         memcpy(r.Ps_old, o + 21, 24); memcpy(r.Rs_old, o + 24, 72); memcpy(r.Ps_second, o + 33, 24); memcpy(r.Rs_second, o + 36, 72);
         r.marg_valid = (int32_t)o[45]; r.n_failed_landmarks = (int32_t)o[46];
+        memcpy(r.tic, o + 48, 24); memcpy(r.ric, o + 51, 72);
         if ((int)o[47] != 0) { h->err = "seq_frame: the device's track list disagrees with the caller's bookkeeping (window " + std::to_string(b) + ", flags " + std::to_string((int)o[47]) + ")"; rc = ISV_ERR_INVALID_ARG; }
         if (solve_flags && solve_flags[b]) memcpy(solve_flags[b], q->h_flags + h->h.lm_off[b], sizeof(int32_t) * (size_t)fr[b].n_landmarks);
     }
@@ -727,8 +744,10 @@ extern "C" int isv_backend_seq_flush(isv_backend_t *h, int32_t n, const int32_t 
         hd[FH_PREV] = prev_slide[b]; hd[FH_MARGIN] = -1; hd[FH_NTRK] = n_tracks[b];
     }
     HIPCHK(h, hipMemcpyAsync(s.f_hdr, q->h_hdr, sizeof(int32_t) * (size_t)n * SEQ_HDR, hipMemcpyHostToDevice, st));
-    HIPCHK(h, hipMemcpyAsync(h->d.tic, h->tic0, sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToDevice, st));
-    HIPCHK(h, hipMemcpyAsync(h->d.ric, h->ric0, sizeof(double) * 9 * (size_t)n, hipMemcpyDeviceToDevice, st));
+    if (!h->cfg.estimate_extrinsic) {
+        HIPCHK(h, hipMemcpyAsync(h->d.tic, h->tic0, sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToDevice, st));
+        HIPCHK(h, hipMemcpyAsync(h->d.ric, h->ric0, sizeof(double) * 9 * (size_t)n, hipMemcpyDeviceToDevice, st));
+    }
     h->d.B = n;
     hipLaunchKernelGGL(k_seq_slide, dim3(n), dim3(256), 0, st, h->d, s);
     HIPCHK(h, hipGetLastError());
@@ -754,7 +773,10 @@ extern "C" int isv_backend_seq_download(isv_backend_t *h, int32_t slot, isv_wind
     const size_t N = d.N, b = (size_t)slot;
     HIPCHK(h, hipStreamSynchronize(h->stream));
 #define DH(dst, src, cnt) HIPCHK(h, hipMemcpy(dst, src, sizeof(*(src)) * (size_t)(cnt), hipMemcpyDeviceToHost))
-    DH(w->Ps, d.Ps + b * N * 3, N * 3); DH(w->Rs, d.Rs + b * N * 9, N * 9); DH(w->Vs, d.Vs + b * N * 3, N * 3); DH(w->Bas, d.Bas + b * N * 3, N * 3); DH(w->Bgs, d.Bgs + b * N * 3, N * 3);
+    const size_t Nr = d.Nr;                    // (the caller's arrays hold the real frames; N is the device stride)
+    DH(w->Ps, d.Ps + b * N * 3, Nr * 3); DH(w->Rs, d.Rs + b * N * 9, Nr * 9); DH(w->Vs, d.Vs + b * N * 3, Nr * 3); DH(w->Bas, d.Bas + b * N * 3, Nr * 3); DH(w->Bgs, d.Bgs + b * N * 3, Nr * 3);
+    if (w->tic) DH(w->tic, d.tic + b * 3, 3);
+    if (w->ric) DH(w->ric, d.ric + b * 9, 9);
     DH(w->pose_prior, d.se3 + b, 1); DH(w->vb_prior, d.lin9 + b, 1); DH(w->relpose, d.relpose + b * (c.n_vo - 1), c.n_vo - 1);
     int32_t nrp = 0;
     DH(&nrp, d.n_rp + b, 1);

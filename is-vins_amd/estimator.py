@@ -30,7 +30,7 @@ class isv_solver_vtbl_t(C.Structure):
 
 EXPORTS = ["isv_estimator_create", "isv_estimator_create_with_solver", "isv_estimator_destroy", "isv_estimator_last_error",
            "isv_estimator_process_imu", "isv_estimator_process_imu_n", "isv_estimator_last_step_ms", "isv_estimator_push_image", "isv_estimator_set_bootstrap", "isv_estimator_step",
-           "isv_estimator_status", "isv_estimator_get_window", "isv_estimator_get_preintegration", "isv_estimator_last_summary", "isv_estimator_trajectory", "isv_estimator_failed_solves",
+           "isv_estimator_status", "isv_estimator_get_window", "isv_estimator_get_extrinsic", "isv_estimator_get_preintegration", "isv_estimator_last_summary", "isv_estimator_trajectory", "isv_estimator_failed_solves",
            "isv_estimator_set_resident", "isv_estimator_resident_frames"]
 
 _bound = False
@@ -53,6 +53,7 @@ def _bind(lib):
     lib.isv_estimator_step.argtypes = [vp]
     lib.isv_estimator_status.argtypes = [vp, C.c_int32, ip]
     lib.isv_estimator_get_window.argtypes = [vp, C.c_int32, dp, dp, dp, dp, dp, dp]
+    lib.isv_estimator_get_extrinsic.argtypes = [vp, C.c_int32, dp, dp]
     lib.isv_estimator_get_preintegration.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(abi.isv_imu_t)]
     lib.isv_estimator_last_summary.argtypes = [vp, C.c_int32, C.POINTER(abi.isv_summary_t)]
     lib.isv_estimator_trajectory.argtypes = [vp, C.c_int32, C.c_int32, dp, C.c_int32]
@@ -137,6 +138,12 @@ class SequenceEstimator:
         Ps, Rs, Vs, Bas, Bgs, H = np.zeros((N, 3)), np.zeros((N, 3, 3)), np.zeros((N, 3)), np.zeros((N, 3)), np.zeros((N, 3)), np.zeros(N)
         self._check(self.lib.isv_estimator_get_window(self.h, seq, abi._p(Ps), abi._p(Rs), abi._p(Vs), abi._p(Bas), abi._p(Bgs), abi._p(H)), "get_window")
         return dict(Ps=Ps, Rs=Rs, Vs=Vs, Bas=Bas, Bgs=Bgs, Headers=H)
+
+    def extrinsic(self, seq):
+        """(tic[0], ric[0]): configured, or as the last solve left them with cfg.estimate_extrinsic = 1"""
+        tic, ric = np.zeros(3), np.zeros((3, 3))
+        self._check(self.lib.isv_estimator_get_extrinsic(self.h, seq, abi._p(tic), abi._p(ric)), "get_extrinsic")
+        return tic, ric
 
     def preintegration(self, seq, frame):
         out = abi.isv_imu_t()
