@@ -91,7 +91,7 @@ static int create_impl(isv_backend *h) {
     TRY(dalloc(h, &d.n_rp, B));
     TRY(dalloc(h, &d.strip, F * ISV_PROJ_STRIP)); TRY(dalloc(h, &d.fcost, F));
     TRY(dalloc(h, &d.imu_strip, NI * ISV_IMU_STRIP)); TRY(dalloc(h, &d.imu_cost, NI));
-    TRY(dalloc(h, &d.imu_raw, NI * 480)); HIPCHK(h, hipMemset(d.imu_raw, 0, NI * 480 * sizeof(double)));
+    TRY(dalloc(h, &d.imu_raw, (NI + 7) / 8 * 8 * 144)); HIPCHK(h, hipMemset(d.imu_raw, 0, (NI + 7) / 8 * 8 * 144 * sizeof(double)));      // (ISV_IMU_RAWC = 144, isv_linearize.hip)
     TRY(dalloc(h, &d.prior_strip, B * (size_t)d.prior_strip_sz)); TRY(dalloc(h, &d.prior_cost, B * (size_t)d.n_prior_slots));
     TRY(dalloc(h, &d.cost, B)); TRY(dalloc(h, &d.st, B));
     d.prior_H_sz = PH_REL0 + PH_REL_SZ * (c.n_vo - 1) + PH_RP_SZ * c.max_rollpitch;
@@ -445,7 +445,7 @@ static int enqueue_linearize(isv_backend *h, bool timed) {
     if (timed) HIPCHK(h, hipEventRecord(h->ev[2], st));
     if (NI) {
         hipLaunchKernelGGL(k_imu_raw, dim3((unsigned)(NI + 63) / 64), dim3(256), 0, st, d, d.pose, d.sb, 0);
-        hipLaunchKernelGGL(k_imu_weight, dim3((unsigned)NI), dim3(64), 0, st, d, d.imu_cost, 0);
+        hipLaunchKernelGGL(k_imu_weight, dim3((unsigned)(NI + 7) / 8), dim3(256), 0, st, d, d.imu_cost, 0);
     }
     {
         hipLaunchKernelGGL(k_prior_linearize<true>, dim3(d.B), dim3(64), prior_lds_bytes(d.n_prior_slots), st, d, d.pose, d.sb, d.prior_cost, 0);

@@ -94,7 +94,7 @@ struct DevBatch {
     double *strip;                      // [Ftot][28]  Jacobian strips, CSR factor order
     double *fcost;                      // [Ftot]      rho(s)/2 per factor
     double *imu_strip;                  // [B (N-1)][465]
-    double *imu_raw;                    // [B (N-1)][15][32] raw (unweighted) [J | r | 0] of the IMU factors, static zero pattern
+    double *imu_raw;                    // [B (N-1) / 8][144][8] the raw (unweighted) IMU residual / Jacobian entries that are not structurally 0 / +-1, eight factors interleaved (k_imu_raw)
     double *imu_cost;                   // [B (N-1)]
     double *prior_strip;                // [B][prior_strip_sz]
     double *prior_cost;                 // [B][n_prior_slots]

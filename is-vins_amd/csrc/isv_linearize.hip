@@ -545,11 +545,22 @@ template __global__ void k_imu_linearize<false>(DevBatch, const double *, const 
 // IMU factors at x with Jacobians (solver schedule), two kernels:
 //   k_imu_raw     raw residual (15) and raw Jacobian blocks (15 x 30) of 64 factors per workgroup; wavefront p
 //                 computes part p (0 residual, 1 d/d pose_i, 2 d/d speedbias_i, 3 d/d pose_j, speedbias_j)
-//                 with one FACTOR PER LANE, so no wavefront diverges over the four bodies; output is the
-//                 dense [15][32] matrix [J | r | 0] per factor in HBM (zero pattern static, set at create).
-//   k_imu_weight  one wavefront per factor, FP64 MFMA (v_mfma_f64_16x16x4): Jw = sqrt_info * [J | r]
-//                 (2 tiles x 4 k-steps), then H = Jw^T Jw (3 lower tiles x 4 k-steps) whose row 30 is J^T r;
-//                 strips, packed J^T J and cost leave through LDS as coalesced stores.
+//                 with one FACTOR PER LANE, so no wavefront diverges over the four bodies.  Output (round 4): only the
+//                 142 entries that are not structurally 0 / +-1 (the block map of include/factor/imu_factor.h:66-155),
+//                 as a COMPACT record of ISV_IMU_RAWC doubles, eight factors interleaved (value j of factor f at
+//                 ((f / 8) * ISV_IMU_RAWC + j) * 8 + f % 8): a store instruction of 64 lanes fills 8 whole cache lines.
+//                 (The dense [15][32] record it wrote before put every lane's 8 bytes in a cache line of its own, 3840 B
+//                 apart: 52 us per launch at N = 11 and 152 us at N = 18, where the 67 MB buffer no longer sat in L2.)
+//   k_imu_weight  one workgroup per EIGHT factors: the group's 9 KB of compact values arrive with coalesced loads and stay compact
+//                 in LDS; every lane knows which compact value (or 0 / +-1) each of its eight entries of the dense [16][32]
+//                 operand [J | r | 0] is; then one wavefront per factor (two factors each),
+//                 FP64 MFMA (v_mfma_f64_16x16x4): Jw = sqrt_info * [J | r] (2 tiles x 4 k-steps; sqrt_info goes from global
+//                 memory straight into the A operand), then H = Jw^T Jw (3 lower tiles x 4 k-steps) whose row 30 is J^T r --
+//                 the A / B operands of these are the Jw accumulator registers themselves (row 4 s + (lane >> 4) of a C tile
+//                 is register s of the same lane), no trip through LDS; packed J^T J and cost leave through LDS as coalesced
+//                 stores.  Same products and sums as the one-wavefront-per-factor kernel of round 3, bit for bit.
+#define ISV_IMU_RAWC 144
+// compact record: residual 0..14 | pose_i blocks 16..51 | speedbias_i blocks 52..114 | pose_j / speedbias_j blocks 115..141 (c_imu_block_of below)
 __global__ __launch_bounds__(256) void k_imu_raw(DevBatch d, const double *pose_src, const double *sb_src, int gate) {
     const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
     const int N = d.N, NI = d.B * (N - 1);
@@ -567,8 +578,8 @@ __global__ __launch_bounds__(256) void k_imu_raw(DevBatch d, const double *pose_
     const double *rec = d.imu_in + (size_t)f * ISV_IMU_IN;
     const double *pi = pose_src + ((size_t)w * N + i) * 7, *pj = pi + 7;
     const double *si = sb_src + ((size_t)w * N + i) * 9, *sj = si + 9;
-    double *raw = d.imu_raw + (size_t)f * 480;
-#define RAW(r, c) raw[(r) * 32 + (c)]
+    double *raw = d.imu_raw + (size_t)(f >> 3) * (ISV_IMU_RAWC * 8) + (f & 7);
+#define RAWC(j) raw[(j) * 8]
     Quat Qi = q_from_pose(pi), Qj = q_from_pose(pj);
     Quat Qii = q_inv(Qi);
     const double dt = rec[IMU_DT];
@@ -581,9 +592,10 @@ __global__ __launch_bounds__(256) void k_imu_raw(DevBatch d, const double *pose_
         double r15[15];
         imu_raw_residual(d.G, rec, pi, pj, si, sj, r15);
 #pragma unroll
-        for (int k = 0; k < 15; k++) RAW(k, 30) = r15[k];
+        for (int k = 0; k < 15; k++) RAWC(k) = r15[k];
     } else if (part == 1) {
         // raw Jacobian (imu_factor.h:66-155), tangent columns: pose_i 0..5, sb_i 6..14, pose_j 15..20, sb_j 21..29
+        // blocks (row, col): (0,0) (0,3) (3,3) (6,3)
         double RiT[9], u[3], o1[3], o2[3], S1[9], S2[9], B1[9], L[9], Rr[9];
         q_to_R(Qii, RiT);
         for (int k = 0; k < 3; k++) u[k] = 0.5 * d.G[k] * dt * dt + pj[k] - pi[k] - si[k] * dt;
@@ -599,141 +611,172 @@ __global__ __launch_bounds__(256) void k_imu_raw(DevBatch d, const double *pose_
 #pragma unroll
             for (int c = 0; c < 3; c++) B1[r * 3 + c] += av[r] * (-bv[c]);
 #pragma unroll
-        for (int a = 0; a < 3; a++)
-#pragma unroll
-            for (int b = 0; b < 3; b++) {
-                const int ab = a * 3 + b;
-                RAW(0 + a, 0 + b) = -RiT[ab];
-                RAW(0 + a, 3 + b) = S1[ab];
-                RAW(3 + a, 3 + b) = -B1[ab];
-                RAW(6 + a, 3 + b) = S2[ab];
-            }
+        for (int ab = 0; ab < 9; ab++) {
+            RAWC(16 + ab) = -RiT[ab];
+            RAWC(25 + ab) = S1[ab];
+            RAWC(34 + ab) = -B1[ab];
+            RAWC(43 + ab) = S2[ab];
+        }
     } else if (part == 2) {
+        // blocks (0,6) (0,9) (0,12) (3,12) (6,6) (6,9) (6,12); (9,9) and (12,12) are -I (k_imu_weight fills them in)
         double RiT[9], L[9], T[9];
         q_to_R(Qii, RiT);
         qleft33(q_mul(q_mul(q_inv(Qj), Qi), dq), L);
         m3_mul(L, rec + IMU_DQ_DBG, T);
 #pragma unroll
-        for (int a = 0; a < 3; a++)
-#pragma unroll
-            for (int b = 0; b < 3; b++) {
-                const int ab = a * 3 + b;
-                RAW(0 + a, 6 + b) = -RiT[ab] * dt;
-                RAW(0 + a, 9 + b) = -rec[IMU_DP_DBA + ab];
-                RAW(0 + a, 12 + b) = -rec[IMU_DP_DBG + ab];
-                RAW(3 + a, 12 + b) = -T[ab];
-                RAW(6 + a, 6 + b) = -RiT[ab];
-                RAW(6 + a, 9 + b) = -rec[IMU_DV_DBA + ab];
-                RAW(6 + a, 12 + b) = -rec[IMU_DV_DBG + ab];
-                RAW(9 + a, 9 + b) = (a == b) ? -1.0 : 0.0;
-                RAW(12 + a, 12 + b) = (a == b) ? -1.0 : 0.0;
-            }
+        for (int ab = 0; ab < 9; ab++) {
+            RAWC(52 + ab) = -RiT[ab] * dt;
+            RAWC(61 + ab) = -rec[IMU_DP_DBA + ab];
+            RAWC(70 + ab) = -rec[IMU_DP_DBG + ab];
+            RAWC(79 + ab) = -T[ab];
+            RAWC(88 + ab) = -RiT[ab];
+            RAWC(97 + ab) = -rec[IMU_DV_DBA + ab];
+            RAWC(106 + ab) = -rec[IMU_DV_DBG + ab];
+        }
     } else {
+        // blocks (0,15) (3,18) (6,21); (9,24) and (12,27) are +I
         double RiT[9], B2[9];
         q_to_R(Qii, RiT);
         qleft33(q_mul(q_mul(q_inv(cdq), Qii), Qj), B2);
 #pragma unroll
-        for (int a = 0; a < 3; a++)
-#pragma unroll
-            for (int b = 0; b < 3; b++) {
-                const int ab = a * 3 + b;
-                RAW(0 + a, 15 + b) = RiT[ab];
-                RAW(3 + a, 18 + b) = B2[ab];
-                RAW(6 + a, 21 + b) = RiT[ab];
-                RAW(9 + a, 24 + b) = (a == b) ? 1.0 : 0.0;
-                RAW(12 + a, 27 + b) = (a == b) ? 1.0 : 0.0;
-            }
+        for (int ab = 0; ab < 9; ab++) {
+            RAWC(115 + ab) = RiT[ab];
+            RAWC(124 + ab) = B2[ab];
+            RAWC(133 + ab) = RiT[ab];
+        }
     }
-#undef RAW
+#undef RAWC
 }
 
 typedef double double4i __attribute__((ext_vector_type(4)));
-__global__ __launch_bounds__(64) void k_imu_weight(DevBatch d, double *cost_out, int gate) {
-    // 6.3 KB of LDS (it was 14.3): S (16x17) and one 16x32 buffer that holds raw, then Jw = S raw; the packed J^T J
-    // overlays both once Jw has been consumed.  The launch is one single-wavefront workgroup per IMU factor, so the
-    // LDS footprint sets how many of them share a CU, i.e. how many rounds the 10 (N-1) x B workgroups take.
-    static_assert(ISV_IMU_H + 1 <= 16 * 17 + 16 * 32, "the packed J^T J must fit the staging buffers it overlays");
-    __shared__ __align__(16) double sA[16 * 17 + 16 * 32];
-    double *sS = sA, *sRaw = sA + 16 * 17, *sJw = sRaw, *sH = sA;
-    const int f = blockIdx.x, t = threadIdx.x;
-    const int N = d.N, w = f / (N - 1);
-    if (gate) {
-        const SolveState &ss = d.st[w];
-        if (!(ss.termination == ISV_TERM_RUNNING && (gate == 1 ? ss.need_linearize != 0 : ss.step_valid != 0))) return;
+DEV double imu_lane_value(double v, int lane) {
+    union { double d; int i[2]; } u;
+    u.d = v;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], lane);
+    u.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
+    return u.d;
+}
+// where entry (row, col) of the dense [16][32] operand [J | r | 0] comes from: >= 0 compact value j, -1 zero, -2 / -3 the constants -1 / +1
+// (3x3 block map of include/factor/imu_factor.h:66-155; block rows: p, q, v, ba, bg; block columns: p_i q_i v_i ba_i bg_i p_j q_j v_j ba_j bg_j)
+__constant__ short c_imu_block_of[5][10] = {{16, 25, 52, 61, 70, 115, -1, -1, -1, -1},
+                                            {-1, 34, -1, -1, 79, -1, 124, -1, -1, -1},
+                                            {-1, 43, 88, 97, 106, -1, -1, 133, -1, -1},
+                                            {-1, -1, -1, -2, -1, -1, -1, -1, -3, -1},
+                                            {-1, -1, -1, -1, -2, -1, -1, -1, -1, -3}};
+DEV int imu_compact_of(int r, int c) {
+    if (r >= 15 || c >= 31) return -1;
+    if (c == 30) return r;
+    const int a = r % 3, cc = c % 3, b0 = c_imu_block_of[r / 3][c / 3];
+    if (b0 >= 0) return b0 + a * 3 + cc;
+    return (b0 == -1 || a != cc) ? -1 : b0;
+}
+__global__ __launch_bounds__(256) void k_imu_weight(DevBatch d, double *cost_out, int gate) {
+    // 25 KB of LDS per eight factors: their compact values (9 KB) and one [16][32] staging buffer per wavefront (Jw for the strips, then the packed J^T J)
+    static_assert(ISV_IMU_H <= 16 * 32, "the packed J^T J must fit the staging buffer");
+    __shared__ __align__(16) double sC[ISV_IMU_RAWC * 8];
+    __shared__ __align__(16) double sA[4 * 512];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int N = d.N, NI = d.B * (N - 1), f0 = blockIdx.x * 8;
+    // 0: nothing to do (beyond the batch / gated off), 1: a skipped factor (cost 0), 2: evaluate
+    auto state_of = [&](int f) -> int {
+        if (f >= NI) return 0;
+        if (gate) {
+            const SolveState &ss = d.st[f / (N - 1)];
+            if (!(ss.termination == ISV_TERM_RUNNING && (gate == 1 ? ss.need_linearize != 0 : ss.step_valid != 0))) return 0;
+        }
+        return d.imu_skip[f] ? 1 : 2;
+    };
+    if (!__syncthreads_or(state_of(f0 + (t & 7)) == 2)) {
+        if (t < 8 && state_of(f0 + t) == 1) cost_out[f0 + t] = 0.0;
+        return;
     }
-    if (d.imu_skip[f]) { if (t == 0) cost_out[f] = 0.0; return; }
-    const double *Sg = d.imu_sqrt + (size_t)f * 225, *Rg = d.imu_raw + (size_t)f * 480;
-    {
-        // (round 4) all thirteen loads of a lane in flight together: clamped addresses, the padding zeros applied when the values
-        // go to LDS.  Written as `cond ? load : 0.0` per loop trip the compiler put every load in a branch of its own behind an
-        // s_waitcnt vmcnt(0): thirteen serialised memory latencies at the top of each of the 10 240 single-wavefront workgroups.
-        double vs[5], vr[8];
+    const int i = lane & 15, kq = lane >> 4;
+    // every global load of the thread in flight together (clamped addresses; the masks are applied at use)
+    const double *Rg = d.imu_raw + (size_t)blockIdx.x * (ISV_IMU_RAWC * 8);
+    double rc[5], sv[2][4];
 #pragma unroll
-        for (int k = 0; k < 5; k++) { const int e = t + 64 * k, r = e / 17, c = e - 17 * r; vs[k] = Sg[(r < 15 && c < 15) ? r * 15 + c : 0]; }
+    for (int k = 0; k < 5; k++) { const int e = t + 256 * k; rc[k] = Rg[e < ISV_IMU_RAWC * 8 ? e : 0]; }
 #pragma unroll
-        for (int k = 0; k < 8; k++) { const int e = t + 64 * k; vr[k] = Rg[e < 480 ? e : 479]; }
+    for (int q = 0; q < 2; q++) {
+        const int f = f0 + 2 * wv + q;
+        const double *Sg = d.imu_sqrt + (size_t)(f < NI ? f : NI - 1) * 225;
 #pragma unroll
-        for (int k = 0; k < 5; k++) { const int e = t + 64 * k, r = e / 17, c = e - 17 * r; if (e < 16 * 17) sS[e] = (r < 15 && c < 15) ? vs[k] : 0.0; }
-#pragma unroll
-        for (int k = 0; k < 8; k++) { const int e = t + 64 * k; sRaw[e] = e < 480 ? vr[k] : 0.0; }
+        for (int s4 = 0; s4 < 4; s4++) { const int k = 4 * s4 + kq; sv[q][s4] = Sg[(i < 15 && k < 15) ? i * 15 + k : 0]; }
     }
+    // the lane's eight B-operand entries (rows 4 s + kq, columns i and 16 + i of [J | r | 0]) as compact indices
+    int src[4][2];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; s4++) { src[s4][0] = imu_compact_of(4 * s4 + kq, i); src[s4][1] = imu_compact_of(4 * s4 + kq, 16 + i); }
+#pragma unroll
+    for (int k = 0; k < 5; k++) { const int e = t + 256 * k; if (e < ISV_IMU_RAWC * 8) sC[e] = rc[k]; }
     __syncthreads();
-    const int i = t & 15, kq = t >> 4;
-    double4i a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
-#pragma unroll
-    for (int s4 = 0; s4 < 4; s4++) {                        // Jw = S * raw: output tiles cols 0..15 and 16..31
-        const int k = 4 * s4 + kq;
-        const double av = sS[i * 17 + k], b0 = sRaw[k * 32 + i], b1 = sRaw[k * 32 + 16 + i];
-        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b0, a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b1, a1, 0, 0, 0);
-    }
-    __syncthreads();                                        // raw has been read by every lane: Jw takes its place
-#pragma unroll
-    for (int reg = 0; reg < 4; reg++) {                     // C/D layout: col = lane & 15, row = (lane >> 4) + 4 reg
-        const int row = kq + 4 * reg;
-        sJw[row * 32 + i] = a0[reg]; sJw[row * 32 + 16 + i] = a1[reg];
-    }
-    __syncthreads();
-    double4i h00 = {0, 0, 0, 0}, h10 = {0, 0, 0, 0}, h11 = {0, 0, 0, 0};
-#pragma unroll
-    for (int s4 = 0; s4 < 4; s4++) {                        // H = Jw^T Jw, lower tiles
-        const int k = 4 * s4 + kq;
-        const double x0 = sJw[k * 32 + i], x1 = sJw[k * 32 + 16 + i];
-        h00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, h00, 0, 0, 0);
-        h10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x0, h10, 0, 0, 0);
-        h11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, h11, 0, 0, 0);
-    }
-    // strip layout: [r15 | 15x6 | 15x9 | 15x6 | 15x9] row-major blocks.  The LDS solver path works from the J^T J
-    // blocks alone (k_build_solve_sb, k_dogleg), so the strips are only written for the linearise API (gate 0)
-    // and for the generic path.  (Jw is read here, before J^T J overwrites it.)
-    double *out = d.imu_strip + (size_t)f * ISV_IMU_STRIP;
     const bool want_strip = gate == 0 || !d.lds_T;
-    if (want_strip && t < 15) out[t] = sJw[t * 32 + 30];
-    for (int e = t; want_strip && e < 450; e += 64) {
-        int row, c;
-        if (e < 90) { row = e / 6; c = e - 6 * row; }
-        else if (e < 225) { const int q = e - 90; row = q / 9; c = 6 + (q - 9 * row); }
-        else if (e < 315) { const int q = e - 225; row = q / 6; c = 15 + (q - 6 * row); }
-        else { const int q = e - 315; row = q / 9; c = 21 + (q - 9 * row); }
-        out[15 + e] = sJw[row * 32 + c];
-    }
-    if (t == 0) {
-        double s = 0;
-        for (int k = 0; k < 15; k++) s += sJw[k * 32 + 30] * sJw[k * 32 + 30];
-        cost_out[f] = 0.5 * s;                              // no loss function on IMU factors (:1050)
-    }
-    __syncthreads();
-    // packed J^T J (pairs a >= b at a(a+1)/2 + b, a, b < 30) then J^T r (row 30 of H)
+    double *sR = sA + wv * 512, *sH = sR;
 #pragma unroll
-    for (int reg = 0; reg < 4; reg++) {
-        const int row = kq + 4 * reg;
-        { const int a = row, b = i; if (b <= a) sH[a * (a + 1) / 2 + b] = h00[reg]; }
-        { const int a = 16 + row, b = i; if (a < 30) sH[a * (a + 1) / 2 + b] = h10[reg]; else if (a == 30) sH[465 + b] = h10[reg]; }
-        { const int a = 16 + row, b = 16 + i; if (a < 30) { if (b <= a) sH[a * (a + 1) / 2 + b] = h11[reg]; } else if (a == 30 && b < 30) sH[465 + b] = h11[reg]; }
+    for (int q = 0; q < 2; q++) {
+        const int fl = 2 * wv + q, f = f0 + fl, stf = state_of(f);          // (wave-uniform)
+        if (stf == 0) continue;
+        if (stf == 1) { if (lane == 0) cost_out[f] = 0.0; continue; }
+        double4i a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) {                        // Jw = S * raw: output tiles cols 0..15 and 16..31
+            const int k = 4 * s4 + kq, j0 = src[s4][0], j1 = src[s4][1];
+            const double av = (i < 15 && k < 15) ? sv[q][s4] : 0.0;
+            const double c0 = sC[(j0 > 0 ? j0 : 0) * 8 + fl], c1 = sC[(j1 > 0 ? j1 : 0) * 8 + fl];
+            const double b0 = j0 >= 0 ? c0 : (j0 == -1 ? 0.0 : (j0 == -2 ? -1.0 : 1.0)), b1 = j1 >= 0 ? c1 : (j1 == -1 ? 0.0 : (j1 == -2 ? -1.0 : 1.0));
+            a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b0, a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b1, a1, 0, 0, 0);
+        }
+        double4i h00 = {0, 0, 0, 0}, h10 = {0, 0, 0, 0}, h11 = {0, 0, 0, 0};
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) {                        // H = Jw^T Jw, lower tiles: Jw[4 s4 + kq][i] is register s4 of this lane
+            const double x0 = a0[s4], x1 = a1[s4];
+            h00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, h00, 0, 0, 0);
+            h10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x0, h10, 0, 0, 0);
+            h11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, h11, 0, 0, 0);
+        }
+        // strip layout: [r15 | 15x6 | 15x9 | 15x6 | 15x9] row-major blocks.  The LDS solver path works from the J^T J
+        // blocks alone (k_build_solve_sb, k_dogleg), so the strips are only written for the linearise API (gate 0)
+        // and for the generic path: Jw through the wavefront's staging buffer
+        if (want_strip) {
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {                 // C/D layout: col = lane & 15, row = (lane >> 4) + 4 reg
+                const int row = kq + 4 * reg;
+                sR[row * 32 + i] = a0[reg]; sR[row * 32 + 16 + i] = a1[reg];
+            }
+            ISV_WSYNC();
+            double *out = d.imu_strip + (size_t)f * ISV_IMU_STRIP;
+            if (lane < 15) out[lane] = sR[lane * 32 + 30];
+            for (int e = lane; e < 450; e += 64) {
+                int row, c;
+                if (e < 90) { row = e / 6; c = e - 6 * row; }
+                else if (e < 225) { const int qq = e - 90; row = qq / 9; c = 6 + (qq - 9 * row); }
+                else if (e < 315) { const int qq = e - 225; row = qq / 6; c = 15 + (qq - 6 * row); }
+                else { const int qq = e - 315; row = qq / 9; c = 21 + (qq - 9 * row); }
+                out[15 + e] = sR[row * 32 + c];
+            }
+            ISV_WSYNC();
+        }
+        {
+            // 0.5 |Jw[:, 30]|^2, rows in order (no loss function on IMU factors, :1050): row k sits in lane 14 + 16 (k & 3), register k >> 2 of tile 1
+            double s = 0;
+#pragma unroll
+            for (int k = 0; k < 15; k++) { const double v = imu_lane_value(a1[k >> 2], 14 + 16 * (k & 3)); s += v * v; }
+            if (lane == 0) cost_out[f] = 0.5 * s;
+        }
+        // packed J^T J (pairs a >= b at a(a+1)/2 + b, a, b < 30) then J^T r (row 30 of H)
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+            const int row = kq + 4 * reg;
+            { const int a = row, b = i; if (b <= a) sH[a * (a + 1) / 2 + b] = h00[reg]; }
+            { const int a = 16 + row, b = i; if (a < 30) sH[a * (a + 1) / 2 + b] = h10[reg]; else if (a == 30) sH[465 + b] = h10[reg]; }
+            { const int a = 16 + row, b = 16 + i; if (a < 30) { if (b <= a) sH[a * (a + 1) / 2 + b] = h11[reg]; } else if (a == 30 && b < 30) sH[465 + b] = h11[reg]; }
+        }
+        ISV_WSYNC();
+        double *H = d.imu_H + (size_t)f * ISV_IMU_H;
+        for (int e = lane; e < ISV_IMU_H; e += 64) H[e] = sH[e];
+        ISV_WSYNC();
     }
-    __syncthreads();
-    double *H = d.imu_H + (size_t)f * ISV_IMU_H;
-    for (int e = t; e < ISV_IMU_H; e += 64) H[e] = sH[e];
 }
 
 

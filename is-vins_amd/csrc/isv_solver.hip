@@ -901,7 +901,7 @@ int isv_solver_enqueue(DevBatch &d, const SolverHost &hc, hipStream_t st, hipStr
         HCHK(hipEventRecord(fj[0], st)); HCHK(hipStreamWaitEvent(st2, fj[0], 0));
         if (NI) {
             hipLaunchKernelGGL(k_imu_raw, dim3((unsigned)(NI + 63) / 64), dim3(256), 0, st2, d, d.pose, d.sb, 1);
-            hipLaunchKernelGGL(k_imu_weight, dim3((unsigned)NI), dim3(64), 0, st2, d, d.imu_cost, 1);
+            hipLaunchKernelGGL(k_imu_weight, dim3((unsigned)(NI + 7) / 8), dim3(256), 0, st2, d, d.imu_cost, 1);
         }
         hipLaunchKernelGGL(k_prior_linearize<true>, dim3(d.B), dim3(64), prior_lds_bytes(d.n_prior_slots), st2, d, d.pose, d.sb, d.prior_cost, 1);
         HCHK(hipEventRecord(fj[1], st2));
