@@ -23,6 +23,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <functional>
+#include <mutex>
 #include <thread>
 #include <cstdio>
 #include <cstring>
@@ -70,6 +71,7 @@ struct PgDev {
     double *cov;                 // [poses][36] tangent-space marginal covariance (zero for constant poses)
     isv_pgo_result_t *res;
     int32_t idx_lds_rows, idx_lds_cols;   // capacity of the LDS copies of start / rowptr / colptr and of colrows (0: read them from global memory)
+    int32_t g0, _pad;                     // first graph of this launch (a batch call launches its graphs in chunks, round 4)
 };
 
 // ---- 6x6 helpers: lane e < 36 owns element (a, b) = (e / 6, e % 6) -------------------------------------------------
@@ -211,18 +213,19 @@ DEV double pg_edge_eval(const PgEdge &E, const double *pose, double huber, doubl
 
 __global__ __launch_bounds__(64) void k_pgo(PgDev dv) {
     __shared__ double T0[36], T1[36], T2[36];
-    const PgGraph G = dv.graphs[blockIdx.x];
+    const int gid = blockIdx.x + dv.g0;
+    const PgGraph G = dv.graphs[gid];
     const int lane = threadIdx.x, nf = G.nf, n = 6 * nf;
     double *pose = dv.pose + (size_t)G.pose0 * 7, *cand = dv.cand + (size_t)G.pose0 * 7;
     const int32_t *free_of = dv.free_of + G.pose0;
     PgEdge *edges = dv.edges + G.edge0;
     double *eres = dv.eres + (size_t)G.edge0 * 6, *ejac = dv.ejac + (size_t)G.edge0 * 72;
-    const int32_t *adj_ptr = dv.adj_ptr + G.free0 + blockIdx.x, *adj = dv.adj + G.adj0;
-    const int32_t *start = dv.start + G.free0, *rowptr = dv.rowptr + G.free0 + blockIdx.x;
-    const int32_t *colptr = dv.colptr + G.free0 + blockIdx.x, *colrows = dv.colrows + G.col0;
+    const int32_t *adj_ptr = dv.adj_ptr + G.free0 + gid, *adj = dv.adj + G.adj0;
+    const int32_t *start = dv.start + G.free0, *rowptr = dv.rowptr + G.free0 + gid;
+    const int32_t *colptr = dv.colptr + G.free0 + gid, *colrows = dv.colrows + G.col0;
     double *H = dv.H + (size_t)G.blk0 * 36, *L = dv.L + (size_t)G.blk0 * 36, *Z = dv.Z + (size_t)G.blk0 * 36;
     double *scale = dv.scale + G.vec0, *diag = dv.diag + G.vec0, *grad = dv.grad + G.vec0, *step = dv.step + G.vec0, *ysol = dv.ysol + G.vec0;
-    isv_pgo_result_t &res = dv.res[blockIdx.x];
+    isv_pgo_result_t &res = dv.res[gid];
     const int e = lane, ea = e / 6, eb = e - 6 * ea;    // my element of a 6x6 block (lanes 0..35)
     // the envelope's index arrays in LDS when they fit (every block address of the factorisation / substitution recurrences
     // starts from them: one LDS read instead of a dependent global load per step)
@@ -726,7 +729,13 @@ struct isv_pgo {
     std::vector<void *> allocs;
     size_t cap_pose = 0, cap_edge = 0, cap_blk = 0, cap_adj = 0, cap_col = 0;
     void *pin = nullptr; size_t pin_cap = 0;      // pinned staging of a batch call's arrays (grown on demand, kept)
-    hipEvent_t ev[2] = {nullptr, nullptr};       // around k_pgo of the last call (isv_pgo_last_kernel_ms)
+    hipEvent_t ev[2] = {nullptr, nullptr};       // (unused since the chunked launches; kept for the destroy loop)
+    // a batch call goes to the device in up to PG_CHUNKS chunks of graphs, each on a stream of its own: chunk c + 1 is assembled and
+    // copied while chunk c is being solved, and chunk c is written back while chunk c + 1 still runs (round 4)
+    static constexpr int PG_CHUNKS = 4;
+    hipStream_t cstream[PG_CHUNKS] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t kev[PG_CHUNKS][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};     // around every chunk's k_pgo
+    double last_kernel_ms = -1;                   // first chunk's kernel start -> last chunk's kernel end of the last call
     double last_blocks = 0;                       // skyline blocks of the last batch (all graphs)
 };
 
@@ -744,10 +753,8 @@ extern "C" const char *isv_pgo_last_error(const isv_pgo_t *h) { return h ? h->er
 // blocks its graphs held
 extern "C" int64_t isv_pgo_structure_cache_hits(const isv_pgo_t *h) { return h ? h->cache_hits : 0; }
 extern "C" int isv_pgo_last_kernel_ms(isv_pgo_t *h, double *ms, double *skyline_blocks) {
-    if (!h || !ms || !h->ev[0]) return ISV_ERR_INVALID_ARG;
-    float f = 0;
-    if (hipEventElapsedTime(&f, h->ev[0], h->ev[1]) != hipSuccess) { (void)hipGetLastError(); return ISV_ERR_DEVICE; }
-    *ms = f;
+    if (!h || !ms || h->last_kernel_ms < 0) return ISV_ERR_INVALID_ARG;
+    *ms = h->last_kernel_ms;
     if (skyline_blocks) *skyline_blocks = h->last_blocks;
     return ISV_OK;
 }
@@ -759,6 +766,8 @@ extern "C" void isv_pgo_destroy(isv_pgo_t *h) {
     for (auto &e : h->ev) if (e) (void)hipEventDestroy(e);
     if (h->pin) (void)hipHostFree(h->pin);
     if (h->stream) (void)hipStreamDestroy(h->stream);
+    for (auto &cs : h->cstream) if (cs) (void)hipStreamDestroy(cs);
+    for (auto &ke : h->kev) for (auto &e : ke) if (e) (void)hipEventDestroy(e);
     delete h;
 }
 
@@ -768,6 +777,8 @@ static int pgo_create_impl(isv_pgo *h) {
     if (ndev <= 0) { h->err = "no HIP device"; return ISV_ERR_DEVICE; }
     PCHK(h, hipGetDevice(&h->device));
     PCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    for (auto &cs : h->cstream) PCHK(h, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+    for (auto &ke : h->kev) for (auto &e : ke) PCHK(h, hipEventCreate(&e));
     const size_t G = h->cfg.max_graphs, K = h->cfg.max_keyframes;
     h->cap_pose = G * K; h->cap_edge = G * 3 * K; h->cap_blk = G * (2 * K + (size_t)h->cfg.max_loop_blocks);
     h->cap_adj = 2 * h->cap_edge; h->cap_col = h->cap_blk;
@@ -1068,7 +1079,7 @@ extern "C" int isv_pgo_optimize_batch(isv_pgo_t *h, int32_t ng, const int32_t *n
         return ISV_OK;
     };
     auto parallel_over_graphs = [&](const std::function<void(int)> &fn) {
-        int T = (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+        int T = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
         if (const char *ev = getenv("ISV_HOST_THREADS")) T = atoi(ev);
         T = std::max(1, std::min(T, ng));
         if (T == 1) { for (int g = 0; g < ng; g++) fn(g); return; }
@@ -1103,12 +1114,13 @@ extern "C" int isv_pgo_optimize_batch(isv_pgo_t *h, int32_t ng, const int32_t *n
         nblk_tot += (size_t)G.nblk; nfree_tot += (size_t)G.nf;
     }
     SpanD cov;
+    isv_pgo_result_t *res_stage = nullptr;
     {
         const Off &e = off[ng];
         auto al = [](size_t b) { return (b + 63) & ~(size_t)63; };
-        const size_t b_pose = al(e.pose * 8), b_cov = al(e.pose / 7 * 36 * 8), b_edges = al(e.edges * sizeof(PgEdge));
+        const size_t b_pose = al(e.pose * 8), b_cov = al(e.pose / 7 * 36 * 8), b_edges = al(e.edges * sizeof(PgEdge)), b_res = al((size_t)ng * sizeof(isv_pgo_result_t));
         const size_t b_i[7] = {al(e.free_of * 4), al(e.adj_ptr * 4), al(e.adj * 4), al(e.start * 4), al(e.rowptr * 4), al(e.colptr * 4), al(e.colrows * 4)};
-        size_t need = b_pose + b_cov + b_edges;
+        size_t need = b_pose + b_cov + b_edges + b_res;
         for (size_t b : b_i) need += b;
         if (need > h->pin_cap) {
             if (h->pin) (void)hipHostFree(h->pin);
@@ -1120,26 +1132,18 @@ extern "C" int isv_pgo_optimize_batch(isv_pgo_t *h, int32_t ng, const int32_t *n
         pose.p = (double *)q; pose.n = e.pose; q += b_pose;
         cov.p = (double *)q; cov.n = e.pose / 7 * 36; q += b_cov;
         edges.p = (PgEdge *)q; edges.n = e.edges; q += b_edges;
+        res_stage = (isv_pgo_result_t *)q; q += b_res;
         SpanI *si[7] = {&free_of, &adj_ptr, &adj, &start, &rowptr, &colptr, &colrows};
         const size_t ni[7] = {e.free_of, e.adj_ptr, e.adj, e.start, e.rowptr, e.colptr, e.colrows};
         for (int k = 0; k < 7; k++) { si[k]->p = (int32_t *)q; si[k]->n = ni[k]; q += b_i[k]; }
     }
-    parallel_over_graphs([&](int g) {
-        GraphBuild &B = builds[g]; const Off &o = off[g];
-#define PUT(v) do { if (!B.v.empty()) memcpy(v.data() + o.v, B.v.data(), sizeof(B.v[0]) * B.v.size()); } while (0)
-        PUT(pose); PUT(free_of); PUT(adj_ptr); PUT(adj); PUT(start); PUT(rowptr); PUT(colptr); PUT(colrows); PUT(edges);
-#undef PUT
-        B = GraphBuild();
-    });
-    if (pose.size() / 7 > h->cap_pose || edges.size() > h->cap_edge || nblk_tot > h->cap_blk || adj.size() > h->cap_adj || colrows.size() > h->cap_col) {
-        h->err = "pose graphs exceed the handle's capacity"; return ISV_ERR_CAPACITY;
+    {
+        const Off &e = off[ng];
+        if (e.pose / 7 > h->cap_pose || e.edges > h->cap_edge || nblk_tot > h->cap_blk || e.adj > h->cap_adj || e.colrows > h->cap_col) {
+            h->err = "pose graphs exceed the handle's capacity"; return ISV_ERR_CAPACITY;
+        }
     }
-    const auto tp2 = std::chrono::steady_clock::now();
-    PgDev &d = h->d; hipStream_t st = h->stream;
-#define UP(dst, vec) do { if (!(vec).empty()) PCHK(h, hipMemcpyAsync(dst, (vec).data(), sizeof((vec)[0]) * (vec).size(), hipMemcpyHostToDevice, st)); } while (0)
-    UP(d.graphs, graphs); UP(d.pose, pose); UP(d.free_of, free_of); UP(d.edges, edges); UP(d.adj_ptr, adj_ptr); UP(d.adj, adj);
-    UP(d.start, start); UP(d.rowptr, rowptr); UP(d.colptr, colptr); UP(d.colrows, colrows);
-#undef UP
+    PgDev &d = h->d;
     // index arrays of the envelope in LDS when the largest graph's fit into 48 KB
     size_t max_nf = 0, max_cols = 0;
     for (int g = 0; g < ng; g++) {
@@ -1150,22 +1154,55 @@ extern "C" int isv_pgo_optimize_batch(isv_pgo_t *h, int32_t ng, const int32_t *n
     d.idx_lds_rows = d.idx_lds_cols = 0;
     // (ISV_PGO_IDX_GLOBAL: test hook for the path graphs too large for the LDS copies take)
     if (max_nf > 0 && idx_bytes <= 48 * 1024 && !getenv("ISV_PGO_IDX_GLOBAL")) { d.idx_lds_rows = (int32_t)max_nf; d.idx_lds_cols = (int32_t)max_cols; } else idx_bytes = 0;
-    if (!h->ev[0]) { PCHK(h, hipEventCreate(&h->ev[0])); PCHK(h, hipEventCreate(&h->ev[1])); }
-    PCHK(h, hipEventRecord(h->ev[0], st));
-    hipLaunchKernelGGL(k_pgo, dim3(ng), dim3(64), idx_bytes, st, d);
-    PCHK(h, hipGetLastError());
-    PCHK(h, hipEventRecord(h->ev[1], st));
     h->last_blocks = (double)nblk_tot;
-
-    // (blocking copies after the stream has drained: the destinations are pageable -- `results` is the caller's array --
-    // and an asynchronous copy into pageable memory may still be completing inside the runtime after the stream is idle)
-    PCHK(h, hipStreamSynchronize(st));
-    PCHK(h, hipMemcpy(pose.data(), d.pose, sizeof(double) * pose.size(), hipMemcpyDeviceToHost));
-    PCHK(h, hipMemcpy(cov.data(), d.cov, sizeof(double) * cov.size(), hipMemcpyDeviceToHost));
-    PCHK(h, hipMemcpy(results, d.res, sizeof(isv_pgo_result_t) * ng, hipMemcpyDeviceToHost));
-    const auto tp3 = std::chrono::steady_clock::now();
+    // ---- the chunked pipeline: [assemble chunk c into the pinned staging -> H2D -> k_pgo -> D2H] on stream c, then write-back ----
+    // One team of host threads walks 2 ng tasks in order (an atomic counter): task g < ng copies graph g's arrays into place, the
+    // thread that completes a chunk's last graph enqueues the chunk; task ng + g writes graph g back, after the chunk's stream has
+    // drained (the first thread to get there waits for it).  Chunks are contiguous graph ranges, so every array of a chunk is ONE
+    // range of the batch's arrays and the offsets the kernel uses are the batch's.
+    int C = ng >= 64 ? isv_pgo::PG_CHUNKS : 1;
+    if (const char *ev = getenv("ISV_PGO_CHUNKS")) { C = atoi(ev); if (C < 1) C = 1; if (C > isv_pgo::PG_CHUNKS) C = isv_pgo::PG_CHUNKS; if (C > ng) C = ng; }
+    auto chunk_lo = [&](int c) { return (int)((int64_t)ng * c / C); };
+    auto chunk_of = [&](int g) { int c = (int)(((int64_t)g * C) / ng); while (c + 1 < C && g >= chunk_lo(c + 1)) c++; while (c > 0 && g < chunk_lo(c)) c--; return c; };
+    std::vector<std::atomic<int>> left((size_t)C), enq((size_t)C), done((size_t)C);
+    for (int c = 0; c < C; c++) { left[c].store(chunk_lo(c + 1) - chunk_lo(c)); enq[c].store(0); done[c].store(0); }
+    std::atomic<int> first_chunk{-1}, fail_rc{ISV_OK};
+    std::mutex err_mu, done_mu[isv_pgo::PG_CHUNKS];
+    auto fail = [&](int rc, const std::string &msg) { std::lock_guard<std::mutex> lk(err_mu); if (fail_rc.load() == ISV_OK) { fail_rc.store(rc); h->err = msg; } };
+#define TCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fail(ISV_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); return; } } while (0)
+    auto enqueue_chunk = [&](int c) {
+        const int g0 = chunk_lo(c), g1 = chunk_lo(c + 1);
+        const Off &a = off[g0], &b = off[g1];
+        hipStream_t st = h->cstream[c];
+        TCHK(hipSetDevice(h->device));
+#define UPR(dst, src, lo, hi) do { if ((hi) > (lo)) TCHK(hipMemcpyAsync((dst) + (lo), (src).data() + (lo), sizeof((src)[0]) * ((hi) - (lo)), hipMemcpyHostToDevice, st)); } while (0)
+        TCHK(hipMemcpyAsync(d.graphs + g0, graphs.data() + g0, sizeof(PgGraph) * (size_t)(g1 - g0), hipMemcpyHostToDevice, st));     // (pageable, 80 B per graph)
+        UPR(d.pose, pose, a.pose, b.pose); UPR(d.free_of, free_of, a.free_of, b.free_of); UPR(d.edges, edges, a.edges, b.edges);
+        UPR(d.adj_ptr, adj_ptr, a.adj_ptr, b.adj_ptr); UPR(d.adj, adj, a.adj, b.adj); UPR(d.start, start, a.start, b.start);
+        UPR(d.rowptr, rowptr, a.rowptr, b.rowptr); UPR(d.colptr, colptr, a.colptr, b.colptr); UPR(d.colrows, colrows, a.colrows, b.colrows);
+#undef UPR
+        PgDev dv = d; dv.g0 = g0;
+        TCHK(hipEventRecord(h->kev[c][0], st));
+        hipLaunchKernelGGL(k_pgo, dim3(g1 - g0), dim3(64), idx_bytes, st, dv);
+        TCHK(hipGetLastError());
+        TCHK(hipEventRecord(h->kev[c][1], st));
+        // results into the pinned staging (the caller's arrays are pageable: copied from there after the stream has drained)
+        if (b.pose > a.pose) {
+            TCHK(hipMemcpyAsync(pose.data() + a.pose, d.pose + a.pose, sizeof(double) * (b.pose - a.pose), hipMemcpyDeviceToHost, st));
+            TCHK(hipMemcpyAsync(cov.data() + a.pose / 7 * 36, d.cov + a.pose / 7 * 36, sizeof(double) * (b.pose - a.pose) / 7 * 36, hipMemcpyDeviceToHost, st));
+        }
+        TCHK(hipMemcpyAsync(res_stage + g0, d.res + g0, sizeof(isv_pgo_result_t) * (size_t)(g1 - g0), hipMemcpyDeviceToHost, st));
+        int exp = -1; first_chunk.compare_exchange_strong(exp, c);
+    };
+    auto assemble = [&](int g) {
+        GraphBuild &B = builds[g]; const Off &o = off[g];
+#define PUT(v) do { if (!B.v.empty()) memcpy(v.data() + o.v, B.v.data(), sizeof(B.v[0]) * B.v.size()); } while (0)
+        PUT(pose); PUT(free_of); PUT(adj_ptr); PUT(adj); PUT(start); PUT(rowptr); PUT(colptr); PUT(colrows); PUT(edges);
+#undef PUT
+        B = GraphBuild();
+    };
     // write back (pose_graph.cpp:362-407): updatePose, updateCov, the update() calls, drift, the keyframes after cur
-    parallel_over_graphs([&](int g) {
+    auto write_back = [&](int g) {
         const int n = ns[g]; isv_pg_keyframe_t *kf = kfs[g];
         const PgGraph &G = graphs[g];
         isv_pgo_result_t &R = results[g];
@@ -1205,7 +1242,61 @@ extern "C" int isv_pgo_optimize_batch(isv_pgo_t *h, int32_t ng, const int32_t *n
             h_mm(R.r_drift, kf[k].vio_R_w_i, Rn);
             memcpy(kf[k].T_w_i, Pn, 24); memcpy(kf[k].R_w_i, Rn, 72);
         }
-    });
+    };
+    std::chrono::steady_clock::time_point tp2 = tp1, tp3 = tp1;      // (trace: the last chunk's enqueue, the last chunk's drain)
+    {
+        int T = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+        if (const char *ev = getenv("ISV_HOST_THREADS")) T = atoi(ev);
+        T = std::max(1, std::min(T, ng));
+        std::atomic<int> next{0};
+        auto worker = [&] {
+            for (int id; (id = next.fetch_add(1)) < 2 * ng; ) {
+                if (id < ng) {
+                    const int g = id, c = chunk_of(g);
+                    if (fail_rc.load() == ISV_OK) assemble(g);
+                    if (left[c].fetch_sub(1) == 1) {
+                        if (fail_rc.load() == ISV_OK) enqueue_chunk(c);
+                        if (c == C - 1) tp2 = std::chrono::steady_clock::now();
+                        enq[c].store(1);
+                    }
+                } else {
+                    const int g = id - ng, c = chunk_of(g);
+                    if (!done[c].load()) {
+                        std::lock_guard<std::mutex> lk(done_mu[c]);
+                        if (!done[c].load()) {
+                            while (!enq[c].load()) std::this_thread::yield();
+                            if (fail_rc.load() == ISV_OK) {
+                                const hipError_t e1 = hipSetDevice(h->device), e2 = e1 == hipSuccess ? hipStreamSynchronize(h->cstream[c]) : e1;
+                                if (e2 != hipSuccess) fail(ISV_ERR_DEVICE, std::string("hipStreamSynchronize: ") + hipGetErrorString(e2));
+                                else memcpy(results + chunk_lo(c), res_stage + chunk_lo(c), sizeof(isv_pgo_result_t) * (size_t)(chunk_lo(c + 1) - chunk_lo(c)));
+                            }
+                            if (c == C - 1) tp3 = std::chrono::steady_clock::now();
+                            done[c].store(1);
+                        }
+                    }
+                    if (fail_rc.load() == ISV_OK) write_back(g);
+                }
+            }
+        };
+        if (T == 1) worker();
+        else {
+            std::vector<std::thread> th;
+            for (int k = 0; k < T; k++) th.emplace_back(worker);
+            for (auto &x : th) x.join();
+        }
+    }
+#undef TCHK
+    if (fail_rc.load() != ISV_OK) {
+        for (int c = 0; c < C; c++) (void)hipStreamSynchronize(h->cstream[c]);      // nothing of this call stays in flight
+        return fail_rc.load();
+    }
+    {
+        // the span of the chunks' kernels: the chunk enqueued first starts first
+        float best = 0;
+        const int fc = first_chunk.load() < 0 ? 0 : first_chunk.load();
+        for (int c = 0; c < C; c++) { float f = 0; if (hipEventElapsedTime(&f, h->kev[fc][0], h->kev[c][1]) == hipSuccess) best = std::max(best, f); else (void)hipGetLastError(); }
+        h->last_kernel_ms = best;
+    }
     if (getenv("ISV_TRACE_HANDOVER")) {
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         fprintf(stderr, "isv pgo batch: %d graphs: analysis %.2f ms, assembly %.2f ms, H2D + kernel + D2H %.2f ms (%.1f MB up), write-back %.2f ms\n", ng, ms(tp0, tp1), ms(tp1, tp2), ms(tp2, tp3),
