@@ -98,7 +98,8 @@ def test_resident_mode_is_refused_without_lock_step_and_recovers():
     ref.close(); est.close()
 
 
-def test_a_failed_solve_in_resident_mode_falls_back_and_recovers(monkeypatch):
+@pytest.mark.parametrize("est_ex", [0, 1])
+def test_a_failed_solve_in_resident_mode_falls_back_and_recovers(monkeypatch, est_ex):
     """a solve that ends non-finite while the windows are resident (injected: ISV_DEBUG_SEQ_FAIL_FRAME poisons window 0's cost
     in the 15th resident frame): the device rolls that window back to the states and priors that entered the solve, every window
     comes back to the host BEFORE the slide, the failed sequence re-initialises its priors with initFactorGraph at its next
@@ -106,7 +107,9 @@ def test_a_failed_solve_in_resident_mode_falls_back_and_recovers(monkeypatch):
     unaffected bit for bit, and the windows are seeded on the device again"""
     from isvins_amd import estimator as E
     N, Nvo, seeds, n_frames = 11, 5, (0, 3), 60
-    cfg = abi.make_config(N, Nvo, max_landmarks=800, max_obs=800 * N, max_batch=2)
+    # (est_ex = 1, round 4: the rolled-back window's extrinsic is the one that entered the solve -- k_seq_writeback restores tic / ric
+    #  from the pseudo-frame's copy -- and the host's tic[0] / ric[0] come back with the windows)
+    cfg = abi.make_config(N, Nvo, max_landmarks=800, max_obs=800 * N, max_batch=2, estimate_extrinsic=est_ex)
     ref = E.SequenceEstimator(sh.estimator_params(cfg), 2)
     ref.set_resident(True)
     sh.run_sequences_native(ref, N, n_frames, seeds)
@@ -131,6 +134,10 @@ def test_a_failed_solve_in_resident_mode_falls_back_and_recovers(monkeypatch):
     assert err_a < max(3.0 * err_b, 0.25)
     # resident again after the re-seed: most of the frames after the failure went through the resident path
     assert est.resident_frames() > n_frames - (N - 1) - 8
+    for s_ in range(2):
+        tic, ric = est.extrinsic(s_)
+        assert np.isfinite(tic).all() and np.isfinite(ric).all() and abs(np.linalg.det(ric) - 1.0) < 1e-9
+    assert np.array_equal(est.extrinsic(1)[0], ref.extrinsic(1)[0]) and np.array_equal(est.extrinsic(1)[1], ref.extrinsic(1)[1])
     est.set_resident(False); ref.set_resident(False)
     est.close(); ref.close()
 
