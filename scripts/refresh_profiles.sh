@@ -54,5 +54,10 @@ REPS=6 rocprofv3 --kernel-trace --stats -d $O/one11 -o one --output-format csv -
 cp $O/one11/one_kernel_stats.csv $O/${RN}_single_window_n11_kernel_stats.csv
 REPS=6 rocprofv3 --kernel-trace --stats -d $O/one18 -o one --output-format csv -- python3 scripts/quick_cfg.py 1 18 8 300 > $O/one18.log 2>&1
 cp $O/one18/one_kernel_stats.csv $O/${RN}_single_window_n18_kernel_stats.csv
+# 10. every kernel ALONE (one stream): what the side-stream kernels cost without queueing behind k_lin_gram
+ISV_ONE_STREAM=1 rocprofv3 --kernel-trace --stats -d $O/os11 -o os --output-format csv -- $B --steps 5 --warmup 2 > $O/os11.log 2>&1
+cp $O/os11/os_kernel_stats.csv $O/${RN}_one_stream_n11_kernel_stats.csv
+ISV_ONE_STREAM=1 rocprofv3 --kernel-trace --stats -d $O/os18 -o os --output-format csv -- $B --steps 5 --warmup 2 --frames 18 --vo 8 > $O/os18.log 2>&1
+cp $O/os18/os_kernel_stats.csv $O/${RN}_one_stream_n18_kernel_stats.csv
 ls $O/*.csv $O/*.json
 head -12 $O/${RN}_bench_${W}win_kernel_stats.csv
