@@ -120,6 +120,8 @@ def test_native_window_manager_carries_the_estimated_extrinsic(oracle):
     eo, _ = sh.run_sequence(sh.OracleSolver(oracle, cfg1), oracle, N, Nvo, n_frames, seed=seed)
     _cmp_native_vs_harness(est, 0, eo, 1e-9)
     assert np.abs(eo.tic - synth.TIC).max() > 1e-6 or np.abs(eo.ric - synth.RIC).max() > 1e-6
+    tic, ric = est.extrinsic(0)                     # isv_estimator_get_extrinsic: tic[0] / ric[0] as the last solve left them
+    assert np.abs(tic - eo.tic).max() < 1e-9 and np.abs(ric - eo.ric).max() < 1e-9
     cfg0 = abi.make_config(N, Nvo, max_landmarks=600, max_obs=6600, max_batch=1)
     e0, _ = sh.run_sequence(sh.OracleSolver(oracle, cfg0), oracle, N, Nvo, n_frames, seed=seed)
     assert np.array_equal(e0.tic, synth.TIC) and np.abs(e0.Ps - eo.Ps).max() > 1e-9
