@@ -1122,3 +1122,4 @@ __global__ __launch_bounds__(ST_THREADS(BIG), 4) void k_build_solve_st(DevBatch 
 template __global__ void k_build_solve_st<false, 0>(DevBatch);
 template __global__ void k_build_solve_st<false, 11>(DevBatch);
 template __global__ void k_build_solve_st<true, 0>(DevBatch);
+template __global__ void k_build_solve_st<true, 18>(DevBatch);      // the reference's own window length (ALL_BUF_SIZE 18)

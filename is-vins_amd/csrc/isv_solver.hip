@@ -847,6 +847,7 @@ int isv_solver_alloc(DevBatch &d, SolverHost &hc, size_t B, size_t L, size_t F, 
             if (d.N == 11) SETLDS((k_build_solve_st<false, 11>), lds_st);
             if (d.N <= 11) SETLDS((k_build_solve_st<false, 0>), lds_st);
             if (d.N > 11) SETLDS((k_build_solve_st<true, 0>), lds_st);
+            if (d.N == 18) SETLDS((k_build_solve_st<true, 18>), lds_st);
         }
         if (d.N == 11) SETLDS((k_build_solve_sb<false, 11>), lds_sb);
         if (d.N <= 11) SETLDS((k_build_solve_sb<false, 0>), lds_sb);
@@ -985,6 +986,9 @@ int isv_solver_enqueue(DevBatch &d, const SolverHost &hc, hipStream_t st, hipStr
             const size_t lds_st = build_solve_st_bytes(d.N, d.prior_H_sz);
             if (d.N == 11 && !generic_n) hipLaunchKernelGGL((k_build_solve_st<false, 11>), dim3(d.B), dim3(256), lds_st, st, d);
             else if (d.N <= 11) hipLaunchKernelGGL((k_build_solve_st<false, 0>), dim3(d.B), dim3(256), lds_st, st, d);
+            // (the reference's ALL_BUF_SIZE as a compile-time constant: 404 -> 357 us per launch, 1024 windows 10.27 -> 9.87 ms.  The same for
+            //  k_build_solve_sb<true, 18> spills 62 registers and is SLOWER for the single window it serves: 2.54 against 2.48 ms; not instantiated)
+            else if (d.N == 18 && !generic_n) hipLaunchKernelGGL((k_build_solve_st<true, 18>), dim3(d.B), dim3(512), lds_st, st, d);     // (the reference's ALL_BUF_SIZE)
             else hipLaunchKernelGGL((k_build_solve_st<true, 0>), dim3(d.B), dim3(512), lds_st, st, d);       // (long windows: eight wavefronts, two windows per CU)
         } else if (d.lds_T && generic_n) {
             if (d.N <= 11) hipLaunchKernelGGL((k_build_solve_sb<false, 0>), dim3(d.B), dim3(512), build_solve_sb_bytes(d.N, d.prior_H_sz), st, d);

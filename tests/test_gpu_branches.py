@@ -184,6 +184,32 @@ def test_unfused_kernel_variants_against_oracle_and_fused(oracle, monkeypatch, e
         bf.close()
 
 
+def test_build_solve_st_compiled_for_18_frames_is_bitwise_the_runtime_n_kernel(monkeypatch):
+    """k_build_solve_st<true, 18> (the reference's ALL_BUF_SIZE as a compile-time constant: every loop bound and index a constant;
+    404 -> 357 us per 1024-window launch) against k_build_solve_st<true, 0> (ISV_GENERIC_N=1) on a handle whose capacity selects
+    the streamed kernel: the same sums in the same order, BITWISE equal states, summaries and marginalisation records"""
+    import ctypes
+    ws = [synth.make_window(300 + i, n_frames=18, n_vo=8, n_landmarks=120, margin_old=i % 2) for i in range(6)]
+    cap = dict(max_landmarks=140, max_obs=max(w.n_obs for w in ws), max_batch=512)
+    out = {}
+    for generic in (False, True):
+        if generic:
+            monkeypatch.setenv("ISV_GENERIC_N", "1")
+        b = backend.Backend(18, 8, **cap)
+        try:
+            g = [w.clone() for w in ws]
+            sums, margs = b.optimize_batch(g)
+            assert b.last_counts()[6] == 1          # k_build_solve_st ran
+            out[generic] = ([w.state_vector() for w in g], [bytes(ctypes.string_at(ctypes.addressof(x), ctypes.sizeof(x))) for x in list(sums) + list(margs)])
+        finally:
+            b.close()
+        if generic:
+            monkeypatch.delenv("ISV_GENERIC_N")
+    for a, c in zip(out[False][0], out[True][0]):
+        assert np.array_equal(a, c)
+    assert out[False][1] == out[True][1]
+
+
 def test_marg_backward_one_launch_against_three(oracle, monkeypatch):
     """MargBackward as one kernel (k_marg_bwd<2>: the window's one wavefront runs the 21 x 21 Jacobi sweeps, what batches
     beyond n_cus windows take) against build / k_marg_jacobi<21> (four wavefronts, one item per lane) / project (small
