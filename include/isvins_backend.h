@@ -345,7 +345,8 @@ int  isv_backend_seq_seed(isv_backend_t *h, int32_t n, isv_window_t *const *w, c
 int  isv_backend_seq_frame(isv_backend_t *h, int32_t n, const isv_seq_frame_t *frames, isv_seq_result_t *results,
                            int32_t *const *solve_flags, isv_marg_result_t *marg);
 /* the resident state of slot b back into caller buffers (a sequence leaving the resident mode, tests): the window as
- * isv_batch_download fills it restricted to states and prior factors, and every track's depth / solve_flag in list order */
+ * isv_batch_download fills it restricted to states and prior factors (w->tic / w->ric too when they are non-NULL: the extrinsic as
+ * the last solve left it), and every track's depth / solve_flag in list order */
 int  isv_backend_seq_download(isv_backend_t *h, int32_t slot, isv_window_t *w, int32_t n_tracks, double *track_depth, int32_t *track_flag);
 /* the slide of the previous solve is applied by the NEXT isv_backend_seq_frame; a caller that has slid its own side and
  * wants the resident state back first lets the device catch up: prev_slide [n] as in isv_seq_frame_t, n_tracks [n] the
