@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void k_seq_append(DevBatch d, SeqDev s) {
 }
 
 // The solver's view of the window from the track list (= pack_window of isv_backend.hip, on the device).
-// Dynamic LDS: sMeta [Lcap] uint32 (host | k << 8) | sF0 [Lcap] int32 | per pair: size, off, order, base [4][NP + 1] int32
+// Dynamic LDS: sMeta [Lcap] uint32 (host | k << 8) | sF0 [Lcap] int32 | per pair: size, off, order, base, wave [5][NP + 1] int32 | quarter counts [4][NP + 1]
 __global__ __launch_bounds__(256) void k_seq_build(DevBatch d, SeqDev s, int lcap) {
     extern __shared__ int ldsi[];
     // (Nd: device frames per window = the stride of the state arrays; N: the real frames -- pairs, schedule, factor stream)
@@ -359,12 +359,26 @@ __global__ __launch_bounds__(256) void k_seq_build(DevBatch d, SeqDev s, int lca
                 sMeta[li] = (unsigned)st | ((unsigned)n << 8); sF0[li] = frel;
                 const double *p0 = ring + (size_t)(off & (ISV_SEQ_RING - 1)) * 3;
                 d.lm_pts_i[(size_t)l * 3] = p0[0]; d.lm_pts_i[(size_t)l * 3 + 1] = p0[1]; d.lm_pts_i[(size_t)l * 3 + 2] = p0[2];
-                for (int o = 1; o < n; o++) {
-                    const double *p = ring + (size_t)((off + o) & (ISV_SEQ_RING - 1)) * 3;
-                    const size_t f = (size_t)f0 + o - 1;
-                    FactorRec rc; rc.lm = l; rc.ij = st | ((st + o) << 8);
-                    d.f_rec[f] = rc;
-                    d.f_pts_j[f * 2] = p[0]; d.f_pts_j[f * 2 + 1] = p[1]; d.f_pts_z[f] = p[2];
+                // (round 4: four observations' points in flight -- clamped ring reads, then the stores; one dependent memory latency
+                //  per observation made this loop 75 of the kernel's 175 us at 512 windows)
+                for (int o0 = 1; o0 < n; o0 += 4) {
+                    double px[4], py[4], pz[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int o = o0 + u < n ? o0 + u : n - 1;
+                        const double *p = ring + (size_t)((off + o) & (ISV_SEQ_RING - 1)) * 3;
+                        px[u] = p[0]; py[u] = p[1]; pz[u] = p[2];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int o = o0 + u;
+                        if (o < n) {
+                            const size_t f = (size_t)f0 + o - 1;
+                            FactorRec rc; rc.lm = l; rc.ij = st | ((st + o) << 8);
+                            d.f_rec[f] = rc;
+                            d.f_pts_j[f * 2] = px[u]; d.f_pts_j[f * 2 + 1] = py[u]; d.f_pts_z[f] = pz[u];
+                        }
+                    }
                 }
             }
         }
@@ -377,25 +391,33 @@ __global__ __launch_bounds__(256) void k_seq_build(DevBatch d, SeqDev s, int lca
     // ---- pass C: factors sorted by (host, observer) pair, stable in landmark order.  A landmark has at most one factor
     //      per pair, so the rank of its factor inside the pair group is the number of EARLIER landmarks in the group:
     //      one thread walks the landmark list per pair (count, then fill) ----
+    // (round 4: the landmark list in four QUARTERS per pair -- item (pair, quarter) counts / fills its quarter in order, a quarter's
+    //  first rank is the pair's offset plus the earlier quarters' counts: the same stable order with four times the threads; the
+    //  55 one-thread walks over ~280 landmarks were 37 of the kernel's 175 us)
+    int *sCnt = sWave + NP + 1;                    // [4][NP + 1]
     for (int p = t; p <= NP; p += 256) sSize[p] = 0;
-    __syncthreads();
     auto pair_of = [N](int p, int &hh, int &jj) { hh = 0; int rem = p; while (rem >= N - 1 - hh) { rem -= N - 1 - hh; hh++; } jj = hh + 1 + rem; };
-    for (int p = t; p < NP; p += 256) {
+    for (int it = t; it < 4 * NP; it += 256) {
+        const int qtr = it / NP, p = it - qtr * NP;
         int hh, jj; pair_of(p, hh, jj);
         int c = 0;
-        if (hh < Nvo) for (int l = 0; l < Lw; l++) { const unsigned m0 = sMeta[l]; const int h = (int)(m0 & 255), k = (int)(m0 >> 8); c += (h == hh && h + k > jj) ? 1 : 0; }
-        sSize[p] = c;
+        if (hh < Nvo) for (int l = Lw * qtr / 4, le = Lw * (qtr + 1) / 4; l < le; l++) { const unsigned m0 = sMeta[l]; const int h = (int)(m0 & 255), k = (int)(m0 >> 8); c += (h == hh && h + k > jj) ? 1 : 0; }
+        sCnt[qtr * (NP + 1) + p] = c;
     }
+    __syncthreads();
+    for (int p = t; p < NP; p += 256) sSize[p] = sCnt[p] + sCnt[(NP + 1) + p] + sCnt[2 * (NP + 1) + p] + sCnt[3 * (NP + 1) + p];
     __syncthreads();
     if (t == 0) { int a = 0; for (int p = 0; p < NP; p++) { sOff[p] = a; a += sSize[p]; } sOff[NP] = a; }
     __syncthreads();
     int32_t *pg_off = d.pg_off + (size_t)w * (NP + 1);
     for (int p = t; p <= NP; p += 256) pg_off[p] = sOff[p];
-    for (int p = t; p < NP; p += 256) {
+    for (int it = t; it < 4 * NP; it += 256) {
+        const int qtr = it / NP, p = it - qtr * NP;
         int hh, jj; pair_of(p, hh, jj);
-        if (hh >= Nvo || sSize[p] == 0) continue;
+        if (hh >= Nvo || sCnt[qtr * (NP + 1) + p] == 0) continue;
         int pos = sOff[p];
-        for (int l = 0; l < Lw; l++) {
+        for (int q2 = 0; q2 < qtr; q2++) pos += sCnt[q2 * (NP + 1) + p];
+        for (int l = Lw * qtr / 4, le = Lw * (qtr + 1) / 4; l < le; l++) {
             const unsigned m0 = sMeta[l]; const int h = (int)(m0 & 255), k = (int)(m0 >> 8);
             if (h == hh && h + k > jj) d.pg_perm[(size_t)F0 + pos++] = sF0[l] + (jj - hh - 1);
         }
@@ -409,8 +431,9 @@ __global__ __launch_bounds__(256) void k_seq_build(DevBatch d, SeqDev s, int lca
     }
     __syncthreads();
     int32_t *soff = d.pg_sched_off + (size_t)w * (ISV_SWEEP_WAVES + 1), *sched = d.pg_sched + (size_t)w * NP, *wst = d.pg_wstart + (size_t)w * (ISV_SWEEP_WAVES + 1);
+    __shared__ int sT[3 * ISV_SWEEP_WAVES];        // (LDS: dynamically indexed private arrays live in scratch memory -- 36 us of this kernel)
     if (t == 0) {
-        int load[ISV_SWEEP_WAVES], cntw[ISV_SWEEP_WAVES], fill[ISV_SWEEP_WAVES];
+        int *load = sT, *cntw = sT + ISV_SWEEP_WAVES, *fill = sT + 2 * ISV_SWEEP_WAVES;
         for (int v = 0; v < ISV_SWEEP_WAVES; v++) { load[v] = 0; cntw[v] = 0; fill[v] = 0; }
         for (int q = 0; q < NP; q++) {
             const int p = sOrder[q];
@@ -433,16 +456,31 @@ __global__ __launch_bounds__(256) void k_seq_build(DevBatch d, SeqDev s, int lca
     }
     __syncthreads();
     // ---- the factor stream of k_lin_gram ----
-    for (int idx = t; idx < Fw; idx += 256) {
-        int lo = 0, hi = NP;                        // the pair group of sorted position idx: sOff[lo] <= idx < sOff[lo + 1]
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sOff[mid] <= idx) lo = mid; else hi = mid; }
-        const int pp = lo;                          // (the LAST group starting at or before idx: empty groups share its offset)
-        int hh, jj; pair_of(pp, hh, jj);
-        const size_t q = (size_t)F0 + sBase[pp] + (idx - sOff[pp]);
-        const int frel = d.pg_perm[(size_t)F0 + idx];
-        const size_t f = (size_t)F0 + frel;
-        d.pg_rec[2 * q] = d.f_rec[f].lm; d.pg_rec[2 * q + 1] = (int32_t)((unsigned)frel | ((unsigned)hh << 16) | ((unsigned)jj << 24));
-        d.pg_pts[2 * q] = d.f_pts_j[2 * f]; d.pg_pts[2 * q + 1] = d.f_pts_j[2 * f + 1];
+    // (four entries per thread in flight: the sorted position's record comes through two dependent global loads)
+    for (int i0 = t; i0 < Fw; i0 += 4 * 256) {
+        int frel4[4], hj4[4]; size_t q4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int idx = i0 + 256 * u < Fw ? i0 + 256 * u : Fw - 1;
+            int lo = 0, hi = NP;                    // the pair group of sorted position idx: sOff[lo] <= idx < sOff[lo + 1]
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sOff[mid] <= idx) lo = mid; else hi = mid; }
+            const int pp = lo;                      // (the LAST group starting at or before idx: empty groups share its offset)
+            int hh, jj; pair_of(pp, hh, jj);
+            q4[u] = (size_t)F0 + sBase[pp] + (idx - sOff[pp]);
+            hj4[u] = (hh << 16) | (jj << 24);
+            frel4[u] = d.pg_perm[(size_t)F0 + idx];
+        }
+        int lm4[4]; double x4[4], y4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const size_t f = (size_t)F0 + frel4[u]; lm4[u] = d.f_rec[f].lm; x4[u] = d.f_pts_j[2 * f]; y4[u] = d.f_pts_j[2 * f + 1]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (i0 + 256 * u < Fw) {
+                const size_t q = q4[u];
+                d.pg_rec[2 * q] = lm4[u]; d.pg_rec[2 * q + 1] = (int32_t)((unsigned)frel4[u] | (unsigned)hj4[u]);
+                d.pg_pts[2 * q] = x4[u]; d.pg_pts[2 * q + 1] = y4[u];
+            }
+        }
     }
 }
 
@@ -685,7 +723,7 @@ extern "C" int isv_backend_seq_frame(isv_backend_t *h, int32_t n, const isv_seq_
     hipLaunchKernelGGL(k_seq_append, dim3(n), dim3(256), 0, st, d, s);
     hipLaunchKernelGGL(k_imu_prep, dim3(2 * n), dim3(64), 0, st, d, s.imu_sel);
     const int NP = N * (N - 1) / 2, lcap = c.max_landmarks > 1 ? c.max_landmarks : 1;
-    const size_t lds_build = ((size_t)2 * lcap + 5 * (size_t)(NP + 1)) * sizeof(int32_t);
+    const size_t lds_build = ((size_t)2 * lcap + 9 * (size_t)(NP + 1)) * sizeof(int32_t);
     hipLaunchKernelGGL(k_seq_build, dim3(n), dim3(256), lds_build, st, d, s, lcap);
     if (L) hipLaunchKernelGGL(k_triangulate, dim3((unsigned)((L + 63) / 64)), dim3(64), 0, st, d);
     HIPCHK(h, hipGetLastError());
