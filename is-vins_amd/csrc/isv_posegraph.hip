@@ -1244,6 +1244,7 @@ extern "C" int isv_pgo_optimize_batch(isv_pgo_t *h, int32_t ng, const int32_t *n
         }
     };
     std::chrono::steady_clock::time_point tp2 = tp1, tp3 = tp1;      // (trace: the last chunk's enqueue, the last chunk's drain)
+    std::chrono::steady_clock::time_point t_enq[isv_pgo::PG_CHUNKS], t_done[isv_pgo::PG_CHUNKS];
     {
         int T = (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
         if (const char *ev = getenv("ISV_HOST_THREADS")) T = atoi(ev);
@@ -1256,6 +1257,7 @@ extern "C" int isv_pgo_optimize_batch(isv_pgo_t *h, int32_t ng, const int32_t *n
                     if (fail_rc.load() == ISV_OK) assemble(g);
                     if (left[c].fetch_sub(1) == 1) {
                         if (fail_rc.load() == ISV_OK) enqueue_chunk(c);
+                        t_enq[c] = std::chrono::steady_clock::now();
                         if (c == C - 1) tp2 = std::chrono::steady_clock::now();
                         enq[c].store(1);
                     }
@@ -1270,6 +1272,7 @@ extern "C" int isv_pgo_optimize_batch(isv_pgo_t *h, int32_t ng, const int32_t *n
                                 if (e2 != hipSuccess) fail(ISV_ERR_DEVICE, std::string("hipStreamSynchronize: ") + hipGetErrorString(e2));
                                 else memcpy(results + chunk_lo(c), res_stage + chunk_lo(c), sizeof(isv_pgo_result_t) * (size_t)(chunk_lo(c + 1) - chunk_lo(c)));
                             }
+                            t_done[c] = std::chrono::steady_clock::now();
                             if (c == C - 1) tp3 = std::chrono::steady_clock::now();
                             done[c].store(1);
                         }
@@ -1301,6 +1304,13 @@ extern "C" int isv_pgo_optimize_batch(isv_pgo_t *h, int32_t ng, const int32_t *n
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         fprintf(stderr, "isv pgo batch: %d graphs: analysis %.2f ms, assembly %.2f ms, H2D + kernel + D2H %.2f ms (%.1f MB up), write-back %.2f ms\n", ng, ms(tp0, tp1), ms(tp1, tp2), ms(tp2, tp3),
                 (pose.size() * 8 + edges.size() * sizeof(PgEdge) + (free_of.size() + adj_ptr.size() + adj.size() + start.size() + rowptr.size() + colptr.size() + colrows.size()) * 4) / 1e6, ms(tp3, std::chrono::steady_clock::now()));
+        const int fc = first_chunk.load() < 0 ? 0 : first_chunk.load();
+        for (int c = 0; c < C; c++) {       // every chunk's kernel on the first chunk's clock, and when the host enqueued / found it drained
+            float a = 0, b = 0;
+            (void)hipEventElapsedTime(&a, h->kev[fc][0], h->kev[c][0]); (void)hipEventElapsedTime(&b, h->kev[fc][0], h->kev[c][1]); (void)hipGetLastError();
+            fprintf(stderr, "  chunk %d: graphs [%d, %d): enqueued at %.2f ms, k_pgo %.2f .. %.2f ms after the first chunk's start, drained at %.2f ms\n", c, chunk_lo(c), chunk_lo(c + 1),
+                    ms(tp0, t_enq[c]), a, b, ms(tp0, t_done[c]));
+        }
     }
     // per-graph failures surface in the return value too (every graph has been written back by now; results[g].status says which)
     for (int g = 0; g < ng; g++) if (results[g].status != ISV_OK) { h->err = "pose graph " + std::to_string(g) + ": the covariance factorisation failed (poses written, covariances left untouched)"; return results[g].status; }
