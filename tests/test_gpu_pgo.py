@@ -104,6 +104,36 @@ def test_batch_of_graphs_is_bitwise_the_single_calls(oracle, opt):
     check_graph(o, ro, batch[2], res[2], graphs[2][2], specs[2][1] - 1)
 
 
+@pytest.mark.parametrize("chunks", ["1", "3", "4"])
+def test_chunked_batch_pipeline_is_bitwise_the_single_chunk_call(monkeypatch, chunks):
+    """round 4: a batch call goes to the device in up to four chunks of graphs on four streams (k_pgo launched per chunk with the
+    index of its first graph; assembly, copies, kernels and write-back of different chunks overlap, one team of host threads).
+    70 graphs of five different shapes (>= 64: the default takes four chunks) against the same call forced to 1 / 3 / 4 chunks
+    (ISV_PGO_CHUNKS, read per call): every keyframe list and every result record bitwise equal, on a cold and on a cached call;
+    the chunk boundaries fall inside runs of equal and of different graphs"""
+    specs = [(30, 90, 3), (31, 40, 1), (32, 150, 5), (33, 25, 0), (34, 120, 2)]
+    graphs = [pg.make_pose_graph(*s) for s in specs]
+    n = 70
+    firsts = [graphs[i % 5][2] for i in range(n)]; curs = [specs[i % 5][1] - 1 for i in range(n)]
+    ref = pg.PoseGraphOptimizer(160, max_graphs=n, max_loop_blocks=8 * 160)
+    tst = pg.PoseGraphOptimizer(160, max_graphs=n, max_loop_blocks=8 * 160)
+    try:
+        for rep in range(2):                         # (the second call hits the structure cache)
+            a = [pg.clone_keyframes(graphs[i % 5][0]) for i in range(n)]
+            b = [pg.clone_keyframes(graphs[i % 5][0]) for i in range(n)]
+            ra = ref.optimize_batch(a, firsts, curs)
+            monkeypatch.setenv("ISV_PGO_CHUNKS", chunks)
+            rb = tst.optimize_batch(b, firsts, curs)
+            monkeypatch.delenv("ISV_PGO_CHUNKS")
+            for i in range(n):
+                assert bytes(a[i]) == bytes(b[i]), (rep, i)
+                assert bytes(ra[i]) == bytes(rb[i]), (rep, i)
+                assert ra[i].status == 0 and ra[i].iterations > 0
+        assert tst.structure_cache_hits() == n and tst.last_kernel_ms()[0] > 0
+    finally:
+        ref.close(); tst.close()
+
+
 def test_global_index_path_is_bitwise_the_lds_one(opt, monkeypatch):
     """graphs whose envelope index arrays do not fit the kernel's 48 KB of LDS read them from global memory instead: forced on
     an ordinary graph (ISV_PGO_IDX_GLOBAL), the result has to be the same bits as with the LDS copies"""
