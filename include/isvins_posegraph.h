@@ -72,8 +72,9 @@ int  isv_combined_factors_add(isv_combined_factors_t *acc, int32_t *acc_length, 
 int  isv_pgo_create(const isv_pgo_config_t *cfg, isv_pgo_t **out);
 void isv_pgo_destroy(isv_pgo_t *h);
 const char *isv_pgo_last_error(const isv_pgo_t *h);
-/* measurement: duration of the pose-graph kernel of the last optimize call (HIP events on the handle's stream) and the
- * number of 6x6 skyline blocks its graphs held */
+/* measurement: duration of the pose-graph kernel(s) of the last optimize call -- a batch of >= 64 graphs goes to the device in
+ * four chunks on four streams (ISV_PGO_CHUNKS overrides): from the first chunk's kernel start to the last chunk's kernel end,
+ * HIP events on the chunks' streams -- and the number of 6x6 skyline blocks its graphs held */
 int  isv_pgo_last_kernel_ms(isv_pgo_t *h, double *ms, double *skyline_blocks);
 /* graphs whose STRUCTURE analysis (parameter blocks, adjacency, skyline, column patterns) was reused from the previous call on the same
    batch slot since the handle was created: a graph that is optimised again with the same keyframe list (same indices, sequences,
