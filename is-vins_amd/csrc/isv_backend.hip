@@ -47,7 +47,7 @@ static int create_impl(isv_backend *h) {
     HIPCHK(h, hipGetDevice(&h->device));
     HIPCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     HIPCHK(h, hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
-    for (auto &e : h->fj) HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto &e : h->fj) HIPCHK(h, hipEventCreateWithFlags(&e, getenv("ISV_EVENT_SYSTEM") ? hipEventDisableTiming : (hipEventDisableTiming | hipEventReleaseToDevice)));
     for (auto &e : h->pk) HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
     for (auto &e : h->ev) HIPCHK(h, hipEventCreate(&e));
     h->prof_ev.assign((size_t)c.num_iterations * ISV_PROF_FAMILIES * 2, nullptr);

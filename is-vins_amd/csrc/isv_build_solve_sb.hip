@@ -24,6 +24,7 @@
 #include <hip/hip_runtime.h>
 #include "isv_kernels.h"
 #include "isv_device_math.h"
+#include "isv_lin_gram.h"
 
 #ifdef ISV_STAMP
 #define STAMP(k) do { if (t == 0) { unsigned long long now_ = wall_clock64(); d.dbg[(size_t)w * 64 + (k)] += (double)(now_ - t_last); t_last = now_; } } while (0)
@@ -106,9 +107,25 @@ DEV bool chol_inv_block(double *A, int lane) {
 // NC: the window length as a compile-time constant (0 = read d.N): the LDS layout, every loop bound and the index
 //     divisions fold, which is worth registers and integer work in every phase; instantiated for the benchmark's 11 and the
 //     reference's 18 frames.
-template <bool BIG, int NC>
-__global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) {
-    extern __shared__ __align__(16) double lds[];
+// MODE (round 5): 0 = the whole solve in one launch (above).  Handles whose batches leave CUs idle (max_batch <= CUs) split it:
+//   MODE 1 (k "chain", SIDE stream, after the IMU / prior kernels, BESIDE k_lin_gram / k_rank1_mfma): everything that does not depend on
+//          the reprojection factors -- the speed/bias blocks couple only through IMU factors and the Linear9 prior, and the landmark
+//          elimination fills pose x pose blocks only -- i.e. the assembly of the non-visual blocks, the Jacobi scaling of the speed/bias
+//          columns, both elimination chains, node M, Y Y^T and Y z.  The POSE rows' Jacobi scales depend on the visual diagonal (first
+//          iteration), so the pose rows of Y stay unscaled here: (S_p Y) L^-T = S_p (Y L^-T), row scaling commutes with every chain operation.
+//          Leaves in d.cs_ws: S_nv (non-visual pose blocks) | S_nv - Y'Y'^T | L_i^-1, C_i', Y_i' | g, hdiag, y (z_i; pose rows: -Y' z) | t_Y | q_ss | flag.
+//   MODE 2 (k "pose", main stream, after k_rank1_mfma and the join): T_pp = s s (V + S_nv - Y'Y'^T) + mu D^2, pose Cholesky, the back-substitutions
+//          and the outputs.  A failed factorisation on either side (mu retry) falls back to the one-launch path inside this kernel.
+// The split sums the same products in a different order than MODE 0 (the row scaling is applied after the chain instead of before): results agree to
+// rounding; which one a handle runs is decided by its max_batch (SolverHost::chain_split), never by the uploaded batch.
+__host__ __device__ inline size_t sb_cs_doubles(int N) {
+    const int M = N / 2;
+    size_t ytot = 0;
+    for (int i = 0; i < N; i++) ytot += (size_t)((i < M ? i + 1 : N - 1) - (i > M ? i - 1 : 0) + 1) * 54;
+    return 2 * ((size_t)N * (N + 1) / 2 * 36) + 162 * (size_t)N + ytot + 3 * 15 * (size_t)N + 6 * (size_t)N + 8;
+}
+template <bool BIG, int NC, int MODE>
+DEV void build_solve_sb_body(const DevBatch &d, double *lds) {
     const int w = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
     SolveState &st = d.st[w];
     if (st.termination != ISV_TERM_RUNNING || !st.need_linearize) return;
@@ -155,7 +172,7 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
     const int ytot = yo[N];
     // cost of the window at x = sum over its residual blocks (fixed-shape strided partials + tree below)
     double cpart = 0;
-    {
+    if (MODE != 1) {
         const int f0w = d.f_off[w], f1w = d.f_off[w + 1];
         // (four trips' loads in flight, masked adds in the same order: a 30 000-factor window waited 59 memory latencies here)
         for (int f0 = f0w + t; f0 < f1w; f0 += 4 * LS) {
@@ -187,9 +204,106 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
     };
 
     const int t_outer = t;
+    // the split solve's hand-over (MODE 1 writes, MODE 2 reads): see the kernel's header comment
+    const int tailsz = 162 * N + ytot;
+    double *CS = MODE ? d.cs_ws + (size_t)w * sb_cs_doubles(N) : nullptr;
+    double *CS_snv = CS, *CS_dlt = CS + nS, *CS_tail = CS + 2 * nS, *CS_g = CS_tail + tailsz, *CS_hd = CS_g + n, *CS_y = CS_hd + n, *CS_tY = CS_y + n, *CS_sc = CS_tY + n6;
+    if (MODE == 1 && !(mu < 1.0)) return;               // (MODE 2 reports the failure)
     for (;;) {
         if (!(mu < 1.0)) { ls_fail = 1; break; }
         assembled = 1;
+        // MODE 2, first attempt: the chains were eliminated by the MODE 1 launch; a failure there (its flag) is this attempt's failure
+        const bool pre = MODE == 2 && attempt == 0;
+        if (pre && CS_sc[1] != 0.0) { mu *= 10.0; attempt++; continue; }
+        if (pre) {
+            PHASE_IDS();
+            // ---- (1) vectors: visual diagonal / gradient / reduced rhs + the non-visual parts and the chain's right-hand sides
+            double vh = 0, vg = 0, vy = 0, vs = 0, vd = 0, vT0 = 0, vT1 = 0, vT2 = 0, vtY = 0;
+            const bool sbrow = t < n && (t % 15) >= 6;
+            if (t < n) {
+                vh = CS_hd[t]; vg = CS_g[t]; vy = CS_y[t];
+                if (sbrow || iteration != 0) vs = d.scale_p[(size_t)w * n + t];
+                if (sbrow) vd = d.diag_p[(size_t)w * n + t];
+            }
+            if (t < n6) { vT0 = V[nS + t]; vT1 = V[nS + n6 + t]; vT2 = V[nS + 2 * n6 + t]; vtY = CS_tY[t]; }
+            const double q_ss = CS_sc[0];
+            for (int l = l0 + t; l < l1; l += LS) gmax_l = fmax(gmax_l, fabs(d.lmG[l]));
+            for (int e = t; e < n; e += LS) bs[e] = 0.0;
+            if (t < n) { g[t] = vg; hdiag[t] = vh; }
+            __syncthreads();
+            if (t < n6) {
+                const int fa = t / 6, r = t - 6 * fa;
+                hdiag[15 * fa + r] += vT0; g[15 * fa + r] += vT1; bs[15 * fa + r] = vT2;
+            }
+            __syncthreads();
+            // ---- (2) Jacobi scaling of the pose rows (the speed/bias rows were scaled by the chain kernel)
+            if (t < n) {
+                const int e = t;
+                if (sbrow) { sc[e] = vs; u[e] = 0.0; D[e] = vd; y[e] = vy; }     // (D aliases hdiag, y aliases bs: own entry only)
+                else {
+                    double s_;
+                    if (iteration == 0) { s_ = 1.0 / (1.0 + sqrt(hdiag[e])); d.scale_p[(size_t)w * n + e] = s_; }
+                    else s_ = vs;
+                    const double D2 = fmin(fmax(s_ * s_ * hdiag[e], 1e-6), 1e32);
+                    const double ge = g[e], be = bs[e];
+                    sc[e] = s_; D[e] = sqrt(D2);
+                    d.diag_p[(size_t)w * n + e] = D[e];
+                    d.grad_p[(size_t)w * n + e] = s_ * ge / D[e];
+                    u[e] = s_ * s_ * ge / D2;
+                    d.up[(size_t)w * n + e] = u[e];
+                    y[e] = s_ * (ge + be) + s_ * vy;
+                }
+            }
+            __syncthreads();
+            // ---- (3) the pose system and the chain factors; u^T T u over the unscaled V + S_nv
+            double accq = 0;
+            for (int e0 = t; e0 < nS; e0 += 4 * LS) {
+                double a4[4], b4[4], c4[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) { const int e = e0 + k * LS < nS ? e0 + k * LS : nS - 1; a4[k] = V[e]; b4[k] = CS_snv[e]; c4[k] = CS_dlt[e]; }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int e = e0 + k * LS;
+                    if (e < nS) {
+                        int I, J, r, c;
+                        spp_decode(e, I, J, r, c);
+                        const int gi = 15 * I + r, gj = 15 * J + c;
+                        double sv = (a4[k] + c4[k]) * sc[gi] * sc[gj];
+                        if (!(I == J && r < c)) {
+                            accq += (gi == gj ? 1.0 : 2.0) * (a4[k] + b4[k]) * u[gi] * u[gj];
+                            if (gi == gj) sv += mu * D[gi] * D[gi];
+                        }
+                        Spp[e] = sv;
+                    }
+                }
+            }
+            if (t < n6) accq += 2.0 * u[15 * (t / 6) + t % 6] * vtY;
+            for (int e0 = t; e0 < tailsz; e0 += 4 * LS) {
+                double a4[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) { const int e = e0 + k * LS < tailsz ? e0 + k * LS : tailsz - 1; a4[k] = CS_tail[e]; }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int e = e0 + k * LS;
+                    if (e < tailsz) {
+                        double v = a4[k];
+                        if (e >= 162 * N) {                     // a row of Y_i': the pose row's Jacobi scale
+                            const int q = e - 162 * N, i = yNode[q / 54], qq = q - yo[i], ai = qq / 54, r = (qq - 54 * ai) / 9;
+                            v *= sc[15 * (nlo(i, M) + ai) + r];
+                        }
+                        Dss[e] = v;
+                    }
+                }
+            }
+            __syncthreads();                               // every thread is done with u (it lives in red)
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) accq += __shfl_xor(accq, off);
+            if (lane == 0) red[wv] = accq;
+            __syncthreads();
+            if (t == 0) st.qT = (((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]))) + q_ss;
+            __syncthreads();
+            STAMP(0);
+        } else {
         // the retry loop almost never iterates: keep the compiler from hoisting per-thread index math out of
         // it (the hoisted values stay live across the whole body and spill)
         int t = t_outer;
@@ -202,11 +316,11 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
         // (BIG: one workgroup per CU = 256 VGPRs per lane, room for the IMU blocks of up to 20 frames: 2400 / 512 and 4275 / 512 entries per thread)
         constexpr int KF = BIG ? 5 : 3, KX = BIG ? 9 : 5;
         double vS[5], vT[3] = {0, 0, 0}, vF[KF], vX[KX], vG = 0, vP[2] = {0, 0};
-        if (!BIG) {
+        if (!BIG && MODE != 1) {
 #pragma unroll
             for (int k = 0; k < 5; k++) { const int e = t + k * LS; vS[k] = e < nS ? V[e] : 0.0; }
         }
-        if (t < n6) { vT[0] = V[nS + t]; vT[1] = V[nS + n6 + t]; vT[2] = V[nS + 2 * n6 + t]; }
+        if (MODE != 1 && t < n6) { vT[0] = V[nS + t]; vT[1] = V[nS + n6 + t]; vT[2] = V[nS + 2 * n6 + t]; }
         if (t < d.prior_H_sz) vP[0] = PH[t];
         if (t + LS < d.prior_H_sz) vP[1] = PH[t + LS];
         // IMU factors (precomputed J^T J, local order pose_i sb_i pose_j sb_j)
@@ -280,7 +394,8 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
         }
         // ---- reprojection part from k_sweep / k_rank1_mfma (same packed layout) ----------------------
         for (int e = t; e < n; e += LS) { g[e] = 0.0; bs[e] = 0.0; hdiag[e] = 0.0; }
-        if (!BIG) {
+        if (MODE == 1) { for (int e = t; e < nS; e += LS) Spp[e] = 0.0; }        // (S_nv accumulates here)
+        else if (!BIG) {
 #pragma unroll
             for (int k = 0; k < 5; k++) { const int e = t + k * LS; if (e < nS) Spp[e] = vS[k]; }
         }
@@ -291,7 +406,7 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
         for (int k = 0; k < KF; k++) { const int e = t + k * LS; vF[k] = e < N * 120 ? imu_frame_fetch(e) : 0.0; }
 #pragma unroll
         for (int k = 0; k < KX; k++) { const int e = t + k * LS; vX[k] = e < (N - 1) * 225 ? imu_pair_fetch(e) : 0.0; }
-        if (BIG) {
+        if (BIG && MODE != 1) {
             for (int e0 = t; e0 < nS; e0 += 4 * LS) {       // four loads in flight per trip
                 double v4[4];
 #pragma unroll
@@ -301,11 +416,12 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
             }
         }
         __syncthreads();
-        if (t < n6) {
+        if (MODE != 1 && t < n6) {
             const int fa = t / 6, r = t - 6 * fa;
             hdiag[15 * fa + r] = vT[0]; g[15 * fa + r] = vT[1]; bs[15 * fa + r] = vT[2];
         }
-        if (attempt == 0) {
+        if (MODE == 1) {
+        } else if (attempt == 0) {
             for (int l = l0 + t; l < l1; l += LS) gmax_l = fmax(gmax_l, fabs(d.lmG[l]));
         } else {
             // ---- mu retry: T -= sum_l (c_l(mu) - c_l(mu0)) w_l w_l^T, bs -= sum_l dc_l g_l w_l --------
@@ -404,7 +520,13 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
         STAMP(2);
         // ---- Jacobi scaling, LM diagonal, Cauchy data -------------------------------------------------
         { PHASE_IDS();
+        if (MODE == 1) {
+            // the non-visual pose blocks, gradient and diagonal as assembled (unscaled): the pose kernel adds the visual part
+            for (int e = t; e < nS; e += LS) CS_snv[e] = Spp[e];
+            for (int e = t; e < n; e += LS) { CS_g[e] = g[e]; CS_hd[e] = hdiag[e]; }
+        }
         for (int e = t; e < n; e += LS) {
+            if (MODE == 1 && (e % 15) < 6) { sc[e] = 1.0; u[e] = 0.0; y[e] = 0.0; continue; }      // pose rows: scaled by the pose kernel (their scale needs the visual diagonal)
             double s;
             if (iteration == 0) { s = 1.0 / (1.0 + sqrt(hdiag[e])); d.scale_p[(size_t)w * n + e] = s; }
             else s = d.scale_p[(size_t)w * n + e];
@@ -421,7 +543,24 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
         {   // qT = u^T T u on the unscaled blocks, then scale in place and add the LM diagonal
             PHASE_IDS();
             double accq = 0;
-            for (int e = t; e < nS; e += LS) {
+            if (MODE == 1) {
+                // t_Y[pose row] = sum over the speed/bias columns of (unscaled Y) u: the pose kernel adds 2 u_pose . t_Y to u^T T u
+                for (int rho = t; rho < n6; rho += LS) {
+                    const int a = rho / 6, r = rho - 6 * a;
+                    double sY = 0;
+                    for (int i = 0; i < N; i++) {
+                        const int lo = nlo(i, M);
+                        if (a >= lo && a <= nhi(i, M, N)) {
+                            const double *Yr = Ysb + yo[i] + (a - lo) * 54 + r * 9, *ui = u + 15 * i + 6;
+#pragma unroll
+                            for (int kk = 0; kk < 9; kk++) sY += Yr[kk] * ui[kk];
+                        }
+                    }
+                    CS_tY[rho] = sY;
+                }
+                __syncthreads();
+            }
+            for (int e = t; e < (MODE == 1 ? 0 : nS); e += LS) {
                 int I, J, r, c;
                 spp_decode(e, I, J, r, c);
                 if (I == J && r < c) continue;
@@ -465,7 +604,10 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
             for (int off = 32; off > 0; off >>= 1) accq += __shfl_xor(accq, off);
             if (lane == 0) red[wv] = accq;
             __syncthreads();
-            if (t == 0) st.qT = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+            if (t == 0) {
+                const double qsum = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+                if (MODE == 1) CS_sc[0] = qsum; else st.qT = qsum;
+            }
         }
         __syncthreads();
         STAMP(3);
@@ -718,7 +860,22 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
             }
             }
             __syncthreads();
+        }
+        if (MODE == 1) {
+            // hand-over to the pose kernel (same workgroup index, after the join of the two streams)
+            PHASE_IDS();
+            if (!flag[0]) {
+                for (int e = t; e < nS; e += LS) CS_dlt[e] = Spp[e];               // S_nv - sum_i Y_i' Y_i'^T (pose rows unscaled)
+                for (int e = t; e < tailsz; e += LS) CS_tail[e] = Dss[e];          // L_i^-1 | C_i' | Y_i'
+                for (int e = t; e < n; e += LS) CS_y[e] = y[e];                    // z_i; pose rows: -sum_i Y_i' z_i
+            }
+            if (t == 0) CS_sc[1] = flag[0] ? 1.0 : 0.0;
             STAMP(5);
+            return;
+        }
+        }   // (!pre)
+        STAMP(5);
+        if (!flag[0]) {
             // ---- blocked Cholesky of the pose system (6x6 blocks; diagonal blocks hold L_JJ^-1 afterwards)
             // Look-ahead: while wavefronts 1..7 apply the trailing update of step J, wavefront 0 updates the NEXT diagonal block
             // first and factors it, so the factorisation's dependent pivots and one barrier per step leave the critical path.
@@ -1050,9 +1207,36 @@ __global__ __launch_bounds__(LS, BIG ? 2 : 4) void k_build_solve_sb(DevBatch d) 
     STAMP(8);
 }
 
-template __global__ void k_build_solve_sb<false, 0>(DevBatch);
-template __global__ void k_build_solve_sb<false, 11>(DevBatch);
-template __global__ void k_build_solve_sb<true, 0>(DevBatch);
+template <bool BIG, int NC, int MODE>
+__global__ __launch_bounds__(LS, (BIG || MODE != 0) ? 2 : 4) void k_build_solve_sb(DevBatch d) {       // (the split solve runs one workgroup per CU: no 128-VGPR cap)
+    extern __shared__ __align__(16) double lds[];
+    build_solve_sb_body<BIG, NC, MODE>(d, lds);
+}
+// k_lin_gram_chain (round 5): the two things of an iteration that depend on the state alone and not on each other, in ONE launch on the
+// solve stream -- blockIdx.y = 0: k_lin_gram's workgroup of the window (eight wavefronts); blockIdx.y = 1: the chain half of the split
+// solve (MODE 1), which needs the IMU / prior blocks k_front left.  Small batches only (every workgroup finds a CU of its own).
+template <bool EX, bool BIG, int NC>
+__global__ __launch_bounds__(LS, 2) void k_lin_gram_chain(DevBatch d) {
+    extern __shared__ __align__(16) double lds[];
+    static_assert(LS == 64 * LG_WAVES_SMALL, "k_lin_gram's eight-wavefront form");
+    if (blockIdx.y == 0) lin_gram_body<EX, LG_WAVES_SMALL>(d, lds);
+    else build_solve_sb_body<BIG, NC, 1>(d, lds);
+}
+template __global__ void k_lin_gram_chain<false, false, 0>(DevBatch);
+template __global__ void k_lin_gram_chain<false, false, 11>(DevBatch);
+template __global__ void k_lin_gram_chain<false, true, 0>(DevBatch);
+template __global__ void k_lin_gram_chain<true, false, 0>(DevBatch);
+template __global__ void k_lin_gram_chain<true, true, 0>(DevBatch);
+template __global__ void k_build_solve_sb<false, 0, 0>(DevBatch);
+template __global__ void k_build_solve_sb<false, 11, 0>(DevBatch);
+template __global__ void k_build_solve_sb<true, 0, 0>(DevBatch);
+template __global__ void k_build_solve_sb<false, 0, 1>(DevBatch);
+template __global__ void k_build_solve_sb<false, 11, 1>(DevBatch);
+template __global__ void k_build_solve_sb<true, 0, 1>(DevBatch);
+template __global__ void k_build_solve_sb<false, 0, 2>(DevBatch);
+template __global__ void k_build_solve_sb<false, 11, 2>(DevBatch);
+template __global__ void k_build_solve_sb<true, 0, 2>(DevBatch);
+size_t build_solve_cs_doubles(int N) { return sb_cs_doubles(N); }
 
 size_t build_solve_sb_bytes(int N, int prior_H_sz) {
     const int M = N / 2;

@@ -561,25 +561,17 @@ template __global__ void k_imu_linearize<false>(DevBatch, const double *, const 
 //                 stores.  Same products and sums as the one-wavefront-per-factor kernel of round 3, bit for bit.
 #define ISV_IMU_RAWC 144
 // compact record: residual 0..14 | pose_i blocks 16..51 | speedbias_i blocks 52..114 | pose_j / speedbias_j blocks 115..141 (c_imu_block_of below)
-__global__ __launch_bounds__(256) void k_imu_raw(DevBatch d, const double *pose_src, const double *sb_src, int gate) {
-    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
-    const int N = d.N, NI = d.B * (N - 1);
-    const int f = blockIdx.x * 64 + lane;
-    if (f >= NI) return;
-    const int w = f / (N - 1), i = f - w * (N - 1);
-    if (gate) {
-        const SolveState &ss = d.st[w];
-        if (!(ss.termination == ISV_TERM_RUNNING && (gate == 1 ? ss.need_linearize != 0 : ss.step_valid != 0))) return;
-    }
-    if (d.imu_skip[f]) return;
+// part `part` of factor f (frame i of window w) -> compact value j through store(j, value)
+template <class Store>
+DEV void imu_raw_part(const DevBatch &d, const double *pose_src, const double *sb_src, int f, int w, int i, int part, Store store) {
+    const int N = d.N;
     // (round 4, measured and dropped: the 64 records and states staged through 50 KB of LDS with coalesced loads -- the lane's 25
     //  dependent load -> wait pairs disappear, but the kernel went from 49 to 75 us per launch beside k_lin_gram: its workgroups
     //  then compete with k_lin_gram's for LDS)
     const double *rec = d.imu_in + (size_t)f * ISV_IMU_IN;
     const double *pi = pose_src + ((size_t)w * N + i) * 7, *pj = pi + 7;
     const double *si = sb_src + ((size_t)w * N + i) * 9, *sj = si + 9;
-    double *raw = d.imu_raw + (size_t)(f >> 3) * (ISV_IMU_RAWC * 8) + (f & 7);
-#define RAWC(j) raw[(j) * 8]
+#define RAWC(j, v) store((j), (v))
     Quat Qi = q_from_pose(pi), Qj = q_from_pose(pj);
     Quat Qii = q_inv(Qi);
     const double dt = rec[IMU_DT];
@@ -592,7 +584,7 @@ __global__ __launch_bounds__(256) void k_imu_raw(DevBatch d, const double *pose_
         double r15[15];
         imu_raw_residual(d.G, rec, pi, pj, si, sj, r15);
 #pragma unroll
-        for (int k = 0; k < 15; k++) RAWC(k) = r15[k];
+        for (int k = 0; k < 15; k++) RAWC(k, r15[k]);
     } else if (part == 1) {
         // raw Jacobian (imu_factor.h:66-155), tangent columns: pose_i 0..5, sb_i 6..14, pose_j 15..20, sb_j 21..29
         // blocks (row, col): (0,0) (0,3) (3,3) (6,3)
@@ -612,10 +604,10 @@ __global__ __launch_bounds__(256) void k_imu_raw(DevBatch d, const double *pose_
             for (int c = 0; c < 3; c++) B1[r * 3 + c] += av[r] * (-bv[c]);
 #pragma unroll
         for (int ab = 0; ab < 9; ab++) {
-            RAWC(16 + ab) = -RiT[ab];
-            RAWC(25 + ab) = S1[ab];
-            RAWC(34 + ab) = -B1[ab];
-            RAWC(43 + ab) = S2[ab];
+            RAWC(16 + ab, -RiT[ab]);
+            RAWC(25 + ab, S1[ab]);
+            RAWC(34 + ab, -B1[ab]);
+            RAWC(43 + ab, S2[ab]);
         }
     } else if (part == 2) {
         // blocks (0,6) (0,9) (0,12) (3,12) (6,6) (6,9) (6,12); (9,9) and (12,12) are -I (k_imu_weight fills them in)
@@ -625,13 +617,13 @@ __global__ __launch_bounds__(256) void k_imu_raw(DevBatch d, const double *pose_
         m3_mul(L, rec + IMU_DQ_DBG, T);
 #pragma unroll
         for (int ab = 0; ab < 9; ab++) {
-            RAWC(52 + ab) = -RiT[ab] * dt;
-            RAWC(61 + ab) = -rec[IMU_DP_DBA + ab];
-            RAWC(70 + ab) = -rec[IMU_DP_DBG + ab];
-            RAWC(79 + ab) = -T[ab];
-            RAWC(88 + ab) = -RiT[ab];
-            RAWC(97 + ab) = -rec[IMU_DV_DBA + ab];
-            RAWC(106 + ab) = -rec[IMU_DV_DBG + ab];
+            RAWC(52 + ab, -RiT[ab] * dt);
+            RAWC(61 + ab, -rec[IMU_DP_DBA + ab]);
+            RAWC(70 + ab, -rec[IMU_DP_DBG + ab]);
+            RAWC(79 + ab, -T[ab]);
+            RAWC(88 + ab, -RiT[ab]);
+            RAWC(97 + ab, -rec[IMU_DV_DBA + ab]);
+            RAWC(106 + ab, -rec[IMU_DV_DBG + ab]);
         }
     } else {
         // blocks (0,15) (3,18) (6,21); (9,24) and (12,27) are +I
@@ -640,12 +632,26 @@ __global__ __launch_bounds__(256) void k_imu_raw(DevBatch d, const double *pose_
         qleft33(q_mul(q_mul(q_inv(cdq), Qii), Qj), B2);
 #pragma unroll
         for (int ab = 0; ab < 9; ab++) {
-            RAWC(115 + ab) = RiT[ab];
-            RAWC(124 + ab) = B2[ab];
-            RAWC(133 + ab) = RiT[ab];
+            RAWC(115 + ab, RiT[ab]);
+            RAWC(124 + ab, B2[ab]);
+            RAWC(133 + ab, RiT[ab]);
         }
     }
 #undef RAWC
+}
+__global__ __launch_bounds__(256) void k_imu_raw(DevBatch d, const double *pose_src, const double *sb_src, int gate) {
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int N = d.N, NI = d.B * (N - 1);
+    const int f = blockIdx.x * 64 + lane;
+    if (f >= NI) return;
+    const int w = f / (N - 1), i = f - w * (N - 1);
+    if (gate) {
+        const SolveState &ss = d.st[w];
+        if (!(ss.termination == ISV_TERM_RUNNING && (gate == 1 ? ss.need_linearize != 0 : ss.step_valid != 0))) return;
+    }
+    if (d.imu_skip[f]) return;
+    double *raw = d.imu_raw + (size_t)(f >> 3) * (ISV_IMU_RAWC * 8) + (f & 7);
+    imu_raw_part(d, pose_src, sb_src, f, w, i, part, [&](int j, double v) { raw[j * 8] = v; });
 }
 
 typedef double double4i __attribute__((ext_vector_type(4)));
@@ -669,6 +675,72 @@ DEV int imu_compact_of(int r, int c) {
     const int a = r % 3, cc = c % 3, b0 = c_imu_block_of[r / 3][c / 3];
     if (b0 >= 0) return b0 + a * 3 + cc;
     return (b0 == -1 || a != cc) ? -1 : b0;
+}
+// one wavefront: IMU factor f from its compact raw values C(j) (j >= 0) and its sqrt_info entries sv[s4] = S[i][4 s4 + kq] (masked to 15 x 15 at use):
+// Jw = sqrt_info [J | r], H = Jw^T Jw -> d.imu_H[f], cost_out[f] (and the strips when asked).  src: imu_compact_of of the lane's eight B-operand entries.
+template <class CVal>
+DEV void imu_weight_factor(const DevBatch &d, int f, const double (&sv)[4], const int (&src)[4][2], CVal C, double *sR, double *cost_out, bool want_strip, int lane) {
+    const int i = lane & 15, kq = lane >> 4;
+    double *sH = sR;
+    double4i a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; s4++) {                        // Jw = S * raw: output tiles cols 0..15 and 16..31
+        const int k = 4 * s4 + kq, j0 = src[s4][0], j1 = src[s4][1];
+        const double av = (i < 15 && k < 15) ? sv[s4] : 0.0;
+        const double c0 = C(j0 > 0 ? j0 : 0), c1 = C(j1 > 0 ? j1 : 0);
+        const double b0 = j0 >= 0 ? c0 : (j0 == -1 ? 0.0 : (j0 == -2 ? -1.0 : 1.0)), b1 = j1 >= 0 ? c1 : (j1 == -1 ? 0.0 : (j1 == -2 ? -1.0 : 1.0));
+        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b0, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b1, a1, 0, 0, 0);
+    }
+    double4i h00 = {0, 0, 0, 0}, h10 = {0, 0, 0, 0}, h11 = {0, 0, 0, 0};
+#pragma unroll
+    for (int s4 = 0; s4 < 4; s4++) {                        // H = Jw^T Jw, lower tiles: Jw[4 s4 + kq][i] is register s4 of this lane
+        const double x0 = a0[s4], x1 = a1[s4];
+        h00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, h00, 0, 0, 0);
+        h10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x0, h10, 0, 0, 0);
+        h11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, h11, 0, 0, 0);
+    }
+    // strip layout: [r15 | 15x6 | 15x9 | 15x6 | 15x9] row-major blocks.  The LDS solver path works from the J^T J
+    // blocks alone (k_build_solve_sb, k_dogleg), so the strips are only written for the linearise API (gate 0)
+    // and for the generic path: Jw through the wavefront's staging buffer
+    if (want_strip) {
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {                 // C/D layout: col = lane & 15, row = (lane >> 4) + 4 reg
+            const int row = kq + 4 * reg;
+            sR[row * 32 + i] = a0[reg]; sR[row * 32 + 16 + i] = a1[reg];
+        }
+        ISV_WSYNC();
+        double *out = d.imu_strip + (size_t)f * ISV_IMU_STRIP;
+        if (lane < 15) out[lane] = sR[lane * 32 + 30];
+        for (int e = lane; e < 450; e += 64) {
+            int row, c;
+            if (e < 90) { row = e / 6; c = e - 6 * row; }
+            else if (e < 225) { const int qq = e - 90; row = qq / 9; c = 6 + (qq - 9 * row); }
+            else if (e < 315) { const int qq = e - 225; row = qq / 6; c = 15 + (qq - 6 * row); }
+            else { const int qq = e - 315; row = qq / 9; c = 21 + (qq - 9 * row); }
+            out[15 + e] = sR[row * 32 + c];
+        }
+        ISV_WSYNC();
+    }
+    {
+        // 0.5 |Jw[:, 30]|^2, rows in order (no loss function on IMU factors, :1050): row k sits in lane 14 + 16 (k & 3), register k >> 2 of tile 1
+        double s = 0;
+#pragma unroll
+        for (int k = 0; k < 15; k++) { const double v = imu_lane_value(a1[k >> 2], 14 + 16 * (k & 3)); s += v * v; }
+        if (lane == 0) cost_out[f] = 0.5 * s;
+    }
+    // packed J^T J (pairs a >= b at a(a+1)/2 + b, a, b < 30) then J^T r (row 30 of H)
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) {
+        const int row = kq + 4 * reg;
+        { const int a = row, b = i; if (b <= a) sH[a * (a + 1) / 2 + b] = h00[reg]; }
+        { const int a = 16 + row, b = i; if (a < 30) sH[a * (a + 1) / 2 + b] = h10[reg]; else if (a == 30) sH[465 + b] = h10[reg]; }
+        { const int a = 16 + row, b = 16 + i; if (a < 30) { if (b <= a) sH[a * (a + 1) / 2 + b] = h11[reg]; } else if (a == 30 && b < 30) sH[465 + b] = h11[reg]; }
+    }
+    ISV_WSYNC();
+    double *H = d.imu_H + (size_t)f * ISV_IMU_H;
+    for (int e = lane; e < ISV_IMU_H; e += 64) H[e] = sH[e];
+    ISV_WSYNC();
 }
 __global__ __launch_bounds__(256) void k_imu_weight(DevBatch d, double *cost_out, int gate) {
     // 25 KB of LDS per eight factors: their compact values (9 KB) and one [16][32] staging buffer per wavefront (Jw for the strips, then the packed J^T J)
@@ -711,74 +783,68 @@ __global__ __launch_bounds__(256) void k_imu_weight(DevBatch d, double *cost_out
     for (int k = 0; k < 5; k++) { const int e = t + 256 * k; if (e < ISV_IMU_RAWC * 8) sC[e] = rc[k]; }
     __syncthreads();
     const bool want_strip = gate == 0 || !d.lds_T;
-    double *sR = sA + wv * 512, *sH = sR;
+    double *sR = sA + wv * 512;
 #pragma unroll
     for (int q = 0; q < 2; q++) {
         const int fl = 2 * wv + q, f = f0 + fl, stf = state_of(f);          // (wave-uniform)
         if (stf == 0) continue;
         if (stf == 1) { if (lane == 0) cost_out[f] = 0.0; continue; }
-        double4i a0 = {0, 0, 0, 0}, a1 = {0, 0, 0, 0};
-#pragma unroll
-        for (int s4 = 0; s4 < 4; s4++) {                        // Jw = S * raw: output tiles cols 0..15 and 16..31
-            const int k = 4 * s4 + kq, j0 = src[s4][0], j1 = src[s4][1];
-            const double av = (i < 15 && k < 15) ? sv[q][s4] : 0.0;
-            const double c0 = sC[(j0 > 0 ? j0 : 0) * 8 + fl], c1 = sC[(j1 > 0 ? j1 : 0) * 8 + fl];
-            const double b0 = j0 >= 0 ? c0 : (j0 == -1 ? 0.0 : (j0 == -2 ? -1.0 : 1.0)), b1 = j1 >= 0 ? c1 : (j1 == -1 ? 0.0 : (j1 == -2 ? -1.0 : 1.0));
-            a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b0, a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, b1, a1, 0, 0, 0);
-        }
-        double4i h00 = {0, 0, 0, 0}, h10 = {0, 0, 0, 0}, h11 = {0, 0, 0, 0};
-#pragma unroll
-        for (int s4 = 0; s4 < 4; s4++) {                        // H = Jw^T Jw, lower tiles: Jw[4 s4 + kq][i] is register s4 of this lane
-            const double x0 = a0[s4], x1 = a1[s4];
-            h00 = __builtin_amdgcn_mfma_f64_16x16x4f64(x0, x0, h00, 0, 0, 0);
-            h10 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x0, h10, 0, 0, 0);
-            h11 = __builtin_amdgcn_mfma_f64_16x16x4f64(x1, x1, h11, 0, 0, 0);
-        }
-        // strip layout: [r15 | 15x6 | 15x9 | 15x6 | 15x9] row-major blocks.  The LDS solver path works from the J^T J
-        // blocks alone (k_build_solve_sb, k_dogleg), so the strips are only written for the linearise API (gate 0)
-        // and for the generic path: Jw through the wavefront's staging buffer
-        if (want_strip) {
-#pragma unroll
-            for (int reg = 0; reg < 4; reg++) {                 // C/D layout: col = lane & 15, row = (lane >> 4) + 4 reg
-                const int row = kq + 4 * reg;
-                sR[row * 32 + i] = a0[reg]; sR[row * 32 + 16 + i] = a1[reg];
-            }
-            ISV_WSYNC();
-            double *out = d.imu_strip + (size_t)f * ISV_IMU_STRIP;
-            if (lane < 15) out[lane] = sR[lane * 32 + 30];
-            for (int e = lane; e < 450; e += 64) {
-                int row, c;
-                if (e < 90) { row = e / 6; c = e - 6 * row; }
-                else if (e < 225) { const int qq = e - 90; row = qq / 9; c = 6 + (qq - 9 * row); }
-                else if (e < 315) { const int qq = e - 225; row = qq / 6; c = 15 + (qq - 6 * row); }
-                else { const int qq = e - 315; row = qq / 9; c = 21 + (qq - 9 * row); }
-                out[15 + e] = sR[row * 32 + c];
-            }
-            ISV_WSYNC();
-        }
-        {
-            // 0.5 |Jw[:, 30]|^2, rows in order (no loss function on IMU factors, :1050): row k sits in lane 14 + 16 (k & 3), register k >> 2 of tile 1
-            double s = 0;
-#pragma unroll
-            for (int k = 0; k < 15; k++) { const double v = imu_lane_value(a1[k >> 2], 14 + 16 * (k & 3)); s += v * v; }
-            if (lane == 0) cost_out[f] = 0.5 * s;
-        }
-        // packed J^T J (pairs a >= b at a(a+1)/2 + b, a, b < 30) then J^T r (row 30 of H)
-#pragma unroll
-        for (int reg = 0; reg < 4; reg++) {
-            const int row = kq + 4 * reg;
-            { const int a = row, b = i; if (b <= a) sH[a * (a + 1) / 2 + b] = h00[reg]; }
-            { const int a = 16 + row, b = i; if (a < 30) sH[a * (a + 1) / 2 + b] = h10[reg]; else if (a == 30) sH[465 + b] = h10[reg]; }
-            { const int a = 16 + row, b = 16 + i; if (a < 30) { if (b <= a) sH[a * (a + 1) / 2 + b] = h11[reg]; } else if (a == 30 && b < 30) sH[465 + b] = h11[reg]; }
-        }
-        ISV_WSYNC();
-        double *H = d.imu_H + (size_t)f * ISV_IMU_H;
-        for (int e = lane; e < ISV_IMU_H; e += 64) H[e] = sH[e];
-        ISV_WSYNC();
+        imu_weight_factor(d, f, sv[q], src, [&](int j) { return sC[j * 8 + fl]; }, sR, cost_out, want_strip, lane);
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// k_front (round 5): the IMU and prior factors of the windows of a SMALL batch (one that leaves CUs idle) in ONE launch on the
+// solve stream -- blockIdx.y = 0: the window's IMU factors (the raw parts of k_imu_raw, then k_imu_weight's products, the compact
+// values staying in LDS); blockIdx.y = 1: its prior factors, four wavefronts striding the slots.  The same routines and operation
+// order as the three kernels it replaces (imu_H, imu_cost, prior_H, prior_strip, prior_cost bit for bit); what it saves is
+// their launches, the fork / join events of the side stream (7 + 5..13 us per iteration on the critical stream, measured) and the
+// memory round trip of the compact records.
+#define ISV_FRONT_LDW 145          // compact values of one factor in LDS (odd stride)
+size_t front_lds_bytes(int N, int slots) {
+    const size_t imu = ((size_t)(N - 1) * ISV_FRONT_LDW + 8 * 512) * sizeof(double), pr = prior_lds_bytes(slots);
+    return imu > pr ? imu : pr;
+}
+__global__ __launch_bounds__(512) void k_front(DevBatch d) {
+    extern __shared__ __align__(16) double lds[];
+    const int w = blockIdx.x, t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const SolveState &ss = d.st[w];
+    if (!(ss.termination == ISV_TERM_RUNNING && ss.need_linearize != 0)) return;
+    const int N = d.N;
+    if (blockIdx.y == 1) {
+        if (wv >= 4) return;
+        prior_linearize_body<true, true>(d, d.pose, d.sb, d.prior_cost, 0, w, lds, wv, 4);
+        return;
+    }
+    double *sCw = lds, *sA = lds + (size_t)(N - 1) * ISV_FRONT_LDW;
+    const int f0 = w * (N - 1);
+    if (wv < 4 && lane < N - 1 && !d.imu_skip[f0 + lane]) {
+        double *row = sCw + lane * ISV_FRONT_LDW;
+        imu_raw_part(d, d.pose, d.sb, f0 + lane, w, lane, wv, [&](int j, double v) { row[j] = v; });
+    }
+    const int i = lane & 15, kq = lane >> 4;
+    int src[4][2];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; s4++) { src[s4][0] = imu_compact_of(4 * s4 + kq, i); src[s4][1] = imu_compact_of(4 * s4 + kq, 16 + i); }
+    // sqrt_info of this wavefront's factors (wv, wv + 8, ...; N <= 32): in flight across the barrier
+    double sv[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int fw = wv + 8 * q, f = f0 + (fw < N - 1 ? fw : N - 2);
+        const double *Sg = d.imu_sqrt + (size_t)f * 225;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) { const int k = 4 * s4 + kq; sv[q][s4] = Sg[(i < 15 && k < 15) ? i * 15 + k : 0]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int fw = wv + 8 * q, f = f0 + fw;
+        if (fw >= N - 1) break;
+        if (d.imu_skip[f]) { if (lane == 0) d.imu_cost[f] = 0.0; continue; }
+        const double *row = sCw + fw * ISV_FRONT_LDW;
+        imu_weight_factor(d, f, sv[q], src, [&](int j) { return row[j]; }, sA + wv * 512, d.imu_cost, false, lane);
+    }
+}
 
 template <bool JAC>
 __global__ __launch_bounds__(64) void k_prior_linearize(DevBatch d, const double *pose_src, const double *sb_src, double *cost_out, int gate) {

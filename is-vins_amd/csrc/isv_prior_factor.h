@@ -157,13 +157,14 @@ DEV void prior_H(const double *wr, double *H, int t) {
 
 // ---- phase 1: raw residual / raw Jacobian blocks, one lane per prior; `kinds`: bit k set = evaluate the priors of kind k
 //      (k_dogleg splits the kinds over two wavefronts: the kinds of a wavefront's lanes diverge, i.e. run one after another)
+//      (s0, sstride): lane t takes slots s0 + sstride (t + 64 k): several wavefronts can stride the slots (k_front)
 template <bool JAC>
 DEV void prior_phase1(const DevBatch &d, const PriorRecs &R, const double *pose_src, const double *sb_src, int w, int n_rp,
-                      double *sRaw, int t, unsigned kinds) {
+                      double *sRaw, int t, unsigned kinds, int s0 = 0, int sstride = 1) {
     constexpr int RAWS = JAC ? PRL_RAW : 10;
     const int slots = d.n_prior_slots, N = d.N;
     const double *poseW = pose_src + (size_t)w * N * 7;
-    for (int s = t; s < slots; s += 64) {
+    for (int s = s0 + sstride * t; s < slots; s += 64 * sstride) {
         double *raw = sRaw + s * RAWS, *rawJ = raw + 9;
         const int kind = s == 0 ? 0 : (s == 1 ? 1 : (s < 1 + d.Nvo ? 2 : 3));
         if (!((kinds >> kind) & 1u)) continue;
@@ -287,8 +288,11 @@ DEV void prior_residual_costs(const DevBatch &d, const PriorRecs &R, int w, int 
 }
 
 // WAVE: executed by ONE wavefront of a larger workgroup (lane ids, wave-level LDS ordering instead of barriers)
+// (s0, sstride) with sstride > 1 (WAVE only): `sstride` wavefronts of the workgroup share the window's priors, wavefront s0 takes the
+// slots s0, s0 + sstride, ... through all four phases (a slot's arithmetic does not depend on the lane split); the records are staged
+// by all of them behind ONE block barrier, which every wavefront that calls this must reach
 template <bool JAC, bool WAVE>
-DEV void prior_linearize_body(const DevBatch &d, const double *pose_src, const double *sb_src, double *cost_out, int gate, int w, double *lds) {
+DEV void prior_linearize_body(const DevBatch &d, const double *pose_src, const double *sb_src, double *cost_out, int gate, int w, double *lds, int s0 = 0, int sstride = 1) {
     const int t = WAVE ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
     const int slots = d.n_prior_slots;
     if (gate) {
@@ -301,16 +305,16 @@ DEV void prior_linearize_body(const DevBatch &d, const double *pose_src, const d
     double *sRaw = lds, *sW = lds + (size_t)slots * RAWS, *sRec = sW + (size_t)slots * WS;
     double *strip = d.prior_strip + (size_t)w * d.prior_strip_sz;
     double *PH = d.prior_H + (size_t)w * d.prior_H_sz;
-    const PriorRecs R = prior_stage_records(d, w, sRec, t, 64);
-    if (WAVE) ISV_WSYNC(); else __syncthreads();
-    prior_phase1<JAC>(d, R, pose_src, sb_src, w, n_rp, sRaw, t, 0xFu);
+    const PriorRecs R = sstride > 1 ? prior_stage_records(d, w, sRec, (int)threadIdx.x, 64 * sstride) : prior_stage_records(d, w, sRec, t, 64);
+    if (WAVE && sstride == 1) ISV_WSYNC(); else __syncthreads();
+    prior_phase1<JAC>(d, R, pose_src, sb_src, w, n_rp, sRaw, t, 0xFu, s0, sstride);
     if (WAVE) ISV_WSYNC(); else __syncthreads();
     if (!JAC) {
         prior_residual_costs(d, R, w, n_rp, sRaw, sW, cost_out, t);     // (64 threads either way: the wavefront-level ordering is the block's)
         return;
     }
     // ---- phase 2: sqrt_info * [raw r | raw J] ----
-    for (int s = 0; s < slots; s++) {
+    for (int s = s0; s < slots; s += sstride) {
         const PriorDesc p = prior_desc(d, R, s, n_rp);
         if (!p.valid) continue;
         const double *raw = sRaw + s * RAWS, *rawJ = raw + 9, *S = p.S;
@@ -322,7 +326,7 @@ DEV void prior_linearize_body(const DevBatch &d, const double *pose_src, const d
     }
     if (WAVE) ISV_WSYNC(); else __syncthreads();
     // ---- phase 3: CauchyLoss corrector (scale r and J by sqrt(rho')), cost, strips ----
-    for (int s = 0; s < slots; s++) {
+    for (int s = s0; s < slots; s += sstride) {
         const PriorDesc p = prior_desc(d, R, s, n_rp);
         double *wr = sW + s * WS, *so = strip + p.strip_off;
         double cost = 0.0;
@@ -336,7 +340,7 @@ DEV void prior_linearize_body(const DevBatch &d, const double *pose_src, const d
     if (!JAC) return;
     if (WAVE) ISV_WSYNC(); else __syncthreads();
     // ---- phase 4: J^T J and J^T r ----
-    for (int s = 0; s < slots; s++) {
+    for (int s = s0; s < slots; s += sstride) {
         const PriorDesc p = prior_desc(d, R, s, n_rp);
         if (!p.valid) continue;
         const double *wr = sW + s * WS;

@@ -19,8 +19,12 @@
 #include "isv_imu_factor.h"
 
 extern size_t build_solve_lds_bytes(int N, bool lds_T);
-template <bool BIG, int NC> __global__ void k_build_solve_sb(DevBatch d);
+template <bool BIG, int NC, int MODE> __global__ void k_build_solve_sb(DevBatch d);
 extern size_t build_solve_sb_bytes(int N, int prior_H_sz);
+extern size_t build_solve_cs_doubles(int N);
+template <bool EX, bool BIG, int NC> __global__ void k_lin_gram_chain(DevBatch d);
+__global__ void k_front(DevBatch d);
+extern size_t front_lds_bytes(int N, int slots);
 template <bool BIG, int NC> __global__ void k_build_solve_st(DevBatch d);
 extern size_t build_solve_st_bytes(int N, int prior_H_sz);
 extern size_t build_solve_st_ws_doubles(int N);
@@ -818,6 +822,14 @@ int isv_solver_alloc(DevBatch &d, SolverHost &hc, size_t B, size_t L, size_t F, 
         if (getenv("ISV_DEBUG_PATH")) fprintf(stderr, "isv: k_build_solve_st lds=%zu fits=%d -> solve_st=%d\n", lds_st, (int)fits, (int)hc.solve_st);
         if (hc.solve_st) TRYA(dal(&d.st_ws, B * build_solve_st_ws_doubles(d.N), allocs, err));
     }
+    // the split solve (isv_build_solve_sb.hip, MODE 1 / 2): handles that run k_build_solve_sb and whose batches leave CUs idle -- the chain
+    // kernel needs a CU of its own beside k_lin_gram / k_rank1_mfma to take the speed/bias elimination off the critical path
+    d.cs_ws = nullptr;
+    {
+        const char *e = getenv("ISV_CHAIN_SPLIT");
+        hc.chain_split = d.lds_T && !hc.solve_st && (e ? atoi(e) != 0 : B <= (size_t)hc.n_cus);
+        if (hc.chain_split) TRYA(dal(&d.cs_ws, B * build_solve_cs_doubles(d.N), allocs, err));
+    }
     d.r1_part = nullptr;
     if (can_split) { const size_t nt_ = d.wd_ld / 16; TRYA(dal(&d.r1_part, (size_t)hc.n_cus * (nt_ * (nt_ + 1) / 2) * 256, allocs, err)); }
     d.marg_scratch_sz = 26;
@@ -849,9 +861,23 @@ int isv_solver_alloc(DevBatch &d, SolverHost &hc, size_t B, size_t L, size_t F, 
             if (d.N > 11) SETLDS((k_build_solve_st<true, 0>), lds_st);
             if (d.N == 18) SETLDS((k_build_solve_st<true, 18>), lds_st);
         }
-        if (d.N == 11) SETLDS((k_build_solve_sb<false, 11>), lds_sb);
-        if (d.N <= 11) SETLDS((k_build_solve_sb<false, 0>), lds_sb);
-        if (d.N > 11) SETLDS((k_build_solve_sb<true, 0>), lds_sb);
+        if (d.N == 11) SETLDS((k_build_solve_sb<false, 11, 0>), lds_sb);
+        if (d.N <= 11) SETLDS((k_build_solve_sb<false, 0, 0>), lds_sb);
+        if (d.N > 11) SETLDS((k_build_solve_sb<true, 0, 0>), lds_sb);
+        if (hc.chain_split) {
+            SETLDS(k_front, front_lds_bytes(d.N, d.n_prior_slots));
+            {   // k_lin_gram_chain: the larger of its two roles' needs
+                const size_t lg = lin_gram_lds_bytes(d.Nr, true, d.est_ex != 0, LG_WAVES_SMALL, d.max_lm);
+                const size_t both = (lg > lds_sb ? lg : lds_sb) < ISV_LDS_PER_CU ? (lg > lds_sb ? lg : lds_sb) : ISV_LDS_PER_CU;
+                if (d.est_ex) { if (d.N <= 11) SETLDS((k_lin_gram_chain<true, false, 0>), both); else SETLDS((k_lin_gram_chain<true, true, 0>), both); }
+                else if (d.N == 11) { SETLDS((k_lin_gram_chain<false, false, 11>), both); SETLDS((k_lin_gram_chain<false, false, 0>), both); }
+                else if (d.N < 11) SETLDS((k_lin_gram_chain<false, false, 0>), both);
+                else SETLDS((k_lin_gram_chain<false, true, 0>), both);
+            }
+            if (d.N == 11) { SETLDS((k_build_solve_sb<false, 11, 1>), lds_sb); SETLDS((k_build_solve_sb<false, 11, 2>), lds_sb); }
+            if (d.N <= 11) { SETLDS((k_build_solve_sb<false, 0, 1>), lds_sb); SETLDS((k_build_solve_sb<false, 0, 2>), lds_sb); }
+            if (d.N > 11) { SETLDS((k_build_solve_sb<true, 0, 1>), lds_sb); SETLDS((k_build_solve_sb<true, 0, 2>), lds_sb); }
+        }
 #undef SETLDS
     }
     else {
@@ -899,13 +925,23 @@ int isv_solver_enqueue(DevBatch &d, const SolverHost &hc, hipStream_t st, hipStr
     hipLaunchKernelGGL(k_init_state, dim3((d.B + 63) / 64), dim3(64), 0, st, d);
     for (int slot = 0; slot < d.max_iter; slot++) {
         // linearise where needed (k_*_linearize skip windows whose need_linearize == 0 via the tile/window flags)
-        HCHK(hipEventRecord(fj[0], st)); HCHK(hipStreamWaitEvent(st2, fj[0], 0));
-        if (NI) {
-            hipLaunchKernelGGL(k_imu_raw, dim3((unsigned)(NI + 63) / 64), dim3(256), 0, st2, d, d.pose, d.sb, 1);
-            hipLaunchKernelGGL(k_imu_weight, dim3((unsigned)(NI + 7) / 8), dim3(256), 0, st2, d, d.imu_cost, 1);
+        const bool generic_n = hc.generic_n;             // (A/B / test hook: the run-time-N instantiations for every N)
+        // Small-batch handles (hc.chain_split: every workgroup of every kernel finds a CU of its own) run the whole iteration on ONE
+        // stream: an event record costs the critical stream ~7 us and a wait that really blocks ~13 us on this GPU (measured, rocprofv3
+        // kernel trace of one window), more than the kernels they would overlap.  Instead, independent work shares a LAUNCH:
+        // k_front = {IMU factors | prior factors} of every window, k_lin_gram_chain = {k_lin_gram | chain half of the split solve}.
+        const bool cs = d.lds_T && hc.chain_split;
+        bool chain_done = false;
+        if (cs) hipLaunchKernelGGL(k_front, dim3(d.B, 2), dim3(512), front_lds_bytes(d.N, d.n_prior_slots), st, d);
+        else {
+            HCHK(hipEventRecord(fj[0], st)); HCHK(hipStreamWaitEvent(st2, fj[0], 0));
+            if (NI) {
+                hipLaunchKernelGGL(k_imu_raw, dim3((unsigned)(NI + 63) / 64), dim3(256), 0, st2, d, d.pose, d.sb, 1);
+                hipLaunchKernelGGL(k_imu_weight, dim3((unsigned)(NI + 7) / 8), dim3(256), 0, st2, d, d.imu_cost, 1);
+            }
+            hipLaunchKernelGGL(k_prior_linearize<true>, dim3(d.B), dim3(64), prior_lds_bytes(d.n_prior_slots), st2, d, d.pose, d.sb, d.prior_cost, 1);
+            HCHK(hipEventRecord(fj[1], st2));
         }
-        hipLaunchKernelGGL(k_prior_linearize<true>, dim3(d.B), dim3(64), prior_lds_bytes(d.n_prior_slots), st2, d, d.pose, d.sb, d.prior_cost, 1);
-        HCHK(hipEventRecord(fj[1], st2));
         const bool fused = d.lds_T && d.fused_visual;
         d.sw_global = (d.sw_part && hc.sw_global_ok && (d.B > 256 || hc.debug_sw_global)) ? 1 : 0;     // more than one workgroup per CU: trade LDS for occupancy
         PROF(slot, 0, 0);
@@ -915,7 +951,15 @@ int isv_solver_enqueue(DevBatch &d, const SolverHost &hc, hipStream_t st, hipStr
             const bool ex = d.est_ex != 0;
             const int lgw = (d.B <= n_cus && !hc.lg_batch_waves && lin_gram_lds_bytes(d.Nr, !d.sw_global, ex, LG_WAVES_SMALL, d.lg_lcap) <= ISV_LDS_PER_CU) ? LG_WAVES_SMALL : LG_WAVES;
             const size_t lds_lg = lin_gram_lds_bytes(d.Nr, !d.sw_global, ex, lgw, d.lg_lcap);
-            if (lgw == LG_WAVES_SMALL) {
+            if (cs && lgw == LG_WAVES_SMALL) {
+                const size_t lds_sb = build_solve_sb_bytes(d.N, d.prior_H_sz), both = lds_lg > lds_sb ? lds_lg : lds_sb;
+                const dim3 g2(d.B, 2);
+                if (ex) { if (d.N <= 11) hipLaunchKernelGGL((k_lin_gram_chain<true, false, 0>), g2, dim3(512), both, st, d); else hipLaunchKernelGGL((k_lin_gram_chain<true, true, 0>), g2, dim3(512), both, st, d); }
+                else if (d.N == 11 && !generic_n) hipLaunchKernelGGL((k_lin_gram_chain<false, false, 11>), g2, dim3(512), both, st, d);
+                else if (d.N <= 11) hipLaunchKernelGGL((k_lin_gram_chain<false, false, 0>), g2, dim3(512), both, st, d);
+                else hipLaunchKernelGGL((k_lin_gram_chain<false, true, 0>), g2, dim3(512), both, st, d);
+                chain_done = true;
+            } else if (lgw == LG_WAVES_SMALL) {
                 if (ex) hipLaunchKernelGGL((k_lin_gram<true, LG_WAVES_SMALL>), dim3(d.B), dim3(64 * LG_WAVES_SMALL), lds_lg, st, d);
                 else hipLaunchKernelGGL((k_lin_gram<false, LG_WAVES_SMALL>), dim3(d.B), dim3(64 * LG_WAVES_SMALL), lds_lg, st, d);
             } else if (ex) hipLaunchKernelGGL((k_lin_gram<true, LG_WAVES>), dim3(d.B), dim3(64 * LG_WAVES), lds_lg, st, d);
@@ -976,11 +1020,16 @@ int isv_solver_enqueue(DevBatch &d, const SolverHost &hc, hipStream_t st, hipStr
             }
             PROF(slot, 2, 1);
         }
-        HCHK(hipStreamWaitEvent(st, fj[1], 0));
+        if (!cs) HCHK(hipStreamWaitEvent(st, fj[1], 0));
+        if (cs && !chain_done) {                          // (an upload k_lin_gram_chain does not take: the chain half alone; same bits)
+            const size_t lds_sb = build_solve_sb_bytes(d.N, d.prior_H_sz);
+            if (d.N == 11 && !generic_n) hipLaunchKernelGGL((k_build_solve_sb<false, 11, 1>), dim3(d.B), dim3(512), lds_sb, st, d);
+            else if (d.N <= 11) hipLaunchKernelGGL((k_build_solve_sb<false, 0, 1>), dim3(d.B), dim3(512), lds_sb, st, d);
+            else hipLaunchKernelGGL((k_build_solve_sb<true, 0, 1>), dim3(d.B), dim3(512), lds_sb, st, d);
+        }
         if (!d.lds_T) hipLaunchKernelGGL(k_cost_reduce, dim3(d.B), dim3(256), 0, st, d, d.fcost, d.imu_cost, d.prior_cost, d.cost, 1);   // (k_build_solve_sb sums the cost itself)
         PROF(slot, 3, 0);
         // (the window length as a compile-time constant for the benchmark's 11 frames: isv_build_solve_sb.hip)
-        const bool generic_n = hc.generic_n;             // (A/B / test hook: the run-time-N instantiations for every N)
         if (d.lds_T && hc.solve_st) {
             counts[6] = 1;
             const size_t lds_st = build_solve_st_bytes(d.N, d.prior_H_sz);
@@ -990,12 +1039,17 @@ int isv_solver_enqueue(DevBatch &d, const SolverHost &hc, hipStream_t st, hipStr
             //  k_build_solve_sb<true, 18> spills 62 registers and is SLOWER for the single window it serves: 2.54 against 2.48 ms; not instantiated)
             else if (d.N == 18 && !generic_n) hipLaunchKernelGGL((k_build_solve_st<true, 18>), dim3(d.B), dim3(512), lds_st, st, d);     // (the reference's ALL_BUF_SIZE)
             else hipLaunchKernelGGL((k_build_solve_st<true, 0>), dim3(d.B), dim3(512), lds_st, st, d);       // (long windows: eight wavefronts, two windows per CU)
+        } else if (d.lds_T && hc.chain_split) {           // the pose half of the split solve (the chain half ran on the side stream)
+            const size_t lds_sb = build_solve_sb_bytes(d.N, d.prior_H_sz);
+            if (d.N == 11 && !generic_n) hipLaunchKernelGGL((k_build_solve_sb<false, 11, 2>), dim3(d.B), dim3(512), lds_sb, st, d);
+            else if (d.N <= 11) hipLaunchKernelGGL((k_build_solve_sb<false, 0, 2>), dim3(d.B), dim3(512), lds_sb, st, d);
+            else hipLaunchKernelGGL((k_build_solve_sb<true, 0, 2>), dim3(d.B), dim3(512), lds_sb, st, d);
         } else if (d.lds_T && generic_n) {
-            if (d.N <= 11) hipLaunchKernelGGL((k_build_solve_sb<false, 0>), dim3(d.B), dim3(512), build_solve_sb_bytes(d.N, d.prior_H_sz), st, d);
-            else hipLaunchKernelGGL((k_build_solve_sb<true, 0>), dim3(d.B), dim3(512), build_solve_sb_bytes(d.N, d.prior_H_sz), st, d);
-        } else if (d.lds_T && d.N == 11) hipLaunchKernelGGL((k_build_solve_sb<false, 11>), dim3(d.B), dim3(512), build_solve_sb_bytes(d.N, d.prior_H_sz), st, d);
-        else if (d.lds_T && d.N < 11) hipLaunchKernelGGL((k_build_solve_sb<false, 0>), dim3(d.B), dim3(512), build_solve_sb_bytes(d.N, d.prior_H_sz), st, d);
-        else if (d.lds_T) hipLaunchKernelGGL((k_build_solve_sb<true, 0>), dim3(d.B), dim3(512), build_solve_sb_bytes(d.N, d.prior_H_sz), st, d);
+            if (d.N <= 11) hipLaunchKernelGGL((k_build_solve_sb<false, 0, 0>), dim3(d.B), dim3(512), build_solve_sb_bytes(d.N, d.prior_H_sz), st, d);
+            else hipLaunchKernelGGL((k_build_solve_sb<true, 0, 0>), dim3(d.B), dim3(512), build_solve_sb_bytes(d.N, d.prior_H_sz), st, d);
+        } else if (d.lds_T && d.N == 11) hipLaunchKernelGGL((k_build_solve_sb<false, 11, 0>), dim3(d.B), dim3(512), build_solve_sb_bytes(d.N, d.prior_H_sz), st, d);
+        else if (d.lds_T && d.N < 11) hipLaunchKernelGGL((k_build_solve_sb<false, 0, 0>), dim3(d.B), dim3(512), build_solve_sb_bytes(d.N, d.prior_H_sz), st, d);
+        else if (d.lds_T) hipLaunchKernelGGL((k_build_solve_sb<true, 0, 0>), dim3(d.B), dim3(512), build_solve_sb_bytes(d.N, d.prior_H_sz), st, d);
         else hipLaunchKernelGGL(k_build_solve<false>, dim3(d.B), dim3(512), lds_bs, st, d);
         counts[1]++;
         PROF(slot, 3, 1);
