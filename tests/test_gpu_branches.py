@@ -346,7 +346,11 @@ def test_termination_min_radius(oracle, monkeypatch):
         o, so, _ = oracle_run(oracle, b.cfg, w)
         g = w.clone(); sg, _ = b.optimize(g)
         assert so.termination == 5 and sg.termination == 5 and so.iterations == sg.iterations == 4
-        check_window(o, so, g, sg)
+        # the solve is cut off in mid-descent, so its "final" cost carries the sensitivity of an intermediate trace entry (2.9e-8
+        # relative on this window) instead of a converged minimum's: measured 8.4e-10 with the one-launch reduced-system solve and
+        # 1.06e-9 with the split solve of small-batch handles (scripts/split_accuracy.py: the two agree with the oracle equally
+        # well on every other figure -- 5.8e-10 / 5.4e-10 on converged final costs, 6.3e-10 / 6.4e-10 on the states)
+        check_window(o, so, g, sg, tol_final=5e-9)
     finally:
         oracle.isvo_debug_min_radius(0.0); b.close()
 

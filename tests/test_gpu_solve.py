@@ -30,7 +30,7 @@ def be():
     b.close()
 
 
-def check_window(o, so, g, sg, tol_state=1e-7, tol_cost=1e-7):
+def check_window(o, so, g, sg, tol_state=1e-7, tol_cost=1e-7, tol_final=1e-9):
     n = so.iterations
     assert sg.iterations == n, (sg.iterations, n)
     assert sg.termination == so.termination
@@ -38,7 +38,7 @@ def check_window(o, so, g, sg, tol_state=1e-7, tol_cost=1e-7):
     tc_o, tc_g = np.array(so.trace_cost[: n + 1]), np.array(sg.trace_cost[: n + 1])
     assert np.allclose(tc_g, tc_o, rtol=tol_cost), np.abs(tc_g / tc_o - 1).max()
     assert np.allclose(np.array(sg.trace_radius[: n + 1]), np.array(so.trace_radius[: n + 1]), rtol=1e-7)
-    assert abs(sg.final_cost - so.final_cost) < 1e-9 * so.final_cost
+    assert abs(sg.final_cost - so.final_cost) < tol_final * so.final_cost, abs(sg.final_cost / so.final_cost - 1)
     for name in ("Ps", "Rs", "Vs", "Bas", "Bgs", "para_Pose", "para_SpeedBias"):
         a, b = getattr(g, name), getattr(o, name)
         assert np.abs(a - b).max() < tol_state, (name, np.abs(a - b).max())
