@@ -25,9 +25,10 @@
 #include "isv_kernels.h"
 #include "isv_device_math.h"
 #include "isv_lin_gram.h"
+#include "isv_rank1.h"
 
 #ifdef ISV_STAMP
-#define STAMP(k) do { if (t == 0) { unsigned long long now_ = wall_clock64(); d.dbg[(size_t)w * 64 + (k)] += (double)(now_ - t_last); t_last = now_; } } while (0)
+#define STAMP(k) do { if (t == 0) { unsigned long long now_ = wall_clock64(); d.dbg[(size_t)w * 64 + (k) + (MODE == 1 ? 32 : 0)] += (double)(now_ - t_last); t_last = now_; } } while (0)     // (the chain kernel of the split solve: slots 32..37)
 #else
 #define STAMP(k) do {} while (0)
 #endif
@@ -46,6 +47,9 @@ __host__ __device__ inline int sb_nred(int N, int prior_H_sz) {   // doubles in 
 #define RCH 32                     // landmarks per staged chunk of the retry correction
 
 DEV int sblk(int I, int J, int N) { return (J * N - J * (J - 1) / 2 + (I - J)) * 36; }   // I >= J
+// the non-visual pose blocks are block-tridiagonal (IMU factors and relative-pose priors couple neighbours, the other priors one pose):
+// the chain kernel of the split solve (MODE 1) keeps them as N diagonal blocks followed by N - 1 sub-diagonal ones
+DEV int sbt(int I, int J, int N) { return (I == J ? I : N + J) * 36; }
 DEV int pairidx2(int a, int b) { return a * (a + 1) / 2 + b; }      // a >= b
 DEV int nlo(int i, int M) { return i > M ? i - 1 : 0; }
 DEV int nhi(int i, int M, int N) { return i < M ? i + 1 : N - 1; }
@@ -122,7 +126,7 @@ __host__ __device__ inline size_t sb_cs_doubles(int N) {
     const int M = N / 2;
     size_t ytot = 0;
     for (int i = 0; i < N; i++) ytot += (size_t)((i < M ? i + 1 : N - 1) - (i > M ? i - 1 : 0) + 1) * 54;
-    return 2 * ((size_t)N * (N + 1) / 2 * 36) + 162 * (size_t)N + ytot + 3 * 15 * (size_t)N + 6 * (size_t)N + 8;
+    return (2 * (size_t)N - 1) * 36 + (size_t)N * (N + 1) / 2 * 36 + 162 * (size_t)N + ytot + 3 * 15 * (size_t)N + 6 * (size_t)N + 8;
 }
 template <bool BIG, int NC, int MODE>
 DEV void build_solve_sb_body(const DevBatch &d, double *lds) {
@@ -207,7 +211,7 @@ DEV void build_solve_sb_body(const DevBatch &d, double *lds) {
     // the split solve's hand-over (MODE 1 writes, MODE 2 reads): see the kernel's header comment
     const int tailsz = 162 * N + ytot;
     double *CS = MODE ? d.cs_ws + (size_t)w * sb_cs_doubles(N) : nullptr;
-    double *CS_snv = CS, *CS_dlt = CS + nS, *CS_tail = CS + 2 * nS, *CS_g = CS_tail + tailsz, *CS_hd = CS_g + n, *CS_y = CS_hd + n, *CS_tY = CS_y + n, *CS_sc = CS_tY + n6;
+    double *CS_snv = CS, *CS_dlt = CS + (2 * N - 1) * 36, *CS_tail = CS_dlt + nS, *CS_g = CS_tail + tailsz, *CS_hd = CS_g + n, *CS_y = CS_hd + n, *CS_tY = CS_y + n, *CS_sc = CS_tY + n6;
     if (MODE == 1 && !(mu < 1.0)) return;               // (MODE 2 reports the failure)
     for (;;) {
         if (!(mu < 1.0)) { ls_fail = 1; break; }
@@ -257,20 +261,27 @@ DEV void build_solve_sb_body(const DevBatch &d, double *lds) {
             __syncthreads();
             // ---- (3) the pose system and the chain factors; u^T T u over the unscaled V + S_nv
             double accq = 0;
-            for (int e0 = t; e0 < nS; e0 += 4 * LS) {
-                double a4[4], b4[4], c4[4];
+            constexpr int KD = 8;                                  // loads in flight per array and trip
+            for (int e0 = t; e0 < nS; e0 += KD * LS) {
+                double a8[KD], b8[KD], c8[KD];
 #pragma unroll
-                for (int k = 0; k < 4; k++) { const int e = e0 + k * LS < nS ? e0 + k * LS : nS - 1; a4[k] = V[e]; b4[k] = CS_snv[e]; c4[k] = CS_dlt[e]; }
+                for (int k = 0; k < KD; k++) {
+                    const int e = e0 + k * LS < nS ? e0 + k * LS : nS - 1;
+                    const int ij = blkIJ[e / 36], I = ij & 255, J = ij >> 8;
+                    a8[k] = V[e]; c8[k] = CS_dlt[e];
+                    b8[k] = CS_snv[(I - J <= 1 ? sbt(I, J, N) : 0) + (e % 36)];       // (clamped: masked below)
+                }
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
+                for (int k = 0; k < KD; k++) {
                     const int e = e0 + k * LS;
                     if (e < nS) {
                         int I, J, r, c;
                         spp_decode(e, I, J, r, c);
                         const int gi = 15 * I + r, gj = 15 * J + c;
-                        double sv = (a4[k] + c4[k]) * sc[gi] * sc[gj];
+                        const double tpp = a8[k] + (I - J <= 1 ? b8[k] : 0.0);           // unscaled T_pp entry: visual + non-visual
+                        double sv = (tpp + c8[k]) * sc[gi] * sc[gj];
                         if (!(I == J && r < c)) {
-                            accq += (gi == gj ? 1.0 : 2.0) * (a4[k] + b4[k]) * u[gi] * u[gj];
+                            accq += (gi == gj ? 1.0 : 2.0) * tpp * u[gi] * u[gj];
                             if (gi == gj) sv += mu * D[gi] * D[gi];
                         }
                         Spp[e] = sv;
@@ -278,15 +289,15 @@ DEV void build_solve_sb_body(const DevBatch &d, double *lds) {
                 }
             }
             if (t < n6) accq += 2.0 * u[15 * (t / 6) + t % 6] * vtY;
-            for (int e0 = t; e0 < tailsz; e0 += 4 * LS) {
-                double a4[4];
+            for (int e0 = t; e0 < tailsz; e0 += KD * LS) {
+                double a8[KD];
 #pragma unroll
-                for (int k = 0; k < 4; k++) { const int e = e0 + k * LS < tailsz ? e0 + k * LS : tailsz - 1; a4[k] = CS_tail[e]; }
+                for (int k = 0; k < KD; k++) { const int e = e0 + k * LS < tailsz ? e0 + k * LS : tailsz - 1; a8[k] = CS_tail[e]; }
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
+                for (int k = 0; k < KD; k++) {
                     const int e = e0 + k * LS;
                     if (e < tailsz) {
-                        double v = a4[k];
+                        double v = a8[k];
                         if (e >= 162 * N) {                     // a row of Y_i': the pose row's Jacobi scale
                             const int q = e - 162 * N, i = yNode[q / 54], qq = q - yo[i], ai = qq / 54, r = (qq - 54 * ai) / 9;
                             v *= sc[15 * (nlo(i, M) + ai) + r];
@@ -352,7 +363,7 @@ DEV void build_solve_sb_body(const DevBatch &d, double *lds) {
             int q = e - 120 * I;
             if (q < 21) {
                 const int r = triAB[2 * q], c = triAB[2 * q + 1];
-                Spp[sblk(I, I, N) + r * 6 + c] += v;
+                Spp[(MODE == 1 ? sbt(I, I, N) : sblk(I, I, N)) + r * 6 + c] += v;
                 if (r == c) hdiag[15 * I + r] += v;
             } else if (q < 66) {
                 q -= 21;
@@ -378,7 +389,7 @@ DEV void build_solve_sb_body(const DevBatch &d, double *lds) {
         auto imu_pair_apply = [&](int e, double v) {
             const int I = e / 225;
             int q = e - 225 * I;
-            if (q < 36) Spp[sblk(I + 1, I, N) + q] += v;
+            if (q < 36) Spp[(MODE == 1 ? sbt(I + 1, I, N) : sblk(I + 1, I, N)) + q] += v;
             else if (q < 90) Ysb[yo[I] + (I + 1 - nlo(I, M)) * 54 + (q - 36)] = v;
             else if (q < 144) Ysb[yo[I + 1] + (I - nlo(I + 1, M)) * 54 + (q - 90)] = v;
             else {
@@ -394,7 +405,7 @@ DEV void build_solve_sb_body(const DevBatch &d, double *lds) {
         }
         // ---- reprojection part from k_sweep / k_rank1_mfma (same packed layout) ----------------------
         for (int e = t; e < n; e += LS) { g[e] = 0.0; bs[e] = 0.0; hdiag[e] = 0.0; }
-        if (MODE == 1) { for (int e = t; e < nS; e += LS) Spp[e] = 0.0; }        // (S_nv accumulates here)
+        if (MODE == 1) { for (int e = t; e < (2 * N - 1) * 36; e += LS) Spp[e] = 0.0; }        // (S_nv accumulates here, block-tridiagonal: sbt())
         else if (!BIG) {
 #pragma unroll
             for (int k = 0; k < 5; k++) { const int e = t + k * LS; if (e < nS) Spp[e] = vS[k]; }
@@ -498,7 +509,7 @@ DEV void build_solve_sb_body(const DevBatch &d, double *lds) {
                     const int ga = (aa < 6 || ncol != 12) ? c0 + aa : c1 + aa - 6;
                     const int gb = (bb < 6 || ncol != 12) ? c0 + bb : c1 + bb - 6;
                     const int Ia = ga / 15, ra = ga - 15 * Ia, Ib = gb / 15, rb = gb - 15 * Ib;
-                    if (ra < 6) Spp[sblk(Ia, Ib, N) + ra * 6 + rb] += v;
+                    if (ra < 6) Spp[(MODE == 1 ? sbt(Ia, Ib, N) : sblk(Ia, Ib, N)) + ra * 6 + rb] += v;
                     else Dss[Ia * 81 + (ra - 6) * 9 + (rb - 6)] += v;
                     if (aa == bb) hdiag[ga] += v;
                 } else {
@@ -522,7 +533,7 @@ DEV void build_solve_sb_body(const DevBatch &d, double *lds) {
         { PHASE_IDS();
         if (MODE == 1) {
             // the non-visual pose blocks, gradient and diagonal as assembled (unscaled): the pose kernel adds the visual part
-            for (int e = t; e < nS; e += LS) CS_snv[e] = Spp[e];
+            for (int e = t; e < (2 * N - 1) * 36; e += LS) CS_snv[e] = Spp[e];
             for (int e = t; e < n; e += LS) { CS_g[e] = g[e]; CS_hd[e] = hdiag[e]; }
         }
         for (int e = t; e < n; e += LS) {
@@ -548,7 +559,7 @@ DEV void build_solve_sb_body(const DevBatch &d, double *lds) {
                 for (int rho = t; rho < n6; rho += LS) {
                     const int a = rho / 6, r = rho - 6 * a;
                     double sY = 0;
-                    for (int i = 0; i < N; i++) {
+                    for (int i = (a > 0 ? a - 1 : 0); i <= (a + 1 < N ? a + 1 : N - 1); i++) {      // (before the elimination only the blocks of the IMU factors are filled)
                         const int lo = nlo(i, M);
                         if (a >= lo && a <= nhi(i, M, N)) {
                             const double *Yr = Ysb + yo[i] + (a - lo) * 54 + r * 9, *ui = u + 15 * i + 6;
@@ -805,13 +816,13 @@ DEV void build_solve_sb_body(const DevBatch &d, double *lds) {
                         }
                     }
                 }
-                double *B = Spp + q * 36 + r0 * 6;
+                double *B = (MODE == 1 ? CS_dlt : Spp) + q * 36 + r0 * 6;
                 const bool dg = I == J;
 #pragma unroll
                 for (int r = 0; r < 3; r++)
 #pragma unroll
                     for (int c = 0; c < 6; c++)
-                        if (!dg || r0 + r >= c) B[r * 6 + c] -= acc[r][c];      // (a diagonal block keeps its lower triangle)
+                        if (!dg || r0 + r >= c) { if (MODE == 1) B[r * 6 + c] = -acc[r][c]; else B[r * 6 + c] -= acc[r][c]; }      // (a diagonal block keeps its lower triangle)
             }
             } else {
             // (round 3) a thread owns a 2 x 3 sub-block of a 6x6 pose block instead of one entry: per k it reads two values of
@@ -835,14 +846,23 @@ DEV void build_solve_sb_body(const DevBatch &d, double *lds) {
                         }
                     }
                 }
-                double *B = Spp + q * 36 + r0 * 6 + c0;
+                double *B = (MODE == 1 ? CS_dlt : Spp) + q * 36 + r0 * 6 + c0;
                 const bool dg = I == J;
+                if (MODE == 1) {        // the chain kernel hands -sum_i Y_i' Y_i'^T over (the lower triangle of a diagonal block)
+                    if (!dg || r0 >= c0) B[0] = -s00;
+                    if (!dg || r0 >= c0 + 1) B[1] = -s01;
+                    if (!dg || r0 >= c0 + 2) B[2] = -s02;
+                    if (!dg || r0 + 1 >= c0) B[6] = -s10;
+                    if (!dg || r0 + 1 >= c0 + 1) B[7] = -s11;
+                    if (!dg || r0 + 1 >= c0 + 2) B[8] = -s12;
+                } else {
                 if (!dg || r0 >= c0) B[0] -= s00;
                 if (!dg || r0 >= c0 + 1) B[1] -= s01;
                 if (!dg || r0 >= c0 + 2) B[2] -= s02;
                 if (!dg || r0 + 1 >= c0) B[6] -= s10;
                 if (!dg || r0 + 1 >= c0 + 1) B[7] -= s11;
                 if (!dg || r0 + 1 >= c0 + 2) B[8] -= s12;
+                }
             }
             }
             if (t >= LS - n6) {                                 // pose right-hand side -= sum_i Y_i z_i
@@ -865,7 +885,6 @@ DEV void build_solve_sb_body(const DevBatch &d, double *lds) {
             // hand-over to the pose kernel (same workgroup index, after the join of the two streams)
             PHASE_IDS();
             if (!flag[0]) {
-                for (int e = t; e < nS; e += LS) CS_dlt[e] = Spp[e];               // S_nv - sum_i Y_i' Y_i'^T (pose rows unscaled)
                 for (int e = t; e < tailsz; e += LS) CS_tail[e] = Dss[e];          // L_i^-1 | C_i' | Y_i'
                 for (int e = t; e < n; e += LS) CS_y[e] = y[e];                    // z_i; pose rows: -sum_i Y_i' z_i
             }
@@ -1215,18 +1234,35 @@ __global__ __launch_bounds__(LS, (BIG || MODE != 0) ? 2 : 4) void k_build_solve_
 // k_lin_gram_chain (round 5): the two things of an iteration that depend on the state alone and not on each other, in ONE launch on the
 // solve stream -- blockIdx.y = 0: k_lin_gram's workgroup of the window (eight wavefronts); blockIdx.y = 1: the chain half of the split
 // solve (MODE 1), which needs the IMU / prior blocks k_front left.  Small batches only (every workgroup finds a CU of its own).
-template <bool EX, bool BIG, int NC>
+// NT > 0 (handles whose elimination is not split over workgroups): the workgroup that linearised the window goes straight on to its
+// rank-1 downdates (k_rank1_mfma's routine with its NT (NT + 1) / 2 output tiles dealt over <= 8 wavefronts: a tile is summed by one
+// wavefront in landmark order either way, the bits are k_rank1_mfma's) -- the chain half beside it takes longer than k_lin_gram alone.
+// Instantiated for the reference's 18 frames (64 windows: 2.76 -> 2.63 ms); at 11 frames it LOSES (128 windows 1.93 -> 2.03 ms, 256: 2.39 -> 2.70):
+// eight wavefronts with two tiles each are slower than k_rank1_mfma's fifteen, and the role becomes the launch's long pole.
+template <bool EX, bool BIG, int NC, int NT>
 __global__ __launch_bounds__(LS, 2) void k_lin_gram_chain(DevBatch d) {
     extern __shared__ __align__(16) double lds[];
     static_assert(LS == 64 * LG_WAVES_SMALL, "k_lin_gram's eight-wavefront form");
-    if (blockIdx.y == 0) lin_gram_body<EX, LG_WAVES_SMALL>(d, lds);
+    if (blockIdx.y == 0) {
+        lin_gram_body<EX, LG_WAVES_SMALL>(d, lds);
+        if constexpr (NT > 0) {
+            constexpr int ntiles = NT * (NT + 1) / 2, TPW = (ntiles + 7) / 8, nwaves = (ntiles + TPW - 1) / TPW;
+            // W, the landmark pieces and Tvis written by this workgroup's wavefronts are read back by others below
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if ((int)threadIdx.x >= 64 * nwaves) return;       // (a wavefront without tiles; it is past the last barrier it shares)
+            rank1_body<NT, TPW, 64, 1, EX>(d);
+        }
+    }
     else build_solve_sb_body<BIG, NC, 1>(d, lds);
 }
-template __global__ void k_lin_gram_chain<false, false, 0>(DevBatch);
-template __global__ void k_lin_gram_chain<false, false, 11>(DevBatch);
-template __global__ void k_lin_gram_chain<false, true, 0>(DevBatch);
-template __global__ void k_lin_gram_chain<true, false, 0>(DevBatch);
-template __global__ void k_lin_gram_chain<true, true, 0>(DevBatch);
+template __global__ void k_lin_gram_chain<false, false, 0, 0>(DevBatch);
+template __global__ void k_lin_gram_chain<false, false, 11, 0>(DevBatch);
+template __global__ void k_lin_gram_chain<false, true, 0, 0>(DevBatch);
+template __global__ void k_lin_gram_chain<true, false, 0, 0>(DevBatch);
+template __global__ void k_lin_gram_chain<true, true, 0, 0>(DevBatch);
+template __global__ void k_lin_gram_chain<false, true, 0, 7>(DevBatch);        // the reference's 18 frames
 template __global__ void k_build_solve_sb<false, 0, 0>(DevBatch);
 template __global__ void k_build_solve_sb<false, 11, 0>(DevBatch);
 template __global__ void k_build_solve_sb<true, 0, 0>(DevBatch);

@@ -22,7 +22,7 @@ extern size_t build_solve_lds_bytes(int N, bool lds_T);
 template <bool BIG, int NC, int MODE> __global__ void k_build_solve_sb(DevBatch d);
 extern size_t build_solve_sb_bytes(int N, int prior_H_sz);
 extern size_t build_solve_cs_doubles(int N);
-template <bool EX, bool BIG, int NC> __global__ void k_lin_gram_chain(DevBatch d);
+template <bool EX, bool BIG, int NC, int NT> __global__ void k_lin_gram_chain(DevBatch d);
 __global__ void k_front(DevBatch d);
 extern size_t front_lds_bytes(int N, int slots);
 template <bool BIG, int NC> __global__ void k_build_solve_st(DevBatch d);
@@ -828,7 +828,7 @@ int isv_solver_alloc(DevBatch &d, SolverHost &hc, size_t B, size_t L, size_t F, 
     {
         const char *e = getenv("ISV_CHAIN_SPLIT");
         hc.chain_split = d.lds_T && !hc.solve_st && (e ? atoi(e) != 0 : B <= (size_t)hc.n_cus);
-        if (hc.chain_split) TRYA(dal(&d.cs_ws, B * build_solve_cs_doubles(d.N), allocs, err));
+        if (hc.chain_split) { TRYA(dal(&d.cs_ws, B * build_solve_cs_doubles(d.N), allocs, err)); HCHK(hipMemset(d.cs_ws, 0, B * build_solve_cs_doubles(d.N) * sizeof(double))); }     // (entries above the diagonal of a diagonal block are never written: finite)
     }
     d.r1_part = nullptr;
     if (can_split) { const size_t nt_ = d.wd_ld / 16; TRYA(dal(&d.r1_part, (size_t)hc.n_cus * (nt_ * (nt_ + 1) / 2) * 256, allocs, err)); }
@@ -868,11 +868,13 @@ int isv_solver_alloc(DevBatch &d, SolverHost &hc, size_t B, size_t L, size_t F, 
             SETLDS(k_front, front_lds_bytes(d.N, d.n_prior_slots));
             {   // k_lin_gram_chain: the larger of its two roles' needs
                 const size_t lg = lin_gram_lds_bytes(d.Nr, true, d.est_ex != 0, LG_WAVES_SMALL, d.max_lm);
-                const size_t both = (lg > lds_sb ? lg : lds_sb) < ISV_LDS_PER_CU ? (lg > lds_sb ? lg : lds_sb) : ISV_LDS_PER_CU;
-                if (d.est_ex) { if (d.N <= 11) SETLDS((k_lin_gram_chain<true, false, 0>), both); else SETLDS((k_lin_gram_chain<true, true, 0>), both); }
-                else if (d.N == 11) { SETLDS((k_lin_gram_chain<false, false, 11>), both); SETLDS((k_lin_gram_chain<false, false, 0>), both); }
-                else if (d.N < 11) SETLDS((k_lin_gram_chain<false, false, 0>), both);
-                else SETLDS((k_lin_gram_chain<false, true, 0>), both);
+                size_t both = lg > lds_sb ? lg : lds_sb;
+                if (both < lds_r1) both = lds_r1;
+                if (both > ISV_LDS_PER_CU) both = ISV_LDS_PER_CU;
+                if (d.est_ex) { if (d.N <= 11) SETLDS((k_lin_gram_chain<true, false, 0, 0>), both); else SETLDS((k_lin_gram_chain<true, true, 0, 0>), both); }
+                else if (d.N == 11) { SETLDS((k_lin_gram_chain<false, false, 11, 0>), both); SETLDS((k_lin_gram_chain<false, false, 0, 0>), both); }
+                else if (d.N < 11) SETLDS((k_lin_gram_chain<false, false, 0, 0>), both);
+                else { SETLDS((k_lin_gram_chain<false, true, 0, 0>), both); SETLDS((k_lin_gram_chain<false, true, 0, 7>), both); }
             }
             if (d.N == 11) { SETLDS((k_build_solve_sb<false, 11, 1>), lds_sb); SETLDS((k_build_solve_sb<false, 11, 2>), lds_sb); }
             if (d.N <= 11) { SETLDS((k_build_solve_sb<false, 0, 1>), lds_sb); SETLDS((k_build_solve_sb<false, 0, 2>), lds_sb); }
@@ -931,7 +933,7 @@ int isv_solver_enqueue(DevBatch &d, const SolverHost &hc, hipStream_t st, hipStr
         // kernel trace of one window), more than the kernels they would overlap.  Instead, independent work shares a LAUNCH:
         // k_front = {IMU factors | prior factors} of every window, k_lin_gram_chain = {k_lin_gram | chain half of the split solve}.
         const bool cs = d.lds_T && hc.chain_split;
-        bool chain_done = false;
+        bool chain_done = false, rank1_done = false;
         if (cs) hipLaunchKernelGGL(k_front, dim3(d.B, 2), dim3(512), front_lds_bytes(d.N, d.n_prior_slots), st, d);
         else {
             HCHK(hipEventRecord(fj[0], st)); HCHK(hipStreamWaitEvent(st2, fj[0], 0));
@@ -942,6 +944,14 @@ int isv_solver_enqueue(DevBatch &d, const SolverHost &hc, hipStream_t st, hipStr
             hipLaunchKernelGGL(k_prior_linearize<true>, dim3(d.B), dim3(64), prior_lds_bytes(d.n_prior_slots), st2, d, d.pose, d.sb, d.prior_cost, 1);
             HCHK(hipEventRecord(fj[1], st2));
         }
+        // a SMALL batch with LONG windows: one window's elimination over many CUs (k_schur_split + k_schur_fold, isv_sweep.hip)
+        // WHETHER a window's downdates are split is decided by the HANDLE (its max_batch and max_landmarks: ADVICE r4 -- with the groups
+        // counted from the longest window of the upload, a 320-landmark window was split alone and unsplit beside a 2048-landmark one);
+        // into how many groups, by the window (schur_split_groups).  An upload without a window of ISV_SPLIT_MIN_PASSES passes skips
+        // the split launch: its windows are one group each, the unsplit sums.
+        const int Pmax = (d.lg_lcap + 63) / 64, PmaxH = (d.max_lm + 63) / 64, GrMax = PmaxH < ISV_SPLIT_MAX_GROUPS ? PmaxH : ISV_SPLIT_MAX_GROUPS;
+        const bool split = d.lds_T && d.r1_part && !hc.no_split && Pmax >= ISV_SPLIT_MIN_PASSES && hc.cap_batch * (size_t)(GrMax + 1) <= (size_t)n_cus;
+        d.bs_split = split ? 1 : 0;
         const bool fused = d.lds_T && d.fused_visual;
         d.sw_global = (d.sw_part && hc.sw_global_ok && (d.B > 256 || hc.debug_sw_global)) ? 1 : 0;     // more than one workgroup per CU: trade LDS for occupancy
         PROF(slot, 0, 0);
@@ -952,13 +962,19 @@ int isv_solver_enqueue(DevBatch &d, const SolverHost &hc, hipStream_t st, hipStr
             const int lgw = (d.B <= n_cus && !hc.lg_batch_waves && lin_gram_lds_bytes(d.Nr, !d.sw_global, ex, LG_WAVES_SMALL, d.lg_lcap) <= ISV_LDS_PER_CU) ? LG_WAVES_SMALL : LG_WAVES;
             const size_t lds_lg = lin_gram_lds_bytes(d.Nr, !d.sw_global, ex, lgw, d.lg_lcap);
             if (cs && lgw == LG_WAVES_SMALL) {
-                const size_t lds_sb = build_solve_sb_bytes(d.N, d.prior_H_sz), both = lds_lg > lds_sb ? lds_lg : lds_sb;
+                const size_t lds_sb = build_solve_sb_bytes(d.N, d.prior_H_sz), lds_r1c = (64 * (d.wd_ld + 4) + (size_t)d.max_lm * 3 + 2) * sizeof(double);
+                size_t both = lds_lg > lds_sb ? lds_lg : lds_sb;
                 const dim3 g2(d.B, 2);
-                if (ex) { if (d.N <= 11) hipLaunchKernelGGL((k_lin_gram_chain<true, false, 0>), g2, dim3(512), both, st, d); else hipLaunchKernelGGL((k_lin_gram_chain<true, true, 0>), g2, dim3(512), both, st, d); }
-                else if (d.N == 11 && !generic_n) hipLaunchKernelGGL((k_lin_gram_chain<false, false, 11>), g2, dim3(512), both, st, d);
-                else if (d.N <= 11) hipLaunchKernelGGL((k_lin_gram_chain<false, false, 0>), g2, dim3(512), both, st, d);
-                else hipLaunchKernelGGL((k_lin_gram_chain<false, true, 0>), g2, dim3(512), both, st, d);
-                chain_done = true;
+                // the rank-1 downdates in the same workgroup (handles that do not split the elimination; the shapes instantiated for it)
+                const int nt = d.wd_ld / 16;
+                const bool r1_here = !split && !ex && !generic_n && d.N > 11 && nt == 7 && lds_r1c <= ISV_LDS_PER_CU;
+                if (r1_here && both < lds_r1c) both = lds_r1c;
+                if (ex) { if (d.N <= 11) hipLaunchKernelGGL((k_lin_gram_chain<true, false, 0, 0>), g2, dim3(512), both, st, d); else hipLaunchKernelGGL((k_lin_gram_chain<true, true, 0, 0>), g2, dim3(512), both, st, d); }
+                else if (r1_here) hipLaunchKernelGGL((k_lin_gram_chain<false, true, 0, 7>), g2, dim3(512), both, st, d);
+                else if (d.N == 11 && !generic_n) hipLaunchKernelGGL((k_lin_gram_chain<false, false, 11, 0>), g2, dim3(512), both, st, d);
+                else if (d.N <= 11) hipLaunchKernelGGL((k_lin_gram_chain<false, false, 0, 0>), g2, dim3(512), both, st, d);
+                else hipLaunchKernelGGL((k_lin_gram_chain<false, true, 0, 0>), g2, dim3(512), both, st, d);
+                chain_done = true; rank1_done = r1_here;
             } else if (lgw == LG_WAVES_SMALL) {
                 if (ex) hipLaunchKernelGGL((k_lin_gram<true, LG_WAVES_SMALL>), dim3(d.B), dim3(64 * LG_WAVES_SMALL), lds_lg, st, d);
                 else hipLaunchKernelGGL((k_lin_gram<false, LG_WAVES_SMALL>), dim3(d.B), dim3(64 * LG_WAVES_SMALL), lds_lg, st, d);
@@ -967,10 +983,6 @@ int isv_solver_enqueue(DevBatch &d, const SolverHost &hc, hipStream_t st, hipStr
             counts[0]++; counts[4] = 1;
         } else if (d.n_tiles > 0) { hipLaunchKernelGGL(k_proj_linearize<0>, dim3((d.n_tiles + 3) / 4), dim3(256), lds_proj, st, d, d.pose, d.lam, d.fcost, 1); counts[0]++; }
         PROF(slot, 0, 1);
-        // a SMALL batch with LONG windows: one window's elimination over many CUs (k_schur_split + k_schur_fold, isv_sweep.hip)
-        const int Pmax = (d.lg_lcap + 63) / 64, GrMax = Pmax < ISV_SPLIT_MAX_GROUPS ? Pmax : ISV_SPLIT_MAX_GROUPS;
-        const bool split = d.lds_T && d.r1_part && !hc.no_split && Pmax >= ISV_SPLIT_MIN_PASSES && hc.cap_batch * (size_t)(GrMax + 1) <= (size_t)n_cus;     // (per handle: its max_batch, not this upload's size)
-        d.bs_split = split ? 1 : 0;
         if (split) {
             int Gs = 0;
             if (!fused) { Gs = n_cus / d.B - GrMax; if (Gs > 16) Gs = 16; if (Gs < 1) Gs = 1; }
@@ -1008,7 +1020,7 @@ int isv_solver_enqueue(DevBatch &d, const SolverHost &hc, hipStream_t st, hipStr
             // one workgroup per window: nt(nt+1)/2 tile wavefronts, w vectors expanded to panel rows in LDS
             const size_t lds_r1 = (64 * (d.wd_ld + 4) + (size_t)d.max_lm * 3 + 2) * sizeof(double);
             PROF(slot, 2, 0);
-            switch (nt) {
+            if (!rank1_done) switch (nt) {
             case 1: if (d.est_ex) hipLaunchKernelGGL((k_rank1_mfma<1, 1, 64, 1, true>), dim3(d.B), dim3(64 * 1), lds_r1, st, d); else hipLaunchKernelGGL((k_rank1_mfma<1, 1, 64, 1, false>), dim3(d.B), dim3(64 * 1), lds_r1, st, d); break;
             case 2: if (d.est_ex) hipLaunchKernelGGL((k_rank1_mfma<2, 1, 64, 1, true>), dim3(d.B), dim3(64 * 3), lds_r1, st, d); else hipLaunchKernelGGL((k_rank1_mfma<2, 1, 64, 1, false>), dim3(d.B), dim3(64 * 3), lds_r1, st, d); break;
             case 3: if (d.est_ex) hipLaunchKernelGGL((k_rank1_mfma<3, 1, 64, 1, true>), dim3(d.B), dim3(64 * 6), lds_r1, st, d); else hipLaunchKernelGGL((k_rank1_mfma<3, 1, 64, 1, false>), dim3(d.B), dim3(64 * 6), lds_r1, st, d); break;

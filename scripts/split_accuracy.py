@@ -32,7 +32,7 @@ def run(split, N, Nvo, ids, L, hook=None):
         b.close()
     return out
 
-for (N, Nvo, ids, L, hook) in [(11, 5, range(16), 300, None), (18, 8, range(16), 300, None), (11, 5, [5], 80, 8000.0), (11, 5, range(40, 56), 80, None)]:
+for (N, Nvo, ids, L, hook) in [(11, 5, range(16), 300, None), (18, 8, range(16), 300, None), (11, 5, [5], 80, 8000.0), (11, 5, range(40, 56), 80, None), (11, 5, range(2000, 2016), 16, None), (11, 5, range(2300, 2316), 16, None)]:
     for split in (0, 1):
         r = run(split, N, Nvo, list(ids), L, hook)
         print(f"N={N} L={L} hook={hook} split={split}: pattern ok {all(x[0] for x in r)}; worst trace {max(x[1] for x in r):.2e}, final cost {max(x[2] for x in r):.2e}, state {max(x[3] for x in r):.2e}; median final cost {np.median([x[2] for x in r]):.2e}", flush=True)

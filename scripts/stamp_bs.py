@@ -15,6 +15,11 @@ print(f"B = {B} N = {N} Nvo = {NVO}")
 dbg = be.debug_read(21, B * 64).reshape(B, 64)
 names = {0: "load Tvis + zero", 1: "imu gather", 2: "priors", 3: "scale+qT", 4: "sb chains", 5: "Y Y^T", 6: "pose cholesky", 7: "solves", 8: "outputs"}
 tot = dbg[:, :9].sum(1)
+if dbg[:, 32:38].sum() > 0:
+    print("split solve, chain kernel (MODE 1), us per call:")
+    for k, nm in {32: "load + zero", 33: "imu gather", 34: "priors", 35: "scale + t_Y + q_ss", 36: "sb chains", 37: "Y Y^T + hand-over"}.items():
+        print(f"  {nm:30s} {np.median(dbg[:, k]) / 10 / 100:8.1f} us")
+    print("split solve, pose kernel (MODE 2): slot 0 = loads + assembly + scaling, then pose cholesky / solves / outputs:")
 print("per k_build_solve_sb call (us), median over windows; 10 calls/solve; wall_clock64 = 100 MHz")
 for k, nm in names.items():
     print(f"  {nm:30s} {np.median(dbg[:, k]) / 10 / 100:8.1f} us")

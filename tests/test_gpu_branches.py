@@ -355,6 +355,28 @@ def test_termination_min_radius(oracle, monkeypatch):
         oracle.isvo_debug_min_radius(0.0); b.close()
 
 
+def test_a_window_has_the_same_bits_alone_and_beside_a_32_pass_window(oracle):
+    """whether a window's rank-1 downdates are split over workgroups is decided by the HANDLE (max_batch x groups of
+    max_landmarks against the CUs), never by the longest window of the upload: a 320-landmark window (5 passes of 64) solved
+    alone and beside a 2048-landmark window (32 passes) on one handle gives the same bits; and both agree with the oracle."""
+    w_small = synth.make_window(310, n_frames=11, n_vo=5, n_landmarks=320)
+    w_long = synth.make_window(311, n_frames=11, n_vo=5, n_landmarks=2048, max_track=4)
+    assert w_long.n_factors <= 8192
+    b = backend.Backend(11, 5, max_landmarks=2048, max_obs=max(w_small.n_obs, w_long.n_obs), max_batch=2)
+    try:
+        alone = w_small.clone(); b.optimize_batch([alone])
+        assert b.last_counts()[7] > 0                       # the split elimination ran
+        pair = [w_small.clone(), w_long.clone()]
+        sums, margs = b.optimize_batch(pair)
+        assert b.last_counts()[7] > 0
+        assert np.array_equal(alone.state_vector(), pair[0].state_vector())
+        for w, g, s_, m in zip((w_small, w_long), pair, sums, margs):
+            o, so, mo = oracle_run(oracle, b.cfg, w)
+            check_window(o, so, g, s_)
+    finally:
+        b.close()
+
+
 # ---- the generic kernel ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("n_frames,n_vo,n_lm", [(24, 8, 120), (21, 10, 60), (32, 8, 40)])
 def test_generic_kernel_for_windows_longer_than_20_frames(oracle, n_frames, n_vo, n_lm):
