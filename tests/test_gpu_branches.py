@@ -139,7 +139,9 @@ def test_batch_beyond_one_resident_round_of_the_control_kernel(oracle):
             assert small.last_counts()[5] == 1 and small.last_counts()[6] == 0
             for k, (a, c) in enumerate(zip(gs[k0: k0 + 4], ref2)):
                 assert s2[k].iterations == sums[k0 + k].iterations
-                assert np.abs(a.state_vector() - c.state_vector()).max() < 1e-7
+                # (relative for entries beyond 1: a window of 16 landmarks can hold a depth of -634 m, whose two values differ by 3.7e-10 relative)
+                va, vc = a.state_vector(), c.state_vector()
+                assert (np.abs(va - vc) <= 1e-7 * np.maximum(1.0, np.abs(vc))).all(), np.abs(va - vc).max()
     finally:
         big.close(); small.close()
 
