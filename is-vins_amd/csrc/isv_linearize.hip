@@ -796,7 +796,7 @@ __global__ __launch_bounds__(256) void k_imu_weight(DevBatch d, double *cost_out
 // ------------------------------------------------------------------------------------------
 // k_front (round 5): the IMU and prior factors of the windows of a SMALL batch (one that leaves CUs idle) in ONE launch on the
 // solve stream -- blockIdx.y = 0: the window's IMU factors (the raw parts of k_imu_raw, then k_imu_weight's products, the compact
-// values staying in LDS); blockIdx.y = 1: its prior factors, four wavefronts striding the slots.  The same routines and operation
+// values staying in LDS); blockIdx.y = 1: its prior factors, eight wavefronts striding the slots.  The same routines and operation
 // order as the three kernels it replaces (imu_H, imu_cost, prior_H, prior_strip, prior_cost bit for bit); what it saves is
 // their launches, the fork / join events of the side stream (7 + 5..13 us per iteration on the critical stream, measured) and the
 // memory round trip of the compact records.
@@ -812,8 +812,7 @@ __global__ __launch_bounds__(512) void k_front(DevBatch d) {
     if (!(ss.termination == ISV_TERM_RUNNING && ss.need_linearize != 0)) return;
     const int N = d.N;
     if (blockIdx.y == 1) {
-        if (wv >= 4) return;
-        prior_linearize_body<true, true>(d, d.pose, d.sb, d.prior_cost, 0, w, lds, wv, 4);
+        prior_linearize_body<true, true>(d, d.pose, d.sb, d.prior_cost, 0, w, lds, wv, 8);      // eight wavefronts stride the slots
         return;
     }
     double *sCw = lds, *sA = lds + (size_t)(N - 1) * ISV_FRONT_LDW;

@@ -951,7 +951,10 @@ int isv_solver_enqueue(DevBatch &d, const SolverHost &hc, hipStream_t st, hipStr
         // the split launch: its windows are one group each, the unsplit sums.
         const int Pmax = (d.lg_lcap + 63) / 64, PmaxH = (d.max_lm + 63) / 64, GrMax = PmaxH < ISV_SPLIT_MAX_GROUPS ? PmaxH : ISV_SPLIT_MAX_GROUPS;
         const bool split = d.lds_T && d.r1_part && !hc.no_split && Pmax >= ISV_SPLIT_MIN_PASSES && hc.cap_batch * (size_t)(GrMax + 1) <= (size_t)n_cus;
-        d.bs_split = split ? 1 : 0;
+        // the landmark back-substitution on its own workgroups (k_backsub_split) pays for LONG windows only: per landmark it is the same
+        // routine as k_dogleg's first phase (same bits), which takes ~2.5 us for 300 landmarks against 6-8 us for the extra launch
+        const bool bsub_split = split && d.lg_lcap > 1024;
+        d.bs_split = bsub_split ? 1 : 0;
         const bool fused = d.lds_T && d.fused_visual;
         d.sw_global = (d.sw_part && hc.sw_global_ok && (d.B > 256 || hc.debug_sw_global)) ? 1 : 0;     // more than one workgroup per CU: trade LDS for occupancy
         PROF(slot, 0, 0);
@@ -1066,7 +1069,7 @@ int isv_solver_enqueue(DevBatch &d, const SolverHost &hc, hipStream_t st, hipStr
         counts[1]++;
         PROF(slot, 3, 1);
         PROF(slot, 4, 0);
-        if (split) hipLaunchKernelGGL(k_backsub_split, dim3(d.B, (d.lg_lcap + 127) / 128), dim3(128), 2 * (size_t)d.np * sizeof(double), st, d);
+        if (bsub_split) hipLaunchKernelGGL(k_backsub_split, dim3(d.B, (d.lg_lcap + 127) / 128), dim3(128), 2 * (size_t)d.np * sizeof(double), st, d);
         if (fuse_control) {
             if (d.est_ex) hipLaunchKernelGGL((k_dogleg<true, true>), dim3(d.B), dim3(256), lds_dgc, st, d);
             else hipLaunchKernelGGL((k_dogleg<true, false>), dim3(d.B), dim3(256), lds_dgc, st, d);
