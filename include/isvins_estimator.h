@@ -132,6 +132,12 @@ int  isv_estimator_trajectory(const isv_estimator_t *e, int32_t seq, int32_t whi
  * after isv_estimator_create or ... a frame boundary is handled internally).                                          */
 int  isv_estimator_set_resident(isv_estimator_t *e, int32_t on);
 int64_t isv_estimator_resident_frames(const isv_estimator_t *e);      /* frames solved through the resident path so far */
+/* frames the resident path handed back to the re-upload path so far (a window beyond the resident store's or the per-window
+ * kernels' limits, a sequence that left the steady state): each costs a flush, the downloads and a re-seed -- more than a frame
+ * of the re-upload path -- so a count that keeps growing says the handle is too tight for resident mode.
+ * SEEDING (the first time, and again after every fall-back or failed solve) needs ONE frame in which EVERY sequence of the
+ * estimator solves and is in steady state; image streams that never meet in one step stay on the re-upload path.      */
+int64_t isv_estimator_resident_fallbacks(const isv_estimator_t *e);
 
 #ifdef __cplusplus
 }

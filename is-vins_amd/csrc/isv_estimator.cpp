@@ -297,7 +297,12 @@ struct isv_estimator {
     bool resident_ready = false;               // every sequence is seeded on the device
     int tracks_cap = 0;
     int64_t resident_frames = 0;
-    bool dbg_fell_back = false;       // the ISV_DEBUG_SEQ_*_FRAME hooks fire once
+    int64_t resident_fallbacks = 0;            // frames the resident path handed to the re-upload path (isv_estimator_resident_fallbacks)
+    // test hooks, read ONCE at creation (getenv on every step of every estimator is neither cheap nor safe beside a setenv):
+    // ISV_DEBUG_SEQ_UNSUPPORTED_FRAME / ISV_DEBUG_SEQ_PRECHECK_FAIL_FRAME = the resident frame that "does not fit" (after / before the
+    // feature pass); each fires once
+    int64_t dbg_unsupported_frame = -1, dbg_precheck_frame = -1;
+    bool dbg_unsupported_fired = false, dbg_precheck_fired = false;
 };
 
 namespace {
@@ -554,6 +559,8 @@ int create_common(const isv_estimator_params_t *p, int32_t n_sequences, isv_esti
     isv_estimator *e = new isv_estimator();
     e->p = *p;
     e->p.cfg.max_batch = n_sequences;
+    if (const char *ev = getenv("ISV_DEBUG_SEQ_UNSUPPORTED_FRAME")) e->dbg_unsupported_frame = strtoll(ev, nullptr, 10);
+    if (const char *ev = getenv("ISV_DEBUG_SEQ_PRECHECK_FAIL_FRAME")) e->dbg_precheck_frame = strtoll(ev, nullptr, 10);
     e->seq.resize(n_sequences);
     for (Sequence &s : e->seq) {
         s.N = N; s.Nvo = Nvo;
@@ -770,6 +777,10 @@ int resident_frame(isv_estimator *e, std::vector<std::string> &errs) {
     std::vector<isv_seq_result_t> res(S);
     std::vector<int32_t *> flags(S);
     std::vector<char> fits(S, 1), idle(S, 0);
+    //  what can REFUSE the frame is checked for every sequence before any of them is touched: an error return must not
+    // leave some sequences with this image's features in their track lists and the device without them
+    for (const Sequence &s : e->seq)
+        if (s.staged && (!s.pre[s.N - 1] || (s.last_slide == 2 && !s.pre[s.N - 2]))) { e->err = "a window frame has no pre-integration (no IMU samples were fed)"; return ISV_ERR_INVALID_ARG; }
     int rc = parallel_for(S, errs, [&](int si, std::string &err) {
         Sequence &s = e->seq[si];
         const int N = s.N;
@@ -783,7 +794,6 @@ int resident_frame(isv_estimator *e, std::vector<std::string> &errs) {
         }
         f.prev_slide = s.last_slide;
         f.n_tracks = (int32_t)s.tracks.size();
-        if (!s.pre[N - 1] || (s.last_slide == 2 && !s.pre[N - 2])) { err = "a window frame has no pre-integration (no IMU samples were fed)"; return (int)ISV_ERR_INVALID_ARG; }
         // (from here on the host state changes.  A window that does not fit the resident store or the per-window
         //  kernels is NOT an error -- the re-upload path solves it -- so the limits only mark the frame for the fall-back below;
         //  the tracks this call appends are remembered so that the device's shorter list can be brought back consistently)
@@ -815,16 +825,14 @@ int resident_frame(isv_estimator *e, std::vector<std::string> &errs) {
     const auto tr1 = std::chrono::steady_clock::now();
     bool fit_all = true;
     for (int si = 0; si < S; si++) fit_all &= fits[si] != 0;
-    {
-        const char *ff = getenv("ISV_DEBUG_SEQ_UNSUPPORTED_FRAME");   // (test hook, read per frame: this resident frame "does not fit")
-        if (ff && !e->dbg_fell_back && e->resident_frames == atoi(ff)) { fit_all = false; e->dbg_fell_back = true; }      // (once)
-    }
+    if (!e->dbg_unsupported_fired && e->resident_frames == e->dbg_unsupported_frame) { fit_all = false; e->dbg_unsupported_fired = true; }      // (test hook, once)
     // isv_backend_seq_frame refuses a frame BEFORE it launches anything (capacity, or windows the per-window kernels do not take):
     // the device still holds the state of the previous solve
     rc = fit_all ? isv_backend_seq_frame(e->backend, S, fr.data(), res.data(), flags.data(), nullptr) : (int)ISV_ERR_UNSUPPORTED;
     if (rc == ISV_ERR_CAPACITY || rc == ISV_ERR_UNSUPPORTED) {
         const int rcl = leave_resident(e, true, true);
         if (rcl != ISV_OK) return rcl;
+        e->resident_fallbacks++;
         return RESIDENT_FELL_BACK;                   // isv_estimator_step goes on with the host path for this frame (the features are in)
     }
     if (rc != ISV_OK) { e->err = std::string("resident frame failed: ") + isv_backend_last_error(e->backend); return rc; }
@@ -897,6 +905,7 @@ extern "C" int isv_estimator_set_resident(isv_estimator_t *e, int32_t on) {
     return ISV_OK;
 }
 extern "C" int64_t isv_estimator_resident_frames(const isv_estimator_t *e) { return e ? e->resident_frames : 0; }
+extern "C" int64_t isv_estimator_resident_fallbacks(const isv_estimator_t *e) { return e ? e->resident_fallbacks : -1; }
 
 // Estimator::processImage (src/estimator.cpp:126-215) on every staged sequence, the solves batched
 extern "C" int isv_estimator_step(isv_estimator_t *e) {
@@ -912,23 +921,32 @@ extern "C" int isv_estimator_step(isv_estimator_t *e) {
         bool all = true, any = false;
         for (const Sequence &s : e->seq) { all &= s.resident && s.flag == NON_LINEAR; any |= s.staged; }
         if (!any) return 0;
-        // the resident store's own limits, checked BEFORE anything is mutated (an upper bound: every staged id taken as a new track)
+        // the resident store's own limits, checked BEFORE anything is mutated.  First the cheap upper bound (every staged id taken as a
+        // new track); a sequence that fails it is counted exactly -- only the ids it does not track yet open a track (a tight
+        // handle that really fits used to fail the bound on every frame and fall back to the slower path without a word)
         bool fits = true;
         for (const Sequence &s : e->seq) {
             if (!s.staged) continue;
-            const size_t fresh = s.staged_image.size() > s.free_slots.size() ? s.staged_image.size() - s.free_slots.size() : 0;
-            fits &= s.tracks.size() + s.staged_image.size() <= (size_t)e->tracks_cap && s.pool.size() / POINT_RING + fresh <= (size_t)e->tracks_cap;
+            auto ok = [&](size_t n_new) {
+                const size_t fresh = n_new > s.free_slots.size() ? n_new - s.free_slots.size() : 0;
+                return s.tracks.size() + n_new <= (size_t)e->tracks_cap && s.pool.size() / POINT_RING + fresh <= (size_t)e->tracks_cap;
+            };
+            if (ok(s.staged_image.size())) continue;
+            std::vector<int> ids(s.tracks.size());
+            for (size_t i = 0; i < s.tracks.size(); i++) ids[i] = s.tracks[i].id;
+            std::sort(ids.begin(), ids.end());
+            size_t n_new = 0;
+            for (const auto &ob : s.staged_image) n_new += !std::binary_search(ids.begin(), ids.end(), ob.first);
+            fits &= ok(n_new);
         }
-        {
-            const char *ff = getenv("ISV_DEBUG_SEQ_PRECHECK_FAIL_FRAME");     // (test hook, read per frame)
-            if (ff && !e->dbg_fell_back && e->resident_frames == atoi(ff)) { fits = false; e->dbg_fell_back = true; }      // (once)
-        }
+        if (!e->dbg_precheck_fired && e->resident_frames == e->dbg_precheck_frame) { fits = false; e->dbg_precheck_fired = true; }      // (test hook, once)
         if (all && fits) {
             const int rc = resident_frame(e, errs);        // (fills step_ms[1] host preparation, [4] hand-over + device, [5] read-back + slide)
             e->step_ms[0] = ms(t0, clk::now());
             if (rc != RESIDENT_FELL_BACK) return rc;
             // the frame did not fit the resident path: the windows are back, this frame's features are already in the track lists
         } else {
+            e->resident_fallbacks++;
             const int rc = leave_resident(e, true);    // a sequence left the steady state, or the store is full:
             if (rc != ISV_OK) return rc;               // the host path takes over (and seeds again once every sequence solves in one frame)
         }

@@ -712,6 +712,7 @@ __global__ __launch_bounds__(64) void k_pgo(PgDev dv) {
 struct PgEdgeTpl { int32_t kind, a, b, fa, fb, dim, robust, src; };     // src: the keyframe whose factor this residual block is
 struct PgStructCache {
     uint64_t key = 0; bool valid = false;
+    std::vector<uint64_t> raw;                    // the key tuple itself: a hash match alone would reuse another topology's structure on a collision
     std::vector<int> loc;
     int cur_pos = -1, n_loops = 0;
     int32_t P1 = 0, nf = 0, nblk = 0;
@@ -933,7 +934,7 @@ extern "C" int isv_pgo_optimize_batch(isv_pgo_t *h, int32_t ng, const int32_t *n
     // host preparation: the graphs are analysed independently (parameter blocks, residual blocks, skyline, column patterns) into
     // per-graph buffers by min(8, cores, graphs) host threads (ISV_HOST_THREADS overrides), then laid end to end
     struct GraphBuild {
-        std::vector<double> pose; std::vector<int32_t> free_of, adj_ptr, adj, start, rowptr, colptr, colrows; std::vector<PgEdge> edges;
+        std::vector<double> pose; std::vector<int32_t> free_of, adj_ptr, adj, start, rowptr, colptr, colrows; std::vector<PgEdge> edges; std::vector<uint64_t> raw_key;
         const char *err = nullptr; int rc = ISV_OK;
     };
     std::vector<PgGraph> graphs(ng);
@@ -941,7 +942,7 @@ extern "C" int isv_pgo_optimize_batch(isv_pgo_t *h, int32_t ng, const int32_t *n
     std::vector<std::vector<int>> local(ng);
     std::vector<int> cur_pos(ng, -1), n_loops(ng, 0);
     if (h->cache.size() < (size_t)h->cfg.max_graphs) h->cache.resize((size_t)h->cfg.max_graphs);
-    static const bool no_cache = getenv("ISV_PGO_NO_CACHE") != nullptr;       // (A/B and test hook)
+    static const bool no_cache = getenv("ISV_PGO_NO_CACHE") != nullptr;       // (A/B and test hook; PROCESS-wide: read once, at the first call)
     std::vector<char> hit(ng, 0);
     auto fill_edge_numbers = [&](PgEdge &E, const isv_pg_keyframe_t &k) {
         if (E.kind == 0) { memcpy(E.meas_R, k.rollpitch.R, 72); memcpy(E.sqrt_info, k.rollpitch.sqrt_info, 32); }
@@ -961,13 +962,16 @@ extern "C" int isv_pgo_optimize_batch(isv_pgo_t *h, int32_t ng, const int32_t *n
         // ---- the cached structure of this slot, when nothing it depends on has changed ----
         PgStructCache &SC = h->cache[g];
         uint64_t key = 1469598103934665603ull;
-        auto mix = [&](uint64_t v) { key ^= v + 0x9e3779b97f4a7c15ull + (key << 6) + (key >> 2); };
+        std::vector<uint64_t> &raw = B.raw_key;
+        raw.clear(); raw.reserve(3 + 2 * (size_t)n);
+        auto mix = [&](uint64_t v) { raw.push_back(v); key ^= v + 0x9e3779b97f4a7c15ull + (key << 6) + (key >> 2); };
         mix((uint64_t)n); mix((uint64_t)(uint32_t)firsts[g]); mix((uint64_t)(uint32_t)curs[g]);
         for (int k = 0; k < n; k++) {
             mix(((uint64_t)(uint32_t)kf[k].index << 32) | (uint32_t)kf[k].sequence);
             mix(((uint64_t)(kf[k].has_rollpitch != 0) << 33) | ((uint64_t)(kf[k].has_loop != 0) << 32) | (uint32_t)(kf[k].has_loop ? kf[k].loop_index : 0));
         }
-        if (!no_cache && SC.valid && SC.key == key && (int)SC.loc.size() == n) {
+        // (the hash only short-cuts the comparison: the tuple itself decides)
+        if (!no_cache && SC.valid && SC.key == key && (int)SC.loc.size() == n && SC.raw.size() == raw.size() && memcmp(SC.raw.data(), raw.data(), raw.size() * sizeof(uint64_t)) == 0) {
             G.max_iter = h->cfg.max_iterations; G.huber = h->cfg.huber_delta;
             G.P1 = SC.P1; G.nf = SC.nf; G.nblk = SC.nblk; G.ne = (int32_t)SC.edges.size();
             local[g] = SC.loc; cur_pos[g] = SC.cur_pos; n_loops[g] = SC.n_loops;
@@ -1071,7 +1075,7 @@ extern "C" int isv_pgo_optimize_batch(isv_pgo_t *h, int32_t ng, const int32_t *n
         for (int j = 0; j < nf; j++) { colptr.push_back((int32_t)colrows.size()); colrows.insert(colrows.end(), cp[j].begin(), cp[j].end()); }
         colptr.push_back((int32_t)colrows.size());
         // remember the structure for the next call on this slot
-        SC.key = key; SC.loc = loc; SC.cur_pos = cur_pos[g]; SC.n_loops = n_loops[g]; SC.P1 = G.P1; SC.nf = G.nf; SC.nblk = G.nblk;
+        SC.key = key; SC.raw = raw; SC.loc = loc; SC.cur_pos = cur_pos[g]; SC.n_loops = n_loops[g]; SC.P1 = G.P1; SC.nf = G.nf; SC.nblk = G.nblk;
         SC.free_of = free_of; SC.adj_ptr = adj_ptr; SC.adj = adj; SC.start = start; SC.rowptr = rowptr; SC.colptr = colptr; SC.colrows = colrows;
         SC.edges.resize(edges.size());
         for (size_t e = 0; e < edges.size(); e++) SC.edges[e] = PgEdgeTpl{edges[e].kind, edges[e].a, edges[e].b, edges[e].fa, edges[e].fb, edges[e].dim, edges[e].robust, edge_src[e]};

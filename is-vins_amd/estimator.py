@@ -31,7 +31,7 @@ class isv_solver_vtbl_t(C.Structure):
 EXPORTS = ["isv_estimator_create", "isv_estimator_create_with_solver", "isv_estimator_destroy", "isv_estimator_last_error",
            "isv_estimator_process_imu", "isv_estimator_process_imu_n", "isv_estimator_last_step_ms", "isv_estimator_push_image", "isv_estimator_set_bootstrap", "isv_estimator_step",
            "isv_estimator_status", "isv_estimator_get_window", "isv_estimator_get_extrinsic", "isv_estimator_get_preintegration", "isv_estimator_last_summary", "isv_estimator_trajectory", "isv_estimator_failed_solves",
-           "isv_estimator_set_resident", "isv_estimator_resident_frames"]
+           "isv_estimator_set_resident", "isv_estimator_resident_frames", "isv_estimator_resident_fallbacks"]
 
 _bound = False
 
@@ -60,6 +60,7 @@ def _bind(lib):
     lib.isv_estimator_failed_solves.argtypes = [vp, C.c_int32]
     lib.isv_estimator_set_resident.argtypes = [vp, C.c_int32]
     lib.isv_estimator_resident_frames.argtypes = [vp]; lib.isv_estimator_resident_frames.restype = C.c_int64
+    lib.isv_estimator_resident_fallbacks.argtypes = [vp]; lib.isv_estimator_resident_fallbacks.restype = C.c_int64
     _bound = True
 
 
@@ -161,6 +162,9 @@ class SequenceEstimator:
 
     def resident_frames(self):
         return int(self.lib.isv_estimator_resident_frames(self.h))
+
+    def resident_fallbacks(self):
+        return int(self.lib.isv_estimator_resident_fallbacks(self.h))
 
     def failed_solves(self, seq):
         return self._check(self.lib.isv_estimator_failed_solves(self.h, seq), "failed_solves")
