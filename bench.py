@@ -259,6 +259,38 @@ def main():
             i for r in range(world) for i in sharding.shard_window_ids(r, world, args.windows, None if args.scaling == "weak" else args.windows))
         if not ok:
             raise RuntimeError("the all-gathered result records do not cover every rank's windows")
+    # ---- N > 1: BASELINE config 4 AS WRITTEN in the same run -- 1024 windows in total, block-partitioned over the ranks (1024 / 8 = 128
+    #      per GPU), same step + exchange, its own handle (max_batch = the shard: the small-batch launch variants).  A second timed
+    #      leg, reported as `strong_scaling_config4` beside the weak line, so that one driver run yields both.
+    strong_leg = None
+    if world > 1 and args.scaling == "weak" and 1024 % world == 0:
+        ids_s = list(sharding.shard_window_ids(rank, world, 0, 1024))
+        ws_s = synth.make_windows(ids_s, n_frames=args.frames, n_vo=args.vo, n_landmarks=args.landmarks)
+        Ws = len(ws_s)
+        be_s = backend.Backend(args.frames, args.vo, max_landmarks=args.landmarks, max_obs=max(w.n_obs for w in ws_s), max_batch=Ws)
+        be_s.upload(ws_s)
+        rec_s = torch.zeros((Ws, rec), dtype=torch.float64, device=f"cuda:{dev}")
+        gat_s = torch.zeros((world * Ws, rec), dtype=torch.float64, device="cpu" if rehearsal else f"cuda:{dev}")
+
+        def step_s():
+            be_s.run_optimize(sync=False)
+            be_s.pack_results(rec_s.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            sharding.gather_records(rec_s.cpu() if rehearsal else rec_s, gat_s, dist)
+        steps_s = min(args.steps, 100)
+        for _ in range(args.warmup):
+            step_s()
+        be_s.sync(); barrier()
+        t0s = time.perf_counter()
+        for _ in range(steps_s):
+            step_s()
+        be_s.sync(); barrier()
+        dts = sharding.max_over_ranks(time.perf_counter() - t0s, dist, device="cpu" if rehearsal else f"cuda:{dev}")
+        gs = gat_s.cpu()
+        if not (bool(torch.isfinite(gs[:, -8]).all()) and sorted(int(x) for x in gs[:, -2].tolist()) == list(range(1024))):
+            raise RuntimeError("strong leg: the all-gathered result records do not cover the 1024 windows")
+        be_s.close()
+        strong_leg = {"workload": f"BASELINE config 4 as written: 1024 windows in total, {Ws} per GPU on {world} GPUs, full backendOptimization() + one all-gather of the result records per step",
+                      "scaling": "strong", "value": 1024 * steps_s / dts, "unit": "windows/s", "ms_per_step": 1e3 * dts / steps_s, "steps": steps_s, "windows_per_gpu": Ws, "n_gpus": world}
     # per-kernel-family HIP-event timing of one more (untimed, profiled) step, on the handle's own stream
     be.run_optimize(sync=True, profile=True)
     fam = be.last_timing(); cnt = be.last_counts()
@@ -614,6 +646,8 @@ def main():
             # MI355X image has no Eigen, Ceres or Sophus either, so the oracle stays unpinned by the reference
             "ceres": "unavailable",
         }
+        if strong_leg is not None:
+            out["strong_scaling_config4"] = strong_leg
         for k in ("config2_single_window_linearize", "strong_scaling_shard", "reference_shape_n18_vo8", "stress_config5", "device_resident_replay", "pose_graph_optimisation"):
             if k in extra:
                 out[k] = extra[k]
