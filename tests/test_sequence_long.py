@@ -113,6 +113,7 @@ class TeacherForced(sh.OracleSolver):
         self.n = 0
         self.flips = dict(iterations=0, termination=0, accept=0, solve_flag=0)
         self.worst = dict(state=0.0, cost=0.0, depth=0.0, prior=0.0, tri=0.0, marg=0.0)
+        self.marg_all = []                # per MARGIN_OLD solve: the largest relative difference of a recovered factor's information
 
     def triangulate(self, w):
         g = w.clone()
@@ -148,9 +149,12 @@ class TeacherForced(sh.OracleSolver):
             if w.L:
                 self.worst["depth"] = max(self.worst["depth"], float((np.abs(g.lm_depth[: w.L] - w.lm_depth[: w.L]) / np.maximum(1.0, np.abs(w.lm_depth[: w.L]))).max()))
             if w.margin_old:
+                mw = 0.0
                 for name, k in (("forward_pose_prior", 6), ("backward_relpose", 6), ("backward_vb", 9), ("backward_rollpitch", 2)):
                     A = abi.arr(getattr(mg, name).sqrt_info, (k, k)); B = abi.arr(getattr(m, name).sqrt_info, (k, k))
-                    self.worst["marg"] = max(self.worst["marg"], float(np.abs(A.T @ A - B.T @ B).max() / np.abs(B.T @ B).max()))
+                    mw = max(mw, float(np.abs(A.T @ A - B.T @ B).max() / np.abs(B.T @ B).max()))
+                self.worst["marg"] = max(self.worst["marg"], mw)
+                self.marg_all.append(mw)
         return s, m
 
 
@@ -275,7 +279,7 @@ def test_euroc_standin_full_length_gpu_vs_oracle(oracle, tmp_path):
           f"[{min(feats)}, {max(feats)}], MARGIN_OLD {old.mean():.2f} / MARGIN_NEW {1 - old.mean():.2f}\n"
           f"  (1) every solve repeated on the MI355X from the oracle side's inputs, on the shim-shaped handle (18 000 observations of capacity; fused k_lin_gram ran: {fused_path == 1}) "
           f"({tf.n} windows): flips {tf.flips}; worst |dstate| {tf.worst['state']:.2e}, cost trace {tf.worst['cost']:.2e} rel, depth {tf.worst['depth']:.2e} rel, "
-          f"priors {tf.worst['prior']:.2e}, marginalisation information {tf.worst['marg']:.2e} rel, triangulation {tf.worst['tri']:.2e} rel\n"
+          f"priors {tf.worst['prior']:.2e}, marginalisation information {tf.worst['marg']:.2e} rel (third largest over the {len(tf.marg_all)} MARGIN_OLD solves: {sorted(tf.marg_all)[-3]:.2e}), triangulation {tf.worst['tri']:.2e} rel\n"
           f"  (2) free-running native + MI355X vs restatement + oracle, the reference's configuration (NUM_ITERATIONS = 10; {100 * tol10:.0f} % of the solves end on a tolerance):\n"
           f"      |dP| at solved frame {marks}:\n        GPU vs oracle                  {fmt(dpos, marks)}   full-length ATE {rms(dpos):.3f} m\n"
           f"        control 1e-12 m (oracle vs oracle) {fmt(d12, marks)}   ATE {rms(d12):.3f} m\n"
@@ -296,6 +300,11 @@ def test_euroc_standin_full_length_gpu_vs_oracle(oracle, tmp_path):
     # eigen-decomposition and small inverses: 1e-4 relative over 2383 real windows; 1e-5 / 1e-6 on the synthetic ones)
     assert tf.worst["state"] < 1e-7 and tf.worst["prior"] < 1e-7 and tf.worst["cost"] < 1e-7 and tf.worst["depth"] < 1e-4
     assert tf.worst["marg"] < 1e-4 and tf.worst["tri"] < 1e-6
+    # (round 5, tests/test_marg_third_opinion.py: the 3.9e-5 / 1.8e-5 of solves 2270 / 2271 are the ORACLE's -- its full-pivot LU of the
+    #  (landmarks + 6)^2 block loses 11 digits there, the device's closed-form elimination is 2.8e-10 from the 40-digit result -- and with
+    #  the extra Jacobi sweep on the device every other solve agrees to 3.6e-9, 3.1e-7 before)
+    marg_sorted = sorted(tf.marg_all)
+    assert len(marg_sorted) > 1500 and marg_sorted[-3] < 2e-8, marg_sorted[-5:]
     # (2) free-running: exact while rounding has not been amplified ...
     assert rms(dpos[:40]) < 1e-6 and dpos[:40].max() < 1e-6
     assert all(a == b for a, b in zip(per_g[:40], per_o[:40]))
