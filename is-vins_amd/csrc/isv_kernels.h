@@ -56,6 +56,7 @@ template <bool EX, int LGW> __global__ void k_lin_gram(DevBatch d);     // EX: t
 size_t lin_gram_lds_bytes(int N, bool partials_in_lds, bool ex, int waves, int lcap);
 #define ISV_LDS_PER_CU ((size_t)160 * 1024)
 template <int NT, int TPW> __global__ void k_schur_split(DevBatch d, int Gs, int GrMax);
+template <int NT, int TPW> __global__ void k_rank1_split(DevBatch d, int GrMax);
 __global__ void k_schur_fold(DevBatch d, int GrMax, int NT, int from_partials);
 __global__ void k_imu_raw(DevBatch d, const double *pose_src, const double *sb_src, int gate);
 __global__ void k_imu_weight(DevBatch d, double *cost_out, int gate);

@@ -27,7 +27,13 @@ typedef double double4v __attribute__((ext_vector_type(4)));
 // the passes [g P / Gr, (g + 1) P / Gr) of the window's P = ceil(L / R1_CHUNK) passes, forms the landmark scalars of exactly
 // those landmarks, and leaves its raw accumulator tiles in d.r1_part for k_schur_fold (fixed order, no atomics).
 // groups of a window with P passes: a function of the window alone (its bits do not depend on the batch around it)
-__host__ __device__ inline int schur_split_groups(int P) { return P >= ISV_SPLIT_MIN_PASSES ? (P < ISV_SPLIT_MAX_GROUPS ? P : ISV_SPLIT_MAX_GROUPS) : 1; }
+// (round 5) ... and of the HANDLE's cap (DevBatch::split_cap: the groups per window that still give every workgroup of a full batch a
+// resident slot, chosen from max_batch at creation): min(passes, ISV_SPLIT_MAX_GROUPS, cap), one group below two
+__host__ __device__ inline int schur_split_groups(int P, int cap) {
+    int g = P < ISV_SPLIT_MAX_GROUPS ? P : ISV_SPLIT_MAX_GROUPS;
+    if (g > cap) g = cap;
+    return (P >= ISV_SPLIT_MIN_PASSES && g >= 2) ? g : 1;
+}
 template <int NT, int TPW, int R1_CHUNK, int MINW, bool EX, bool SPLIT = false>
 // (NT = 5, the benchmark's 11 frames: 15 wavefronts per workgroup, and two workgroups share a CU only at <= 64 VGPRs)
 __device__ __forceinline__ void rank1_body(DevBatch &d, const int grp = 0, const int GrMax = 1) {
@@ -41,7 +47,7 @@ __device__ __forceinline__ void rank1_body(DevBatch &d, const int grp = 0, const
     const int N = d.N, n6 = 6 * N;
     int l0 = d.lm_off[w], l1 = d.lm_off[w + 1];
     if (SPLIT) {                           // this group's passes: everything below indexes relative to ITS first landmark
-        const int P = (l1 - l0 + R1_CHUNK - 1) / R1_CHUNK, Gr = schur_split_groups(P);
+        const int P = (l1 - l0 + R1_CHUNK - 1) / R1_CHUNK, Gr = schur_split_groups(P, d.split_cap);
         if (grp >= Gr) return;             // (uniform over the workgroup; a short window of the batch is one group: the unsplit sums)
         const int pa = (int)((long long)grp * P / Gr), pb = (int)((long long)(grp + 1) * P / Gr);
         const int e1 = l0 + R1_CHUNK * pb;

@@ -831,7 +831,19 @@ int isv_solver_alloc(DevBatch &d, SolverHost &hc, size_t B, size_t L, size_t F, 
         if (hc.chain_split) { TRYA(dal(&d.cs_ws, B * build_solve_cs_doubles(d.N), allocs, err)); HCHK(hipMemset(d.cs_ws, 0, B * build_solve_cs_doubles(d.N) * sizeof(double))); }     // (entries above the diagonal of a diagonal block are never written: finite)
     }
     d.r1_part = nullptr;
-    if (can_split) { const size_t nt_ = d.wd_ld / 16; TRYA(dal(&d.r1_part, (size_t)hc.n_cus * (nt_ * (nt_ + 1) / 2) * 256, allocs, err)); }
+    // groups per window (DevBatch::split_cap), PER HANDLE (its max_batch and max_landmarks): a window is split the same way alone and inside
+    // any batch of the handle.  All or nothing: the split pays while every group of every window of a full batch finds a CU of its own
+    // (measured, round 5: with two groups' workgroups per CU -- 128 windows x 4 groups, 256 x 2 -- the partial tiles' traffic, 123 KB per
+    // window and group against 20 KB of Tvis, and the fold launch cost what the shorter passes save: 1.89 -> 1.90 ms, 2.35 -> 2.45 ms).
+    d.split_cap = 1;
+    if (can_split) {
+        const size_t pm = ((size_t)d.max_lm + 63) / 64, gmH = pm < ISV_SPLIT_MAX_GROUPS ? pm : ISV_SPLIT_MAX_GROUPS;
+        if (B * (gmH + 1) <= (size_t)hc.n_cus) d.split_cap = ISV_SPLIT_MAX_GROUPS;
+    }
+    if (can_split && d.split_cap >= 2) {
+        const size_t nt_ = d.wd_ld / 16, pm = ((size_t)d.max_lm + 63) / 64, gm = pm < (size_t)d.split_cap ? pm : (size_t)d.split_cap;
+        TRYA(dal(&d.r1_part, B * gm * (nt_ * (nt_ + 1) / 2) * 256, allocs, err));
+    }
     d.marg_scratch_sz = 26;
     TRYA(dal(&d.marg_scratch, L * 26, allocs, err));
     TRYA(dal(&d.marg_ws, B * ISV_MARG_WS, allocs, err));
@@ -848,6 +860,8 @@ int isv_solver_alloc(DevBatch &d, SolverHost &hc, size_t B, size_t L, size_t F, 
             const size_t lds_sp = lds_r1 > (2 * n_pairs + 2) * sizeof(int) ? lds_r1 : (2 * n_pairs + 2) * sizeof(int);
             SETLDS((k_schur_split<1, 1>), lds_sp); SETLDS((k_schur_split<2, 1>), lds_sp); SETLDS((k_schur_split<3, 1>), lds_sp); SETLDS((k_schur_split<4, 1>), lds_sp);
             SETLDS((k_schur_split<5, 1>), lds_sp); SETLDS((k_schur_split<6, 2>), lds_sp); SETLDS((k_schur_split<7, 2>), lds_sp); SETLDS((k_schur_split<8, 3>), lds_sp);
+            SETLDS((k_rank1_split<1, 1>), lds_r1); SETLDS((k_rank1_split<2, 1>), lds_r1); SETLDS((k_rank1_split<3, 1>), lds_r1); SETLDS((k_rank1_split<4, 1>), lds_r1);
+            SETLDS((k_rank1_split<5, 1>), lds_r1); SETLDS((k_rank1_split<6, 2>), lds_r1); SETLDS((k_rank1_split<7, 2>), lds_r1); SETLDS((k_rank1_split<8, 3>), lds_r1);
         }
         {   // k_lin_gram: up to the whole CU (the launch sizes its LDS from the uploaded windows: isv_batch_upload)
             auto cap = [&](int waves) { const size_t b = lin_gram_lds_bytes(d.Nr, true, d.est_ex != 0, waves, d.max_lm); return b < ISV_LDS_PER_CU ? b : ISV_LDS_PER_CU; };
@@ -949,8 +963,8 @@ int isv_solver_enqueue(DevBatch &d, const SolverHost &hc, hipStream_t st, hipStr
         // counted from the longest window of the upload, a 320-landmark window was split alone and unsplit beside a 2048-landmark one);
         // into how many groups, by the window (schur_split_groups).  An upload without a window of ISV_SPLIT_MIN_PASSES passes skips
         // the split launch: its windows are one group each, the unsplit sums.
-        const int Pmax = (d.lg_lcap + 63) / 64, PmaxH = (d.max_lm + 63) / 64, GrMax = PmaxH < ISV_SPLIT_MAX_GROUPS ? PmaxH : ISV_SPLIT_MAX_GROUPS;
-        const bool split = d.lds_T && d.r1_part && !hc.no_split && Pmax >= ISV_SPLIT_MIN_PASSES && hc.cap_batch * (size_t)(GrMax + 1) <= (size_t)n_cus;
+        const int Pmax = (d.lg_lcap + 63) / 64, PmaxH = (d.max_lm + 63) / 64, GrMax = PmaxH < d.split_cap ? PmaxH : d.split_cap;
+        const bool split = d.lds_T && d.r1_part && !hc.no_split && Pmax >= ISV_SPLIT_MIN_PASSES && d.split_cap >= 2;
         // the landmark back-substitution on its own workgroups (k_backsub_split) pays for LONG windows only: per landmark it is the same
         // routine as k_dogleg's first phase (same bits), which takes ~2.5 us for 300 landmarks against 6-8 us for the extra launch
         const bool bsub_split = split && d.lg_lcap > 1024;
@@ -992,10 +1006,21 @@ int isv_solver_enqueue(DevBatch &d, const SolverHost &hc, hipStream_t st, hipStr
             const int nt = d.wd_ld / 16;
             const size_t n_pairs = (size_t)d.N * (d.N - 1) / 2;
             size_t lds_sp = (64 * (d.wd_ld + 4) + (size_t)d.max_lm * 3 + 2) * sizeof(double);
+            const size_t lds_r1s = lds_sp;
             if (lds_sp < (2 * n_pairs + 2) * sizeof(int)) lds_sp = (2 * n_pairs + 2) * sizeof(int);
             const dim3 grid(d.B, Gs + GrMax);
             PROF(slot, 1, 0);
-            switch (nt) {
+            if (Gs == 0) switch (nt) {          // the downdates alone: the lean kernel (two workgroups per CU)
+            case 1: hipLaunchKernelGGL((k_rank1_split<1, 1>), grid, dim3(64 * 1), lds_r1s, st, d, GrMax); break;
+            case 2: hipLaunchKernelGGL((k_rank1_split<2, 1>), grid, dim3(64 * 3), lds_r1s, st, d, GrMax); break;
+            case 3: hipLaunchKernelGGL((k_rank1_split<3, 1>), grid, dim3(64 * 6), lds_r1s, st, d, GrMax); break;
+            case 4: hipLaunchKernelGGL((k_rank1_split<4, 1>), grid, dim3(64 * 10), lds_r1s, st, d, GrMax); break;
+            case 5: hipLaunchKernelGGL((k_rank1_split<5, 1>), grid, dim3(64 * 15), lds_r1s, st, d, GrMax); break;
+            case 6: hipLaunchKernelGGL((k_rank1_split<6, 2>), grid, dim3(64 * 11), lds_r1s, st, d, GrMax); break;
+            case 7: hipLaunchKernelGGL((k_rank1_split<7, 2>), grid, dim3(64 * 14), lds_r1s, st, d, GrMax); break;
+            default: hipLaunchKernelGGL((k_rank1_split<8, 3>), grid, dim3(64 * 12), lds_r1s, st, d, GrMax); break;
+            }
+            else switch (nt) {
             case 1: hipLaunchKernelGGL((k_schur_split<1, 1>), grid, dim3(64 * 1), lds_sp, st, d, Gs, GrMax); break;
             case 2: hipLaunchKernelGGL((k_schur_split<2, 1>), grid, dim3(64 * 3), lds_sp, st, d, Gs, GrMax); break;
             case 3: hipLaunchKernelGGL((k_schur_split<3, 1>), grid, dim3(64 * 6), lds_sp, st, d, Gs, GrMax); break;

@@ -272,6 +272,18 @@ __global__ __launch_bounds__(64 * ((NT * (NT + 1) / 2 + TPW - 1) / TPW)) void k_
     if ((int)blockIdx.y < Gs) sweep_split_body(d, blockIdx.y, Gs, nwaves);
     else rank1_body<NT, TPW, 64, 1, false, true>(d, (int)blockIdx.y - Gs, GrMax);
 }
+// the downdates alone (handles whose direct part k_lin_gram forms: Gs = 0): without the direct part's registers a workgroup stays at
+// <= 64 VGPRs for the benchmark's 11 frames, two of them share a CU, and a batch of 128 windows can split every window four ways
+template <int NT, int TPW>
+__global__ __launch_bounds__(64 * ((NT * (NT + 1) / 2 + TPW - 1) / TPW)) void k_rank1_split(DevBatch d, int GrMax) { rank1_body<NT, TPW, 64, 1, false, true>(d, (int)blockIdx.y, GrMax); }
+template <> __global__ __launch_bounds__(960) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_rank1_split<5, 1>(DevBatch d, int GrMax) { rank1_body<5, 1, 64, 1, false, true>(d, (int)blockIdx.y, GrMax); }
+template __global__ void k_rank1_split<1, 1>(DevBatch, int);
+template __global__ void k_rank1_split<2, 1>(DevBatch, int);
+template __global__ void k_rank1_split<3, 1>(DevBatch, int);
+template __global__ void k_rank1_split<4, 1>(DevBatch, int);
+template __global__ void k_rank1_split<6, 2>(DevBatch, int);
+template __global__ void k_rank1_split<7, 2>(DevBatch, int);
+template __global__ void k_rank1_split<8, 3>(DevBatch, int);
 template __global__ void k_schur_split<1, 1>(DevBatch, int, int);
 template __global__ void k_schur_split<2, 1>(DevBatch, int, int);
 template __global__ void k_schur_split<3, 1>(DevBatch, int, int);
@@ -321,7 +333,7 @@ __global__ __launch_bounds__(256) void k_schur_fold(DevBatch d, int GrMax, int N
             }
         }
     }
-    const int Gr = schur_split_groups((d.lm_off[w + 1] - d.lm_off[w] + 63) / 64);
+    const int Gr = schur_split_groups((d.lm_off[w + 1] - d.lm_off[w] + 63) / 64, d.split_cap);
     const double *r1 = d.r1_part + (size_t)w * GrMax * (size_t)(ntiles * 256);
     for (int e = tid; e < ntiles * 256; e += nthr) {
         const int tile = e >> 8, reg = (e >> 6) & 3, lane = e & 63;
