@@ -26,6 +26,7 @@
 #include "isv_device_math.h"
 #include "isv_lin_gram.h"
 #include "isv_rank1.h"
+#include "isv_dogleg.h"
 
 #ifdef ISV_STAMP
 #define STAMP(k) do { if (t == 0) { unsigned long long now_ = wall_clock64(); d.dbg[(size_t)w * 64 + (k) + (MODE == 1 ? 32 : 0)] += (double)(now_ - t_last); t_last = now_; } } while (0)     // (the chain kernel of the split solve: slots 32..37)
@@ -1248,15 +1249,36 @@ __global__ __launch_bounds__(LS, 2) void k_lin_gram_chain(DevBatch d) {
         if constexpr (NT > 0) {
             constexpr int ntiles = NT * (NT + 1) / 2, TPW = (ntiles + 7) / 8, nwaves = (ntiles + TPW - 1) / TPW;
             // W, the landmark pieces and Tvis written by this workgroup's wavefronts are read back by others below
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __syncthreads();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __syncthreads();                                   // (same workgroup: the barrier's workgroup-scope release / acquire)
             if ((int)threadIdx.x >= 64 * nwaves) return;       // (a wavefront without tiles; it is past the last barrier it shares)
             rank1_body<NT, TPW, 64, 1, EX>(d);
         }
     }
     else build_solve_sb_body<BIG, NC, 1>(d, lds);
 }
+// k_pose_dogleg (round 5): the pose half of the split solve, the dogleg step and the step control of a window in ONE launch -- three stages
+// of one workgroup per window that followed each other as separate launches (~4 us each on this GPU for a small batch, plus the reload
+// of what the previous stage had in LDS).  The same routines in the same order: bit for bit the three-launch sequence.
+template <bool BIG, int NC, bool EX>
+__global__ __launch_bounds__(LS, 2) void k_pose_dogleg(DevBatch d) {
+    extern __shared__ __align__(16) double lds[];
+    __shared__ double red[256];
+    __shared__ int s_accept;
+    build_solve_sb_body<BIG, NC, 2>(d, lds);
+    // z_p, the Gauss-Newton step, u_p and the solver scalars this workgroup wrote are read back below by other threads of the SAME
+    // workgroup: the barrier's workgroup-scope release / acquire is what that needs (an agent-scope fence writes the XCD's L2 back on
+    // this GPU: measured, it cost the 18-frame window more than the launch it saved)
+    __syncthreads();
+    if (threadIdx.x >= 256) return;                   // (the dogleg and the step control are 256-thread routines)
+    dogleg_body<EX>(d, blockIdx.x, threadIdx.x, red);
+    __syncthreads();                                  // candidate states, per-factor costs and model pieces of this window are written
+    step_control_body<true, EX>(d, blockIdx.x, threadIdx.x, lds, red, s_accept);
+}
+template __global__ void k_pose_dogleg<false, 11, false>(DevBatch);
+template __global__ void k_pose_dogleg<false, 0, false>(DevBatch);
+template __global__ void k_pose_dogleg<true, 0, false>(DevBatch);
+template __global__ void k_pose_dogleg<false, 0, true>(DevBatch);
+template __global__ void k_pose_dogleg<true, 0, true>(DevBatch);
 template __global__ void k_lin_gram_chain<false, false, 0, 0>(DevBatch);
 template __global__ void k_lin_gram_chain<false, false, 11, 0>(DevBatch);
 template __global__ void k_lin_gram_chain<false, true, 0, 0>(DevBatch);

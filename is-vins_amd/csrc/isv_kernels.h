@@ -35,6 +35,7 @@ struct SolverHost {
     bool solve_st = false;            // this handle runs k_build_solve_st (four windows per CU; chosen from the handle's max_batch, ISV_SOLVE_ST=0/1 forces)
     bool chain_split = false;         // this handle splits the reduced-system solve into the chain kernel (side stream) and the pose kernel (k_build_solve_sb MODE 1 / 2):
                                       // handles whose batches leave CUs idle (max_batch <= CUs); ISV_CHAIN_SPLIT=0/1 forces
+    bool no_pose_dogleg = false;      // ISV_NO_POSE_DOGLEG (A/B and test hook): the pose half, the dogleg and the step control as separate launches (same bits)
     bool no_split = false;            // ISV_NO_SPLIT: never spread one window's landmark elimination over several workgroups (k_schur_split)
     bool marg_one_kernel = false;     // ISV_MARG_ONE_KERNEL / ISV_MARG_SPLIT force MargBackward as one launch (k_marg_bwd<2>) or as build / k_marg_jacobi /
     bool marg_split = false;          // project, whatever the batch size (default: split up to n_cus windows); the two are bitwise equal (tested)
