@@ -320,11 +320,15 @@ __global__ void k_marg_clear(DevBatch d) {
 }
 
 // MargForward (+ the pose-graph edge); the record is cleared by k_marg_clear beforehand
-__global__ __launch_bounds__(MT) void k_marg_fwd(DevBatch d) {
+// (round 5) MTF = 256 threads: the two phases that walk the window's landmarks -- the Jacobians of the landmarks hosted in frame 0 (a lane per
+// landmark of the WINDOW: 2000 of them in BASELINE config 5) and their sums into the 12 x 12 pose blocks -- use four wavefronts, the 12 x 12
+// algebra behind them the first (the others have left by then).  Slots and sums in the same order as the one-wavefront kernel: same bits.
+#define MTF 256
+__global__ __launch_bounds__(MTF) void k_marg_fwd(DevBatch d) {
     // (LDS decides how many windows a CU holds next to k_marg_bwd's: 4 + 4 workgroups need <= 40 KB for the pair)
     __shared__ double Lam[144], M1[144], M2[144], Wk[936], Vv[36], wv[8], JU[36];
     __shared__ double sJ[3 * 36];
-    __shared__ int keep[8], piv[4];
+    __shared__ int keep[8], piv[4], wcnt[4];
     const int w = blockIdx.x, t = threadIdx.x;
     isv_marg_result_t &out = d.marg[w];
     if (!d.margin_old[w] || ISV_SEQ_IDLE(d, w)) return;
@@ -343,12 +347,17 @@ __global__ __launch_bounds__(MT) void k_marg_fwd(DevBatch d) {
         double Ri[9], Rj[9], ric[9];
         q_to_R(q_from_pose(pose), Ri); q_to_R(q_from_pose(pose + 7), Rj); q_to_R(q_from_pose(ex), ric);
         const double ident[4] = {1, 0, 0, 1};
-        for (int base = l0; base < l1; base += MT) {
-            const int l = base + t;
+        for (int base = l0; base < l1; base += MTF) {
+            const int l = base + t, lane = t & 63, wvf = t >> 6;
             const bool is0 = l < l1 && d.lm_host[l] == 0;
             const unsigned long long m = __ballot(is0);
+            if (lane == 0) wcnt[wvf] = __popcll(m);
+            __syncthreads();
+            int before = 0, total = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) { const int c = wcnt[q]; total += c; if (q < wvf) before += c; }
             if (is0) {
-                const int slot = n0 + __popcll(m & ((1ull << t) - 1));
+                const int slot = n0 + before + __popcll(m & ((1ull << lane) - 1));
                 const int f = d.lm_f0[l];                     // factor 0 -> 1
                 double r0, r1, Ji[12], Jj[12], Jl[2];
                 const double *pi3 = d.lm_pts_i + (size_t)l * 3;
@@ -363,7 +372,8 @@ __global__ __launch_bounds__(MT) void k_marg_fwd(DevBatch d) {
                 }
                 o[12] = sq[0] * Jl[0] + sq[1] * Jl[1]; o[25] = sq[2] * Jl[0] + sq[3] * Jl[1];
             }
-            n0 += __popcll(m);
+            n0 += total;
+            __syncthreads();                               // (wcnt is rewritten by the next chunk)
         }
     }
     __threadfence_block();
@@ -371,31 +381,28 @@ __global__ __launch_bounds__(MT) void k_marg_fwd(DevBatch d) {
     MSTAMP(0);
     // raw pose block Hraw (12x12, order [T1, T0]) in Lam[0..143]; Schur-reduced over the landmarks in M1[0..143]
     {
-        double hr[3] = {0, 0, 0}, hs[3] = {0, 0, 0};
+        // (a thread per entry of the 12 x 12 blocks; the landmarks in slot order: the sums of the one-wavefront kernel)
+        double hr = 0, hs = 0;
+        const int ea = t < 144 ? t / 12 : 0, eb = t < 144 ? t % 12 : 0;
         for (int mb = 0; mb < n0; mb += 32) {
             const int cnt = (n0 - mb) < 32 ? (n0 - mb) : 32;
-            for (int e = t; e < cnt * 26; e += MT) Wk[e] = Jw[(size_t)mb * 26 + e];
+            for (int e = t; e < cnt * 26; e += MTF) Wk[e] = Jw[(size_t)mb * 26 + e];
             SYNC();
-            for (int m = 0; m < cnt; m++) {
-                const double *o = Wk + m * 26;
-                const double dmi = 1.0 / (o[12] * o[12] + o[25] * o[25]);
-#pragma unroll
-                for (int i = 0; i < 3; i++) {
-                    const int e = t + 64 * i;
-                    if (e < 144) {
-                        const int a = e / 12, b = e % 12;
-                        const double h = o[a] * o[b] + o[13 + a] * o[13 + b];
-                        const double ba = o[a] * o[12] + o[13 + a] * o[25], bb = o[b] * o[12] + o[13 + b] * o[25];
-                        hr[i] += h; hs[i] += h - ba * bb * dmi;
-                    }
+            if (t < 144) {
+                for (int m = 0; m < cnt; m++) {
+                    const double *o = Wk + m * 26;
+                    const double dmi = 1.0 / (o[12] * o[12] + o[25] * o[25]);
+                    const double h = o[ea] * o[eb] + o[13 + ea] * o[13 + eb];
+                    const double ba = o[ea] * o[12] + o[13 + ea] * o[25], bb = o[eb] * o[12] + o[13 + eb] * o[25];
+                    hr += h; hs += h - ba * bb * dmi;
                 }
             }
             SYNC();
         }
-#pragma unroll
-        for (int i = 0; i < 3; i++) { const int e = t + 64 * i; if (e < 144) { Lam[e] = hr[i]; M1[e] = hs[i]; } }
+        if (t < 144) { Lam[t] = hr; M1[t] = hs; }
     }
     SYNC();
+    if (t >= MT) return;                                    // the 12 x 12 algebra below: the first wavefront
     MSTAMP(1);
     // pose prior on T0 and relative-pose edge (0,1): unweighted Jacobians, info = S^T S
     if (t == 0) {

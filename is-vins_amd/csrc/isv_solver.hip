@@ -454,8 +454,26 @@ int isv_solver_enqueue(DevBatch &d, const SolverHost &hc, hipStream_t st, hipStr
         // k_front = {IMU factors | prior factors} of every window, k_lin_gram_chain = {k_lin_gram | chain half of the split solve}.
         const bool cs = d.lds_T && hc.chain_split;
         bool chain_done = false, rank1_done = false, dogleg_done = false;
-        if (cs) hipLaunchKernelGGL(k_front, dim3(d.B, 2), dim3(512), front_lds_bytes(d.N, d.n_prior_slots), st, d);
-        else {
+        // (what the visual part of this upload will run, needed here already: k_lin_gram_chain or not)
+        const bool fused = d.lds_T && d.fused_visual;
+        d.sw_global = (d.sw_part && hc.sw_global_ok && (d.B > 256 || hc.debug_sw_global)) ? 1 : 0;     // more than one workgroup per CU: trade LDS for occupancy
+        const int lgw = (fused && d.B <= n_cus && !hc.lg_batch_waves && lin_gram_lds_bytes(d.Nr, !d.sw_global, d.est_ex != 0, LG_WAVES_SMALL, d.lg_lcap) <= ISV_LDS_PER_CU) ? LG_WAVES_SMALL : LG_WAVES;
+        bool chain_on_side = false;
+        if (cs) {
+            hipLaunchKernelGGL(k_front, dim3(d.B, 2), dim3(512), front_lds_bytes(d.N, d.n_prior_slots), st, d);
+            if (!(fused && lgw == LG_WAVES_SMALL)) {
+                // an upload k_lin_gram_chain does not take (windows beyond the fused kernel's limits: BASELINE config 5's 30 000 factors):
+                // the chain half (~75 us at 20 frames) on the side stream beside the linearisation and the split elimination -- worth its
+                // fork / join events here (on the solve stream behind them it made the one-launch solve's 142 us into 75 + 75)
+                HCHK(hipEventRecord(fj[0], st)); HCHK(hipStreamWaitEvent(st2, fj[0], 0));
+                const size_t lds_sb = build_solve_sb_bytes(d.N, d.prior_H_sz);
+                if (d.N == 11 && !generic_n) hipLaunchKernelGGL((k_build_solve_sb<false, 11, 1>), dim3(d.B), dim3(512), lds_sb, st2, d);
+                else if (d.N <= 11) hipLaunchKernelGGL((k_build_solve_sb<false, 0, 1>), dim3(d.B), dim3(512), lds_sb, st2, d);
+                else hipLaunchKernelGGL((k_build_solve_sb<true, 0, 1>), dim3(d.B), dim3(512), lds_sb, st2, d);
+                HCHK(hipEventRecord(fj[1], st2));
+                chain_on_side = true; chain_done = true;
+            }
+        } else {
             HCHK(hipEventRecord(fj[0], st)); HCHK(hipStreamWaitEvent(st2, fj[0], 0));
             if (NI) {
                 hipLaunchKernelGGL(k_imu_raw, dim3((unsigned)(NI + 63) / 64), dim3(256), 0, st2, d, d.pose, d.sb, 1);
@@ -475,14 +493,11 @@ int isv_solver_enqueue(DevBatch &d, const SolverHost &hc, hipStream_t st, hipStr
         // routine as k_dogleg's first phase (same bits), which takes ~2.5 us for 300 landmarks against 6-8 us for the extra launch
         const bool bsub_split = split && d.lg_lcap > 1024;
         d.bs_split = bsub_split ? 1 : 0;
-        const bool fused = d.lds_T && d.fused_visual;
-        d.sw_global = (d.sw_part && hc.sw_global_ok && (d.B > 256 || hc.debug_sw_global)) ? 1 : 0;     // more than one workgroup per CU: trade LDS for occupancy
         PROF(slot, 0, 0);
         if (fused) {
             // linearisation fused with the Gram products: no Jacobian strip goes to HBM (isv_visual.hip)
             // (eight wavefronts per window while the batch leaves every window a CU of its own: 41 -> 27 us per launch for one window)
             const bool ex = d.est_ex != 0;
-            const int lgw = (d.B <= n_cus && !hc.lg_batch_waves && lin_gram_lds_bytes(d.Nr, !d.sw_global, ex, LG_WAVES_SMALL, d.lg_lcap) <= ISV_LDS_PER_CU) ? LG_WAVES_SMALL : LG_WAVES;
             const size_t lds_lg = lin_gram_lds_bytes(d.Nr, !d.sw_global, ex, lgw, d.lg_lcap);
             if (cs && lgw == LG_WAVES_SMALL) {
                 const size_t lds_sb = build_solve_sb_bytes(d.N, d.prior_H_sz), lds_r1c = (64 * (d.wd_ld + 4) + (size_t)d.max_lm * 3 + 2) * sizeof(double);
@@ -566,7 +581,7 @@ int isv_solver_enqueue(DevBatch &d, const SolverHost &hc, hipStream_t st, hipStr
             }
             PROF(slot, 2, 1);
         }
-        if (!cs) HCHK(hipStreamWaitEvent(st, fj[1], 0));
+        if (!cs || chain_on_side) HCHK(hipStreamWaitEvent(st, fj[1], 0));
         if (cs && !chain_done) {                          // (an upload k_lin_gram_chain does not take: the chain half alone; same bits)
             const size_t lds_sb = build_solve_sb_bytes(d.N, d.prior_H_sz);
             if (d.N == 11 && !generic_n) hipLaunchKernelGGL((k_build_solve_sb<false, 11, 1>), dim3(d.B), dim3(512), lds_sb, st, d);
@@ -664,7 +679,7 @@ int isv_solver_enqueue(DevBatch &d, const SolverHost &hc, hipStream_t st, hipStr
         hipLaunchKernelGGL(k_marg_jacobi<21>, dim3(d.B), dim3(256), 0, st, d);
         hipLaunchKernelGGL(k_marg_bwd<1>, dim3(d.B), dim3(64), 0, st, d);
     }
-    hipLaunchKernelGGL(k_marg_fwd, dim3(d.B), dim3(64), 0, st2, d);
+    hipLaunchKernelGGL(k_marg_fwd, dim3(d.B), dim3(256), 0, st2, d);      // (MTF: four wavefronts for the landmark phases)
     HCHK(hipEventRecord(fj[1], st2));
     HCHK(hipStreamWaitEvent(st, fj[1], 0));
     HCHK(hipGetLastError());
