@@ -3,6 +3,7 @@
 // No torch types, no allocation across the ABI.  There is NO CPU fallback: every entry point
 // fails with ISV_ERR_DEVICE when HIP is unavailable.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -114,12 +115,44 @@ static int create_impl(isv_backend *h) {
     TRY(halloc(h, &s.f_rec, F)); TRY(halloc(h, &s.pg_rec, F * 2)); TRY(halloc(h, &s.pg_pts, F * 2)); TRY(halloc(h, &s.pg_wstart, B * (ISV_SWEEP_WAVES + 1)));
     TRY(halloc(h, &s.margin_old, B)); TRY(halloc(h, &s.header0, B));
     TRY(halloc(h, &s.lm_meta, L));
+    TRY(halloc(h, &s.lm_optr, L + B)); TRY(halloc(h, &s.obs_raw, F * 3)); TRY(dalloc(h, &h->d_optr, L + B)); TRY(dalloc(h, &h->d_obs_raw, F * 3));
+    h->dev_build = getenv("ISV_HOST_PACK") == nullptr && upload_build_lds_bytes(c.n_frames, c.max_landmarks > 1 ? c.max_landmarks : 1) <= 64 * 1024;
     TRY(halloc(h, &s.se3, B)); TRY(halloc(h, &s.lin9, B)); TRY(halloc(h, &s.relpose, B * (c.n_vo - 1))); TRY(halloc(h, &s.rollpitch, B * (size_t)c.max_rollpitch));
     TRY(halloc(h, &s.st, B));
     TRY(halloc(h, &s.pose, B * N * 7)); TRY(halloc(h, &s.sb, B * N * 9)); TRY(halloc(h, &s.ex, B * 7)); TRY(halloc(h, &s.lam, L));
     TRY(halloc(h, &h->stage.st, B)); TRY(halloc(h, &h->stage.tc, B * ISV_MAX_TRACE)); TRY(halloc(h, &h->stage.tr, B * ISV_MAX_TRACE));
     TRY(halloc(h, &h->stage.ts, B * ISV_MAX_TRACE)); TRY(halloc(h, &h->stage.ta, B * ISV_MAX_TRACE)); TRY(halloc(h, &h->stage.marg, B));
     TRY(isv_solver_alloc(h->d, h->hc, B, L, F, h->allocs, h->err));
+    {
+        // (round 5) everything a RAW upload sends lives in ONE pinned block and ONE device block with the same layout, so that an upload
+        // is ONE host-to-device copy: on this GPU a copy command costs 20-50 us of stream time whatever its size (rocprofv3: 30 commands
+        // per upload, 0.7 ms of transfers inside 1.5 ms of stream time).  The arrays were allocated one by one above; they are re-pointed
+        // into the blocks and the originals are released.
+        struct Item { void **hp, **dp; size_t bytes, off; };
+        std::vector<Item> it;
+#define ARENA(hptr, dptr, cnt) it.push_back(Item{(void **)&(hptr), (void **)&(dptr), sizeof(*(hptr)) * (size_t)(cnt), 0})
+        ARENA(s.lm_off, d.lm_off, B + 1); ARENA(s.f_off, d.f_off, B + 1);
+        ARENA(s.Ps, d.Ps, B * N * 3); ARENA(s.Rs, d.Rs, B * N * 9); ARENA(s.Vs, d.Vs, B * N * 3); ARENA(s.Bas, d.Bas, B * N * 3); ARENA(s.Bgs, d.Bgs, B * N * 3);
+        ARENA(s.tic, d.tic, B * 3); ARENA(s.ric, d.ric, B * 9);
+        ARENA(s.se3, d.se3, B); ARENA(s.lin9, d.lin9, B); ARENA(s.relpose, d.relpose, B * (c.n_vo - 1)); ARENA(s.rollpitch, d.rollpitch, B * (size_t)c.max_rollpitch);
+        ARENA(s.n_rp, d.n_rp, B); ARENA(s.margin_old, d.margin_old, B); ARENA(s.header0, d.header0, B);
+        ARENA(s.imu_skip, d.imu_skip, NI); ARENA(s.imu_in, d.imu_in, NI * ISV_IMU_IN); ARENA(s.imu_cov, d.imu_cov, NI * 225);
+        ARENA(s.tile_win, d.tile_win, T); ARENA(s.tile_f0, d.tile_f0, T); ARENA(s.tile_n, d.tile_n, T);
+        ARENA(s.depth, d.depth, L); ARENA(s.lm_host, d.lm_host, L); ARENA(s.lm_optr, h->d_optr, L + B); ARENA(s.obs_raw, h->d_obs_raw, F * 3);
+#undef ARENA
+        size_t tot = 0;
+        for (Item &q : it) { q.off = tot; tot += (q.bytes + 255) / 256 * 256; }
+        void *hb = nullptr, *db = nullptr;
+        HIPCHK(h, hipHostMalloc(&hb, tot ? tot : 1, hipHostMallocDefault)); h->hallocs.push_back(hb);
+        HIPCHK(h, hipMalloc(&db, tot ? tot : 1)); h->allocs.push_back(db);
+        HIPCHK(h, hipMemset(db, 0, tot ? tot : 1)); memset(hb, 0, tot ? tot : 1);
+        auto drop = [](std::vector<void *> &v, void *p, bool host) { for (size_t i = 0; i < v.size(); i++) if (v[i] == p) { if (host) (void)hipHostFree(p); else (void)hipFree(p); v.erase(v.begin() + i); return; } };
+        for (Item &q : it) {
+            drop(h->hallocs, *q.hp, true); drop(h->allocs, *q.dp, false);
+            *q.hp = (char *)hb + q.off; *q.dp = (char *)db + q.off;
+        }
+        h->arena_h = hb; h->arena_d = db; h->arena_bytes = tot;
+    }
     if (d.est_ex) {
         if (!d.lds_T) { h->err = "estimate_extrinsic = 1 is built for the LDS solver path only (ALL_BUF_SIZE <= 19)"; return ISV_ERR_UNSUPPORTED; }
         const size_t NPr = (size_t)c.n_frames * (c.n_frames - 1) / 2;
@@ -154,7 +187,7 @@ static bool finite_all(const double *p, size_t n) {
 }
 
 // pack one caller window into its slice of the pinned staging area (offsets fixed by the caller's first pass)
-static int pack_window(isv_backend *h, int b, const isv_window_t *w, size_t L, size_t F, size_t T, std::string &err) {
+static int pack_window(isv_backend *h, int b, const isv_window_t *w, size_t L, size_t F, size_t T, std::string &err, const bool raw = false, const bool want_tiles = true) {
     const isv_config_t &c = h->cfg;
     const int N = c.n_frames, Nd = h->d.N;        // real frames; device frames (+ the extrinsic's pseudo-frame)
     auto &s = h->h;
@@ -176,6 +209,21 @@ static int pack_window(isv_backend *h, int b, const isv_window_t *w, size_t L, s
         !finite_all(w->pose_prior->t, 3 + 9 + 36) || !finite_all(w->vb_prior->VB, 9 + 81)) { err = "non-finite input"; return ISV_ERR_NONFINITE; }
     for (int i = 0; i < c.n_vo - 1; i++) if (!finite_all(w->relpose[i].delta_t, 3 + 9 + 36)) { err = "non-finite relative-pose prior"; return ISV_ERR_NONFINITE; }
     for (int i = 0; i < w->n_rollpitch; i++) if (!finite_all(w->rollpitch[i].R, 9 + 4)) { err = "non-finite roll/pitch prior"; return ISV_ERR_NONFINITE; }
+    if (raw) {
+        // (round 5) the window goes up as it is -- start frames, observation offsets, points, depths -- and k_upload_build derives the
+        // solver's view (landmark / factor records, pair groups, schedule, factor stream) on the device
+        const int Lw = w->n_landmarks, p0 = Lw > 0 ? w->lm_obs_ptr[0] : 0, nobs = Lw > 0 ? w->lm_obs_ptr[Lw] - p0 : 0;     // (a landmark's observations are [ptr[l], ptr[l + 1]))
+        if (Lw > 0 && (size_t)(w->lm_obs_ptr[Lw - 1] - p0 - (Lw - 1)) > 65535) { err = "more than 65535 factors in one window"; return ISV_ERR_CAPACITY; }
+        if (Lw > 0) {
+            memcpy(s.lm_host + L, w->lm_start_frame, sizeof(int32_t) * Lw);
+            memcpy(s.depth + L, w->lm_depth, sizeof(double) * Lw);
+            memcpy(s.obs_raw + (F + L) * 3, w->obs_point + (size_t)p0 * 3, sizeof(double) * 3 * (size_t)nobs);
+        }
+        int32_t *op = s.lm_optr + L + b;
+        for (int l = 0; l <= Lw; l++) op[l] = Lw > 0 ? w->lm_obs_ptr[l] - p0 : 0;
+        for (int l = 0; l < Lw; l++) s.lm_k[L + l] = op[l + 1] - op[l];        // (the tiles below; the device derives its own)
+        F += (size_t)(nobs - Lw); L += (size_t)Lw;
+    } else
     for (int l = 0; l < w->n_landmarks; l++) {
         const int hst = w->lm_start_frame[l], o0 = w->lm_obs_ptr[l], k = w->lm_obs_ptr[l + 1] - o0;
         s.lm_host[L] = hst; s.lm_k[L] = k; s.lm_f0[L] = (int32_t)F;
@@ -193,7 +241,7 @@ static int pack_window(isv_backend *h, int b, const isv_window_t *w, size_t L, s
     }
     // tiles of <= 64 consecutive factors made of WHOLE landmarks (the linearise kernel reduces a
     // landmark's factors inside one wavefront); window_tiles() below counts them the same way
-    {
+    if (want_tiles) {
         size_t tf0 = f_off, tn = 0;
         for (size_t l = lm_off; l < L; l++) {
             const size_t kf = (size_t)s.lm_k[l] - 1;
@@ -203,7 +251,7 @@ static int pack_window(isv_backend *h, int b, const isv_window_t *w, size_t L, s
         if (tn) { s.tile_win[T] = b; s.tile_f0[T] = (int32_t)tf0; s.tile_n[T] = (int32_t)tn; T++; }
     }
     // factors sorted by (host, observer) pair for the MFMA sweep: counting sort, stable in landmark order
-    {
+    if (!raw) {
         const int NP = N * (N - 1) / 2;
         int32_t *off = s.pg_off + (size_t)b * (NP + 1);
         auto pidx = [N](int hh, int jj) { return hh * N - hh * (hh + 1) / 2 + (jj - hh - 1); };
@@ -301,6 +349,33 @@ static int host_threads(int n) {
     return k < 1 ? 1 : k;
 }
 
+// isv_batch_optimize starts from the state that was uploaded: twelve small device-to-device copies, as ONE kernel (a
+// hipMemcpyAsync each costs ~5 us of stream time at these sizes: 60 us of every 1024-window step)
+struct RestoreJobs { uint64_t *dst[12]; const uint64_t *src[12]; size_t n8[12]; };     // 8-byte words: every buffer holds doubles
+__global__ __launch_bounds__(256) void k_restore(RestoreJobs j) {
+    const int job = blockIdx.y;
+    uint64_t *dst = j.dst[job]; const uint64_t *src = j.src[job];
+    const size_t n = j.n8[job];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+// (save = true: the other direction, at the end of isv_batch_upload -- the twelve hipMemcpyAsync it replaced cost ~0.2 ms of stream time)
+static int restore_initial(isv_backend *h, bool save = false) {
+    DevBatch &d = h->d; const isv_config_t &c = h->cfg; hipStream_t st = h->stream;
+    const size_t n = d.B, N = d.N, L = d.Ltot;
+    RestoreJobs j;
+    int k = 0;
+#define RJOB(dstp, srcp, cnt) do { static_assert(sizeof(*(srcp)) % 8 == 0, "8-byte words"); j.dst[k] = (uint64_t *)(dstp); j.src[k] = (const uint64_t *)(srcp); j.n8[k] = sizeof(*(srcp)) / 8 * (size_t)(cnt); k++; } while (0)
+    RJOB(d.Ps, h->Ps0, n * N * 3); RJOB(d.Rs, h->Rs0, n * N * 9); RJOB(d.Vs, h->Vs0, n * N * 3);
+    RJOB(d.Bas, h->Bas0, n * N * 3); RJOB(d.Bgs, h->Bgs0, n * N * 3); RJOB(d.depth, h->depth0, L);
+    RJOB(d.tic, h->tic0, n * 3); RJOB(d.ric, h->ric0, n * 9);
+    RJOB(d.se3, h->se30, n); RJOB(d.lin9, h->lin90, n); RJOB(d.relpose, h->relpose0, n * (c.n_vo - 1)); RJOB(d.rollpitch, h->rollpitch0, n * c.max_rollpitch);
+#undef RJOB
+    if (save) for (int q = 0; q < k; q++) { uint64_t *t_ = j.dst[q]; j.dst[q] = (uint64_t *)j.src[q]; j.src[q] = t_; }
+    hipLaunchKernelGGL(k_restore, dim3(64, 12), dim3(256), 0, st, j);
+    HIPCHK(h, hipGetLastError());
+    return ISV_OK;
+}
+
 // pack n caller windows into the pinned staging area and copy them to the device.  Pass 1 (serial) validates the
 // tracks and fixes every window's landmark / factor / tile offsets; pass 2 packs the windows on host threads.
 extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const *ws) {
@@ -313,36 +388,65 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
     auto &s = h->h;
     size_t L = 0, F = 0, T = 0, Fmax = 0, Lmax = 0;
     std::vector<size_t> t_off((size_t)n + 1);
-    for (int b = 0; b < n; b++) {
+    const bool raw = h->dev_build;
+    DevBatch &d = h->d;
+    hipStream_t st = h->stream;
+    const size_t NIw = (size_t)(Nd - 1);
+    // ONE team of host threads, three phases (round 5; the counting pass used to run on the calling thread alone: 0.7 of the 2.0 ms):
+    //   1. every thread validates its windows' tracks and counts their landmarks / factors / tiles;
+    //   2. thread 0 turns the counts into the windows' offsets (a prefix sum over n windows);
+    //   3. every thread packs its windows into the pinned staging area.
+    struct Cnt { int32_t L, F, T; int rc; };
+    std::vector<Cnt> cnt((size_t)n);
+    auto count_window = [&](int b) -> int {
         const isv_window_t *w = ws[b];
         if (!w || !w->Ps || !w->Rs || !w->Vs || !w->Bas || !w->Bgs || !w->tic || !w->ric || !w->imu || !w->pose_prior ||
             !w->vb_prior || !w->relpose || (w->n_rollpitch > 0 && !w->rollpitch) || w->n_landmarks < 0 ||
             (w->n_landmarks > 0 && (!w->lm_start_frame || !w->lm_obs_ptr || !w->obs_point || !w->lm_depth)))
             return ISV_ERR_INVALID_ARG;
-        if (w->n_landmarks > c.max_landmarks || w->n_obs > c.max_obs || w->n_rollpitch > c.max_rollpitch) { h->err = "window exceeds capacity"; return ISV_ERR_CAPACITY; }
+        if (w->n_landmarks > c.max_landmarks || w->n_obs > c.max_obs || w->n_rollpitch > c.max_rollpitch) return ISV_ERR_CAPACITY;
         for (int i = 0; i < w->n_rollpitch; i++) if (w->rollpitch[i].index < 0 || w->rollpitch[i].index >= N) return ISV_ERR_INVALID_ARG;
-        s.lm_off[b] = (int32_t)L; s.f_off[b] = (int32_t)F; t_off[b] = T;
-        size_t tn = 0;
+        size_t tn = 0, Tw = 0, Fw = 0;
         for (int l = 0; l < w->n_landmarks; l++) {
             const int hst = w->lm_start_frame[l], o0 = w->lm_obs_ptr[l], k = w->lm_obs_ptr[l + 1] - o0;
-            if (hst < 0 || k < 2 || hst + k > N || o0 < 0 || o0 + k > w->n_obs) { h->err = "bad landmark track"; return ISV_ERR_INVALID_ARG; }
-            if (tn + (size_t)(k - 1) > ISV_TILE) { T++; tn = 0; }
+            if (hst < 0 || k < 2 || hst + k > N || o0 < 0 || o0 + k > w->n_obs) return -1000;      // "bad landmark track"
+            if (tn + (size_t)(k - 1) > ISV_TILE) { Tw++; tn = 0; }
             tn += (size_t)(k - 1);
-            F += (size_t)(k - 1);
+            Fw += (size_t)(k - 1);
         }
-        if (tn) T++;
-        L += (size_t)w->n_landmarks;
-        if (F - (size_t)s.f_off[b] > Fmax) Fmax = F - (size_t)s.f_off[b];
-        if ((size_t)w->n_landmarks > Lmax) Lmax = (size_t)w->n_landmarks;
-    }
-    t_off[n] = T;
+        if (tn) Tw++;
+        cnt[b].L = w->n_landmarks; cnt[b].F = (int32_t)Fw; cnt[b].T = (int32_t)Tw;
+        return ISV_OK;
+    };
     {
         const int K = host_threads(n);
         std::vector<int> rcs((size_t)K, ISV_OK);
         std::vector<std::string> errs((size_t)K);
+        std::atomic<int> counted{0}, offsets_ready{0};
         auto work = [&](int k) {
-            for (int b = (int)((int64_t)n * k / K), e = (int)((int64_t)n * (k + 1) / K); b < e; b++) {
-                const int rc = pack_window(h, b, ws[b], (size_t)s.lm_off[b], (size_t)s.f_off[b], t_off[b], errs[k]);
+            const int b0 = (int)((int64_t)n * k / K), b1 = (int)((int64_t)n * (k + 1) / K);
+            for (int b = b0; b < b1 && rcs[k] == ISV_OK; b++) rcs[k] = count_window(b);
+            counted.fetch_add(1, std::memory_order_release);
+            if (k == 0) {
+                while (counted.load(std::memory_order_acquire) < K) std::this_thread::yield();
+                bool ok = true;
+                for (int q = 0; q < K; q++) ok &= rcs[q] == ISV_OK;
+                if (ok) {
+                    for (int b = 0; b < n; b++) {
+                        s.lm_off[b] = (int32_t)L; s.f_off[b] = (int32_t)F; t_off[b] = T;
+                        L += (size_t)cnt[b].L; F += (size_t)cnt[b].F; T += (size_t)cnt[b].T;
+                        if ((size_t)cnt[b].F > Fmax) Fmax = (size_t)cnt[b].F;
+                        if ((size_t)cnt[b].L > Lmax) Lmax = (size_t)cnt[b].L;
+                    }
+                    t_off[n] = T; s.lm_off[n] = (int32_t)L; s.f_off[n] = (int32_t)F;
+                }
+                offsets_ready.store(ok ? 1 : -1, std::memory_order_release);
+            }
+            int ready;
+            while ((ready = offsets_ready.load(std::memory_order_acquire)) == 0) std::this_thread::yield();
+            if (ready < 0) return;
+            for (int b = b0; b < b1; b++) {
+                const int rc = pack_window(h, b, ws[b], (size_t)s.lm_off[b], (size_t)s.f_off[b], t_off[b], errs[k], raw, true);
                 if (rc != ISV_OK) { rcs[k] = rc; return; }
             }
         };
@@ -353,11 +457,33 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
             work(0);
             for (auto &t : th) t.join();
         }
-        for (int k = 0; k < K; k++) if (rcs[k] != ISV_OK) { if (!errs[k].empty()) h->err = errs[k]; return rcs[k]; }
+        for (int k = 0; k < K; k++) if (rcs[k] != ISV_OK) {
+            if (rcs[k] == -1000) { h->err = "bad landmark track"; return ISV_ERR_INVALID_ARG; }
+            if (rcs[k] == ISV_ERR_CAPACITY && errs[k].empty()) h->err = "window exceeds capacity"; else if (!errs[k].empty()) h->err = errs[k];
+            return rcs[k];
+        }
     }
-    s.lm_off[n] = (int32_t)L; s.f_off[n] = (int32_t)F;
+    // the copies of a raw upload when the one-block copy below does not pay (a batch far below the handle's capacity): array by array
+    auto enqueue_arrays = [&](int b0, int b1) -> int {
+#define H2DC(dst, src, off, cnt) do { if ((cnt) > 0 && hipMemcpyAsync((dst) + (off), (src) + (off), sizeof(*(src)) * (size_t)(cnt), hipMemcpyHostToDevice, st) != hipSuccess) return ISV_ERR_DEVICE; } while (0)
+        const size_t nb = (size_t)(b1 - b0), l0 = (size_t)s.lm_off[b0], l1 = (size_t)s.lm_off[b1], f0 = (size_t)s.f_off[b0], f1 = (size_t)s.f_off[b1];
+        H2DC(d.Ps, s.Ps, (size_t)b0 * Nd * 3, nb * Nd * 3); H2DC(d.Rs, s.Rs, (size_t)b0 * Nd * 9, nb * Nd * 9); H2DC(d.Vs, s.Vs, (size_t)b0 * Nd * 3, nb * Nd * 3);
+        H2DC(d.Bas, s.Bas, (size_t)b0 * Nd * 3, nb * Nd * 3); H2DC(d.Bgs, s.Bgs, (size_t)b0 * Nd * 3, nb * Nd * 3);
+        H2DC(d.tic, s.tic, (size_t)b0 * 3, nb * 3); H2DC(d.ric, s.ric, (size_t)b0 * 9, nb * 9);
+        H2DC(d.depth, s.depth, l0, l1 - l0); H2DC(d.lm_host, s.lm_host, l0, l1 - l0);
+        H2DC(h->d_optr, s.lm_optr, l0 + b0, (l1 - l0) + nb); H2DC(h->d_obs_raw, s.obs_raw, (f0 + l0) * 3, ((f1 + l1) - (f0 + l0)) * 3);
+        H2DC(d.imu_in, s.imu_in, (size_t)b0 * NIw * ISV_IMU_IN, nb * NIw * ISV_IMU_IN); H2DC(d.imu_cov, s.imu_cov, (size_t)b0 * NIw * 225, nb * NIw * 225);
+        H2DC(d.imu_skip, s.imu_skip, (size_t)b0 * NIw, nb * NIw);
+        H2DC(d.se3, s.se3, (size_t)b0, nb); H2DC(d.lin9, s.lin9, (size_t)b0, nb); H2DC(d.relpose, s.relpose, (size_t)b0 * (c.n_vo - 1), nb * (c.n_vo - 1));
+        H2DC(d.rollpitch, s.rollpitch, (size_t)b0 * c.max_rollpitch, nb * c.max_rollpitch);
+        H2DC(d.n_rp, s.n_rp, (size_t)b0, nb); H2DC(d.margin_old, s.margin_old, (size_t)b0, nb); H2DC(d.header0, s.header0, (size_t)b0, nb);
+        // (the tiles of k_proj_linearize: the linearise API reads them whatever the solver runs; built on the host, a counting loop)
+        H2DC(d.tile_win, s.tile_win, t_off[b0], t_off[b1] - t_off[b0]); H2DC(d.tile_f0, s.tile_f0, t_off[b0], t_off[b1] - t_off[b0]); H2DC(d.tile_n, s.tile_n, t_off[b0], t_off[b1] - t_off[b0]);
+        H2DC(d.lm_off, s.lm_off, 0, (size_t)n + 1); H2DC(d.f_off, s.f_off, 0, (size_t)n + 1);
+#undef H2DC
+        return ISV_OK;
+    };
     const auto t_packed = std::chrono::steady_clock::now();
-    DevBatch &d = h->d;
     d.B = n; d.Ltot = (int32_t)L; d.Ftot = (int32_t)F; d.n_tiles = (int32_t)T;
     d.seq_hdr = nullptr;                       // (the upload path: every window of the batch is solved)
     // k_lin_gram takes one window per workgroup: right for windows of ordinary length, whatever the handle's capacity is
@@ -372,13 +498,44 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
     const bool lg_fits = lin_gram_lds_bytes(c.n_frames, true, c.estimate_extrinsic != 0, LG_WAVES, d.lg_lcap) <= ISV_LDS_PER_CU;
     if (c.estimate_extrinsic && !lg_fits) { h->err = "estimate_extrinsic = 1: a window has more landmarks than k_lin_gram<true> can stage in LDS"; return ISV_ERR_CAPACITY; }
     d.fused_visual = (c.estimate_extrinsic || !(h->hc.legacy_visual || Fmax > ISV_FUSED_MAX_FACTORS || !lg_fits)) ? 1 : 0;
-    hipStream_t st = h->stream;
 #define H2D(dst, src, cnt) HIPCHK(h, hipMemcpyAsync(dst, src, sizeof(*(src)) * (size_t)(cnt), hipMemcpyHostToDevice, st))
     const size_t NI = (size_t)n * (Nd - 1);
+    if (raw) {
+        // the raw CSR goes up (69 KB per benchmark window against 110 KB of derived arrays) and the device derives the rest.  ONE copy of
+        // the whole block while the batch uses most of it (or the block is small: a window or two); array by array otherwise.
+        const size_t used = (F + L) * 24 + L * 16 + (size_t)n * ((size_t)Nd * 21 * 8 + NIw * (289 * 8 + 4) + sizeof(isv_se3_prior_t) + sizeof(isv_linear9_t) +
+                            (size_t)(c.n_vo - 1) * sizeof(isv_relpose_t) + (size_t)c.max_rollpitch * sizeof(isv_rollpitch_t));
+        if (h->arena_bytes <= ((size_t)16 << 20) || used * 10 >= h->arena_bytes * 6) HIPCHK(h, hipMemcpyAsync(h->arena_d, h->arena_h, h->arena_bytes, hipMemcpyHostToDevice, st));
+        else if (enqueue_arrays(0, n) != ISV_OK) { h->err = "isv_batch_upload: host-to-device copy failed"; return ISV_ERR_DEVICE; }
+        if (isv_upload_build_enqueue(d, h->d_optr, h->d_obs_raw, c.max_landmarks > 1 ? c.max_landmarks : 1, st) != ISV_OK) { h->err = "k_upload_build launch failed"; return ISV_ERR_DEVICE; }
+        if (getenv("ISV_DEBUG_UPLOAD_CHECK")) {
+            // test hook: pack the same windows on the host as well and compare EVERY derived array with what the device built
+            HIPCHK(h, hipStreamSynchronize(st));
+            for (int b = 0; b < n; b++) { std::string e2; (void)pack_window(h, b, ws[b], (size_t)s.lm_off[b], (size_t)s.f_off[b], t_off[b], e2, false, true); }
+            const size_t NPp = (size_t)N * (N - 1) / 2;
+            int bad = 0;
+            auto cmp = [&](const char *name, const void *host, const void *dev, size_t bytes) {
+                std::vector<unsigned char> tmp(bytes ? bytes : 1);
+                if (hipMemcpy(tmp.data(), dev, bytes, hipMemcpyDeviceToHost) != hipSuccess) { fprintf(stderr, "isv upload check: %s: copy failed\n", name); bad++; return; }
+                if (memcmp(tmp.data(), host, bytes) != 0) {
+                    size_t k = 0; while (k < bytes && tmp[k] == ((const unsigned char *)host)[k]) k++;
+                    fprintf(stderr, "isv upload check: %s differs at byte %zu of %zu\n", name, k, bytes); bad++;
+                }
+            };
+            cmp("lm_k", s.lm_k, d.lm_k, L * 4); cmp("lm_f0", s.lm_f0, d.lm_f0, L * 4); cmp("lm_meta", s.lm_meta, d.lm_meta, L * 4); cmp("lm_pts_i", s.lm_pts_i, d.lm_pts_i, L * 24);
+            cmp("f_rec", s.f_rec, d.f_rec, F * sizeof(FactorRec)); cmp("f_pts_j", s.f_pts_j, d.f_pts_j, F * 16); cmp("f_pts_z", s.f_pts_z, d.f_pts_z, F * 8);
+            cmp("pg_perm", s.pg_perm, d.pg_perm, F * 4); cmp("pg_off", s.pg_off, d.pg_off, (size_t)n * (NPp + 1) * 4); cmp("pg_sched", s.pg_sched, d.pg_sched, (size_t)n * NPp * 4);
+            cmp("pg_sched_off", s.pg_sched_off, d.pg_sched_off, (size_t)n * (ISV_SWEEP_WAVES + 1) * 4); cmp("pg_wstart", s.pg_wstart, d.pg_wstart, (size_t)n * (ISV_SWEEP_WAVES + 1) * 4);
+            cmp("pg_rec", s.pg_rec, d.pg_rec, F * 8); cmp("pg_pts", s.pg_pts, d.pg_pts, F * 16);
+            if (bad) { h->err = "ISV_DEBUG_UPLOAD_CHECK: the device-built arrays differ from the host packer's"; return ISV_ERR_DEVICE; }
+        }
+    } else {
+    H2D(d.lm_off, s.lm_off, n + 1); H2D(d.f_off, s.f_off, n + 1);
     H2D(d.Ps, s.Ps, (size_t)n * Nd * 3); H2D(d.Rs, s.Rs, (size_t)n * Nd * 9); H2D(d.Vs, s.Vs, (size_t)n * Nd * 3);
     H2D(d.Bas, s.Bas, (size_t)n * Nd * 3); H2D(d.Bgs, s.Bgs, (size_t)n * Nd * 3); H2D(d.tic, s.tic, (size_t)n * 3); H2D(d.ric, s.ric, (size_t)n * 9);
-    H2D(d.depth, s.depth, L); H2D(d.lm_off, s.lm_off, n + 1); H2D(d.f_off, s.f_off, n + 1);
-    H2D(d.lm_host, s.lm_host, L); H2D(d.lm_k, s.lm_k, L); H2D(d.lm_f0, s.lm_f0, L); H2D(d.lm_pts_i, s.lm_pts_i, L * 3);
+    H2D(d.depth, s.depth, L);
+    H2D(d.lm_host, s.lm_host, L);
+    H2D(d.lm_k, s.lm_k, L); H2D(d.lm_f0, s.lm_f0, L); H2D(d.lm_pts_i, s.lm_pts_i, L * 3);
     H2D(d.f_rec, s.f_rec, F); H2D(d.f_pts_j, s.f_pts_j, F * 2); H2D(d.f_pts_z, s.f_pts_z, F);
     H2D(d.lm_meta, s.lm_meta, L);
     H2D(d.tile_win, s.tile_win, T); H2D(d.tile_f0, s.tile_f0, T); H2D(d.tile_n, s.tile_n, T);
@@ -388,12 +545,9 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
     H2D(d.imu_in, s.imu_in, NI * ISV_IMU_IN); H2D(d.imu_cov, s.imu_cov, NI * 225); H2D(d.imu_skip, s.imu_skip, NI);
     H2D(d.se3, s.se3, n); H2D(d.lin9, s.lin9, n); H2D(d.relpose, s.relpose, (size_t)n * (c.n_vo - 1)); H2D(d.rollpitch, s.rollpitch, (size_t)n * c.max_rollpitch);
     H2D(d.n_rp, s.n_rp, n); H2D(d.margin_old, s.margin_old, n); H2D(d.header0, s.header0, n);
+    }
 #undef H2D
-#define D2D(dst, src, cnt) HIPCHK(h, hipMemcpyAsync(dst, src, sizeof(*(src)) * (size_t)(cnt), hipMemcpyDeviceToDevice, st))
-    D2D(h->Ps0, d.Ps, (size_t)n * Nd * 3); D2D(h->Rs0, d.Rs, (size_t)n * Nd * 9); D2D(h->Vs0, d.Vs, (size_t)n * Nd * 3);
-    D2D(h->Bas0, d.Bas, (size_t)n * Nd * 3); D2D(h->Bgs0, d.Bgs, (size_t)n * Nd * 3); D2D(h->depth0, d.depth, L);
-    D2D(h->tic0, d.tic, (size_t)n * 3); D2D(h->ric0, d.ric, (size_t)n * 9);
-    D2D(h->se30, d.se3, n); D2D(h->lin90, d.lin9, n); D2D(h->relpose0, d.relpose, (size_t)n * (c.n_vo - 1)); D2D(h->rollpitch0, d.rollpitch, (size_t)n * c.max_rollpitch);
+    TRY(restore_initial(h, true));              // the pristine copies isv_batch_optimize starts from
     // IMU sqrt_info once per upload (the covariances do not change during a solve)
     if (NI) hipLaunchKernelGGL(k_imu_prep, dim3((unsigned)NI), dim3(64), 0, st, d, (const int32_t *)nullptr);
     HIPCHK(h, hipGetLastError());
@@ -404,31 +558,6 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
         fprintf(stderr, "isv upload: n=%d pack %.2f ms, enqueue copies %.2f ms, wait %.2f ms\n", n, ms(t_up0, t_packed), ms(t_packed, t_enq), ms(t_enq, std::chrono::steady_clock::now()));
     }
     h->resident = n;
-    return ISV_OK;
-}
-
-// isv_batch_optimize starts from the state that was uploaded: twelve small device-to-device copies, as ONE kernel (a
-// hipMemcpyAsync each costs ~5 us of stream time at these sizes: 60 us of every 1024-window step)
-struct RestoreJobs { uint64_t *dst[12]; const uint64_t *src[12]; size_t n8[12]; };     // 8-byte words: every buffer holds doubles
-__global__ __launch_bounds__(256) void k_restore(RestoreJobs j) {
-    const int job = blockIdx.y;
-    uint64_t *dst = j.dst[job]; const uint64_t *src = j.src[job];
-    const size_t n = j.n8[job];
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
-}
-static int restore_initial(isv_backend *h) {
-    DevBatch &d = h->d; const isv_config_t &c = h->cfg; hipStream_t st = h->stream;
-    const size_t n = d.B, N = d.N, L = d.Ltot;
-    RestoreJobs j;
-    int k = 0;
-#define RJOB(dstp, srcp, cnt) do { static_assert(sizeof(*(srcp)) % 8 == 0, "8-byte words"); j.dst[k] = (uint64_t *)(dstp); j.src[k] = (const uint64_t *)(srcp); j.n8[k] = sizeof(*(srcp)) / 8 * (size_t)(cnt); k++; } while (0)
-    RJOB(d.Ps, h->Ps0, n * N * 3); RJOB(d.Rs, h->Rs0, n * N * 9); RJOB(d.Vs, h->Vs0, n * N * 3);
-    RJOB(d.Bas, h->Bas0, n * N * 3); RJOB(d.Bgs, h->Bgs0, n * N * 3); RJOB(d.depth, h->depth0, L);
-    RJOB(d.tic, h->tic0, n * 3); RJOB(d.ric, h->ric0, n * 9);
-    RJOB(d.se3, h->se30, n); RJOB(d.lin9, h->lin90, n); RJOB(d.relpose, h->relpose0, n * (c.n_vo - 1)); RJOB(d.rollpitch, h->rollpitch0, n * c.max_rollpitch);
-#undef RJOB
-    hipLaunchKernelGGL(k_restore, dim3(64, 12), dim3(256), 0, st, j);
-    HIPCHK(h, hipGetLastError());
     return ISV_OK;
 }
 
@@ -711,7 +840,7 @@ extern "C" int isv_backend_solve_odometry_batch(isv_backend_t *h, int32_t n, isv
     if (d.Ltot) {
         hipLaunchKernelGGL(k_triangulate, dim3((d.Ltot + 63) / 64), dim3(64), 0, st, d);
         HIPCHK(h, hipGetLastError());
-        D2D(h->depth0, d.depth, (size_t)d.Ltot);        // isv_batch_optimize restores the state from the *0 copies
+        HIPCHK(h, hipMemcpyAsync(h->depth0, d.depth, sizeof(double) * (size_t)d.Ltot, hipMemcpyDeviceToDevice, st));        // isv_batch_optimize restores the state from the *0 copies
     }
     TRY(isv_batch_optimize(h, 1));
     const auto t2 = std::chrono::steady_clock::now();

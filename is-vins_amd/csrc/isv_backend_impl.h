@@ -36,6 +36,7 @@ struct isv_backend {
         int32_t *lm_off, *f_off, *lm_host, *lm_k, *lm_f0, *tile_win, *tile_f0, *tile_n, *imu_skip, *n_rp, *solve_flag, *pg_perm, *pg_off, *pg_sched, *pg_sched_off;
         FactorRec *f_rec;
         int32_t *pg_rec, *pg_wstart; double *pg_pts;
+        int32_t *lm_optr; double *obs_raw;       // raw CSR of the upload (round 5: the derived arrays are built on the device)
         uint32_t *lm_meta; int32_t *margin_old; double *header0;
         isv_se3_prior_t *se3; isv_linear9_t *lin9; isv_relpose_t *relpose; isv_rollpitch_t *rollpitch;
         SolveState *st;
@@ -46,6 +47,9 @@ struct isv_backend {
     // pristine copies for isv_batch_optimize restore
     double *Ps0 = nullptr, *Rs0 = nullptr, *Vs0 = nullptr, *Bas0 = nullptr, *Bgs0 = nullptr, *depth0 = nullptr, *tic0 = nullptr, *ric0 = nullptr;
     isv_se3_prior_t *se30 = nullptr; isv_linear9_t *lin90 = nullptr; isv_relpose_t *relpose0 = nullptr; isv_rollpitch_t *rollpitch0 = nullptr;
+    void *arena_h = nullptr, *arena_d = nullptr; size_t arena_bytes = 0;      // the raw upload's arrays, one pinned and one device block of the same layout (one copy per upload)
+    int32_t *d_optr = nullptr; double *d_obs_raw = nullptr;     // device copies of the raw CSR (isv_batch_upload -> k_upload_build)
+    bool dev_build = false;       // this handle derives the solver's view of an upload on the device (ISV_HOST_PACK=1: the host packer, for A/B and the bitwise test)
     int resident = 0;
     int device = 0;               // the HIP device the handle was created on; every entry point re-selects it
     double *init_scratch = nullptr, *init_kld = nullptr;   // initFactorGraph scratch, allocated on first use and kept

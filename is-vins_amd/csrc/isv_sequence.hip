@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include "isv_backend_impl.h"
 
 #define ISV_SEQ_RING 32                 // observation ring of a track (>= ISV_MAX_FRAMES, power of two)
@@ -308,14 +309,119 @@ __global__ __launch_bounds__(256) void k_seq_append(DevBatch d, SeqDev s) {
     if (t == 0) s.n_tracks[w] = T0 + s_new;
 }
 
+// The (host, observer) pair groups of a window's factors (stable counting sort in landmark order), the longest-first schedule of the
+// groups over the sweep wavefronts and the factor stream of k_lin_gram -- what pack_window builds on the host (isv_backend.hip), from
+// the landmark table pass A of the calling kernel left in LDS (sMeta[l] = host | k << 8, sF0[l] = first factor, window-relative).
+// Shared by k_seq_build (device-resident sequences) and k_upload_build (isv_batch_upload, round 5).  host_end: landmarks are hosted in
+// frames < host_end (Nvo for goodFeature() landmarks, N for a caller's window).
+__device__ __forceinline__ void build_pairs_stream(const DevBatch &d, const int w, const int t, const int Lw, const int Fw, const int F0, const int host_end, const int lcap, int *ldsi) {
+    const int N = d.Nr, NP = N * (N - 1) / 2;
+    unsigned *sMeta = (unsigned *)ldsi;
+    int *sF0 = ldsi + lcap, *sSize = sF0 + lcap, *sOff = sSize + NP + 1, *sOrder = sOff + NP + 1, *sBase = sOrder + NP + 1, *sWave = sBase + NP + 1;
+    // ---- pass C: factors sorted by (host, observer) pair, stable in landmark order.  A landmark has at most one factor
+    //      per pair, so the rank of its factor inside the pair group is the number of EARLIER landmarks in the group:
+    //      one thread walks the landmark list per pair (count, then fill) ----
+    // (round 4: the landmark list in four QUARTERS per pair -- item (pair, quarter) counts / fills its quarter in order, a quarter's
+    //  first rank is the pair's offset plus the earlier quarters' counts: the same stable order with four times the threads; the
+    //  55 one-thread walks over ~280 landmarks were 37 of the kernel's 175 us)
+    int *sCnt = sWave + NP + 1;                    // [4][NP + 1]
+    for (int p = t; p <= NP; p += 256) sSize[p] = 0;
+    auto pair_of = [N](int p, int &hh, int &jj) { hh = 0; int rem = p; while (rem >= N - 1 - hh) { rem -= N - 1 - hh; hh++; } jj = hh + 1 + rem; };
+    for (int it = t; it < 4 * NP; it += 256) {
+        const int qtr = it / NP, p = it - qtr * NP;
+        int hh, jj; pair_of(p, hh, jj);
+        int c = 0;
+        if (hh < host_end) for (int l = Lw * qtr / 4, le = Lw * (qtr + 1) / 4; l < le; l++) { const unsigned m0 = sMeta[l]; const int h = (int)(m0 & 255), k = (int)(m0 >> 8); c += (h == hh && h + k > jj) ? 1 : 0; }
+        sCnt[qtr * (NP + 1) + p] = c;
+    }
+    __syncthreads();
+    for (int p = t; p < NP; p += 256) sSize[p] = sCnt[p] + sCnt[(NP + 1) + p] + sCnt[2 * (NP + 1) + p] + sCnt[3 * (NP + 1) + p];
+    __syncthreads();
+    if (t == 0) { int a = 0; for (int p = 0; p < NP; p++) { sOff[p] = a; a += sSize[p]; } sOff[NP] = a; }
+    __syncthreads();
+    int32_t *pg_off = d.pg_off + (size_t)w * (NP + 1);
+    for (int p = t; p <= NP; p += 256) pg_off[p] = sOff[p];
+    for (int it = t; it < 4 * NP; it += 256) {
+        const int qtr = it / NP, p = it - qtr * NP;
+        int hh, jj; pair_of(p, hh, jj);
+        if (hh >= host_end || sCnt[qtr * (NP + 1) + p] == 0) continue;
+        int pos = sOff[p];
+        for (int q2 = 0; q2 < qtr; q2++) pos += sCnt[q2 * (NP + 1) + p];
+        for (int l = Lw * qtr / 4, le = Lw * (qtr + 1) / 4; l < le; l++) {
+            const unsigned m0 = sMeta[l]; const int h = (int)(m0 & 255), k = (int)(m0 >> 8);
+            if (h == hh && h + k > jj) d.pg_perm[(size_t)F0 + pos++] = sF0[l] + (jj - hh - 1);
+        }
+    }
+    // ---- pass D: longest group first onto the least loaded sweep wavefront (stable order), as the host packer ----
+    for (int p = t; p < NP; p += 256) {
+        const int sp = sSize[p];
+        int rank = 0;
+        for (int q = 0; q < NP; q++) { const int sq = sSize[q]; rank += (sq > sp || (sq == sp && q < p)) ? 1 : 0; }
+        sOrder[rank] = p;
+    }
+    __syncthreads();
+    int32_t *soff = d.pg_sched_off + (size_t)w * (ISV_SWEEP_WAVES + 1), *sched = d.pg_sched + (size_t)w * NP, *wst = d.pg_wstart + (size_t)w * (ISV_SWEEP_WAVES + 1);
+    __shared__ int sT[3 * ISV_SWEEP_WAVES];        // (LDS: dynamically indexed private arrays live in scratch memory -- 36 us of this kernel)
+    if (t == 0) {
+        int *load = sT, *cntw = sT + ISV_SWEEP_WAVES, *fill = sT + 2 * ISV_SWEEP_WAVES;
+        for (int v = 0; v < ISV_SWEEP_WAVES; v++) { load[v] = 0; cntw[v] = 0; fill[v] = 0; }
+        for (int q = 0; q < NP; q++) {
+            const int p = sOrder[q];
+            int best = 0;
+            for (int v = 1; v < ISV_SWEEP_WAVES; v++) if (load[v] < load[best]) best = v;
+            load[best] += 1 + 4 * ((sSize[p] + 7) / 8);
+            sWave[p] = best; cntw[best]++;
+        }
+        soff[0] = 0;
+        for (int v = 0; v < ISV_SWEEP_WAVES; v++) soff[v + 1] = soff[v] + cntw[v];
+        for (int hh = 0, p = 0; hh < N - 1; hh++)
+            for (int jj = hh + 1; jj < N; jj++, p++) { const int v = sWave[p]; sched[soff[v] + fill[v]++] = hh | (jj << 8) | (p << 16); }
+        // stream offsets: the groups back to back in schedule order (wavefront, then pair)
+        int q = 0;
+        for (int v = 0; v < ISV_SWEEP_WAVES; v++) {
+            wst[v] = q;
+            for (int e = soff[v]; e < soff[v + 1]; e++) { const int pp = sched[e] >> 16; sBase[pp] = q; q += sSize[pp]; }
+        }
+        wst[ISV_SWEEP_WAVES] = q;
+    }
+    __syncthreads();
+    // ---- the factor stream of k_lin_gram ----
+    // (four entries per thread in flight: the sorted position's record comes through two dependent global loads)
+    for (int i0 = t; i0 < Fw; i0 += 4 * 256) {
+        int frel4[4], hj4[4]; size_t q4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int idx = i0 + 256 * u < Fw ? i0 + 256 * u : Fw - 1;
+            int lo = 0, hi = NP;                    // the pair group of sorted position idx: sOff[lo] <= idx < sOff[lo + 1]
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sOff[mid] <= idx) lo = mid; else hi = mid; }
+            const int pp = lo;                      // (the LAST group starting at or before idx: empty groups share its offset)
+            int hh, jj; pair_of(pp, hh, jj);
+            q4[u] = (size_t)F0 + sBase[pp] + (idx - sOff[pp]);
+            hj4[u] = (hh << 16) | (jj << 24);
+            frel4[u] = d.pg_perm[(size_t)F0 + idx];
+        }
+        int lm4[4]; double x4[4], y4[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const size_t f = (size_t)F0 + frel4[u]; lm4[u] = d.f_rec[f].lm; x4[u] = d.f_pts_j[2 * f]; y4[u] = d.f_pts_j[2 * f + 1]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (i0 + 256 * u < Fw) {
+                const size_t q = q4[u];
+                d.pg_rec[2 * q] = lm4[u]; d.pg_rec[2 * q + 1] = (int32_t)((unsigned)frel4[u] | (unsigned)hj4[u]);
+                d.pg_pts[2 * q] = x4[u]; d.pg_pts[2 * q + 1] = y4[u];
+            }
+        }
+    }
+}
+
 // The solver's view of the window from the track list (= pack_window of isv_backend.hip, on the device).
 // Dynamic LDS: sMeta [Lcap] uint32 (host | k << 8) | sF0 [Lcap] int32 | per pair: size, off, order, base, wave [5][NP + 1] int32 | quarter counts [4][NP + 1]
 __global__ __launch_bounds__(256) void k_seq_build(DevBatch d, SeqDev s, int lcap) {
     extern __shared__ int ldsi[];
     // (Nd: device frames per window = the stride of the state arrays; N: the real frames -- pairs, schedule, factor stream)
-    const int w = blockIdx.x, t = threadIdx.x, Nd = d.N, N = d.Nr, Nvo = d.Nvo, NP = N * (N - 1) / 2;
+    const int w = blockIdx.x, t = threadIdx.x, Nd = d.N, Nvo = d.Nvo;
     unsigned *sMeta = (unsigned *)ldsi;
-    int *sF0 = ldsi + lcap, *sSize = sF0 + lcap, *sOff = sSize + NP + 1, *sOrder = sOff + NP + 1, *sBase = sOrder + NP + 1, *sWave = sBase + NP + 1;
+    int *sF0 = ldsi + lcap;
     __shared__ int sbuf[8];
     const int *hdr = s.f_hdr + (size_t)w * SEQ_HDR;
     if (hdr[FH_PREV] < 0) return;                  // (no frame: the window contributes no landmarks / factors to this step's batch)
@@ -388,100 +494,59 @@ __global__ __launch_bounds__(256) void k_seq_build(DevBatch d, SeqDev s, int lca
     if (t == 0 && (Lw != hdr[FH_NLM] || Fw != hdr[FH_NF] || Lw != d.lm_off[w + 1] - L0 || Fw != d.f_off[w + 1] - F0)) atomicOr(&s.err[w], SEQ_ERR_COUNTS);
     __syncthreads();
     if (Lw > lcap) return;
-    // ---- pass C: factors sorted by (host, observer) pair, stable in landmark order.  A landmark has at most one factor
-    //      per pair, so the rank of its factor inside the pair group is the number of EARLIER landmarks in the group:
-    //      one thread walks the landmark list per pair (count, then fill) ----
-    // (round 4: the landmark list in four QUARTERS per pair -- item (pair, quarter) counts / fills its quarter in order, a quarter's
-    //  first rank is the pair's offset plus the earlier quarters' counts: the same stable order with four times the threads; the
-    //  55 one-thread walks over ~280 landmarks were 37 of the kernel's 175 us)
-    int *sCnt = sWave + NP + 1;                    // [4][NP + 1]
-    for (int p = t; p <= NP; p += 256) sSize[p] = 0;
-    auto pair_of = [N](int p, int &hh, int &jj) { hh = 0; int rem = p; while (rem >= N - 1 - hh) { rem -= N - 1 - hh; hh++; } jj = hh + 1 + rem; };
-    for (int it = t; it < 4 * NP; it += 256) {
-        const int qtr = it / NP, p = it - qtr * NP;
-        int hh, jj; pair_of(p, hh, jj);
-        int c = 0;
-        if (hh < Nvo) for (int l = Lw * qtr / 4, le = Lw * (qtr + 1) / 4; l < le; l++) { const unsigned m0 = sMeta[l]; const int h = (int)(m0 & 255), k = (int)(m0 >> 8); c += (h == hh && h + k > jj) ? 1 : 0; }
-        sCnt[qtr * (NP + 1) + p] = c;
-    }
-    __syncthreads();
-    for (int p = t; p < NP; p += 256) sSize[p] = sCnt[p] + sCnt[(NP + 1) + p] + sCnt[2 * (NP + 1) + p] + sCnt[3 * (NP + 1) + p];
-    __syncthreads();
-    if (t == 0) { int a = 0; for (int p = 0; p < NP; p++) { sOff[p] = a; a += sSize[p]; } sOff[NP] = a; }
-    __syncthreads();
-    int32_t *pg_off = d.pg_off + (size_t)w * (NP + 1);
-    for (int p = t; p <= NP; p += 256) pg_off[p] = sOff[p];
-    for (int it = t; it < 4 * NP; it += 256) {
-        const int qtr = it / NP, p = it - qtr * NP;
-        int hh, jj; pair_of(p, hh, jj);
-        if (hh >= Nvo || sCnt[qtr * (NP + 1) + p] == 0) continue;
-        int pos = sOff[p];
-        for (int q2 = 0; q2 < qtr; q2++) pos += sCnt[q2 * (NP + 1) + p];
-        for (int l = Lw * qtr / 4, le = Lw * (qtr + 1) / 4; l < le; l++) {
-            const unsigned m0 = sMeta[l]; const int h = (int)(m0 & 255), k = (int)(m0 >> 8);
-            if (h == hh && h + k > jj) d.pg_perm[(size_t)F0 + pos++] = sF0[l] + (jj - hh - 1);
-        }
-    }
-    // ---- pass D: longest group first onto the least loaded sweep wavefront (stable order), as the host packer ----
-    for (int p = t; p < NP; p += 256) {
-        const int sp = sSize[p];
-        int rank = 0;
-        for (int q = 0; q < NP; q++) { const int sq = sSize[q]; rank += (sq > sp || (sq == sp && q < p)) ? 1 : 0; }
-        sOrder[rank] = p;
-    }
-    __syncthreads();
-    int32_t *soff = d.pg_sched_off + (size_t)w * (ISV_SWEEP_WAVES + 1), *sched = d.pg_sched + (size_t)w * NP, *wst = d.pg_wstart + (size_t)w * (ISV_SWEEP_WAVES + 1);
-    __shared__ int sT[3 * ISV_SWEEP_WAVES];        // (LDS: dynamically indexed private arrays live in scratch memory -- 36 us of this kernel)
-    if (t == 0) {
-        int *load = sT, *cntw = sT + ISV_SWEEP_WAVES, *fill = sT + 2 * ISV_SWEEP_WAVES;
-        for (int v = 0; v < ISV_SWEEP_WAVES; v++) { load[v] = 0; cntw[v] = 0; fill[v] = 0; }
-        for (int q = 0; q < NP; q++) {
-            const int p = sOrder[q];
-            int best = 0;
-            for (int v = 1; v < ISV_SWEEP_WAVES; v++) if (load[v] < load[best]) best = v;
-            load[best] += 1 + 4 * ((sSize[p] + 7) / 8);
-            sWave[p] = best; cntw[best]++;
-        }
-        soff[0] = 0;
-        for (int v = 0; v < ISV_SWEEP_WAVES; v++) soff[v + 1] = soff[v] + cntw[v];
-        for (int hh = 0, p = 0; hh < N - 1; hh++)
-            for (int jj = hh + 1; jj < N; jj++, p++) { const int v = sWave[p]; sched[soff[v] + fill[v]++] = hh | (jj << 8) | (p << 16); }
-        // stream offsets: the groups back to back in schedule order (wavefront, then pair)
-        int q = 0;
-        for (int v = 0; v < ISV_SWEEP_WAVES; v++) {
-            wst[v] = q;
-            for (int e = soff[v]; e < soff[v + 1]; e++) { const int pp = sched[e] >> 16; sBase[pp] = q; q += sSize[pp]; }
-        }
-        wst[ISV_SWEEP_WAVES] = q;
-    }
-    __syncthreads();
-    // ---- the factor stream of k_lin_gram ----
-    // (four entries per thread in flight: the sorted position's record comes through two dependent global loads)
-    for (int i0 = t; i0 < Fw; i0 += 4 * 256) {
-        int frel4[4], hj4[4]; size_t q4[4];
+    build_pairs_stream(d, w, t, Lw, Fw, F0, Nvo, lcap, ldsi);
+}
+
+// isv_batch_upload's device half (round 5): the caller's windows arrive as RAW CSR -- start frames (d.lm_host), observation offsets
+// (optr: the window's lm_obs_ptr, L + 1 entries at lm_off[w] + w), the observations' points (obs_raw, n_obs x 3 at f_off[w] + lm_off[w])
+// and depths -- and this kernel derives what pack_window derived on the host: lm_k / lm_f0 / lm_meta / lm_pts_i, the factor records and
+// observing points, then the pair groups, the schedule and the factor stream (build_pairs_stream).  Entry for entry the host packer's
+// arrays (tests/test_gpu_upload_build.py: the two paths give bitwise the same solves).
+__global__ __launch_bounds__(256) void k_upload_build(DevBatch d, const int32_t *optr, const double *obs_raw, int lcap) {
+    extern __shared__ int ldsi[];
+    const int w = blockIdx.x, t = threadIdx.x;
+    unsigned *sMeta = (unsigned *)ldsi;
+    int *sF0 = ldsi + lcap;
+    const int L0 = d.lm_off[w], Lw = d.lm_off[w + 1] - L0, F0 = d.f_off[w], Fw = d.f_off[w + 1] - F0;
+    const int32_t *op = optr + L0 + w;
+    const double *pts = obs_raw + (size_t)(F0 + L0) * 3;
+    for (int li = t; li < Lw; li += 256) {
+        const int l = L0 + li, st = d.lm_host[l], o0 = op[li], n = op[li + 1] - o0, frel = o0 - li, f0 = F0 + frel;
+        d.lm_k[l] = n; d.lm_f0[l] = f0;
+        d.lm_meta[l] = (uint32_t)st | ((uint32_t)n << 8) | ((uint32_t)frel << 16);
+        sMeta[li] = (unsigned)st | ((unsigned)n << 8); sF0[li] = frel;
+        const double *p0 = pts + (size_t)o0 * 3;
+        d.lm_pts_i[(size_t)l * 3] = p0[0]; d.lm_pts_i[(size_t)l * 3 + 1] = p0[1]; d.lm_pts_i[(size_t)l * 3 + 2] = p0[2];
+        for (int o1 = 1; o1 < n; o1 += 4) {                 // (four observations in flight)
+            double px[4], py[4], pz[4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int idx = i0 + 256 * u < Fw ? i0 + 256 * u : Fw - 1;
-            int lo = 0, hi = NP;                    // the pair group of sorted position idx: sOff[lo] <= idx < sOff[lo + 1]
-            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sOff[mid] <= idx) lo = mid; else hi = mid; }
-            const int pp = lo;                      // (the LAST group starting at or before idx: empty groups share its offset)
-            int hh, jj; pair_of(pp, hh, jj);
-            q4[u] = (size_t)F0 + sBase[pp] + (idx - sOff[pp]);
-            hj4[u] = (hh << 16) | (jj << 24);
-            frel4[u] = d.pg_perm[(size_t)F0 + idx];
-        }
-        int lm4[4]; double x4[4], y4[4];
+            for (int u = 0; u < 4; u++) { const int o = o1 + u < n ? o1 + u : n - 1; const double *p = p0 + (size_t)o * 3; px[u] = p[0]; py[u] = p[1]; pz[u] = p[2]; }
 #pragma unroll
-        for (int u = 0; u < 4; u++) { const size_t f = (size_t)F0 + frel4[u]; lm4[u] = d.f_rec[f].lm; x4[u] = d.f_pts_j[2 * f]; y4[u] = d.f_pts_j[2 * f + 1]; }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-            if (i0 + 256 * u < Fw) {
-                const size_t q = q4[u];
-                d.pg_rec[2 * q] = lm4[u]; d.pg_rec[2 * q + 1] = (int32_t)((unsigned)frel4[u] | (unsigned)hj4[u]);
-                d.pg_pts[2 * q] = x4[u]; d.pg_pts[2 * q + 1] = y4[u];
+            for (int u = 0; u < 4; u++) {
+                const int o = o1 + u;
+                if (o < n) {
+                    const size_t f = (size_t)f0 + o - 1;
+                    FactorRec rc; rc.lm = l; rc.ij = st | ((st + o) << 8);
+                    d.f_rec[f] = rc;
+                    d.f_pts_j[f * 2] = px[u]; d.f_pts_j[f * 2 + 1] = py[u]; d.f_pts_z[f] = pz[u];
+                }
             }
         }
     }
+    __syncthreads();
+    build_pairs_stream(d, w, t, Lw, Fw, F0, d.Nr, lcap, ldsi);
+}
+size_t upload_build_lds_bytes(int N, int lcap) { return ((size_t)2 * lcap + 9 * ((size_t)N * (N - 1) / 2 + 1)) * sizeof(int32_t); }
+int isv_upload_build_enqueue(DevBatch &d, const int32_t *optr, const double *obs_raw, int lcap, hipStream_t st) {
+    const size_t lds = upload_build_lds_bytes(d.Nr, lcap);
+    if (lds > 48 * 1024) {
+        static std::mutex mtx; static size_t cur[64] = {};
+        int dev = 0; (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lk(mtx);
+        if (lds > cur[dev & 63]) { if (hipFuncSetAttribute((const void *)k_upload_build, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return ISV_ERR_DEVICE; cur[dev & 63] = lds; }
+    }
+    hipLaunchKernelGGL(k_upload_build, dim3(d.B), dim3(256), lds, st, d, optr, obs_raw, lcap);
+    return hipGetLastError() == hipSuccess ? ISV_OK : ISV_ERR_DEVICE;
 }
 
 // test hook (ISV_DEBUG_SEQ_FAIL_FRAME=k): the solve of window 0 in the k-th resident frame "ends non-finite"
