@@ -423,7 +423,7 @@ def main():
                              "traffic": None, "active_launch_us": r1_us,
                              "flops_dense_equivalent": r1_dense, "flops_sparse_exact": r1_sparse,
                              "note": "the Schur panel contraction S -= sum_l c_l w_l w_l^T of ONE window, dense-equivalent 2 (6N)^2 L flops (SURVEY 8d), per ACTIVE launch; "
-                                     + ("round 4: the window's landmarks are split over schur_split_groups workgroups (+ up to 16 for the direct part in the same launch) and folded in fixed order by k_schur_fold; MfmaUtil of the same launch: profiles/r04_config5_pmc_utilisation.csv"
+                                     + ("round 4: the window's landmarks are split over schur_split_groups workgroups (+ up to 16 for the direct part in the same launch) and folded in fixed order by k_schur_fold; MfmaUtil of the same launch: profiles/r05_config5_pmc_utilisation.csv"
                                         if split5 > 0 else "one workgroup of 12 wavefronts on one CU")}}
         if cpu_lib is not None:
             cfg5c = backend.abi.make_config(20, 8, max_landmarks=2000, max_obs=w5.n_obs, max_batch=1)
@@ -579,7 +579,7 @@ def main():
         bytes_control = Fw * 24.0 + Lw * (24.0 + 24.0) + 3 * 16 * N * 8.0
         flops_bs = bs_flops(N)
         pmc = {}
-        for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
             try:
                 pmc = json.load(open(os.path.join(ROOT, "profiles", name)))
                 break
@@ -636,7 +636,7 @@ def main():
                 "value": W / t_incl, "unit": "windows/s", "ms_per_batch": 1e3 * t_incl,
                 "pipelined_two_handles": {"value": W / t_pipe, "unit": "windows/s", "ms_per_batch": 1e3 * t_pipe},
                 "ms_upload": 1e3 * t_up, "ms_optimize": 1e3 * t_opt, "ms_download": 1e3 * (t_incl - t_up - t_opt),
-                "what": "one isv_batch_upload (host packing + H2D) + isv_batch_optimize + isv_batch_download (D2H) of the same batch, pageable host buffers; packing on min(16, allowed CPUs) host threads.  This is the STATELESS hand-over (every call carries whole windows); consecutive frames of the same sequences keep their windows on the device instead: device_resident_replay",
+                "what": "one isv_batch_upload (raw CSR into ONE pinned block on min(16, allowed CPUs) host threads + ONE H2D copy + k_upload_build: the solver's view -- pair groups, schedule, factor stream -- is derived on the device, round 5) + isv_batch_optimize + isv_batch_download (D2H) of the same batch, pageable host buffers.  This is the STATELESS hand-over (every call carries whole windows); consecutive frames of the same sequences keep their windows on the device instead: device_resident_replay",
                 "resident_path_frames_per_s_2048_sequences": (extra.get("device_resident_replay") or {}).get("resident_2048_seq_4_groups_frames_per_s")},
             "kernel_ms": {"profiled_step_total_events": float(fam[0]), "lin_gram_or_proj_linearize_sum": lin_ms, "sweep_mfma_sum": sw_ms, "rank1_mfma_sum": r1_ms, "build_solve_sum": bs_ms,
                           "dogleg_sum": dg_ms, "step_control_sum": sc_ms, "window_iterations": win_iters},

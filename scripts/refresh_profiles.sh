@@ -1,13 +1,15 @@
 #!/bin/bash
 # Run ON THE GPU BOX (via gpurun): the rocprofv3 evidence of one round, everything under gpurun_out/prof_rNN/; copy the
 # summaries into profiles/ afterwards (scripts/copy_profiles.sh).  --pmc passes are separate runs with --kernel-trace only.
-# usage: bash scripts/refresh_profiles.sh [round prefix, default r04] [windows, default 1024]
+# usage: bash scripts/refresh_profiles.sh [round prefix, default r05] [windows, default 1024] [part: A = steps 1-5, B = steps 6-11, default both]
+# (one gpurun call is limited to 20 minutes: the two parts are two calls)
 set -e
-RN=${1:-r04}; W=${2:-1024}
+RN=${1:-r05}; W=${2:-1024}; PART=${3:-AB}
 cd /tmp; export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 O=gpurun_out/prof_$RN
-rm -rf $O; mkdir -p $O
+mkdir -p $O
 B="python3 bench.py --no-cpu-baseline --no-host-legs --windows $W"
+if [[ $PART == *A* ]]; then
 # 1. kernel-trace stats of the bench command (the launches of the benchmark only)
 rocprofv3 --kernel-trace --stats -d $O/bench -o bench --output-format csv -- $B --steps 5 --warmup 2 > $O/bench_under_rocprof.json 2> $O/bench.err
 cp $O/bench/bench_kernel_stats.csv $O/${RN}_bench_${W}win_kernel_stats.csv
@@ -30,6 +32,8 @@ REPS=10 rocprofv3 --kernel-trace --stats -d $O/cfg5 -o cfg5 --output-format csv 
 cp $O/cfg5/cfg5_kernel_stats.csv $O/${RN}_config5_kernel_stats.csv
 REPS=3 rocprofv3 --kernel-trace --pmc VALUBusy MfmaUtil -d $O/cfg5_u -o u --output-format csv -- python3 scripts/quick_cfg.py 1 20 8 2000 30000 > $O/cfg5_u.log 2>&1
 python3 scripts/pmc_util_summary.py $O/cfg5_u/u_counter_collection.csv > $O/${RN}_config5_pmc_utilisation.csv
+fi
+if [[ $PART == *B* ]]; then
 # 6. the pose-graph kernel: one graph and 1024 graphs of 200 keyframes
 PGO_CFGS=200:5:1,200:5:1024 PGO_NO_ORACLE=1 rocprofv3 --kernel-trace --stats -d $O/pgo -o pgo --output-format csv -- python3 scripts/pgo_bench.py > $O/pgo.log 2>&1
 cp $O/pgo/pgo_kernel_stats.csv $O/${RN}_pgo_kernel_stats.csv
@@ -59,5 +63,13 @@ ISV_ONE_STREAM=1 rocprofv3 --kernel-trace --stats -d $O/os11 -o os --output-form
 cp $O/os11/os_kernel_stats.csv $O/${RN}_one_stream_n11_kernel_stats.csv
 ISV_ONE_STREAM=1 rocprofv3 --kernel-trace --stats -d $O/os18 -o os --output-format csv -- $B --steps 5 --warmup 2 --frames 18 --vo 8 > $O/os18.log 2>&1
 cp $O/os18/os_kernel_stats.csv $O/${RN}_one_stream_n18_kernel_stats.csv
+# 11. (round 5) the single-stream launch chain of a small batch: timelines of one window (11 and 18 frames) and the kernels of the 128-window shard
+N=11 V=5 rocprofv3 --kernel-trace --output-format csv -d $O/tl11 -o tl -- python3 scripts/b1_trace.py > $O/tl11.log 2>&1
+python3 scripts/timeline.py $(find $O/tl11 -name "*kernel_trace.csv" | head -1) 40 > $O/${RN}_single_window_n11_timeline.txt
+N=18 V=8 rocprofv3 --kernel-trace --output-format csv -d $O/tl18 -o tl -- python3 scripts/b1_trace.py > $O/tl18.log 2>&1
+python3 scripts/timeline.py $(find $O/tl18 -name "*kernel_trace.csv" | head -1) 40 > $O/${RN}_single_window_n18_timeline.txt
+REPS=6 rocprofv3 --kernel-trace --stats -d $O/b128 -o b128 --output-format csv -- python3 scripts/quick_cfg.py 128 11 5 300 > $O/b128.log 2>&1
+cp $O/b128/b128_kernel_stats.csv $O/${RN}_shard_128win_kernel_stats.csv
+fi
 ls $O/*.csv $O/*.json
 head -12 $O/${RN}_bench_${W}win_kernel_stats.csv
