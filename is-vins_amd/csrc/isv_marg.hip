@@ -130,8 +130,8 @@ DEV void w_jacobi_t(double *A, int n_rt, double *wv, double *V, double *tmp, int
         // ~ 1e-7, and that vector carries the largest weight 1 / lambda of the projected covariance -- the recovered roll/pitch factor's
         // information was 1.2e-7 (relative) from the 40-digit result where the oracle's cyclic Jacobi (threshold 1e-34) is at 1e-10
         // (tests/test_marg_third_opinion.py).  One more sweep once the threshold is met squares the residual (Jacobi converges
-        // quadratically); the oracle's threshold itself would not always fire with these rotations.
-        if (offs <= 1e-60 || offs <= 1e-34 * dgs || polish) break;
+        // quadratically); no extra sweep when the mass is already below 1e-32 (1e-16 of the diagonal: the level the oracle reaches).
+        if (offs <= 1e-60 || offs <= 1e-32 * dgs || polish) break;
         if (offs <= 1e-28 * dgs) polish = true;
         for (int r = 0; r < m - 1; r++) {
             if (t < half) {
@@ -219,7 +219,7 @@ DEV void w_jacobi_pipe(double *A, double *wv, double *V, int t) {
         double off = 0, dg = 0;
         for (int e = t; e < n * n; e += MT) { const int i = e / n, j = e % n; if (j > i) off += A[e] * A[e]; else if (i == j) dg += A[e] * A[e]; }
         for (int o = 32; o > 0; o >>= 1) { off += __shfl_xor(off, o); dg += __shfl_xor(dg, o); }
-        if (off <= 1e-60 || off <= 1e-34 * dg || polish) break;      // as w_jacobi_t: one more sweep after the 1e-28 threshold
+        if (off <= 1e-60 || off <= 1e-32 * dg || polish) break;      // as w_jacobi_t: one more sweep after the 1e-28 threshold
         if (off <= 1e-28 * dg) polish = true;
         params(0, 0);
         SYNC();
@@ -323,12 +323,15 @@ __global__ void k_marg_clear(DevBatch d) {
 // (round 5) MTF = 256 threads: the two phases that walk the window's landmarks -- the Jacobians of the landmarks hosted in frame 0 (a lane per
 // landmark of the WINDOW: 2000 of them in BASELINE config 5) and their sums into the 12 x 12 pose blocks -- use four wavefronts, the 12 x 12
 // algebra behind them the first (the others have left by then).  Slots and sums in the same order as the one-wavefront kernel: same bits.
-#define MTF 256
+// MTF = 64 for batches that fill the GPU (1024 windows: the four-wavefront form takes 350 us against 110 -- the extra wavefronts only add
+// barriers where every SIMD already holds windows); chosen per launch from the batch size, the bits are the same.
+template <int MTF>
 __global__ __launch_bounds__(MTF) void k_marg_fwd(DevBatch d) {
     // (LDS decides how many windows a CU holds next to k_marg_bwd's: 4 + 4 workgroups need <= 40 KB for the pair)
     __shared__ double Lam[144], M1[144], M2[144], Wk[936], Vv[36], wv[8], JU[36];
     __shared__ double sJ[3 * 36];
     __shared__ int keep[8], piv[4], wcnt[4];
+    if (MTF == 64 && threadIdx.x >= 1 && threadIdx.x < 4) wcnt[threadIdx.x] = 0;       // (one wavefront: the other three counts of the slot arithmetic are zero)
     const int w = blockIdx.x, t = threadIdx.x;
     isv_marg_result_t &out = d.marg[w];
     if (!d.margin_old[w] || ISV_SEQ_IDLE(d, w)) return;
@@ -348,7 +351,7 @@ __global__ __launch_bounds__(MTF) void k_marg_fwd(DevBatch d) {
         q_to_R(q_from_pose(pose), Ri); q_to_R(q_from_pose(pose + 7), Rj); q_to_R(q_from_pose(ex), ric);
         const double ident[4] = {1, 0, 0, 1};
         for (int base = l0; base < l1; base += MTF) {
-            const int l = base + t, lane = t & 63, wvf = t >> 6;
+            const int l = base + t, lane = t & 63, wvf = t >> 6;      // (MTF = 64: one wavefront, wcnt[1..3] stay zero)
             const bool is0 = l < l1 && d.lm_host[l] == 0;
             const unsigned long long m = __ballot(is0);
             if (lane == 0) wcnt[wvf] = __popcll(m);
@@ -382,24 +385,32 @@ __global__ __launch_bounds__(MTF) void k_marg_fwd(DevBatch d) {
     // raw pose block Hraw (12x12, order [T1, T0]) in Lam[0..143]; Schur-reduced over the landmarks in M1[0..143]
     {
         // (a thread per entry of the 12 x 12 blocks; the landmarks in slot order: the sums of the one-wavefront kernel)
-        double hr = 0, hs = 0;
-        const int ea = t < 144 ? t / 12 : 0, eb = t < 144 ? t % 12 : 0;
+        constexpr int NE = (144 + MTF - 1) / MTF;            // entries per thread: 1 (MTF = 256) or 3 (MTF = 64)
+        double hr[NE], hs[NE];
+#pragma unroll
+        for (int i = 0; i < NE; i++) { hr[i] = 0; hs[i] = 0; }
         for (int mb = 0; mb < n0; mb += 32) {
             const int cnt = (n0 - mb) < 32 ? (n0 - mb) : 32;
             for (int e = t; e < cnt * 26; e += MTF) Wk[e] = Jw[(size_t)mb * 26 + e];
             SYNC();
-            if (t < 144) {
-                for (int m = 0; m < cnt; m++) {
-                    const double *o = Wk + m * 26;
-                    const double dmi = 1.0 / (o[12] * o[12] + o[25] * o[25]);
-                    const double h = o[ea] * o[eb] + o[13 + ea] * o[13 + eb];
-                    const double ba = o[ea] * o[12] + o[13 + ea] * o[25], bb = o[eb] * o[12] + o[13 + eb] * o[25];
-                    hr += h; hs += h - ba * bb * dmi;
+            for (int m = 0; m < cnt; m++) {
+                const double *o = Wk + m * 26;
+                const double dmi = 1.0 / (o[12] * o[12] + o[25] * o[25]);
+#pragma unroll
+                for (int i = 0; i < NE; i++) {
+                    const int e = t + MTF * i;
+                    if (e < 144) {
+                        const int a = e / 12, b = e % 12;
+                        const double h = o[a] * o[b] + o[13 + a] * o[13 + b];
+                        const double ba = o[a] * o[12] + o[13 + a] * o[25], bb = o[b] * o[12] + o[13 + b] * o[25];
+                        hr[i] += h; hs[i] += h - ba * bb * dmi;
+                    }
                 }
             }
             SYNC();
         }
-        if (t < 144) { Lam[t] = hr; M1[t] = hs; }
+#pragma unroll
+        for (int i = 0; i < NE; i++) { const int e = t + MTF * i; if (e < 144) { Lam[e] = hr[i]; M1[e] = hs[i]; } }
     }
     SYNC();
     if (t >= MT) return;                                    // the 12 x 12 algebra below: the first wavefront
@@ -557,6 +568,8 @@ __global__ __launch_bounds__(MTF) void k_marg_fwd(DevBatch d) {
     }
     MSTAMP(4);
 }
+template __global__ void k_marg_fwd<64>(DevBatch);
+template __global__ void k_marg_fwd<256>(DevBatch);
 
 // ------------------------------------------------------------------------------------------
 // The eigen-decomposition of MargBackward's 21 x 21 marginal as a kernel of its own, FOUR wavefronts per window.  One
@@ -613,7 +626,7 @@ __global__ __launch_bounds__(256) void k_marg_jacobi(DevBatch d) {
         // (the sums of the one-wavefront version run over the same lanes in another order: the test below is a
         // threshold many orders of magnitude wide, not a value that is carried on)
         off = red[0] + red[2] + red[4] + red[6]; dg = red[1] + red[3] + red[5] + red[7];
-        if (off <= 1e-60 || off <= 1e-34 * dg || polish) break;      // (w_jacobi_t's rule: one more sweep after the 1e-28 threshold)
+        if (off <= 1e-60 || off <= 1e-32 * dg || polish) break;      // (w_jacobi_t's rule: one more sweep after the 1e-28 threshold)
         if (off <= 1e-28 * dg) polish = true;
         for (int r = 0; r < m - 1; r++) {
             const int buf = r & 1;

@@ -37,7 +37,7 @@ __global__ void k_imu_weight(DevBatch d, double *cost_out, int gate);
 __global__ void k_sweep_mfma(DevBatch d);
 template <int NT, int TPW, int R1_CHUNK, int MINW, bool EX> __global__ void k_rank1_mfma(DevBatch d);
 __global__ void k_marg_clear(DevBatch d);
-__global__ void k_marg_fwd(DevBatch d);
+template <int MTF> __global__ void k_marg_fwd(DevBatch d);
 template <int PART> __global__ void k_marg_bwd(DevBatch d);
 template <int NC> __global__ void k_marg_jacobi(DevBatch d);
 template <bool LDS_T> __global__ void k_build_solve(DevBatch d);
@@ -679,7 +679,9 @@ int isv_solver_enqueue(DevBatch &d, const SolverHost &hc, hipStream_t st, hipStr
         hipLaunchKernelGGL(k_marg_jacobi<21>, dim3(d.B), dim3(256), 0, st, d);
         hipLaunchKernelGGL(k_marg_bwd<1>, dim3(d.B), dim3(64), 0, st, d);
     }
-    hipLaunchKernelGGL(k_marg_fwd, dim3(d.B), dim3(256), 0, st2, d);      // (MTF: four wavefronts for the landmark phases)
+    // (four wavefronts for the landmark phases while the batch leaves SIMDs idle; same bits either way)
+    if (d.B <= 2 * n_cus) hipLaunchKernelGGL(k_marg_fwd<256>, dim3(d.B), dim3(256), 0, st2, d);
+    else hipLaunchKernelGGL(k_marg_fwd<64>, dim3(d.B), dim3(64), 0, st2, d);
     HCHK(hipEventRecord(fj[1], st2));
     HCHK(hipStreamWaitEvent(st, fj[1], 0));
     HCHK(hipGetLastError());
