@@ -22,7 +22,7 @@ def digest(ws, sums, margs):
 
 
 cases = [("N11 B1", 11, 5, 300, 1, 1, 0), ("N11 B37", 11, 5, 120, 37, 64, 0), ("N11 B300 cap1024", 11, 5, 150, 300, 1024, 0),
-         ("N18 B5", 18, 8, 200, 5, 8, 0), ("N18 B40 cap512", 18, 8, 100, 40, 512, 0), ("N11 ex B3", 11, 5, 120, 3, 4, 1), ("N24 B2", 24, 10, 80, 2, 2, 0)]
+         ("N18 B5", 18, 8, 200, 5, 8, 0), ("N18 B40 cap512", 18, 8, 100, 40, 512, 0), ("N18 B300 cap512", 18, 8, 100, 300, 512, 0), ("N11 B600 cap1024", 11, 5, 300, 600, 1024, 0), ("N11 ex B3", 11, 5, 120, 3, 4, 1), ("N24 B2", 24, 10, 80, 2, 2, 0)]
 for name, N, Nvo, L, B, cap, ex in cases:
     ws = [synth.make_window(i, n_frames=N, n_vo=Nvo, n_landmarks=L, margin_old=i % 2) for i in range(B)]
     be = backend.Backend(N, Nvo, max_landmarks=L + 20, max_obs=max(w.n_obs for w in ws), max_batch=cap, estimate_extrinsic=ex)
