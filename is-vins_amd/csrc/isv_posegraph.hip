@@ -63,6 +63,7 @@ struct PgDev {
     int32_t *free_of;            // [poses] free index of a local pose or -1
     PgEdge *edges;
     double *eres, *ejac;         // [edges][6], [edges][72]: corrected residual, Jacobians (block a | block b), Jacobi-scaled
+    double *red;                 // [edges][6]: per-item terms of the sums a multi-wavefront launch hands to wavefront 0 (k_pgo<4>)
     int32_t *adj_ptr, *adj;      // per free pose: the residual blocks touching it, (edge << 1) | side
     int32_t *start, *rowptr;     // skyline: first column of row r, block offset of row r   (per free pose; rowptr has nf + 1)
     int32_t *colptr, *colrows;   // column pattern: rows i > j with start[i] <= j, ascending
@@ -211,11 +212,42 @@ DEV double pg_edge_eval(const PgEdge &E, const double *pose, double huber, doubl
     return 0.5 * rho;
 }
 
-__global__ __launch_bounds__(64) void k_pgo(PgDev dv) {
+// NW wavefronts per pose graph (round 5).  NW = 1: the batch form, a graph per wavefront.  NW = 4: a call with few graphs -- what
+// PoseGraph::optimizeCS is in the reference: ONE graph, when a loop closes -- leaves the GPU idle around one wavefront per graph, so
+// the loops that are lane-per-residual-block or lane-per-pose (evaluation + linearisation, column norms, scaling, gradient, assembly,
+// candidate, the element-wise passes, the covariance read-out) stride over four wavefronts; the block recurrences (factor, solve,
+// the selected inverse) stay on wavefront 0: row r needs row r - 1.  SAME BITS as NW = 1: the owner-computes loops have no
+// cross-lane sum, and every sum over items is taken by wavefront 0 over the stored per-item terms in the order NW = 1 adds them.
+template <int NW>
+__global__ __launch_bounds__(64 * NW) void k_pgo(PgDev dv) {
     __shared__ double T0[36], T1[36], T2[36];
+    __shared__ double bcast_[2 + NW];
+    constexpr int NT = 64 * NW;
     const int gid = blockIdx.x + dv.g0;
     const PgGraph G = dv.graphs[gid];
-    const int lane = threadIdx.x, nf = G.nf, n = 6 * nf;
+    const int tid = threadIdx.x, lane = tid & 63, wv = NW > 1 ? __builtin_amdgcn_readfirstlane(tid >> 6) : 0, nf = G.nf, n = 6 * nf;
+    // block-wide ordering of global + LDS traffic (NW = 1: the wavefront's own)
+#define PG_BSYNC() do { if constexpr (NW > 1) __syncthreads(); else PG_GSYNC(); } while (0)
+    // a value wavefront 0 holds -> every wavefront
+    auto bc = [&](double v) -> double {
+        if constexpr (NW == 1) return v;
+        if (tid == 0) bcast_[0] = v;
+        __syncthreads();
+        const double r = bcast_[0];
+        __syncthreads();
+        return r;
+    };
+    auto block_max = [&](double m) -> double {          // (a maximum does not depend on the order)
+        m = wave_max(m);
+        if constexpr (NW == 1) return m;
+        if (lane == 0) bcast_[2 + wv] = m;
+        __syncthreads();
+        double r = bcast_[2];
+        for (int k = 1; k < NW; k++) r = fmax(r, bcast_[2 + k]);
+        __syncthreads();
+        return r;
+    };
+    double *red = dv.red + (size_t)G.edge0 * 6;
     double *pose = dv.pose + (size_t)G.pose0 * 7, *cand = dv.cand + (size_t)G.pose0 * 7;
     const int32_t *free_of = dv.free_of + G.pose0;
     PgEdge *edges = dv.edges + G.edge0;
@@ -234,10 +266,10 @@ __global__ __launch_bounds__(64) void k_pgo(PgDev dv) {
     const int IR = dv.idx_lds_rows;
     if (idx_lds) {
         const int nc = colptr[nf];
-        for (int q = lane; q < nf; q += 64) { dyn_idx[q] = start[q]; dyn_idx[IR + q] = rowptr[q]; }
-        for (int q = lane; q <= nf; q += 64) dyn_idx[2 * IR + q] = colptr[q];
-        for (int q = lane; q < nc; q += 64) dyn_idx[3 * IR + 1 + q] = colrows[q];
-        PG_WSYNC();
+        for (int q = tid; q < nf; q += NT) { dyn_idx[q] = start[q]; dyn_idx[IR + q] = rowptr[q]; }
+        for (int q = tid; q <= nf; q += NT) dyn_idx[2 * IR + q] = colptr[q];
+        for (int q = tid; q < nc; q += NT) dyn_idx[3 * IR + 1 + q] = colrows[q];
+        if constexpr (NW > 1) __syncthreads(); else PG_WSYNC();
     }
     // (explicit LDS reads: a pointer that may be LDS or global becomes a FLAT access, which waits for every outstanding
     //  global load and store as well)
@@ -250,13 +282,20 @@ __global__ __launch_bounds__(64) void k_pgo(PgDev dv) {
     // ---- evaluation of every residual block at x (and linearisation) ------------------------------------------------
     auto evaluate = [&](const double *x, bool jac) -> double {
         double c = 0;
-        for (int q = lane; q < G.ne; q += 64) c += pg_edge_eval(edges[q], x, G.huber, eres + 6 * q, ejac + 72 * q, ejac + 72 * q + 36, jac);
-        PG_GSYNC();
-        return wave_sum(c);
+        if constexpr (NW == 1) {
+            for (int q = lane; q < G.ne; q += 64) c += pg_edge_eval(edges[q], x, G.huber, eres + 6 * q, ejac + 72 * q, ejac + 72 * q + 36, jac);
+            PG_GSYNC();
+            return wave_sum(c);
+        } else {
+            for (int q = tid; q < G.ne; q += NT) red[q] = pg_edge_eval(edges[q], x, G.huber, eres + 6 * q, ejac + 72 * q, ejac + 72 * q + 36, jac);
+            __syncthreads();
+            if (wv == 0) { for (int q = lane; q < G.ne; q += 64) c += red[q]; c = wave_sum(c); }
+            return bc(c);
+        }
     };
     // squared column norms of the (current) Jacobian, owner computes: lane per free pose
     auto colnorm2 = [&](double *out) {
-        for (int f = lane; f < nf; f += 64) {
+        for (int f = tid; f < nf; f += NT) {
             double s[6] = {0, 0, 0, 0, 0, 0};
             for (int q = adj_ptr[f]; q < adj_ptr[f + 1]; q++) {
                 const int ed = adj[q] >> 1, side = adj[q] & 1, dim = edges[ed].dim;
@@ -265,10 +304,10 @@ __global__ __launch_bounds__(64) void k_pgo(PgDev dv) {
             }
             for (int c = 0; c < 6; c++) out[6 * f + c] = s[c];
         }
-        PG_GSYNC();
+        PG_BSYNC();
     };
     auto scale_jac = [&]() {                           // J <- J diag(scale), lane per residual block
-        for (int q = lane; q < G.ne; q += 64) {
+        for (int q = tid; q < G.ne; q += NT) {
             const PgEdge &E = edges[q];
             for (int side = 0; side < (E.kind == 0 ? 1 : 2); side++) {
                 const int f = side ? E.fb : E.fa;
@@ -284,11 +323,11 @@ __global__ __launch_bounds__(64) void k_pgo(PgDev dv) {
                 for (int k = 0; k < 36; k++) if (k < nq) J[k] = Jl[k] * sc6[k % 6];
             }
         }
-        PG_GSYNC();
+        PG_BSYNC();
     };
     // gradient g = J^T r (scaled Jacobian), lane per free pose; returns nothing
     auto gradient = [&]() {
-        for (int f = lane; f < nf; f += 64) {
+        for (int f = tid; f < nf; f += NT) {
             double s[6] = {0, 0, 0, 0, 0, 0};
             for (int q = adj_ptr[f]; q < adj_ptr[f + 1]; q++) {
                 const int ed = adj[q] >> 1, side = adj[q] & 1, dim = edges[ed].dim;
@@ -297,12 +336,12 @@ __global__ __launch_bounds__(64) void k_pgo(PgDev dv) {
             }
             for (int c = 0; c < 6; c++) grad[6 * f + c] = s[c];
         }
-        PG_GSYNC();
+        PG_BSYNC();
     };
     // gradient_max_norm = |x - Plus(x, -g_unscaled)|_inf over the free blocks
     auto gmax_of = [&]() -> double {
         double m = 0;
-        for (int k = lane; k < G.P1; k += 64) {
+        for (int k = tid; k < G.P1; k += NT) {
             const int f = free_of[k];
             if (f < 0) continue;
             double ng[6], xp[7];
@@ -310,18 +349,18 @@ __global__ __launch_bounds__(64) void k_pgo(PgDev dv) {
             pose_plus(pose + 7 * k, ng, xp);
             for (int c = 0; c < 7; c++) m = fmax(m, fabs(pose[7 * k + c] - xp[c]));
         }
-        return wave_max(m);
+        return block_max(m);
     };
     auto xnorm_of = [&](const double *x) -> double {
         double s = 0;
-        for (int k = lane; k < G.P1; k += 64) if (free_of[k] >= 0) for (int c = 0; c < 7; c++) s += x[7 * k + c] * x[7 * k + c];
-        return sqrt(wave_sum(s));
+        if (wv == 0) { for (int k = lane; k < G.P1; k += 64) if (free_of[k] >= 0) for (int c = 0; c < 7; c++) s += x[7 * k + c] * x[7 * k + c]; s = wave_sum(s); }
+        return sqrt(bc(s));
     };
     // H = J^T J on the envelope, lane per free pose (row): its diagonal block and the blocks towards EARLIER neighbours
     auto assemble = [&]() {
-        for (int q = lane; q < G.nblk * 36; q += 64) H[q] = 0.0;
-        PG_GSYNC();
-        for (int f = lane; f < nf; f += 64) {
+        for (int q = tid; q < G.nblk * 36; q += NT) H[q] = 0.0;
+        PG_BSYNC();
+        for (int f = tid; f < nf; f += NT) {
             for (int q = adj_ptr[f]; q < adj_ptr[f + 1]; q++) {
                 const int ed = adj[q] >> 1, side = adj[q] & 1;
                 const PgEdge &E = edges[ed];
@@ -366,7 +405,7 @@ __global__ __launch_bounds__(64) void k_pgo(PgDev dv) {
                 }
             }
         }
-        PG_GSYNC();
+        PG_BSYNC();
     };
     // L L^T = H + diag(damp) on the envelope; diagonal slots hold L_rr^-1.  Returns false when a pivot is not positive.
     // The recurrence runs through LDS: a CHAIN row (its envelope starts at r - 1) needs L_{r-1,r-1}^-1 (still in T2 from the
@@ -545,20 +584,21 @@ __global__ __launch_bounds__(64) void k_pgo(PgDev dv) {
     };
 
     // ================= TrustRegionMinimizer::Minimize + LevenbergMarquardtStrategy (Ceres 2.0.0 defaults) =============
-    if (lane == 0) { res.status = ISV_OK; res.num_successful = 0; for (int k = 0; k < ISV_MAX_TRACE; k++) { res.trace_cost[k] = 0; res.trace_accepted[k] = 0; } }
+    if (tid == 0) { res.status = ISV_OK; res.num_successful = 0; res.n_loop_edges = 0; res._pad = 0;     // (every byte of the record is defined: callers compare records)
+                    for (int k = 0; k < ISV_MAX_TRACE; k++) { res.trace_cost[k] = 0; res.trace_accepted[k] = 0; } }
     double x_cost = evaluate(pose, true);
     int it = 0, term = ISV_TERM_RUNNING, nsucc = 0;
     if (nf > 0) {
         colnorm2(scale);
-        for (int q = lane; q < n; q += 64) scale[q] = 1.0 / (1.0 + sqrt(scale[q]));
-        PG_GSYNC();
+        for (int q = tid; q < n; q += NT) scale[q] = 1.0 / (1.0 + sqrt(scale[q]));
+        PG_BSYNC();
         scale_jac();
         gradient();
         double gmax = gmax_of(), x_norm = xnorm_of(pose);
         double radius = 1e4, decrease = 2.0;
         bool reuse_diag = false;
         int invalid = 0;
-        if (lane == 0) { res.initial_cost = x_cost; res.trace_cost[0] = x_cost; }
+        if (tid == 0) { res.initial_cost = x_cost; res.trace_cost[0] = x_cost; }
         for (;;) {
             if (it >= G.max_iter) { term = ISV_TERM_MAX_ITERATIONS; break; }
             if (gmax <= 1e-10) { term = ISV_TERM_GRADIENT_TOL; break; }
@@ -566,79 +606,95 @@ __global__ __launch_bounds__(64) void k_pgo(PgDev dv) {
             it++;
             if (!reuse_diag) {                         // diagonal_ = clamp(squared column norms)
                 colnorm2(diag);
-                for (int q = lane; q < n; q += 64) diag[q] = fmin(fmax(diag[q], 1e-6), 1e32);
-                PG_GSYNC();
+                for (int q = tid; q < n; q += NT) diag[q] = fmin(fmax(diag[q], 1e-6), 1e32);
+                PG_BSYNC();
             }
             reuse_diag = true;
             assemble();
-            for (int q0 = lane; q0 < n; q0 += 256) {   // D^2 = diagonal / radius (step[] as scratch); four loads in flight per lane
+            for (int q0 = tid; q0 < n; q0 += 4 * NT) {   // D^2 = diagonal / radius (step[] as scratch); four loads in flight per lane
                 double v[4];
-                for (int u = 0; u < 4; u++) v[u] = q0 + 64 * u < n ? diag[q0 + 64 * u] : 0.0;
-                for (int u = 0; u < 4; u++) if (q0 + 64 * u < n) step[q0 + 64 * u] = v[u] / radius;
+                for (int u = 0; u < 4; u++) v[u] = q0 + NT * u < n ? diag[q0 + NT * u] : 0.0;
+                for (int u = 0; u < 4; u++) if (q0 + NT * u < n) step[q0 + NT * u] = v[u] / radius;
             }
-            PG_GSYNC();
-            bool ok = factor(step);
+            PG_BSYNC();
+            bool ok = false;
+            if (wv == 0) ok = factor(step);               // (the recurrences: wavefront 0)
+            if (wv == 0 && ok) solve(grad, step);
+            ok = bc(ok ? 1.0 : 0.0) != 0.0;               // (NW > 1: also the barrier that hands wavefront 0's stores to the others)
             if (ok) {
-                solve(grad, step);
                 double bad = 0;
-                for (int q0 = lane; q0 < n; q0 += 256) {
+                for (int q0 = tid; q0 < n; q0 += 4 * NT) {
                     double v[4];
-                    for (int u = 0; u < 4; u++) v[u] = q0 + 64 * u < n ? step[q0 + 64 * u] : 0.0;
-                    for (int u = 0; u < 4; u++) if (q0 + 64 * u < n) { if (!(v[u] - v[u] == 0.0)) bad = 1; step[q0 + 64 * u] = -v[u]; }
+                    for (int u = 0; u < 4; u++) v[u] = q0 + NT * u < n ? step[q0 + NT * u] : 0.0;
+                    for (int u = 0; u < 4; u++) if (q0 + NT * u < n) { if (!(v[u] - v[u] == 0.0)) bad = 1; step[q0 + NT * u] = -v[u]; }
                 }
-                PG_GSYNC();
-                if (wave_max(bad) > 0) ok = false;
+                PG_BSYNC();
+                if (block_max(bad) > 0) ok = false;
             }
             bool valid = false;
             double model_cost_change = 0;
             if (ok) {                                  // -(J step)^T (r + J step / 2)
+                // (the term of a residual row is rounded before it is added -- no fused multiply-add across the two: what NW > 1 adds
+                //  is the stored term)
                 double mc = 0;
-                for (int q = lane; q < G.ne; q += 64) {
+                for (int q = tid; q < G.ne; q += NT) {
                     const PgEdge &E = edges[q];
                     for (int a = 0; a < E.dim; a++) {
                         double m = 0;
                         if (E.fa >= 0) for (int c = 0; c < 6; c++) m += ejac[72 * q + a * 6 + c] * step[6 * E.fa + c];
                         if (E.kind != 0 && E.fb >= 0) for (int c = 0; c < 6; c++) m += ejac[72 * q + 36 + a * 6 + c] * step[6 * E.fb + c];
-                        mc += m * (eres[6 * q + a] + m / 2.0);
+                        double term = m * (eres[6 * q + a] + m / 2.0);
+                        asm volatile("" : "+v"(term));
+                        if constexpr (NW == 1) mc += term; else red[6 * q + a] = term;
                     }
                 }
-                model_cost_change = -wave_sum(mc);
+                if constexpr (NW > 1) {
+                    __syncthreads();
+                    if (wv == 0) for (int q = lane; q < G.ne; q += 64) { const int dim = edges[q].dim; for (int a = 0; a < dim; a++) mc += red[6 * q + a]; }
+                }
+                model_cost_change = -bc(wave_sum(mc));
                 valid = model_cost_change > 0.0;
             }
             if (!valid) {
                 if (++invalid >= 5) { term = ok ? ISV_TERM_INVALID_STEPS : ISV_TERM_LINEAR_SOLVER; break; }
                 radius /= decrease; decrease *= 2.0; reuse_diag = true;        // StepIsInvalid == StepRejected
-                if (lane == 0 && it < ISV_MAX_TRACE) { res.trace_cost[it] = x_cost; res.trace_accepted[it] = 0; }
+                if (tid == 0 && it < ISV_MAX_TRACE) { res.trace_cost[it] = x_cost; res.trace_accepted[it] = 0; }
                 continue;
             }
             invalid = 0;
             double dn = 0;
-            for (int k = lane; k < G.P1; k += 64) {    // candidate = Plus(x, step * scale)
+            for (int k = tid; k < G.P1; k += NT) {     // candidate = Plus(x, step * scale)
                 const int f = free_of[k];
                 if (f < 0) { double x0[7]; for (int c = 0; c < 7; c++) x0[c] = pose[7 * k + c]; for (int c = 0; c < 7; c++) cand[7 * k + c] = x0[c]; continue; }
                 double dl[6], xp[7], x0[7];
                 for (int c = 0; c < 6; c++) dl[c] = step[6 * f + c] * scale[6 * f + c];
                 for (int c = 0; c < 7; c++) x0[c] = pose[7 * k + c];
                 pose_plus(x0, dl, xp);
-                for (int c = 0; c < 7; c++) { const double df = x0[c] - xp[c]; dn += df * df; }
+                if constexpr (NW == 1) { for (int c = 0; c < 7; c++) { const double df = x0[c] - xp[c]; dn = __builtin_fma(df, df, dn); } }
                 for (int c = 0; c < 7; c++) cand[7 * k + c] = xp[c];
             }
-            PG_GSYNC();
-            const double step_norm = sqrt(wave_sum(dn));
+            PG_BSYNC();
+            if constexpr (NW > 1) {                    // |x - candidate|^2 in NW = 1's order, from the stored candidate
+                if (wv == 0) for (int k = lane; k < G.P1; k += 64) {
+                    if (free_of[k] < 0) continue;
+                    for (int c = 0; c < 7; c++) { const double df = pose[7 * k + c] - cand[7 * k + c]; dn = __builtin_fma(df, df, dn); }
+                }
+            }
+            const double step_norm = sqrt(bc(wave_sum(dn)));
             const double cand_cost = evaluate(cand, false);
             bool stop = false, accepted = false;
             if (step_norm <= 1e-8 * (x_norm + 1e-8)) { term = ISV_TERM_PARAMETER_TOL; stop = true; }
             else if (fabs(x_cost - cand_cost) <= 1e-6 * x_cost) { term = ISV_TERM_FUNCTION_TOL; stop = true; }
-            if (stop) { if (lane == 0 && it < ISV_MAX_TRACE) { res.trace_cost[it] = x_cost; res.trace_accepted[it] = 0; } break; }
+            if (stop) { if (tid == 0 && it < ISV_MAX_TRACE) { res.trace_cost[it] = x_cost; res.trace_accepted[it] = 0; } break; }
             const double rel = (x_cost - cand_cost) / model_cost_change;
             if (rel > 1e-3) {
                 accepted = true;
-                for (int q0 = lane; q0 < 7 * G.P1; q0 += 256) {
+                for (int q0 = tid; q0 < 7 * G.P1; q0 += 4 * NT) {
                     double v[4];
-                    for (int u = 0; u < 4; u++) v[u] = q0 + 64 * u < 7 * G.P1 ? cand[q0 + 64 * u] : 0.0;
-                    for (int u = 0; u < 4; u++) if (q0 + 64 * u < 7 * G.P1) pose[q0 + 64 * u] = v[u];
+                    for (int u = 0; u < 4; u++) v[u] = q0 + NT * u < 7 * G.P1 ? cand[q0 + NT * u] : 0.0;
+                    for (int u = 0; u < 4; u++) if (q0 + NT * u < 7 * G.P1) pose[q0 + NT * u] = v[u];
                 }
-                PG_GSYNC();
+                PG_BSYNC();
                 x_norm = xnorm_of(pose);
                 x_cost = evaluate(pose, true);
                 scale_jac();
@@ -648,27 +704,30 @@ __global__ __launch_bounds__(64) void k_pgo(PgDev dv) {
                 radius = fmin(1e16, radius); decrease = 2.0; reuse_diag = false;
                 nsucc++;
             } else { radius /= decrease; decrease *= 2.0; reuse_diag = true; }
-            if (lane == 0 && it < ISV_MAX_TRACE) { res.trace_cost[it] = accepted ? x_cost : cand_cost; res.trace_accepted[it] = accepted ? 1 : 0; }
+            if (tid == 0 && it < ISV_MAX_TRACE) { res.trace_cost[it] = accepted ? x_cost : cand_cost; res.trace_accepted[it] = accepted ? 1 : 0; }
         }
     } else {
         term = ISV_TERM_GRADIENT_TOL;
-        if (lane == 0) res.initial_cost = x_cost;
+        if (tid == 0) res.initial_cost = x_cost;
     }
-    if (lane == 0) { res.iterations = it; res.termination = term; res.final_cost = x_cost; res.num_successful = nsucc; res.n_poses = G.P1; res.n_free = nf; }
+    if (tid == 0) { res.iterations = it; res.termination = term; res.final_cost = x_cost; res.num_successful = nsucc; res.n_poses = G.P1; res.n_free = nf; }
 
     // ================= ceres::Covariance: diagonal blocks of (J^T J)^-1 at the solution, tangent space ==================
     double *cov = dv.cov + (size_t)G.pose0 * 36;
-    for (int q = lane; q < G.P1 * 36; q += 64) cov[q] = 0.0;
-    PG_GSYNC();
+    for (int q = tid; q < G.P1 * 36; q += NT) cov[q] = 0.0;
+    PG_BSYNC();
     if (nf == 0) return;
     // the stored Jacobian is the Jacobi-scaled one at x: H_s = S H S, so H^-1 = S H_s^-1 S
     assemble();
-    for (int q = lane; q < n; q += 64) step[q] = 0.0;
-    PG_GSYNC();
-    if (!factor(step)) { if (lane == 0) res.status = ISV_ERR_NONFINITE; return; }
+    for (int q = tid; q < n; q += NT) step[q] = 0.0;
+    PG_BSYNC();
+    bool fok = false;
+    if (wv == 0) fok = factor(step);
+    if (bc(fok ? 1.0 : 0.0) == 0.0) { if (tid == 0) res.status = ISV_ERR_NONFINITE; return; }
     // Takahashi recurrence on the envelope, columns from the last to the first:
     //   Z(i,j) = [delta_ij L_jj^-T - sum_{k in colpat(j)} Z(i,k) L(k,j)] L_jj^-1      for i in {j} U colpat(j)
-    for (int j = nf - 1; j >= 0; j--) {
+    // (a recurrence over the columns: wavefront 0)
+    if (wv == 0) for (int j = nf - 1; j >= 0; j--) {
         const double *Li = BLK(L, j, j);
         const int c0 = CP(j), c1 = CP(j + 1);
         for (int qi = c0; qi <= c1; qi++) {            // the rows below j first: Z(j,j) needs Z(k,j), k in colpat(j)
@@ -695,7 +754,8 @@ __global__ __launch_bounds__(64) void k_pgo(PgDev dv) {
         }
         PG_GSYNC();
     }
-    for (int k = lane; k < G.P1; k += 64) {
+    if constexpr (NW > 1) __syncthreads();
+    for (int k = tid; k < G.P1; k += NT) {
         const int f = free_of[k];
         if (f < 0) continue;
         const double *Zd = BLK(Z, f, f);
@@ -724,7 +784,7 @@ struct isv_pgo {
     int64_t cache_hits = 0;
     isv_pgo_config_t cfg;
     std::string err;
-    int device = 0;
+    int device = 0, n_cus = 256;
     hipStream_t stream = nullptr;
     PgDev d{};
     std::vector<void *> allocs;
@@ -777,6 +837,7 @@ static int pgo_create_impl(isv_pgo *h) {
     PCHK(h, hipGetDeviceCount(&ndev));
     if (ndev <= 0) { h->err = "no HIP device"; return ISV_ERR_DEVICE; }
     PCHK(h, hipGetDevice(&h->device));
+    { int cu = 0; if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, h->device) == hipSuccess && cu > 0) h->n_cus = cu; else (void)hipGetLastError(); }
     PCHK(h, hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     for (auto &cs : h->cstream) PCHK(h, hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
     for (auto &ke : h->kev) for (auto &e : ke) PCHK(h, hipEventCreate(&e));
@@ -785,7 +846,7 @@ static int pgo_create_impl(isv_pgo *h) {
     h->cap_adj = 2 * h->cap_edge; h->cap_col = h->cap_blk;
     PgDev &d = h->d;
     PTRY(pal(h, &d.graphs, G)); PTRY(pal(h, &d.pose, h->cap_pose * 7)); PTRY(pal(h, &d.cand, h->cap_pose * 7)); PTRY(pal(h, &d.free_of, h->cap_pose));
-    PTRY(pal(h, &d.edges, h->cap_edge)); PTRY(pal(h, &d.eres, h->cap_edge * 6)); PTRY(pal(h, &d.ejac, h->cap_edge * 72));
+    PTRY(pal(h, &d.edges, h->cap_edge)); PTRY(pal(h, &d.eres, h->cap_edge * 6)); PTRY(pal(h, &d.ejac, h->cap_edge * 72)); PTRY(pal(h, &d.red, h->cap_edge * 6));
     PTRY(pal(h, &d.adj_ptr, h->cap_pose + G)); PTRY(pal(h, &d.adj, h->cap_adj));
     PTRY(pal(h, &d.start, h->cap_pose)); PTRY(pal(h, &d.rowptr, h->cap_pose + G)); PTRY(pal(h, &d.colptr, h->cap_pose + G)); PTRY(pal(h, &d.colrows, h->cap_col));
     PTRY(pal(h, &d.H, h->cap_blk * 36)); PTRY(pal(h, &d.L, h->cap_blk * 36)); PTRY(pal(h, &d.Z, h->cap_blk * 36));
@@ -1174,6 +1235,8 @@ extern "C" int isv_pgo_optimize_batch(isv_pgo_t *h, int32_t ng, const int32_t *n
     std::mutex err_mu, done_mu[isv_pgo::PG_CHUNKS];
     auto fail = [&](int rc, const std::string &msg) { std::lock_guard<std::mutex> lk(err_mu); if (fail_rc.load() == ISV_OK) { fail_rc.store(rc); h->err = msg; } };
 #define TCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { fail(ISV_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); return; } } while (0)
+    bool pgo_waves4 = ng <= h->n_cus;
+    if (const char *ev = getenv("ISV_PGO_WAVES")) pgo_waves4 = atoi(ev) > 1;
     auto enqueue_chunk = [&](int c) {
         const int g0 = chunk_lo(c), g1 = chunk_lo(c + 1);
         const Off &a = off[g0], &b = off[g1];
@@ -1187,7 +1250,9 @@ extern "C" int isv_pgo_optimize_batch(isv_pgo_t *h, int32_t ng, const int32_t *n
 #undef UPR
         PgDev dv = d; dv.g0 = g0;
         TCHK(hipEventRecord(h->kev[c][0], st));
-        hipLaunchKernelGGL(k_pgo, dim3(g1 - g0), dim3(64), idx_bytes, st, dv);
+        // (round 5) a call that leaves CUs idle gives every graph four wavefronts -- the same bits (k_pgo's header); ISV_PGO_WAVES=1 / 4 forces a form
+        if (pgo_waves4) hipLaunchKernelGGL(k_pgo<4>, dim3(g1 - g0), dim3(256), idx_bytes, st, dv);
+        else hipLaunchKernelGGL(k_pgo<1>, dim3(g1 - g0), dim3(64), idx_bytes, st, dv);
         TCHK(hipGetLastError());
         TCHK(hipEventRecord(h->kev[c][1], st));
         // results into the pinned staging (the caller's arrays are pageable: copied from there after the stream has drained)

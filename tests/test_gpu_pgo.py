@@ -151,6 +151,28 @@ def test_global_index_path_is_bitwise_the_lds_one(opt, monkeypatch):
         assert np.array_equal(abi.arr(a[k].cov), abi.arr(b[k].cov))
 
 
+@pytest.mark.parametrize("seed,K,loops", [(11, 300, 8), (3, 200, 5), (7, 40, 1), (9, 64, 0)])
+def test_four_wavefronts_per_graph_are_bitwise_the_one_wavefront_form(opt, monkeypatch, seed, K, loops):
+    """round 5: a call that leaves CUs idle runs k_pgo<4> (evaluation, assembly and the element-wise passes on four wavefronts, the
+    recurrences on wavefront 0); a call that fills the GPU runs k_pgo<1>.  ISV_PGO_WAVES forces either form (read per call): every
+    trace entry, pose, covariance and drift has to be the same bits."""
+    kf, P, first = pg.make_pose_graph(seed, K, loops)
+    out = []
+    for waves in ("1", "4"):
+        monkeypatch.setenv("ISV_PGO_WAVES", waves)
+        g = pg.clone_keyframes(kf)
+        out.append((g, opt.optimize(g, first, K - 1)))
+    (a, ra), (b, rb) = out
+    assert ra.status == 0 and rb.status == 0
+    assert (ra.iterations, ra.termination, ra.num_successful) == (rb.iterations, rb.termination, rb.num_successful)
+    assert list(ra.trace_cost) == list(rb.trace_cost) and list(ra.trace_accepted) == list(rb.trace_accepted)
+    assert ra.final_cost == rb.final_cost and ra.yaw_drift == rb.yaw_drift
+    assert np.array_equal(abi.arr(ra.r_drift), abi.arr(rb.r_drift)) and np.array_equal(abi.arr(ra.t_drift), abi.arr(rb.t_drift))
+    for k in range(len(a)):
+        assert np.array_equal(abi.arr(a[k].T_w_i), abi.arr(b[k].T_w_i)) and np.array_equal(abi.arr(a[k].R_w_i), abi.arr(b[k].R_w_i)), k
+        assert np.array_equal(abi.arr(a[k].cov), abi.arr(b[k].cov)), k
+
+
 def test_loop_pose_output_file(opt, tmp_path):
     """./loop_pose_output.txt (pose_graph.cpp:412-423): one `fixed` row per keyframe, stamp px py pz qw qx qy qz of getPose()"""
     kf, P, first = pg.make_pose_graph(30, 50, 2)
