@@ -63,6 +63,7 @@ struct PgDev {
     int32_t *free_of;            // [poses] free index of a local pose or -1
     PgEdge *edges;
     double *eres, *ejac;         // [edges][6], [edges][72]: corrected residual, Jacobians (block a | block b), Jacobi-scaled
+    double *Bt;                  // [free poses][36]: B_c = L_cc^-1 L(c, c-1) of every chain row c (factor(): a loop row's step through column c)
     double *red;                 // [edges][6]: per-item terms of the sums a multi-wavefront launch hands to wavefront 0 (k_pgo<4>)
     int32_t *adj_ptr, *adj;      // per free pose: the residual blocks touching it, (edge << 1) | side
     int32_t *start, *rowptr;     // skyline: first column of row r, block offset of row r   (per free pose; rowptr has nf + 1)
@@ -248,6 +249,7 @@ __global__ __launch_bounds__(64 * NW) void k_pgo(PgDev dv) {
         return r;
     };
     double *red = dv.red + (size_t)G.edge0 * 6;
+    double *Bt = dv.Bt + (size_t)G.vec0 * 6;
     double *pose = dv.pose + (size_t)G.pose0 * 7, *cand = dv.cand + (size_t)G.pose0 * 7;
     const int32_t *free_of = dv.free_of + G.pose0;
     PgEdge *edges = dv.edges + G.edge0;
@@ -428,39 +430,9 @@ __global__ __launch_bounds__(64 * NW) void k_pgo(PgDev dv) {
                 have_nx = true;
             }
             if (loop_row) PG_GSYNC();                  // blocks of earlier rows written since the last fence
-            // inside a loop row the operands of the NEXT step (H(r,c+1), row eb of L(c+1,c) and of L_{c+1,c+1}^-1) are loaded
-            // one step ahead whenever column c + 1 is a chain row: the step itself then runs from registers and LDS
-            double pA = 0, pY[6] = {0, 0, 0, 0, 0, 0}, pLi[6] = {0, 0, 0, 0, 0, 0};
-            bool pnext = false;
-            for (int c = s0; c < r; c++) {
-                // S = A(r,c) - sum_{m = max(start[r], start[c])}^{c-1} L(r,m) L(c,m)^T ;  L(r,c) = S L_cc^-T
+            // one column of row r the general way: S = A(r,c) - sum_{m = max(start[r], start[c])}^{c-1} L(r,m) L(c,m)^T ;  L(r,c) = S L_cc^-T
+            auto general_step = [&](int c) {
                 const int sc = ST(c), m0 = s0 > sc ? s0 : sc;
-                const double cA = pA;
-                double cY[6], cLi[6];
-                for (int k = 0; k < 6; k++) { cY[k] = pY[k]; cLi[k] = pLi[k]; }
-                const bool have = pnext;
-                pnext = false;
-                if (loop_row && c + 1 < r && ST(c + 1) >= c) {
-                    if (e < 36) {
-                        pA = BLK(H, r, c + 1)[e];
-                        const double *Y = BLK(L, c + 1, c), *Li = BLK(L, c + 1, c + 1);
-                        for (int k = 0; k < 6; k++) { pY[k] = Y[eb * 6 + k]; pLi[k] = Li[eb * 6 + k]; }
-                    }
-                    pnext = true;
-                }
-                if (have) {                            // (column c is a chain row: the only earlier block of this row it meets is L(r, c-1) = T1)
-                    double acc = cA;
-                    if (e < 36) { for (int k = 0; k < 6; k++) acc -= T1[ea * 6 + k] * cY[k]; }
-                    PG_LSYNC();
-                    if (e < 36) T0[e] = acc;
-                    PG_LSYNC();
-                    double x = 0;
-                    if (e < 36) { for (int k = 0; k <= eb; k++) x += T0[ea * 6 + k] * cLi[k]; }
-                    PG_LSYNC();
-                    if (e < 36) { T1[e] = x; BLK(L, r, c)[e] = x; }
-                    PG_LSYNC();
-                    continue;
-                }
                 if (m0 < c - 1) PG_GSYNC();            // several blocks of THIS row are read back (column c is a loop row)
                 double acc = 0;
                 if (e < 36) {
@@ -485,6 +457,48 @@ __global__ __launch_bounds__(64 * NW) void k_pgo(PgDev dv) {
                 PG_LSYNC();
                 if (e < 36) { T1[e] = x; BLK(L, r, c)[e] = x; }
                 PG_LSYNC();
+            };
+            if (!loop_row) { for (int c = s0; c < r; c++) general_step(c); }
+            else {
+                // (round 5) A loop closure's row walks its envelope column by column, every step waiting for the one before: ~900 of the
+                // dependent block steps of a factorisation of 200 keyframes / 5 loops, and each took one memory latency (its operands were
+                // loaded ONE step ahead: 0.45 us per step whatever the arithmetic).  An interior column c is a chain row this row has no
+                // factor with -- H(r,c) = 0 --, so L(r,c) = -L(r,c-1) L(c,c-1)^T L_cc^-T = -L(r,c-1) B_c^T with B_c left behind by row c:
+                // ONE 6 x 6 product and two LDS hand-overs.  H(r,c) and B_c are loaded PD steps ahead into a register ring (the
+                // envelope is contiguous in both); any other column takes general_step (it loads what it needs itself).
+                constexpr int PD = 8;
+                double rA[PD], rB[PD][6];
+                // (the row's blocks of H and L and the chain rows' B are contiguous in c: one base address each, no index look-ups per step)
+                const int el = e < 36 ? e : 0;
+                const double *const Hr = BLK(H, r, s0) + el, *const Br = Bt + (size_t)s0 * 36 + (el % 6) * 6;
+                double *const Lr = BLK(L, r, s0) + el;
+                auto prefetch = [&](double &pa, double *pb, int c) {
+                    const int dc = (c < r ? c : r - 1) - s0;                            // (past the row: a valid address, never used)
+                    pa = Hr[dc * 36];
+                    for (int k = 0; k < 6; k++) pb[k] = Br[dc * 36 + k];
+                };
+                general_step(s0);
+#pragma unroll
+                for (int u = 0; u < PD; u++) prefetch(rA[u], rB[u], s0 + 1 + u);
+                for (int cb = s0 + 1; cb < r; cb += PD) {
+#pragma unroll
+                    for (int u = 0; u < PD; u++) {
+                        const int c = cb + u;
+                        if (c < r) {
+                            const double cA = rA[u];
+                            double cB[6];
+                            for (int k = 0; k < 6; k++) cB[k] = rB[u][k];
+                            prefetch(rA[u], rB[u], c + PD);
+                            if (ST(c) == c - 1 && __all(e >= 36 || cA == 0.0)) {
+                                double x = 0;
+                                if (e < 36) { for (int k = 0; k < 6; k++) x -= T1[ea * 6 + k] * cB[k]; }
+                                PG_LSYNC();
+                                if (e < 36) { T1[e] = x; Lr[(c - s0) * 36] = x; }
+                                PG_LSYNC();
+                            } else general_step(c);
+                        }
+                    }
+                }
             }
             // diagonal: D = A(r,r) + damp - sum_m L(r,m) L(r,m)^T
             if (loop_row) PG_GSYNC();
@@ -498,86 +512,119 @@ __global__ __launch_bounds__(64 * NW) void k_pgo(PgDev dv) {
             if (e < 36) T2[e] = acc;
             PG_LSYNC();
             ok = pg_chol_inv6(T2, lane);
-            if (e < 36) BLK(L, r, r)[e] = T2[e];
+            if (e < 36) {
+                BLK(L, r, r)[e] = T2[e];
+                // B_r = L_rr^-1 L(r, r-1) for the loop rows that will pass through column r (zero where row r has no earlier block)
+                double b = 0;
+                if (s0 == r - 1) { for (int k = 0; k <= ea; k++) b += T2[ea * 6 + k] * T1[k * 6 + eb]; }
+                Bt[(size_t)r * 36 + e] = b;
+            }
         }
         PG_GSYNC();
         return ok;
     };
     // x = (L L^T)^-1 b  -> xs ; lanes 0..5 own the components of a block.  The previous block of the recurrence stays in
-    // registers (v_readlane) and the two blocks of L a chain row needs are loaded one row ahead, so a step is a few dozen
-    // FMAs; only loop rows exchange through global memory (fences as in factor()).
+    // registers (v_readlane); only loop rows exchange through global memory (fences as in factor()).
+    // (round 5) The blocks of L a row needs -- its diagonal block and the one towards its chain neighbour -- and its right-hand side
+    // are loaded PS rows AHEAD into a register ring: with the loads one row ahead (forward) or not ahead at all (backward) every one
+    // of the 2 nf steps waited for a memory latency, 0.74 us per step for a few dozen FMAs.  The backward pass re-reads the ring's
+    // right-hand sides after a loop row has updated them.
     auto solve = [&](const double *b, double *xs) {
         const int ln = lane < 6 ? lane : 0;
+        constexpr int PS = 8;
         double prev = 0;                               // y_{r-1} (forward) / x_{r+1} (backward), component = lane
-        double nX[6], nLi[6], nb = 0;                  // prefetched: row ln of L(r, r-1), row ln of L_rr^-1, b_r
-        bool have_nx = false;
-        for (int r = 0; r < nf; r++) {                 // forward: y_r = L_rr^-1 (b_r - sum_{m<r} L(r,m) y_m)
-            const int s0 = ST(r);
-            double cX[6], cLi[6], cb = nb;
-            const bool pre = have_nx;
-            for (int k = 0; k < 6; k++) { cX[k] = nX[k]; cLi[k] = nLi[k]; }
-            have_nx = false;
-            if (r + 1 < nf && ST(r + 1) == r) {
-                const double *X = BLK(L, r + 1, r), *Li = BLK(L, r + 1, r + 1);
-                for (int k = 0; k < 6; k++) { nX[k] = X[ln * 6 + k]; nLi[k] = Li[ln * 6 + k]; }
-                nb = b[6 * (r + 1) + ln];
-                have_nx = true;
-            }
-            if (s0 < r - 1) PG_GSYNC();
-            double pv[6];
-            for (int k = 0; k < 6; k++) pv[k] = readlane_d(prev, k);
-            double v = 0;
-            if (pre) {
-                v = cb;
-                for (int k = 0; k < 6; k++) v -= cX[k] * pv[k];
-            } else {
-                const double *Li = BLK(L, r, r);
-                for (int k = 0; k < 6; k++) cLi[k] = Li[ln * 6 + k];
-                v = b[6 * r + ln];
-                for (int m = s0; m < r; m++) {
-                    const double *X = BLK(L, r, m);
-                    if (m == r - 1) { for (int k = 0; k < 6; k++) v -= X[ln * 6 + k] * pv[k]; }
-                    else { for (int k = 0; k < 6; k++) v -= X[ln * 6 + k] * ysol[6 * m + k]; }
+        {
+            double fX[PS][6], fLi[PS][6], fb[PS];      // row ln of L(r, r-1), row ln of L_rr^-1, b_r of the rows r .. r + PS - 1
+            auto fpf = [&](double *X6, double *Li6, double &bb, int rr) {
+                const int q = rr < nf ? rr : nf - 1;
+                const double *Li = BLK(L, q, q), *X = ST(q) < q ? BLK(L, q, q - 1) : Li;          // (no earlier block: a valid address, never used)
+                for (int k = 0; k < 6; k++) { X6[k] = X[ln * 6 + k]; Li6[k] = Li[ln * 6 + k]; }
+                bb = b[6 * q + ln];
+            };
+#pragma unroll
+            for (int u = 0; u < PS; u++) fpf(fX[u], fLi[u], fb[u], u);
+            for (int r0 = 0; r0 < nf; r0 += PS) {      // forward: y_r = L_rr^-1 (b_r - sum_{m<r} L(r,m) y_m)
+#pragma unroll
+                for (int u = 0; u < PS; u++) {
+                    const int r = r0 + u;
+                    if (r < nf) {
+                        const int s0 = ST(r);
+                        double cX[6], cLi[6];
+                        const double cb = fb[u];
+                        for (int k = 0; k < 6; k++) { cX[k] = fX[u][k]; cLi[k] = fLi[u][k]; }
+                        fpf(fX[u], fLi[u], fb[u], r + PS);
+                        if (s0 < r - 1) PG_GSYNC();
+                        double pv[6];
+                        for (int k = 0; k < 6; k++) pv[k] = readlane_d(prev, k);
+                        double v = cb;
+                        if (s0 == r - 1) { for (int k = 0; k < 6; k++) v -= cX[k] * pv[k]; }
+                        else {
+                            for (int m = s0; m < r; m++) {
+                                const double *X = BLK(L, r, m);
+                                if (m == r - 1) { for (int k = 0; k < 6; k++) v -= X[ln * 6 + k] * pv[k]; }
+                                else { for (int k = 0; k < 6; k++) v -= X[ln * 6 + k] * ysol[6 * m + k]; }
+                            }
+                        }
+                        double y = 0;
+                        for (int k = 0; k < 6; k++) { const double vk = readlane_d(v, k); if (k <= ln) y += cLi[k] * vk; }
+                        if (lane < 6) ysol[6 * r + lane] = y;
+                        prev = y;
+                    }
                 }
             }
-            double y = 0;
-            for (int k = 0; k < 6; k++) { const double vk = readlane_d(v, k); if (k <= ln) y += cLi[k] * vk; }
-            if (lane < 6) ysol[6 * r + lane] = y;
-            prev = y;
         }
         PG_GSYNC();
         // backward: x_r = L_rr^-T (y_r - sum_{i in colpat(r)} L(i,r)^T x_i).  A loop row i subtracts its L(i,c)^T x_i from y_c of
         // every column c it covers as soon as x_i is known (lanes over the span); what is left for a row is the term of row
         // r + 1 when that is a chain row, from registers.
         prev = 0;
-        bool next_is_chain = false;                    // row r + 1 exists and its envelope starts at r
-        for (int r = nf - 1; r >= 0; r--) {
-            const double *Li = BLK(L, r, r);
-            double cLi[6], cX[6];
-            for (int k = 0; k < 6; k++) cLi[k] = Li[k * 6 + ln];
-            if (next_is_chain) { const double *X = BLK(L, r + 1, r); for (int k = 0; k < 6; k++) cX[k] = X[k * 6 + ln]; }
-            double pv[6];
-            for (int k = 0; k < 6; k++) pv[k] = readlane_d(prev, k);
-            double v = ysol[6 * r + ln];
-            if (next_is_chain) { for (int k = 0; k < 6; k++) v -= cX[k] * pv[k]; }
-            double x = 0;
-            for (int k = 0; k < 6; k++) { const double vk = readlane_d(v, k); if (k >= ln) x += cLi[k] * vk; }
-            if (lane < 6) xs[6 * r + lane] = x;
-            prev = x;
-            const int s0 = ST(r);
-            next_is_chain = s0 == r - 1;
-            if (s0 < r - 1) {                          // loop row: y_c -= L(r,c)^T x_r for c in [s0, r)
-                double xr[6];
-                for (int k = 0; k < 6; k++) xr[k] = readlane_d(x, k);
-                PG_GSYNC();
-                for (int q = lane; q < (r - s0) * 6; q += 64) {
-                    const int c = s0 + q / 6, comp = q % 6;
-                    const double *X = BLK(L, r, c);
-                    double a = ysol[6 * c + comp];
-                    for (int k = 0; k < 6; k++) a -= X[k * 6 + comp] * xr[k];
-                    ysol[6 * c + comp] = a;
+        {
+            double gLi[PS][6], gX[PS][6], gy[PS];      // column ln of L_rr^-1, column ln of L(r+1, r), y_r of the rows r .. r - PS + 1
+            auto bpf = [&](double *Li6, double *X6, double &yy, int rr) {
+                const int q = rr >= 0 ? rr : 0;
+                const double *Li = BLK(L, q, q), *X = (q + 1 < nf && ST(q + 1) == q) ? BLK(L, q + 1, q) : Li;      // (row q + 1 not a chain row: never used)
+                for (int k = 0; k < 6; k++) { Li6[k] = Li[k * 6 + ln]; X6[k] = X[k * 6 + ln]; }
+                yy = ysol[6 * q + ln];
+            };
+#pragma unroll
+            for (int u = 0; u < PS; u++) bpf(gLi[u], gX[u], gy[u], nf - 1 - u);
+            bool next_is_chain = false;                // row r + 1 exists and its envelope starts at r
+            for (int r0 = nf - 1; r0 >= 0; r0 -= PS) {
+#pragma unroll
+                for (int u = 0; u < PS; u++) {
+                    const int r = r0 - u;
+                    if (r >= 0) {
+                        double cLi[6], cX[6];
+                        double v = gy[u];
+                        for (int k = 0; k < 6; k++) { cLi[k] = gLi[u][k]; cX[k] = gX[u][k]; }
+                        bpf(gLi[u], gX[u], gy[u], r - PS);
+                        double pv[6];
+                        for (int k = 0; k < 6; k++) pv[k] = readlane_d(prev, k);
+                        if (next_is_chain) { for (int k = 0; k < 6; k++) v -= cX[k] * pv[k]; }
+                        double x = 0;
+                        for (int k = 0; k < 6; k++) { const double vk = readlane_d(v, k); if (k >= ln) x += cLi[k] * vk; }
+                        if (lane < 6) xs[6 * r + lane] = x;
+                        prev = x;
+                        const int s0 = ST(r);
+                        next_is_chain = s0 == r - 1;
+                        if (s0 < r - 1) {              // loop row: y_c -= L(r,c)^T x_r for c in [s0, r)
+                            double xr[6];
+                            for (int k = 0; k < 6; k++) xr[k] = readlane_d(x, k);
+                            PG_GSYNC();
+                            for (int q = lane; q < (r - s0) * 6; q += 64) {
+                                const int c = s0 + q / 6, comp = q % 6;
+                                const double *X = BLK(L, r, c);
+                                double a = ysol[6 * c + comp];
+                                for (int k = 0; k < 6; k++) a -= X[k * 6 + comp] * xr[k];
+                                ysol[6 * c + comp] = a;
+                            }
+                            PG_GSYNC();
+                            // the ring's right-hand sides were read before this update: slot j holds row r0 - j (j > u) or r0 - PS - j (already refilled)
+#pragma unroll
+                            for (int j = 0; j < PS; j++) { const int rowj = j <= u ? r0 - PS - j : r0 - j; gy[j] = ysol[6 * (rowj >= 0 ? rowj : 0) + ln]; }
+                        }
+                    }
                 }
-                PG_GSYNC();
             }
         }
         PG_GSYNC();
@@ -846,7 +893,7 @@ static int pgo_create_impl(isv_pgo *h) {
     h->cap_adj = 2 * h->cap_edge; h->cap_col = h->cap_blk;
     PgDev &d = h->d;
     PTRY(pal(h, &d.graphs, G)); PTRY(pal(h, &d.pose, h->cap_pose * 7)); PTRY(pal(h, &d.cand, h->cap_pose * 7)); PTRY(pal(h, &d.free_of, h->cap_pose));
-    PTRY(pal(h, &d.edges, h->cap_edge)); PTRY(pal(h, &d.eres, h->cap_edge * 6)); PTRY(pal(h, &d.ejac, h->cap_edge * 72)); PTRY(pal(h, &d.red, h->cap_edge * 6));
+    PTRY(pal(h, &d.edges, h->cap_edge)); PTRY(pal(h, &d.eres, h->cap_edge * 6)); PTRY(pal(h, &d.ejac, h->cap_edge * 72)); PTRY(pal(h, &d.red, h->cap_edge * 6)); PTRY(pal(h, &d.Bt, h->cap_pose * 36));
     PTRY(pal(h, &d.adj_ptr, h->cap_pose + G)); PTRY(pal(h, &d.adj, h->cap_adj));
     PTRY(pal(h, &d.start, h->cap_pose)); PTRY(pal(h, &d.rowptr, h->cap_pose + G)); PTRY(pal(h, &d.colptr, h->cap_pose + G)); PTRY(pal(h, &d.colrows, h->cap_col));
     PTRY(pal(h, &d.H, h->cap_blk * 36)); PTRY(pal(h, &d.L, h->cap_blk * 36)); PTRY(pal(h, &d.Z, h->cap_blk * 36));
