@@ -463,7 +463,7 @@ def main():
             pgo = {"workload": f"PoseGraph::optimizeCS pass (LM <= 10 iterations + marginal covariances + write-back) over {K} keyframes with {loops} loop closures, synthetic",
                    "ms_one_graph": 1e3 * t_one, "lm_iterations_one_graph": it_one,
                    "batch_graphs": S, "ms_per_batch_call": 1e3 * t_all, "value": S / t_all, "unit": "graphs/s", "lm_iterations_batch_mean": it_all,
-                   "what": "one isv_pgo_optimize_batch call: host structure analysis + H2D + k_pgo (one wavefront per graph) + D2H + write-back",
+                   "what": "one isv_pgo_optimize_batch call: host structure analysis + H2D + k_pgo (a call that leaves CUs idle: four wavefronts per graph, k_pgo<4>; a batch that fills the GPU: one, k_pgo<1>; same bits) + D2H + write-back",
                    "kernel_ms_one_graph": k_one, "kernel_ms_batch": k_all,
                    "roofline": {"kernel": "k_pgo", "bound": "fp64-valu-latency", "achieved": flops_all / (k_all * 1e-3) / 1e12 if k_all else None, "peak": FP64_PEAK_TFLOPS,
                                 "unit": "TFLOP/s", "frac": (flops_all / (k_all * 1e-3) / 1e12 / FP64_PEAK_TFLOPS) if k_all else None, "traffic": None,
