@@ -135,10 +135,11 @@ static int create_impl(isv_backend *h) {
         ARENA(s.Ps, d.Ps, B * N * 3); ARENA(s.Rs, d.Rs, B * N * 9); ARENA(s.Vs, d.Vs, B * N * 3); ARENA(s.Bas, d.Bas, B * N * 3); ARENA(s.Bgs, d.Bgs, B * N * 3);
         ARENA(s.tic, d.tic, B * 3); ARENA(s.ric, d.ric, B * 9);
         ARENA(s.se3, d.se3, B); ARENA(s.lin9, d.lin9, B); ARENA(s.relpose, d.relpose, B * (c.n_vo - 1)); ARENA(s.rollpitch, d.rollpitch, B * (size_t)c.max_rollpitch);
+        ARENA(s.depth, d.depth, L);            // (Ps .. depth: what isv_batch_download brings back from this block, in one copy)
         ARENA(s.n_rp, d.n_rp, B); ARENA(s.margin_old, d.margin_old, B); ARENA(s.header0, d.header0, B);
         ARENA(s.imu_skip, d.imu_skip, NI); ARENA(s.imu_in, d.imu_in, NI * ISV_IMU_IN); ARENA(s.imu_cov, d.imu_cov, NI * 225);
         ARENA(s.tile_win, d.tile_win, T); ARENA(s.tile_f0, d.tile_f0, T); ARENA(s.tile_n, d.tile_n, T);
-        ARENA(s.depth, d.depth, L); ARENA(s.lm_host, d.lm_host, L); ARENA(s.lm_optr, h->d_optr, L + B); ARENA(s.obs_raw, h->d_obs_raw, F * 3);
+        ARENA(s.lm_host, d.lm_host, L); ARENA(s.lm_optr, h->d_optr, L + B); ARENA(s.obs_raw, h->d_obs_raw, F * 3);
 #undef ARENA
         size_t tot = 0;
         for (Item &q : it) { q.off = tot; tot += (q.bytes + 255) / 256 * 256; }
@@ -152,6 +153,26 @@ static int create_impl(isv_backend *h) {
             *q.hp = (char *)hb + q.off; *q.dp = (char *)db + q.off;
         }
         h->arena_h = hb; h->arena_d = db; h->arena_bytes = tot;
+        h->down_a_off = (size_t)((char *)d.Ps - (char *)db); h->down_a_bytes = (size_t)((char *)d.depth - (char *)d.Ps) + sizeof(double) * L;
+        // the solver's outputs: one pinned and one device block as well (a download was 24 copy commands: ~0.8 of its 1.7 ms)
+        std::vector<Item> dn;
+#define ARENA(hptr, dptr, cnt) dn.push_back(Item{(void **)&(hptr), (void **)&(dptr), sizeof(*(hptr)) * (size_t)(cnt), 0})
+        ARENA(s.pose, d.pose, B * N * 7); ARENA(s.sb, d.sb, B * N * 9); ARENA(s.ex, d.ex, B * 7); ARENA(s.lam, d.lam, L); ARENA(s.solve_flag, d.solve_flag, L);
+        ARENA(s.st, d.st, B); ARENA(h->stage.tc, d.trace_cost, B * ISV_MAX_TRACE); ARENA(h->stage.tr, d.trace_radius, B * ISV_MAX_TRACE);
+        ARENA(h->stage.ts, d.trace_step, B * ISV_MAX_TRACE); ARENA(h->stage.ta, d.trace_acc, B * ISV_MAX_TRACE); ARENA(h->stage.marg, d.marg, B);
+#undef ARENA
+        size_t tot2 = 0;
+        for (Item &q : dn) { q.off = tot2; tot2 += (q.bytes + 255) / 256 * 256; }
+        void *hb2 = nullptr, *db2 = nullptr;
+        HIPCHK(h, hipHostMalloc(&hb2, tot2 ? tot2 : 1, hipHostMallocDefault)); h->hallocs.push_back(hb2);
+        HIPCHK(h, hipMalloc(&db2, tot2 ? tot2 : 1)); h->allocs.push_back(db2);
+        HIPCHK(h, hipMemset(db2, 0, tot2 ? tot2 : 1)); memset(hb2, 0, tot2 ? tot2 : 1);
+        for (Item &q : dn) {
+            drop(h->hallocs, *q.hp, true); drop(h->allocs, *q.dp, false);
+            *q.hp = (char *)hb2 + q.off; *q.dp = (char *)db2 + q.off;
+        }
+        drop(h->hallocs, h->stage.st, true); h->stage.st = s.st;      // (the solver's staging of the solve states: the same record)
+        h->down_h = hb2; h->down_d = db2; h->down_bytes = tot2;
     }
     if (d.est_ex) {
         if (!d.lds_T) { h->err = "estimate_extrinsic = 1 is built for the LDS solver path only (ALL_BUF_SIZE <= 19)"; return ISV_ERR_UNSUPPORTED; }
@@ -704,13 +725,21 @@ extern "C" int isv_batch_download(isv_backend_t *h, int32_t n, isv_window_t *con
     DevBatch &d = h->d; hipStream_t st = h->stream; auto &s = h->h; const isv_config_t &c = h->cfg;
     const size_t N = d.N, Nr = d.Nr, L = d.Ltot;          // device stride (incl. the extrinsic's pseudo-frame), real frames
 #define D2H(dst, src, cnt) HIPCHK(h, hipMemcpyAsync(dst, src, sizeof(*(src)) * (size_t)(cnt), hipMemcpyDeviceToHost, st))
+    // (round 5) a batch that uses most of the handle comes back in TWO copies (a copy command costs 20-50 us of stream time whatever its
+    // size: the 24 of the array-by-array form were ~0.8 ms of a 1024-window download's 1.7); a small one array by array
+    const bool two_copies = h->down_bytes > 0 && (size_t)n * 2 >= (size_t)c.max_batch && !getenv("ISV_DOWNLOAD_ARRAYS");
+    if (two_copies) {
+        HIPCHK(h, hipMemcpyAsync((char *)h->arena_h + h->down_a_off, (char *)h->arena_d + h->down_a_off, h->down_a_bytes, hipMemcpyDeviceToHost, st));
+        HIPCHK(h, hipMemcpyAsync(h->down_h, h->down_d, h->down_bytes, hipMemcpyDeviceToHost, st));
+    } else {
     D2H(s.Ps, d.Ps, n * N * 3); D2H(s.Rs, d.Rs, n * N * 9); D2H(s.Vs, d.Vs, n * N * 3); D2H(s.Bas, d.Bas, n * N * 3); D2H(s.Bgs, d.Bgs, n * N * 3);
     D2H(s.tic, d.tic, (size_t)n * 3); D2H(s.ric, d.ric, (size_t)n * 9); D2H(s.depth, d.depth, L); D2H(s.solve_flag, d.solve_flag, L);
     D2H(s.se3, d.se3, n); D2H(s.lin9, d.lin9, n); D2H(s.relpose, d.relpose, (size_t)n * (c.n_vo - 1)); D2H(s.rollpitch, d.rollpitch, (size_t)n * c.max_rollpitch);
     D2H(s.pose, d.pose, n * N * 7); D2H(s.sb, d.sb, n * N * 9); D2H(s.ex, d.ex, (size_t)n * 7); D2H(s.lam, d.lam, L);
     D2H(s.st, d.st, n);
+    }
     HIPCHK(h, hipStreamSynchronize(st));
-    int rcs = isv_solver_download(h->d, st, n, h->stage, summary, marg, h->err);
+    int rcs = isv_solver_download(h->d, st, n, h->stage, summary, marg, h->err, two_copies);
     if (rcs != ISV_OK) return rcs;
     auto unpack = [&](int b) {
         isv_window_t *w = ws[b];

@@ -48,6 +48,10 @@ struct isv_backend {
     double *Ps0 = nullptr, *Rs0 = nullptr, *Vs0 = nullptr, *Bas0 = nullptr, *Bgs0 = nullptr, *depth0 = nullptr, *tic0 = nullptr, *ric0 = nullptr;
     isv_se3_prior_t *se30 = nullptr; isv_linear9_t *lin90 = nullptr; isv_relpose_t *relpose0 = nullptr; isv_rollpitch_t *rollpitch0 = nullptr;
     void *arena_h = nullptr, *arena_d = nullptr; size_t arena_bytes = 0;      // the raw upload's arrays, one pinned and one device block of the same layout (one copy per upload)
+    // (round 5) isv_batch_download in TWO copies: the window's state / priors / depths sit next to each other inside the upload block
+    // (down_a_off .. + down_a_bytes), the solver's outputs (tangent state, depth flags, traces, marginalisation records) in a block of their own
+    size_t down_a_off = 0, down_a_bytes = 0;
+    void *down_h = nullptr, *down_d = nullptr; size_t down_bytes = 0;
     int32_t *d_optr = nullptr; double *d_obs_raw = nullptr;     // device copies of the raw CSR (isv_batch_upload -> k_upload_build)
     bool dev_build = false;       // this handle derives the solver's view of an upload on the device (ISV_HOST_PACK=1: the host packer, for A/B and the bitwise test)
     int resident = 0;

@@ -69,5 +69,5 @@ struct SolverStage { SolveState *st; double *tc, *tr, *ts; int32_t *ta; isv_marg
 // isv_batch_upload's device half (isv_sequence.hip): raw CSR -> lm_* / f_* / pg_* arrays
 size_t upload_build_lds_bytes(int N, int lcap);
 int isv_upload_build_enqueue(DevBatch &d, const int32_t *optr, const double *obs_raw, int lcap, hipStream_t st);
-int isv_solver_download(DevBatch &d, hipStream_t st, int n, const SolverStage &stage, isv_summary_t *summary, isv_marg_result_t *marg, std::string &err);
+int isv_solver_download(DevBatch &d, hipStream_t st, int n, const SolverStage &stage, isv_summary_t *summary, isv_marg_result_t *marg, std::string &err, bool staged = false);
 int isv_solver_debug_read(DevBatch &d, hipStream_t st, int what, double *out, int64_t count, std::string &err);

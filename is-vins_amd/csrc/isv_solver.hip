@@ -688,9 +688,11 @@ int isv_solver_enqueue(DevBatch &d, const SolverHost &hc, hipStream_t st, hipStr
     return ISV_OK;
 }
 
-int isv_solver_download(DevBatch &d, hipStream_t st, int n, const SolverStage &g, isv_summary_t *summary, isv_marg_result_t *marg, std::string &err) {
+// staged: the caller has brought the records into g already (isv_batch_download's two-copy form) and synchronised
+int isv_solver_download(DevBatch &d, hipStream_t st, int n, const SolverStage &g, isv_summary_t *summary, isv_marg_result_t *marg, std::string &err, bool staged) {
     if (!summary && !marg) return ISV_OK;
     const size_t nt = (size_t)n * ISV_MAX_TRACE;
+    if (!staged) {
     if (summary) {
         HCHK(hipMemcpyAsync(g.st, d.st, sizeof(SolveState) * n, hipMemcpyDeviceToHost, st));
         HCHK(hipMemcpyAsync(g.tc, d.trace_cost, sizeof(double) * nt, hipMemcpyDeviceToHost, st));
@@ -700,6 +702,7 @@ int isv_solver_download(DevBatch &d, hipStream_t st, int n, const SolverStage &g
     }
     if (marg) HCHK(hipMemcpyAsync(g.marg, d.marg, sizeof(isv_marg_result_t) * n, hipMemcpyDeviceToHost, st));
     HCHK(hipStreamSynchronize(st));
+    }
     if (marg) memcpy(marg, g.marg, sizeof(isv_marg_result_t) * n);
     if (summary) {
         for (int b = 0; b < n; b++) {
