@@ -208,11 +208,15 @@ static bool finite_all(const double *p, size_t n) {
 }
 
 // pack one caller window into its slice of the pinned staging area (offsets fixed by the caller's first pass)
-static int pack_window(isv_backend *h, int b, const isv_window_t *w, size_t L, size_t F, size_t T, std::string &err, const bool raw = false, const bool want_tiles = true) {
+// phase (raw uploads, round 5): 0 = the whole window; 1 = what lies in the FIRST part of the upload block (states, priors, depths, IMU records), 2 = the
+// rest (start frames, observation offsets and points, tiles) -- isv_batch_upload sends the first part while the host threads still pack the second
+static int pack_window(isv_backend *h, int b, const isv_window_t *w, size_t L, size_t F, size_t T, std::string &err, const bool raw = false, const bool want_tiles = true, const int phase = 0) {
+    const bool doA = phase != 2, doB = phase != 1;
     const isv_config_t &c = h->cfg;
     const int N = c.n_frames, Nd = h->d.N;        // real frames; device frames (+ the extrinsic's pseudo-frame)
     auto &s = h->h;
     const size_t f_off = F, lm_off = L;
+    if (doA) {
     memcpy(s.Ps + (size_t)b * Nd * 3, w->Ps, sizeof(double) * N * 3); memcpy(s.Rs + (size_t)b * Nd * 9, w->Rs, sizeof(double) * N * 9);
     memcpy(s.Vs + (size_t)b * Nd * 3, w->Vs, sizeof(double) * N * 3); memcpy(s.Bas + (size_t)b * Nd * 3, w->Bas, sizeof(double) * N * 3);
     memcpy(s.Bgs + (size_t)b * Nd * 3, w->Bgs, sizeof(double) * N * 3);
@@ -225,24 +229,28 @@ static int pack_window(isv_backend *h, int b, const isv_window_t *w, size_t L, s
     // non-finite cost many kernels later (the reference has no such check: it asserts or silently diverges)
     if (!finite_all(w->Ps, N * 3) || !finite_all(w->Rs, N * 9) || !finite_all(w->Vs, N * 3) || !finite_all(w->Bas, N * 3) ||
         !finite_all(w->Bgs, N * 3) || !finite_all(w->tic, 3) || !finite_all(w->ric, 9) ||
-        (w->n_landmarks > 0 && (!finite_all(w->lm_depth, w->n_landmarks) || !finite_all(w->obs_point, (size_t)w->n_obs * 3))) ||
+        (w->n_landmarks > 0 && !finite_all(w->lm_depth, w->n_landmarks)) ||
         !finite_all((const double *)w->imu, (size_t)(N - 1) * (sizeof(isv_imu_t) / sizeof(double))) ||
         !finite_all(w->pose_prior->t, 3 + 9 + 36) || !finite_all(w->vb_prior->VB, 9 + 81)) { err = "non-finite input"; return ISV_ERR_NONFINITE; }
     for (int i = 0; i < c.n_vo - 1; i++) if (!finite_all(w->relpose[i].delta_t, 3 + 9 + 36)) { err = "non-finite relative-pose prior"; return ISV_ERR_NONFINITE; }
     for (int i = 0; i < w->n_rollpitch; i++) if (!finite_all(w->rollpitch[i].R, 9 + 4)) { err = "non-finite roll/pitch prior"; return ISV_ERR_NONFINITE; }
+    }
+    if (doB && w->n_landmarks > 0 && !finite_all(w->obs_point, (size_t)w->n_obs * 3)) { err = "non-finite input"; return ISV_ERR_NONFINITE; }
     if (raw) {
         // (round 5) the window goes up as it is -- start frames, observation offsets, points, depths -- and k_upload_build derives the
         // solver's view (landmark / factor records, pair groups, schedule, factor stream) on the device
         const int Lw = w->n_landmarks, p0 = Lw > 0 ? w->lm_obs_ptr[0] : 0, nobs = Lw > 0 ? w->lm_obs_ptr[Lw] - p0 : 0;     // (a landmark's observations are [ptr[l], ptr[l + 1]))
         if (Lw > 0 && (size_t)(w->lm_obs_ptr[Lw - 1] - p0 - (Lw - 1)) > 65535) { err = "more than 65535 factors in one window"; return ISV_ERR_CAPACITY; }
+        if (Lw > 0 && doA) memcpy(s.depth + L, w->lm_depth, sizeof(double) * Lw);
+        if (doB) {
         if (Lw > 0) {
             memcpy(s.lm_host + L, w->lm_start_frame, sizeof(int32_t) * Lw);
-            memcpy(s.depth + L, w->lm_depth, sizeof(double) * Lw);
             memcpy(s.obs_raw + (F + L) * 3, w->obs_point + (size_t)p0 * 3, sizeof(double) * 3 * (size_t)nobs);
         }
         int32_t *op = s.lm_optr + L + b;
         for (int l = 0; l <= Lw; l++) op[l] = Lw > 0 ? w->lm_obs_ptr[l] - p0 : 0;
         for (int l = 0; l < Lw; l++) s.lm_k[L + l] = op[l + 1] - op[l];        // (the tiles below; the device derives its own)
+        }
         F += (size_t)(nobs - Lw); L += (size_t)Lw;
     } else
     for (int l = 0; l < w->n_landmarks; l++) {
@@ -262,7 +270,7 @@ static int pack_window(isv_backend *h, int b, const isv_window_t *w, size_t L, s
     }
     // tiles of <= 64 consecutive factors made of WHOLE landmarks (the linearise kernel reduces a
     // landmark's factors inside one wavefront); window_tiles() below counts them the same way
-    if (want_tiles) {
+    if (want_tiles && doB) {
         size_t tf0 = f_off, tn = 0;
         for (size_t l = lm_off; l < L; l++) {
             const size_t kf = (size_t)s.lm_k[l] - 1;
@@ -321,6 +329,7 @@ static int pack_window(isv_backend *h, int b, const isv_window_t *w, size_t L, s
         }
         wst[ISV_SWEEP_WAVES] = (int32_t)(q - f_off);
     }
+    if (!doA) return ISV_OK;
     if (Nd > N) {       // the IMU "factor" towards the pseudo-frame does not exist: flagged skipped (like sum_dt > 10)
         const size_t fi = (size_t)b * (Nd - 1) + (N - 1);
         memset(s.imu_in + fi * ISV_IMU_IN, 0, sizeof(double) * ISV_IMU_IN);
@@ -413,6 +422,12 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
     DevBatch &d = h->d;
     hipStream_t st = h->stream;
     const size_t NIw = (size_t)(Nd - 1);
+    // bytes of the windows in the upload block, and whether the block goes up in two parts (see the packing loop)
+    auto used_bytes = [&]() { return (F + L) * 24 + L * 16 + (size_t)n * ((size_t)Nd * 21 * 8 + NIw * (289 * 8 + 4) + sizeof(isv_se3_prior_t) + sizeof(isv_linear9_t) +
+                                      (size_t)(c.n_vo - 1) * sizeof(isv_relpose_t) + (size_t)c.max_rollpitch * sizeof(isv_rollpitch_t)); };
+    bool split_copy = false;
+    const size_t split_bytes = raw ? (size_t)((char *)d.tile_win - (char *)h->arena_d) : 0;
+    std::atomic<int> phase_a_done{0}, copy_failed{0}, first_sent{0};
     // ONE team of host threads, three phases (round 5; the counting pass used to run on the calling thread alone: 0.7 of the 2.0 ms):
     //   1. every thread validates its windows' tracks and counts their landmarks / factors / tiles;
     //   2. thread 0 turns the counts into the windows' offsets (a prefix sum over n windows);
@@ -460,12 +475,35 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
                         if ((size_t)cnt[b].L > Lmax) Lmax = (size_t)cnt[b].L;
                     }
                     t_off[n] = T; s.lm_off[n] = (int32_t)L; s.f_off[n] = (int32_t)F;
+                    h->resident = 0;           // (from here on the staging area and, with the two-part copy, the device block are being overwritten)
+                    split_copy = raw && K > 1 && h->arena_bytes > ((size_t)16 << 20) && used_bytes() * 10 >= h->arena_bytes * 6 && !getenv("ISV_UPLOAD_ONE_COPY");
                 }
                 offsets_ready.store(ok ? 1 : -1, std::memory_order_release);
             }
             int ready;
             while ((ready = offsets_ready.load(std::memory_order_acquire)) == 0) std::this_thread::yield();
             if (ready < 0) return;
+            // (round 5) a raw upload that goes up as one block is packed in TWO phases -- the first part of the block (states, priors, depths,
+            // IMU records: ~45 %) and the rest (observations, tiles) -- and whichever thread finishes the first phase last sends the first
+            // part while every thread packs the second: the copy (1.5 ms for 62 MB) used to start after the whole packing pass
+            if (split_copy) {
+                for (int b = b0; b < b1; b++) {
+                    const int rc = pack_window(h, b, ws[b], (size_t)s.lm_off[b], (size_t)s.f_off[b], t_off[b], errs[k], raw, true, 1);
+                    if (rc != ISV_OK) { rcs[k] = rc; break; }
+                }
+                if (phase_a_done.fetch_add(1, std::memory_order_acq_rel) == K - 1) {
+                    bool okA = true;
+                    for (int q = 0; q < K; q++) okA &= rcs[q] == ISV_OK;
+                    if (okA && (hipSetDevice(h->device) != hipSuccess || hipMemcpyAsync(h->arena_d, h->arena_h, split_bytes, hipMemcpyHostToDevice, st) != hipSuccess)) copy_failed.store(1);
+                    if (okA) first_sent.store(1, std::memory_order_release);
+                }
+                if (rcs[k] != ISV_OK) return;
+                for (int b = b0; b < b1; b++) {
+                    const int rc = pack_window(h, b, ws[b], (size_t)s.lm_off[b], (size_t)s.f_off[b], t_off[b], errs[k], raw, true, 2);
+                    if (rc != ISV_OK) { rcs[k] = rc; return; }
+                }
+                return;
+            }
             for (int b = b0; b < b1; b++) {
                 const int rc = pack_window(h, b, ws[b], (size_t)s.lm_off[b], (size_t)s.f_off[b], t_off[b], errs[k], raw, true);
                 if (rc != ISV_OK) { rcs[k] = rc; return; }
@@ -524,9 +562,10 @@ extern "C" int isv_batch_upload(isv_backend_t *h, int32_t n, isv_window_t *const
     if (raw) {
         // the raw CSR goes up (69 KB per benchmark window against 110 KB of derived arrays) and the device derives the rest.  ONE copy of
         // the whole block while the batch uses most of it (or the block is small: a window or two); array by array otherwise.
-        const size_t used = (F + L) * 24 + L * 16 + (size_t)n * ((size_t)Nd * 21 * 8 + NIw * (289 * 8 + 4) + sizeof(isv_se3_prior_t) + sizeof(isv_linear9_t) +
-                            (size_t)(c.n_vo - 1) * sizeof(isv_relpose_t) + (size_t)c.max_rollpitch * sizeof(isv_rollpitch_t));
-        if (h->arena_bytes <= ((size_t)16 << 20) || used * 10 >= h->arena_bytes * 6) HIPCHK(h, hipMemcpyAsync(h->arena_d, h->arena_h, h->arena_bytes, hipMemcpyHostToDevice, st));
+        const size_t used = used_bytes();
+        if (copy_failed.load()) { h->err = "isv_batch_upload: host-to-device copy failed"; return ISV_ERR_DEVICE; }
+        if (first_sent.load(std::memory_order_acquire)) HIPCHK(h, hipMemcpyAsync((char *)h->arena_d + split_bytes, (char *)h->arena_h + split_bytes, h->arena_bytes - split_bytes, hipMemcpyHostToDevice, st));     // (the first part went up during the packing pass)
+        else if (h->arena_bytes <= ((size_t)16 << 20) || used * 10 >= h->arena_bytes * 6) HIPCHK(h, hipMemcpyAsync(h->arena_d, h->arena_h, h->arena_bytes, hipMemcpyHostToDevice, st));
         else if (enqueue_arrays(0, n) != ISV_OK) { h->err = "isv_batch_upload: host-to-device copy failed"; return ISV_ERR_DEVICE; }
         if (isv_upload_build_enqueue(d, h->d_optr, h->d_obs_raw, c.max_landmarks > 1 ? c.max_landmarks : 1, st) != ISV_OK) { h->err = "k_upload_build launch failed"; return ISV_ERR_DEVICE; }
         if (getenv("ISV_DEBUG_UPLOAD_CHECK")) {
