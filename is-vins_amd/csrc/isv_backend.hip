@@ -778,8 +778,7 @@ extern "C" int isv_batch_download(isv_backend_t *h, int32_t n, isv_window_t *con
     D2H(s.st, d.st, n);
     }
     HIPCHK(h, hipStreamSynchronize(st));
-    int rcs = isv_solver_download(h->d, st, n, h->stage, summary, marg, h->err, two_copies);
-    if (rcs != ISV_OK) return rcs;
+    if (!two_copies) { int rcs = isv_solver_download(h->d, st, n, h->stage, summary, marg, h->err); if (rcs != ISV_OK) return rcs; }      // (two copies: the records are here already; unpacked per window below)
     auto unpack = [&](int b) {
         isv_window_t *w = ws[b];
         memcpy(w->Ps, s.Ps + (size_t)b * N * 3, sizeof(double) * Nr * 3); memcpy(w->Rs, s.Rs + (size_t)b * N * 9, sizeof(double) * Nr * 9);
@@ -798,6 +797,7 @@ extern "C" int isv_batch_download(isv_backend_t *h, int32_t n, isv_window_t *con
         if (w->para_Pose) memcpy(w->para_Pose, s.pose + (size_t)b * N * 7, sizeof(double) * Nr * 7);
         if (w->para_SpeedBias) memcpy(w->para_SpeedBias, s.sb + (size_t)b * N * 9, sizeof(double) * Nr * 9);
         if (w->para_Ex_Pose) memcpy(w->para_Ex_Pose, s.ex + (size_t)b * 7, 56);
+        if (two_copies && (summary || marg)) isv_solver_unpack_window(h->stage, b, summary ? &summary[b] : nullptr, marg ? &marg[b] : nullptr);
     };
     {
         const int K = host_threads(n);

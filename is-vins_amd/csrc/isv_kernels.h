@@ -70,4 +70,5 @@ struct SolverStage { SolveState *st; double *tc, *tr, *ts; int32_t *ta; isv_marg
 size_t upload_build_lds_bytes(int N, int lcap);
 int isv_upload_build_enqueue(DevBatch &d, const int32_t *optr, const double *obs_raw, int lcap, hipStream_t st);
 int isv_solver_download(DevBatch &d, hipStream_t st, int n, const SolverStage &stage, isv_summary_t *summary, isv_marg_result_t *marg, std::string &err, bool staged = false);
+void isv_solver_unpack_window(const SolverStage &stage, int b, isv_summary_t *summary, isv_marg_result_t *marg);
 int isv_solver_debug_read(DevBatch &d, hipStream_t st, int what, double *out, int64_t count, std::string &err);

@@ -703,21 +703,24 @@ int isv_solver_download(DevBatch &d, hipStream_t st, int n, const SolverStage &g
     if (marg) HCHK(hipMemcpyAsync(g.marg, d.marg, sizeof(isv_marg_result_t) * n, hipMemcpyDeviceToHost, st));
     HCHK(hipStreamSynchronize(st));
     }
-    if (marg) memcpy(marg, g.marg, sizeof(isv_marg_result_t) * n);
-    if (summary) {
-        for (int b = 0; b < n; b++) {
-            isv_summary_t &s = summary[b];
-            memset(&s, 0, sizeof(s));
-            s.status = ISV_OK; s.termination = g.st[b].termination; s.iterations = g.st[b].iteration; s.num_successful = g.st[b].num_successful;
-            s.initial_cost = g.st[b].initial_cost; s.final_cost = g.st[b].x_cost;
-            memcpy(s.trace_cost, &g.tc[(size_t)b * ISV_MAX_TRACE], sizeof(s.trace_cost));
-            memcpy(s.trace_radius, &g.tr[(size_t)b * ISV_MAX_TRACE], sizeof(s.trace_radius));
-            memcpy(s.trace_step_norm, &g.ts[(size_t)b * ISV_MAX_TRACE], sizeof(s.trace_step_norm));
-            memcpy(s.trace_accepted, &g.ta[(size_t)b * ISV_MAX_TRACE], sizeof(s.trace_accepted));
-            if (!(s.final_cost - s.final_cost == 0.0)) s.status = ISV_ERR_NONFINITE;
-        }
-    }
+    for (int b = 0; b < n; b++) isv_solver_unpack_window(g, b, summary ? &summary[b] : nullptr, marg ? &marg[b] : nullptr);
     return ISV_OK;
+}
+
+// window b's records out of the staging area (isv_batch_download's host threads call it per window; isv_solver_download for all)
+void isv_solver_unpack_window(const SolverStage &g, int b, isv_summary_t *summary, isv_marg_result_t *marg) {
+    if (marg) *marg = g.marg[b];
+    if (summary) {
+        isv_summary_t &s = *summary;
+        memset(&s, 0, sizeof(s));
+        s.status = ISV_OK; s.termination = g.st[b].termination; s.iterations = g.st[b].iteration; s.num_successful = g.st[b].num_successful;
+        s.initial_cost = g.st[b].initial_cost; s.final_cost = g.st[b].x_cost;
+        memcpy(s.trace_cost, &g.tc[(size_t)b * ISV_MAX_TRACE], sizeof(s.trace_cost));
+        memcpy(s.trace_radius, &g.tr[(size_t)b * ISV_MAX_TRACE], sizeof(s.trace_radius));
+        memcpy(s.trace_step_norm, &g.ts[(size_t)b * ISV_MAX_TRACE], sizeof(s.trace_step_norm));
+        memcpy(s.trace_accepted, &g.ta[(size_t)b * ISV_MAX_TRACE], sizeof(s.trace_accepted));
+        if (!(s.final_cost - s.final_cost == 0.0)) s.status = ISV_ERR_NONFINITE;
+    }
 }
 
 int isv_solver_debug_read(DevBatch &d, hipStream_t st, int what, double *out, int64_t count, std::string &err) {
