@@ -70,3 +70,27 @@ def test_observation_offsets_that_do_not_start_at_zero(monkeypatch):
         assert sa.iterations == sb.iterations and np.array_equal(a.state_vector(), b.state_vector())
     finally:
         bd.close()
+
+
+def test_two_part_upload_and_two_copy_download_change_nothing(monkeypatch):
+    """round 5: a batch that uses most of a large handle goes up in two parts (the first while the host threads still pack the second)
+    and comes back in two copies instead of 24; ISV_UPLOAD_ONE_COPY / ISV_DOWNLOAD_ARRAYS (read per call) keep the old forms.  Same
+    handle, same windows: every state, prior, summary and marginalisation record has to be the same bits, with a ragged batch
+    (the offsets of the second part depend on every window before it)."""
+    n = 420
+    ws = synth.make_windows(range(3000, 3000 + n), n_frames=11, n_vo=5, n_landmarks=150)
+    ws[7] = synth.make_window(3999, n_frames=11, n_vo=5, n_landmarks=30)
+    be = backend.Backend(11, 5, max_landmarks=160, max_obs=max(w.n_obs for w in ws) + 40, max_batch=512)
+    try:
+        a = [w.clone() for w in ws]; b = [w.clone() for w in ws]
+        sa, ma = be.optimize_batch(a)
+        monkeypatch.setenv("ISV_UPLOAD_ONE_COPY", "1"); monkeypatch.setenv("ISV_DOWNLOAD_ARRAYS", "1")
+        sb, mb = be.optimize_batch(b)
+        for x, y, p, q in zip(a, b, sa, sb):
+            assert bytes(p) == bytes(q)
+            assert np.array_equal(x.state_vector(), y.state_vector()) and np.array_equal(x.priors_vector(), y.priors_vector())
+        for p, q in zip(ma, mb):
+            assert bytes(p) == bytes(q)
+        assert sa[0].iterations > 0 and sa[0].status == 0
+    finally:
+        be.close()
