@@ -774,32 +774,76 @@ __global__ __launch_bounds__(64 * NW) void k_pgo(PgDev dv) {
     // Takahashi recurrence on the envelope, columns from the last to the first:
     //   Z(i,j) = [delta_ij L_jj^-T - sum_{k in colpat(j)} Z(i,k) L(k,j)] L_jj^-1      for i in {j} U colpat(j)
     // (a recurrence over the columns: wavefront 0)
-    if (wv == 0) for (int j = nf - 1; j >= 0; j--) {
-        const double *Li = BLK(L, j, j);
-        const int c0 = CP(j), c1 = CP(j + 1);
-        for (int qi = c0; qi <= c1; qi++) {            // the rows below j first: Z(j,j) needs Z(k,j), k in colpat(j)
-            const int i = qi < c1 ? CR(qi) : j;
-            if (qi == c1) PG_GSYNC();
-            double acc = 0;
-            if (e < 36) {
-                if (i == j) acc = Li[eb * 6 + ea];                                   // L_jj^-T
-                for (int q = c0; q < c1; q++) {
-                    const int k = CR(q);
-                    const double *Lkj = BLK(L, k, j);
-                    if (i >= k) { const double *Zik = BLK(Z, i, k); for (int m = 0; m < 6; m++) acc -= Zik[ea * 6 + m] * Lkj[m * 6 + eb]; }
-                    else { const double *Zki = BLK(Z, k, i); for (int m = 0; m < 6; m++) acc -= Zki[m * 6 + ea] * Lkj[m * 6 + eb]; }
+    // (round 5) A column that only its chain neighbour reaches down into -- colpat(j) = {j + 1} -- needs Z(j+1,j+1) (the diagonal block the
+    // previous column ended with) and Z(j+1,j) (what its first step produces): both stay in LDS tiles (T1, T2), so such a column reads no
+    // block of Z back from global memory and needs none of the two fences of the general column (each a memory round trip: 6.4 us per
+    // column before); its blocks of L are loaded one column ahead.  Same operations in the same order as the general column: same bits.
+    if (wv == 0) {
+        bool dirty = false, have_pf = false;           // dirty: blocks of Z written since the last fence; have_pf: pLk / pLi / pLt hold column j's operands
+        double pLk[6] = {0, 0, 0, 0, 0, 0}, pLi[6] = {0, 0, 0, 0, 0, 0}, pLt = 0;
+        for (int j = nf - 1; j >= 0; j--) {
+            const double *Li = BLK(L, j, j);
+            const int c0 = CP(j), c1 = CP(j + 1);
+            const bool fast = j + 1 < nf && c1 - c0 == 1 && CR(c0) == j + 1;      // (T1 = Z(j+1,j+1): every column leaves its diagonal block there)
+            double lk[6], li[6], lt = pLt;
+            for (int m = 0; m < 6; m++) { lk[m] = pLk[m]; li[m] = pLi[m]; }
+            const bool pre = have_pf;
+            have_pf = false;
+            if (j >= 1 && ST(j) == j - 1 && e < 36) {                          // column j - 1's operands: L(j, j-1) (column eb), L_{j-1,j-1}^-1 (column eb; entry (eb, ea))
+                const double *Ln = BLK(L, j, j - 1), *Lin = BLK(L, j - 1, j - 1);
+                for (int m = 0; m < 6; m++) { pLk[m] = Ln[m * 6 + eb]; pLi[m] = Lin[m * 6 + eb]; }
+                pLt = Lin[eb * 6 + ea];
+            }
+            if (j >= 1 && ST(j) == j - 1) have_pf = true;
+            if (fast) {
+                if (!pre && e < 36) {
+                    const double *Lkj = BLK(L, j + 1, j);
+                    for (int m = 0; m < 6; m++) { lk[m] = Lkj[m * 6 + eb]; li[m] = Li[m * 6 + eb]; }
+                    lt = Li[eb * 6 + ea];
+                }
+                double acc = 0, x = 0;
+                if (e < 36) { for (int m = 0; m < 6; m++) acc -= T1[ea * 6 + m] * lk[m]; }                 // Z(j+1,j) = -Z(j+1,j+1) L(j+1,j) L_jj^-1
+                PG_LSYNC();
+                if (e < 36) T0[e] = acc;
+                PG_LSYNC();
+                if (e < 36) { for (int m = eb; m < 6; m++) x += T0[ea * 6 + m] * li[m]; BLK(Z, j + 1, j)[e] = x; T2[e] = x; }
+                PG_LSYNC();
+                acc = lt; x = 0;                                                                             // Z(j,j) = (L_jj^-T - Z(j+1,j)^T L(j+1,j)) L_jj^-1
+                if (e < 36) { for (int m = 0; m < 6; m++) acc -= T2[m * 6 + ea] * lk[m]; }
+                if (e < 36) T0[e] = acc;
+                PG_LSYNC();
+                if (e < 36) { for (int m = eb; m < 6; m++) x += T0[ea * 6 + m] * li[m]; BLK(Z, j, j)[e] = x; T1[e] = x; }
+                PG_LSYNC();
+                dirty = true;
+                continue;
+            }
+            if (dirty) { PG_GSYNC(); dirty = false; }
+            for (int qi = c0; qi <= c1; qi++) {            // the rows below j first: Z(j,j) needs Z(k,j), k in colpat(j)
+                const int i = qi < c1 ? CR(qi) : j;
+                if (qi == c1) PG_GSYNC();
+                double acc = 0;
+                if (e < 36) {
+                    if (i == j) acc = Li[eb * 6 + ea];                                   // L_jj^-T
+                    for (int q = c0; q < c1; q++) {
+                        const int k = CR(q);
+                        const double *Lkj = BLK(L, k, j);
+                        if (i >= k) { const double *Zik = BLK(Z, i, k); for (int m = 0; m < 6; m++) acc -= Zik[ea * 6 + m] * Lkj[m * 6 + eb]; }
+                        else { const double *Zki = BLK(Z, k, i); for (int m = 0; m < 6; m++) acc -= Zki[m * 6 + ea] * Lkj[m * 6 + eb]; }
+                    }
+                }
+                PG_LSYNC();
+                if (e < 36) T0[e] = acc;
+                PG_LSYNC();
+                if (e < 36) {
+                    double x = 0;
+                    for (int m = eb; m < 6; m++) x += T0[ea * 6 + m] * Li[m * 6 + eb];   // times L_jj^-1 (lower)
+                    BLK(Z, i, j)[e] = x;
+                    if (i == j) T1[e] = x;
                 }
             }
-            PG_LSYNC();
-            if (e < 36) T0[e] = acc;
-            PG_LSYNC();
-            if (e < 36) {
-                double x = 0;
-                for (int m = eb; m < 6; m++) x += T0[ea * 6 + m] * Li[m * 6 + eb];   // times L_jj^-1 (lower)
-                BLK(Z, i, j)[e] = x;
-            }
+            PG_GSYNC();
         }
-        PG_GSYNC();
+        if (dirty) PG_GSYNC();
     }
     if constexpr (NW > 1) __syncthreads();
     for (int k = tid; k < G.P1; k += NT) {
