@@ -13,8 +13,8 @@
 //     (Y_parent = init - Y_i' C_i'^T row by row);
 //   * the pose-system downdate Spp -= Y_i' Y_i'^T is applied as node i LEAVES the pipeline (it was a phase of its own after
 //     both chains, which is why every Y_i had to stay resident);
-//   * L_i^-1, C_i', Y_i' go to a global scratch (d.st_ws, 36 KB per window at N = 11) as they become final and come back for
-//     the back-substitution (the chain part from registers, the Y^T x part as one coalesced sweep);
+//   * L_i^-1 and C_i' go to a global scratch (d.st_ws) as they become final and come back for the back-substitution; Y_i' does
+//     not (round 5, ST_NO_YSPILL): Y_i'^T x_pose is rebuilt by a recurrence along the chains from the nodes' own blocks;
 //   * every global load of the assembly is unconditional (clamped address, multiplied by a 0/1 mask): written as
 //     `if (has) v += H[i]` the compiler puts each load in a branch of its own behind an s_waitcnt vmcnt(0).
 // Summation orders differ from k_build_solve_sb in the last bits (Spp is downdated node by node; u^T T u is summed per
@@ -31,6 +31,13 @@
 #define STSTAMP(k) do {} while (0)
 #endif
 #define RCH_ST 16                  // landmarks per staged chunk of the retry correction
+// ST_NO_YSPILL (round 5): the back-substitution does not read the nodes' Y_i' back from the global scratch: v_i = Y_i'^T x_pose
+// follows from the chain recurrence v_p = L_p^-1 (E_p^T x_pose - C_j' v_j) (E_p: the node's own three blocks, j: its child), so a
+// short window no longer spills Y_i' at all (22 KB written + 22 KB read per window at N = 11; long windows keep the spill for
+// their tile wavefronts).  0: the round-4 form (Y_i' column-major in the scratch, one sweep Y_i'^T x_pose), kept for A/B builds.
+#ifndef ST_NO_YSPILL
+#define ST_NO_YSPILL 1
+#endif
 
 DEV int st_sblk(int I, int J, int N) { return (J * N - J * (J - 1) / 2 + (I - J)) * 36; }   // I >= J
 DEV int st_pair(int a, int b) { return a * (a + 1) / 2 + b; }      // a >= b
@@ -108,7 +115,11 @@ __host__ __device__ inline int st_work_doubles(int N, int prior_H_sz) {
     if (retry > wk) wk = retry;
     return (wk + 1) & ~1;
 }
-size_t build_solve_st_ws_doubles(int N) { return (size_t)324 * N + (size_t)st_ytot(N); }     // L_i^-1 | C_i' | Y_i' | the scaled init blocks of every node
+// the global scratch of a window: L_i^-1 | C_i' | Y_i' (long windows, whose tile wavefronts read it; every window in the
+// ST_NO_YSPILL = 0 form) | the scaled init blocks of every node
+__host__ __device__ inline int st_ws_y(int N) { return (!ST_NO_YSPILL || N > 11) ? st_ytot(N) : 0; }
+__host__ __device__ inline size_t st_ws_doubles(int N) { return (size_t)324 * N + (size_t)st_ws_y(N); }
+size_t build_solve_st_ws_doubles(int N) { return st_ws_doubles(N); }
 size_t build_solve_st_bytes(int N, int prior_H_sz) {
     const size_t n = 15 * (size_t)N, nS = (size_t)N * (N + 1) / 2 * 36;
     //      g, y, D, sc   red   yo + skip (ints)   flag   blkIJ (ushort)              triAB (bytes)   Spp   work
@@ -187,8 +198,8 @@ __global__ __launch_bounds__(ST_THREADS(BIG), 4) void k_build_solve_st(DevBatch 
     const double *V = d.Tvis + (size_t)w * d.tvis_sz;
     const double *H = d.imu_H + (size_t)w * (N - 1) * ISV_IMU_H;
     const double *PH = d.prior_H + (size_t)w * d.prior_H_sz;
-    double *ws = d.st_ws + (size_t)w * (324 * (size_t)N + (size_t)st_ytot(N));
-    double *gDinv = ws, *gC = ws + 81 * N, *gY = ws + 162 * N, *gYi = gY + st_ytot(N);
+    double *ws = d.st_ws + (size_t)w * st_ws_doubles(N);
+    double *gDinv = ws, *gC = ws + 81 * N, *gY = ws + 162 * N, *gYi = gY + st_ws_y(N);
 
     // ---- the raw (unscaled) blocks of chain node i from the packed records; every load unconditional, masked ---------
     // IMU factor f = frames (f, f + 1); local tangent order pose_f (0..5) sb_f (6..14) pose_f+1 (15..20) sb_f+1 (21..29)
@@ -585,7 +596,7 @@ __global__ __launch_bounds__(ST_THREADS(BIG), 4) void k_build_solve_st(DevBatch 
             auto ywork = [&](int ch, int j, bool last) {
                 const int lo = st_nlo(j, M), hi = st_nhi(j, M, N), nr = hi - lo + 1, s0 = lo + ch;       // first slot
                 const double *Lj = Dslot(ch, j), *Cj = Cslot(ch, j);
-                double *Yg = gY + yo[j];
+                double *Yg = gY + yo[j]; (void)Yg;
                 // spill L_j^-1 and C_j' (final since the critical path left node j)
                 for (int e = lane; e < 162; e += 64) { if (e < 81) gDinv[j * 81 + e] = Lj[e]; else gC[j * 81 + (e - 81)] = Cj[e - 81]; }
                 for (int rho = lane; rho < 6 * nr; rho += 64) {
@@ -601,7 +612,11 @@ __global__ __launch_bounds__(ST_THREADS(BIG), 4) void k_build_solve_st(DevBatch 
                         o[c] = s;
                     }
 #pragma unroll
-                    for (int k = 0; k < 9; k++) { ptr[k] = o[k]; Yg[k * (6 * nr) + rho] = o[k]; }       // global: column-major per node
+                    for (int k = 0; k < 9; k++) ptr[k] = o[k];
+                    if constexpr (BIG || !ST_NO_YSPILL) {              // (long windows: the tile wavefronts read it; ST_NO_YSPILL = 0: the back-substitution)
+#pragma unroll
+                        for (int k = 0; k < 9; k++) Yg[k * (6 * nr) + rho] = o[k];                       // global: column-major per node
+                    }
                 }
                 ST_WSYNC();
                 {   // pose rhs -= Y_j' z_j, then the pose blocks' downdate
@@ -841,7 +856,7 @@ __global__ __launch_bounds__(ST_THREADS(BIG), 4) void k_build_solve_st(DevBatch 
             __syncthreads();
             if (!flag[0]) {
                 // Y_M' = Y_M L_M^-T, spill; then Spp -= Y_M' Y_M'^T over ALL pose blocks, pose rhs -= Y_M' z_M
-                double *Yg = gY + yo[M];
+                double *Yg = gY + yo[M]; (void)Yg;
                 for (int e = t; e < 81; e += LT) gDinv[M * 81 + e] = DM[e];
                 for (int rho = t; rho < 6 * N; rho += LT) {
                     const int pz = rho / 6, r = rho - 6 * pz;
@@ -857,7 +872,11 @@ __global__ __launch_bounds__(ST_THREADS(BIG), 4) void k_build_solve_st(DevBatch 
                         o[c] = s;
                     }
 #pragma unroll
-                    for (int k = 0; k < 9; k++) { ptr[k] = o[k]; Yg[k * (6 * N) + rho] = o[k]; }
+                    for (int k = 0; k < 9; k++) ptr[k] = o[k];
+#if !ST_NO_YSPILL
+#pragma unroll
+                    for (int k = 0; k < 9; k++) Yg[k * (6 * N) + rho] = o[k];
+#endif
                 }
                 __syncthreads();
                 // Spp -= sum_i Y_i' Y_i'^T as FP64 MFMA tiles (v_mfma_f64_16x16x4: D += A^T B over four k): the operand is a dense
@@ -1005,6 +1024,88 @@ __global__ __launch_bounds__(ST_THREADS(BIG), 4) void k_build_solve_st(DevBatch 
             if (hasPB) y[15 * fB + c6] = yp1;
         }
         __syncthreads();
+#if ST_NO_YSPILL
+        // chain rhs -= v_i, v_i = Y_i'^T x_pose, WITHOUT the nodes' Y' (round 5: they are not spilled): Y_p = E_p - Y_j' C_j'^T (E_p: the
+        // node's own three pose x speed/bias blocks, j: its child; two children for the middle node), so
+        //     v_p = L_p^-1 Y_p^T x_pose = L_p^-1 (E_p^T x_pose - C_j' v_j),
+        // one pass along each chain in elimination order (wavefronts 0 / 1), then x_i = L_i^-T (z_i - v_i - C_i'^T x_parent) in reverse
+        // order as before.  e_p = E_p^T x_pose for all nodes first, by all threads (an item = (speed/bias row, pose block), from the
+        // prescaled init blocks in the scratch), folded in fixed order.
+        {
+            // every node's C_i' and L_i^-1 come back from the global scratch with ONE coalesced sweep -- into the (dead) chain buffers
+            // (162 N doubles fit them up to N = 11: st_work_doubles), or, for long windows, over the pose blocks: the pose system's
+            // factor is dead once x_pose is known -- then the nodes run out of LDS
+            ST_IDS();
+            double *stg = BIG ? Spp : work;
+            double *sDi = stg, *sC = stg + 81 * N;
+            double *ev = BIG ? Spp + 162 * N : Spp, *vv = ev + 9 * N, *pt = vv + 9 * N;       // e_i, v_i [9 N], the fold's parts [27 N]: over the dead pose blocks
+            for (int e = t; e < 162 * N; e += LT) stg[e] = ws[e];          // gDinv | gC are contiguous in the scratch
+            for (int it = t; it < 27 * N; it += LT) {
+                const int o = it / 3, b3 = it - 3 * o, i = o / 9, c = o - 9 * i, pz = i - 1 + b3;
+                const double *xa = y + 15 * (pz < 0 ? 0 : pz > N - 1 ? N - 1 : pz);
+                const double *Ei = gYi + (size_t)i * 162 + b3 * 54 + c;               // (zeros where the pose lies outside the window)
+                double ya[6];
+#pragma unroll
+                for (int r = 0; r < 6; r++) ya[r] = Ei[r * 9];
+                double s = 0;
+#pragma unroll
+                for (int r = 0; r < 6; r++) s += ya[r] * xa[r];
+                pt[it] = s;
+            }
+            __syncthreads();
+            for (int o = t; o < 9 * N; o += LT) ev[o] = (pt[3 * o] + pt[3 * o + 1]) + pt[3 * o + 2];
+            __syncthreads();
+            const int cl = lane < 9 ? lane : 0;
+            auto node_fwd = [&](int i, int c1, int c2) {            // v_i from its children's (c1, c2; -1: none); the rhs takes -v_i
+                double wr = ev[9 * i + cl];
+                if (c1 >= 0) {
+#pragma unroll
+                    for (int k = 0; k < 9; k++) wr -= sC[c1 * 81 + cl * 9 + k] * vv[9 * c1 + k];
+                }
+                if (c2 >= 0) {
+#pragma unroll
+                    for (int k = 0; k < 9; k++) wr -= sC[c2 * 81 + cl * 9 + k] * vv[9 * c2 + k];
+                }
+                double v = 0;
+#pragma unroll
+                for (int k = 0; k < 9; k++) v += sDi[i * 81 + cl * 9 + k] * st_readlane(wr, k);      // (L^-1 is lower: the upper part is stored as zeros)
+                ST_WSYNC();
+                if (lane < 9) { vv[9 * i + lane] = v; y[15 * i + 6 + lane] -= v; }
+                ST_WSYNC();
+            };
+            auto node_bwd = [&](int i, int pp) {
+                double sv = y[15 * i + 6 + cl];
+                if (pp >= 0) {
+#pragma unroll
+                    for (int k = 0; k < 9; k++) sv -= sC[i * 81 + k * 9 + cl] * y[15 * pp + 6 + k];
+                }
+                double x = 0;
+#pragma unroll
+                for (int k = 0; k < 9; k++) x += sDi[i * 81 + k * 9 + cl] * st_readlane(sv, k);
+                ST_WSYNC();
+                if (lane < 9) y[15 * i + 6 + lane] = x;
+                ST_WSYNC();
+            };
+            // (run-time N: ONE loop for both chains with per-lane selects, as in the elimination.  Written as two loops under
+            //  `if (wv == 0) .. else if (wv == 1)`, or as one loop on a readfirstlane'd wavefront index, the run-time-N instantiation gave
+            //  wrong v_i on gfx950 / ROCm 7.2 (scripts/st_probe.py: every N <= 11 through <false, 0>) while the compile-time-N ones,
+            //  where both loops unroll to straight-line code, are right and 8 us per launch faster than the one-loop form: each
+            //  instantiation gets the form that is verified for it -- tests/test_gpu_branches.py covers N = 6, 9, 11, 16, 18 against
+            //  the oracle and N = 11 through both instantiations)
+            if constexpr (NC != 0) {
+                if (wv == 0) { for (int i = 0; i < M; i++) node_fwd(i, i - 1, -1); }
+                else if (wv == 1) { for (int i = N - 1; i > M; i--) node_fwd(i, i + 1 <= N - 1 ? i + 1 : -1, -1); }
+            } else if (wv < 2) {
+                const int cnt = wv == 0 ? M : N - 1 - M;
+                for (int k = 0; k < cnt; k++) { const int i = wv == 0 ? k : N - 1 - k; node_fwd(i, k > 0 ? (wv == 0 ? i - 1 : i + 1) : -1, -1); }
+            }
+            __syncthreads();
+            if (wv == 0) { node_fwd(M, M - 1, M + 1 <= N - 1 ? M + 1 : -1); node_bwd(M, -1); }
+            __syncthreads();
+            if (wv == 0) { for (int i = M - 1; i >= 0; i--) node_bwd(i, i + 1); }
+            else if (wv == 1) { for (int i = M + 1; i <= N - 1; i++) node_bwd(i, i - 1); }
+        }
+#else
         // chain rhs -= Y_i'^T x_pose from the global scratch (column-major per node: a thread reads contiguous rows);
         // thread = (speed/bias row, quarter of the pose blocks), folded in fixed order through the work area
         {
@@ -1061,6 +1162,7 @@ __global__ __launch_bounds__(ST_THREADS(BIG), 4) void k_build_solve_st(DevBatch 
             if (wv == 0) { for (int i = M - 1; i >= 0; i--) node_bwd(i, i + 1); }
             else if (wv == 1) { for (int i = M + 1; i <= N - 1; i++) node_bwd(i, i - 1); }
         }
+#endif
         __syncthreads();
         STSTAMP(7);
         break;

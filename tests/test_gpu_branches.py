@@ -186,18 +186,22 @@ def test_unfused_kernel_variants_against_oracle_and_fused(oracle, monkeypatch, e
         bf.close()
 
 
-def test_build_solve_st_compiled_for_18_frames_is_bitwise_the_runtime_n_kernel(monkeypatch):
+@pytest.mark.parametrize("N,Nvo", [(18, 8), (11, 5)])
+def test_build_solve_st_compiled_for_18_frames_is_bitwise_the_runtime_n_kernel(monkeypatch, N, Nvo):
     """k_build_solve_st<true, 18> (the reference's ALL_BUF_SIZE as a compile-time constant: every loop bound and index a constant;
     404 -> 357 us per 1024-window launch) against k_build_solve_st<true, 0> (ISV_GENERIC_N=1) on a handle whose capacity selects
-    the streamed kernel: the same sums in the same order, BITWISE equal states, summaries and marginalisation records"""
+    the streamed kernel: the same sums in the same order, BITWISE equal states, summaries and marginalisation records.  The same for
+    k_build_solve_st<false, 11> against <false, 0> (round 5: the two instantiations run the chain recurrence of the
+    back-substitution in two loop forms -- isv_build_solve_st.hip -- with the same arithmetic per node)."""
     import ctypes
-    ws = [synth.make_window(300 + i, n_frames=18, n_vo=8, n_landmarks=120, margin_old=i % 2) for i in range(6)]
+    ws = [synth.make_window(300 + i, n_frames=N, n_vo=Nvo, n_landmarks=120, margin_old=i % 2) for i in range(6)]
     cap = dict(max_landmarks=140, max_obs=max(w.n_obs for w in ws), max_batch=512)
+    monkeypatch.setenv("ISV_SOLVE_ST", "1")
     out = {}
     for generic in (False, True):
         if generic:
             monkeypatch.setenv("ISV_GENERIC_N", "1")
-        b = backend.Backend(18, 8, **cap)
+        b = backend.Backend(N, Nvo, **cap)
         try:
             g = [w.clone() for w in ws]
             sums, margs = b.optimize_batch(g)
