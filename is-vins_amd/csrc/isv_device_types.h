@@ -127,7 +127,7 @@ struct DevBatch {
     double *sw_part;                    // [B][NP * 84] pair partials of k_sweep_mfma when they do not share a CU's LDS four ways (long windows); else null
     const int32_t *seq_hdr;             // device-resident sequences: the frame headers [B][8]; header word 0 < 0 = this window has NO FRAME this step (ISV_SEQ_IDLE):
                                         // nothing is slid, appended, solved or written back for it.  null on the upload path
-    double *st_ws;                      // [B][324 N + ytot] (build_solve_st_ws_doubles) k_build_solve_st: L_i^-1 | C_i' | Y_i' of the chain nodes between elimination and back-substitution; null: the handle runs k_build_solve_sb
+    double *st_ws;                      // [B][build_solve_st_ws_doubles(N)] = [324 N] (N <= 11) or [324 N + ytot] k_build_solve_st: L_i^-1 | C_i' of the chain nodes between elimination and back-substitution | Y_i' (long windows only: their tile wavefronts read it) | the prescaled init blocks of every node; null: the handle runs k_build_solve_sb
     int32_t split_cap, _pad4;            // groups a window's rank-1 downdates may be split into on this handle (from max_batch at creation; 1: never split)
     double *cs_ws;                      // [B][sb_cs_doubles(N)] hand-over of the split solve (k_build_solve_sb MODE 1 -> MODE 2: isv_build_solve_sb.hip); null: the handle solves in one launch
     double *r1_part;                    // [split_cap_B][ISV_SPLIT_MAX_GROUPS][tiles * 256] raw accumulator tiles of the split rank-1 downdates (k_schur_split -> k_schur_fold); null: no split on this handle
